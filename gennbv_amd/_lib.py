@@ -1,0 +1,98 @@
+"""ctypes binding of libgennbv_hip.so (C-ABI declared in include/gennbv_hip.h).
+
+There is NO fallback: if the shared object is missing or a call fails, this
+module raises.  The CPU oracle under oracle/ is test infrastructure and is
+never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgennbv_hip.so")
+
+_p = C.c_void_p
+_i = C.c_int
+_i64 = C.c_int64
+_f = C.c_float
+_d = C.c_double
+_sz = C.c_size_t
+
+# name -> (restype, argtypes): must list every symbol include/gennbv_hip.h declares
+SIGNATURES = {
+    "gnbv_abi_version": (_i, []),
+    "gnbv_build_arch": (C.c_char_p, []),
+    "gnbv_post_process_depth": (_i, [_p, _p, _i64, _f, _p, _p, _p]),
+    "gnbv_rgb_to_gray": (_i, [_p, _i, _i, _i, _i, _i, _p, _i64, _p]),
+    "gnbv_back_projection": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p]),
+    "gnbv_points_to_idx": (_i, [_p, _p, _p, _p, _i, _i64, _i, _p, _p]),
+    "gnbv_pose_to_idx": (_i, [_p, _p, _p, _i, _p, _p]),
+    "gnbv_bresenham3d": (_i, [_p, _p, _i, _i, _p, _p, _p]),
+    "gnbv_grid_tri_cls": (_i, [_p, _i64, _f, _f, _p, _p]),
+    "gnbv_voxel_workspace_bytes": (_sz, [_i, _i]),
+    "gnbv_update_occ_grid": (_i, [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _i64, _p,
+                                  _p, _sz, _p]),
+    "gnbv_unpack_masks": (_i, [_p, _i, _i, _p, _p, _p]),
+    "gnbv_gae_sb3": (_i, [_p, _p, _p, _p, _p, _i, _i, _d, _d, _p, _p, _p]),
+    "gnbv_gae_rsl": (_i, [_p, _p, _p, _p, _i, _i, _d, _d, _p, _p, _p]),
+}
+
+
+class GennbvHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library and bind every C-ABI symbol.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GennbvHipError(
+            f"{LIB_PATH} is missing: build it with `python -m gennbv_amd.csrc.build` "
+            "(or __graft_entry__.build()).  gennbv_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gnbv_abi_version() != 1:
+        raise GennbvHipError("libgennbv_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(err: int, what: str):
+    if err != 0:
+        raise GennbvHipError(f"{what} failed with hipError_t={err}")
+
+
+def ptr(t):
+    """Device (or host) pointer of a tensor; None -> NULL."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_ptr(device=None):
+    """The caller's current HIP stream as void* (the kernels enqueue on it)."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise GennbvHipError("gennbv_amd operators run on the GPU only (tensor is on %s); "
+                                 "there is no CPU fallback" % t.device)
+
+
+def require_contig(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_contiguous():
+            raise GennbvHipError("tensor must be contiguous")

@@ -1,0 +1,725 @@
+// voxel.hip -- GenNBV state encoding on MI355X (gfx950): depth -> world points ->
+// voxel indices -> hit bitmask -> Bresenham ray cast -> probabilistic grid update.
+//
+// Replaces the reference's per-environment Python loop
+//   gennbv/env/env_train_gennbv.py:277-326 (update_occ_grid), :494-533 (back_projection_fg),
+//   gennbv/utils.py:24-227 (bresenham3D_pycuda), :230-270, :273-306, :309-325,
+//   gennbv/env/env_train_base.py:513-534 (post_process_camera_tensor)
+// with three launches per environment step for the whole batch:
+//
+//   k_hit_mask     N x chunks workgroups.  Streams the raw depth+seg batch once
+//                  (16 B/lane coalesced), back-projects in the canonical fp32 order,
+//                  and ORs voxel bits into an LDS-resident G^3-bit mask
+//                  (64^3 bits = 32 KiB); non-zero words are flushed with one
+//                  device-scope atomicOr each.  HBM-bound: H*W*8 B per env.
+//   k_raycast      one workgroup per env (1024 threads).  Compacts the set bits of
+//                  the hit mask into an LDS queue and walks one integer Bresenham
+//                  ray per lane, OR-ing the visited voxels into an LDS path mask.
+//                  Integer-ALU / LDS-atomic bound, touches ~2 * G^3/8 B of HBM.
+//   k_grid_update  streaming pass over prob / scanned / gt -> prob / scanned / tri,
+//                  float4 per lane, + per-env coverage count.  HBM-bound:
+//                  G^3 * 4 * 6 B per env (the dominant term of SURVEY 8d's B_vox).
+//
+// Set semantics: a voxel crossed by any number of rays is
+// decremented once per step, hit voxels are then set to 1.0 -- exactly what the
+// reference's non-accumulating index_put does -- hence bitmasks, not counters.
+//
+// Workgroup -> XCD placement: block b runs on XCD b % 8 (observed, used for speed
+// only).  k_hit_mask maps env e to blocks with b % 8 == e % 8 and k_raycast uses
+// b == e, so one env's mask words stay in one XCD's L2 between the launches.
+// Correctness never depends on it: the only inter-workgroup traffic inside a
+// launch is device-scope atomicOr, the rest crosses kernel boundaries.
+#include "common.h"
+#include "../../include/gennbv_hip.h"
+
+// ---------------------------------------------------------------------------
+// canonical fp32 arithmetic (DESIGN.md "canonical order"); file is built with
+// -ffp-contract=off and every product/sum below is an explicit _rn intrinsic.
+// ---------------------------------------------------------------------------
+struct Intrinsics { float k[9]; };
+
+__device__ __forceinline__ float nan_to_num_neginf0(float x)
+{
+    // torch.nan_to_num(x, neginf=0): NaN -> 0, +inf -> FLT_MAX, -inf -> 0
+    if (x != x) return 0.0f;
+    if (__builtin_isinf(x)) return x > 0.0f ? FLT_MAX : 0.0f;
+    return x;
+}
+
+__device__ __forceinline__ float process_depth(float raw, float sense_dist)
+{
+    float d = nan_to_num_neginf0(raw);
+    d = d < sense_dist ? sense_dist : d;  // clamp(min=-50)
+    return fabsf(d);
+}
+
+__device__ __forceinline__ void pixel_to_world(float d, float u, float v, const Intrinsics &K, const float *M, float *out)
+{
+    const float pu = __fmul_rn(d, u), pv = __fmul_rn(d, v), pw = d;  // d * 1.0f == d
+    float cam[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float acc = __fmul_rn(K.k[i * 3 + 0], pu);
+        acc = __fmaf_rn(K.k[i * 3 + 1], pv, acc);
+        acc = __fmaf_rn(K.k[i * 3 + 2], pw, acc);
+        cam[i] = acc;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float acc = __fmul_rn(M[i * 4 + 0], cam[0]);
+        acc = __fmaf_rn(M[i * 4 + 1], cam[1], acc);
+        acc = __fmaf_rn(M[i * 4 + 2], cam[2], acc);
+        acc = __fmaf_rn(M[i * 4 + 3], 1.0f, acc);
+        out[i] = acc;
+    }
+}
+
+struct VoxelFrame {  // per-env constants of scanned_pts_to_idx_3D
+    float vmin[3], vmax[3], vox[3];
+};
+
+__device__ __forceinline__ VoxelFrame load_frame(const float *range6, const float *vox3)
+{
+    VoxelFrame f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float v = vox3[a];
+        const float half = __fmul_rn(0.5f, v);
+        f.vox[a] = v;
+        f.vmax[a] = __fadd_rn(range6[2 * a], half);
+        f.vmin[a] = __fsub_rn(range6[2 * a + 1], half);
+    }
+    return f;
+}
+
+// returns the linear voxel index (x*G + y)*G + z, or -1 when the point is dropped
+__device__ __forceinline__ int point_to_voxel(const float *p, const VoxelFrame &f, int g, int *ix)
+{
+    bool keep = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float q = __fdiv_rn(__fsub_rn(p[a], f.vmin[a]), f.vox[a]);
+        const float fl = floorf(q);
+        keep = keep && (f.vmax[a] > p[a]) && (p[a] > f.vmin[a]);
+        int i = (fl == fl && fabsf(fl) < 1.0e9f) ? (int)fl : 0;
+        i = i < 0 ? 0 : (i > g - 1 ? g - 1 : i);
+        ix[a] = i;
+    }
+    return keep ? (ix[0] * g + ix[1]) * g + ix[2] : -1;
+}
+
+__device__ __forceinline__ int pose_axis_to_idx(float p, float range_min, float v)
+{
+    const float vmin = __fsub_rn(range_min, __fmul_rn(0.5f, v));
+    const float fl = floorf(__fdiv_rn(__fsub_rn(p, vmin), v));
+    // float -> int64 -> int32 (pts_source.int(), utils.py:32); poses are finite
+    return (int)(long long)fl;
+}
+
+// ---------------------------------------------------------------------------
+// integer 3-D Bresenham (gennbv/utils.py:48-167).  Visit(x, y, z) is invoked for
+// every emitted (in-bounds) voxel; returns the emitted count.
+// ---------------------------------------------------------------------------
+template <typename Visit>
+__device__ __forceinline__ int bresenham_walk(int x0, int y0, int z0, int x1, int y1, int z1, int g, int max_pts, Visit &&visit)
+{
+    const int dx = abs(x1 - x0), dy = abs(y1 - y0), dz = abs(z1 - z0);
+    const int sx = x0 < x1 ? 1 : -1, sy = y0 < y1 ? 1 : -1, sz = z0 < z1 ? 1 : -1;
+    const int dm = max(max(dx, dy), dz);
+    // permute so that `a` is the dominant axis and (b, c) keep the reference's order
+    int pa, pb, pc, da, db, dc, sa, sb, sc, axis;
+    if (dm == dx)      { axis = 0; pa = x0; pb = y0; pc = z0; da = dx; db = dy; dc = dz; sa = sx; sb = sy; sc = sz; }
+    else if (dm == dy) { axis = 1; pa = y0; pb = x0; pc = z0; da = dy; db = dx; dc = dz; sa = sy; sb = sx; sc = sz; }
+    else               { axis = 2; pa = z0; pb = x0; pc = y0; da = dz; db = dx; dc = dy; sa = sz; sb = sx; sc = sy; }
+    int p1 = 2 * db - da, p2 = 2 * dc - da;
+    const unsigned ug = (unsigned)g;
+    int emitted = 0;
+    auto emit = [&]() {
+        if ((unsigned)pa < ug && (unsigned)pb < ug && (unsigned)pc < ug) {
+            if (axis == 0) visit(pa, pb, pc);
+            else if (axis == 1) visit(pb, pa, pc);
+            else visit(pb, pc, pa);
+            ++emitted;
+        }
+    };
+    emit();
+    for (int i = 0; i < da && emitted < max_pts; ++i) {
+        if (p1 >= 0) { pb += sb; p1 -= 2 * da; }
+        if (p2 >= 0) { pc += sc; p2 -= 2 * da; }
+        pa += sa;
+        p1 += 2 * db;
+        p2 += 2 * dc;
+        emit();
+    }
+    return emitted;
+}
+
+// ===========================================================================
+// fused path, launch 1: hit mask
+// ===========================================================================
+constexpr int kHitThreads = 256;
+
+__global__ __launch_bounds__(kHitThreads) void k_hit_mask(
+    const float *__restrict__ depth_raw, const float *__restrict__ seg_raw, const float *__restrict__ c2w,
+    Intrinsics K, const float *__restrict__ range_gt, const float *__restrict__ voxel_size,
+    int n, int h, int w, int g, float sense_dist, int chunks, int words, uint32_t *__restrict__ hit_mask)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_mask[];
+    // XCD-aware block -> (env, chunk): all chunks of env e run on XCD e % 8
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int e = (slot / chunks) * 8 + xcd;
+    const int c = slot % chunks;
+    if (e >= n) return;
+    for (int i = threadIdx.x; i < words; i += kHitThreads) s_mask[i] = 0u;
+
+    float M[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) M[i] = c2w[(size_t)e * 16 + i];
+    const VoxelFrame f = load_frame(range_gt + e * 6, voxel_size + e * 3);
+    const int hw = h * w;
+    int ppc = (hw + chunks - 1) / chunks;
+    ppc = (ppc + 3) & ~3;
+    const int px0 = c * ppc, px1 = min(hw, px0 + ppc);
+    const float *dptr = depth_raw + (size_t)e * hw;
+    const float *sptr = seg_raw + (size_t)e * hw;
+    __syncthreads();
+
+    auto one_pixel = [&](int p, float draw, float sraw) {
+        // seg: nan_to_num then > 50 (env_train_base.py:530-531, env_train_gennbv.py:504)
+        if (!(nan_to_num_neginf0(sraw) > 50.0f)) return;
+        const int y = p / w, x = p - y * w;
+        float wp[3];
+        int ix[3];
+        pixel_to_world(process_depth(draw, sense_dist), (float)x, (float)y, K, M, wp);
+        const int lin = point_to_voxel(wp, f, g, ix);
+        if (lin >= 0) atomicOr(&s_mask[lin >> 5], 1u << (lin & 31));
+    };
+
+    if ((hw & 3) == 0) {
+        for (int p = px0 + threadIdx.x * 4; p < px1; p += kHitThreads * 4) {
+            const float4 d4 = *reinterpret_cast<const float4 *>(dptr + p);
+            const float4 s4 = *reinterpret_cast<const float4 *>(sptr + p);
+            one_pixel(p + 0, d4.x, s4.x);
+            one_pixel(p + 1, d4.y, s4.y);
+            one_pixel(p + 2, d4.z, s4.z);
+            one_pixel(p + 3, d4.w, s4.w);
+        }
+    } else {
+        for (int p = px0 + threadIdx.x; p < px1; p += kHitThreads) one_pixel(p, dptr[p], sptr[p]);
+    }
+    __syncthreads();
+    uint32_t *gm = hit_mask + (size_t)e * words;
+    for (int i = threadIdx.x; i < words; i += kHitThreads) {
+        const uint32_t v = s_mask[i];
+        if (v) atomicOr(&gm[i], v);
+    }
+}
+
+// fallback for grids whose bitmask does not fit LDS (G > 96): straight to L2 atomics
+__global__ __launch_bounds__(kHitThreads) void k_hit_mask_global(
+    const float *__restrict__ depth_raw, const float *__restrict__ seg_raw, const float *__restrict__ c2w,
+    Intrinsics K, const float *__restrict__ range_gt, const float *__restrict__ voxel_size,
+    int n, int h, int w, int g, float sense_dist, int chunks, int words, uint32_t *__restrict__ hit_mask)
+{
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int e = (slot / chunks) * 8 + xcd;
+    const int c = slot % chunks;
+    if (e >= n) return;
+    float M[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) M[i] = c2w[(size_t)e * 16 + i];
+    const VoxelFrame f = load_frame(range_gt + e * 6, voxel_size + e * 3);
+    const int hw = h * w;
+    const int ppc = (hw + chunks - 1) / chunks;
+    const int px0 = c * ppc, px1 = min(hw, px0 + ppc);
+    uint32_t *gm = hit_mask + (size_t)e * words;
+    int last_word = -1;
+    uint32_t acc = 0u;
+    for (int p = px0 + threadIdx.x; p < px1; p += kHitThreads) {
+        const float sraw = seg_raw[(size_t)e * hw + p];
+        if (!(nan_to_num_neginf0(sraw) > 50.0f)) continue;
+        const int y = p / w, x = p - y * w;
+        float wp[3];
+        int ix[3];
+        pixel_to_world(process_depth(depth_raw[(size_t)e * hw + p], sense_dist), (float)x, (float)y, K, M, wp);
+        const int lin = point_to_voxel(wp, f, g, ix);
+        if (lin < 0) continue;
+        const int wd = lin >> 5;
+        if (wd != last_word) {
+            if (acc) atomicOr(&gm[last_word], acc);
+            last_word = wd;
+            acc = 0u;
+        }
+        acc |= 1u << (lin & 31);
+    }
+    if (acc) atomicOr(&gm[last_word], acc);
+}
+
+// ===========================================================================
+// fused path, launch 2: ray cast (one workgroup per env)
+// ===========================================================================
+constexpr int kRayThreads = 1024;
+constexpr int kRayWaves = kRayThreads / kWave;
+constexpr int kQueueCap = 8192;  // targets per round (32 KiB of LDS)
+
+template <bool LDS_PATH>
+__global__ __launch_bounds__(kRayThreads) void k_raycast(
+    const uint32_t *__restrict__ hit_mask, const float *__restrict__ poses_xyz, int64_t pose_stride,
+    const float *__restrict__ range_gt, const float *__restrict__ voxel_size, int n, int g, int words,
+    uint32_t *__restrict__ path_mask)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *s_queue = smem;                 // kQueueCap
+    int *s_wave = (int *)(smem + kQueueCap);  // kRayWaves + 1
+    uint32_t *s_path = smem + kQueueCap + 32;  // words (LDS_PATH only)
+    const int e = blockIdx.x;
+    if (e >= n) return;
+    const uint32_t *hm = hit_mask + (size_t)e * words;
+    uint32_t *pm = path_mask + (size_t)e * words;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+
+    if (LDS_PATH) for (int i = tid; i < words; i += kRayThreads) s_path[i] = 0u;
+    // (global path mask is zeroed by the host memset when !LDS_PATH)
+
+    // source voxel (pose_coord_to_idx_3D, no clamp)
+    const float *pp = poses_xyz + (size_t)e * pose_stride;
+    const int sx = pose_axis_to_idx(pp[0], range_gt[e * 6 + 1], voxel_size[e * 3 + 0]);
+    const int sy = pose_axis_to_idx(pp[1], range_gt[e * 6 + 3], voxel_size[e * 3 + 1]);
+    const int sz = pose_axis_to_idx(pp[2], range_gt[e * 6 + 5], voxel_size[e * 3 + 2]);
+
+    // each thread owns words tid, tid + T, ... ; count its targets
+    int cnt = 0;
+    for (int i = tid; i < words; i += kRayThreads) cnt += __popc(hm[i]);
+    const int incl = wave_inclusive_scan(cnt);
+    if (lane == kWave - 1) s_wave[wv] = incl;
+    __syncthreads();
+    if (wv == 0) {
+        int v = lane < kRayWaves ? s_wave[lane] : 0;
+        const int sc = wave_inclusive_scan(v);
+        if (lane < kRayWaves) s_wave[lane] = sc - v;  // exclusive per wave
+        if (lane == kRayWaves - 1) s_wave[kRayWaves] = sc;  // total
+    }
+    __syncthreads();
+    const int my_off = s_wave[wv] + incl - cnt;
+    const int total = s_wave[kRayWaves];
+    const int max_pts = 3 * g;
+    const int gg = g * g;
+
+    for (int base = 0; base < total; base += kQueueCap) {
+        // fill the queue with targets whose global offset falls in [base, base + cap)
+        if (my_off < base + kQueueCap && my_off + cnt > base) {
+            int o = my_off;
+            for (int i = tid; i < words; i += kRayThreads) {
+                uint32_t v = hm[i];
+                while (v) {
+                    const int bit = __ffs(v) - 1;
+                    v &= v - 1;
+                    if (o >= base && o < base + kQueueCap) s_queue[o - base] = (uint32_t)(i * 32 + bit);
+                    ++o;
+                }
+            }
+        }
+        __syncthreads();
+        const int nq = min(kQueueCap, total - base);
+        for (int q = tid; q < nq; q += kRayThreads) {
+            const int lin = (int)s_queue[q];
+            const int tx = lin / gg, r = lin - tx * gg, ty = r / g, tz = r - ty * g;
+            bresenham_walk(sx, sy, sz, tx, ty, tz, g, max_pts, [&](int x, int y, int z) {
+                const int l = (x * g + y) * g + z;
+                if (LDS_PATH) atomicOr(&s_path[l >> 5], 1u << (l & 31));
+                else atomicOr(&pm[l >> 5], 1u << (l & 31));
+            });
+        }
+        __syncthreads();
+    }
+    if (LDS_PATH) for (int i = tid; i < words; i += kRayThreads) pm[i] = s_path[i];
+}
+
+// ===========================================================================
+// fused path, launch 3: streaming grid update (A6 tail + A7 + coverage count)
+// ===========================================================================
+constexpr int kGridThreads = 256;
+
+__device__ __forceinline__ void update_voxel(float &prob, float &scan, float gt, bool hit, bool path, float &tri, int &cov)
+{
+    float pr = prob;
+    if (path) pr = __fsub_rn(pr, 0.05f);
+    if (hit) pr = 1.0f;
+    prob = pr;
+    tri = (pr > 0.5f ? 1.0f : 0.0f) - (pr < 0.0f ? 1.0f : 0.0f);
+    float sc = __fadd_rn(scan, __fmul_rn(hit ? 1.0f : 0.0f, gt));
+    sc = sc < 0.0f ? 0.0f : (sc > 1.0f ? 1.0f : sc);  // torch.clip(min=0,max=1); NaN propagates like torch
+    scan = sc;
+    cov += (sc != 0.0f) ? 1 : 0;
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(kGridThreads) void k_grid_update(
+    const uint32_t *__restrict__ hit_mask, const uint32_t *__restrict__ path_mask, const float *__restrict__ grid_gt,
+    const uint8_t *__restrict__ reset_mask, int n, int g3, int words, float *__restrict__ prob_grid,
+    float *__restrict__ scanned, float *__restrict__ tri_out, int64_t tri_stride, int32_t *__restrict__ coverage)
+{
+    const int e = blockIdx.y;
+    const bool reset = reset_mask != nullptr && reset_mask[e] != 0;
+    const uint32_t *hm = hit_mask + (size_t)e * words, *pm = path_mask + (size_t)e * words;
+    float *prob = prob_grid + (size_t)e * g3, *scan = scanned + (size_t)e * g3;
+    const float *gt = grid_gt + (size_t)e * g3;
+    float *tri = tri_out + (size_t)e * tri_stride;
+    int cov = 0;
+    if (VEC4) {
+        const int nv = g3 >> 2;
+        for (int i = blockIdx.x * kGridThreads + threadIdx.x; i < nv; i += gridDim.x * kGridThreads) {
+            const int v0 = i << 2;
+            const uint32_t hb = (hm[v0 >> 5] >> (v0 & 31)) & 0xFu, pb = (pm[v0 >> 5] >> (v0 & 31)) & 0xFu;
+            float4 p4 = reset ? make_float4(0, 0, 0, 0) : reinterpret_cast<const float4 *>(prob)[i];
+            float4 s4 = reset ? make_float4(0, 0, 0, 0) : reinterpret_cast<const float4 *>(scan)[i];
+            const float4 g4 = reinterpret_cast<const float4 *>(gt)[i];
+            float4 t4;
+            update_voxel(p4.x, s4.x, g4.x, hb & 1u, pb & 1u, t4.x, cov);
+            update_voxel(p4.y, s4.y, g4.y, hb & 2u, pb & 2u, t4.y, cov);
+            update_voxel(p4.z, s4.z, g4.z, hb & 4u, pb & 4u, t4.z, cov);
+            update_voxel(p4.w, s4.w, g4.w, hb & 8u, pb & 8u, t4.w, cov);
+            reinterpret_cast<float4 *>(prob)[i] = p4;
+            reinterpret_cast<float4 *>(scan)[i] = s4;
+            reinterpret_cast<float4 *>(tri)[i] = t4;
+        }
+    } else {
+        for (int v = blockIdx.x * kGridThreads + threadIdx.x; v < g3; v += gridDim.x * kGridThreads) {
+            const bool hb = (hm[v >> 5] >> (v & 31)) & 1u, pb = (pm[v >> 5] >> (v & 31)) & 1u;
+            float p = reset ? 0.0f : prob[v], s = reset ? 0.0f : scan[v], t;
+            update_voxel(p, s, gt[v], hb, pb, t, cov);
+            prob[v] = p;
+            scan[v] = s;
+            tri[v] = t;
+        }
+    }
+    __shared__ int s_cov[kGridThreads / kWave];
+    cov = wave_reduce_sum(cov);
+    if ((threadIdx.x & (kWave - 1)) == 0) s_cov[threadIdx.x / kWave] = cov;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < kGridThreads / kWave; ++i) t += s_cov[i];
+        if (t) atomicAdd(&coverage[e], t);
+    }
+}
+
+// ===========================================================================
+// standalone operators (function-level drop-ins, parity at every stage)
+// ===========================================================================
+__global__ void k_post_process_depth(const float *__restrict__ d, const float *__restrict__ s, int64_t count, float sense,
+                                     float *__restrict__ dout, float *__restrict__ sout)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        dout[i] = process_depth(d[i], sense);
+        sout[i] = nan_to_num_neginf0(s[i]);
+    }
+}
+
+__global__ void k_rgb_to_gray(const uint8_t *__restrict__ rgba, int n, int h, int w, int oh, int ow, float *__restrict__ gray,
+                              int64_t row_stride)
+{
+    const int total = n * oh * ow;
+    const float sh = (float)h / (float)oh, sw = (float)w / (float)ow;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int e = i / (oh * ow), r = i - e * oh * ow, y = r / ow, x = r - y * ow;
+        int sy = (int)floorf(__fmul_rn((float)y, sh)), sx = (int)floorf(__fmul_rn((float)x, sw));
+        sy = min(sy, h - 1);
+        sx = min(sx, w - 1);
+        const uint8_t *p = rgba + (((size_t)e * h + sy) * w + sx) * 4;
+        float v = __fmul_rn(0.2989f, (float)p[0]);
+        v = __fadd_rn(v, __fmul_rn(0.587f, (float)p[1]));
+        v = __fadd_rn(v, __fmul_rn(0.114f, (float)p[2]));
+        gray[(size_t)e * row_stride + r] = (float)(uint8_t)v;
+    }
+}
+
+__global__ void k_back_projection(const float *__restrict__ depth, const float *__restrict__ seg, const float *__restrict__ c2w,
+                                  Intrinsics K, int n, int h, int w, float *__restrict__ world, uint8_t *__restrict__ fg)
+{
+    const int hw = h * w;
+    const int64_t total = (int64_t)n * hw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i / hw), p = (int)(i - (int64_t)e * hw), y = p / w, x = p - y * w;
+        const bool is_fg = seg[i] > 50.0f;
+        float M[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) M[k] = c2w[(size_t)e * 16 + k];
+        float wp[3];
+        pixel_to_world(is_fg ? depth[i] : 0.0f, (float)x, (float)y, K, M, wp);
+        world[i * 3 + 0] = wp[0];
+        world[i * 3 + 1] = wp[1];
+        world[i * 3 + 2] = wp[2];
+        fg[i] = is_fg ? 1 : 0;
+    }
+}
+
+__global__ void k_points_to_idx(const float *__restrict__ world, const uint8_t *__restrict__ fg, const float *__restrict__ range_gt,
+                                const float *__restrict__ voxel_size, int n, int64_t hw, int g, int32_t *__restrict__ idx)
+{
+    const int64_t total = (int64_t)n * hw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i / hw);
+        const VoxelFrame f = load_frame(range_gt + e * 6, voxel_size + e * 3);
+        const float p[3] = {world[i * 3], world[i * 3 + 1], world[i * 3 + 2]};
+        int ix[3];
+        const int lin = fg[i] ? point_to_voxel(p, f, g, ix) : -1;
+        idx[i * 3 + 0] = lin >= 0 ? ix[0] : -1;
+        idx[i * 3 + 1] = lin >= 0 ? ix[1] : -1;
+        idx[i * 3 + 2] = lin >= 0 ? ix[2] : -1;
+    }
+}
+
+__global__ void k_pose_to_idx(const float *__restrict__ poses, const float *__restrict__ range_gt, const float *__restrict__ voxel_size,
+                              int n, int64_t *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 3) return;
+    const int e = i / 3, a = i - e * 3;
+    const float v = voxel_size[e * 3 + a];
+    const float vmin = __fsub_rn(range_gt[e * 6 + 2 * a + 1], __fmul_rn(0.5f, v));
+    out[i] = (long long)floorf(__fdiv_rn(__fsub_rn(poses[i], vmin), v));
+}
+
+// one lane per ray, same launch geometry as the reference (block 256)
+__global__ __launch_bounds__(256) void k_bresenham3d(const int32_t *__restrict__ src, const int32_t *__restrict__ tgt, int num_rays,
+                                                     int g, int32_t *__restrict__ traj, int32_t *__restrict__ lens)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= num_rays) return;
+    const int max_pts = 3 * g;
+    int32_t *out = traj + (size_t)r * max_pts * 3;
+    int k = 0;
+    lens[r] = bresenham_walk(src[0], src[1], src[2], tgt[r * 3], tgt[r * 3 + 1], tgt[r * 3 + 2], g, max_pts,
+                             [&](int x, int y, int z) { out[k * 3] = x; out[k * 3 + 1] = y; out[k * 3 + 2] = z; ++k; });
+}
+
+__global__ void k_tri_cls(const float *__restrict__ p, int64_t count, float t_occ, float t_free, float *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = p[i];
+        out[i] = (v > t_occ ? 1.0f : 0.0f) - (v < t_free ? 1.0f : 0.0f);
+    }
+}
+
+__global__ void k_unpack(const uint32_t *__restrict__ mask, int64_t bits_per_env, int words, int n, uint8_t *__restrict__ out)
+{
+    const int64_t total = (int64_t)n * bits_per_env;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i / bits_per_env);
+        const int v = (int)(i - (int64_t)e * bits_per_env);
+        out[i] = (mask[(size_t)e * words + (v >> 5)] >> (v & 31)) & 1u;
+    }
+}
+
+// ===========================================================================
+// C-ABI
+// ===========================================================================
+static inline int grid_for(int64_t count, int block, int cap = 256 * 8)
+{
+    int64_t b = (count + block - 1) / block;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+static inline int mask_words(int g) { return (int)(((int64_t)g * g * g + 31) / 32); }
+// words rounded so that every env's mask starts 256-byte aligned
+static inline int mask_words_padded(int g) { return (mask_words(g) + 63) & ~63; }
+
+struct VoxelWorkspace {
+    uint32_t *hit, *path;
+    int words;
+};
+
+static inline VoxelWorkspace carve(void *ws, int n, int g)
+{
+    VoxelWorkspace v;
+    v.words = mask_words_padded(g);
+    v.hit = (uint32_t *)ws;
+    v.path = v.hit + (size_t)n * v.words;
+    return v;
+}
+
+GNBV_API size_t gnbv_voxel_workspace_bytes(int n, int g)
+{
+    if (n <= 0 || g <= 0) return 0;
+    return (size_t)2 * n * mask_words_padded(g) * sizeof(uint32_t);
+}
+
+// inv_intri is a HOST pointer to 9 floats: the matrix is a constant of the task
+// (env_train_gennbv.py:168-169) and travels to the kernels by value.
+static inline int fetch_intrinsics(const float *p, hipStream_t, Intrinsics *K)
+{
+    for (int i = 0; i < 9; ++i) K->k[i] = p[i];
+    return 0;
+}
+
+GNBV_API int gnbv_abi_version(void) { return GNBV_ABI_VERSION; }
+GNBV_API const char *gnbv_build_arch(void) { return "gfx950"; }
+
+GNBV_API int gnbv_post_process_depth(const float *depth_raw, const float *seg_raw, int64_t count, float depth_sense_dist,
+                                     float *depth_out, float *seg_out, void *stream)
+{
+    GNBV_CHECK_ARG(depth_raw && seg_raw && depth_out && seg_out && count >= 0);
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(k_post_process_depth, dim3(grid_for(count, 256)), dim3(256), 0, gnbv_stream(stream), depth_raw,
+                       seg_raw, count, depth_sense_dist, depth_out, seg_out);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_rgb_to_gray(const uint8_t *rgba, int n, int h, int w, int oh, int ow, float *gray, int64_t gray_row_stride,
+                              void *stream)
+{
+    GNBV_CHECK_ARG(rgba && gray && n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && gray_row_stride >= (int64_t)oh * ow);
+    hipLaunchKernelGGL(k_rgb_to_gray, dim3(grid_for((int64_t)n * oh * ow, 256)), dim3(256), 0, gnbv_stream(stream), rgba, n,
+                       h, w, oh, ow, gray, gray_row_stride);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_back_projection(const float *depth, const float *seg, const float *c2w, const float *inv_intri, int n, int h,
+                                  int w, float *world, uint8_t *fg, void *stream)
+{
+    GNBV_CHECK_ARG(depth && seg && c2w && inv_intri && world && fg && n > 0 && h > 0 && w > 0);
+    Intrinsics K;
+    int err = fetch_intrinsics(inv_intri, gnbv_stream(stream), &K);
+    if (err) return err;
+    hipLaunchKernelGGL(k_back_projection, dim3(grid_for((int64_t)n * h * w, 256)), dim3(256), 0, gnbv_stream(stream), depth,
+                       seg, c2w, K, n, h, w, world, fg);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_points_to_idx(const float *world, const uint8_t *fg, const float *range_gt, const float *voxel_size, int n,
+                                int64_t hw, int g, int32_t *idx, void *stream)
+{
+    GNBV_CHECK_ARG(world && fg && range_gt && voxel_size && idx && n > 0 && hw > 0 && g > 0);
+    hipLaunchKernelGGL(k_points_to_idx, dim3(grid_for(n * hw, 256)), dim3(256), 0, gnbv_stream(stream), world, fg, range_gt,
+                       voxel_size, n, hw, g, idx);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_pose_to_idx(const float *poses_xyz, const float *range_gt, const float *voxel_size, int n, int64_t *pose_idx,
+                              void *stream)
+{
+    GNBV_CHECK_ARG(poses_xyz && range_gt && voxel_size && pose_idx && n > 0);
+    hipLaunchKernelGGL(k_pose_to_idx, dim3((n * 3 + 255) / 256), dim3(256), 0, gnbv_stream(stream), poses_xyz, range_gt,
+                       voxel_size, n, pose_idx);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_bresenham3d(const int32_t *source_pts, const int32_t *target_pts, int num_rays, int map_size,
+                              int32_t *trajectory_pts, int32_t *trajectory_lengths, void *stream)
+{
+    GNBV_CHECK_ARG(source_pts && trajectory_lengths && num_rays >= 0 && map_size > 0);
+    if (num_rays == 0) return 0;
+    GNBV_CHECK_ARG(target_pts && trajectory_pts);
+    hipLaunchKernelGGL(k_bresenham3d, dim3((num_rays + 255) / 256), dim3(256), 0, gnbv_stream(stream), source_pts, target_pts,
+                       num_rays, map_size, trajectory_pts, trajectory_lengths);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_grid_tri_cls(const float *grid_prob, int64_t count, float threshold_occu, float threshold_free,
+                               float *grid_tri_cls, void *stream)
+{
+    GNBV_CHECK_ARG(grid_prob && grid_tri_cls && count >= 0);
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(k_tri_cls, dim3(grid_for(count, 256)), dim3(256), 0, gnbv_stream(stream), grid_prob, count,
+                       threshold_occu, threshold_free, grid_tri_cls);
+    return gnbv_launch_status();
+}
+
+constexpr size_t kMaxLdsBytes = 160 * 1024;
+
+GNBV_API int gnbv_update_occ_grid(const float *depth_raw, const float *seg_raw, const float *c2w, const float *inv_intri,
+                                  const float *poses_xyz, int64_t poses_row_stride, const float *range_gt,
+                                  const float *voxel_size, const float *grid_gt, const uint8_t *reset_mask, int n, int h,
+                                  int w, int g, float depth_sense_dist, float *prob_grid, float *scanned_gt_grid,
+                                  float *tri_out, int64_t tri_row_stride, int32_t *coverage_count, void *workspace,
+                                  size_t workspace_bytes, void *stream)
+{
+    GNBV_CHECK_ARG(depth_raw && seg_raw && c2w && inv_intri && poses_xyz && range_gt && voxel_size && grid_gt);
+    GNBV_CHECK_ARG(prob_grid && scanned_gt_grid && tri_out && coverage_count && workspace);
+    GNBV_CHECK_ARG(n > 0 && h > 0 && w > 0 && g > 1 && g <= 1024 && poses_row_stride >= 3);
+    const int64_t g3 = (int64_t)g * g * g;
+    GNBV_CHECK_ARG(g3 < (1ll << 31) && tri_row_stride >= g3 && (int64_t)h * w < (1ll << 31));
+    GNBV_CHECK_ARG(workspace_bytes >= gnbv_voxel_workspace_bytes(n, g) && ((uintptr_t)workspace & 255) == 0);
+    hipStream_t st = gnbv_stream(stream);
+    Intrinsics K;
+    int err = fetch_intrinsics(inv_intri, st, &K);
+    if (err) return err;
+    VoxelWorkspace ws = carve(workspace, n, g);
+    const int words = ws.words;
+    const size_t mask_bytes = (size_t)words * sizeof(uint32_t);
+    const bool lds_hit = mask_bytes <= 64 * 1024;
+    const bool lds_path = mask_bytes + (kQueueCap + 32) * sizeof(uint32_t) <= kMaxLdsBytes;
+
+    // zero: hit masks always; path masks only when rays OR straight into HBM/L2
+    err = (int)hipMemsetAsync(ws.hit, 0, (lds_path ? 1 : 2) * (size_t)n * mask_bytes, st);
+    if (err) return err;
+    err = (int)hipMemsetAsync(coverage_count, 0, (size_t)n * sizeof(int32_t), st);
+    if (err) return err;
+
+    // launch 1: hit mask.  chunks: enough workgroups to cover the chip several times.
+    const int env_groups = (n + 7) / 8;
+    int chunks = (8 * 256 + n - 1) / n;  // aim at >= 8 workgroups per CU-equivalent
+    chunks = chunks < 1 ? 1 : (chunks > 16 ? 16 : chunks);
+    const int hit_grid = env_groups * 8 * chunks;
+    if (lds_hit) {
+        hipLaunchKernelGGL(k_hit_mask, dim3(hit_grid), dim3(kHitThreads), mask_bytes, st, depth_raw, seg_raw, c2w, K,
+                           range_gt, voxel_size, n, h, w, g, depth_sense_dist, chunks, words, ws.hit);
+    } else {
+        hipLaunchKernelGGL(k_hit_mask_global, dim3(hit_grid), dim3(kHitThreads), 0, st, depth_raw, seg_raw, c2w, K,
+                           range_gt, voxel_size, n, h, w, g, depth_sense_dist, chunks, words, ws.hit);
+    }
+    err = gnbv_launch_status();
+    if (err) return err;
+
+    // launch 2: ray cast
+    if (lds_path) {
+        const size_t lds = (kQueueCap + 32) * sizeof(uint32_t) + mask_bytes;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)k_raycast<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)kMaxLdsBytes);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_raycast<true>, dim3(n), dim3(kRayThreads), lds, st, ws.hit, poses_xyz, poses_row_stride,
+                           range_gt, voxel_size, n, g, words, ws.path);
+    } else {
+        const size_t lds = (kQueueCap + 32) * sizeof(uint32_t);
+        hipLaunchKernelGGL(k_raycast<false>, dim3(n), dim3(kRayThreads), lds, st, ws.hit, poses_xyz, poses_row_stride,
+                           range_gt, voxel_size, n, g, words, ws.path);
+    }
+    err = gnbv_launch_status();
+    if (err) return err;
+
+    // launch 3: grid update
+    const bool vec4 = (g3 % 4 == 0) && (tri_row_stride % 4 == 0) && (((uintptr_t)tri_out & 15) == 0) &&
+                      (((uintptr_t)prob_grid & 15) == 0) && (((uintptr_t)scanned_gt_grid & 15) == 0) &&
+                      (((uintptr_t)grid_gt & 15) == 0);
+    const int64_t items = vec4 ? g3 / 4 : g3;
+    int bx = (int)((items + kGridThreads - 1) / kGridThreads);
+    const int cap = (4096 + n - 1) / n;  // ~16 workgroups per CU in total, grid-stride beyond
+    bx = bx > cap ? cap : bx;
+    if (vec4)
+        hipLaunchKernelGGL(k_grid_update<true>, dim3(bx, n), dim3(kGridThreads), 0, st, ws.hit, ws.path, grid_gt, reset_mask,
+                           n, (int)g3, words, prob_grid, scanned_gt_grid, tri_out, tri_row_stride, coverage_count);
+    else
+        hipLaunchKernelGGL(k_grid_update<false>, dim3(bx, n), dim3(kGridThreads), 0, st, ws.hit, ws.path, grid_gt,
+                           reset_mask, n, (int)g3, words, prob_grid, scanned_gt_grid, tri_out, tri_row_stride,
+                           coverage_count);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_unpack_masks(const void *workspace, int n, int g, uint8_t *hit_u8, uint8_t *path_u8, void *stream)
+{
+    GNBV_CHECK_ARG(workspace && n > 0 && g > 0);
+    VoxelWorkspace ws = carve(const_cast<void *>(workspace), n, g);
+    const int64_t g3 = (int64_t)g * g * g;
+    if (hit_u8)
+        hipLaunchKernelGGL(k_unpack, dim3(grid_for(n * g3, 256)), dim3(256), 0, gnbv_stream(stream), ws.hit, g3, ws.words, n,
+                           hit_u8);
+    if (path_u8)
+        hipLaunchKernelGGL(k_unpack, dim3(grid_for(n * g3, 256)), dim3(256), 0, gnbv_stream(stream), ws.path, g3, ws.words, n,
+                           path_u8);
+    return gnbv_launch_status();
+}

@@ -1,0 +1,83 @@
+"""Fused state encoding: counterpart of Env_Train_GenNBV.update_occ_grid
+(gennbv/env/env_train_gennbv.py:277-326) + post_process_camera_tensor's depth/seg
+branch (gennbv/env/env_train_base.py:521-534) + back_projection_fg (:494-533).
+
+One `update()` call = one environment step for all N envs = three gfx950 kernel
+launches (gennbv_amd/csrc/voxel.hip) instead of the reference's N-iteration
+Python loop.  State tensors keep the reference's names, shapes and dtypes:
+
+    prob_grid, scanned_gt_grid, grid_gt : [N,G,G,G] f32
+    occ_grids_tri_cls                   : [N,G,G,G] f32 view (may alias a slice of
+                                          the flat observation rows)
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import _lib
+
+
+class OccupancyGridUpdater:
+    def __init__(self, num_envs: int, grid_size: int, camera_height: int, camera_width: int,
+                 inv_intri: torch.Tensor, range_gt: torch.Tensor, voxel_size_gt: torch.Tensor, grid_gt: torch.Tensor,
+                 device, depth_sense_dist: float = -50.0):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.GennbvHipError("OccupancyGridUpdater needs a GPU device (no CPU fallback)")
+        self.num_envs, self.grid_size = int(num_envs), int(grid_size)
+        self.h, self.w = int(camera_height), int(camera_width)
+        self.depth_sense_dist = float(depth_sense_dist)
+        g = self.grid_size
+        self.inv_intri_host = inv_intri.detach().to("cpu", torch.float32).contiguous()
+        self.range_gt = range_gt.to(self.device, torch.float32).contiguous()
+        self.voxel_size_gt = voxel_size_gt.to(self.device, torch.float32).contiguous()
+        self.grid_gt = grid_gt.to(self.device, torch.float32).contiguous()
+        assert self.grid_gt.shape == (num_envs, g, g, g)
+        self.prob_grid = torch.zeros(num_envs, g, g, g, dtype=torch.float32, device=self.device)
+        self.scanned_gt_grid = torch.zeros_like(self.prob_grid)
+        self.coverage_count = torch.zeros(num_envs, dtype=torch.int32, device=self.device)
+        nbytes = self.lib.gnbv_voxel_workspace_bytes(num_envs, g)
+        # torch's caching allocator returns >=512-byte aligned blocks
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        assert self.workspace.data_ptr() % 256 == 0
+        self._own_tri = None
+
+    def update(self, depth_raw: torch.Tensor, seg_raw: torch.Tensor, c2w: torch.Tensor, poses: torch.Tensor,
+               reset_mask: Optional[torch.Tensor] = None, tri_out: Optional[torch.Tensor] = None,
+               tri_row_stride: Optional[int] = None) -> torch.Tensor:
+        """depth_raw/seg_raw [N,H,W] f32 RAW camera tensors, c2w [N,4,4] f32, poses [N,>=3]
+        f32 (xyz first).  `tri_out`: optional destination whose row e starts at
+        tri_out.data_ptr() + e*tri_row_stride*4 (e.g. the grid slice of the flat obs)."""
+        n, g = self.num_envs, self.grid_size
+        _lib.require_cuda(depth_raw, seg_raw, c2w, poses, reset_mask, tri_out)
+        _lib.require_contig(depth_raw, seg_raw, c2w)
+        assert depth_raw.shape == (n, self.h, self.w) and depth_raw.dtype == torch.float32
+        assert seg_raw.shape == (n, self.h, self.w) and seg_raw.dtype == torch.float32
+        assert c2w.shape == (n, 4, 4) and c2w.dtype == torch.float32
+        assert poses.dtype == torch.float32 and poses.stride(-1) == 1 and poses.shape[0] == n
+        if tri_out is None:
+            if self._own_tri is None:
+                self._own_tri = torch.empty(n, g, g, g, dtype=torch.float32, device=self.device)
+            tri_out, tri_row_stride = self._own_tri, g ** 3
+        if reset_mask is not None:
+            assert reset_mask.dtype == torch.uint8 and reset_mask.is_contiguous()
+        _lib.check(self.lib.gnbv_update_occ_grid(
+            depth_raw.data_ptr(), seg_raw.data_ptr(), c2w.data_ptr(), self.inv_intri_host.data_ptr(),
+            poses.data_ptr(), poses.stride(0), self.range_gt.data_ptr(), self.voxel_size_gt.data_ptr(),
+            self.grid_gt.data_ptr(), _lib.ptr(reset_mask), n, self.h, self.w, g, self.depth_sense_dist,
+            self.prob_grid.data_ptr(), self.scanned_gt_grid.data_ptr(), tri_out.data_ptr(), int(tri_row_stride),
+            self.coverage_count.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
+            _lib.stream_ptr(self.device)), "gnbv_update_occ_grid")
+        return tri_out
+
+    def masks(self):
+        """(hit, path) bool [N,G,G,G] of the last update (parity / debugging)."""
+        n, g = self.num_envs, self.grid_size
+        hit = torch.empty(n, g, g, g, dtype=torch.uint8, device=self.device)
+        path = torch.empty_like(hit)
+        _lib.check(self.lib.gnbv_unpack_masks(self.workspace.data_ptr(), n, g, hit.data_ptr(), path.data_ptr(),
+                                              _lib.stream_ptr(self.device)), "gnbv_unpack_masks")
+        return hit.bool(), path.bool()

@@ -1,0 +1,122 @@
+/*
+ * gennbv_hip.h -- C-ABI of libgennbv_hip.so, the MI355X (gfx950) implementation of
+ * GenNBV's state-encoding + PPO hot path.
+ *
+ * Conventions (SURVEY.md section 8b "Ownership / lifetime"):
+ *   - every pointer is a CALLER-OWNED DEVICE pointer (HBM) unless marked [host];
+ *     nothing is retained or freed; scratch comes from a caller-owned workspace;
+ *   - `stream` is the caller's hipStream_t passed as void* (NULL = default stream);
+ *     all work is enqueued on it, nothing synchronises the device;
+ *   - return value: 0 on success, otherwise a hipError_t value
+ *     (1 = hipErrorInvalidValue for bad arguments). Never throws.
+ *   - tensors are dense row-major fp32 unless stated; grids are [N, G, G, G]
+ *     C-order over (X, Y, Z) exactly like the reference's torch tensors.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to
+ * the zjwzcx/GenNBV root). INTEGRATION.md shows the ctypes binding a maintainer
+ * would add on the reference side.
+ */
+#ifndef GENNBV_HIP_H
+#define GENNBV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNBV_ABI_VERSION 1
+
+int gnbv_abi_version(void);
+/* Name of the device architecture the library was compiled for ("gfx950"). [host] */
+const char *gnbv_build_arch(void);
+
+/* ------------------------------------------------------------------------- */
+/* A1  Env_Train_Base.post_process_camera_tensor, depth + seg branch          */
+/*     gennbv/env/env_train_base.py:521-534                                    */
+/* ------------------------------------------------------------------------- */
+int gnbv_post_process_depth(const float *depth_raw, const float *seg_raw, int64_t count,
+                            float depth_sense_dist, float *depth_out, float *seg_out, void *stream);
+
+/* A1 rgb branch (env_train_base.py:517-520): RGBA u8 [N,H,W,4] -> nearest
+ * resize to [oh,ow] -> grayscale f32 [N,1,oh,ow].  Parity unpinned (torchvision). */
+int gnbv_rgb_to_gray(const uint8_t *rgba, int n, int h, int w, int oh, int ow, float *gray,
+                     int64_t gray_row_stride /* floats between envs, >= oh*ow */, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* A2  Env_Train_GenNBV.back_projection_fg  (env_train_gennbv.py:494-533)      */
+/*     depth/seg are the PROCESSED tensors; c2w [N,4,4] is inv(view^T) @        */
+/*     blender2opencv with env_origins subtracted (host plumbing, :512-514).   */
+/*     world [N,HW,3]; fg [N,HW] u8 (seg > 50).                                 */
+/* ------------------------------------------------------------------------- */
+int gnbv_back_projection(const float *depth, const float *seg, const float *c2w, const float *inv_intri /*[host] [3,3]*/,
+                         int n, int h, int w, float *world, uint8_t *fg, void *stream);
+
+/* A3  scanned_pts_to_idx_3D (gennbv/utils.py:230-270), per point, before the
+ *     set reduction: idx [N,HW,3] int32, (-1,-1,-1) for dropped points. */
+int gnbv_points_to_idx(const float *world, const uint8_t *fg, const float *range_gt /*[N,6]*/,
+                       const float *voxel_size /*[N,3]*/, int n, int64_t hw, int g, int32_t *idx, void *stream);
+
+/* A4  pose_coord_to_idx_3D (gennbv/utils.py:273-306, if_col=False): no clamp. */
+int gnbv_pose_to_idx(const float *poses_xyz /*[N,3]*/, const float *range_gt, const float *voxel_size, int n,
+                     int64_t *pose_idx /*[N,3]*/, void *stream);
+
+/* A5  bresenham3D_pycuda kernel launch (gennbv/utils.py:170-220): one source,
+ *     num_rays targets; trajectory_pts [num_rays, 3*map_size, 3] int32 and
+ *     trajectory_lengths [num_rays] int32 must be zero-filled by the caller
+ *     (as utils.py:40-41 does). */
+int gnbv_bresenham3d(const int32_t *source_pts /*[3]*/, const int32_t *target_pts /*[R,3]*/, int num_rays, int map_size,
+                     int32_t *trajectory_pts, int32_t *trajectory_lengths, void *stream);
+
+/* A7  grid_occupancy_tri_cls (gennbv/utils.py:309-325), return_tri_cls_only. */
+int gnbv_grid_tri_cls(const float *grid_prob, int64_t count, float threshold_occu, float threshold_free,
+                      float *grid_tri_cls, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* A1-A7 fused: Env_Train_GenNBV.update_occ_grid (env_train_gennbv.py:277-326)  */
+/*   One call = one environment step for all N envs, three launches:           */
+/*     hit-mask scatter (LDS-staged bitmask) -> ray cast (LDS path bitmask)     */
+/*     -> streaming grid update.                                                */
+/*   depth_raw / seg_raw are the RAW camera tensors (A1 is fused).              */
+/*   reset_mask [N] u8 or NULL: env rows whose prob/scanned grids are treated   */
+/*   as zero before the update (reset_idx :416-420 folded into the next step).  */
+/*   tri_out: row e starts at tri_out + e*tri_row_stride (floats) so the        */
+/*   tri-class grid can land directly inside the flat observation row           */
+/*   (wrapper key order state, grid, state_rgb).                                */
+/*   coverage_count [N] int32 = number of non-zero scanned_gt voxels            */
+/*   (== scanned_gt.sum() for the reference's binary GT, :537).                 */
+/*   workspace: gnbv_voxel_workspace_bytes(n, g) bytes, 256-byte aligned.       */
+/* ------------------------------------------------------------------------- */
+size_t gnbv_voxel_workspace_bytes(int n, int g);
+
+int gnbv_update_occ_grid(const float *depth_raw, const float *seg_raw, const float *c2w,
+                         const float *inv_intri /*[host] [3,3]*/,
+                         const float *poses_xyz /*[N,3]*/, int64_t poses_row_stride /*floats*/,
+                         const float *range_gt, const float *voxel_size, const float *grid_gt,
+                         const uint8_t *reset_mask, int n, int h, int w, int g, float depth_sense_dist,
+                         float *prob_grid, float *scanned_gt_grid, float *tri_out, int64_t tri_row_stride,
+                         int32_t *coverage_count, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Debug/parity view of the workspace after gnbv_update_occ_grid: expands the
+ * hit / path bitmasks to u8 [N,G^3] (either output may be NULL). */
+int gnbv_unpack_masks(const void *workspace, int n, int g, uint8_t *hit_u8, uint8_t *path_u8, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* C2  TensorRolloutBuffer_Grid_Obs.compute_returns_and_advantage               */
+/*     stable_baselines3/common/buffers.py:706-724.  All arrays [T,N] (the      */
+/*     reference's [T,N,1]); episode_starts / dones are u8.                      */
+/* ------------------------------------------------------------------------- */
+int gnbv_gae_sb3(const float *rewards, const float *values, const uint8_t *episode_starts, const float *last_values,
+                 const uint8_t *dones, int t_steps, int n, double gamma, double gae_lambda, float *advantages,
+                 float *returns, void *stream);
+
+/* C-alt  rsl_rl RolloutStorage.compute_returns (rsl_rl/storage/rollout_storage.py:130-142),
+ *        advantages = returns - values, NOT yet normalised (:143-144 is the caller's reduction). */
+int gnbv_gae_rsl(const float *rewards, const float *values, const uint8_t *dones, const float *last_values,
+                 int t_steps, int n, double gamma, double lam, float *returns, float *advantages, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENNBV_HIP_H */

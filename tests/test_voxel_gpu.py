@@ -1,0 +1,181 @@
+"""GPU: HIP state-encoding kernels (through the C-ABI) vs the CPU oracle and the goldens."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from tests import golden_util as gu
+from gennbv_amd.env import synthetic as S
+from gennbv_amd.env.config import TaskConfig
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def test_bresenham_bit_exact_vs_golden_and_oracle():
+    from gennbv_amd import utils
+    fx = gu.load("F4_bresenham")
+    for k in sorted(k[:-4] for k in fx.files if k.endswith("_src")):
+        g = int(k.split("_")[0][1:])
+        traj, lens = utils.bresenham3D_raw(T(fx[k + "_src"]), T(fx[k + "_tgt"]), g)
+        assert np.array_equal(lens.cpu().numpy(), fx[k + "_len"]), k
+        assert np.array_equal(traj.cpu().numpy(), fx[k + "_traj"].astype(np.int32)), k
+    rs = np.random.RandomState(1)
+    for g in (8, 20, 64, 128):
+        src = rs.randint(-g, 2 * g, size=(1, 3)).astype(np.int32)
+        tgt = rs.randint(0, g, size=(5000, 3)).astype(np.int32)
+        otraj, olens = orc.bresenham3d(src, tgt, g)
+        out = utils.bresenham3D_pycuda(T(src), T(tgt), g).cpu().numpy()
+        ref = otraj[np.arange(3 * g)[None, :] < olens[:, None]].reshape(-1, 3)
+        assert out.dtype == np.int64 and np.array_equal(out, ref)
+    # empty target list: reference returns an empty [0,3] long tensor
+    assert utils.bresenham3D_pycuda(T(src), torch.zeros(0, 3, device=DEV), 16).shape == (0, 3)
+
+
+def test_postprocess_backprojection_voxelidx_vs_golden():
+    from gennbv_amd import utils
+    fx = gu.load("F2_backproj")
+    n, g = int(fx["n"]), int(fx["g"])
+    d, seg = gu.frames(fx)
+    dp, sp = utils.post_process_depth(T(d[0]), T(seg[0]))
+    assert dp.cpu().numpy().tobytes() == fx["depth_processed"].tobytes()
+    assert sp.cpu().numpy().tobytes() == fx["seg_processed"].tobytes()
+    c2w = T(fx["c2w"])
+    pts, world, fg = utils.back_projection_fg(dp, sp, c2w, torch.from_numpy(fx["inv_intri"]), return_all=True)
+    idx_lists = utils.scanned_pts_to_idx_3D(pts, T(fx["range_gt"]), T(fx["voxel_size"]), map_size=g)
+    for e in range(n):
+        assert pts[e].cpu().numpy().tobytes() == fx[f"world_{e}"].tobytes()
+        assert np.array_equal(idx_lists[e].cpu().numpy(), fx[f"uidx_{e}"].reshape(-1, 3))
+    assert np.array_equal(utils.pose_coord_to_idx_3D(T(fx["poses"][:, :3]), T(fx["range_gt"]), T(fx["voxel_size"]), g).cpu().numpy(), fx["pose_idx"])
+    assert np.array_equal(utils.pose_coord_to_idx_3D(T(fx["far_poses"]), T(fx["range_gt"]), T(fx["voxel_size"]), g).cpu().numpy(), fx["far_idx"])
+    # empty env list entry
+    assert utils.scanned_pts_to_idx_3D([torch.zeros(0, 3, device=DEV)], T(fx["range_gt"]), T(fx["voxel_size"]), g) == [[]]
+
+
+def _run_sequence(n, h, w, g, steps, seed, reset_at=()):
+    """HIP updater vs oracle on the same seeded synthetic frames; returns per-step mismatch info."""
+    from gennbv_amd.env.state_encoding import OccupancyGridUpdater
+    cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
+    scene = S.make_scenes(n, g, seed=seed)
+    frames = S.make_frames(scene, cfg, min(steps, 4), seed=seed, with_rgba=False)
+    kinv = S.inverse_intrinsics(h, w)
+    upd = OccupancyGridUpdater(n, g, h, w, kinv, scene.range_gt, scene.voxel_size, scene.grid_gt, DEV)
+    prob = np.zeros((n, g, g, g), np.float32)
+    scan = np.zeros_like(prob)
+    rs = np.random.RandomState(seed)
+    for s in range(steps):
+        f = frames[s % len(frames)]
+        c2w = S.c2w_from_view(f.view, scene.env_origins)
+        reset = None
+        if s in reset_at:
+            reset = (rs.rand(n) < 0.5).astype(np.uint8)
+            reset[0] = 1
+        dp, sp = orc.post_process_depth(f.depth_raw.numpy(), f.seg_raw.numpy())
+        tri_o, cov_o, hit_o, path_o = orc.update_occ_grid(
+            dp, sp, c2w.numpy(), kinv.numpy(), f.poses[:, :3].numpy(), scene.range_gt.numpy(), scene.voxel_size.numpy(),
+            scene.grid_gt.numpy(), prob, scan, reset_mask=reset, return_masks=True)
+        tri = upd.update(f.depth_raw.to(DEV), f.seg_raw.to(DEV), c2w.to(DEV), f.poses.to(DEV).contiguous(),
+                         reset_mask=None if reset is None else torch.from_numpy(reset).to(DEV))
+        hit, path = upd.masks()
+        assert np.array_equal(hit.cpu().numpy(), hit_o), f"step {s}: hit mask differs"
+        assert np.array_equal(path.cpu().numpy(), path_o), f"step {s}: path mask differs"
+        assert upd.prob_grid.cpu().numpy().tobytes() == prob.tobytes(), f"step {s}: prob grid differs"
+        assert upd.scanned_gt_grid.cpu().numpy().tobytes() == scan.tobytes(), f"step {s}"
+        assert tri.cpu().numpy().tobytes() == tri_o.tobytes(), f"step {s}"
+        assert np.array_equal(upd.coverage_count.cpu().numpy(), cov_o), f"step {s}"
+        assert hit_o.sum() > 0 and path_o.sum() > hit_o.sum()
+    return upd
+
+
+@pytest.mark.parametrize("n,h,w,g,steps", [(4, 240, 320, 16, 6), (3, 100, 100, 20, 5), (9, 120, 160, 64, 4),
+                                           (2, 30, 37, 33, 3), (2, 60, 80, 128, 2)])
+def test_fused_update_bit_exact_vs_oracle(n, h, w, g, steps):
+    _run_sequence(n, h, w, g, steps, seed=11 + g, reset_at=(2,))
+
+
+def test_fused_update_matches_reference_golden_masks():
+    """Golden F5 (reference env on CPU): prob/tri/scanned after real reference steps."""
+    from gennbv_amd.env.state_encoding import OccupancyGridUpdater
+    fx = gu.load("F5_envstep_g20")
+    n, h, w, g = int(fx["n"]), int(fx["h"]), int(fx["w"]), int(fx["g"])
+    d, seg = gu.frames(fx)
+    cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
+    gt = gu.unpack_bits(fx["grid_gt_bits"], g)
+    upd = OccupancyGridUpdater(n, g, h, w, torch.from_numpy(fx["inv_intri"]), torch.from_numpy(fx["range_gt"]),
+                               torch.from_numpy(fx["voxel_size"]), torch.from_numpy(gt), DEV)
+    org = torch.from_numpy(fx["env_origins"])
+    # reset(): frame 0 at the init pose
+    init_pose = torch.tensor(cfg.init_pose_buf).repeat(n, 1).to(DEV)
+    c2w = S.c2w_from_view(torch.from_numpy(fx["view"][0]), org).to(DEV)
+    tri = upd.update(T(d[0]), T(seg[0]), c2w, init_pose)
+    assert np.array_equal(tri.cpu().numpy().astype(np.int8), fx["reset_tri"])
+    assert upd.prob_grid.cpu().numpy().tobytes() == fx["reset_prob"].tobytes()
+
+
+def test_full_size_properties_config1():
+    """BASELINE config 1 size (256 envs, 240x320, 64^3): size-independent properties."""
+    from gennbv_amd.env.state_encoding import OccupancyGridUpdater
+    n, h, w, g = 256, 240, 320, 64
+    cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
+    scene = S.make_scenes(n, g, seed=3, device=DEV)
+    f = S.make_frames(scene, cfg, 1, seed=3, with_rgba=False)[0]
+    upd = OccupancyGridUpdater(n, g, h, w, S.inverse_intrinsics(h, w), scene.range_gt, scene.voxel_size, scene.grid_gt, DEV)
+    c2w = S.c2w_from_view(f.view, scene.env_origins)
+    tri1 = upd.update(f.depth_raw, f.seg_raw, c2w, f.poses.contiguous()).clone()
+    hit, path = upd.masks()
+    prob1 = upd.prob_grid.clone()
+    # hit voxels are occupied, path-only voxels are free, everything else unknown
+    assert bool((prob1[hit] == 1.0).all())
+    assert bool((prob1[path & ~hit] == -0.05).all())
+    assert bool((prob1[~path & ~hit] == 0.0).all())
+    assert bool(hit.flatten(1).any(1).float().mean() > 0.9)
+    # every hit voxel is the endpoint of its own ray -> hit subset of path (source->target, endpoint included)
+    assert bool((path | ~hit).all())
+    assert bool((tri1 == (prob1 > 0.5).float() - (prob1 < 0).float()).all())
+    # coverage count == sum(scanned) and scanned == hit & gt for binary gt after one step
+    assert torch.equal(upd.coverage_count.long(), upd.scanned_gt_grid.flatten(1).sum(1).long())
+    assert torch.equal(upd.scanned_gt_grid, (hit & (scene.grid_gt > 0)).float())
+    # idempotence of the sets: same frame again leaves hit voxels at 1, decrements path-only voxels once more
+    upd.update(f.depth_raw, f.seg_raw, c2w, f.poses.contiguous())
+    hit2, path2 = upd.masks()
+    assert torch.equal(hit, hit2) and torch.equal(path, path2)
+    assert bool((upd.prob_grid[path & ~hit] == torch.tensor(-0.05, device=DEV) - 0.05).all())
+    # a reset mask zeroes history: result equals the first step again
+    upd.update(f.depth_raw, f.seg_raw, c2w, f.poses.contiguous(), reset_mask=torch.ones(n, dtype=torch.uint8, device=DEV))
+    assert torch.equal(upd.prob_grid, prob1)
+    # spot-check 3 envs bit-exactly against the oracle at full resolution
+    sel = [0, 101, 255]
+    pr = np.zeros((3, g, g, g), np.float32); sc = np.zeros_like(pr)
+    dp, sp = orc.post_process_depth(f.depth_raw[sel].cpu().numpy(), f.seg_raw[sel].cpu().numpy())
+    tri_o, cov_o = orc.update_occ_grid(dp, sp, c2w[sel].cpu().numpy(), S.inverse_intrinsics(h, w).numpy(), f.poses[sel, :3].cpu().numpy(),
+                                       scene.range_gt[sel].cpu().numpy(), scene.voxel_size[sel].cpu().numpy(), scene.grid_gt[sel].cpu().numpy(), pr, sc)
+    assert prob1[sel].cpu().numpy().tobytes() == pr.tobytes()
+    assert tri1[sel].cpu().numpy().tobytes() == tri_o.tobytes()
+
+
+def test_tri_written_into_strided_observation_rows():
+    from gennbv_amd.env.state_encoding import OccupancyGridUpdater
+    n, h, w, g = 5, 48, 64, 16
+    cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
+    scene = S.make_scenes(n, g, seed=9, device=DEV)
+    f = S.make_frames(scene, cfg, 1, seed=9, with_rgba=False)[0]
+    upd = OccupancyGridUpdater(n, g, h, w, S.inverse_intrinsics(h, w), scene.range_gt, scene.voxel_size, scene.grid_gt, DEV)
+    obs = torch.full((n, cfg.obs_dim), 7.0, device=DEV)
+    c2w = S.c2w_from_view(f.view, scene.env_origins)
+    upd.update(f.depth_raw, f.seg_raw, c2w, f.poses.contiguous(), tri_out=obs[:, cfg.state_dim:], tri_row_stride=cfg.obs_dim)
+    ref = OccupancyGridUpdater(n, g, h, w, S.inverse_intrinsics(h, w), scene.range_gt, scene.voxel_size, scene.grid_gt, DEV)
+    tri = ref.update(f.depth_raw, f.seg_raw, c2w, f.poses.contiguous())
+    assert torch.equal(obs[:, cfg.state_dim:cfg.state_dim + g ** 3], tri.view(n, -1))
+    assert bool((obs[:, :cfg.state_dim] == 7).all()) and bool((obs[:, cfg.state_dim + g ** 3:] == 7).all())
+
+
+def test_bad_arguments_return_error_codes():
+    from gennbv_amd import _lib
+    lib = _lib.load()
+    assert lib.gnbv_update_occ_grid(*([None] * 10), 1, 1, 1, 2, -50.0, None, None, None, 8, None, None, 0, None) == 1
+    assert lib.gnbv_gae_sb3(None, None, None, None, None, 1, 1, 0.99, 0.95, None, None, None) == 1
