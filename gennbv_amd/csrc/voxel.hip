@@ -609,9 +609,9 @@ GNBV_API int gnbv_pose_to_idx(const float *poses_xyz, const float *range_gt, con
 GNBV_API int gnbv_bresenham3d(const int32_t *source_pts, const int32_t *target_pts, int num_rays, int map_size,
                               int32_t *trajectory_pts, int32_t *trajectory_lengths, void *stream)
 {
-    GNBV_CHECK_ARG(source_pts && trajectory_lengths && num_rays >= 0 && map_size > 0);
-    if (num_rays == 0) return 0;
-    GNBV_CHECK_ARG(target_pts && trajectory_pts);
+    GNBV_CHECK_ARG(num_rays >= 0 && map_size > 0);
+    if (num_rays == 0) return 0;  // empty target list: nothing to write (pointers may be NULL)
+    GNBV_CHECK_ARG(source_pts && trajectory_lengths && target_pts && trajectory_pts);
     hipLaunchKernelGGL(k_bresenham3d, dim3((num_rays + 255) / 256), dim3(256), 0, gnbv_stream(stream), source_pts, target_pts,
                        num_rays, map_size, trajectory_pts, trajectory_lengths);
     return gnbv_launch_status();

@@ -177,5 +177,5 @@ def test_tri_written_into_strided_observation_rows():
 def test_bad_arguments_return_error_codes():
     from gennbv_amd import _lib
     lib = _lib.load()
-    assert lib.gnbv_update_occ_grid(*([None] * 10), 1, 1, 1, 2, -50.0, None, None, None, 8, None, None, 0, None) == 1
+    assert lib.gnbv_update_occ_grid(*([None] * 5), 3, *([None] * 4), 1, 1, 1, 2, -50.0, None, None, None, 8, None, None, 0, None) == 1
     assert lib.gnbv_gae_sb3(None, None, None, None, None, 1, 1, 0.99, 0.95, None, None, None) == 1
