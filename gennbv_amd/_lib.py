@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgennbv_hip.so")
+LIB_PATH = os.environ.get("GENNBV_HIP_LIB", os.path.join(_HERE, "libgennbv_hip.so"))  # override: A/B builds
 
 _p = C.c_void_p
 _i = C.c_int

@@ -12,9 +12,9 @@
 //                  and ORs voxel bits into an LDS-resident G^3-bit mask
 //                  (64^3 bits = 32 KiB); non-zero words are flushed with one
 //                  device-scope atomicOr each.  HBM-bound: H*W*8 B per env.
-//   k_raycast      one workgroup per env (1024 threads).  Compacts the set bits of
-//                  the hit mask into an LDS queue and walks one integer Bresenham
-//                  ray per lane, OR-ing the visited voxels into an LDS path mask.
+//   k_raycast      N x S workgroups of 1024 threads.  Compacts the set bits of the
+//                  hit mask into an LDS queue and walks one integer Bresenham ray per
+//                  lane, OR-ing the visited voxels into an LDS path mask.
 //                  Integer-ALU / LDS-atomic bound, touches ~2 * G^3/8 B of HBM.
 //   k_grid_update  streaming pass over prob / scanned / gt -> prob / scanned / tri,
 //                  float4 per lane, + per-env coverage count.  HBM-bound:
@@ -25,12 +25,13 @@
 // reference's non-accumulating index_put does -- hence bitmasks, not counters.
 //
 // Workgroup -> XCD placement: block b runs on XCD b % 8 (observed, used for speed
-// only).  k_hit_mask maps env e to blocks with b % 8 == e % 8 and k_raycast uses
-// b == e, so one env's mask words stay in one XCD's L2 between the launches.
+// only).  k_hit_mask and k_raycast map env e to blocks with b % 8 == e % 8, so one
+// env's mask words stay in one XCD's L2 between the launches.
 // Correctness never depends on it: the only inter-workgroup traffic inside a
 // launch is device-scope atomicOr, the rest crosses kernel boundaries.
 #include "common.h"
 #include "../../include/gennbv_hip.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------
 // canonical fp32 arithmetic (DESIGN.md "canonical order"); file is built with
@@ -159,6 +160,38 @@ __device__ __forceinline__ int bresenham_walk(int x0, int y0, int z0, int x1, in
 // ===========================================================================
 constexpr int kHitThreads = 256;
 
+// floor(num / den) for 0 <= num < 2^23, den > 0, inv_den = 1/den rounded: one mul + fix-up.
+__device__ __forceinline__ int floor_div_small(int num, int den, float inv_den)
+{
+    int q = (int)(__fmul_rn((float)num, inv_den));
+    const int r = num - q * den;
+    q += (r >= den) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
+
+// Per-env constants of the hot loop.  inv_vox is only a *predictor*: the result is
+// always floor(RN(x / v)) -- see voxel_axis_fast.
+struct HitFrame {
+    float vmin[3], vmax[3], vox[3], inv_vox[3], gmax;
+};
+
+// floor((p - vmin) / v) with IEEE division semantics, without paying for the division:
+// q' = x * RN(1/v) differs from RN(x / v) by at most ~1.6 * 2^-23 * |q|, so the two floors
+// can only differ when q' lies within that distance of an integer; there (and only there)
+// the exact quotient is evaluated.  Bit-exact by construction, ~2^-20 slow-path rate.
+__device__ __forceinline__ float voxel_axis_fast(float p, float vmin, float v, float inv_v)
+{
+    const float x = __fsub_rn(p, vmin);
+    const float q = __fmul_rn(x, inv_v);
+    float fl = floorf(q);
+    const float frac = __fsub_rn(q, fl);
+    const float thr = __fmul_rn(fabsf(q), 4.76837158203125e-07f);  // 2^-21
+    if (__builtin_expect(!(frac >= thr && frac <= __fsub_rn(1.0f, thr)), 0)) fl = floorf(__fdiv_rn(x, v));
+    return fl;
+}
+
+template <bool KFAST>
 __global__ __launch_bounds__(kHitThreads) void k_hit_mask(
     const float *__restrict__ depth_raw, const float *__restrict__ seg_raw, const float *__restrict__ c2w,
     Intrinsics K, const float *__restrict__ range_gt, const float *__restrict__ voxel_size,
@@ -176,36 +209,73 @@ __global__ __launch_bounds__(kHitThreads) void k_hit_mask(
 #pragma unroll
     for (int i = 0; i < 12; ++i) M[i] = c2w[(size_t)e * 16 + i];
     const VoxelFrame f = load_frame(range_gt + e * 6, voxel_size + e * 3);
+    HitFrame hf;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        hf.vmin[a] = f.vmin[a]; hf.vmax[a] = f.vmax[a]; hf.vox[a] = f.vox[a];
+        hf.inv_vox[a] = __frcp_rn(f.vox[a]);
+    }
+    hf.gmax = (float)(g - 1);
     const int hw = h * w;
     int ppc = (hw + chunks - 1) / chunks;
     ppc = (ppc + 3) & ~3;
     const int px0 = c * ppc, px1 = min(hw, px0 + ppc);
     const float *dptr = depth_raw + (size_t)e * hw;
     const float *sptr = seg_raw + (size_t)e * hw;
+    const float inv_w = __frcp_rn((float)w);
+    const int gg = g * g;
     __syncthreads();
 
-    auto one_pixel = [&](int p, float draw, float sraw) {
-        // seg: nan_to_num then > 50 (env_train_base.py:530-531, env_train_gennbv.py:504)
-        if (!(nan_to_num_neginf0(sraw) > 50.0f)) return;
-        const int y = p / w, x = p - y * w;
+    // (x, y) pixel coordinates as floats; draw/sraw the RAW camera values
+    auto one_pixel = [&](float fx, float fy, float draw, float sraw) {
+        // seg: nan_to_num(neginf=0) then > 50 (env_train_base.py:530-531, env_train_gennbv.py:504)
+        // == plain `> 50` (NaN and -inf compare false, +inf -> FLT_MAX stays true)
+        if (!(sraw > 50.0f)) return;
+        const float d = process_depth(draw, sense_dist);
         float wp[3];
-        int ix[3];
-        pixel_to_world(process_depth(draw, sense_dist), (float)x, (float)y, K, M, wp);
-        const int lin = point_to_voxel(wp, f, g, ix);
-        if (lin >= 0) atomicOr(&s_mask[lin >> 5], 1u << (lin & 31));
+        if (KFAST && d <= 50.0f) {
+            // inv_intri = [[a,0,c],[0,b,d],[0,0,1]] (checked on the host) and finite products:
+            // the zero terms of the fma chain vanish exactly, cam_z = d.
+            const float pu = __fmul_rn(d, fx), pv = __fmul_rn(d, fy);
+            const float cx = __fmaf_rn(K.k[2], d, __fmul_rn(K.k[0], pu));
+            const float cy = __fmaf_rn(K.k[5], d, __fmul_rn(K.k[4], pv));
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float acc = __fmul_rn(M[i * 4 + 0], cx);
+                acc = __fmaf_rn(M[i * 4 + 1], cy, acc);
+                acc = __fmaf_rn(M[i * 4 + 2], d, acc);
+                wp[i] = __fadd_rn(acc, M[i * 4 + 3]);  // fma(t, 1, acc) == acc + t
+            }
+        } else {
+            pixel_to_world(d, fx, fy, K, M, wp);
+        }
+        const bool keep = (hf.vmax[0] > wp[0]) && (wp[0] > hf.vmin[0]) && (hf.vmax[1] > wp[1]) && (wp[1] > hf.vmin[1]) &&
+                          (hf.vmax[2] > wp[2]) && (wp[2] > hf.vmin[2]);
+        if (!keep) return;
+        // kept points are finite: clamp in fp32 (v_med3) then convert
+        const int ix = (int)__builtin_fminf(__builtin_fmaxf(voxel_axis_fast(wp[0], hf.vmin[0], hf.vox[0], hf.inv_vox[0]), 0.0f), hf.gmax);
+        const int iy = (int)__builtin_fminf(__builtin_fmaxf(voxel_axis_fast(wp[1], hf.vmin[1], hf.vox[1], hf.inv_vox[1]), 0.0f), hf.gmax);
+        const int iz = (int)__builtin_fminf(__builtin_fmaxf(voxel_axis_fast(wp[2], hf.vmin[2], hf.vox[2], hf.inv_vox[2]), 0.0f), hf.gmax);
+        const int lin = ix * gg + iy * g + iz;
+        atomicOr(&s_mask[lin >> 5], 1u << (lin & 31));
     };
 
-    if ((hw & 3) == 0) {
+    if ((w & 3) == 0 && hw < (1 << 23)) {
         for (int p = px0 + threadIdx.x * 4; p < px1; p += kHitThreads * 4) {
             const float4 d4 = *reinterpret_cast<const float4 *>(dptr + p);
             const float4 s4 = *reinterpret_cast<const float4 *>(sptr + p);
-            one_pixel(p + 0, d4.x, s4.x);
-            one_pixel(p + 1, d4.y, s4.y);
-            one_pixel(p + 2, d4.z, s4.z);
-            one_pixel(p + 3, d4.w, s4.w);
+            const int y = floor_div_small(p, w, inv_w);  // 4 consecutive pixels share the row (w % 4 == 0)
+            const float fy = (float)y, fx = (float)(p - y * w);
+            one_pixel(fx, fy, d4.x, s4.x);
+            one_pixel(fx + 1.0f, fy, d4.y, s4.y);
+            one_pixel(fx + 2.0f, fy, d4.z, s4.z);
+            one_pixel(fx + 3.0f, fy, d4.w, s4.w);
         }
     } else {
-        for (int p = px0 + threadIdx.x; p < px1; p += kHitThreads) one_pixel(p, dptr[p], sptr[p]);
+        for (int p = px0 + threadIdx.x; p < px1; p += kHitThreads) {
+            const int y = p / w;
+            one_pixel((float)(p - y * w), (float)y, dptr[p], sptr[p]);
+        }
     }
     __syncthreads();
     uint32_t *gm = hit_mask + (size_t)e * words;
@@ -256,83 +326,167 @@ __global__ __launch_bounds__(kHitThreads) void k_hit_mask_global(
 }
 
 // ===========================================================================
-// fused path, launch 2: ray cast (one workgroup per env)
+// fused path, launch 2: ray cast
+//
+// N x S workgroups of 1024 threads.  A workgroup loads its env's hit mask in
+// super-chunks of 8192 words, 8 words per lane, coalesced and all in flight at
+// once (registers, no re-read), numbers the set bits with a block-wide prefix
+// sum, compacts the targets it owns (ray number % S == split) into an LDS queue
+// and walks ONE RAY PER LANE.  The walk is the reference's integer Bresenham
+// (gennbv/utils.py:48-167) with the axes permuted up front, so the loop body is
+// branch-free and carries the linear voxel index incrementally.  Visited voxels
+// are OR-ed into an LDS-resident path mask (ds_or_b32, no return) which is
+// flushed once: plain coalesced stores when S == 1, device-scope atomicOr of the
+// non-zero words otherwise.
+//
+// The `emitted < 3G` cap of the reference can never trigger: a straight line has
+// at most G in-bound voxels because its dominant coordinate is strictly monotone.
+//
+// Measured alternatives (profiles/r01_notes.md): one wave per ray with lane = step
+// via the closed form b_j = b0 + s_b*floor((2 d_b j + d_a)/(2 d_a)) is 10x slower
+// (per-ray setup is replicated over 64 lanes); thread-contiguous word ranges made
+// the mask reads uncoalesced and latency-serialised (141 us of pure overhead).
 // ===========================================================================
 constexpr int kRayThreads = 1024;
 constexpr int kRayWaves = kRayThreads / kWave;
-constexpr int kQueueCap = 8192;  // targets per round (32 KiB of LDS)
+constexpr int kRayWordsPerLane = 8;
+constexpr int kRayChunkWords = kRayThreads * kRayWordsPerLane;
+constexpr int kQueueCap = 4096;  // targets per round (16 KiB of LDS)
+
+template <bool LDS_PATH>
+__device__ __forceinline__ void trace_ray_lane(const int (&src)[3], int lin_t, int g, int gg, uint32_t *s_path, uint32_t *pm)
+{
+    const unsigned ug = (unsigned)g;
+    int tgt[3];
+    tgt[0] = lin_t / gg;
+    const int rem = lin_t - tgt[0] * gg;
+    tgt[1] = rem / g;
+    tgt[2] = rem - tgt[1] * g;
+    const int d0 = abs(tgt[0] - src[0]), d1 = abs(tgt[1] - src[1]), d2 = abs(tgt[2] - src[2]);
+    const int dm = max(max(d0, d1), d2);
+    // dominant axis tested x, y, z (utils.py:69,102,133); minors keep the reference's order
+    const bool ax = dm == d0, ay = !ax && dm == d1;
+    int pa = ax ? src[0] : (ay ? src[1] : src[2]);
+    int pb = ax ? src[1] : src[0];
+    int pc = (ax || ay) ? src[2] : src[1];
+    const int ta = ax ? tgt[0] : (ay ? tgt[1] : tgt[2]), tb = ax ? tgt[1] : tgt[0], tc = (ax || ay) ? tgt[2] : tgt[1];
+    const int da = dm, db = ax ? d1 : d0, dc = (ax || ay) ? d2 : d1;
+    const int st_a = ax ? gg : (ay ? g : 1), st_b = ax ? g : gg, st_c = (ax || ay) ? 1 : g;
+    const int sa = pa < ta ? 1 : -1, sb = pb < tb ? 1 : -1, sc = pc < tc ? 1 : -1;
+    int p1 = 2 * db - da, p2 = 2 * dc - da;
+    int l = pa * st_a + pb * st_b + pc * st_c;
+    const int la = sa * st_a, lb = sb * st_b, lc = sc * st_c;
+    for (int i = 0; i <= da; ++i) {
+        if ((unsigned)pa < ug && (unsigned)pb < ug && (unsigned)pc < ug) {
+            if (LDS_PATH) atomicOr(&s_path[l >> 5], 1u << (l & 31));
+            else atomicOr(&pm[l >> 5], 1u << (l & 31));
+        }
+        const bool ib = p1 >= 0, ic = p2 >= 0;
+        pb += ib ? sb : 0; l += ib ? lb : 0; p1 -= ib ? 2 * da : 0;
+        pc += ic ? sc : 0; l += ic ? lc : 0; p2 -= ic ? 2 * da : 0;
+        pa += sa; l += la;
+        p1 += 2 * db; p2 += 2 * dc;
+    }
+}
 
 template <bool LDS_PATH>
 __global__ __launch_bounds__(kRayThreads) void k_raycast(
     const uint32_t *__restrict__ hit_mask, const float *__restrict__ poses_xyz, int64_t pose_stride,
-    const float *__restrict__ range_gt, const float *__restrict__ voxel_size, int n, int g, int words,
+    const float *__restrict__ range_gt, const float *__restrict__ voxel_size, int n, int g, int words, int splits,
     uint32_t *__restrict__ path_mask)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t *s_queue = smem;                 // kQueueCap
-    int *s_wave = (int *)(smem + kQueueCap);  // kRayWaves + 1
-    uint32_t *s_path = smem + kQueueCap + 32;  // words (LDS_PATH only)
-    const int e = blockIdx.x;
+    uint32_t *s_queue = smem;                      // kQueueCap
+    int *s_wave = (int *)(smem + kQueueCap);       // kRayWaves + 1
+    uint32_t *s_path = smem + kQueueCap + 32;      // words (LDS_PATH only)
+    // block -> (env, split); all splits of env e sit on XCD e % 8 like k_hit_mask's chunks
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int e = (slot / splits) * 8 + xcd;
+    const int sp = slot % splits;
     if (e >= n) return;
     const uint32_t *hm = hit_mask + (size_t)e * words;
     uint32_t *pm = path_mask + (size_t)e * words;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
-
     if (LDS_PATH) for (int i = tid; i < words; i += kRayThreads) s_path[i] = 0u;
-    // (global path mask is zeroed by the host memset when !LDS_PATH)
 
     // source voxel (pose_coord_to_idx_3D, no clamp)
     const float *pp = poses_xyz + (size_t)e * pose_stride;
-    const int sx = pose_axis_to_idx(pp[0], range_gt[e * 6 + 1], voxel_size[e * 3 + 0]);
-    const int sy = pose_axis_to_idx(pp[1], range_gt[e * 6 + 3], voxel_size[e * 3 + 1]);
-    const int sz = pose_axis_to_idx(pp[2], range_gt[e * 6 + 5], voxel_size[e * 3 + 2]);
-
-    // each thread owns words tid, tid + T, ... ; count its targets
-    int cnt = 0;
-    for (int i = tid; i < words; i += kRayThreads) cnt += __popc(hm[i]);
-    const int incl = wave_inclusive_scan(cnt);
-    if (lane == kWave - 1) s_wave[wv] = incl;
-    __syncthreads();
-    if (wv == 0) {
-        int v = lane < kRayWaves ? s_wave[lane] : 0;
-        const int sc = wave_inclusive_scan(v);
-        if (lane < kRayWaves) s_wave[lane] = sc - v;  // exclusive per wave
-        if (lane == kRayWaves - 1) s_wave[kRayWaves] = sc;  // total
-    }
-    __syncthreads();
-    const int my_off = s_wave[wv] + incl - cnt;
-    const int total = s_wave[kRayWaves];
-    const int max_pts = 3 * g;
+    const int src[3] = {pose_axis_to_idx(pp[0], range_gt[e * 6 + 1], voxel_size[e * 3 + 0]),
+                        pose_axis_to_idx(pp[1], range_gt[e * 6 + 3], voxel_size[e * 3 + 1]),
+                        pose_axis_to_idx(pp[2], range_gt[e * 6 + 5], voxel_size[e * 3 + 2])};
     const int gg = g * g;
 
-    for (int base = 0; base < total; base += kQueueCap) {
-        // fill the queue with targets whose global offset falls in [base, base + cap)
-        if (my_off < base + kQueueCap && my_off + cnt > base) {
-            int o = my_off;
-            for (int i = tid; i < words; i += kRayThreads) {
-                uint32_t v = hm[i];
-                while (v) {
-                    const int bit = __ffs(v) - 1;
-                    v &= v - 1;
-                    if (o >= base && o < base + kQueueCap) s_queue[o - base] = (uint32_t)(i * 32 + bit);
-                    ++o;
+    for (int chunk0 = 0; chunk0 < words; chunk0 += kRayChunkWords) {
+        uint32_t wreg[kRayWordsPerLane];
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < kRayWordsPerLane; ++k) {
+            const int wi = chunk0 + k * kRayThreads + tid;
+            wreg[k] = wi < words ? hm[wi] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kRayWordsPerLane; ++k) cnt += __popc(wreg[k]);
+        const int incl = wave_inclusive_scan(cnt);
+        __syncthreads();  // s_wave / s_queue free (previous chunk done), s_path zeroed
+        if (lane == kWave - 1) s_wave[wv] = incl;
+        __syncthreads();
+        if (wv == 0) {
+            int v = lane < kRayWaves ? s_wave[lane] : 0;
+            const int sc = wave_inclusive_scan(v);
+            if (lane < kRayWaves) s_wave[lane] = sc - v;
+            if (lane == kRayWaves - 1) s_wave[kRayWaves] = sc;
+        }
+        __syncthreads();
+        const int my_off = s_wave[wv] + incl - cnt;
+        const int total = s_wave[kRayWaves];
+        // this split traces rays o with o % splits == sp; local index (o - sp) / splits
+        const int my_total = total > sp ? (total - sp + splits - 1) / splits : 0;
+        for (int base = 0; base < my_total; base += kQueueCap) {
+            const int o_lo = base * splits + sp, o_hi = (base + kQueueCap) * splits + sp;
+            if (cnt && my_off < o_hi && my_off + cnt > o_lo) {
+                // ray o is mine iff rel = o - sp >= 0 and rel % splits == 0; its queue slot is
+                // rel / splits - base.  (ph, slot) are advanced incrementally: no division per bit.
+                const int rel0 = my_off - sp;
+                int slot_q = rel0 >= 0 ? rel0 / splits : 0;
+                int ph = rel0 >= 0 ? rel0 - slot_q * splits : rel0;  // < 0: counts up to the first owned ray
+#pragma unroll
+                for (int k = 0; k < kRayWordsPerLane; ++k) {
+                    uint32_t v = wreg[k];
+                    const int wi = chunk0 + k * kRayThreads + tid;
+                    while (v) {
+                        const int bit = __ffs(v) - 1;
+                        v &= v - 1;
+                        if (ph == 0 && slot_q >= base && slot_q < base + kQueueCap) s_queue[slot_q - base] = (uint32_t)(wi * 32 + bit);
+                        ++ph;
+                        if (ph == splits) { ph = 0; ++slot_q; }
+                    }
                 }
             }
+            __syncthreads();
+            const int nq = min(kQueueCap, my_total - base);
+#ifndef RAY_VARIANT
+#define RAY_VARIANT 0
+#endif
+#if RAY_VARIANT != 1
+            for (int q = tid; q < nq; q += kRayThreads)
+                trace_ray_lane<LDS_PATH>(src, (int)s_queue[q], g, gg, s_path, pm);
+#else
+            (void)nq;
+#endif
+            __syncthreads();
         }
-        __syncthreads();
-        const int nq = min(kQueueCap, total - base);
-        for (int q = tid; q < nq; q += kRayThreads) {
-            const int lin = (int)s_queue[q];
-            const int tx = lin / gg, r = lin - tx * gg, ty = r / g, tz = r - ty * g;
-            bresenham_walk(sx, sy, sz, tx, ty, tz, g, max_pts, [&](int x, int y, int z) {
-                const int l = (x * g + y) * g + z;
-                if (LDS_PATH) atomicOr(&s_path[l >> 5], 1u << (l & 31));
-                else atomicOr(&pm[l >> 5], 1u << (l & 31));
-            });
-        }
-        __syncthreads();
     }
-    if (LDS_PATH) for (int i = tid; i < words; i += kRayThreads) pm[i] = s_path[i];
+    if (LDS_PATH) {
+        __syncthreads();
+        if (splits == 1) {
+            for (int i = tid; i < words; i += kRayThreads) pm[i] = s_path[i];
+        } else {
+            for (int i = tid; i < words; i += kRayThreads) {
+                const uint32_t v = s_path[i];
+                if (v) atomicOr(&pm[i], v);
+            }
+        }
+    }
 }
 
 // ===========================================================================
@@ -627,7 +781,6 @@ GNBV_API int gnbv_grid_tri_cls(const float *grid_prob, int64_t count, float thre
     return gnbv_launch_status();
 }
 
-constexpr size_t kMaxLdsBytes = 160 * 1024;
 
 GNBV_API int gnbv_update_occ_grid(const float *depth_raw, const float *seg_raw, const float *c2w, const float *inv_intri,
                                   const float *poses_xyz, int64_t poses_row_stride, const float *range_gt,
@@ -650,10 +803,20 @@ GNBV_API int gnbv_update_occ_grid(const float *depth_raw, const float *seg_raw, 
     const int words = ws.words;
     const size_t mask_bytes = (size_t)words * sizeof(uint32_t);
     const bool lds_hit = mask_bytes <= 64 * 1024;
-    const bool lds_path = mask_bytes + (kQueueCap + 32) * sizeof(uint32_t) <= kMaxLdsBytes;
+    const bool lds_path = mask_bytes + (kQueueCap + 32) * sizeof(uint32_t) <= 64 * 1024;
 
-    // zero: hit masks always; path masks only when rays OR straight into HBM/L2
-    err = (int)hipMemsetAsync(ws.hit, 0, (lds_path ? 1 : 2) * (size_t)n * mask_bytes, st);
+    // ray-cast workgroups per env: ~4 per CU in total, so that an env with many hit voxels
+    // (measured 4x the mean) is spread over several CUs (A/B in profiles/r01_voxel_ab.txt)
+    int splits = (1024 + n - 1) / n;
+    splits = splits < 1 ? 1 : (splits > 8 ? 8 : splits);
+    {
+        static const int forced = [] { const char *v = getenv("GENNBV_RAY_SPLITS"); return v ? atoi(v) : 0; }();
+        if (forced > 0) splits = forced;  // tuning knob (tools/ab_voxel.sh)
+    }
+    // zero the hit masks (OR-accumulated by atomics); the path masks only when they are
+    // OR-accumulated too (several splits, or no LDS staging)
+    const bool path_needs_zero = !lds_path || splits > 1;
+    err = (int)hipMemsetAsync(ws.hit, 0, (path_needs_zero ? 2 : 1) * (size_t)n * mask_bytes, st);
     if (err) return err;
     err = (int)hipMemsetAsync(coverage_count, 0, (size_t)n * sizeof(int32_t), st);
     if (err) return err;
@@ -663,8 +826,13 @@ GNBV_API int gnbv_update_occ_grid(const float *depth_raw, const float *seg_raw, 
     int chunks = (8 * 256 + n - 1) / n;  // aim at >= 8 workgroups per CU-equivalent
     chunks = chunks < 1 ? 1 : (chunks > 16 ? 16 : chunks);
     const int hit_grid = env_groups * 8 * chunks;
-    if (lds_hit) {
-        hipLaunchKernelGGL(k_hit_mask, dim3(hit_grid), dim3(kHitThreads), mask_bytes, st, depth_raw, seg_raw, c2w, K,
+    // inv_intri of a pinhole camera is [[a,0,c],[0,b,d],[0,0,1]]: lets the kernel drop exact-zero terms
+    const bool kfast = K.k[1] == 0.0f && K.k[3] == 0.0f && K.k[6] == 0.0f && K.k[7] == 0.0f && K.k[8] == 1.0f;
+    if (lds_hit && kfast) {
+        hipLaunchKernelGGL(k_hit_mask<true>, dim3(hit_grid), dim3(kHitThreads), mask_bytes, st, depth_raw, seg_raw, c2w, K,
+                           range_gt, voxel_size, n, h, w, g, depth_sense_dist, chunks, words, ws.hit);
+    } else if (lds_hit) {
+        hipLaunchKernelGGL(k_hit_mask<false>, dim3(hit_grid), dim3(kHitThreads), mask_bytes, st, depth_raw, seg_raw, c2w, K,
                            range_gt, voxel_size, n, h, w, g, depth_sense_dist, chunks, words, ws.hit);
     } else {
         hipLaunchKernelGGL(k_hit_mask_global, dim3(hit_grid), dim3(kHitThreads), 0, st, depth_raw, seg_raw, c2w, K,
@@ -673,21 +841,15 @@ GNBV_API int gnbv_update_occ_grid(const float *depth_raw, const float *seg_raw, 
     err = gnbv_launch_status();
     if (err) return err;
 
-    // launch 2: ray cast
+    // launch 2: ray cast, N x splits workgroups (>= ~4 per CU)
+    const int ray_grid = env_groups * 8 * splits;
+    const size_t ray_lds = (kQueueCap + 32) * sizeof(uint32_t);
     if (lds_path) {
-        const size_t lds = (kQueueCap + 32) * sizeof(uint32_t) + mask_bytes;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)k_raycast<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)kMaxLdsBytes);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(k_raycast<true>, dim3(n), dim3(kRayThreads), lds, st, ws.hit, poses_xyz, poses_row_stride,
-                           range_gt, voxel_size, n, g, words, ws.path);
+        hipLaunchKernelGGL(k_raycast<true>, dim3(ray_grid), dim3(kRayThreads), ray_lds + mask_bytes, st, ws.hit, poses_xyz,
+                           poses_row_stride, range_gt, voxel_size, n, g, words, splits, ws.path);
     } else {
-        const size_t lds = (kQueueCap + 32) * sizeof(uint32_t);
-        hipLaunchKernelGGL(k_raycast<false>, dim3(n), dim3(kRayThreads), lds, st, ws.hit, poses_xyz, poses_row_stride,
-                           range_gt, voxel_size, n, g, words, ws.path);
+        hipLaunchKernelGGL(k_raycast<false>, dim3(ray_grid), dim3(kRayThreads), ray_lds, st, ws.hit, poses_xyz,
+                           poses_row_stride, range_gt, voxel_size, n, g, words, splits, ws.path);
     }
     err = gnbv_launch_status();
     if (err) return err;
