@@ -36,9 +36,29 @@ SIGNATURES = {
     "gnbv_update_occ_grid": (_i, [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _i64, _p,
                                   _p, _sz, _p]),
     "gnbv_unpack_masks": (_i, [_p, _i, _i, _p, _p, _p]),
+    "gnbv_env_pre_step": (_i, [_p, _p, _p, _i, _p, _p, _p]),
+    "gnbv_env_obs_state": (_i, [_p, _p, _p, _p, _i, _i, _p, _i64, _p]),
+    "gnbv_env_obs_rgb": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i64, _p]),
+    "gnbv_env_post_step": (_i, [_p, _p]),
     "gnbv_gae_sb3": (_i, [_p, _p, _p, _p, _p, _i, _i, _d, _d, _p, _p, _p]),
     "gnbv_gae_rsl": (_i, [_p, _p, _p, _p, _i, _i, _d, _d, _p, _p, _p]),
 }
+
+
+class GnbvLattice(C.Structure):
+    """include/gennbv_hip.h: GnbvLattice"""
+    _fields_ = [("clip_low", C.c_int64 * 6), ("clip_up", C.c_int64 * 6), ("init_action", C.c_int64 * 6),
+                ("action_unit", C.c_float * 6), ("pose_low", C.c_float * 6), ("init_pose", C.c_float * 6)]
+
+
+class GnbvEnvPost(C.Structure):
+    """include/gennbv_hip.h: GnbvEnvPost"""
+    _fields_ = [("n", _i), ("only_positive", _i), ("max_episode_length", _i64),
+                ("scale_cov", _f), ("scale_short", _f), ("scale_term", _f), ("coverage_threshold", _f),
+                ("coverage_count", _p), ("num_valid_voxel_gt", _p), ("prev_ratio", _p), ("episode_length_buf", _p),
+                ("rewards", _p), ("dones", _p), ("reset_mask", _p), ("step_time_out", _p), ("extras_time_outs", _p),
+                ("coverage_ratio", _p), ("episode_sums", _p), ("cur_reward_sum", _p), ("cur_episode_length", _p),
+                ("ring_reward", _p), ("ring_length", _p), ("ring_state", _p), ("ring_len", _i)]
 
 
 class GennbvHipError(RuntimeError):

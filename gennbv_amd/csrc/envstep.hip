@@ -1,0 +1,230 @@
+// envstep.hip -- per-environment bookkeeping of one Env_Train_GenNBV step on MI355X.
+//
+// Replaces the Python / tiny-torch-op glue around the voxel update:
+//   step()                 gennbv/env/env_train_gennbv.py:246-264  (clip, forced init action, poses)
+//   update_obs_buf         :273-275   (pose / gray-frame history)
+//   compute_reward         gennbv/env/env_train_base.py:377-398, _reward_* env_train_gennbv.py:535-556
+//   check_termination      env_train_gennbv.py:438-457
+//   reset_idx              :377-436   (history refill, counters; grid zeroing is folded into the
+//                                      next gnbv_update_occ_grid through reset_mask)
+//   get_step_return / flatten_observations  :359-366, wrapper :27-56 (obs written in place:
+//                                      [state | grid | state_rgb], row stride = D_obs)
+//   update_extra_episode_info  env_train_base.py:629-639 (episode reward/length ring buffers,
+//                                      kept on the device: no .cpu() per step)
+// None of it is heavy: N x a few hundred floats.  The point is zero host synchronisation
+// and four launches instead of ~60 torch ops + N device->host reads per step.
+#include "common.h"
+#include "../../include/gennbv_hip.h"
+
+// ---------------------------------------------------------------------------
+// pre-step: actions -> clipped actions, poses; episode_length_buf += 1
+// ---------------------------------------------------------------------------
+__global__ void k_env_pre_step(const int64_t *__restrict__ actions_in, GnbvLattice lat, int64_t *__restrict__ episode_length_buf,
+                               int n, int64_t *__restrict__ actions_out, float *__restrict__ poses_out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const bool fresh = episode_length_buf[e] == 0;  // env_train_gennbv.py:249-253
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        int64_t v = actions_in[(size_t)e * 6 + a];
+        v = v < lat.clip_low[a] ? lat.clip_low[a] : (v > lat.clip_up[a] ? lat.clip_up[a] : v);
+        if (fresh) v = lat.init_action[a];
+        actions_out[(size_t)e * 6 + a] = v;
+        // poses = action * action_unit + clip_pose_low (env_train_base.py:665-667): int64 -> fp32, two roundings
+        poses_out[(size_t)e * 6 + a] = __fadd_rn(__fmul_rn((float)v, lat.action_unit[a]), lat.pose_low[a]);
+    }
+    episode_length_buf[e] += 1;  // post_physics_step :337
+}
+
+// ---------------------------------------------------------------------------
+// observation, state slice: pose history shift + append, written to the obs row.
+// One 64-lane workgroup per env; history is [stack, 6] oldest -> newest.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_env_obs_state(float *__restrict__ pose_hist, const float *__restrict__ poses,
+                                                      const uint8_t *__restrict__ reset_mask, GnbvLattice lat, int n, int stack,
+                                                      float *__restrict__ obs, int64_t obs_row_stride)
+{
+    const int e = blockIdx.x;
+    if (e >= n) return;
+    const int len = stack * 6;
+    float *hist = pose_hist + (size_t)e * len;
+    float *out = obs + (size_t)e * obs_row_stride;
+    const bool reset = reset_mask != nullptr && reset_mask[e] != 0;  // reset_idx refilled the deque with init_pose_buf
+    // new[i] = old[i + 6] for i < len - 6 ; new[len-6 .. len) = pose
+    constexpr int kMaxPerLane = 16;  // stack <= 170
+    float reg[kMaxPerLane];
+#pragma unroll
+    for (int k = 0; k < kMaxPerLane; ++k) {
+        const int i = threadIdx.x + k * 64;
+        if (i < len) {
+            const int src = i + 6;
+            reg[k] = src < len ? (reset ? lat.init_pose[src % 6] : hist[src]) : poses[(size_t)e * 6 + (src - len)];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kMaxPerLane; ++k) {
+        const int i = threadIdx.x + k * 64;
+        if (i < len) {
+            hist[i] = reg[k];
+            out[i] = reg[k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// observation, rgb slice: [older gray | newest gray]; newest = nearest-resized,
+// grayscaled RGBA (env_train_base.py:517-520, parity unpinned -- torchvision).
+// ---------------------------------------------------------------------------
+__global__ void k_env_obs_rgb(const uint8_t *__restrict__ rgba, float *__restrict__ gray_prev, const uint8_t *__restrict__ reset_mask,
+                              int n, int h, int w, int oh, int ow, float *__restrict__ obs_rgb, int64_t obs_row_stride)
+{
+    const int per = oh * ow;
+    const int total = n * per;
+    const float sh = (float)h / (float)oh, sw = (float)w / (float)ow;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int e = i / per, r = i - e * per, y = r / ow, x = r - y * ow;
+        int sy = (int)floorf(__fmul_rn((float)y, sh)), sx = (int)floorf(__fmul_rn((float)x, sw));
+        sy = min(sy, h - 1);
+        sx = min(sx, w - 1);
+        const uint8_t *p = rgba + (((size_t)e * h + sy) * w + sx) * 4;
+        float v = __fmul_rn(0.2989f, (float)p[0]);
+        v = __fadd_rn(v, __fmul_rn(0.587f, (float)p[1]));
+        v = __fadd_rn(v, __fmul_rn(0.114f, (float)p[2]));
+        v = (float)(uint8_t)v;
+        const bool reset = reset_mask != nullptr && reset_mask[e] != 0;
+        float *row = obs_rgb + (size_t)e * obs_row_stride;
+        row[r] = reset ? 0.0f : gray_prev[i];
+        row[per + r] = v;
+        gray_prev[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// post-step: rewards, termination, reset bookkeeping, episode statistics.
+// ONE workgroup (cross-env "any reset" + ordered ring-buffer appends need a scan).
+// ---------------------------------------------------------------------------
+constexpr int kPostThreads = 1024;
+
+__global__ __launch_bounds__(kPostThreads) void k_env_post_step(GnbvEnvPost a)
+{
+    __shared__ int s_wave[kPostThreads / kWave + 1];
+    __shared__ int s_any;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    int base_count = 0;  // dones seen in earlier tiles (ring-buffer order = env order)
+    for (int e0 = 0; e0 < a.n; e0 += kPostThreads) {
+        const int e = e0 + tid;
+        const bool live = e < a.n;
+        bool reset = false, time_out = false;
+        float rew = 0.0f, cur_sum = 0.0f, cur_len = 0.0f;
+        if (live) {
+            const int64_t len = a.episode_length_buf[e];
+            // _reward_surface_coverage :535-539 -- count is exact in fp32 (< 2^24)
+            const float ratio = __fdiv_rn((float)a.coverage_count[e], a.num_valid_voxel_gt[e]);
+            const float r_cov = __fmul_rn(__fsub_rn(ratio, a.prev_ratio[e]), a.scale_cov);
+            rew = __fadd_rn(0.0f, r_cov);
+            // _reward_short_path :541-545
+            int64_t extra = len - 30;
+            extra = extra < 0 ? 0 : (extra > 2 ? 2 : extra);
+            const float r_short = __fmul_rn((float)(-extra), a.scale_short);
+            rew = __fadd_rn(rew, r_short);
+            if (a.only_positive) rew = rew < 0.0f ? 0.0f : rew;  // torch.clip(min=0.)
+            // check_termination :438-457 (no contact forces in a replay feed)
+            time_out = len >= a.max_episode_length;
+            reset = time_out || (ratio > a.coverage_threshold);
+            const float r_term = __fmul_rn((reset && !time_out) ? 1.0f : 0.0f, a.scale_term);
+            rew = __fadd_rn(rew, r_term);
+            a.rewards[e] = rew;
+            a.dones[e] = reset ? 1 : 0;
+            a.coverage_ratio[e] = ratio;
+            a.episode_sums[e] = __fadd_rn(a.episode_sums[e], r_cov);
+            a.episode_sums[a.n + e] = __fadd_rn(a.episode_sums[a.n + e], r_short);
+            a.episode_sums[2 * a.n + e] = __fadd_rn(a.episode_sums[2 * a.n + e], r_term);
+            // reset_idx :377-436
+            a.prev_ratio[e] = reset ? 0.0f : ratio;
+            a.reset_mask[e] = reset ? 1 : 0;
+            if (reset) a.episode_length_buf[e] = 0;
+            a.step_time_out[e] = time_out ? 1 : 0;
+            // update_extra_episode_info (env_train_base.py:629-639)
+            cur_sum = __fadd_rn(a.cur_reward_sum[e], rew);
+            cur_len = __fadd_rn(a.cur_episode_length[e], 1.0f);
+            a.cur_reward_sum[e] = reset ? 0.0f : cur_sum;
+            a.cur_episode_length[e] = reset ? 0.0f : cur_len;
+        }
+        // ordered append of finished episodes to the 100-deep ring buffers
+        const int flag = (live && reset) ? 1 : 0;
+        const int incl = wave_inclusive_scan(flag);
+        if (lane == kWave - 1) s_wave[wv] = incl;
+        __syncthreads();
+        if (wv == 0) {
+            int v = lane < kPostThreads / kWave ? s_wave[lane] : 0;
+            const int sc = wave_inclusive_scan(v);
+            if (lane < kPostThreads / kWave) s_wave[lane] = sc - v;
+            if (lane == kPostThreads / kWave - 1) s_wave[kPostThreads / kWave] = sc;
+        }
+        __syncthreads();
+        const int tile_total = s_wave[kPostThreads / kWave];
+        if (flag) {
+            const int64_t pos = a.ring_state[0] + base_count + s_wave[wv] + incl - 1;
+            a.ring_reward[pos % a.ring_len] = cur_sum;
+            a.ring_length[pos % a.ring_len] = cur_len;
+            atomicOr(&s_any, 1);
+        }
+        base_count += tile_total;
+        __syncthreads();
+    }
+    if (tid == 0) a.ring_state[0] += base_count;  // total finished episodes so far
+    // infos["time_outs"]: refreshed only on steps where some env resets (reference quirk,
+    // reset_idx returns early on an empty id list :390-391)
+    const bool any = s_any != 0;
+    for (int e = tid; e < a.n; e += kPostThreads)
+        if (any) a.extras_time_outs[e] = a.step_time_out[e];
+}
+
+// ===========================================================================
+// C-ABI
+// ===========================================================================
+GNBV_API int gnbv_env_pre_step(const int64_t *actions_in, const GnbvLattice *lattice, int64_t *episode_length_buf, int n,
+                               int64_t *actions_out, float *poses_out, void *stream)
+{
+    GNBV_CHECK_ARG(actions_in && lattice && episode_length_buf && actions_out && poses_out && n > 0);
+    hipLaunchKernelGGL(k_env_pre_step, dim3((n + 255) / 256), dim3(256), 0, gnbv_stream(stream), actions_in, *lattice,
+                       episode_length_buf, n, actions_out, poses_out);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_env_obs_state(float *pose_hist, const float *poses, const uint8_t *reset_mask, const GnbvLattice *lattice, int n,
+                                int stack, float *obs, int64_t obs_row_stride, void *stream)
+{
+    GNBV_CHECK_ARG(pose_hist && poses && lattice && obs && n > 0 && stack > 0 && stack * 6 <= 16 * 64);
+    GNBV_CHECK_ARG(obs_row_stride >= (int64_t)stack * 6);
+    hipLaunchKernelGGL(k_env_obs_state, dim3(n), dim3(64), 0, gnbv_stream(stream), pose_hist, poses, reset_mask, *lattice, n,
+                       stack, obs, obs_row_stride);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_env_obs_rgb(const uint8_t *rgba, float *gray_prev, const uint8_t *reset_mask, int n, int h, int w, int oh, int ow,
+                              float *obs_rgb, int64_t obs_row_stride, void *stream)
+{
+    GNBV_CHECK_ARG(rgba && gray_prev && obs_rgb && n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0);
+    GNBV_CHECK_ARG(obs_row_stride >= (int64_t)2 * oh * ow);
+    int grid = (n * oh * ow + 255) / 256;
+    grid = grid > 2048 ? 2048 : grid;
+    hipLaunchKernelGGL(k_env_obs_rgb, dim3(grid), dim3(256), 0, gnbv_stream(stream), rgba, gray_prev, reset_mask, n, h, w, oh, ow,
+                       obs_rgb, obs_row_stride);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_env_post_step(const GnbvEnvPost *args, void *stream)
+{
+    GNBV_CHECK_ARG(args && args->n > 0 && args->ring_len > 0);
+    GNBV_CHECK_ARG(args->coverage_count && args->num_valid_voxel_gt && args->prev_ratio && args->episode_length_buf);
+    GNBV_CHECK_ARG(args->rewards && args->dones && args->reset_mask && args->step_time_out && args->extras_time_outs);
+    GNBV_CHECK_ARG(args->coverage_ratio && args->episode_sums && args->cur_reward_sum && args->cur_episode_length);
+    GNBV_CHECK_ARG(args->ring_reward && args->ring_length && args->ring_state);
+    hipLaunchKernelGGL(k_env_post_step, dim3(1), dim3(kPostThreads), 0, gnbv_stream(stream), *args);
+    return gnbv_launch_status();
+}

@@ -1,0 +1,257 @@
+"""ReplayFeedEnv: Env_Train_GenNBV with Isaac Gym cut at the observation boundary.
+
+The reference env (gennbv/env/env_train_gennbv.py + env_train_base.py) renders
+depth / segmentation / RGB with Isaac Gym and then runs the state encoding.  Here a
+recorded or synthetic feed supplies exactly the tensors the simulator would
+(`depth_raw`, `seg_raw`, `rgba`, camera view matrix), everything after that
+boundary runs on gfx950 kernels through the C-ABI, and the env speaks the
+protocol the reference algorithm expects from `EnvWrapperGenNBVTrain`
+(gennbv/wrapper/env_wrapper_gennbv_train.py:90-133):
+
+    num_envs, device, observation_space (flat Box (D_obs,)), action_space
+    (MultiDiscrete [81,81,51,1,13,13]), episode_length_buf (int64 [N], writable),
+    max_episode_length, seed(), close(),
+    reset() -> obs f32 [N, D_obs]
+    step(actions int64 [N,6]) -> (obs, rewards f32 [N], dones bool [N], infos)
+        infos["time_outs"] bool [N], infos["episode"] dict
+
+The flat observation is written in place by the kernels in the wrapper's key
+order [state | grid | state_rgb]; `step(..., obs_out=rows)` lets the rollout
+buffer hand its own storage to the env (no assemble + copy pass).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..spaces import Box, MultiDiscrete
+from .config import TaskConfig
+from .state_encoding import OccupancyGridUpdater
+from . import synthetic as S
+
+
+@dataclass
+class ReplayFeed:
+    """A pool of recorded frames, resident in HBM: frame f of env e."""
+    depth_raw: torch.Tensor  # [F,N,H,W] f32, Isaac convention (negative metres, -inf = nothing)
+    seg_raw: torch.Tensor  # [F,N,H,W] f32
+    rgba: Optional[torch.Tensor]  # [F,N,H,W,4] u8 or None (gray frames stay zero)
+    c2w: torch.Tensor  # [F,N,4,4] f32: inv(view^T) @ blender2opencv, translation - env_origins
+    cursor: int = 0
+
+    @property
+    def num_frames(self):
+        return self.depth_raw.shape[0]
+
+    def next(self):
+        f = self.cursor % self.num_frames
+        self.cursor += 1
+        return (self.depth_raw[f], self.seg_raw[f], None if self.rgba is None else self.rgba[f], self.c2w[f])
+
+    @staticmethod
+    def from_views(depth_raw, seg_raw, rgba, view, env_origins):
+        """Host plumbing of back_projection_fg (env_train_gennbv.py:512-514) done once for the
+        whole recording: c2w = inv(view^T) @ blender2opencv, translation minus env_origins."""
+        f, n = view.shape[0], view.shape[1]
+        c2w = S.c2w_from_view(view.reshape(f * n, 4, 4), env_origins.repeat(f, 1)).reshape(f, n, 4, 4)
+        return ReplayFeed(depth_raw.contiguous(), seg_raw.contiguous(), None if rgba is None else rgba.contiguous(),
+                          c2w.contiguous())
+
+    @staticmethod
+    def synthetic(scene: S.Scene, cfg: TaskConfig, num_frames: int, seed: int = 1, with_rgba: bool = True):
+        frames = S.make_frames(scene, cfg, num_frames, seed=seed, with_rgba=with_rgba)
+        return ReplayFeed.from_views(torch.stack([f.depth_raw for f in frames]), torch.stack([f.seg_raw for f in frames]),
+                                     torch.stack([f.rgba for f in frames]) if with_rgba else None,
+                                     torch.stack([f.view for f in frames]), scene.env_origins)
+
+
+class ReplayFeedEnv:
+    def __init__(self, cfg: TaskConfig, scene: S.Scene, feed: ReplayFeed, device="cuda:0",
+                 max_episode_length: Optional[int] = None):
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.GennbvHipError("ReplayFeedEnv runs on the GPU only (no CPU fallback)")
+        self.feed = feed
+        n = scene.grid_gt.shape[0]
+        self.num_envs = n
+        self.grid_size = cfg.grid_size
+        self.max_episode_length = int(cfg.max_episode_length if max_episode_length is None else max_episode_length)
+        self.max_episode_length_s = cfg.episode_length_s
+        dev = self.device
+        self.updater = OccupancyGridUpdater(n, cfg.grid_size, cfg.camera_height, cfg.camera_width,
+                                            S.inverse_intrinsics(cfg.camera_height, cfg.camera_width, cfg.horizontal_fov),
+                                            scene.range_gt, scene.voxel_size, scene.grid_gt, dev, cfg.depth_sense_dist)
+        self.num_valid_voxel_gt = scene.num_valid_voxel_gt.to(dev, torch.float32).contiguous()
+        # spaces (update_observation_space :459-492 flattened by the wrapper :59-88)
+        self.action_space = MultiDiscrete(cfg.action_nvec)
+        self.observation_space = Box(-np.inf, np.inf, shape=(cfg.obs_dim,), dtype=np.float32)
+        # lattice constants for the kernels
+        lat = _lib.GnbvLattice()
+        for i in range(6):
+            lat.clip_low[i], lat.clip_up[i] = cfg.clip_pose_idx_low[i], cfg.clip_pose_idx_up[i]
+            lat.init_action[i] = cfg.init_action[i]
+            lat.action_unit[i] = float(np.float32(cfg.action_unit[i]))
+            lat.pose_low[i] = float(np.float32(cfg.clip_pose_low[i]))
+            lat.init_pose[i] = float(np.float32(cfg.init_pose_buf[i]))
+        self._lat = lat
+        # state tensors
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
+        self.episode_length_buf = z(n, dt=torch.int64)
+        self.actions = torch.tensor(cfg.init_action, dtype=torch.int64, device=dev).repeat(n, 1)
+        self.poses = z(n, 6)
+        self.pose_hist = torch.tensor(cfg.init_pose_buf, dtype=torch.float32, device=dev).repeat(n, cfg.stack, 1)
+        self.gray_prev = z(n, cfg.rgb_h * cfg.rgb_w)
+        self.prev_ratio = z(n)
+        self.rew_buf = z(n)
+        self.reset_buf = z(n, dt=torch.uint8)
+        self.reset_mask = torch.ones(n, dtype=torch.uint8, device=dev)
+        self.time_out_buf = z(n, dt=torch.uint8)
+        self.extras_time_outs = z(n, dt=torch.uint8)
+        self.coverage_ratio = z(n)
+        self.episode_sums = z(3, n)
+        self.cur_reward_sum = z(n)
+        self.cur_episode_length = z(n)
+        self.ring_len = 100
+        self.ring_reward = z(self.ring_len)
+        self.ring_length = z(self.ring_len)
+        self.ring_state = z(1, dt=torch.int64)
+        self._zero_rgba = None
+        self._obs = torch.zeros(n, cfg.obs_dim, dtype=torch.float32, device=dev)
+        p = _lib.GnbvEnvPost()
+        p.n, p.only_positive, p.max_episode_length = n, int(cfg.only_positive_rewards), self.max_episode_length
+        # a Python-float scale multiplying an fp32 tensor is rounded to fp32 first
+        p.scale_cov = float(np.float32(cfg.scale_surface_coverage * cfg.dt))
+        p.scale_short = float(np.float32(cfg.scale_short_path * cfg.dt))
+        p.scale_term = float(np.float32(cfg.scale_termination * cfg.dt))
+        p.coverage_threshold = float(np.float32(cfg.coverage_threshold))
+        p.coverage_count = self.updater.coverage_count.data_ptr()
+        p.num_valid_voxel_gt = self.num_valid_voxel_gt.data_ptr()
+        p.prev_ratio = self.prev_ratio.data_ptr()
+        p.rewards, p.dones = self.rew_buf.data_ptr(), self.reset_buf.data_ptr()
+        p.reset_mask, p.step_time_out = self.reset_mask.data_ptr(), self.time_out_buf.data_ptr()
+        p.extras_time_outs, p.coverage_ratio = self.extras_time_outs.data_ptr(), self.coverage_ratio.data_ptr()
+        p.episode_sums, p.cur_reward_sum = self.episode_sums.data_ptr(), self.cur_reward_sum.data_ptr()
+        p.cur_episode_length = self.cur_episode_length.data_ptr()
+        p.ring_reward, p.ring_length = self.ring_reward.data_ptr(), self.ring_length.data_ptr()
+        p.ring_state, p.ring_len = self.ring_state.data_ptr(), self.ring_len
+        self._post = p
+        self.extras = {}
+
+    # reference attribute names for the grids
+    @property
+    def prob_grid(self):
+        return self.updater.prob_grid
+
+    @property
+    def scanned_gt_grid(self):
+        return self.updater.scanned_gt_grid
+
+    @property
+    def grid_gt(self):
+        return self.updater.grid_gt
+
+    def seed(self, seed=None):
+        return [seed]
+
+    def close(self):
+        pass
+
+    # ------------------------------------------------------------------------
+    def _observe_and_finish(self, actions_in: torch.Tensor, obs_out: Optional[torch.Tensor]):
+        cfg, n, lib = self.cfg, self.num_envs, self.lib
+        st = _lib.stream_ptr(self.device)
+        obs = self._obs if obs_out is None else obs_out
+        assert obs.shape == (n, cfg.obs_dim) and obs.dtype == torch.float32 and obs.stride(1) == 1
+        stride = obs.stride(0)
+        depth_raw, seg_raw, rgba, c2w = self.feed.next()
+        # step(): clip, forced init action, poses; episode_length_buf += 1
+        self._post.episode_length_buf = self.episode_length_buf.data_ptr()  # the algorithm may have replaced the tensor
+        _lib.check(lib.gnbv_env_pre_step(actions_in.data_ptr(), C.byref(self._lat), self.episode_length_buf.data_ptr(), n,
+                                         self.actions.data_ptr(), self.poses.data_ptr(), st), "gnbv_env_pre_step")
+        # obs["state"]
+        _lib.check(lib.gnbv_env_obs_state(self.pose_hist.data_ptr(), self.poses.data_ptr(), self.reset_mask.data_ptr(),
+                                          C.byref(self._lat), n, cfg.stack, obs.data_ptr(), stride, st), "gnbv_env_obs_state")
+        # obs["state_rgb"]
+        if rgba is None:
+            if self._zero_rgba is None:
+                self._zero_rgba = torch.zeros(n, cfg.camera_height, cfg.camera_width, 4, dtype=torch.uint8, device=self.device)
+            rgba = self._zero_rgba
+        rgb_off = cfg.state_dim + cfg.grid_dim
+        _lib.check(lib.gnbv_env_obs_rgb(rgba.data_ptr(), self.gray_prev.data_ptr(), self.reset_mask.data_ptr(), n,
+                                        cfg.camera_height, cfg.camera_width, cfg.rgb_h, cfg.rgb_w,
+                                        obs.data_ptr() + 4 * rgb_off, stride, st), "gnbv_env_obs_rgb")
+        # obs["grid"]: tri-class grid straight into the observation rows
+        self.updater.update(depth_raw, seg_raw, c2w, self.poses, reset_mask=self.reset_mask,
+                            tri_out=obs[:, cfg.state_dim:], tri_row_stride=stride)
+        # rewards / termination / reset bookkeeping
+        _lib.check(lib.gnbv_env_post_step(C.byref(self._post), st), "gnbv_env_post_step")
+        return obs
+
+    def reset(self, obs_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Env_Train_GenNBV.reset (:229-244): reset every env, observe at the init pose."""
+        n = self.num_envs
+        self.episode_length_buf.zero_()
+        self.reset_mask.fill_(1)
+        self.prev_ratio.zero_()
+        self.extras_time_outs.zero_()
+        self.gray_prev.zero_()
+        init = torch.tensor(self.cfg.init_action, dtype=torch.int64, device=self.device).repeat(n, 1)
+        return self._observe_and_finish(init, obs_out)
+
+    def step(self, actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None):
+        _lib.require_cuda(actions)
+        a = actions.to(torch.int64).contiguous()
+        obs = self._observe_and_finish(a, obs_out)
+        self.extras["time_outs"] = self.extras_time_outs.bool()
+        self.extras["episode"] = _LazyEpisodeInfo(self)
+        return obs, self.rew_buf, self.reset_buf.bool(), self.extras
+
+    # ------------------------------------------------------------------------
+    def episode_info(self):
+        """extras["episode"] of the reference (reset_idx :424-428, update_extra_episode_info
+        base:629-639), evaluated on demand from device state (the reference pays a .cpu() per step)."""
+        k = int(min(int(self.ring_state.item()), self.ring_len))
+        out = {"episode_reward": float(self.ring_reward[:k].mean()) if k else 0.0,
+               "episode_length": float(self.ring_length[:k].mean()) if k else 0.0}
+        return out
+
+
+class _LazyEpisodeInfo(dict):
+    """Behaves like the reference's extras["episode"] dict but costs nothing unless read."""
+
+    def __init__(self, env):
+        super().__init__()
+        self._env = env
+        self._done = False
+
+    def _fill(self):
+        if not self._done:
+            self._done = True
+            super().update(self._env.episode_info())
+
+    def __getitem__(self, k):
+        self._fill()
+        return super().__getitem__(k)
+
+    def __iter__(self):
+        self._fill()
+        return super().__iter__()
+
+    def keys(self):
+        self._fill()
+        return super().keys()
+
+    def items(self):
+        self._fill()
+        return super().items()
+
+    def get(self, k, d=None):
+        self._fill()
+        return super().get(k, d)

@@ -102,6 +102,65 @@ int gnbv_update_occ_grid(const float *depth_raw, const float *seg_raw, const flo
  * hit / path bitmasks to u8 [N,G^3] (either output may be NULL). */
 int gnbv_unpack_masks(const void *workspace, int n, int g, uint8_t *hit_u8, uint8_t *path_u8, void *stream);
 
+
+/* ------------------------------------------------------------------------- */
+/* A8/A9  environment-step bookkeeping (no simulator: recorded/synthetic feed)  */
+/* ------------------------------------------------------------------------- */
+/* Action lattice of the task (gennbv/env/config_gennbv_train.py:62-69). [host struct] */
+typedef struct GnbvLattice {
+    int64_t clip_low[6], clip_up[6], init_action[6];
+    float action_unit[6], pose_low[6], init_pose[6];
+} GnbvLattice;
+
+/* Env_Train_GenNBV.step head (env_train_gennbv.py:246-255) + post_physics_step's
+ * episode_length_buf += 1 (:337): clip actions, force init_action where
+ * episode_length_buf == 0, poses = action*unit + low. actions int64 [N,6], poses f32 [N,6]. */
+int gnbv_env_pre_step(const int64_t *actions_in, const GnbvLattice *lattice /*[host]*/, int64_t *episode_length_buf,
+                      int n, int64_t *actions_out, float *poses_out, void *stream);
+
+/* update_obs_buf pose deque (:273-275) + obs["state"] (:361): pose_hist [N,stack,6]
+ * oldest->newest is shifted, the new pose appended, and the row is written to
+ * obs + e*obs_row_stride. reset_mask [N] (may be NULL): history was refilled with
+ * init_pose_buf by reset_idx (:397-400). */
+int gnbv_env_obs_state(float *pose_hist, const float *poses, const uint8_t *reset_mask, const GnbvLattice *lattice /*[host]*/,
+                       int n, int stack, float *obs, int64_t obs_row_stride, void *stream);
+
+/* post_process_camera_tensor rgb branch (env_train_base.py:517-520) + rgb deque (k=2)
+ * + obs["state_rgb"] (:363): writes [older | newest] gray frames (2*oh*ow floats) at
+ * obs_rgb + e*obs_row_stride; gray_prev [N,oh*ow] is the persistent older frame. */
+int gnbv_env_obs_rgb(const uint8_t *rgba, float *gray_prev, const uint8_t *reset_mask, int n, int h, int w, int oh, int ow,
+                     float *obs_rgb, int64_t obs_row_stride, void *stream);
+
+/* compute_reward (env_train_base.py:377-398), _reward_* / check_termination /
+ * reset_idx (env_train_gennbv.py:377-457,535-556), update_extra_episode_info
+ * (env_train_base.py:629-639). All pointers device, arrays [N] unless noted. [host struct] */
+typedef struct GnbvEnvPost {
+    int n;
+    int only_positive;              /* cfg.rewards.only_positive_rewards */
+    int64_t max_episode_length;
+    float scale_cov, scale_short, scale_term; /* reward scales * dt, rounded to fp32 */
+    float coverage_threshold;       /* 0.99 */
+    const int32_t *coverage_count;  /* from gnbv_update_occ_grid */
+    const float *num_valid_voxel_gt;
+    float *prev_ratio;              /* in/out: reward_ratio_buf[-1] */
+    int64_t *episode_length_buf;    /* in/out */
+    float *rewards;                 /* out */
+    uint8_t *dones;                 /* out: reset_buf */
+    uint8_t *reset_mask;            /* out: envs whose grids/history reset before the next step */
+    uint8_t *step_time_out;         /* out: time_out_buf of this step */
+    uint8_t *extras_time_outs;      /* in/out: infos["time_outs"] (refreshed only if any env reset) */
+    float *coverage_ratio;          /* out */
+    float *episode_sums;            /* in/out [3,N]: surface_coverage, short_path, termination */
+    float *cur_reward_sum;          /* in/out */
+    float *cur_episode_length;      /* in/out */
+    float *ring_reward;             /* in/out [ring_len]: rewbuffer (deque maxlen 100) */
+    float *ring_length;             /* in/out [ring_len]: lenbuffer */
+    int64_t *ring_state;            /* in/out [1]: episodes finished so far */
+    int ring_len;
+} GnbvEnvPost;
+
+int gnbv_env_post_step(const GnbvEnvPost *args /*[host]*/, void *stream);
+
 /* ------------------------------------------------------------------------- */
 /* C2  TensorRolloutBuffer_Grid_Obs.compute_returns_and_advantage               */
 /*     stable_baselines3/common/buffers.py:706-724.  All arrays [T,N] (the      */

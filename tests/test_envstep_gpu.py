@@ -1,0 +1,92 @@
+"""GPU: ReplayFeedEnv (HIP env-step kernels) vs the reference env goldens and the oracle env."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as gu
+from gennbv_amd.env import synthetic as S
+from gennbv_amd.env.config import TaskConfig
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def make_env_from_fixture(fx):
+    from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
+    n, h, w, g = int(fx["n"]), int(fx["h"]), int(fx["w"]), int(fx["g"])
+    cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
+    d, seg = gu.frames(fx)
+    gt = torch.from_numpy(gu.unpack_bits(fx["grid_gt_bits"], g))
+    scene = S.Scene(None, None, gt, torch.from_numpy(fx["range_gt"]), torch.from_numpy(fx["voxel_size"]),
+                    torch.from_numpy(fx["num_valid_voxel_gt"]), torch.from_numpy(fx["env_origins"]))
+    feed = ReplayFeed.from_views(torch.from_numpy(d), torch.from_numpy(seg), torch.from_numpy(fx["rgba"]),
+                                 torch.from_numpy(fx["view"]), scene.env_origins)
+    feed = ReplayFeed(feed.depth_raw.to(DEV), feed.seg_raw.to(DEV), feed.rgba.to(DEV), feed.c2w.to(DEV))
+    env = ReplayFeedEnv(cfg, scene, feed, DEV, max_episode_length=int(fx["max_episode_length"]))
+    return env, cfg
+
+
+@pytest.mark.parametrize("name", ["F5_envstep_g20", "F5_envstep_c0", "F5_envstep_g64"])
+def test_replay_env_matches_reference_env_bit_exact(name):
+    if not os.path.exists(os.path.join(gu.GOLDEN, name + ".npz")):
+        pytest.skip("fixture not generated")
+    fx = gu.load(name)
+    env, cfg = make_env_from_fixture(fx)
+    nf = int(fx["num_frames"])
+    env.feed.cursor = 0
+    obs = env.reset()
+    assert sha(obs.cpu().numpy()) == str(fx["reset_flat_obs_sha"])
+    assert env.prob_grid.cpu().numpy().tobytes() == fx["reset_prob"].tobytes()
+    env.episode_length_buf.copy_(torch.from_numpy(fx["init_episode_length"].astype(np.int64)))
+    for s in range(int(fx["num_steps"])):
+        fi = (s + 1) % nf
+        env.feed.cursor = fi
+        obs, rew, done, info = env.step(torch.from_numpy(fx["actions"][fi]).to(DEV))
+        assert rew.cpu().numpy().tobytes() == fx["rewards"][s].tobytes(), f"step {s}"
+        assert np.array_equal(done.cpu().numpy(), fx["dones"][s].astype(bool)), f"step {s}"
+        assert np.array_equal(info["time_outs"].cpu().numpy(), fx["time_outs"][s]), f"step {s}"
+        # the fixture read reward_ratio_buf[-1] after reset_idx had zeroed the reset envs' entries
+        assert env.prev_ratio.cpu().numpy().tobytes() == fx["coverage"][s].tobytes()
+        assert sha(obs.cpu().numpy()) == str(fx["flat_obs_sha"][s]), f"step {s} flat obs"
+        assert sha(env.prob_grid.cpu().numpy()) == str(fx["prob_sha"][s])
+        assert sha(env.scanned_gt_grid.cpu().numpy()) == str(fx["scan_sha"][s])
+
+
+def test_replay_env_writes_into_caller_rows_and_tracks_episodes():
+    """obs_out = rows of a larger buffer (rollout-buffer hand-off); ring-buffer episode stats
+    equal a host recomputation in env order (update_extra_episode_info)."""
+    from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
+    n, h, w, g = 6, 48, 64, 16
+    cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
+    scene = S.make_scenes(n, g, seed=2)
+    feed = ReplayFeed.synthetic(scene, cfg, 3, seed=2)
+    feed = ReplayFeed(feed.depth_raw.to(DEV), feed.seg_raw.to(DEV), feed.rgba.to(DEV), feed.c2w.to(DEV))
+    env = ReplayFeedEnv(cfg, scene, feed, DEV, max_episode_length=4)
+    buf = torch.full((9, n, cfg.obs_dim), float("nan"), device=DEV)
+    env.reset(obs_out=buf[0])
+    env.episode_length_buf.copy_(torch.tensor([0, 1, 2, 3, 0, 2], device=DEV))
+    g_ = torch.Generator().manual_seed(0)
+    rew_host, len_host = [], []
+    cur_r, cur_l = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    for t in range(8):
+        a = S.sample_actions(n, cfg, g_).to(DEV)
+        obs, rew, done, info = env.step(a, obs_out=buf[t + 1])
+        assert obs.data_ptr() == buf[t + 1].data_ptr()
+        r, d = rew.cpu().numpy(), done.cpu().numpy()
+        cur_r += r; cur_l += 1
+        for e in range(n):
+            if d[e]:
+                rew_host.append(cur_r[e]); len_host.append(cur_l[e]); cur_r[e] = 0; cur_l[e] = 0
+    assert not bool(torch.isnan(buf).any())
+    ei = env.episode_info()
+    assert len(rew_host) > 4
+    np.testing.assert_allclose(ei["episode_reward"], np.mean(rew_host[-100:]), rtol=1e-6)
+    np.testing.assert_allclose(ei["episode_length"], np.mean(len_host[-100:]), rtol=1e-6)
+    assert int(env.ring_state.item()) == len(rew_host)
