@@ -74,7 +74,8 @@ def test_replay_env_writes_into_caller_rows_and_tracks_episodes():
     env.episode_length_buf.copy_(torch.tensor([0, 1, 2, 3, 0, 2], device=DEV))
     g_ = torch.Generator().manual_seed(0)
     rew_host, len_host = [], []
-    cur_r, cur_l = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    # reset() itself runs get_step_return -> update_extra_episode_info (reference :229-244,:346-375)
+    cur_r, cur_l = env.rew_buf.cpu().numpy().copy(), np.ones(n, np.float32)
     for t in range(8):
         a = S.sample_actions(n, cfg, g_).to(DEV)
         obs, rew, done, info = env.step(a, obs_out=buf[t + 1])
