@@ -1,0 +1,131 @@
+"""TensorRolloutBuffer_Grid_Obs (stable_baselines3/common/buffers.py:628-762).
+
+Same public surface (`reset`, `add`, `compute_returns_and_advantage`, `get`,
+`.observations/.actions/.rewards/.values/.log_probs/.returns/.advantages/
+.episode_starts`, `.indices`), redesigned for 288 GB of HBM:
+
+  * allocated ONCE ([T+1, N, D_obs] fp32 observations; the reference re-allocates and
+    zero-fills the whole buffer every rollout, :655-674); row t+1 can be handed to the
+    env as the destination of its next observation (`next_obs_row`), so `add()` does
+    not copy observations at all;
+  * the GAE scan is one gfx950 kernel (gennbv_amd/csrc/gae.hip) instead of T x 8 launches;
+  * `get()` does not materialise the swapped [N*T, D_obs] copy (:56-69,:739-740): a
+    minibatch index i maps to (env n = i // T, step t = i % T) -- the same row the
+    reference's swap_and_flatten puts at position i -- and rows are gathered from the
+    [T, N] layout directly;
+  * `indices = np.random.permutation(T*N)` is drawn in `reset()` from numpy's global RNG
+    and reused by every epoch, exactly like the reference (:673, :749-751).
+"""
+from __future__ import annotations
+
+from typing import Generator, NamedTuple, Optional
+
+import numpy as np
+import torch
+
+from .. import gae as gae_ops
+
+
+class RolloutBufferSamples(NamedTuple):
+    observations: torch.Tensor
+    actions: torch.Tensor
+    old_values: torch.Tensor
+    old_log_prob: torch.Tensor
+    advantages: torch.Tensor
+    returns: torch.Tensor
+
+
+class TensorRolloutBuffer_Grid_Obs:
+    def __init__(self, buffer_size: int, observation_space, action_space, device="cpu", gae_lambda: float = 1,
+                 gamma: float = 0.99, n_envs: int = 1):
+        self.buffer_size, self.n_envs = int(buffer_size), int(n_envs)
+        self.num_transitions_per_env, self.num_envs = self.buffer_size, self.n_envs
+        self.observation_space, self.action_space = observation_space, action_space
+        self.obs_shape = tuple(observation_space.shape)
+        self.actions_shape = action_space.shape[0]
+        self.device = torch.device(device)
+        self.gae_lambda, self.gamma = gae_lambda, gamma
+        t, n, dev = self.buffer_size, self.n_envs, self.device
+        self.observations = torch.zeros(t + 1, n, *self.obs_shape, device=dev)
+        self.rewards = torch.zeros(t, n, 1, device=dev)
+        self.actions = torch.zeros(t, n, self.actions_shape, device=dev)
+        self.episode_starts = torch.zeros(t, n, 1, device=dev, dtype=torch.uint8)
+        self.log_probs = torch.zeros(t, n, 1, device=dev)
+        self.values = torch.zeros(t, n, 1, device=dev)
+        self.returns = torch.zeros(t, n, 1, device=dev)
+        self.advantages = torch.zeros(t, n, 1, device=dev)
+        self.privileged_observations = None
+        self.reset()
+
+    def reset(self) -> None:
+        if getattr(self, "step", 0) == self.buffer_size:
+            # the observation that followed the last transition opens the next rollout
+            self.observations[0].copy_(self.observations[self.buffer_size])
+        self.step = 0
+        self.pos = 0
+        self.full = False
+        self.generator_ready = False
+        self.indices = np.random.permutation(self.buffer_size * self.n_envs)
+        self._indices_dev = None
+
+    def next_obs_row(self) -> torch.Tensor:
+        """Storage of the observation that will be `add()`ed at the NEXT step."""
+        return self.observations[self.step + 1]
+
+    def first_obs_row(self) -> torch.Tensor:
+        return self.observations[0]
+
+    def add(self, obs, action, reward, episode_start, value, log_prob) -> None:
+        if isinstance(episode_start, np.ndarray):
+            episode_start = torch.from_numpy(episode_start).to(self.device)
+        if self.step >= self.num_transitions_per_env:
+            raise AssertionError("Rollout buffer overflow")
+        if type(obs) is tuple:
+            obs = obs[0]
+        row = self.observations[self.step]
+        if obs.data_ptr() != row.data_ptr():
+            row.copy_(obs)
+        self.actions[self.step].copy_(action)
+        self.rewards[self.step].copy_(reward.view(-1, 1))
+        self.episode_starts[self.step].copy_(episode_start.view(-1, 1))
+        self.values[self.step].copy_(value)
+        self.log_probs[self.step].copy_(log_prob.view(-1, 1))
+        self.step += 1
+        self.pos += 1
+        if self.pos == self.buffer_size:
+            self.full = True
+
+    def compute_returns_and_advantage(self, last_values: torch.Tensor, dones) -> None:
+        gae_ops.compute_returns_and_advantage(self.rewards, self.values, self.episode_starts, last_values.detach(), dones,
+                                              self.gamma, self.gae_lambda, advantages=self.advantages, returns=self.returns)
+
+    # ---- minibatches -----------------------------------------------------------
+    def rows_of(self, batch_inds: torch.Tensor):
+        """flat index i (reference order n*T + t) -> row index t*N + n of the [T, N] layout."""
+        t_steps, n = self.buffer_size, self.n_envs
+        env = torch.div(batch_inds, t_steps, rounding_mode="floor")
+        return (batch_inds - env * t_steps) * n + env
+
+    def get(self, batch_size: Optional[int] = None) -> Generator[RolloutBufferSamples, None, None]:
+        assert self.step == self.num_transitions_per_env, ""
+        total = self.buffer_size * self.n_envs
+        if self._indices_dev is None:
+            self._indices_dev = torch.from_numpy(np.asarray(self.indices, dtype=np.int64)).to(self.device)
+        if batch_size is None:
+            batch_size = total
+        start_idx = 0
+        while start_idx < total:
+            yield self._get_samples(self._indices_dev[int(start_idx):int(start_idx) + int(batch_size)])
+            start_idx += batch_size
+
+    def _get_samples(self, batch_inds: torch.Tensor) -> RolloutBufferSamples:
+        rows = self.rows_of(batch_inds)
+        t, n = self.buffer_size, self.n_envs
+        flat = lambda x: x.view(x.shape[0] * n, *x.shape[2:])  # noqa: E731
+        return RolloutBufferSamples(
+            flat(self.observations[:t])[rows], flat(self.actions)[rows], flat(self.values)[rows].flatten(),
+            flat(self.log_probs)[rows].flatten(), flat(self.advantages)[rows].flatten(), flat(self.returns)[rows].flatten())
+
+    def flat_values_returns(self):
+        """values / returns in the reference's flattened (n*T + t) order, for explained variance."""
+        return (self.values.squeeze(-1).transpose(0, 1).reshape(-1), self.returns.squeeze(-1).transpose(0, 1).reshape(-1))

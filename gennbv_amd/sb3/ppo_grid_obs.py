@@ -1,0 +1,323 @@
+"""PPO_Grid_Obs: the GenNBV PPO (stable_baselines3/ppo/ppo_grid_obs.py:75-322) with its
+on-policy loop (stable_baselines3/common/on_policy_algorithm_grid_obs.py:102-298) and the
+pieces of the algorithm base it needs (base_class_grid_obs.py:408-477, :600-614).
+
+Same constructor signature, `.train()`, `.learn()`, `.collect_rollouts()` contracts and the
+exact loss of the reference:
+
+    adv   = (A - mean) / (std_unbiased + 1e-8)            per minibatch          (:214-216)
+    ratio = exp(logp - logp_old); pg = -mean(min(adv*ratio, adv*clamp(ratio, 1-c, 1+c)))
+    v_pred = v_old + clamp(v - v_old, -c_vf, c_vf); vl = mse(returns, v_pred)  (:231-241)
+    loss  = 10*pg + ent_coef*(-mean(entropy)) + vf_coef*vl                       (:253)
+    approx_kl = mean(exp(lr) - 1 - lr); stop when > 1.5*target_kl (before the step) (:259-268)
+    clip_grad_norm_(max_grad_norm); Adam(eps=1e-5)                                (:271-275)
+
+MI355X-first differences (all observationally equivalent, DESIGN.md section "PPO"):
+  * collect_rollouts evaluates the policy ONCE per env step: the reference computes
+    V(new_obs) for the time-out bootstrap (:205-208) and then, at the next step, runs the
+    full policy on the very same observation with the very same (eval-mode) parameters
+    (:168); both values come from one forward here. RNG consumption order is unchanged.
+  * the env writes each observation straight into the rollout buffer row it will be
+    stored in (`step(..., obs_out=...)`), the GAE scan is one kernel, the buffer is
+    allocated once;
+  * logging scalars are accumulated on the device and read back once per train() call
+    instead of five host syncs per minibatch; the KL early-stop decision is the only
+    per-minibatch read (and can be polled per epoch with `kl_poll="epoch"`, which masks
+    the updates after the stopping minibatch on the device).
+"""
+from __future__ import annotations
+
+import time
+from typing import Any, Dict, Optional, Union
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .buffers import TensorRolloutBuffer_Grid_Obs
+from .logger import Logger
+
+
+def _schedule(v):
+    if isinstance(v, (float, int)):
+        val = float(v)
+        return lambda _: val
+    assert callable(v)
+    return v
+
+
+class PPO_Grid_Obs:
+    def __init__(self, policy, env, learning_rate=3e-4, n_steps: int = 2048, batch_size: int = 64, n_epochs: int = 10,
+                 gamma: float = 0.99, gae_lambda: float = 0.95, clip_range=0.2, clip_range_vf=None,
+                 normalize_advantage: bool = True, ent_coef: float = 0.0, vf_coef: float = 0.5, max_grad_norm: float = 0.5,
+                 use_sde: bool = False, sde_sample_freq: int = -1, target_kl: Optional[float] = None,
+                 tensorboard_log: Optional[str] = None, create_eval_env: bool = False,
+                 policy_kwargs: Optional[Dict[str, Any]] = None, verbose: int = 0, seed: Optional[int] = None,
+                 device: Union[torch.device, str] = "auto", _init_setup_model: bool = True):
+        assert not use_sde, "gSDE is not on the GenNBV path"
+        if normalize_advantage:
+            assert batch_size > 1, "`batch_size` must be greater than 1. See https://github.com/DLR-RM/stable-baselines3/issues/440"
+        self.policy_class, self.env = policy, env
+        self.policy_kwargs = {} if policy_kwargs is None else policy_kwargs
+        self.learning_rate, self.n_steps, self.batch_size, self.n_epochs = learning_rate, n_steps, batch_size, n_epochs
+        self.gamma, self.gae_lambda = gamma, gae_lambda
+        self.clip_range, self.clip_range_vf = clip_range, clip_range_vf
+        self.normalize_advantage, self.ent_coef, self.vf_coef = normalize_advantage, ent_coef, vf_coef
+        self.max_grad_norm, self.target_kl = max_grad_norm, target_kl
+        self.verbose, self.seed = verbose, seed
+        if device == "auto":
+            device = getattr(env, "device", "cuda" if torch.cuda.is_available() else "cpu")
+        self.device = torch.device(device)
+        self.observation_space, self.action_space = env.observation_space, env.action_space
+        self.n_envs = env.num_envs
+        if self.env is not None:
+            buffer_size = self.n_envs * self.n_steps
+            assert buffer_size > 1
+        self.num_timesteps = 0
+        self._n_updates = 0
+        self._current_progress_remaining = 1.0
+        self._last_obs = None
+        self._last_episode_starts = None
+        self._pending = None  # (actions, values, log_probs) already evaluated on _last_obs
+        self.ep_info_buffer = None
+        self._logger = Logger(verbose)
+        self.policy_loss_scale = 10.0  # ppo_grid_obs.py:253
+        self.kl_poll = "minibatch"
+        if _init_setup_model:
+            self._setup_model()
+
+    # ------------------------------------------------------------------------------
+    @property
+    def logger(self):
+        return self._logger
+
+    def set_random_seed(self, seed: Optional[int] = None) -> None:
+        """base_class_grid_obs.py:600-614 / common/utils.py:25-42."""
+        if seed is None:
+            return
+        import random
+        random.seed(seed)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        self.action_space_seed = seed
+        if self.env is not None:
+            self.env.seed(seed)
+
+    def _setup_model(self) -> None:
+        self.lr_schedule = _schedule(self.learning_rate)
+        self.set_random_seed(self.seed)
+        self.rollout_buffer = TensorRolloutBuffer_Grid_Obs(self.n_steps, self.observation_space, self.action_space,
+                                                           device=self.device, gamma=self.gamma,
+                                                           gae_lambda=self.gae_lambda, n_envs=self.n_envs)
+        self.policy = self.policy_class(self.observation_space, self.action_space, self.lr_schedule, use_sde=False,
+                                        **self.policy_kwargs).to(self.device)
+        self.clip_range = _schedule(self.clip_range)
+        if self.clip_range_vf is not None:
+            if isinstance(self.clip_range_vf, (float, int)):
+                assert self.clip_range_vf > 0, "`clip_range_vf` must be positive, pass `None` to deactivate vf clipping"
+            self.clip_range_vf = _schedule(self.clip_range_vf)
+
+    def _update_learning_rate(self, optimizer) -> None:
+        lr = self.lr_schedule(self._current_progress_remaining)
+        self.logger.record("train/learning_rate", lr)
+        for group in optimizer.param_groups:
+            group["lr"] = lr
+
+    # ------------------------------------------------------------------------------
+    def train(self) -> None:
+        """Update the policy on the gathered rollout buffer (ppo_grid_obs.py:176-297)."""
+        training_start = time.time()
+        self.policy.set_training_mode(True)
+        self._update_learning_rate(self.policy.optimizer)
+        clip_range = self.clip_range(self._current_progress_remaining)
+        clip_range_vf = None if self.clip_range_vf is None else self.clip_range_vf(self._current_progress_remaining)
+        stats = []  # per minibatch: [pg, vl, ent, kl, clip_fraction, loss] on the device
+        kl_per_epoch = []
+        continue_training = True
+        for epoch in range(self.n_epochs):
+            epoch_kl = []
+            for rollout_data in self.rollout_buffer.get(self.batch_size):
+                actions = rollout_data.actions
+                values, log_prob, entropy = self.policy.evaluate_actions(rollout_data.observations, actions)
+                values = values.flatten()
+                advantages = rollout_data.advantages
+                if self.normalize_advantage:
+                    advantages = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
+                ratio = torch.exp(log_prob - rollout_data.old_log_prob)
+                policy_loss_1 = advantages * ratio
+                policy_loss_2 = advantages * torch.clamp(ratio, 1 - clip_range, 1 + clip_range)
+                policy_loss = -torch.min(policy_loss_1, policy_loss_2).mean()
+                clip_fraction = torch.mean((torch.abs(ratio - 1) > clip_range).float())
+                if clip_range_vf is None:
+                    values_pred = values
+                else:
+                    values_pred = rollout_data.old_values + torch.clamp(values - rollout_data.old_values, -clip_range_vf,
+                                                                        clip_range_vf)
+                value_loss = F.mse_loss(rollout_data.returns, values_pred)
+                entropy_loss = -torch.mean(entropy)
+                loss = policy_loss * self.policy_loss_scale + self.ent_coef * entropy_loss + self.vf_coef * value_loss
+                with torch.no_grad():
+                    log_ratio = log_prob - rollout_data.old_log_prob
+                    approx_kl_div = torch.mean((torch.exp(log_ratio) - 1) - log_ratio)
+                stats.append(torch.stack([policy_loss.detach(), value_loss.detach(), entropy_loss.detach(), approx_kl_div,
+                                          clip_fraction, loss.detach()]))
+                epoch_kl.append(len(stats) - 1)
+                if self.target_kl is not None and float(approx_kl_div) > 1.5 * self.target_kl:
+                    continue_training = False
+                    if self.verbose >= 1:
+                        print(f"Early stopping at step {epoch} due to reaching max kl: {float(approx_kl_div):.2f}")
+                    break
+                self.policy.optimizer.zero_grad()
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
+                self.policy.optimizer.step()
+            kl_per_epoch.append(epoch_kl)
+            if not continue_training:
+                break
+        self._n_updates += self.n_epochs
+        s = torch.stack(stats).double().cpu().numpy()  # ONE read-back for all logging scalars
+        self.last_train_stats = s
+        v_flat, r_flat = self.rollout_buffer.flat_values_returns()
+        var_y = torch.var(r_flat, unbiased=False)
+        explained_var = float("nan") if float(var_y) == 0 else float(1 - torch.var(r_flat - v_flat, unbiased=False) / var_y)
+        self.logger.record("train/entropy_loss", float(np.mean(s[:, 2])))
+        self.logger.record("train/policy_gradient_loss", float(np.mean(s[:, 0])))
+        self.logger.record("train/value_loss", float(np.mean(s[:, 1])))
+        self.logger.record("train/approx_kl", float(np.mean(s[kl_per_epoch[-1], 3])))  # last epoch's list (:241)
+        self.logger.record("train/clip_fraction", float(np.mean(s[:, 4])))
+        self.logger.record("train/loss", float(s[-1, 5]))
+        self.logger.record("train/explained_variance", explained_var)
+        self.logger.record("train/n_updates", self._n_updates)
+        self.logger.record("train/clip_range", clip_range)
+        if clip_range_vf is not None:
+            self.logger.record("train/clip_range_vf", clip_range_vf)
+        self.logger.record("time/training", time.time() - training_start)
+
+    # ------------------------------------------------------------------------------
+    def _env_step(self, actions, obs_out):
+        try:
+            return self.env.step(actions, obs_out=obs_out)
+        except TypeError:
+            return self.env.step(actions)
+
+    def collect_rollouts(self, env, callback, rollout_buffer, n_rollout_steps: int) -> bool:
+        """on_policy_algorithm_grid_obs.py:128-221 (tensor-env branch)."""
+        assert self._last_obs is not None, "No previous observation was provided"
+        self.policy.set_training_mode(False)
+        n_steps = 0
+        rollout_buffer.reset()
+        first = rollout_buffer.first_obs_row()
+        if self._last_obs.data_ptr() != first.data_ptr():
+            first.copy_(self._last_obs)
+            self._last_obs = first
+        if callback is not None:
+            callback.on_rollout_start()
+        dones = None
+        new_obs = None
+        while n_steps < n_rollout_steps:
+            with torch.no_grad():
+                if self._pending is None:
+                    actions, values, log_probs = self.policy(self._last_obs)
+                else:
+                    actions, values, log_probs = self._pending
+            new_obs, rewards, dones, infos = self._env_step(actions, rollout_buffer.next_obs_row())
+            self.num_timesteps += env.num_envs
+            if callback is not None:
+                callback.update_locals(locals())
+                if callback.on_step() is False:
+                    return False
+            self._update_info_buffer(infos)
+            n_steps += 1
+            with torch.no_grad():
+                # ONE policy evaluation of new_obs: its value is the time-out bootstrap of this
+                # step (:205-208) and its action / value / log-prob are next step's (:168).
+                # The last step only needs the value (:213-215) and must not draw from the RNG.
+                if n_steps < n_rollout_steps:
+                    nxt = self.policy(new_obs)
+                    terminal_value = nxt[1]
+                else:
+                    nxt = None
+                    terminal_value = self.policy.predict_values(new_obs)
+            rewards = rewards + self.gamma * torch.squeeze(terminal_value * infos["time_outs"].unsqueeze(1).to(self.device), 1)
+            rollout_buffer.add(self._last_obs, actions, rewards, self._last_episode_starts, values, log_probs)
+            self._last_obs = new_obs
+            self._last_episode_starts = dones
+            self._pending = nxt
+        last_values = terminal_value  # V(new_obs) of the last step (:213-215)
+        rollout_buffer.compute_returns_and_advantage(last_values=last_values, dones=dones)
+        if callback is not None:
+            callback.on_rollout_end()
+        return True
+
+    def _update_info_buffer(self, infos) -> None:
+        if self.ep_info_buffer is not None:
+            self.ep_info_buffer.append(infos.get("episode"))
+
+    def _setup_learn(self, total_timesteps: int, reset_num_timesteps: bool = True):
+        """base_class_grid_obs.py:408-477."""
+        from collections import deque
+        self.start_time = time.time()
+        if self.ep_info_buffer is None or reset_num_timesteps:
+            self.ep_info_buffer = deque(maxlen=100)
+        if reset_num_timesteps:
+            self.num_timesteps = 0
+        else:
+            total_timesteps += self.num_timesteps
+        self._total_timesteps = total_timesteps
+        if reset_num_timesteps or self._last_obs is None:
+            try:
+                self._last_obs = self.env.reset(obs_out=self.rollout_buffer.first_obs_row())
+            except TypeError:
+                self._last_obs = self.env.reset()
+            self._last_episode_starts = torch.ones(self.env.num_envs, dtype=torch.bool, device=self.device)
+            self._pending = None
+        # "keep same with PPO from RSL-rl" (:470-475): de-synchronise the episodes
+        elb = self.env.episode_length_buf
+        self.env.episode_length_buf = torch.randint_like(elb, high=int(self.env.max_episode_length))
+        return total_timesteps
+
+    def _update_current_progress_remaining(self, num_timesteps: int, total_timesteps: int) -> None:
+        self._current_progress_remaining = 1.0 - float(num_timesteps) / float(total_timesteps)
+
+    def learn(self, total_timesteps: int, callback=None, log_interval: int = 1, eval_env=None, eval_freq: int = -1,
+              n_eval_episodes: int = 5, tb_log_name: str = "PPO", eval_log_path: Optional[str] = None,
+              reset_num_timesteps: bool = True) -> "PPO_Grid_Obs":
+        """on_policy_algorithm_grid_obs.py:230-298."""
+        iteration = 0
+        total_timesteps = self._setup_learn(total_timesteps, reset_num_timesteps)
+        if callback is not None:
+            callback.on_training_start(locals(), globals())
+        while self.num_timesteps < total_timesteps:
+            collect_start_time = time.time()
+            continue_training = self.collect_rollouts(self.env, callback, self.rollout_buffer, n_rollout_steps=self.n_steps)
+            if continue_training is False:
+                break
+            iteration += 1
+            self._update_current_progress_remaining(self.num_timesteps, total_timesteps)
+            if log_interval is not None and iteration % log_interval == 0:
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize(self.device)
+                time_to_collect = time.time() - collect_start_time
+                fps = int(self.rollout_buffer.buffer_size * self.rollout_buffer.n_envs / max(time_to_collect, 1e-9))
+                self.logger.record("time/iterations", iteration)
+                if len(self.ep_info_buffer) > 0 and self.ep_info_buffer[-1] is not None:
+                    for key, val in dict(self.ep_info_buffer[-1].items()).items():
+                        self.logger.record("rollout/{}".format(key), float(val))
+                self.logger.record("time/fps", fps)
+                self.logger.record("time/time_elapsed", int(time.time() - self.start_time))
+                self.logger.record("time/total_timesteps", self.num_timesteps)
+                self.logger.record("time/rollout", time_to_collect)
+                self.logger.dump(step=self.num_timesteps)
+            self.train()
+        if callback is not None:
+            callback.on_training_end()
+        return self
+
+    # checkpoint plumbing: the reference's zip holds `policy` and `policy.optimizer` state_dicts
+    def get_parameters(self):
+        return {"policy": self.policy.state_dict(), "policy.optimizer": self.policy.optimizer.state_dict()}
+
+    def set_parameters(self, params, exact_match: bool = True):
+        self.policy.load_state_dict(params["policy"], strict=exact_match)
+        if "policy.optimizer" in params:
+            self.policy.optimizer.load_state_dict(params["policy.optimizer"])
