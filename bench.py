@@ -1,0 +1,259 @@
+"""bench.py -- env-steps/sec of the GenNBV state-encoding + PPO hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input = one PPO
+iteration of BASELINE.json configs[1]: 256 envs x 240x320 depth x 64^3 grid,
+n_steps=128 env steps (state encoding + policy forward + buffer add per env step),
+the GAE scan, and PPO_Grid_Obs.train() (5 epochs x minibatch 128).  The metric is
+whole-job env-steps/sec = N_gpus * 256 * 128 * K / time(K iterations); envs shard
+across ranks (weak scaling), gradients are all-reduced over RCCL.
+
+Inputs are resident in HBM when the timed region starts (a pool of pre-rendered
+synthetic frames).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--envs", type=int, default=256, help="envs per GPU")
+    ap.add_argument("--grid", type=int, default=64)
+    ap.add_argument("--height", type=int, default=240)
+    ap.add_argument("--width", type=int, default=320)
+    ap.add_argument("--n-steps", type=int, default=128)
+    ap.add_argument("--batch-size", type=int, default=128)
+    ap.add_argument("--n-epochs", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=8, help="frames in the synthetic feed pool")
+    ap.add_argument("--backend", default=os.environ.get("GENNBV_ENCODER_BACKEND", "torch"))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def build_algo(args, device, rank, world):
+    import torch
+    from gennbv_amd.env import synthetic as S
+    from gennbv_amd.env.config import TaskConfig, PPOConfig
+    from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
+    from gennbv_amd.network.hybrid_encoder import Hybrid_Encoder
+    from gennbv_amd.sb3.policies import ActorCriticPolicy_Train_Eval
+    from gennbv_amd.sb3.ppo_grid_obs import PPO_Grid_Obs
+
+    cfg = TaskConfig(camera_width=args.width, camera_height=args.height, grid_size=args.grid)
+    pc = PPOConfig()
+    scene = S.make_scenes(args.envs, args.grid, seed=1 + rank, device=device)
+    feed = ReplayFeed.synthetic(scene, cfg, args.frames, seed=1 + rank, with_rgba=True)
+    env = ReplayFeedEnv(cfg, scene, feed, device)
+    algo = PPO_Grid_Obs(
+        ActorCriticPolicy_Train_Eval, env, learning_rate=pc.learning_rate, n_steps=args.n_steps, batch_size=args.batch_size,
+        n_epochs=args.n_epochs, gamma=pc.gamma, gae_lambda=pc.gae_lambda, clip_range=pc.clip_range,
+        clip_range_vf=pc.clip_range_vf, ent_coef=pc.ent_coef, vf_coef=pc.vf_coef, max_grad_norm=pc.max_grad_norm,
+        target_kl=pc.target_kl, seed=1, device=device,
+        policy_kwargs=dict(net_arch=[], features_extractor_class=Hybrid_Encoder,
+                           features_extractor_kwargs=dict(
+                               encoder_param={"hidden_shapes": [256, 256], "visual_dim": 256},
+                               net_param={"transformer_params": [[1, 256], [1, 256]], "append_hidden_shapes": [256, 256]},
+                               state_input_shape=(cfg.state_dim,),
+                               visual_input_shape=(cfg.stack, cfg.camera_height, cfg.camera_width),
+                               grid_size=args.grid, backend=args.backend,
+                               compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)))
+    if world > 1:
+        from gennbv_amd import parallel
+        parallel.attach(algo, world)
+    return algo, cfg, env
+
+
+class Phase:
+    """Accumulates device time of a code region with events on the current stream."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def __enter__(self):
+        import torch
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e1 = torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        self.e1.record()
+        self.pairs.append((self.e0, self.e1))
+
+    def total_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.pairs)
+
+    def count(self):
+        return len(self.pairs)
+
+
+def instrument_voxel(env):
+    """HIP events around every gnbv_update_occ_grid call (same stream as the kernels)."""
+    ph = Phase()
+    upd = env.updater
+    orig = upd.update
+
+    def timed(*a, **k):
+        with ph:
+            return orig(*a, **k)
+    upd.update = timed
+    return ph
+
+
+def one_iteration(algo, phases):
+    import torch
+    with phases["rollout"]:
+        algo.collect_rollouts(algo.env, None, algo.rollout_buffer, n_rollout_steps=algo.n_steps)
+    with phases["train"]:
+        algo.train()
+
+
+def cpu_baseline(args, cfg):
+    """The oracle (CPU restatement, proven equal to the reference on the goldens) + torch-CPU
+    fp32 PPO on a bounded sample of the same workload: 4 envs, 2 env steps, full 240x320 / G
+    state encoding, policy forward, GAE and one PPO epoch.  kind = "port", single process."""
+    import numpy as np
+    import torch
+    from gennbv_amd.env import synthetic as S
+    from oracle.env_oracle import OracleEnv
+    from oracle import oracle as orc
+    from tests import policy_util as pu
+
+    n, t_steps = 4, 2
+    torch.set_num_threads(os.cpu_count() or 1)
+    scene = S.make_scenes(n, cfg.grid_size, seed=99)
+    frames = S.make_frames(scene, cfg, 2, seed=99)
+    kinv = S.inverse_intrinsics(cfg.camera_height, cfg.camera_width)
+    env = OracleEnv(cfg, kinv.numpy(), scene.range_gt.numpy(), scene.voxel_size.numpy(), scene.grid_gt.numpy(),
+                    scene.num_valid_voxel_gt.numpy())
+    c2w = [S.c2w_from_view(f.view, scene.env_origins).numpy() for f in frames]
+    pol, _, _ = pu.make_policy(g=cfg.grid_size, det_weights=False)
+    pol.set_training_mode(False)
+    t0 = time.time()
+    obs = env.reset(frames[0].depth_raw.numpy(), frames[0].seg_raw.numpy(), frames[0].rgba.numpy(), c2w[0])
+    obs_l, val_l, rew_l, act_l, lp_l = [], [], [], [], []
+    for t in range(t_steps):
+        with torch.no_grad():
+            a, v, lp = pol(torch.from_numpy(obs))
+        f = frames[(t + 1) % 2]
+        nobs, rew, done, info = env.step(a.numpy(), f.depth_raw.numpy(), f.seg_raw.numpy(), f.rgba.numpy(), c2w[(t + 1) % 2])
+        obs_l.append(obs); val_l.append(v.numpy().reshape(-1)); rew_l.append(rew); act_l.append(a.numpy()); lp_l.append(lp.numpy())
+        obs = nobs
+    with torch.no_grad():
+        lv = pol.predict_values(torch.from_numpy(obs)).numpy().reshape(-1)
+    adv, ret = orc.gae_sb3(np.stack(rew_l), np.stack(val_l), np.zeros((t_steps, n), np.uint8), lv, np.zeros(n, np.uint8))
+    # one PPO epoch over the n*t_steps samples (n_epochs passes are scaled analytically below)
+    pol.set_training_mode(True)
+    o = torch.from_numpy(np.concatenate(obs_l)); a = torch.from_numpy(np.concatenate(act_l)).float()
+    advt = torch.from_numpy(adv.reshape(-1)); rett = torch.from_numpy(ret.reshape(-1))
+    oldv = torch.from_numpy(np.concatenate(val_l)); oldlp = torch.from_numpy(np.concatenate(lp_l))
+    t_train0 = time.time()
+    values, log_prob, entropy = pol.evaluate_actions(o, a)
+    values = values.flatten()
+    advn = (advt - advt.mean()) / (advt.std() + 1e-8)
+    ratio = torch.exp(log_prob - oldlp)
+    pg = -torch.min(advn * ratio, advn * torch.clamp(ratio, 0.8, 1.2)).mean()
+    vp = oldv + torch.clamp(values - oldv, -0.2, 0.2)
+    loss = 10 * pg + 0.01 * (-entropy.mean()) + 0.8 * torch.nn.functional.mse_loss(rett, vp)
+    pol.optimizer.zero_grad(); loss.backward()
+    torch.nn.utils.clip_grad_norm_(pol.parameters(), 1.0); pol.optimizer.step()
+    t_train = time.time() - t_train0
+    total = (time.time() - t0) + (args.n_epochs - 1) * t_train
+    return {"value": n * t_steps / total, "unit": "env-steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{n} envs x {t_steps} env steps at {cfg.camera_height}x{cfg.camera_width}, {cfg.grid_size}^3: "
+                      f"oracle state encoding (1 thread) + torch-CPU fp32 policy/PPO ({args.n_epochs} epochs, "
+                      f"{torch.get_num_threads()} threads)"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    algo, cfg, env = build_algo(args, device, rank, world)
+    algo._setup_learn(total_timesteps=10 ** 12)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    dummy = {"rollout": Phase(), "train": Phase()}
+    for _ in range(args.warmup):
+        one_iteration(algo, dummy)
+    phases = {"rollout": Phase(), "train": Phase()}
+    vox = instrument_voxel(env)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_iteration(algo, phases)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    env_steps = world * args.envs * args.n_steps * args.steps
+    value = env_steps / elapsed
+    # roofline of the voxel update: algorithmic bytes per env-step x envs per launch
+    b_vox = args.height * args.width * 8 + args.grid ** 3 * 4 * 6 + 200
+    vox_ms = vox.total_ms() / max(vox.count(), 1)
+    achieved = args.envs * b_vox / (vox_ms * 1e-3) / 1e9
+    out = {
+        "metric": "env-steps/sec at 256 envs x 64^3 grid (state encoding + policy forward + GAE + PPO update)",
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype if args.backend == "hip" else "fp32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: {args.envs} envs/GPU x {args.height}x{args.width} depth x "
+                               f"{args.grid}^3 grid, n_steps={args.n_steps}, batch_size={args.batch_size}, "
+                               f"n_epochs={args.n_epochs}, one step = one PPO iteration",
+                   "global_envs": world * args.envs, "encoder_backend": args.backend,
+                   "parallelism": f"env-sharded dp{world}",
+                   "breakdown_ms_per_step": {"rollout": phases["rollout"].total_ms() / args.steps,
+                                             "train": phases["train"].total_ms() / args.steps,
+                                             "voxel_update_total": vox.total_ms() / args.steps}},
+        "roofline": {"bound": "hbm", "kernel": "gnbv_update_occ_grid (k_hit_mask + k_raycast + k_grid_update)",
+                     "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                     "launch_ms": vox_ms, "algorithmic_bytes_per_launch": args.envs * b_vox, "traffic": None},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, cfg)
+            except Exception as ex:  # the baseline must never take the bench line down
+                out["cpu_baseline"] = {"value": None, "error": repr(ex)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -40,6 +40,9 @@ SIGNATURES = {
     "gnbv_env_obs_state": (_i, [_p, _p, _p, _p, _i, _i, _p, _i64, _p]),
     "gnbv_env_obs_rgb": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i64, _p]),
     "gnbv_env_post_step": (_i, [_p, _p]),
+    "gnbv_encoder_workspace_bytes": (_sz, [_i, _i]),
+    "gnbv_encoder_grid_forward": (_i, [_p, _p, _i64, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gnbv_encoder_grid_backward": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnbv_gae_sb3": (_i, [_p, _p, _p, _p, _p, _i, _i, _d, _d, _p, _p, _p]),
     "gnbv_gae_rsl": (_i, [_p, _p, _p, _p, _i, _i, _d, _d, _p, _p, _p]),
 }
@@ -59,6 +62,18 @@ class GnbvEnvPost(C.Structure):
                 ("rewards", _p), ("dones", _p), ("reset_mask", _p), ("step_time_out", _p), ("extras_time_outs", _p),
                 ("coverage_ratio", _p), ("episode_sums", _p), ("cur_reward_sum", _p), ("cur_episode_length", _p),
                 ("ring_reward", _p), ("ring_length", _p), ("ring_state", _p), ("ring_len", _i)]
+
+
+class GnbvEncoderParams(C.Structure):
+    """include/gennbv_hip.h: GnbvEncoderParams"""
+    _fields_ = [("w1", _p), ("b1", _p), ("bn1_w", _p), ("bn1_b", _p), ("bn1_rm", _p), ("bn1_rv", _p), ("bn1_nbt", _p),
+                ("w2", _p), ("b2", _p), ("bn2_w", _p), ("bn2_b", _p), ("bn2_rm", _p), ("bn2_rv", _p), ("bn2_nbt", _p),
+                ("eps", _f), ("momentum", _f)]
+
+
+class GnbvEncoderGrads(C.Structure):
+    """include/gennbv_hip.h: GnbvEncoderGrads"""
+    _fields_ = [(k, _p) for k in ("w1", "b1", "bn1_w", "bn1_b", "w2", "b2", "bn2_w", "bn2_b")]
 
 
 class GennbvHipError(RuntimeError):

@@ -1,0 +1,645 @@
+// encoder.hip -- the 3-D-CNN occupancy encoder of gennbv/network/hybrid_encoder.py:38-45
+//   Conv3d(1,16,k3,s2) -> BatchNorm3d(16) -> ReLU -> Conv3d(16,16,k3,s2) -> BatchNorm3d(16) -> ReLU
+// forward AND backward, hand-written for gfx950 (MI355X).
+//
+// Why not the library path: MIOpen runs these convolutions as a per-sample im2col + GEMM
+// (1664 tiny GEMM launches per minibatch step, profiles/r01_torch_minibatch.txt): 18.4 ms per
+// PPO minibatch at B=128, G=64.  The contraction is tiny (K = 27 and K = 432) while the
+// activations are large (conv1 output at G=64: 244 MB fp32 per minibatch), so the design is
+// bandwidth-first:
+//   * activations are CHANNELS-LAST ([B, D, H, W, 16]): the 16 channels of a voxel are one
+//     64-byte line, which is exactly one MFMA operand row -- no im2col buffer ever exists;
+//   * the contraction runs on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32,
+//     bit-equal to an fmaf chain) with operands loaded straight from L1/L2;
+//   * BatchNorm statistics are accumulated in the producing kernel's epilogue (per-wave
+//     partials, reduced in a fixed order -> deterministic), BN + ReLU of layer 1 is applied
+//     in the CONSUMER's operand load, BN backward of layer 1 is fused into conv1's
+//     weight-gradient kernel: the conv1 activation is written once and read three times,
+//     never rewritten;
+//   * conv1 reads its input rows straight out of the rollout buffer through a row-index
+//     table (the minibatch gather of buffers.py:753-762 is never materialised).
+//
+// MFMA 16x16x4 fp32 fragment layout (cdna_hip_programming.md section 3), lane l:
+//   A[i = l & 15][k = l >> 4]   B[k = l >> 4][j = l & 15]   D[i = 4*(l >> 4) + r][j = l & 15], r = 0..3
+#include "common.h"
+#include "../../include/gennbv_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kC = 16;          // channels of both conv layers
+constexpr int kTaps = 27;
+constexpr int kEncThreads = 256;
+constexpr int kEncWaves = kEncThreads / kWave;
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// sum over the four k-groups (lanes l, l^16, l^32, l^48): afterwards every lane holds the total
+__device__ __forceinline__ float kgroup_sum(float v)
+{
+    v += __shfl_xor(v, 16, kWave);
+    v += __shfl_xor(v, 32, kWave);
+    return v;
+}
+
+// per-wave BN partials: part[wave_global][0][c] = sum, [1][c] = sum of squares / second sum
+__device__ __forceinline__ void write_partials(float *partials, int wave_global, float s, float q)
+{
+    s = kgroup_sum(s);
+    q = kgroup_sum(q);
+    const int lane = threadIdx.x & (kWave - 1);
+    if (partials != nullptr && lane < kC) {
+        partials[(size_t)wave_global * 2 * kC + lane] = s;
+        partials[(size_t)wave_global * 2 * kC + kC + lane] = q;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// conv1 forward: in [B rows of the obs buffer, G^3 fp32] -> y1 [B,O1,O1,O1,16] (pre-BN, + bias)
+// workgroup = (sample b, output plane oz); wave = output rows oy; tile = 16 outputs along x
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kEncThreads) void k_conv1_fwd(
+    const float *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, int B, int G, int O1,
+    const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ b1, float *__restrict__ y1,
+    float *__restrict__ partials)
+{
+    const int b = blockIdx.x / O1, oz = blockIdx.x - b * O1;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const int m = lane & 15, kq = lane >> 4;
+    const float *in = obs_base + (rows ? rows[b] : (int64_t)b) * row_stride;
+    float wf[7];
+    int off[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        const int t = 4 * s + kq;
+        const bool ok = t < kTaps;
+        wf[s] = ok ? W1[m * kTaps + t] : 0.0f;  // B[k = tap][j = co = m]
+        const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+        off[s] = ok ? (dz * G + dy) * G + dx : 0;
+    }
+    const float bias = b1[m];
+    float s_sum = 0.0f, s_sq = 0.0f;
+    for (int oy = wv; oy < O1; oy += kEncWaves) {
+        for (int ox0 = 0; ox0 < O1; ox0 += 16) {
+            const int ox = min(ox0 + m, O1 - 1);
+            const float *p = in + ((size_t)(2 * oz) * G + 2 * oy) * G + 2 * ox;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 7; ++s) acc = mfma4(p[off[s]], wf[s], acc);
+            float *out = y1 + ((((size_t)b * O1 + oz) * O1 + oy) * O1) * kC;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int oxi = ox0 + 4 * kq + r;
+                if (oxi < O1) {
+                    const float y = acc[r] + bias;
+                    out[(size_t)oxi * kC + m] = y;
+                    s_sum += y;
+                    s_sq += y * y;
+                }
+            }
+        }
+    }
+    write_partials(partials, blockIdx.x * kEncWaves + wv, s_sum, s_sq);
+}
+
+// ---------------------------------------------------------------------------
+// conv2 forward: z1 = relu(scale1*y1 + shift1) applied on load; y2 [B,16,O2^3] (NCDHW, pre-BN)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kEncThreads) void k_conv2_fwd(
+    const float *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1, int B, int O1, int O2,
+    const float *__restrict__ W2 /*[16 co][16 ci][27]*/, const float *__restrict__ b2, float *__restrict__ y2,
+    float *__restrict__ partials)
+{
+    __shared__ float w2s[kTaps * 4 * 4 * kC];  // [(tap*4+s)*4+kq][n] = W2[n][4kq+s][tap]
+    for (int i = threadIdx.x; i < kTaps * 256; i += kEncThreads) {
+        const int n = i & 15, kq_ = (i >> 4) & 3, s = (i >> 6) & 3, tap = i >> 8;
+        w2s[i] = W2[((size_t)n * kC + 4 * kq_ + s) * kTaps + tap];
+    }
+    __syncthreads();
+    const int b = blockIdx.x / O2, oz = blockIdx.x - b * O2;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const int m = lane & 15, kq = lane >> 4;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        sc[s] = scale1[4 * kq + s];
+        sh[s] = shift1[4 * kq + s];
+    }
+    const float bias = b2[m];
+    const int P2 = O2 * O2 * O2;
+    float s_sum = 0.0f, s_sq = 0.0f;
+    for (int oy = wv; oy < O2; oy += kEncWaves) {
+        for (int ox0 = 0; ox0 < O2; ox0 += 16) {
+            const int ox = min(ox0 + m, O2 - 1);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 3
+            for (int tap = 0; tap < kTaps; ++tap) {
+                const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+                const float4 v = *reinterpret_cast<const float4 *>(
+                    y1 + ((((size_t)b * O1 + 2 * oz + dz) * O1 + 2 * oy + dy) * O1 + 2 * ox + dx) * kC + 4 * kq);
+                const float z0 = fmaxf(fmaf(sc[0], v.x, sh[0]), 0.f), z1 = fmaxf(fmaf(sc[1], v.y, sh[1]), 0.f);
+                const float z2 = fmaxf(fmaf(sc[2], v.z, sh[2]), 0.f), z3 = fmaxf(fmaf(sc[3], v.w, sh[3]), 0.f);
+                const float *wb = w2s + tap * 256 + lane;  // + s*64
+                acc = mfma4(z0, wb[0], acc);
+                acc = mfma4(z1, wb[64], acc);
+                acc = mfma4(z2, wb[128], acc);
+                acc = mfma4(z3, wb[192], acc);
+            }
+            float *out = y2 + ((size_t)b * kC + m) * P2 + ((size_t)oz * O2 + oy) * O2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int oxi = ox0 + 4 * kq + r;
+                if (oxi < O2) {
+                    const float y = acc[r] + bias;
+                    out[oxi] = y;
+                    s_sum += y;
+                    s_sq += y * y;
+                }
+            }
+        }
+    }
+    write_partials(partials, blockIdx.x * kEncWaves + wv, s_sum, s_sq);
+}
+
+// ---------------------------------------------------------------------------
+// BatchNorm bookkeeping.  sums [2][16] come from k_reduce_partials.
+//   train: mean / biased var from (sum, sumsq); running stats updated with the UNBIASED var
+//          (torch.nn.BatchNorm3d, momentum 0.1) unless *skip_flag != 0
+//   eval : statistics = running stats
+//   out  : scale = gamma*rstd, shift = beta - mean*scale, mean, rstd
+// ---------------------------------------------------------------------------
+__global__ void k_bn_finalize(const double *__restrict__ sums, double count, const float *__restrict__ gamma,
+                              const float *__restrict__ beta, float eps, float momentum, int training,
+                              float *__restrict__ running_mean, float *__restrict__ running_var,
+                              int64_t *__restrict__ num_batches_tracked, const int *__restrict__ skip_flag,
+                              float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out,
+                              float *__restrict__ rstd_out)
+{
+    const int c = threadIdx.x;
+    if (c >= kC) return;
+    float mean, var;
+    if (training) {
+        const double mu = sums[c] / count;
+        double v = sums[kC + c] / count - mu * mu;
+        v = v < 0.0 ? 0.0 : v;
+        mean = (float)mu;
+        var = (float)v;
+        const bool skip = skip_flag != nullptr && *skip_flag != 0;
+        if (!skip && running_mean != nullptr) {
+            const float unbiased = (float)(v * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+            if (c == 0 && num_batches_tracked != nullptr) num_batches_tracked[0] += 1;
+        }
+    } else {
+        mean = running_mean[c];
+        var = running_var[c];
+    }
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    mean_out[c] = mean;
+    rstd_out[c] = rstd;
+}
+
+// out[e] = sum_p partial[p][e] in fp64 and in a fixed order (deterministic), two stages:
+//   stage 1: grid (ceil(E/64), slices): every workgroup sums a contiguous slice of P (4 waves
+//            stride through it, combined through LDS) -> tmp[slice][E] (fp64)
+//   stage 2: the same kernel over tmp with one slice.
+template <typename T>
+__global__ __launch_bounds__(256) void k_reduce_partials(const T *__restrict__ partial, int P, int E, int per_slice,
+                                                         double *__restrict__ out_d, float *__restrict__ out_f)
+{
+    __shared__ double s[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const int p0 = blockIdx.y * per_slice, p1 = min(P, p0 + per_slice);
+    double acc = 0.0;
+    if (e < E)
+        for (int p = p0 + wv; p < p1; p += 4) acc += (double)partial[(size_t)p * E + e];
+    s[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0 && e < E) {
+        const double t = ((s[0][lane] + s[1][lane]) + s[2][lane]) + s[3][lane];
+        if (out_d) out_d[(size_t)blockIdx.y * E + e] = t;
+        if (out_f) out_f[(size_t)blockIdx.y * E + e] = (float)t;
+    }
+}
+
+// z2 = relu(scale2*y2 + shift2), y2 NCDHW [B,16,P2] -> flat features [B, 16*P2]
+__global__ void k_bn_relu_apply(const float *__restrict__ y2, const float *__restrict__ scale, const float *__restrict__ shift,
+                                int64_t total, int P2, float *__restrict__ z2)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i / P2) % kC);
+        z2[i] = fmaxf(fmaf(scale[c], y2[i], shift[c]), 0.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// BN2 + ReLU backward.  pass 1: per-(b, c) partial sums S1 = sum dz', S2 = sum dz'*xhat
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bn2_bwd_reduce(const float *__restrict__ dz2, const float *__restrict__ y2,
+                                                        const float *__restrict__ scale, const float *__restrict__ shift,
+                                                        const float *__restrict__ mean, const float *__restrict__ rstd, int P2,
+                                                        float *__restrict__ partials /*[B*16][2]*/)
+{
+    const int bc = blockIdx.x, c = bc % kC;
+    const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < P2; i += 256) {
+        const float y = y2[(size_t)bc * P2 + i];
+        const float g = fmaf(sc, y, sh) > 0.0f ? dz2[(size_t)bc * P2 + i] : 0.0f;
+        s1 += g;
+        s2 += g * ((y - mu) * rs);
+    }
+    __shared__ float r1[4], r2[4];
+    s1 = wave_reduce_sum(s1);
+    s2 = wave_reduce_sum(s2);
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[(size_t)bc * 2] = (r1[0] + r1[1]) + (r1[2] + r1[3]);
+        partials[(size_t)bc * 2 + 1] = (r2[0] + r2[1]) + (r2[2] + r2[3]);
+    }
+}
+
+// sums over b of the [B][16][2] partials -> S[2][16] (fp64 accumulate)
+__global__ void k_bn2_bwd_finalize(const float *__restrict__ partials, int B, double *__restrict__ S)
+{
+    const int t = threadIdx.x;  // 32 threads: (which, c)
+    if (t >= 2 * kC) return;
+    const int which = t / kC, c = t % kC;
+    double acc = 0.0;
+    for (int b = 0; b < B; ++b) acc += (double)partials[((size_t)b * kC + c) * 2 + which];
+    S[which * kC + c] = acc;
+}
+
+// pass 2: dy2 (channels-last [B,P2,16]) = scale*(dz' - S1/M - xhat*S2/M)
+__global__ void k_bn2_bwd_apply(const float *__restrict__ dz2, const float *__restrict__ y2, const float *__restrict__ scale,
+                                const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ rstd,
+                                const double *__restrict__ S, double count, int64_t total, int P2, float *__restrict__ dy2)
+{
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(o & (kC - 1));
+        const int64_t bp = o >> 4;  // b*P2 + pos
+        const int64_t b = bp / P2, pos = bp - b * P2;
+        const size_t i = ((size_t)b * kC + c) * P2 + pos;
+        const float y = y2[i];
+        const float g = fmaf(scale[c], y, shift[c]) > 0.0f ? dz2[i] : 0.0f;
+        const float xhat = (y - mean[c]) * rstd[c];
+        const float m1 = (float)(S[c] / count), m2 = (float)(S[kC + c] / count);
+        dy2[o] = scale[c] * (g - m1 - xhat * m2);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// conv2 weight gradient: dW2[(tap, ci), co] = sum_pos z1[inpos(pos, tap), ci] * dy2[pos, co]
+// MFMA: i = ci, j = co, k = 4 consecutive output positions along x.  27 accumulators / wave.
+// partial[w][tap][ci][co] (+ 16 bias sums), reduced by k_reduce_partials.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kEncThreads) void k_conv2_wgrad(
+    const float *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1,
+    const float *__restrict__ dy2 /*[B,O2,O2,O2,16]*/, int B, int O1, int O2, float *__restrict__ partial)
+{
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const int n = lane & 15, kq = lane >> 4;
+    const int wave_global = blockIdx.x * kEncWaves + wv, nwaves = gridDim.x * kEncWaves;
+    const float sc = scale1[n], sh = shift1[n];
+    f32x4 acc[kTaps];
+#pragma unroll
+    for (int t = 0; t < kTaps; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.0f;
+    const int nrows = B * O2 * O2;
+    for (int row = wave_global; row < nrows; row += nwaves) {
+        const int b = row / (O2 * O2), rem = row - b * O2 * O2, oz = rem / O2, oy = rem - oz * O2;
+        for (int x0 = 0; x0 < O2; x0 += 4) {
+            const int x = x0 + kq;
+            const bool ok = x < O2;
+            const int xc = ok ? x : O2 - 1;
+            float bv = dy2[((((size_t)b * O2 + oz) * O2 + oy) * O2 + xc) * kC + n];
+            bv = ok ? bv : 0.0f;
+            bsum += bv;
+            const float *p = y1 + ((((size_t)b * O1 + 2 * oz) * O1 + 2 * oy) * O1 + 2 * xc) * kC + n;
+#pragma unroll
+            for (int tap = 0; tap < kTaps; ++tap) {
+                const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+                const float a = fmaxf(fmaf(sc, p[(((size_t)dz * O1 + dy) * O1 + dx) * kC], sh), 0.0f);
+                acc[tap] = mfma4(a, bv, acc[tap]);  // rows with bv == 0 contribute nothing
+            }
+        }
+    }
+    float *out = partial + (size_t)wave_global * (kTaps * 256 + kC);
+#pragma unroll
+    for (int tap = 0; tap < kTaps; ++tap)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[tap * 256 + (4 * kq + r) * kC + n] = acc[tap][r];  // [tap][ci][co]
+    bsum = kgroup_sum(bsum);
+    if (lane < kC) out[kTaps * 256 + lane] = bsum;
+}
+
+// partial-sum layout [tap][ci][co] (+16) -> torch layout dW2 [co][ci][27], db2 [16]
+__global__ void k_conv2_wgrad_finish(const double *__restrict__ red, float *__restrict__ dW2, float *__restrict__ db2)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < kTaps * 256) {
+        const int tap = i >> 8, ci = (i >> 4) & 15, co = i & 15;
+        dW2[((size_t)co * kC + ci) * kTaps + tap] = (float)red[i];
+    } else if (i < kTaps * 256 + kC) {
+        db2[i - kTaps * 256] = (float)red[i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// conv2 data gradient (transposed conv, stride 2) + ReLU mask of layer 1 + BN1-backward sums.
+//   dz1'[v, ci] = [pre1 > 0] * sum_{tap, co} dy2[(v - tap)/2, co] * W2[co][ci][tap]
+// Input voxels of one x-parity share their tap set -> tiles of 16 voxels ix = 2j + px.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kEncThreads) void k_conv2_dgrad(
+    const float *__restrict__ dy2, const float *__restrict__ W2, const float *__restrict__ y1, const float *__restrict__ scale1,
+    const float *__restrict__ shift1, const float *__restrict__ mean1, const float *__restrict__ rstd1, int B, int O1, int O2,
+    float *__restrict__ dz1p, float *__restrict__ partials)
+{
+    __shared__ float w2d[kTaps * 4 * 4 * kC];  // [(tap*4+s)*4+kq][n] = W2[co = 4kq+s][ci = n][tap]
+    for (int i = threadIdx.x; i < kTaps * 256; i += kEncThreads) {
+        const int n = i & 15, kq_ = (i >> 4) & 3, s = (i >> 6) & 3, tap = i >> 8;
+        w2d[i] = W2[((size_t)(4 * kq_ + s) * kC + n) * kTaps + tap];
+    }
+    __syncthreads();
+    const int b = blockIdx.x / O1, iz = blockIdx.x - b * O1;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const int m = lane & 15, kq = lane >> 4;
+    const float sc = scale1[m], sh = shift1[m], mu = mean1[m], rs = rstd1[m];
+    float s1 = 0.f, s2 = 0.f;
+    // taps along one axis for input index i: even -> {0, 2}, odd -> {1}; output index (i - d)/2 in [0, O2)
+    const int nz = (iz & 1) ? 1 : 2;
+    for (int iy = wv; iy < O1; iy += kEncWaves) {
+        const int ny = (iy & 1) ? 1 : 2;
+        for (int px = 0; px < 2; ++px) {
+            const int nvox = (O1 - px + 1) / 2;  // voxels ix = 2j + px < O1
+            const int nx = px ? 1 : 2;
+            for (int j0 = 0; j0 < nvox; j0 += 16) {
+                const int j = j0 + m;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int tz = 0; tz < nz; ++tz) {
+                    const int dz = (iz & 1) ? 1 : 2 * tz, oz = (iz - dz) >> 1;
+                    if (oz < 0 || oz >= O2) continue;
+                    for (int ty = 0; ty < ny; ++ty) {
+                        const int dy = (iy & 1) ? 1 : 2 * ty, oy = (iy - dy) >> 1;
+                        if (oy < 0 || oy >= O2) continue;
+                        for (int tx = 0; tx < nx; ++tx) {
+                            const int dx = px ? 1 : 2 * tx, ox = j - (dx >> 1);
+                            const bool ok = ox >= 0 && ox < O2 && j < nvox;
+                            const int oxc = min(max(ox, 0), O2 - 1);
+                            float4 v = *reinterpret_cast<const float4 *>(
+                                dy2 + ((((size_t)b * O2 + oz) * O2 + oy) * O2 + oxc) * kC + 4 * kq);
+                            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                            const int tap = (dz * 3 + dy) * 3 + dx;
+                            const float *wb = w2d + tap * 256 + lane;
+                            acc = mfma4(v.x, wb[0], acc);
+                            acc = mfma4(v.y, wb[64], acc);
+                            acc = mfma4(v.z, wb[128], acc);
+                            acc = mfma4(v.w, wb[192], acc);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ji = j0 + 4 * kq + r;
+                    if (ji < nvox) {
+                        const size_t idx = ((((size_t)b * O1 + iz) * O1 + iy) * O1 + (2 * ji + px)) * kC + m;
+                        const float y = y1[idx];
+                        const float g = fmaf(sc, y, sh) > 0.0f ? acc[r] : 0.0f;
+                        dz1p[idx] = g;
+                        s1 += g;
+                        s2 += g * ((y - mu) * rs);
+                    }
+                }
+            }
+        }
+    }
+    write_partials(partials, blockIdx.x * kEncWaves + wv, s1, s2);
+}
+
+// ---------------------------------------------------------------------------
+// conv1 weight gradient with BN1 backward fused into the operand load:
+//   dy1 = scale1 * (dz1' - S1/M - xhat * S2/M);  dW1[co][tap] = sum_pos in[inpos(pos,tap)] * dy1[pos, co]
+// MFMA: i = tap (two 16-row tiles), j = co, k = 4 consecutive output positions along x.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kEncThreads) void k_conv1_wgrad(
+    const float *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, const float *__restrict__ dz1p,
+    const float *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ mean1,
+    const float *__restrict__ rstd1, const double *__restrict__ S /*[2][16]*/, double count, int B, int G, int O1,
+    float *__restrict__ partial /*[nwaves][2*256 + 16]*/)
+{
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const int n = lane & 15, kq = lane >> 4;
+    const int wave_global = blockIdx.x * kEncWaves + wv, nwaves = gridDim.x * kEncWaves;
+    const float sc = scale1[n], mu = mean1[n], rs = rstd1[n];
+    const float m1 = (float)(S[n] / count), m2 = (float)(S[kC + n] / count);
+    int off[2];
+    bool tok[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int t = 16 * tt + n;  // A row i = tap (lane & 15)
+        tok[tt] = t < kTaps;
+        const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+        off[tt] = tok[tt] ? (dz * G + dy) * G + dx : 0;
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.0f;
+    const int nrows = B * O1 * O1;
+    for (int row = wave_global; row < nrows; row += nwaves) {
+        const int b = row / (O1 * O1), rem = row - b * O1 * O1, oz = rem / O1, oy = rem - oz * O1;
+        const float *in = obs_base + (rows ? rows[b] : (int64_t)b) * row_stride + ((size_t)(2 * oz) * G + 2 * oy) * G;
+        const size_t base = (((size_t)b * O1 + oz) * O1 + oy) * O1;
+        for (int x0 = 0; x0 < O1; x0 += 4) {
+            const int x = x0 + kq;
+            const bool ok = x < O1;
+            const int xc = ok ? x : O1 - 1;
+            const size_t idx = (base + xc) * kC + n;
+            const float y = y1[idx];
+            float dy = sc * (dz1p[idx] - m1 - ((y - mu) * rs) * m2);  // B[k = pos][j = co = n]
+            dy = ok ? dy : 0.0f;
+            bsum += dy;
+            const float a0 = tok[0] ? in[2 * xc + off[0]] : 0.0f;  // A[i = tap][k = pos]
+            const float a1 = tok[1] ? in[2 * xc + off[1]] : 0.0f;
+            acc0 = mfma4(a0, dy, acc0);
+            acc1 = mfma4(a1, dy, acc1);
+        }
+    }
+    float *out = partial + (size_t)wave_global * (2 * 256 + kC);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        out[(4 * kq + r) * kC + n] = acc0[r];          // [tap 0..15][co]
+        out[256 + (4 * kq + r) * kC + n] = acc1[r];    // [tap 16..31][co]
+    }
+    bsum = kgroup_sum(bsum);
+    if (lane < kC) out[512 + lane] = bsum;
+}
+
+__global__ void k_conv1_wgrad_finish(const double *__restrict__ red, float *__restrict__ dW1, float *__restrict__ db1)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 512) {
+        const int tap = i >> 4, co = i & 15;
+        if (tap < kTaps) dW1[co * kTaps + tap] = (float)red[i];
+    } else if (i < 512 + kC) {
+        db1[i - 512] = (float)red[i];
+    }
+}
+
+__global__ void k_bn_grads(const double *__restrict__ S1, const double *__restrict__ S2, float *g1w, float *g1b, float *g2w, float *g2b)
+{
+    const int c = threadIdx.x;
+    if (c >= kC) return;
+    g1b[c] = (float)S1[c];
+    g1w[c] = (float)S1[kC + c];
+    g2b[c] = (float)S2[c];
+    g2w[c] = (float)S2[kC + c];
+}
+
+// ===========================================================================
+// C-ABI
+// ===========================================================================
+static inline int out_size(int g) { return (g - 3) / 2 + 1; }
+
+GNBV_API size_t gnbv_encoder_workspace_bytes(int batch, int grid)
+{
+    if (batch <= 0 || grid < 7) return 0;
+    const int o1 = out_size(grid);
+    // BN partials of the largest producer (conv1 fwd / conv2 dgrad: B*O1 workgroups x 4 waves x 32 floats),
+    // weight-gradient partials (kWgradWaves x 6928 floats), fp64 reduction scratch
+    const size_t bn = (size_t)batch * o1 * kEncWaves * 2 * kC * sizeof(float);
+    const size_t wg = (size_t)2048 * (kTaps * 256 + kC) * sizeof(float);
+    return bn + wg + (8192 + (size_t)64 * (kTaps * 256 + kC)) * sizeof(double) + 4096;
+}
+
+struct EncWs {
+    float *bn_part, *wg_part;
+    double *red, *tmp;
+};
+static inline EncWs enc_carve(void *ws, int batch, int grid)
+{
+    EncWs w;
+    const int o1 = out_size(grid);
+    w.bn_part = (float *)ws;
+    w.wg_part = w.bn_part + (size_t)batch * o1 * kEncWaves * 2 * kC;
+    w.red = (double *)(((uintptr_t)(w.wg_part + (size_t)2048 * (kTaps * 256 + kC)) + 255) & ~(uintptr_t)255);
+    w.tmp = w.red + 8192;
+    return w;
+}
+
+constexpr int kReduceSlices = 64;
+
+// tmp: kReduceTmpDoubles fp64 of scratch
+static inline int reduce_launch(const float *partial, int P, int E, double *out_d, double *tmp, hipStream_t st)
+{
+    int slices = P / 16;
+    slices = slices < 1 ? 1 : (slices > kReduceSlices ? kReduceSlices : slices);
+    const int per = (P + slices - 1) / slices;
+    hipLaunchKernelGGL(k_reduce_partials<float>, dim3((E + 63) / 64, slices), dim3(256), 0, st, partial, P, E, per, tmp,
+                       (float *)nullptr);
+    hipLaunchKernelGGL(k_reduce_partials<double>, dim3((E + 63) / 64, 1), dim3(256), 0, st, (const double *)tmp, slices, E,
+                       slices, out_d, (float *)nullptr);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *rows, int64_t row_stride, int batch, int grid,
+                                       const GnbvEncoderParams *p, int training, const int *skip_flag, float *y1, float *y2,
+                                       float *bn_state /*[2][4][16]: scale, shift, mean, rstd per layer*/, float *features,
+                                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    GNBV_CHECK_ARG(obs_grid && p && y1 && y2 && bn_state && features && workspace && batch > 0 && grid >= 7);
+    GNBV_CHECK_ARG(workspace_bytes >= gnbv_encoder_workspace_bytes(batch, grid) && ((uintptr_t)workspace & 255) == 0);
+    GNBV_CHECK_ARG(p->w1 && p->b1 && p->bn1_w && p->bn1_b && p->bn1_rm && p->bn1_rv && p->w2 && p->b2 && p->bn2_w && p->bn2_b &&
+                   p->bn2_rm && p->bn2_rv);
+    hipStream_t st = gnbv_stream(stream);
+    const int O1 = out_size(grid), O2 = out_size(O1);
+    GNBV_CHECK_ARG(O2 >= 1);
+    const int P2 = O2 * O2 * O2;
+    EncWs w = enc_carve(workspace, batch, grid);
+    float *bn1 = bn_state, *bn2 = bn_state + 4 * kC;
+    int err;
+    // conv1 (+ BN1 statistics)
+    hipLaunchKernelGGL(k_conv1_fwd, dim3(batch * O1), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, batch, grid, O1, p->w1,
+                       p->b1, y1, training ? w.bn_part : nullptr);
+    if ((err = gnbv_launch_status())) return err;
+    if (training && (err = reduce_launch(w.bn_part, batch * O1 * kEncWaves, 2 * kC, w.red, w.tmp, st))) return err;
+    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, w.red, (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps,
+                       p->momentum, training, p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC);
+    if ((err = gnbv_launch_status())) return err;
+    // conv2 (BN1 + ReLU on load; + BN2 statistics)
+    hipLaunchKernelGGL(k_conv2_fwd, dim3(batch * O2), dim3(kEncThreads), 0, st, y1, bn1, bn1 + kC, batch, O1, O2, p->w2, p->b2, y2,
+                       training ? w.bn_part : nullptr);
+    if ((err = gnbv_launch_status())) return err;
+    if (training && (err = reduce_launch(w.bn_part, batch * O2 * kEncWaves, 2 * kC, w.red + 64, w.tmp, st))) return err;
+    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, w.red + 64, (double)batch * P2, p->bn2_w, p->bn2_b, p->eps,
+                       p->momentum, training, p->bn2_rm, p->bn2_rv, p->bn2_nbt, skip_flag, bn2, bn2 + kC, bn2 + 2 * kC, bn2 + 3 * kC);
+    if ((err = gnbv_launch_status())) return err;
+    // BN2 + ReLU -> flat features [B, 16*P2] (C-major, the reference's .reshape(num_env, -1))
+    const int64_t total = (int64_t)batch * kC * P2;
+    int grid_x = (int)((total + 255) / 256);
+    grid_x = grid_x > 4096 ? 4096 : grid_x;
+    hipLaunchKernelGGL(k_bn_relu_apply, dim3(grid_x), dim3(256), 0, st, y2, bn2, bn2 + kC, total, P2, features);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *rows, int64_t row_stride, int batch, int grid,
+                                        const GnbvEncoderParams *p, const float *y1, const float *y2, const float *bn_state,
+                                        const float *d_features, float *dy2_scratch, float *dz1_scratch,
+                                        const GnbvEncoderGrads *g, void *workspace, size_t workspace_bytes, void *stream)
+{
+    GNBV_CHECK_ARG(obs_grid && p && y1 && y2 && bn_state && d_features && dy2_scratch && dz1_scratch && g && workspace);
+    GNBV_CHECK_ARG(batch > 0 && grid >= 7 && workspace_bytes >= gnbv_encoder_workspace_bytes(batch, grid));
+    GNBV_CHECK_ARG(g->w1 && g->b1 && g->bn1_w && g->bn1_b && g->w2 && g->b2 && g->bn2_w && g->bn2_b);
+    hipStream_t st = gnbv_stream(stream);
+    const int O1 = out_size(grid), O2 = out_size(O1), P2 = O2 * O2 * O2;
+    EncWs w = enc_carve(workspace, batch, grid);
+    const float *bn1 = bn_state, *bn2 = bn_state + 4 * kC;
+    int err;
+    // ---- BN2 + ReLU backward ----
+    hipLaunchKernelGGL(k_bn2_bwd_reduce, dim3(batch * kC), dim3(256), 0, st, d_features, y2, bn2, bn2 + kC, bn2 + 2 * kC,
+                       bn2 + 3 * kC, P2, w.bn_part);
+    if ((err = gnbv_launch_status())) return err;
+    double *S2 = w.red + 128;
+    hipLaunchKernelGGL(k_bn2_bwd_finalize, dim3(1), dim3(64), 0, st, w.bn_part, batch, S2);
+    if ((err = gnbv_launch_status())) return err;
+    const int64_t total2 = (int64_t)batch * P2 * kC;
+    int gx = (int)((total2 + 255) / 256);
+    gx = gx > 4096 ? 4096 : gx;
+    hipLaunchKernelGGL(k_bn2_bwd_apply, dim3(gx), dim3(256), 0, st, d_features, y2, bn2, bn2 + kC, bn2 + 2 * kC, bn2 + 3 * kC, S2,
+                       (double)batch * P2, total2, P2, dy2_scratch);
+    if ((err = gnbv_launch_status())) return err;
+    // ---- conv2 weight gradient ----
+    int nrows2 = batch * O2 * O2;
+    int wg_blocks = (nrows2 + kEncWaves - 1) / kEncWaves;
+    wg_blocks = wg_blocks > 512 ? 512 : wg_blocks;
+    hipLaunchKernelGGL(k_conv2_wgrad, dim3(wg_blocks), dim3(kEncThreads), 0, st, y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
+                       w.wg_part);
+    if ((err = gnbv_launch_status())) return err;
+    const int E2 = kTaps * 256 + kC;
+    if ((err = reduce_launch(w.wg_part, wg_blocks * kEncWaves, E2, w.red + 256, w.tmp, st))) return err;
+    hipLaunchKernelGGL(k_conv2_wgrad_finish, dim3((E2 + 255) / 256), dim3(256), 0, st, w.red + 256, g->w2, g->b2);
+    if ((err = gnbv_launch_status())) return err;
+    // ---- conv2 data gradient (+ ReLU1 mask, BN1 backward sums) ----
+    hipLaunchKernelGGL(k_conv2_dgrad, dim3(batch * O1), dim3(kEncThreads), 0, st, dy2_scratch, p->w2, y1, bn1, bn1 + kC, bn1 + 2 * kC,
+                       bn1 + 3 * kC, batch, O1, O2, dz1_scratch, w.bn_part);
+    if ((err = gnbv_launch_status())) return err;
+    double *S1 = w.red + 192;
+    if ((err = reduce_launch(w.bn_part, batch * O1 * kEncWaves, 2 * kC, S1, w.tmp, st))) return err;
+    // ---- conv1 weight gradient (BN1 backward fused) ----
+    int nrows1 = batch * O1 * O1;
+    int wg1_blocks = (nrows1 + kEncWaves - 1) / kEncWaves;
+    wg1_blocks = wg1_blocks > 512 ? 512 : wg1_blocks;
+    hipLaunchKernelGGL(k_conv1_wgrad, dim3(wg1_blocks), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, dz1_scratch, y1, bn1,
+                       bn1 + 2 * kC, bn1 + 3 * kC, S1, (double)batch * O1 * O1 * O1, batch, grid, O1, w.wg_part);
+    if ((err = gnbv_launch_status())) return err;
+    const int E1 = 512 + kC;
+    if ((err = reduce_launch(w.wg_part, wg1_blocks * kEncWaves, E1, w.red + 256, w.tmp, st))) return err;
+    hipLaunchKernelGGL(k_conv1_wgrad_finish, dim3((E1 + 255) / 256), dim3(256), 0, st, w.red + 256, g->w1, g->b1);
+    if ((err = gnbv_launch_status())) return err;
+    // ---- BN affine gradients: d beta = S[0], d gamma = S[1] ----
+    hipLaunchKernelGGL(k_bn_grads, dim3(1), dim3(64), 0, st, S1, S2, g->bn1_w, g->bn1_b, g->bn2_w, g->bn2_b);
+    return gnbv_launch_status();
+}
+

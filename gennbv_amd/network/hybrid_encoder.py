@@ -72,16 +72,18 @@ class Hybrid_Encoder(nn.Module):
         pts = (positions[..., None] * freq_bands).reshape(positions.shape[:-1] + (freqs * positions.shape[-1],))
         return torch.cat([torch.sin(pts), torch.cos(pts)], dim=-1)
 
-    def forward(self, observations: torch.Tensor) -> torch.Tensor:
+    def forward(self, observations) -> torch.Tensor:
+        if self.backend == "hip":
+            from ..ops import encoder_ops
+            return encoder_ops.hybrid_forward(self, observations)
+        if not isinstance(observations, torch.Tensor):  # ops.encoder_ops.RowGather
+            observations = observations.materialize()
         num_env = observations.shape[0]
         s = self.state_input_shape[0]
         g = self.grid_size
         action_input = observations[:, :s].view(num_env, -1, 6)
         action_input = self.positional_encoding(action_input).view(num_env, -1)
         grid_input = observations[:, s:s + g ** 3].reshape(num_env, 1, g, g, g)
-        if self.backend == "hip":
-            from ..ops import encoder_ops
-            return encoder_ops.hybrid_forward(self, action_input, grid_input)
         feature_action = self.naive_encoder_action(action_input)
         feature_grid = self.naive_encoder_grid(grid_input).reshape(num_env, -1)
         feature_grid = self.output_layer_grid(feature_grid)

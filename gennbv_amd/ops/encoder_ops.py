@@ -1,0 +1,143 @@
+"""torch.autograd bridge to the gfx950 encoder kernels (gennbv_amd/csrc/encoder.hip).
+
+`grid_encoder(obs, rows, module, training)` evaluates
+`naive_encoder_grid(obs[rows, s:s+G^3].reshape(B,1,G,G,G)).reshape(B,-1)` of the reference
+(gennbv/network/hybrid_encoder.py:90-94) -- conv1, BN1, ReLU, conv2, BN2, ReLU -- and its
+backward on hand-written kernels through the C-ABI.  `rows` (int64 [B] or None) selects the
+minibatch rows straight out of the rollout buffer, so the gather is fused into conv1's load.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from .. import _lib
+
+
+class RowGather:
+    """A lazily gathered observation batch: rows `rows` of the 2-D fp32 matrix `base`."""
+
+    def __init__(self, base: torch.Tensor, rows: torch.Tensor):
+        assert base.dim() == 2 and base.stride(1) == 1 and rows.dtype == torch.int64
+        self.base, self.rows = base, rows.contiguous()
+        self.shape = (rows.shape[0], base.shape[1])
+        self.device = base.device
+
+    def float(self):
+        return self
+
+    def materialize(self) -> torch.Tensor:
+        return self.base[self.rows]
+
+    def columns(self, a: int, b: int) -> torch.Tensor:
+        return self.base[:, a:b][self.rows]
+
+
+def conv_out(g: int) -> int:
+    return (g - 3) // 2 + 1
+
+
+_ws_cache = {}
+
+
+def _workspace(lib, batch, grid, device):
+    key = (batch, grid, str(device))
+    ws = _ws_cache.get(key)
+    if ws is None:
+        n = lib.gnbv_encoder_workspace_bytes(batch, grid)
+        ws = torch.empty(n, dtype=torch.uint8, device=device)
+        assert ws.data_ptr() % 256 == 0
+        _ws_cache[key] = ws
+    return ws
+
+
+def _params_struct(seq) -> _lib.GnbvEncoderParams:
+    conv1, bn1, conv2, bn2 = seq[0], seq[1], seq[3], seq[4]
+    p = _lib.GnbvEncoderParams()
+    p.w1, p.b1, p.bn1_w, p.bn1_b = conv1.weight.data_ptr(), conv1.bias.data_ptr(), bn1.weight.data_ptr(), bn1.bias.data_ptr()
+    p.bn1_rm, p.bn1_rv, p.bn1_nbt = bn1.running_mean.data_ptr(), bn1.running_var.data_ptr(), bn1.num_batches_tracked.data_ptr()
+    p.w2, p.b2, p.bn2_w, p.bn2_b = conv2.weight.data_ptr(), conv2.bias.data_ptr(), bn2.weight.data_ptr(), bn2.bias.data_ptr()
+    p.bn2_rm, p.bn2_rv, p.bn2_nbt = bn2.running_mean.data_ptr(), bn2.running_var.data_ptr(), bn2.num_batches_tracked.data_ptr()
+    p.eps, p.momentum = float(bn1.eps), float(bn1.momentum)
+    return p
+
+
+class _GridEncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, base, rows, grid_off, grid, training, skip_flag, seq, w1, b1, g1, be1, w2, b2, g2, be2):
+        lib = _lib.load()
+        _lib.require_cuda(base, w1)
+        for t in (w1, b1, g1, be1, w2, b2, g2, be2):
+            assert t.is_contiguous() and t.dtype == torch.float32
+        dev = base.device
+        batch = int(rows.shape[0]) if rows is not None else int(base.shape[0])
+        o1 = conv_out(grid)
+        o2 = conv_out(o1)
+        p2 = o2 ** 3
+        y1 = torch.empty(batch * o1 ** 3 * 16, dtype=torch.float32, device=dev)
+        y2 = torch.empty(batch * 16 * p2, dtype=torch.float32, device=dev)
+        bn_state = torch.empty(2 * 4 * 16, dtype=torch.float32, device=dev)
+        feats = torch.empty(batch, 16 * p2, dtype=torch.float32, device=dev)
+        ws = _workspace(lib, batch, grid, dev)
+        params = _params_struct(seq)
+        obs_ptr = base.data_ptr() + 4 * grid_off
+        _lib.check(lib.gnbv_encoder_grid_forward(
+            obs_ptr, _lib.ptr(rows), base.stride(0), batch, grid, C.byref(params), int(training), _lib.ptr(skip_flag),
+            y1.data_ptr(), y2.data_ptr(), bn_state.data_ptr(), feats.data_ptr(), ws.data_ptr(), ws.numel(),
+            _lib.stream_ptr(dev)), "gnbv_encoder_grid_forward")
+        ctx.save_for_backward(base, rows, y1, y2, bn_state, w1, w2)
+        ctx.meta = (grid_off, grid, batch, seq)
+        return feats
+
+    @staticmethod
+    def backward(ctx, d_feats):
+        lib = _lib.load()
+        base, rows, y1, y2, bn_state, w1, w2 = ctx.saved_tensors
+        grid_off, grid, batch, seq = ctx.meta
+        dev = base.device
+        o1 = conv_out(grid)
+        o2 = conv_out(o1)
+        d_feats = d_feats.contiguous().float()
+        dy2 = torch.empty(batch * o2 ** 3 * 16, dtype=torch.float32, device=dev)
+        dz1 = torch.empty(batch * o1 ** 3 * 16, dtype=torch.float32, device=dev)
+        grads = [torch.empty_like(t) for t in (seq[0].weight, seq[0].bias, seq[1].weight, seq[1].bias,
+                                               seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias)]
+        gs = _lib.GnbvEncoderGrads()
+        for name, t in zip(("w1", "b1", "bn1_w", "bn1_b", "w2", "b2", "bn2_w", "bn2_b"), grads):
+            setattr(gs, name, t.data_ptr())
+        params = _params_struct(seq)
+        ws = _workspace(lib, batch, grid, dev)
+        _lib.check(lib.gnbv_encoder_grid_backward(
+            base.data_ptr() + 4 * grid_off, _lib.ptr(rows), base.stride(0), batch, grid, C.byref(params), y1.data_ptr(),
+            y2.data_ptr(), bn_state.data_ptr(), d_feats.data_ptr(), dy2.data_ptr(), dz1.data_ptr(), C.byref(gs),
+            ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "gnbv_encoder_grid_backward")
+        return (None, None, None, None, None, None, None, *grads)
+
+
+def grid_encoder(base: torch.Tensor, rows: Optional[torch.Tensor], grid_off: int, grid: int, seq, training: bool,
+                 skip_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """seq = the `naive_encoder_grid` nn.Sequential (conv, bn, relu, conv, bn, relu)."""
+    return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, seq[0].weight, seq[0].bias,
+                                seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias)
+
+
+def hybrid_forward(enc, observations) -> torch.Tensor:
+    """Hybrid_Encoder.forward with the grid branch on the gfx950 kernels."""
+    s = enc.state_input_shape[0]
+    g = enc.grid_size
+    if isinstance(observations, RowGather):
+        base, rows = observations.base, observations.rows
+        state = observations.columns(0, s)
+    else:
+        base, rows = observations, None
+        state = observations[:, :s]
+        if base.stride(1) != 1:
+            base = base.contiguous()
+    num_env = state.shape[0]
+    action_input = enc.positional_encoding(state.view(num_env, -1, 6)).view(num_env, -1)
+    feature_action = enc.naive_encoder_action(action_input)
+    feature_grid = grid_encoder(base, rows, s, g, enc.naive_encoder_grid, enc.training)
+    feature_grid = enc.output_layer_grid(feature_grid)
+    return enc.output_layer(torch.cat((feature_action, feature_grid), dim=-1))

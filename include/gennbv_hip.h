@@ -162,6 +162,49 @@ typedef struct GnbvEnvPost {
 int gnbv_env_post_step(const GnbvEnvPost *args /*[host]*/, void *stream);
 
 /* ------------------------------------------------------------------------- */
+/* B1  Hybrid_Encoder grid branch (gennbv/network/hybrid_encoder.py:38-45,90-94): */
+/*     Conv3d(1,16,3,s2) BN ReLU Conv3d(16,16,3,s2) BN ReLU -> flatten             */
+/*     fp32, forward + backward, hand-written MFMA kernels (csrc/encoder.hip).     */
+/* ------------------------------------------------------------------------- */
+/* Device pointers to the parameters / buffers of `naive_encoder_grid`
+ * (torch layouts: w1 [16,1,3,3,3], w2 [16,16,3,3,3], vectors [16]). [host struct] */
+typedef struct GnbvEncoderParams {
+    const float *w1, *b1, *bn1_w, *bn1_b;
+    float *bn1_rm, *bn1_rv;       /* running_mean / running_var (updated when training) */
+    int64_t *bn1_nbt;             /* num_batches_tracked [1] or NULL */
+    const float *w2, *b2, *bn2_w, *bn2_b;
+    float *bn2_rm, *bn2_rv;
+    int64_t *bn2_nbt;
+    float eps, momentum;          /* 1e-5, 0.1 (torch.nn.BatchNorm3d defaults) */
+} GnbvEncoderParams;
+
+typedef struct GnbvEncoderGrads {  /* outputs, same shapes as the parameters */
+    float *w1, *b1, *bn1_w, *bn1_b, *w2, *b2, *bn2_w, *bn2_b;
+} GnbvEncoderGrads;
+
+size_t gnbv_encoder_workspace_bytes(int batch, int grid);
+
+/* obs_grid: pointer to the grid slice of row 0 of an observation matrix; sample b reads
+ * obs_grid + (rows ? rows[b] : b) * row_stride floats (the minibatch gather of
+ * buffers.py:753-762 is fused into the read).  training != 0: BatchNorm uses batch statistics
+ * and updates the running stats (unless *skip_flag != 0), else the running stats.
+ * Saved for backward: y1 [B,O1,O1,O1,16] (channels-last, pre-BN), y2 [B,16,O2^3] (pre-BN),
+ * bn_state [2][4][16] (scale, shift, mean, rstd per layer).
+ * features [B, 16*O2^3] is the reference's `naive_encoder_grid(x).reshape(num_env, -1)`. */
+int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *rows, int64_t row_stride, int batch, int grid,
+                              const GnbvEncoderParams *params /*[host]*/, int training, const int *skip_flag, float *y1,
+                              float *y2, float *bn_state, float *features, void *workspace, size_t workspace_bytes,
+                              void *stream);
+
+/* Gradients of all eight parameter tensors given d_features [B, 16*O2^3].
+ * dy2_scratch [B,O2^3,16] and dz1_scratch [B,O1^3,16] are caller-owned scratch. */
+int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *rows, int64_t row_stride, int batch, int grid,
+                               const GnbvEncoderParams *params /*[host]*/, const float *y1, const float *y2,
+                               const float *bn_state, const float *d_features, float *dy2_scratch, float *dz1_scratch,
+                               const GnbvEncoderGrads *grads /*[host]*/, void *workspace, size_t workspace_bytes,
+                               void *stream);
+
+/* ------------------------------------------------------------------------- */
 /* C2  TensorRolloutBuffer_Grid_Obs.compute_returns_and_advantage               */
 /*     stable_baselines3/common/buffers.py:706-724.  All arrays [T,N] (the      */
 /*     reference's [T,N,1]); episode_starts / dones are u8.                      */
