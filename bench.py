@@ -39,8 +39,8 @@ def parse():
     ap.add_argument("--batch-size", type=int, default=128)
     ap.add_argument("--n-epochs", type=int, default=5)
     ap.add_argument("--frames", type=int, default=8, help="frames in the synthetic feed pool")
-    ap.add_argument("--backend", default=os.environ.get("GENNBV_ENCODER_BACKEND", "torch"))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--backend", default=os.environ.get("GENNBV_ENCODER_BACKEND", "hip"), choices=["hip", "torch"])
+    ap.add_argument("--dtype", default="fp32", choices=["fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -231,7 +231,7 @@ def main():
         "metric": "env-steps/sec at 256 envs x 64^3 grid (state encoding + policy forward + GAE + PPO update)",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype if args.backend == "hip" else "fp32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: {args.envs} envs/GPU x {args.height}x{args.width} depth x "
                                f"{args.grid}^3 grid, n_steps={args.n_steps}, batch_size={args.batch_size}, "
                                f"n_epochs={args.n_epochs}, one step = one PPO iteration",

@@ -43,6 +43,10 @@ SIGNATURES = {
     "gnbv_encoder_workspace_bytes": (_sz, [_i, _i]),
     "gnbv_encoder_grid_forward": (_i, [_p, _p, _i64, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnbv_encoder_grid_backward": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gnbv_gather_minibatch": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "gnbv_ppo_loss": (_i, [_p, _p]),
+    "gnbv_adam_workspace_bytes": (_sz, []),
+    "gnbv_clip_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _p, _p, _p, _sz, _p]),
     "gnbv_gae_sb3": (_i, [_p, _p, _p, _p, _p, _i, _i, _d, _d, _p, _p, _p]),
     "gnbv_gae_rsl": (_i, [_p, _p, _p, _p, _i, _i, _d, _d, _p, _p, _p]),
 }
@@ -74,6 +78,16 @@ class GnbvEncoderParams(C.Structure):
 class GnbvEncoderGrads(C.Structure):
     """include/gennbv_hip.h: GnbvEncoderGrads"""
     _fields_ = [(k, _p) for k in ("w1", "b1", "bn1_w", "bn1_b", "w2", "b2", "bn2_w", "bn2_b")]
+
+
+class GnbvPpoLoss(C.Structure):
+    """include/gennbv_hip.h: GnbvPpoLoss"""
+    _fields_ = [("batch", _i), ("n_logits", _i), ("n_heads", _i), ("head_dims", _i * 8), ("normalize_advantage", _i),
+                ("clip_range", _f), ("clip_range_vf", _f), ("ent_coef", _f), ("vf_coef", _f), ("policy_scale", _f),
+                ("target_kl", _f),
+                ("logits", _p), ("values", _p), ("actions", _p), ("old_values", _p), ("old_log_prob", _p),
+                ("advantages", _p), ("returns", _p), ("d_logits", _p), ("d_values", _p), ("head_entropy", _p),
+                ("head_lse", _p), ("stats", _p), ("stats_row", _p), ("stop_flag", _p)]
 
 
 class GennbvHipError(RuntimeError):

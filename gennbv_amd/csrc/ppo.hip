@@ -1,0 +1,294 @@
+// ppo.hip -- the PPO minibatch update of stable_baselines3/ppo/ppo_grid_obs.py:196-275 on MI355X:
+//   * k_gather_minibatch   the five per-sample gathers of buffers.py:753-762 in one launch
+//   * k_ppo_loss           advantage normalisation (:214-216), MultiCategorical log-prob / entropy
+//                          (distributions.py:321-332), clipped surrogate (:219-224), clipped value
+//                          loss (:231-241), entropy loss (:245-249), loss = 10*pg + c_e*ent + c_v*vl
+//                          (:253), approx-KL (:259-262) AND the analytic gradient of the loss with
+//                          respect to the logits and the values -- one workgroup, one launch,
+//                          instead of ~100 tiny torch kernels forward + backward;
+//                          sets the sticky early-stop flag (:264-268) on the device.
+//   * k_grad_sqnorm / k_adam_flat   clip_grad_norm_(max_norm) + Adam(eps=1e-5) (:271-275) over ONE
+//                          flat fp32 parameter / gradient buffer, masked by the stop flag.
+// Nothing here synchronises with the host: the five .item()/.cpu() reads per minibatch of the
+// reference (:227,228,242,251,261) become rows of a device-side statistics table.
+#include "common.h"
+#include "../../include/gennbv_hip.h"
+
+constexpr int kLossThreads = 256;
+constexpr int kMaxHeads = 8;
+
+// ---------------------------------------------------------------------------
+__global__ void k_gather_minibatch(const int64_t *__restrict__ rows, int batch, int act_dim, const float *__restrict__ actions,
+                                   const float *__restrict__ values, const float *__restrict__ log_probs,
+                                   const float *__restrict__ advantages, const float *__restrict__ returns,
+                                   float *__restrict__ o_actions, float *__restrict__ o_values, float *__restrict__ o_log_probs,
+                                   float *__restrict__ o_adv, float *__restrict__ o_ret)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch) return;
+    const int64_t r = rows[i];
+    for (int a = 0; a < act_dim; ++a) o_actions[(size_t)i * act_dim + a] = actions[(size_t)r * act_dim + a];
+    o_values[i] = values[r];
+    o_log_probs[i] = log_probs[r];
+    o_adv[i] = advantages[r];
+    o_ret[i] = returns[r];
+}
+
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float *scratch /*[kLossThreads/64 + 1]*/)
+{
+    v = wave_reduce_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < kLossThreads / 64; ++i) t += scratch[i];
+    return t;
+}
+
+__global__ __launch_bounds__(kLossThreads) void k_ppo_loss(GnbvPpoLoss a)
+{
+    extern __shared__ float smem[];
+    float *s_adv = smem;                 // [B] normalised advantage
+    float *s_gl = smem + a.batch;        // [B] dL/dlogp
+    float *s_logp = smem + 2 * a.batch;  // [B]
+    float *s_ent = smem + 3 * a.batch;   // [B]
+    __shared__ float scratch[kLossThreads / 64 + 1];
+    const int B = a.batch, tid = threadIdx.x;
+    const float invB = 1.0f / (float)B;
+
+    // ---- advantage normalisation: (A - mean) / (std_unbiased + 1e-8) ----
+    float s = 0.f;
+    for (int i = tid; i < B; i += kLossThreads) s += a.advantages[i];
+    const float mean = block_sum(s, scratch) * invB;
+    float q = 0.f;
+    for (int i = tid; i < B; i += kLossThreads) {
+        const float d = a.advantages[i] - mean;
+        q += d * d;
+    }
+    const float var = block_sum(q, scratch) / (float)(B > 1 ? B - 1 : 1);
+    const float inv_std = 1.0f / (sqrtf(var) + 1e-8f);
+    for (int i = tid; i < B; i += kLossThreads) s_adv[i] = a.normalize_advantage ? (a.advantages[i] - mean) * inv_std : a.advantages[i];
+
+    // ---- per (sample, head): log-softmax, log-prob of the taken action, entropy ----
+    for (int i = tid; i < B; i += kLossThreads) { s_logp[i] = 0.f; s_ent[i] = 0.f; }
+    __syncthreads();
+    // one wave per sample: lanes stride over the head's categories
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int i = wv; i < B; i += kLossThreads / 64) {
+        const float *lg = a.logits + (size_t)i * a.n_logits;
+        float logp = 0.f, ent = 0.f;
+        int off = 0;
+        for (int h = 0; h < a.n_heads; ++h) {
+            const int n = a.head_dims[h];
+            float mx = -INFINITY;
+            for (int j = lane; j < n; j += 64) mx = fmaxf(mx, lg[off + j]);
+            for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+            float se = 0.f;
+            for (int j = lane; j < n; j += 64) se += expf(lg[off + j] - mx);
+            for (int d = 32; d > 0; d >>= 1) se += __shfl_xor(se, d, 64);
+            const float lse = mx + logf(se);
+            float pe = 0.f;
+            for (int j = lane; j < n; j += 64) {
+                const float lp = lg[off + j] - lse;
+                pe += expf(lp) * lp;
+            }
+            for (int d = 32; d > 0; d >>= 1) pe += __shfl_xor(pe, d, 64);
+            const int act = (int)a.actions[(size_t)i * a.n_heads + h];  // actions are stored as float (buffers.py:664)
+            logp += lg[off + act] - lse;
+            ent += -pe;
+            if (a.head_entropy) a.head_entropy[(size_t)i * a.n_heads + h] = -pe;
+            if (a.head_lse) a.head_lse[(size_t)i * a.n_heads + h] = lse;
+            off += n;
+        }
+        if (lane == 0) { s_logp[i] = logp; s_ent[i] = ent; }
+    }
+    __syncthreads();
+
+    // ---- losses and dL/dlogp, dL/dv ----
+    float pg = 0.f, vl = 0.f, en = 0.f, kl = 0.f, cf = 0.f;
+    for (int i = tid; i < B; i += kLossThreads) {
+        const float adv = s_adv[i];
+        const float log_ratio = s_logp[i] - a.old_log_prob[i];
+        const float ratio = expf(log_ratio);
+        const float lo = 1.0f - a.clip_range, hi = 1.0f + a.clip_range;
+        const float rc = fminf(fmaxf(ratio, lo), hi);
+        const float s1 = adv * ratio, s2 = adv * rc;
+        pg += -fminf(s1, s2);
+        // d min(s1, s2): the smaller operand takes the gradient, ties split evenly (torch.minimum)
+        const float g1 = s1 < s2 ? 1.f : (s1 > s2 ? 0.f : 0.5f), g2 = 1.f - g1;
+        const float inrange = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+        s_gl[i] = -invB * a.policy_scale * adv * ratio * (g1 + g2 * inrange);
+        cf += fabsf(ratio - 1.0f) > a.clip_range ? 1.f : 0.f;
+        kl += (ratio - 1.0f) - log_ratio;
+        const float v = a.values[i], vo = a.old_values[i];
+        float vp = v, dvp = 1.f;
+        if (a.clip_range_vf > 0.f) {
+            const float dv = v - vo;
+            vp = vo + fminf(fmaxf(dv, -a.clip_range_vf), a.clip_range_vf);
+            dvp = (dv >= -a.clip_range_vf && dv <= a.clip_range_vf) ? 1.f : 0.f;
+        }
+        const float err = vp - a.returns[i];
+        vl += err * err;
+        a.d_values[i] = a.vf_coef * 2.0f * invB * err * dvp;
+        en += -s_ent[i];
+    }
+    pg = block_sum(pg, scratch) * invB;
+    vl = block_sum(vl, scratch) * invB;
+    en = block_sum(en, scratch) * invB;
+    kl = block_sum(kl, scratch) * invB;
+    cf = block_sum(cf, scratch) * invB;
+    const float loss = pg * a.policy_scale + a.ent_coef * en + a.vf_coef * vl;
+    const int stopped_before = a.stop_flag ? *a.stop_flag : 0;
+    __syncthreads();
+    if (tid == 0) {
+        float *row = a.stats + (size_t)(*a.stats_row) * 8;
+        row[0] = pg; row[1] = vl; row[2] = en; row[3] = kl; row[4] = cf; row[5] = loss;
+        row[6] = stopped_before ? 0.f : 1.f;  // row is live (the reference never ran this minibatch otherwise)
+        row[7] = 0.f;
+        *a.stats_row += 1;
+        if (a.stop_flag && a.target_kl > 0.f && kl > 1.5f * a.target_kl) *a.stop_flag = 1;  // sticky (:264-268)
+    }
+
+    // ---- d logits: gl*(onehot - p) + (ent_coef/B) * p*(log p + H_head) ----
+    for (int i = wv; i < B; i += kLossThreads / 64) {
+        const float *lg = a.logits + (size_t)i * a.n_logits;
+        float *dl = a.d_logits + (size_t)i * a.n_logits;
+        const float gl = s_gl[i];
+        int off = 0;
+        for (int h = 0; h < a.n_heads; ++h) {
+            const int n = a.head_dims[h];
+            // recompute the head's lse / entropy (cheap; avoids B x heads of LDS)
+            float mx = -INFINITY;
+            for (int j = lane; j < n; j += 64) mx = fmaxf(mx, lg[off + j]);
+            for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+            float se = 0.f;
+            for (int j = lane; j < n; j += 64) se += expf(lg[off + j] - mx);
+            for (int d = 32; d > 0; d >>= 1) se += __shfl_xor(se, d, 64);
+            const float lse = mx + logf(se);
+            float pe = 0.f;
+            for (int j = lane; j < n; j += 64) {
+                const float lp = lg[off + j] - lse;
+                pe += expf(lp) * lp;
+            }
+            for (int d = 32; d > 0; d >>= 1) pe += __shfl_xor(pe, d, 64);
+            const float H = -pe;
+            const int act = (int)a.actions[(size_t)i * a.n_heads + h];
+            for (int j = lane; j < n; j += 64) {
+                const float lp = lg[off + j] - lse, p = expf(lp);
+                dl[off + j] = gl * ((j == act ? 1.f : 0.f) - p) + a.ent_coef * invB * p * (lp + H);
+            }
+            off += n;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// clip_grad_norm_ + Adam over a flat buffer
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_grad_sqnorm(const float *__restrict__ g, int64_t n, double *__restrict__ partial)
+{
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = (double)g[i];
+        acc += v * v;
+    }
+    __shared__ double s[256];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) s[threadIdx.x] += s[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
+}
+
+// clip coefficient = min(1, max_norm / (total_norm + 1e-6))  (torch.nn.utils.clip_grad_norm_)
+__global__ void k_grad_norm_finalize(const double *__restrict__ partial, int nparts, float max_norm, float *__restrict__ out /*[2]: norm, coef*/)
+{
+    if (threadIdx.x != 0) return;
+    double t = 0.0;
+    for (int i = 0; i < nparts; ++i) t += partial[i];
+    const float norm = (float)sqrt(t);
+    float coef = max_norm / (norm + 1e-6f);
+    coef = coef > 1.0f ? 1.0f : coef;
+    out[0] = norm;
+    out[1] = coef;
+}
+
+__global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                            int64_t n, const float *__restrict__ norm_coef, const int *__restrict__ stop_flag,
+                            const int64_t *__restrict__ step /*already incremented*/, float lr, float beta1, float beta2, float eps)
+{
+    if (stop_flag != nullptr && *stop_flag != 0) return;
+    const float coef = norm_coef ? norm_coef[1] : 1.0f;
+    // bias corrections in double like torch's scalar path (1 - beta**step evaluated in Python floats)
+    const double t = (double)(*step);
+    const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * coef;
+        const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);  // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;  // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+
+__global__ void k_step_increment(int64_t *step, const int *stop_flag)
+{
+    if (stop_flag != nullptr && *stop_flag != 0) return;
+    *step += 1;
+}
+
+// ===========================================================================
+// C-ABI
+// ===========================================================================
+GNBV_API int gnbv_gather_minibatch(const int64_t *rows, int batch, int act_dim, const float *actions, const float *values,
+                                   const float *log_probs, const float *advantages, const float *returns, float *o_actions,
+                                   float *o_values, float *o_log_probs, float *o_adv, float *o_ret, void *stream)
+{
+    GNBV_CHECK_ARG(rows && actions && values && log_probs && advantages && returns && o_actions && o_values && o_log_probs &&
+                   o_adv && o_ret && batch > 0 && act_dim > 0);
+    hipLaunchKernelGGL(k_gather_minibatch, dim3((batch + 255) / 256), dim3(256), 0, gnbv_stream(stream), rows, batch, act_dim,
+                       actions, values, log_probs, advantages, returns, o_actions, o_values, o_log_probs, o_adv, o_ret);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_ppo_loss(const GnbvPpoLoss *a, void *stream)
+{
+    GNBV_CHECK_ARG(a && a->batch > 1 && a->n_heads > 0 && a->n_heads <= kMaxHeads && a->n_logits > 0);
+    GNBV_CHECK_ARG(a->logits && a->values && a->actions && a->old_values && a->old_log_prob && a->advantages && a->returns);
+    GNBV_CHECK_ARG(a->d_logits && a->d_values && a->stats && a->stats_row);
+    int sum = 0;
+    for (int h = 0; h < a->n_heads; ++h) sum += a->head_dims[h];
+    GNBV_CHECK_ARG(sum == a->n_logits && (size_t)a->batch * 4 * sizeof(float) <= 60 * 1024);
+    hipLaunchKernelGGL(k_ppo_loss, dim3(1), dim3(kLossThreads), (size_t)a->batch * 4 * sizeof(float), gnbv_stream(stream), *a);
+    return gnbv_launch_status();
+}
+
+GNBV_API size_t gnbv_adam_workspace_bytes(void) { return 1024 * sizeof(double) + 64; }
+
+GNBV_API int gnbv_clip_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float max_grad_norm,
+                                 float lr, float beta1, float beta2, float eps, int64_t *step, const int *stop_flag,
+                                 float *norm_out /*[2]: total norm, clip coefficient*/, void *workspace, size_t workspace_bytes,
+                                 void *stream)
+{
+    GNBV_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && step && norm_out && workspace && n > 0);
+    GNBV_CHECK_ARG(workspace_bytes >= gnbv_adam_workspace_bytes());
+    hipStream_t st = gnbv_stream(stream);
+    double *partial = (double *)workspace;
+    int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    hipLaunchKernelGGL(k_grad_sqnorm, dim3(blocks), dim3(256), 0, st, grads, n, partial);
+    hipLaunchKernelGGL(k_grad_norm_finalize, dim3(1), dim3(64), 0, st, partial, blocks, max_grad_norm, norm_out);
+    hipLaunchKernelGGL(k_step_increment, dim3(1), dim3(1), 0, st, step, stop_flag);
+    int ab = (int)((n + 255) / 256);
+    ab = ab > 4096 ? 4096 : ab;
+    hipLaunchKernelGGL(k_adam_flat, dim3(ab), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n,
+                       max_grad_norm > 0.f ? norm_out : (const float *)nullptr, stop_flag, step, lr, beta1, beta2, eps);
+    return gnbv_launch_status();
+}

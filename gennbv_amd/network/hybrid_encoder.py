@@ -60,6 +60,9 @@ class Hybrid_Encoder(nn.Module):
         self.naive_encoder_action = nn.Sequential(nn.Linear(pose_feat, 256), nn.ReLU(inplace=True),
                                                   nn.Linear(256, 256), nn.ReLU(inplace=True))
         self.output_layer = nn.Sequential(nn.Linear(512, 256), nn.ReLU(inplace=True))
+        # 2**arange(2); kept on the module's device (not in the state_dict) so that the forward is
+        # capturable in a hipGraph -- the reference re-creates and uploads it on every call (:71)
+        self.register_buffer("_freq_bands", 2 ** torch.arange(2).float(), persistent=False)
 
     @property
     def features_dim(self) -> int:
@@ -68,7 +71,7 @@ class Hybrid_Encoder(nn.Module):
     def positional_encoding(self, positions: torch.Tensor, freqs: int = 2) -> torch.Tensor:
         """[..., A] -> [..., 4A]: cat(sin(p), cos(p)) of p = (x0*1, x0*2, x1*1, ...)
         (hybrid_encoder.py:63-74)."""
-        freq_bands = (2 ** torch.arange(freqs).float()).to(positions.device)
+        freq_bands = self._freq_bands if freqs == 2 else (2 ** torch.arange(freqs).float()).to(positions.device)
         pts = (positions[..., None] * freq_bands).reshape(positions.shape[:-1] + (freqs * positions.shape[-1],))
         return torch.cat([torch.sin(pts), torch.cos(pts)], dim=-1)
 

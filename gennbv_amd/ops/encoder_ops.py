@@ -138,6 +138,6 @@ def hybrid_forward(enc, observations) -> torch.Tensor:
     num_env = state.shape[0]
     action_input = enc.positional_encoding(state.view(num_env, -1, 6)).view(num_env, -1)
     feature_action = enc.naive_encoder_action(action_input)
-    feature_grid = grid_encoder(base, rows, s, g, enc.naive_encoder_grid, enc.training)
+    feature_grid = grid_encoder(base, rows, s, g, enc.naive_encoder_grid, enc.training, getattr(enc, "_bn_skip_flag", None))
     feature_grid = enc.output_layer_grid(feature_grid)
     return enc.output_layer(torch.cat((feature_action, feature_grid), dim=-1))

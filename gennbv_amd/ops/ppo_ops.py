@@ -1,0 +1,111 @@
+"""Host side of the PPO minibatch kernels (gennbv_amd/csrc/ppo.hip)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+
+from .. import _lib
+
+
+class FlatAdam:
+    """clip_grad_norm_ + torch.optim.Adam over ONE flat fp32 buffer.
+
+    The module's parameters are re-pointed at slices of `self.params` (and their `.grad` at
+    slices of `self.grads`), so autograd accumulates straight into the flat gradient buffer and
+    one kernel pair (norm, update) replaces torch's ~60 per-tensor launches
+    (stable_baselines3/ppo/ppo_grid_obs.py:271-275; Adam eps 1e-5, policies.py:851-855)."""
+
+    def __init__(self, module: torch.nn.Module, lr: float, betas=(0.9, 0.999), eps: float = 1e-5):
+        self.lib = _lib.load()
+        ps = [p for p in module.parameters() if p.requires_grad]
+        dev = ps[0].device
+        _lib.require_cuda(ps[0])
+        n = sum(p.numel() for p in ps)
+        self.n = n
+        self.params = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.ws = torch.empty(self.lib.gnbv_adam_workspace_bytes(), dtype=torch.uint8, device=dev)
+        self.lr, self.betas, self.eps = lr, betas, eps
+        off = 0
+        self.slices = []
+        for p in ps:
+            k = p.numel()
+            self.params[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.params[off:off + k].view_as(p)
+            p.grad = self.grads[off:off + k].view_as(p)
+            self.slices.append((off, k))
+            off += k
+        self.module_params = ps
+
+    def zero_grad(self):
+        self.grads.zero_()
+
+    def step(self, max_grad_norm: float, stop_flag: Optional[torch.Tensor] = None):
+        _lib.check(self.lib.gnbv_clip_adam_step(
+            self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.n,
+            float(max_grad_norm if max_grad_norm is not None else -1.0), float(self.lr), float(self.betas[0]),
+            float(self.betas[1]), float(self.eps), self.step_count.data_ptr(), _lib.ptr(stop_flag), self.norm_out.data_ptr(),
+            self.ws.data_ptr(), self.ws.numel(), _lib.stream_ptr(self.params.device)), "gnbv_clip_adam_step")
+
+    def load_torch_adam_state(self, opt: torch.optim.Adam):
+        """Adopt exp_avg / exp_avg_sq / step of a torch Adam over the same parameters (checkpoints)."""
+        for (off, k), p in zip(self.slices, self.module_params):
+            st = opt.state.get(p)
+            if st:
+                self.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                self.step_count.fill_(int(st["step"]))
+
+
+class PpoLossOp:
+    """Static buffers + the fused loss/gradient kernel for minibatches of a fixed size."""
+
+    def __init__(self, batch: int, head_dims: List[int], device, max_rows: int, clip_range: float, clip_range_vf,
+                 ent_coef: float, vf_coef: float, policy_scale: float, target_kl, normalize_advantage: bool = True):
+        self.lib = _lib.load()
+        self.batch, self.head_dims = batch, list(head_dims)
+        n_logits, nh = sum(head_dims), len(head_dims)
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=device)  # noqa: E731
+        self.rows = z(batch, dt=torch.int64)
+        self.actions, self.old_values, self.old_log_prob = z(batch, nh), z(batch), z(batch)
+        self.advantages, self.returns = z(batch), z(batch)
+        self.d_logits, self.d_values = z(batch, n_logits), z(batch)
+        self.stats = z(max_rows + 1, 8)
+        self.stats_row = z(1, dt=torch.int64)
+        self.stop_flag = z(1, dt=torch.int32)
+        a = _lib.GnbvPpoLoss()
+        a.batch, a.n_logits, a.n_heads = batch, n_logits, nh
+        for i, d in enumerate(head_dims):
+            a.head_dims[i] = int(d)
+        a.normalize_advantage = int(normalize_advantage)
+        a.clip_range = float(clip_range)
+        a.clip_range_vf = float(clip_range_vf) if clip_range_vf is not None else -1.0
+        a.ent_coef, a.vf_coef, a.policy_scale = float(ent_coef), float(vf_coef), float(policy_scale)
+        a.target_kl = float(target_kl) if target_kl is not None else -1.0
+        a.actions, a.old_values, a.old_log_prob = self.actions.data_ptr(), self.old_values.data_ptr(), self.old_log_prob.data_ptr()
+        a.advantages, a.returns = self.advantages.data_ptr(), self.returns.data_ptr()
+        a.d_logits, a.d_values = self.d_logits.data_ptr(), self.d_values.data_ptr()
+        a.head_entropy, a.head_lse = None, None
+        a.stats, a.stats_row, a.stop_flag = self.stats.data_ptr(), self.stats_row.data_ptr(), self.stop_flag.data_ptr()
+        self.args = a
+        self.device = device
+
+    def gather(self, buf):
+        """actions / values / log_probs / advantages / returns of rows `self.rows` (row = t*N + n)."""
+        _lib.check(self.lib.gnbv_gather_minibatch(
+            self.rows.data_ptr(), self.batch, self.actions.shape[1], buf.actions.data_ptr(), buf.values.data_ptr(),
+            buf.log_probs.data_ptr(), buf.advantages.data_ptr(), buf.returns.data_ptr(), self.actions.data_ptr(),
+            self.old_values.data_ptr(), self.old_log_prob.data_ptr(), self.advantages.data_ptr(), self.returns.data_ptr(),
+            _lib.stream_ptr(self.device)), "gnbv_gather_minibatch")
+
+    def __call__(self, logits: torch.Tensor, values: torch.Tensor):
+        assert logits.is_contiguous() and values.is_contiguous() and logits.dtype == torch.float32
+        self.args.logits, self.args.values = logits.data_ptr(), values.data_ptr()
+        _lib.check(self.lib.gnbv_ppo_loss(C.byref(self.args), _lib.stream_ptr(self.device)), "gnbv_ppo_loss")
+        return self.d_logits, self.d_values

@@ -55,6 +55,7 @@ class TensorRolloutBuffer_Grid_Obs:
         self.returns = torch.zeros(t, n, 1, device=dev)
         self.advantages = torch.zeros(t, n, 1, device=dev)
         self.privileged_observations = None
+        self.lazy_obs = False  # True: minibatch observations are RowGather views (gather fused into conv1)
         self.reset()
 
     def reset(self) -> None:
@@ -122,8 +123,13 @@ class TensorRolloutBuffer_Grid_Obs:
         rows = self.rows_of(batch_inds)
         t, n = self.buffer_size, self.n_envs
         flat = lambda x: x.view(x.shape[0] * n, *x.shape[2:])  # noqa: E731
+        if self.lazy_obs:
+            from ..ops.encoder_ops import RowGather
+            obs = RowGather(flat(self.observations[:t]), rows)
+        else:
+            obs = flat(self.observations[:t])[rows]
         return RolloutBufferSamples(
-            flat(self.observations[:t])[rows], flat(self.actions)[rows], flat(self.values)[rows].flatten(),
+            obs, flat(self.actions)[rows], flat(self.values)[rows].flatten(),
             flat(self.log_probs)[rows].flatten(), flat(self.advantages)[rows].flatten(), flat(self.returns)[rows].flatten())
 
     def flat_values_returns(self):

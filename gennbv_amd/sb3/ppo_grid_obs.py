@@ -83,6 +83,9 @@ class PPO_Grid_Obs:
         self._logger = Logger(verbose)
         self.policy_loss_scale = 10.0  # ppo_grid_obs.py:253
         self.kl_poll = "minibatch"
+        self.train_impl = "hip"   # fused loss / flat Adam / device-side early stop when the encoder backend is "hip"
+        self.use_graph = True     # replay the minibatch step as one hipGraph
+        self._hip = None
         if _init_setup_model:
             self._setup_model()
 
@@ -111,6 +114,7 @@ class PPO_Grid_Obs:
                                                            gae_lambda=self.gae_lambda, n_envs=self.n_envs)
         self.policy = self.policy_class(self.observation_space, self.action_space, self.lr_schedule, use_sde=False,
                                         **self.policy_kwargs).to(self.device)
+        self.rollout_buffer.lazy_obs = getattr(self.policy.features_extractor, "backend", "torch") == "hip"
         self.clip_range = _schedule(self.clip_range)
         if self.clip_range_vf is not None:
             if isinstance(self.clip_range_vf, (float, int)):
@@ -126,6 +130,8 @@ class PPO_Grid_Obs:
     # ------------------------------------------------------------------------------
     def train(self) -> None:
         """Update the policy on the gathered rollout buffer (ppo_grid_obs.py:176-297)."""
+        if getattr(self.policy.features_extractor, "backend", "torch") == "hip" and self.train_impl == "hip":
+            return self._train_hip()
         training_start = time.time()
         self.policy.set_training_mode(True)
         self._update_learning_rate(self.policy.optimizer)
@@ -192,6 +198,127 @@ class PPO_Grid_Obs:
         if clip_range_vf is not None:
             self.logger.record("train/clip_range_vf", clip_range_vf)
         self.logger.record("time/training", time.time() - training_start)
+
+    # ------------------------------------------------------------------------------
+    def _hip_setup(self, batch: int, n_minibatches: int):
+        from ..ops.ppo_ops import FlatAdam, PpoLossOp
+        pc = self
+        loss = PpoLossOp(batch, list(self.action_space.nvec), self.device, self.n_epochs * n_minibatches,
+                         self.clip_range(1.0), None if self.clip_range_vf is None else self.clip_range_vf(1.0),
+                         self.ent_coef, self.vf_coef, self.policy_loss_scale, self.target_kl, self.normalize_advantage)
+        opt = self._hip["opt"] if self._hip else None
+        if opt is None:
+            old = self.policy.optimizer
+            opt = FlatAdam(self.policy, lr=self.lr_schedule(1.0), eps=old.defaults.get("eps", 1e-5),
+                           betas=old.defaults.get("betas", (0.9, 0.999)))
+            opt.load_torch_adam_state(old)
+        self._hip = {"loss": loss, "opt": opt, "batch": batch, "n_mb": n_minibatches, "graph": None}
+        self.policy.features_extractor._bn_skip_flag = loss.stop_flag
+        return self._hip
+
+    def _hip_minibatch_body(self, st):
+        """gather -> forward -> fused loss + d(logits, values) -> backward -> clip + Adam; no host sync."""
+        from ..ops.encoder_ops import RowGather
+        buf, pol, loss, opt = self.rollout_buffer, self.policy, st["loss"], st["opt"]
+        t, n = buf.buffer_size, buf.n_envs
+        loss.gather(buf)
+        obs = RowGather(buf.observations[:t].view(t * n, -1), loss.rows)
+        features = pol.extract_features(obs)
+        logits = pol.action_net(features)
+        values = pol.value_net(features).flatten()
+        d_logits, d_values = loss(logits, values)
+        opt.zero_grad()
+        torch.autograd.backward([logits, values], [d_logits, d_values])
+        opt.step(self.max_grad_norm, loss.stop_flag)
+
+    def _train_hip(self) -> None:
+        """train() on the gfx950 kernels: same arithmetic as the reference loop
+        (ppo_grid_obs.py:196-275), zero host synchronisation inside an epoch."""
+        training_start = time.time()
+        buf = self.rollout_buffer
+        total = buf.buffer_size * buf.n_envs
+        batch = int(self.batch_size)
+        assert total % batch == 0, "the fused train path needs n_steps*n_envs to be a multiple of batch_size"
+        n_mb = total // batch
+        st = self._hip
+        if st is None or st["batch"] != batch or st["n_mb"] != n_mb:
+            st = self._hip_setup(batch, n_mb)
+        loss, opt = st["loss"], st["opt"]
+        self.policy.set_training_mode(True)
+        lr = self.lr_schedule(self._current_progress_remaining)
+        self.logger.record("train/learning_rate", lr)
+        opt.lr = lr
+        clip_range = self.clip_range(self._current_progress_remaining)
+        clip_range_vf = None if self.clip_range_vf is None else self.clip_range_vf(self._current_progress_remaining)
+        loss.args.clip_range = float(clip_range)
+        loss.args.clip_range_vf = float(clip_range_vf) if clip_range_vf is not None else -1.0
+        loss.stats_row.zero_()
+        loss.stop_flag.zero_()
+        idx = torch.from_numpy(np.asarray(buf.indices, dtype=np.int64)).to(self.device)
+        rows_all = buf.rows_of(idx)  # the reference's flattened index -> row of the [T, N] layout
+        use_graph = self.use_graph and self.device.type == "cuda"
+        hyper = (float(lr), float(clip_range), None if clip_range_vf is None else float(clip_range_vf))
+        if st.get("hyper") != hyper:
+            st["graph"], st["hyper"] = None, hyper  # kernel arguments are baked into the graph: re-capture
+        if use_graph and st["graph"] is None:
+            loss.rows.copy_(rows_all[:batch])
+            st["graph"] = self._capture_minibatch_graph(st)
+            loss.stats_row.zero_()
+            loss.stop_flag.zero_()
+        epochs_run = 0
+        for epoch in range(self.n_epochs):
+            for k in range(n_mb):
+                loss.rows.copy_(rows_all[k * batch:(k + 1) * batch])
+                if use_graph:
+                    st["graph"].replay()
+                else:
+                    self._hip_minibatch_body(st)
+            epochs_run += 1
+            # the ONLY read-back inside train(): early-stop flag, once per epoch (the reference
+            # reads approx_kl on the host after every minibatch, :261-268)
+            if self.target_kl is not None and int(loss.stop_flag.item()) != 0:
+                if self.verbose >= 1:
+                    print(f"Early stopping at step {epoch} due to reaching max kl")
+                break
+        self._n_updates += self.n_epochs
+        rows_done = int(loss.stats_row.item())
+        s = loss.stats[:rows_done].double().cpu().numpy()
+        s = s[s[:, 6] > 0.5]  # minibatches the reference would have executed
+        self.last_train_stats = s
+        last_epoch = (len(s) - 1) // n_mb
+        v_flat, r_flat = buf.flat_values_returns()
+        var_y = torch.var(r_flat, unbiased=False)
+        explained_var = float("nan") if float(var_y) == 0 else float(1 - torch.var(r_flat - v_flat, unbiased=False) / var_y)
+        self.logger.record("train/entropy_loss", float(np.mean(s[:, 2])))
+        self.logger.record("train/policy_gradient_loss", float(np.mean(s[:, 0])))
+        self.logger.record("train/value_loss", float(np.mean(s[:, 1])))
+        self.logger.record("train/approx_kl", float(np.mean(s[last_epoch * n_mb:, 3])))
+        self.logger.record("train/clip_fraction", float(np.mean(s[:, 4])))
+        self.logger.record("train/loss", float(s[-1, 5]))
+        self.logger.record("train/explained_variance", explained_var)
+        self.logger.record("train/n_updates", self._n_updates)
+        self.logger.record("train/clip_range", clip_range)
+        if clip_range_vf is not None:
+            self.logger.record("train/clip_range_vf", clip_range_vf)
+        self.logger.record("time/training", time.time() - training_start)
+
+    def _capture_minibatch_graph(self, st):
+        """Capture gather+forward+loss+backward+Adam of one minibatch as a hipGraph.  Warm-up runs
+        happen on a side stream with the update masked (stop_flag = 1), so parameters, Adam state
+        and BatchNorm running statistics are untouched."""
+        loss = st["loss"]
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                loss.stop_flag.fill_(1)
+                self._hip_minibatch_body(st)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        loss.stop_flag.fill_(1)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._hip_minibatch_body(st)
+        return g
 
     # ------------------------------------------------------------------------------
     def _env_step(self, actions, obs_out):

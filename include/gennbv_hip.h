@@ -218,6 +218,49 @@ int gnbv_gae_sb3(const float *rewards, const float *values, const uint8_t *episo
 int gnbv_gae_rsl(const float *rewards, const float *values, const uint8_t *dones, const float *last_values,
                  int t_steps, int n, double gamma, double lam, float *returns, float *advantages, void *stream);
 
+/* ------------------------------------------------------------------------- */
+/* C3/C4  minibatch gather + PPO loss + clip/Adam                               */
+/*        stable_baselines3/common/buffers.py:753-762, ppo/ppo_grid_obs.py:196-275 */
+/* ------------------------------------------------------------------------- */
+/* rows [batch] int64 index the flattened [T*N] arrays (row = t*N + n). */
+int gnbv_gather_minibatch(const int64_t *rows, int batch, int act_dim, const float *actions, const float *values,
+                          const float *log_probs, const float *advantages, const float *returns, float *o_actions,
+                          float *o_values, float *o_log_probs, float *o_adv, float *o_ret, void *stream);
+
+/* One launch: advantage normalisation, MultiCategorical log-prob / entropy, clipped surrogate,
+ * clipped value loss, entropy loss, loss = policy_scale*pg + ent_coef*ent + vf_coef*vl,
+ * approx-KL, clip fraction, and d loss / d logits, d loss / d values.
+ * stats row (8 floats) = pg, vl, ent, approx_kl, clip_fraction, loss, live, 0 is written at
+ * stats[*stats_row] and *stats_row is incremented; *stop_flag becomes 1 (sticky) when
+ * approx_kl > 1.5*target_kl (target_kl <= 0: never). [host struct, device pointers] */
+typedef struct GnbvPpoLoss {
+    int batch, n_logits, n_heads;
+    int head_dims[8];
+    int normalize_advantage;
+    float clip_range, clip_range_vf /* <= 0: no value clipping */, ent_coef, vf_coef, policy_scale, target_kl;
+    const float *logits;        /* [B, n_logits] */
+    const float *values;        /* [B] */
+    const float *actions;       /* [B, n_heads] stored as float like the reference buffer */
+    const float *old_values, *old_log_prob, *advantages, *returns; /* [B] */
+    float *d_logits;            /* out [B, n_logits] */
+    float *d_values;            /* out [B] */
+    float *head_entropy;        /* out [B, n_heads] or NULL */
+    float *head_lse;            /* out [B, n_heads] or NULL */
+    float *stats;               /* [rows, 8] */
+    int64_t *stats_row;         /* in/out [1] */
+    int *stop_flag;             /* in/out [1] or NULL */
+} GnbvPpoLoss;
+
+int gnbv_ppo_loss(const GnbvPpoLoss *args /*[host]*/, void *stream);
+
+/* torch.nn.utils.clip_grad_norm_(max_grad_norm) + torch.optim.Adam step over ONE flat fp32
+ * buffer of n parameters (max_grad_norm <= 0: no clipping). *step is incremented and the
+ * update applied unless *stop_flag != 0. norm_out[0] = total norm, [1] = clip coefficient. */
+size_t gnbv_adam_workspace_bytes(void);
+int gnbv_clip_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float max_grad_norm,
+                        float lr, float beta1, float beta2, float eps, int64_t *step, const int *stop_flag, float *norm_out,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,105 @@
+"""GPU: PPO_Grid_Obs.train() on the fused gfx950 path (HIP encoder, fused loss kernel, flat Adam,
+device-side early stop, hipGraph replay) against the reference's train() goldens (F9)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as gu
+from tests.test_policy_ppo_cpu import _ppo_from_fixture
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _check(ppo, fx, loss_tol=1e-4):
+    ppo.train()
+    log = ppo.logger.name_to_value
+    for k in ("train/entropy_loss", "train/policy_gradient_loss", "train/value_loss", "train/approx_kl",
+              "train/clip_fraction", "train/loss", "train/explained_variance"):
+        ref = float(fx["log/" + k])
+        assert abs(float(log[k]) - ref) <= loss_tol * max(1.0, abs(ref)), (k, log[k], ref)
+    if ppo._hip is not None:
+        assert int(ppo._hip["opt"].step_count.item()) == int(fx["n_optimizer_steps"])  # early-stop position
+    for name, p in ppo.policy.named_parameters():
+        a = p.detach().cpu().numpy()
+        mine = a if a.size <= 70000 else a.reshape(-1)[::97]
+        np.testing.assert_allclose(mine, fx["final/" + name], rtol=2e-3, atol=3e-4, err_msg=name)
+    for k, v in ppo.policy.state_dict().items():
+        if "running" in k:
+            np.testing.assert_allclose(v.cpu().numpy(), fx["final_bn/" + k], rtol=1e-4, atol=1e-5)
+        if "num_batches" in k:
+            assert int(v) == int(fx["final_bn/" + k]), k
+
+
+@pytest.mark.parametrize("name", ["F9_ppo_train", "F9_ppo_train_earlystop"])
+@pytest.mark.parametrize("graph", [False, True])
+def test_fused_train_matches_reference(name, graph):
+    fx = gu.load(name)
+    ppo = _ppo_from_fixture(fx, device=DEV, backend="hip")
+    ppo.use_graph = graph
+    _check(ppo, fx)
+
+
+def test_torch_backend_on_gpu_matches_reference_losses():
+    """The torch-module path on the GPU (library conv/BN) also reproduces the logged losses."""
+    fx = gu.load("F9_ppo_train")
+    ppo = _ppo_from_fixture(fx, device=DEV, backend="torch")
+    _check(ppo, fx, loss_tol=2e-4)
+
+
+def test_ppo_loss_kernel_vs_torch_autograd():
+    """d(loss)/d(logits, values) and the six statistics of k_ppo_loss against torch autograd on
+    the reference's loss expression (ppo_grid_obs.py:209-262)."""
+    from gennbv_amd.ops.ppo_ops import PpoLossOp
+    from gennbv_amd.sb3.distributions import MultiCategoricalDistribution
+    torch.manual_seed(0)
+    B, dims = 96, [81, 81, 51, 1, 13, 13]
+    op = PpoLossOp(B, dims, DEV, 4, 0.2, 0.2, 0.01, 0.8, 10.0, 0.05)
+    logits = torch.randn(B, sum(dims), device=DEV, requires_grad=True)
+    values = torch.randn(B, device=DEV, requires_grad=True)
+    op.actions.copy_(torch.stack([torch.randint(0, n, (B,)) for n in dims], -1).float())
+    op.old_values.copy_(values.detach() + 0.3 * torch.randn(B, device=DEV))
+    op.advantages.copy_(torch.randn(B, device=DEV) * 2 + 0.5)
+    op.returns.copy_(torch.randn(B, device=DEV))
+    dist = MultiCategoricalDistribution(dims).proba_distribution(logits)
+    log_prob, entropy = dist.log_prob(op.actions), dist.entropy()
+    op.old_log_prob.copy_(log_prob.detach() + 0.25 * torch.randn(B, device=DEV))
+    adv = (op.advantages - op.advantages.mean()) / (op.advantages.std() + 1e-8)
+    ratio = torch.exp(log_prob - op.old_log_prob)
+    pg = -torch.min(adv * ratio, adv * torch.clamp(ratio, 0.8, 1.2)).mean()
+    vp = op.old_values + torch.clamp(values - op.old_values, -0.2, 0.2)
+    vl = torch.nn.functional.mse_loss(op.returns, vp)
+    el = -entropy.mean()
+    loss = 10 * pg + 0.01 * el + 0.8 * vl
+    loss.backward()
+    dl, dv = op(logits.detach().contiguous(), values.detach().contiguous())
+    torch.testing.assert_close(dl, logits.grad, rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(dv, values.grad, rtol=1e-4, atol=1e-7)
+    st = op.stats[0].cpu()
+    lr_ = (log_prob - op.old_log_prob).detach()
+    ref = torch.tensor([pg.item(), vl.item(), el.item(), ((torch.exp(lr_) - 1) - lr_).mean().item(),
+                        (torch.abs(ratio - 1) > 0.2).float().mean().item(), loss.item()])
+    torch.testing.assert_close(st[:6], ref, rtol=1e-5, atol=1e-6)
+    assert int(op.stats_row.item()) == 1 and int(op.stop_flag.item()) == int(ref[3] > 0.075)
+
+
+def test_flat_adam_matches_torch_adam_with_clipping():
+    from gennbv_amd.ops.ppo_ops import FlatAdam
+    torch.manual_seed(1)
+    m1 = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.Linear(19, 5)).to(DEV)
+    m2 = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.Linear(19, 5)).to(DEV)
+    m2.load_state_dict(m1.state_dict())
+    o1 = torch.optim.Adam(m1.parameters(), lr=3e-3, eps=1e-5)
+    o2 = FlatAdam(m2, lr=3e-3, eps=1e-5)
+    x = torch.randn(64, 37, device=DEV)
+    for it in range(25):
+        o1.zero_grad(); o2.zero_grad()
+        (m1(x) ** 2).sum().backward(); (m2(x) ** 2).sum().backward()
+        torch.nn.utils.clip_grad_norm_(m1.parameters(), 1.0)
+        o1.step(); o2.step(1.0)
+    for a, b in zip(m1.parameters(), m2.parameters()):
+        torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6)
+    flag = torch.ones(1, dtype=torch.int32, device=DEV)
+    before = o2.params.clone()
+    o2.step(1.0, flag)  # masked: nothing moves, step count frozen
+    assert torch.equal(before, o2.params) and int(o2.step_count.item()) == 25
