@@ -264,14 +264,21 @@ __global__ __launch_bounds__(256) void k_bn2_bwd_reduce(const float *__restrict_
 }
 
 // sums over b of the [B][16][2] partials -> S[2][16] (fp64 accumulate)
-__global__ void k_bn2_bwd_finalize(const float *__restrict__ partials, int B, double *__restrict__ S)
+__global__ __launch_bounds__(256) void k_bn2_bwd_finalize(const float *__restrict__ partials, int B, double *__restrict__ S)
 {
-    const int t = threadIdx.x;  // 32 threads: (which, c)
-    if (t >= 2 * kC) return;
-    const int which = t / kC, c = t % kC;
+    // 32 outputs (which, c) x 8 slices of b; fixed summation order
+    __shared__ double sh[8][32];
+    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int which = o / kC, c = o % kC;
     double acc = 0.0;
-    for (int b = 0; b < B; ++b) acc += (double)partials[((size_t)b * kC + c) * 2 + which];
-    S[which * kC + c] = acc;
+    for (int b = sl; b < B; b += 8) acc += (double)partials[((size_t)b * kC + c) * 2 + which];
+    sh[sl][o] = acc;
+    __syncthreads();
+    if (sl == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 8; ++i) t += sh[i][o];
+        S[which * kC + c] = t;
+    }
 }
 
 // pass 2: dy2 (channels-last [B,P2,16]) = scale*(dz' - S1/M - xhat*S2/M)
@@ -602,7 +609,7 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
                        bn2 + 3 * kC, P2, w.bn_part);
     if ((err = gnbv_launch_status())) return err;
     double *S2 = w.red + 128;
-    hipLaunchKernelGGL(k_bn2_bwd_finalize, dim3(1), dim3(64), 0, st, w.bn_part, batch, S2);
+    hipLaunchKernelGGL(k_bn2_bwd_finalize, dim3(1), dim3(256), 0, st, w.bn_part, batch, S2);
     if ((err = gnbv_launch_status())) return err;
     const int64_t total2 = (int64_t)batch * P2 * kC;
     int gx = (int)((total2 + 255) / 256);

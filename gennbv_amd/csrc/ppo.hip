@@ -1,10 +1,10 @@
 // ppo.hip -- the PPO minibatch update of stable_baselines3/ppo/ppo_grid_obs.py:196-275 on MI355X:
 //   * k_gather_minibatch   the five per-sample gathers of buffers.py:753-762 in one launch
-//   * k_ppo_loss           advantage normalisation (:214-216), MultiCategorical log-prob / entropy
+//   * k_ppo_logp / k_ppo_scalars / k_ppo_dlogits   advantage normalisation (:214-216), MultiCategorical log-prob / entropy
 //                          (distributions.py:321-332), clipped surrogate (:219-224), clipped value
 //                          loss (:231-241), entropy loss (:245-249), loss = 10*pg + c_e*ent + c_v*vl
 //                          (:253), approx-KL (:259-262) AND the analytic gradient of the loss with
-//                          respect to the logits and the values -- one workgroup, one launch,
+//                          respect to the logits and the values -- three small launches
 //                          instead of ~100 tiny torch kernels forward + backward;
 //                          sets the sticky early-stop flag (:264-268) on the device.
 //   * k_grad_sqnorm / k_adam_flat   clip_grad_norm_(max_norm) + Adam(eps=1e-5) (:271-275) over ONE
@@ -46,17 +46,54 @@ __device__ __forceinline__ float block_sum(float v, float *scratch /*[kLossThrea
     return t;
 }
 
-__global__ __launch_bounds__(kLossThreads) void k_ppo_loss(GnbvPpoLoss a)
+// head statistics of one sample, computed by one wave (lanes stride over the categories)
+struct HeadStats { float lse, ent; };
+__device__ __forceinline__ HeadStats head_stats(const float *lg, int n, int lane)
 {
-    extern __shared__ float smem[];
-    float *s_adv = smem;                 // [B] normalised advantage
-    float *s_gl = smem + a.batch;        // [B] dL/dlogp
-    float *s_logp = smem + 2 * a.batch;  // [B]
-    float *s_ent = smem + 3 * a.batch;   // [B]
+    float mx = -INFINITY;
+    for (int j = lane; j < n; j += 64) mx = fmaxf(mx, lg[j]);
+    for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    float se = 0.f;
+    for (int j = lane; j < n; j += 64) se += expf(lg[j] - mx);
+    for (int d = 32; d > 0; d >>= 1) se += __shfl_xor(se, d, 64);
+    const float lse = mx + logf(se);
+    float pe = 0.f;
+    for (int j = lane; j < n; j += 64) {
+        const float lp = lg[j] - lse;
+        pe += expf(lp) * lp;
+    }
+    for (int d = 32; d > 0; d >>= 1) pe += __shfl_xor(pe, d, 64);
+    return {lse, -pe};
+}
+
+// launch 1: one wave per sample -> log-prob of the taken actions, entropy (sums over the heads)
+__global__ __launch_bounds__(kLossThreads) void k_ppo_logp(GnbvPpoLoss a, float *__restrict__ logp_out, float *__restrict__ ent_out)
+{
+    const int lane = threadIdx.x & 63, i = blockIdx.x * (kLossThreads / 64) + (threadIdx.x >> 6);
+    if (i >= a.batch) return;
+    const float *lg = a.logits + (size_t)i * a.n_logits;
+    float logp = 0.f, ent = 0.f;
+    int off = 0;
+    for (int h = 0; h < a.n_heads; ++h) {
+        const int n = a.head_dims[h];
+        const HeadStats hs = head_stats(lg + off, n, lane);
+        const int act = (int)a.actions[(size_t)i * a.n_heads + h];  // actions are stored as float (buffers.py:664)
+        logp += lg[off + act] - hs.lse;
+        ent += hs.ent;
+        if (a.head_entropy && lane == 0) a.head_entropy[(size_t)i * a.n_heads + h] = hs.ent;
+        if (a.head_lse && lane == 0) a.head_lse[(size_t)i * a.n_heads + h] = hs.lse;
+        off += n;
+    }
+    if (lane == 0) { logp_out[i] = logp; ent_out[i] = ent; }
+}
+
+// launch 2: one workgroup -> advantage normalisation, the scalar losses, dL/dlogp, dL/dv, flags
+__global__ __launch_bounds__(kLossThreads) void k_ppo_scalars(GnbvPpoLoss a, const float *__restrict__ logp_in,
+                                                             const float *__restrict__ ent_in, float *__restrict__ gl_out)
+{
     __shared__ float scratch[kLossThreads / 64 + 1];
     const int B = a.batch, tid = threadIdx.x;
     const float invB = 1.0f / (float)B;
-
     // ---- advantage normalisation: (A - mean) / (std_unbiased + 1e-8) ----
     float s = 0.f;
     for (int i = tid; i < B; i += kLossThreads) s += a.advantages[i];
@@ -68,48 +105,10 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_loss(GnbvPpoLoss a)
     }
     const float var = block_sum(q, scratch) / (float)(B > 1 ? B - 1 : 1);
     const float inv_std = 1.0f / (sqrtf(var) + 1e-8f);
-    for (int i = tid; i < B; i += kLossThreads) s_adv[i] = a.normalize_advantage ? (a.advantages[i] - mean) * inv_std : a.advantages[i];
-
-    // ---- per (sample, head): log-softmax, log-prob of the taken action, entropy ----
-    for (int i = tid; i < B; i += kLossThreads) { s_logp[i] = 0.f; s_ent[i] = 0.f; }
-    __syncthreads();
-    // one wave per sample: lanes stride over the head's categories
-    const int lane = tid & 63, wv = tid >> 6;
-    for (int i = wv; i < B; i += kLossThreads / 64) {
-        const float *lg = a.logits + (size_t)i * a.n_logits;
-        float logp = 0.f, ent = 0.f;
-        int off = 0;
-        for (int h = 0; h < a.n_heads; ++h) {
-            const int n = a.head_dims[h];
-            float mx = -INFINITY;
-            for (int j = lane; j < n; j += 64) mx = fmaxf(mx, lg[off + j]);
-            for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
-            float se = 0.f;
-            for (int j = lane; j < n; j += 64) se += expf(lg[off + j] - mx);
-            for (int d = 32; d > 0; d >>= 1) se += __shfl_xor(se, d, 64);
-            const float lse = mx + logf(se);
-            float pe = 0.f;
-            for (int j = lane; j < n; j += 64) {
-                const float lp = lg[off + j] - lse;
-                pe += expf(lp) * lp;
-            }
-            for (int d = 32; d > 0; d >>= 1) pe += __shfl_xor(pe, d, 64);
-            const int act = (int)a.actions[(size_t)i * a.n_heads + h];  // actions are stored as float (buffers.py:664)
-            logp += lg[off + act] - lse;
-            ent += -pe;
-            if (a.head_entropy) a.head_entropy[(size_t)i * a.n_heads + h] = -pe;
-            if (a.head_lse) a.head_lse[(size_t)i * a.n_heads + h] = lse;
-            off += n;
-        }
-        if (lane == 0) { s_logp[i] = logp; s_ent[i] = ent; }
-    }
-    __syncthreads();
-
-    // ---- losses and dL/dlogp, dL/dv ----
     float pg = 0.f, vl = 0.f, en = 0.f, kl = 0.f, cf = 0.f;
     for (int i = tid; i < B; i += kLossThreads) {
-        const float adv = s_adv[i];
-        const float log_ratio = s_logp[i] - a.old_log_prob[i];
+        const float adv = a.normalize_advantage ? (a.advantages[i] - mean) * inv_std : a.advantages[i];
+        const float log_ratio = logp_in[i] - a.old_log_prob[i];
         const float ratio = expf(log_ratio);
         const float lo = 1.0f - a.clip_range, hi = 1.0f + a.clip_range;
         const float rc = fminf(fmaxf(ratio, lo), hi);
@@ -118,7 +117,7 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_loss(GnbvPpoLoss a)
         // d min(s1, s2): the smaller operand takes the gradient, ties split evenly (torch.minimum)
         const float g1 = s1 < s2 ? 1.f : (s1 > s2 ? 0.f : 0.5f), g2 = 1.f - g1;
         const float inrange = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
-        s_gl[i] = -invB * a.policy_scale * adv * ratio * (g1 + g2 * inrange);
+        gl_out[i] = -invB * a.policy_scale * adv * ratio * (g1 + g2 * inrange);
         cf += fabsf(ratio - 1.0f) > a.clip_range ? 1.f : 0.f;
         kl += (ratio - 1.0f) - log_ratio;
         const float v = a.values[i], vo = a.old_values[i];
@@ -131,55 +130,44 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_loss(GnbvPpoLoss a)
         const float err = vp - a.returns[i];
         vl += err * err;
         a.d_values[i] = a.vf_coef * 2.0f * invB * err * dvp;
-        en += -s_ent[i];
+        en += -ent_in[i];
     }
     pg = block_sum(pg, scratch) * invB;
     vl = block_sum(vl, scratch) * invB;
     en = block_sum(en, scratch) * invB;
     kl = block_sum(kl, scratch) * invB;
     cf = block_sum(cf, scratch) * invB;
-    const float loss = pg * a.policy_scale + a.ent_coef * en + a.vf_coef * vl;
-    const int stopped_before = a.stop_flag ? *a.stop_flag : 0;
-    __syncthreads();
     if (tid == 0) {
+        const float loss = pg * a.policy_scale + a.ent_coef * en + a.vf_coef * vl;
+        const int stopped_before = a.stop_flag ? *a.stop_flag : 0;
         float *row = a.stats + (size_t)(*a.stats_row) * 8;
         row[0] = pg; row[1] = vl; row[2] = en; row[3] = kl; row[4] = cf; row[5] = loss;
-        row[6] = stopped_before ? 0.f : 1.f;  // row is live (the reference never ran this minibatch otherwise)
+        row[6] = stopped_before ? 0.f : 1.f;  // live row (the reference never ran this minibatch otherwise)
         row[7] = 0.f;
         *a.stats_row += 1;
         if (a.stop_flag && a.target_kl > 0.f && kl > 1.5f * a.target_kl) *a.stop_flag = 1;  // sticky (:264-268)
     }
+}
 
-    // ---- d logits: gl*(onehot - p) + (ent_coef/B) * p*(log p + H_head) ----
-    for (int i = wv; i < B; i += kLossThreads / 64) {
-        const float *lg = a.logits + (size_t)i * a.n_logits;
-        float *dl = a.d_logits + (size_t)i * a.n_logits;
-        const float gl = s_gl[i];
-        int off = 0;
-        for (int h = 0; h < a.n_heads; ++h) {
-            const int n = a.head_dims[h];
-            // recompute the head's lse / entropy (cheap; avoids B x heads of LDS)
-            float mx = -INFINITY;
-            for (int j = lane; j < n; j += 64) mx = fmaxf(mx, lg[off + j]);
-            for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
-            float se = 0.f;
-            for (int j = lane; j < n; j += 64) se += expf(lg[off + j] - mx);
-            for (int d = 32; d > 0; d >>= 1) se += __shfl_xor(se, d, 64);
-            const float lse = mx + logf(se);
-            float pe = 0.f;
-            for (int j = lane; j < n; j += 64) {
-                const float lp = lg[off + j] - lse;
-                pe += expf(lp) * lp;
-            }
-            for (int d = 32; d > 0; d >>= 1) pe += __shfl_xor(pe, d, 64);
-            const float H = -pe;
-            const int act = (int)a.actions[(size_t)i * a.n_heads + h];
-            for (int j = lane; j < n; j += 64) {
-                const float lp = lg[off + j] - lse, p = expf(lp);
-                dl[off + j] = gl * ((j == act ? 1.f : 0.f) - p) + a.ent_coef * invB * p * (lp + H);
-            }
-            off += n;
+// launch 3: one wave per sample -> d logits = gl*(onehot - p) + (ent_coef/B) * p*(log p + H_head)
+__global__ __launch_bounds__(kLossThreads) void k_ppo_dlogits(GnbvPpoLoss a, const float *__restrict__ gl_in)
+{
+    const int lane = threadIdx.x & 63, i = blockIdx.x * (kLossThreads / 64) + (threadIdx.x >> 6);
+    if (i >= a.batch) return;
+    const float invB = 1.0f / (float)a.batch;
+    const float *lg = a.logits + (size_t)i * a.n_logits;
+    float *dl = a.d_logits + (size_t)i * a.n_logits;
+    const float gl = gl_in[i];
+    int off = 0;
+    for (int h = 0; h < a.n_heads; ++h) {
+        const int n = a.head_dims[h];
+        const HeadStats hs = head_stats(lg + off, n, lane);
+        const int act = (int)a.actions[(size_t)i * a.n_heads + h];
+        for (int j = lane; j < n; j += 64) {
+            const float lp = lg[off + j] - hs.lse, p = expf(lp);
+            dl[off + j] = gl * ((j == act ? 1.f : 0.f) - p) + a.ent_coef * invB * p * (lp + hs.ent);
         }
+        off += n;
     }
 }
 
@@ -204,11 +192,19 @@ __global__ __launch_bounds__(256) void k_grad_sqnorm(const float *__restrict__ g
 }
 
 // clip coefficient = min(1, max_norm / (total_norm + 1e-6))  (torch.nn.utils.clip_grad_norm_)
-__global__ void k_grad_norm_finalize(const double *__restrict__ partial, int nparts, float max_norm, float *__restrict__ out /*[2]: norm, coef*/)
+__global__ __launch_bounds__(256) void k_grad_norm_finalize(const double *__restrict__ partial, int nparts, float max_norm, float *__restrict__ out /*[2]: norm, coef*/)
 {
+    __shared__ double sh[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += partial[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+        __syncthreads();
+    }
     if (threadIdx.x != 0) return;
-    double t = 0.0;
-    for (int i = 0; i < nparts; ++i) t += partial[i];
+    const double t = sh[0];
     const float norm = (float)sqrt(t);
     float coef = max_norm / (norm + 1e-6f);
     coef = coef > 1.0f ? 1.0f : coef;
@@ -265,8 +261,13 @@ GNBV_API int gnbv_ppo_loss(const GnbvPpoLoss *a, void *stream)
     GNBV_CHECK_ARG(a->d_logits && a->d_values && a->stats && a->stats_row);
     int sum = 0;
     for (int h = 0; h < a->n_heads; ++h) sum += a->head_dims[h];
-    GNBV_CHECK_ARG(sum == a->n_logits && (size_t)a->batch * 4 * sizeof(float) <= 60 * 1024);
-    hipLaunchKernelGGL(k_ppo_loss, dim3(1), dim3(kLossThreads), (size_t)a->batch * 4 * sizeof(float), gnbv_stream(stream), *a);
+    GNBV_CHECK_ARG(sum == a->n_logits && a->scratch);
+    hipStream_t st = gnbv_stream(stream);
+    float *logp = a->scratch, *ent = a->scratch + a->batch, *gl = a->scratch + 2 * (size_t)a->batch;
+    const int blocks = (a->batch + kLossThreads / 64 - 1) / (kLossThreads / 64);
+    hipLaunchKernelGGL(k_ppo_logp, dim3(blocks), dim3(kLossThreads), 0, st, *a, logp, ent);
+    hipLaunchKernelGGL(k_ppo_scalars, dim3(1), dim3(kLossThreads), 0, st, *a, (const float *)logp, (const float *)ent, gl);
+    hipLaunchKernelGGL(k_ppo_dlogits, dim3(blocks), dim3(kLossThreads), 0, st, *a, (const float *)gl);
     return gnbv_launch_status();
 }
 
@@ -284,7 +285,7 @@ GNBV_API int gnbv_clip_adam_step(float *params, const float *grads, float *exp_a
     int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
     blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
     hipLaunchKernelGGL(k_grad_sqnorm, dim3(blocks), dim3(256), 0, st, grads, n, partial);
-    hipLaunchKernelGGL(k_grad_norm_finalize, dim3(1), dim3(64), 0, st, partial, blocks, max_grad_norm, norm_out);
+    hipLaunchKernelGGL(k_grad_norm_finalize, dim3(1), dim3(256), 0, st, partial, blocks, max_grad_norm, norm_out);
     hipLaunchKernelGGL(k_step_increment, dim3(1), dim3(1), 0, st, step, stop_flag);
     int ab = (int)((n + 255) / 256);
     ab = ab > 4096 ? 4096 : ab;

@@ -93,6 +93,8 @@ class PpoLossOp:
         a.d_logits, a.d_values = self.d_logits.data_ptr(), self.d_values.data_ptr()
         a.head_entropy, a.head_lse = None, None
         a.stats, a.stats_row, a.stop_flag = self.stats.data_ptr(), self.stats_row.data_ptr(), self.stop_flag.data_ptr()
+        self.scratch = z(3 * batch)
+        a.scratch = self.scratch.data_ptr()
         self.args = a
         self.device = device
 

@@ -227,7 +227,7 @@ int gnbv_gather_minibatch(const int64_t *rows, int batch, int act_dim, const flo
                           const float *log_probs, const float *advantages, const float *returns, float *o_actions,
                           float *o_values, float *o_log_probs, float *o_adv, float *o_ret, void *stream);
 
-/* One launch: advantage normalisation, MultiCategorical log-prob / entropy, clipped surrogate,
+/* Three small launches: advantage normalisation, MultiCategorical log-prob / entropy, clipped surrogate,
  * clipped value loss, entropy loss, loss = policy_scale*pg + ent_coef*ent + vf_coef*vl,
  * approx-KL, clip fraction, and d loss / d logits, d loss / d values.
  * stats row (8 floats) = pg, vl, ent, approx_kl, clip_fraction, loss, live, 0 is written at
@@ -249,6 +249,7 @@ typedef struct GnbvPpoLoss {
     float *stats;               /* [rows, 8] */
     int64_t *stats_row;         /* in/out [1] */
     int *stop_flag;             /* in/out [1] or NULL */
+    float *scratch;             /* [3*B] device scratch */
 } GnbvPpoLoss;
 
 int gnbv_ppo_loss(const GnbvPpoLoss *args /*[host]*/, void *stream);
