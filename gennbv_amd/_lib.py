@@ -46,7 +46,7 @@ SIGNATURES = {
     "gnbv_gather_minibatch": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnbv_ppo_loss": (_i, [_p, _p]),
     "gnbv_adam_workspace_bytes": (_sz, []),
-    "gnbv_clip_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _p, _p, _p, _sz, _p]),
+    "gnbv_clip_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _p, _f, _p, _f, _p, _p, _sz, _p]),
     "gnbv_gae_sb3": (_i, [_p, _p, _p, _p, _p, _i, _i, _d, _d, _p, _p, _p]),
     "gnbv_gae_rsl": (_i, [_p, _p, _p, _p, _i, _i, _d, _d, _p, _p, _p]),
 }
@@ -87,7 +87,7 @@ class GnbvPpoLoss(C.Structure):
                 ("target_kl", _f),
                 ("logits", _p), ("values", _p), ("actions", _p), ("old_values", _p), ("old_log_prob", _p),
                 ("advantages", _p), ("returns", _p), ("d_logits", _p), ("d_values", _p), ("head_entropy", _p),
-                ("head_lse", _p), ("stats", _p), ("stats_row", _p), ("stop_flag", _p), ("scratch", _p)]
+                ("head_lse", _p), ("stats", _p), ("stats_row", _p), ("stop_flag", _p), ("scratch", _p), ("kl_out", _p)]
 
 
 class GennbvHipError(RuntimeError):

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_scalars(GnbvPpoLoss a, con
         row[6] = stopped_before ? 0.f : 1.f;  // live row (the reference never ran this minibatch otherwise)
         row[7] = 0.f;
         *a.stats_row += 1;
-        if (a.stop_flag && a.target_kl > 0.f && kl > 1.5f * a.target_kl) *a.stop_flag = 1;  // sticky (:264-268)
+        if (a.kl_out) *a.kl_out = kl;  // data-parallel: the decision is taken on the global mean after the all-reduce
+        else if (a.stop_flag && a.target_kl > 0.f && kl > 1.5f * a.target_kl) *a.stop_flag = 1;  // sticky (:264-268)
     }
 }
 
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void k_grad_sqnorm(const float *__restrict__ g
 }
 
 // clip coefficient = min(1, max_norm / (total_norm + 1e-6))  (torch.nn.utils.clip_grad_norm_)
-__global__ __launch_bounds__(256) void k_grad_norm_finalize(const double *__restrict__ partial, int nparts, float max_norm, float *__restrict__ out /*[2]: norm, coef*/)
+__global__ __launch_bounds__(256) void k_grad_norm_finalize(const double *__restrict__ partial, int nparts, float max_norm, float grad_scale, float *__restrict__ out /*[2]: norm, coef*/)
 {
     __shared__ double sh[256];
     double acc = 0.0;
@@ -205,11 +206,11 @@ __global__ __launch_bounds__(256) void k_grad_norm_finalize(const double *__rest
     }
     if (threadIdx.x != 0) return;
     const double t = sh[0];
-    const float norm = (float)sqrt(t);
-    float coef = max_norm / (norm + 1e-6f);
+    const float norm = (float)sqrt(t) * grad_scale;  // norm of the averaged gradient
+    float coef = max_norm > 0.f ? max_norm / (norm + 1e-6f) : 1.0f;
     coef = coef > 1.0f ? 1.0f : coef;
     out[0] = norm;
-    out[1] = coef;
+    out[1] = coef * grad_scale;  // factor applied to the raw (summed) gradient
 }
 
 __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
@@ -234,8 +235,11 @@ __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, 
     }
 }
 
-__global__ void k_step_increment(int64_t *step, const int *stop_flag)
+// data-parallel: kl_slot holds the SUM of the ranks' approx-KL (it rode behind the gradient in the
+// all-reduce); kl_scale = 1/world.  Sets the sticky stop flag before this step's update.
+__global__ void k_step_increment(int64_t *step, int *stop_flag, const float *kl_slot, float kl_scale, float target_kl)
 {
+    if (stop_flag != nullptr && kl_slot != nullptr && target_kl > 0.f && (*kl_slot) * kl_scale > 1.5f * target_kl) *stop_flag = 1;
     if (stop_flag != nullptr && *stop_flag != 0) return;
     *step += 1;
 }
@@ -274,9 +278,9 @@ GNBV_API int gnbv_ppo_loss(const GnbvPpoLoss *a, void *stream)
 GNBV_API size_t gnbv_adam_workspace_bytes(void) { return 1024 * sizeof(double) + 64; }
 
 GNBV_API int gnbv_clip_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float max_grad_norm,
-                                 float lr, float beta1, float beta2, float eps, int64_t *step, const int *stop_flag,
-                                 float *norm_out /*[2]: total norm, clip coefficient*/, void *workspace, size_t workspace_bytes,
-                                 void *stream)
+                                 float lr, float beta1, float beta2, float eps, int64_t *step, int *stop_flag, float grad_scale,
+                                 const float *kl_slot, float target_kl, float *norm_out /*[2]: total norm, applied factor*/,
+                                 void *workspace, size_t workspace_bytes, void *stream)
 {
     GNBV_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && step && norm_out && workspace && n > 0);
     GNBV_CHECK_ARG(workspace_bytes >= gnbv_adam_workspace_bytes());
@@ -285,11 +289,11 @@ GNBV_API int gnbv_clip_adam_step(float *params, const float *grads, float *exp_a
     int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
     blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
     hipLaunchKernelGGL(k_grad_sqnorm, dim3(blocks), dim3(256), 0, st, grads, n, partial);
-    hipLaunchKernelGGL(k_grad_norm_finalize, dim3(1), dim3(256), 0, st, partial, blocks, max_grad_norm, norm_out);
-    hipLaunchKernelGGL(k_step_increment, dim3(1), dim3(1), 0, st, step, stop_flag);
+    hipLaunchKernelGGL(k_grad_norm_finalize, dim3(1), dim3(256), 0, st, partial, blocks, max_grad_norm, grad_scale, norm_out);
+    hipLaunchKernelGGL(k_step_increment, dim3(1), dim3(1), 0, st, step, stop_flag, kl_slot, grad_scale, target_kl);
     int ab = (int)((n + 255) / 256);
     ab = ab > 4096 ? 4096 : ab;
-    hipLaunchKernelGGL(k_adam_flat, dim3(ab), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n,
-                       max_grad_norm > 0.f ? norm_out : (const float *)nullptr, stop_flag, step, lr, beta1, beta2, eps);
+    hipLaunchKernelGGL(k_adam_flat, dim3(ab), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, (const float *)norm_out,
+                       (const int *)stop_flag, step, lr, beta1, beta2, eps);
     return gnbv_launch_status();
 }

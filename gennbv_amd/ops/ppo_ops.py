@@ -25,7 +25,10 @@ class FlatAdam:
         n = sum(p.numel() for p in ps)
         self.n = n
         self.params = torch.empty(n, dtype=torch.float32, device=dev)
-        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        # one extra slot behind the gradient: the rank's approx-KL rides in the same all-reduce
+        self.grads_with_slot = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        self.grads = self.grads_with_slot[:n]
+        self.kl_slot = self.grads_with_slot[n:]
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -46,11 +49,15 @@ class FlatAdam:
     def zero_grad(self):
         self.grads.zero_()
 
-    def step(self, max_grad_norm: float, stop_flag: Optional[torch.Tensor] = None):
+    def step(self, max_grad_norm: float, stop_flag: Optional[torch.Tensor] = None, grad_scale: float = 1.0,
+             kl_slot_target: Optional[float] = None):
+        """grad_scale = 1/world and kl_slot_target = target_kl for the data-parallel tail."""
         _lib.check(self.lib.gnbv_clip_adam_step(
             self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.n,
             float(max_grad_norm if max_grad_norm is not None else -1.0), float(self.lr), float(self.betas[0]),
-            float(self.betas[1]), float(self.eps), self.step_count.data_ptr(), _lib.ptr(stop_flag), self.norm_out.data_ptr(),
+            float(self.betas[1]), float(self.eps), self.step_count.data_ptr(), _lib.ptr(stop_flag), float(grad_scale),
+            self.kl_slot.data_ptr() if kl_slot_target is not None else None,
+            float(kl_slot_target) if kl_slot_target is not None else -1.0, self.norm_out.data_ptr(),
             self.ws.data_ptr(), self.ws.numel(), _lib.stream_ptr(self.params.device)), "gnbv_clip_adam_step")
 
     def load_torch_adam_state(self, opt: torch.optim.Adam):
@@ -91,7 +98,7 @@ class PpoLossOp:
         a.actions, a.old_values, a.old_log_prob = self.actions.data_ptr(), self.old_values.data_ptr(), self.old_log_prob.data_ptr()
         a.advantages, a.returns = self.advantages.data_ptr(), self.returns.data_ptr()
         a.d_logits, a.d_values = self.d_logits.data_ptr(), self.d_values.data_ptr()
-        a.head_entropy, a.head_lse = None, None
+        a.head_entropy, a.head_lse, a.kl_out = None, None, None
         a.stats, a.stats_row, a.stop_flag = self.stats.data_ptr(), self.stats_row.data_ptr(), self.stop_flag.data_ptr()
         self.scratch = z(3 * batch)
         a.scratch = self.scratch.data_ptr()

@@ -1,0 +1,92 @@
+"""Multi-GPU: environments shard across ranks, the policy is replicated, gradients are averaged
+with ONE all-reduce per optimizer step over RCCL/xGMI.
+
+The reference has no multi-GPU path (no torch.distributed / NCCL call site anywhere), so this
+module defines it:
+
+  * one process per GPU, `torch.distributed` with backend "nccl" (= RCCL on ROCm); rank r owns
+    envs [r*N, (r+1)*N) with their grids, pose history, feed and rollout-buffer columns --
+    state encoding, buffer add and the GAE scan need no exchange (independent per env);
+  * every rank draws the same minibatch permutation (same numpy seed) over its own columns,
+    so the global minibatch k is the concatenation of the ranks' minibatches k;
+  * one all-reduce(sum) of the FLAT gradient buffer per optimizer step; the buffer carries one
+    extra slot with the rank's approx-KL, so the early-stop decision (KL of the global
+    minibatch = mean of the ranks' KLs) rides in the same collective and every rank stops at
+    the same minibatch -- no second collective, no divergence, no deadlock;
+  * clip_grad_norm_ is evaluated on the averaged gradient (after the all-reduce);
+  * per-minibatch advantage normalisation and BatchNorm batch statistics stay local to the
+    rank's shard of the minibatch (like torch DDP without SyncBatchNorm); with world = 1 this
+    is exactly the reference.
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): the 58 MB fp32 gradient of the G=64
+policy costs ~2*(7/8)*58 MB / (7*153 GB/s) = 95 us on a direct reduce-scatter + all-gather
+when every link is used, ~0.66 ms on a single ring; RCCL picks the algorithm.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_process_group(backend: Optional[str] = None) -> int:
+    """RANK / WORLD_SIZE / MASTER_* come from the launcher (torch.distributed.run)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend)
+    return world
+
+
+def shard_range(total_envs: int, rank: int, world: int):
+    """Contiguous env shard of `rank`."""
+    assert total_envs % world == 0, "envs must divide evenly over the ranks"
+    per = total_envs // world
+    return rank * per, (rank + 1) * per
+
+
+class GradSync:
+    """Gradient (+ KL) averaging for both train paths."""
+
+    def __init__(self, world: int, group=None):
+        self.world, self.group = int(world), group
+
+    # ---- torch-module path (per-parameter grads) --------------------------------------
+    def average_grads(self, params: Iterable[torch.nn.Parameter]) -> None:
+        if self.world == 1:
+            return
+        grads = [p.grad for p in params if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.div_(self.world)
+        off = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n
+
+    def mean_scalar(self, x: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return x
+        y = x.detach().clone()
+        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
+        return y / self.world
+
+    # ---- fused path: flat gradient buffer with the KL slot appended ---------------------
+    def all_reduce_flat(self, flat_with_slot: torch.Tensor) -> None:
+        if self.world > 1:
+            dist.all_reduce(flat_with_slot, op=dist.ReduceOp.SUM, group=self.group)
+
+
+def attach(algo, world: int, group=None) -> GradSync:
+    """Make `algo` (PPO_Grid_Obs) a data-parallel replica: identical initial parameters on every
+    rank (broadcast from rank 0) and gradient / KL synchronisation in train()."""
+    sync = GradSync(world, group)
+    algo._sync = sync
+    if world > 1:
+        for t in list(algo.policy.parameters()) + list(algo.policy.buffers()):
+            dist.broadcast(t.data, src=0, group=group)
+    return sync

@@ -86,6 +86,7 @@ class PPO_Grid_Obs:
         self.train_impl = "hip"   # fused loss / flat Adam / device-side early stop when the encoder backend is "hip"
         self.use_graph = True     # replay the minibatch step as one hipGraph
         self._hip = None
+        self._sync = None         # gennbv_amd.parallel.GradSync when data-parallel
         if _init_setup_model:
             self._setup_model()
 
@@ -165,6 +166,8 @@ class PPO_Grid_Obs:
                 with torch.no_grad():
                     log_ratio = log_prob - rollout_data.old_log_prob
                     approx_kl_div = torch.mean((torch.exp(log_ratio) - 1) - log_ratio)
+                    if self._sync is not None:  # KL of the global minibatch: every rank stops together
+                        approx_kl_div = self._sync.mean_scalar(approx_kl_div)
                 stats.append(torch.stack([policy_loss.detach(), value_loss.detach(), entropy_loss.detach(), approx_kl_div,
                                           clip_fraction, loss.detach()]))
                 epoch_kl.append(len(stats) - 1)
@@ -175,6 +178,8 @@ class PPO_Grid_Obs:
                     break
                 self.policy.optimizer.zero_grad()
                 loss.backward()
+                if self._sync is not None:
+                    self._sync.average_grads(self.policy.parameters())
                 torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
                 self.policy.optimizer.step()
             kl_per_epoch.append(epoch_kl)
@@ -213,6 +218,10 @@ class PPO_Grid_Obs:
                            betas=old.defaults.get("betas", (0.9, 0.999)))
             opt.load_torch_adam_state(old)
         self._hip = {"loss": loss, "opt": opt, "batch": batch, "n_mb": n_minibatches, "graph": None}
+        if self._sync is not None and self._sync.world > 1:
+            # the rank's approx-KL rides in the slot behind the flat gradient; the flag is set from
+            # the GLOBAL mean after the all-reduce (gnbv_clip_adam_step), not by the loss kernel
+            loss.args.kl_out = opt.kl_slot.data_ptr()
         self.policy.features_extractor._bn_skip_flag = loss.stop_flag
         return self._hip
 
@@ -229,7 +238,13 @@ class PPO_Grid_Obs:
         d_logits, d_values = loss(logits, values)
         opt.zero_grad()
         torch.autograd.backward([logits, values], [d_logits, d_values])
-        opt.step(self.max_grad_norm, loss.stop_flag)
+        if self._sync is None or self._sync.world == 1:
+            opt.step(self.max_grad_norm, loss.stop_flag)
+
+    def _hip_minibatch_tail(self, st):
+        """data-parallel tail: global KL decision + clip + Adam on the summed gradient."""
+        loss, opt = st["loss"], st["opt"]
+        opt.step(self.max_grad_norm, loss.stop_flag, grad_scale=1.0 / self._sync.world, kl_slot_target=loss.args.target_kl)
 
     def _train_hip(self) -> None:
         """train() on the gfx950 kernels: same arithmetic as the reference loop
@@ -273,6 +288,9 @@ class PPO_Grid_Obs:
                     st["graph"].replay()
                 else:
                     self._hip_minibatch_body(st)
+                if self._sync is not None and self._sync.world > 1:
+                    self._sync.all_reduce_flat(opt.grads_with_slot)  # ONE collective per optimizer step
+                    self._hip_minibatch_tail(st)
             epochs_run += 1
             # the ONLY read-back inside train(): early-stop flag, once per epoch (the reference
             # reads approx_kl on the host after every minibatch, :261-268)

@@ -250,17 +250,23 @@ typedef struct GnbvPpoLoss {
     int64_t *stats_row;         /* in/out [1] */
     int *stop_flag;             /* in/out [1] or NULL */
     float *scratch;             /* [3*B] device scratch */
+    float *kl_out;              /* NULL, or [1]: receives approx_kl INSTEAD of setting stop_flag
+                                   (data-parallel: decided on the global mean, gnbv_clip_adam_step) */
 } GnbvPpoLoss;
 
 int gnbv_ppo_loss(const GnbvPpoLoss *args /*[host]*/, void *stream);
 
 /* torch.nn.utils.clip_grad_norm_(max_grad_norm) + torch.optim.Adam step over ONE flat fp32
- * buffer of n parameters (max_grad_norm <= 0: no clipping). *step is incremented and the
- * update applied unless *stop_flag != 0. norm_out[0] = total norm, [1] = clip coefficient. */
+ * buffer of n parameters (max_grad_norm <= 0: no clipping). grads is the SUM over ranks,
+ * grad_scale = 1/world turns it into the mean (1.0 on one GPU).  kl_slot (may be NULL): sum over
+ * ranks of approx_kl; *stop_flag becomes 1 (sticky) when kl_slot*grad_scale > 1.5*target_kl.
+ * *step is incremented and the update applied unless *stop_flag != 0.
+ * norm_out[0] = norm of the mean gradient, [1] = factor applied to `grads`. */
 size_t gnbv_adam_workspace_bytes(void);
 int gnbv_clip_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float max_grad_norm,
-                        float lr, float beta1, float beta2, float eps, int64_t *step, const int *stop_flag, float *norm_out,
-                        void *workspace, size_t workspace_bytes, void *stream);
+                        float lr, float beta1, float beta2, float eps, int64_t *step, int *stop_flag, float grad_scale,
+                        const float *kl_slot, float target_kl, float *norm_out, void *workspace, size_t workspace_bytes,
+                        void *stream);
 
 #ifdef __cplusplus
 }
