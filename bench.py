@@ -126,7 +126,7 @@ def one_iteration(algo, phases):
 def cpu_baseline(args, cfg):
     """The oracle (CPU restatement, proven equal to the reference on the goldens) + torch-CPU
     fp32 PPO on a bounded sample of the same workload: 4 envs, 2 env steps, full 240x320 / G
-    state encoding, policy forward, GAE and one PPO epoch.  kind = "port", single process."""
+    state encoding, policy forward, GAE and one PPO epoch (remaining epochs scaled from it).  kind = "port", single process."""
     import numpy as np
     import torch
     from gennbv_amd.env import synthetic as S
@@ -134,8 +134,8 @@ def cpu_baseline(args, cfg):
     from oracle import oracle as orc
     from tests import policy_util as pu
 
-    n, t_steps = 4, 2
-    torch.set_num_threads(os.cpu_count() or 1)
+    n, t_steps = 2, 2
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     scene = S.make_scenes(n, cfg.grid_size, seed=99)
     frames = S.make_frames(scene, cfg, 2, seed=99)
     kinv = S.inverse_intrinsics(cfg.camera_height, cfg.camera_width)
@@ -227,6 +227,13 @@ def main():
     b_vox = args.height * args.width * 8 + args.grid ** 3 * 4 * 6 + 200
     vox_ms = vox.total_ms() / max(vox.count(), 1)
     achieved = args.envs * b_vox / (vox_ms * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "r01_voxel_traffic.json")
+    if os.path.exists(tf):
+        tj = json.load(open(tf))
+        c = tj["config"]
+        if (c["envs"], c["height"], c["width"], c["grid"]) == (args.envs, args.height, args.width, args.grid):
+            traffic = tj["traffic_bytes_per_launch"]  # rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (profiles/r01_voxel_pmc.txt)
     out = {
         "metric": "env-steps/sec at 256 envs x 64^3 grid (state encoding + policy forward + GAE + PPO update)",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -242,7 +249,7 @@ def main():
                                              "voxel_update_total": vox.total_ms() / args.steps}},
         "roofline": {"bound": "hbm", "kernel": "gnbv_update_occ_grid (k_hit_mask + k_raycast + k_grid_update)",
                      "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "launch_ms": vox_ms, "algorithmic_bytes_per_launch": args.envs * b_vox, "traffic": None},
+                     "launch_ms": vox_ms, "algorithmic_bytes_per_launch": args.envs * b_vox, "traffic": traffic},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
