@@ -30,6 +30,19 @@ constexpr int kTaps = 27;
 constexpr int kEncThreads = 256;
 constexpr int kEncWaves = kEncThreads / kWave;
 
+// Layer-1 activations (y1, dz1') are channels-last AND split by x-parity:
+//   voxel (b, z, y, x) -> (((b*O1 + z)*O1 + y)*2 + (x & 1))*XH + (x >> 1)      XH = ceil(O1 / 2)
+// A stride-2 convolution reads, for a fixed tap, input x = 2*ox + dx: with the split layout the 16
+// consecutive outputs of an MFMA tile read 16 CONSECUTIVE voxels (1 KiB per wave-load, fully
+// coalesced) instead of every other 64-byte half line; the transposed conv (dgrad) tiles are per
+// x-parity already and become contiguous too.
+__device__ __forceinline__ size_t vox1(int b, int z, int y, int x, int O1)
+{
+    const int XH = (O1 + 1) >> 1;
+    return ((((size_t)b * O1 + z) * O1 + y) * 2 + (x & 1)) * XH + (x >> 1);
+}
+static inline size_t y1_elems(int batch, int O1) { return (size_t)batch * O1 * O1 * 2 * ((O1 + 1) / 2) * kC; }
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // sum over the four k-groups (lanes l, l^16, l^32, l^48): afterwards every lane holds the total
@@ -39,6 +52,18 @@ __device__ __forceinline__ float kgroup_sum(float v)
     v += __shfl_xor(v, 32, kWave);
     return v;
 }
+
+// Workgroup -> (sample b, plane o) with all planes of sample b on XCD b % 8 (block i runs on XCD
+// i % 8, observed; speed only): neighbouring output planes share an input plane, which then hits
+// the XCD's L2 instead of being fetched twice from HBM.  Returns false for padding blocks.
+__device__ __forceinline__ bool sample_plane(int B, int O, int &b, int &o)
+{
+    const int i = blockIdx.x, xcd = i & 7, slot = i >> 3;
+    o = slot % O;
+    b = (slot / O) * 8 + xcd;
+    return b < B;
+}
+static inline int sample_plane_grid(int B, int O) { return ((B + 7) / 8) * 8 * O; }
 
 // per-wave BN partials: part[wave_global][0][c] = sum, [1][c] = sum of squares / second sum
 __device__ __forceinline__ void write_partials(float *partials, int wave_global, float s, float q)
@@ -52,6 +77,29 @@ __device__ __forceinline__ void write_partials(float *partials, int wave_global,
     }
 }
 
+// same, for kernels whose lanes own channels 4*kq .. 4*kq+3 of position (lane & 15):
+// reduce over the 16 positions (lanes with equal kq), lanes with m == 0 write 4 channels each
+__device__ __forceinline__ void write_partials_cl(float *partials, int wave_global, float (&s)[4], float (&q)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            s[r] += __shfl_xor(s[r], d, kWave);
+            q[r] += __shfl_xor(q[r], d, kWave);
+        }
+    }
+    const int lane = threadIdx.x & (kWave - 1);
+    if (partials != nullptr && (lane & 15) == 0) {
+        const int kq = lane >> 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            partials[(size_t)wave_global * 2 * kC + 4 * kq + r] = s[r];
+            partials[(size_t)wave_global * 2 * kC + kC + 4 * kq + r] = q[r];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // conv1 forward: in [B rows of the obs buffer, G^3 fp32] -> y1 [B,O1,O1,O1,16] (pre-BN, + bias)
 // workgroup = (sample b, output plane oz); wave = output rows oy; tile = 16 outputs along x
@@ -61,62 +109,102 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd(
     const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ b1, float *__restrict__ y1,
     float *__restrict__ partials)
 {
-    const int b = blockIdx.x / O1, oz = blockIdx.x - b * O1;
+    int b, oz;
+    const bool live = sample_plane(B, O1, b, oz);
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const int m = lane & 15, kq = lane >> 4;
-    const float *in = obs_base + (rows ? rows[b] : (int64_t)b) * row_stride;
-    float wf[7];
-    int off[7];
+    float s_sum[4] = {0.f, 0.f, 0.f, 0.f}, s_sq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const float *in = obs_base + (rows ? rows[b] : (int64_t)b) * row_stride;
+        // MFMA roles: A[i = co][k = tap] = W1, B[k = tap][j = output position] = input voxel
+        //   -> D[i = co = 4*kq + r][j = position m]: a lane owns 4 consecutive channels of one
+        //      voxel = one 16-byte channels-last store.
+        float wf[7];
+        int off[7];
 #pragma unroll
-    for (int s = 0; s < 7; ++s) {
-        const int t = 4 * s + kq;
-        const bool ok = t < kTaps;
-        wf[s] = ok ? W1[m * kTaps + t] : 0.0f;  // B[k = tap][j = co = m]
-        const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
-        off[s] = ok ? (dz * G + dy) * G + dx : 0;
-    }
-    const float bias = b1[m];
-    float s_sum = 0.0f, s_sq = 0.0f;
-    for (int oy = wv; oy < O1; oy += kEncWaves) {
-        for (int ox0 = 0; ox0 < O1; ox0 += 16) {
-            const int ox = min(ox0 + m, O1 - 1);
-            const float *p = in + ((size_t)(2 * oz) * G + 2 * oy) * G + 2 * ox;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < 7; ++s) {
+            const int t = 4 * s + kq;
+            const bool ok = t < kTaps;
+            wf[s] = ok ? W1[m * kTaps + t] : 0.0f;  // A[i = co = m][k = tap]
+            const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+            off[s] = ok ? (dz * G + dy) * G + dx : 0;
+        }
+        const float4 bias = *reinterpret_cast<const float4 *>(b1 + 4 * kq);
+        for (int oy = wv; oy < O1; oy += kEncWaves) {
+            for (int ox0 = 0; ox0 < O1; ox0 += 16) {
+                const int ox = min(ox0 + m, O1 - 1);
+                const float *p = in + ((size_t)(2 * oz) * G + 2 * oy) * G + 2 * ox;
+                float v[7];
 #pragma unroll
-            for (int s = 0; s < 7; ++s) acc = mfma4(p[off[s]], wf[s], acc);
-            float *out = y1 + ((((size_t)b * O1 + oz) * O1 + oy) * O1) * kC;
+                for (int s = 0; s < 7; ++s) v[s] = p[off[s]];
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int oxi = ox0 + 4 * kq + r;
-                if (oxi < O1) {
-                    const float y = acc[r] + bias;
-                    out[(size_t)oxi * kC + m] = y;
-                    s_sum += y;
-                    s_sq += y * y;
+                for (int s = 0; s < 7; ++s) acc = mfma4(wf[s], v[s], acc);
+                if (ox0 + m < O1) {
+                    float4 y = make_float4(acc[0] + bias.x, acc[1] + bias.y, acc[2] + bias.z, acc[3] + bias.w);
+                    *reinterpret_cast<float4 *>(y1 + vox1(b, oz, oy, ox0 + m, O1) * kC + 4 * kq) = y;
+                    s_sum[0] += y.x; s_sq[0] += y.x * y.x;
+                    s_sum[1] += y.y; s_sq[1] += y.y * y.y;
+                    s_sum[2] += y.z; s_sq[2] += y.z * y.z;
+                    s_sum[3] += y.w; s_sq[3] += y.w * y.w;
                 }
             }
         }
     }
-    write_partials(partials, blockIdx.x * kEncWaves + wv, s_sum, s_sq);
+    write_partials_cl(partials, blockIdx.x * kEncWaves + wv, s_sum, s_sq);
 }
+
+// W2 [co][ci][27] -> the two LDS images the conv2 kernels use, written once per call so that the
+// workgroups fill their LDS with coalesced 16-byte loads instead of 6912 scattered 4-byte reads:
+//   fwd  image [(tap*4+s)*4+kq][n] = W2[co = n][ci = 4kq+s][tap]
+//   dgrad image [(tap*4+s)*4+kq][n] = W2[co = 4kq+s][ci = n][tap]
+__global__ void k_prep_w2(const float *__restrict__ W2, float *__restrict__ img_fwd, float *__restrict__ img_dgrad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= kTaps * 256) return;
+    const int n = i & 15, kq = (i >> 4) & 3, s = (i >> 6) & 3, tap = i >> 8;
+    img_fwd[i] = W2[((size_t)n * kC + 4 * kq + s) * kTaps + tap];
+    img_dgrad[i] = W2[((size_t)(4 * kq + s) * kC + n) * kTaps + tap];
+}
+
+__device__ __forceinline__ void fill_lds_image(float *lds, const float *__restrict__ img)
+{
+    for (int i = threadIdx.x; i < kTaps * 64; i += blockDim.x)
+        reinterpret_cast<float4 *>(lds)[i] = reinterpret_cast<const float4 *>(img)[i];
+    __syncthreads();
+}
+
+// Workgroup -> (sample b, group of PZ planes) with all groups of sample b on XCD b % 8.
+__device__ __forceinline__ bool sample_plane_group(int B, int O, int PZ, int &b, int &o0, int &o1)
+{
+    const int ng = (O + PZ - 1) / PZ;
+    const int i = blockIdx.x, xcd = i & 7, slot = i >> 3;
+    const int gidx = slot % ng;
+    b = (slot / ng) * 8 + xcd;
+    o0 = gidx * PZ;
+    o1 = min(O, o0 + PZ);
+    return b < B;
+}
+static inline int sample_plane_group_grid(int B, int O, int PZ) { return ((B + 7) / 8) * 8 * ((O + PZ - 1) / PZ); }
+constexpr int kPlanesPerGroup = 4;
+constexpr int kBigThreads = 1024;  // conv2 fwd / dgrad: 16 waves share one 27 KiB weight image -> 32 waves per CU
+constexpr int kBigWaves = kBigThreads / kWave;
 
 // ---------------------------------------------------------------------------
 // conv2 forward: z1 = relu(scale1*y1 + shift1) applied on load; y2 [B,16,O2^3] (NCDHW, pre-BN)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kEncThreads) void k_conv2_fwd(
+__global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
     const float *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1, int B, int O1, int O2,
-    const float *__restrict__ W2 /*[16 co][16 ci][27]*/, const float *__restrict__ b2, float *__restrict__ y2,
+    const float *__restrict__ W2img /*k_prep_w2 fwd image*/, const float *__restrict__ b2, float *__restrict__ y2,
     float *__restrict__ partials)
 {
-    __shared__ float w2s[kTaps * 4 * 4 * kC];  // [(tap*4+s)*4+kq][n] = W2[n][4kq+s][tap]
-    for (int i = threadIdx.x; i < kTaps * 256; i += kEncThreads) {
-        const int n = i & 15, kq_ = (i >> 4) & 3, s = (i >> 6) & 3, tap = i >> 8;
-        w2s[i] = W2[((size_t)n * kC + 4 * kq_ + s) * kTaps + tap];
-    }
-    __syncthreads();
-    const int b = blockIdx.x / O2, oz = blockIdx.x - b * O2;
+    __shared__ __attribute__((aligned(16))) float w2s[kTaps * 4 * 4 * kC];  // [(tap*4+s)*4+kq][n] = W2[n][4kq+s][tap]
+    fill_lds_image(w2s, W2img);
+    int b, oz0, oz1;
+    const bool live = sample_plane_group(B, O2, kPlanesPerGroup, b, oz0, oz1);
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const int m = lane & 15, kq = lane >> 4;
+    if (!live) { write_partials(partials, blockIdx.x * kBigWaves + wv, 0.f, 0.f); return; }
     float sc[4], sh[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -126,22 +214,41 @@ __global__ __launch_bounds__(kEncThreads) void k_conv2_fwd(
     const float bias = b2[m];
     const int P2 = O2 * O2 * O2;
     float s_sum = 0.0f, s_sq = 0.0f;
-    for (int oy = wv; oy < O2; oy += kEncWaves) {
-        for (int ox0 = 0; ox0 < O2; ox0 += 16) {
+    const int ntile_x = (O2 + 15) / 16, nwork = (oz1 - oz0) * O2 * ntile_x;
+    for (int wk = wv; wk < nwork; wk += kBigWaves) {
+        const int oz = oz0 + wk / (O2 * ntile_x), rr = wk % (O2 * ntile_x), oy = rr / ntile_x;
+        {
+            const int ox0 = (rr % ntile_x) * 16;
             const int ox = min(ox0 + m, O2 - 1);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 3
+#pragma unroll 9
             for (int tap = 0; tap < kTaps; ++tap) {
                 const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+#ifndef ENC_VARIANT
+#define ENC_VARIANT 0
+#endif
+#if ENC_VARIANT == 1   // A/B: no global loads
+                const float4 v = make_float4((float)(tap + ox), 1.f, 2.f, 3.f);
+#else
                 const float4 v = *reinterpret_cast<const float4 *>(
-                    y1 + ((((size_t)b * O1 + 2 * oz + dz) * O1 + 2 * oy + dy) * O1 + 2 * ox + dx) * kC + 4 * kq);
+                    y1 + vox1(b, 2 * oz + dz, 2 * oy + dy, 2 * ox + dx, O1) * kC + 4 * kq);
+#endif
                 const float z0 = fmaxf(fmaf(sc[0], v.x, sh[0]), 0.f), z1 = fmaxf(fmaf(sc[1], v.y, sh[1]), 0.f);
                 const float z2 = fmaxf(fmaf(sc[2], v.z, sh[2]), 0.f), z3 = fmaxf(fmaf(sc[3], v.w, sh[3]), 0.f);
                 const float *wb = w2s + tap * 256 + lane;  // + s*64
+#if ENC_VARIANT == 2   // A/B: no MFMA, no LDS
+                acc[0] += z0; acc[1] += z1; acc[2] += z2; acc[3] += z3;
+#elif ENC_VARIANT == 3 // A/B: MFMA with register B operand (no LDS reads)
+                acc = mfma4(z0, sc[0], acc);
+                acc = mfma4(z1, sc[1], acc);
+                acc = mfma4(z2, sc[2], acc);
+                acc = mfma4(z3, sc[3], acc);
+#else
                 acc = mfma4(z0, wb[0], acc);
                 acc = mfma4(z1, wb[64], acc);
                 acc = mfma4(z2, wb[128], acc);
                 acc = mfma4(z3, wb[192], acc);
+#endif
             }
             float *out = y2 + ((size_t)b * kC + m) * P2 + ((size_t)oz * O2 + oy) * O2;
 #pragma unroll
@@ -156,7 +263,7 @@ __global__ __launch_bounds__(kEncThreads) void k_conv2_fwd(
             }
         }
     }
-    write_partials(partials, blockIdx.x * kEncWaves + wv, s_sum, s_sq);
+    write_partials(partials, blockIdx.x * kBigWaves + wv, s_sum, s_sq);
 }
 
 // ---------------------------------------------------------------------------
@@ -299,6 +406,19 @@ __global__ void k_bn2_bwd_apply(const float *__restrict__ dz2, const float *__re
     }
 }
 
+// Weight-gradient kernels walk output rows (b, oz, oy).  Every wave owns a CONTIGUOUS range of rows
+// (neighbouring rows share input lines -> L1/L2 hits) and the ranges of the 8 XCDs are contiguous
+// too (block i runs on XCD i % 8), so a sample's planes stay within one XCD's L2.
+__device__ __forceinline__ void wave_row_range(int nrows, int &r0, int &r1)
+{
+    const int nblk = gridDim.x, per_xcd = (nblk + 7) / 8;
+    const int chunk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);  // position of this block in row order
+    const int wave = chunk * kEncWaves + (threadIdx.x / kWave), nwaves = per_xcd * 8 * kEncWaves;
+    const int per = (nrows + nwaves - 1) / nwaves;
+    r0 = min(nrows, wave * per);
+    r1 = min(nrows, r0 + per);
+}
+
 // ---------------------------------------------------------------------------
 // conv2 weight gradient: dW2[(tap, ci), co] = sum_pos z1[inpos(pos, tap), ci] * dy2[pos, co]
 // MFMA: i = ci, j = co, k = 4 consecutive output positions along x.  27 accumulators / wave.
@@ -317,7 +437,10 @@ __global__ __launch_bounds__(kEncThreads) void k_conv2_wgrad(
     for (int t = 0; t < kTaps; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bsum = 0.0f;
     const int nrows = B * O2 * O2;
-    for (int row = wave_global; row < nrows; row += nwaves) {
+    int row0, row1;
+    wave_row_range(nrows, row0, row1);
+    (void)nwaves;
+    for (int row = row0; row < row1; ++row) {
         const int b = row / (O2 * O2), rem = row - b * O2 * O2, oz = rem / O2, oy = rem - oz * O2;
         for (int x0 = 0; x0 < O2; x0 += 4) {
             const int x = x0 + kq;
@@ -326,11 +449,11 @@ __global__ __launch_bounds__(kEncThreads) void k_conv2_wgrad(
             float bv = dy2[((((size_t)b * O2 + oz) * O2 + oy) * O2 + xc) * kC + n];
             bv = ok ? bv : 0.0f;
             bsum += bv;
-            const float *p = y1 + ((((size_t)b * O1 + 2 * oz) * O1 + 2 * oy) * O1 + 2 * xc) * kC + n;
+            const float *p = y1 + n;
 #pragma unroll
             for (int tap = 0; tap < kTaps; ++tap) {
                 const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-                const float a = fmaxf(fmaf(sc, p[(((size_t)dz * O1 + dy) * O1 + dx) * kC], sh), 0.0f);
+                const float a = fmaxf(fmaf(sc, p[vox1(b, 2 * oz + dz, 2 * oy + dy, 2 * xc + dx, O1) * kC], sh), 0.0f);
                 acc[tap] = mfma4(a, bv, acc[tap]);  // rows with bv == 0 contribute nothing
             }
         }
@@ -361,25 +484,27 @@ __global__ void k_conv2_wgrad_finish(const double *__restrict__ red, float *__re
 //   dz1'[v, ci] = [pre1 > 0] * sum_{tap, co} dy2[(v - tap)/2, co] * W2[co][ci][tap]
 // Input voxels of one x-parity share their tap set -> tiles of 16 voxels ix = 2j + px.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kEncThreads) void k_conv2_dgrad(
+__global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad(
     const float *__restrict__ dy2, const float *__restrict__ W2, const float *__restrict__ y1, const float *__restrict__ scale1,
     const float *__restrict__ shift1, const float *__restrict__ mean1, const float *__restrict__ rstd1, int B, int O1, int O2,
     float *__restrict__ dz1p, float *__restrict__ partials)
 {
-    __shared__ float w2d[kTaps * 4 * 4 * kC];  // [(tap*4+s)*4+kq][n] = W2[co = 4kq+s][ci = n][tap]
-    for (int i = threadIdx.x; i < kTaps * 256; i += kEncThreads) {
-        const int n = i & 15, kq_ = (i >> 4) & 3, s = (i >> 6) & 3, tap = i >> 8;
-        w2d[i] = W2[((size_t)(4 * kq_ + s) * kC + n) * kTaps + tap];
-    }
-    __syncthreads();
-    const int b = blockIdx.x / O1, iz = blockIdx.x - b * O1;
+    __shared__ __attribute__((aligned(16))) float w2d[kTaps * 4 * 4 * kC];  // [(tap*4+s)*4+kq][n] = W2[co = 4kq+s][ci = n][tap]
+    fill_lds_image(w2d, W2 /* k_prep_w2 dgrad image */);
+    int b, iz0, iz1;
+    const bool live = sample_plane_group(B, O1, kPlanesPerGroup, b, iz0, iz1);
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const int m = lane & 15, kq = lane >> 4;
-    const float sc = scale1[m], sh = shift1[m], mu = mean1[m], rs = rstd1[m];
-    float s1 = 0.f, s2 = 0.f;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!live) { write_partials_cl(partials, blockIdx.x * kBigWaves + wv, s1, s2); return; }
+    // MFMA roles: A[i = ci][k = co] = W2, B[k = co][j = input voxel] = dy2 -> D[i = ci = 4*kq+r][j = voxel m]:
+    // a lane owns 4 consecutive channels of one voxel (16-byte load of y1, 16-byte store of dz1')
+    const float4 sc = *reinterpret_cast<const float4 *>(scale1 + 4 * kq), sh = *reinterpret_cast<const float4 *>(shift1 + 4 * kq);
+    const float4 mu = *reinterpret_cast<const float4 *>(mean1 + 4 * kq), rs = *reinterpret_cast<const float4 *>(rstd1 + 4 * kq);
     // taps along one axis for input index i: even -> {0, 2}, odd -> {1}; output index (i - d)/2 in [0, O2)
-    const int nz = (iz & 1) ? 1 : 2;
-    for (int iy = wv; iy < O1; iy += kEncWaves) {
+    for (int wk = wv; wk < (iz1 - iz0) * O1; wk += kBigWaves) {
+        const int iz = iz0 + wk / O1, iy = wk % O1;
+        const int nz = (iz & 1) ? 1 : 2;
         const int ny = (iy & 1) ? 1 : 2;
         for (int px = 0; px < 2; ++px) {
             const int nvox = (O1 - px + 1) / 2;  // voxels ix = 2j + px < O1
@@ -401,30 +526,32 @@ __global__ __launch_bounds__(kEncThreads) void k_conv2_dgrad(
                                 dy2 + ((((size_t)b * O2 + oz) * O2 + oy) * O2 + oxc) * kC + 4 * kq);
                             if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
                             const int tap = (dz * 3 + dy) * 3 + dx;
-                            const float *wb = w2d + tap * 256 + lane;
-                            acc = mfma4(v.x, wb[0], acc);
-                            acc = mfma4(v.y, wb[64], acc);
-                            acc = mfma4(v.z, wb[128], acc);
-                            acc = mfma4(v.w, wb[192], acc);
+                            const float *wb = w2d + tap * 256 + lane;  // [(tap*4+s)*4+kq][ci = m]
+                            acc = mfma4(wb[0], v.x, acc);
+                            acc = mfma4(wb[64], v.y, acc);
+                            acc = mfma4(wb[128], v.z, acc);
+                            acc = mfma4(wb[192], v.w, acc);
                         }
                     }
                 }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ji = j0 + 4 * kq + r;
-                    if (ji < nvox) {
-                        const size_t idx = ((((size_t)b * O1 + iz) * O1 + iy) * O1 + (2 * ji + px)) * kC + m;
-                        const float y = y1[idx];
-                        const float g = fmaf(sc, y, sh) > 0.0f ? acc[r] : 0.0f;
-                        dz1p[idx] = g;
-                        s1 += g;
-                        s2 += g * ((y - mu) * rs);
-                    }
+                if (j < nvox) {
+                    const size_t idx = vox1(b, iz, iy, 2 * j + px, O1) * kC + 4 * kq;
+                    const float4 y = *reinterpret_cast<const float4 *>(y1 + idx);
+                    float4 g;
+                    g.x = fmaf(sc.x, y.x, sh.x) > 0.0f ? acc[0] : 0.0f;
+                    g.y = fmaf(sc.y, y.y, sh.y) > 0.0f ? acc[1] : 0.0f;
+                    g.z = fmaf(sc.z, y.z, sh.z) > 0.0f ? acc[2] : 0.0f;
+                    g.w = fmaf(sc.w, y.w, sh.w) > 0.0f ? acc[3] : 0.0f;
+                    *reinterpret_cast<float4 *>(dz1p + idx) = g;
+                    s1[0] += g.x; s2[0] += g.x * ((y.x - mu.x) * rs.x);
+                    s1[1] += g.y; s2[1] += g.y * ((y.y - mu.y) * rs.y);
+                    s1[2] += g.z; s2[2] += g.z * ((y.z - mu.z) * rs.z);
+                    s1[3] += g.w; s2[3] += g.w * ((y.w - mu.w) * rs.w);
                 }
             }
         }
     }
-    write_partials(partials, blockIdx.x * kEncWaves + wv, s1, s2);
+    write_partials_cl(partials, blockIdx.x * kBigWaves + wv, s1, s2);
 }
 
 // ---------------------------------------------------------------------------
@@ -455,23 +582,34 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_wgrad(
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float bsum = 0.0f;
     const int nrows = B * O1 * O1;
-    for (int row = wave_global; row < nrows; row += nwaves) {
+    int row0, row1;
+    wave_row_range(nrows, row0, row1);
+    (void)nwaves;
+    for (int row = row0; row < row1; ++row) {
         const int b = row / (O1 * O1), rem = row - b * O1 * O1, oz = rem / O1, oy = rem - oz * O1;
         const float *in = obs_base + (rows ? rows[b] : (int64_t)b) * row_stride + ((size_t)(2 * oz) * G + 2 * oy) * G;
-        const size_t base = (((size_t)b * O1 + oz) * O1 + oy) * O1;
-        for (int x0 = 0; x0 < O1; x0 += 4) {
-            const int x = x0 + kq;
-            const bool ok = x < O1;
-            const int xc = ok ? x : O1 - 1;
-            const size_t idx = (base + xc) * kC + n;
-            const float y = y1[idx];
-            float dy = sc * (dz1p[idx] - m1 - ((y - mu) * rs) * m2);  // B[k = pos][j = co = n]
-            dy = ok ? dy : 0.0f;
-            bsum += dy;
-            const float a0 = tok[0] ? in[2 * xc + off[0]] : 0.0f;  // A[i = tap][k = pos]
-            const float a1 = tok[1] ? in[2 * xc + off[1]] : 0.0f;
-            acc0 = mfma4(a0, dy, acc0);
-            acc1 = mfma4(a1, dy, acc1);
+        for (int x0 = 0; x0 < O1; x0 += 16) {
+            // four x-groups per trip: all 16 loads are issued before the first MFMA
+            float g4[4], y4[4], a04[4], a14[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int x = x0 + 4 * u + kq;
+                const int xc = x < O1 ? x : O1 - 1;
+                const size_t idx = vox1(b, oz, oy, xc, O1) * kC + n;
+                g4[u] = dz1p[idx];
+                y4[u] = y1[idx];
+                a04[u] = tok[0] ? in[2 * xc + off[0]] : 0.0f;  // A[i = tap][k = pos]
+                a14[u] = tok[1] ? in[2 * xc + off[1]] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = x0 + 4 * u + kq < O1;
+                float dy = sc * (g4[u] - m1 - ((y4[u] - mu) * rs) * m2);  // B[k = pos][j = co = n]
+                dy = ok ? dy : 0.0f;
+                bsum += dy;
+                acc0 = mfma4(a04[u], dy, acc0);
+                acc1 = mfma4(a14[u], dy, acc1);
+            }
         }
     }
     float *out = partial + (size_t)wave_global * (2 * 256 + kC);
@@ -510,29 +648,37 @@ __global__ void k_bn_grads(const double *__restrict__ S1, const double *__restri
 // ===========================================================================
 static inline int out_size(int g) { return (g - 3) / 2 + 1; }
 
+GNBV_API size_t gnbv_encoder_y1_elems(int batch, int grid)
+{
+    if (batch <= 0 || grid < 7) return 0;
+    return y1_elems(batch, (grid - 3) / 2 + 1);
+}
+
 GNBV_API size_t gnbv_encoder_workspace_bytes(int batch, int grid)
 {
     if (batch <= 0 || grid < 7) return 0;
     const int o1 = out_size(grid);
     // BN partials of the largest producer (conv1 fwd / conv2 dgrad: B*O1 workgroups x 4 waves x 32 floats),
     // weight-gradient partials (kWgradWaves x 6928 floats), fp64 reduction scratch
-    const size_t bn = (size_t)batch * o1 * kEncWaves * 2 * kC * sizeof(float);
+    const size_t bn = (size_t)(batch + 8) * o1 * kEncWaves * 2 * kC * sizeof(float);
     const size_t wg = (size_t)2048 * (kTaps * 256 + kC) * sizeof(float);
-    return bn + wg + (8192 + (size_t)64 * (kTaps * 256 + kC)) * sizeof(double) + 4096;
+    return bn + wg + (8192 + (size_t)64 * (kTaps * 256 + kC)) * sizeof(double) + 2 * kTaps * 256 * sizeof(float) + 4096;
 }
 
 struct EncWs {
     float *bn_part, *wg_part;
     double *red, *tmp;
+    float *w2img;  // 2 x 6912 floats
 };
 static inline EncWs enc_carve(void *ws, int batch, int grid)
 {
     EncWs w;
     const int o1 = out_size(grid);
     w.bn_part = (float *)ws;
-    w.wg_part = w.bn_part + (size_t)batch * o1 * kEncWaves * 2 * kC;
+    w.wg_part = w.bn_part + (size_t)(batch + 8) * o1 * kEncWaves * 2 * kC;
     w.red = (double *)(((uintptr_t)(w.wg_part + (size_t)2048 * (kTaps * 256 + kC)) + 255) & ~(uintptr_t)255);
     w.tmp = w.red + 8192;
+    w.w2img = (float *)(w.tmp + (size_t)64 * (kTaps * 256 + kC));
     return w;
 }
 
@@ -568,18 +714,20 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     float *bn1 = bn_state, *bn2 = bn_state + 4 * kC;
     int err;
     // conv1 (+ BN1 statistics)
-    hipLaunchKernelGGL(k_conv1_fwd, dim3(batch * O1), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, batch, grid, O1, p->w1,
+    hipLaunchKernelGGL(k_conv1_fwd, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, batch, grid, O1, p->w1,
                        p->b1, y1, training ? w.bn_part : nullptr);
     if ((err = gnbv_launch_status())) return err;
-    if (training && (err = reduce_launch(w.bn_part, batch * O1 * kEncWaves, 2 * kC, w.red, w.tmp, st))) return err;
+    if (training && (err = reduce_launch(w.bn_part, sample_plane_grid(batch, O1) * kEncWaves, 2 * kC, w.red, w.tmp, st))) return err;
     hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, w.red, (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps,
                        p->momentum, training, p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC);
     if ((err = gnbv_launch_status())) return err;
     // conv2 (BN1 + ReLU on load; + BN2 statistics)
-    hipLaunchKernelGGL(k_conv2_fwd, dim3(batch * O2), dim3(kEncThreads), 0, st, y1, bn1, bn1 + kC, batch, O1, O2, p->w2, p->b2, y2,
+    hipLaunchKernelGGL(k_prep_w2, dim3(kTaps), dim3(256), 0, st, p->w2, w.w2img, w.w2img + kTaps * 256);
+    const int g2 = sample_plane_group_grid(batch, O2, kPlanesPerGroup);
+    hipLaunchKernelGGL(k_conv2_fwd, dim3(g2), dim3(kBigThreads), 0, st, y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
                        training ? w.bn_part : nullptr);
     if ((err = gnbv_launch_status())) return err;
-    if (training && (err = reduce_launch(w.bn_part, batch * O2 * kEncWaves, 2 * kC, w.red + 64, w.tmp, st))) return err;
+    if (training && (err = reduce_launch(w.bn_part, g2 * kBigWaves, 2 * kC, w.red + 64, w.tmp, st))) return err;
     hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, w.red + 64, (double)batch * P2, p->bn2_w, p->bn2_b, p->eps,
                        p->momentum, training, p->bn2_rm, p->bn2_rv, p->bn2_nbt, skip_flag, bn2, bn2 + kC, bn2 + 2 * kC, bn2 + 3 * kC);
     if ((err = gnbv_launch_status())) return err;
@@ -620,7 +768,7 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     // ---- conv2 weight gradient ----
     int nrows2 = batch * O2 * O2;
     int wg_blocks = (nrows2 + kEncWaves - 1) / kEncWaves;
-    wg_blocks = wg_blocks > 512 ? 512 : wg_blocks;
+    wg_blocks = wg_blocks > 512 ? 512 : ((wg_blocks + 7) & ~7);
     hipLaunchKernelGGL(k_conv2_wgrad, dim3(wg_blocks), dim3(kEncThreads), 0, st, y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
                        w.wg_part);
     if ((err = gnbv_launch_status())) return err;
@@ -629,15 +777,17 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     hipLaunchKernelGGL(k_conv2_wgrad_finish, dim3((E2 + 255) / 256), dim3(256), 0, st, w.red + 256, g->w2, g->b2);
     if ((err = gnbv_launch_status())) return err;
     // ---- conv2 data gradient (+ ReLU1 mask, BN1 backward sums) ----
-    hipLaunchKernelGGL(k_conv2_dgrad, dim3(batch * O1), dim3(kEncThreads), 0, st, dy2_scratch, p->w2, y1, bn1, bn1 + kC, bn1 + 2 * kC,
+    hipLaunchKernelGGL(k_prep_w2, dim3(kTaps), dim3(256), 0, st, p->w2, w.w2img, w.w2img + kTaps * 256);
+    const int gd = sample_plane_group_grid(batch, O1, kPlanesPerGroup);
+    hipLaunchKernelGGL(k_conv2_dgrad, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), y1, bn1, bn1 + kC, bn1 + 2 * kC,
                        bn1 + 3 * kC, batch, O1, O2, dz1_scratch, w.bn_part);
     if ((err = gnbv_launch_status())) return err;
     double *S1 = w.red + 192;
-    if ((err = reduce_launch(w.bn_part, batch * O1 * kEncWaves, 2 * kC, S1, w.tmp, st))) return err;
+    if ((err = reduce_launch(w.bn_part, gd * kBigWaves, 2 * kC, S1, w.tmp, st))) return err;
     // ---- conv1 weight gradient (BN1 backward fused) ----
     int nrows1 = batch * O1 * O1;
     int wg1_blocks = (nrows1 + kEncWaves - 1) / kEncWaves;
-    wg1_blocks = wg1_blocks > 512 ? 512 : wg1_blocks;
+    wg1_blocks = wg1_blocks > 512 ? 512 : ((wg1_blocks + 7) & ~7);
     hipLaunchKernelGGL(k_conv1_wgrad, dim3(wg1_blocks), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, dz1_scratch, y1, bn1,
                        bn1 + 2 * kC, bn1 + 3 * kC, S1, (double)batch * O1 * O1 * O1, batch, grid, O1, w.wg_part);
     if ((err = gnbv_launch_status())) return err;

@@ -76,7 +76,7 @@ class _GridEncoderFn(torch.autograd.Function):
         o1 = conv_out(grid)
         o2 = conv_out(o1)
         p2 = o2 ** 3
-        y1 = torch.empty(batch * o1 ** 3 * 16, dtype=torch.float32, device=dev)
+        y1 = torch.empty(lib.gnbv_encoder_y1_elems(batch, grid), dtype=torch.float32, device=dev)
         y2 = torch.empty(batch * 16 * p2, dtype=torch.float32, device=dev)
         bn_state = torch.empty(2 * 4 * 16, dtype=torch.float32, device=dev)
         feats = torch.empty(batch, 16 * p2, dtype=torch.float32, device=dev)
@@ -101,7 +101,7 @@ class _GridEncoderFn(torch.autograd.Function):
         o2 = conv_out(o1)
         d_feats = d_feats.contiguous().float()
         dy2 = torch.empty(batch * o2 ** 3 * 16, dtype=torch.float32, device=dev)
-        dz1 = torch.empty(batch * o1 ** 3 * 16, dtype=torch.float32, device=dev)
+        dz1 = torch.empty(lib.gnbv_encoder_y1_elems(batch, grid), dtype=torch.float32, device=dev)
         grads = [torch.empty_like(t) for t in (seq[0].weight, seq[0].bias, seq[1].weight, seq[1].bias,
                                                seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias)]
         gs = _lib.GnbvEncoderGrads()

@@ -183,12 +183,15 @@ typedef struct GnbvEncoderGrads {  /* outputs, same shapes as the parameters */
 } GnbvEncoderGrads;
 
 size_t gnbv_encoder_workspace_bytes(int batch, int grid);
+/* number of floats of the layer-1 activation buffers (y1, dz1_scratch) */
+size_t gnbv_encoder_y1_elems(int batch, int grid);
 
 /* obs_grid: pointer to the grid slice of row 0 of an observation matrix; sample b reads
  * obs_grid + (rows ? rows[b] : b) * row_stride floats (the minibatch gather of
  * buffers.py:753-762 is fused into the read).  training != 0: BatchNorm uses batch statistics
  * and updates the running stats (unless *skip_flag != 0), else the running stats.
- * Saved for backward: y1 [B,O1,O1,O1,16] (channels-last, pre-BN), y2 [B,16,O2^3] (pre-BN),
+ * Saved for backward: y1 (gnbv_encoder_y1_elems floats: channels-last, x-parity-split, pre-BN),
+ * y2 [B,16,O2^3] (pre-BN),
  * bn_state [2][4][16] (scale, shift, mean, rstd per layer).
  * features [B, 16*O2^3] is the reference's `naive_encoder_grid(x).reshape(num_env, -1)`. */
 int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *rows, int64_t row_stride, int batch, int grid,
@@ -197,7 +200,7 @@ int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *rows, int64_
                               void *stream);
 
 /* Gradients of all eight parameter tensors given d_features [B, 16*O2^3].
- * dy2_scratch [B,O2^3,16] and dz1_scratch [B,O1^3,16] are caller-owned scratch. */
+ * dy2_scratch [B,O2^3,16] and dz1_scratch (gnbv_encoder_y1_elems floats) are caller-owned scratch. */
 int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *rows, int64_t row_stride, int batch, int grid,
                                const GnbvEncoderParams *params /*[host]*/, const float *y1, const float *y2,
                                const float *bn_state, const float *d_features, float *dy2_scratch, float *dz1_scratch,
