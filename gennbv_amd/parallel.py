@@ -51,12 +51,14 @@ def shard_range(total_envs: int, rank: int, world: int):
 class GradSync:
     """Gradient (+ KL) averaging for both train paths."""
 
-    def __init__(self, world: int, group=None):
+    def __init__(self, world: int, group=None, always_sync: bool = False):
         self.world, self.group = int(world), group
+        # exercise the collective path even with one rank (single-GPU test of the data-parallel code)
+        self.active = self.world > 1 or always_sync
 
     # ---- torch-module path (per-parameter grads) --------------------------------------
     def average_grads(self, params: Iterable[torch.nn.Parameter]) -> None:
-        if self.world == 1:
+        if not self.active:
             return
         grads = [p.grad for p in params if p.grad is not None]
         flat = torch.cat([g.reshape(-1) for g in grads])
@@ -69,7 +71,7 @@ class GradSync:
             off += n
 
     def mean_scalar(self, x: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
+        if not self.active:
             return x
         y = x.detach().clone()
         dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
@@ -77,16 +79,16 @@ class GradSync:
 
     # ---- fused path: flat gradient buffer with the KL slot appended ---------------------
     def all_reduce_flat(self, flat_with_slot: torch.Tensor) -> None:
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(flat_with_slot, op=dist.ReduceOp.SUM, group=self.group)
 
 
-def attach(algo, world: int, group=None) -> GradSync:
+def attach(algo, world: int, group=None, always_sync: bool = False) -> GradSync:
     """Make `algo` (PPO_Grid_Obs) a data-parallel replica: identical initial parameters on every
     rank (broadcast from rank 0) and gradient / KL synchronisation in train()."""
-    sync = GradSync(world, group)
+    sync = GradSync(world, group, always_sync)
     algo._sync = sync
-    if world > 1:
+    if sync.active:
         for t in list(algo.policy.parameters()) + list(algo.policy.buffers()):
             dist.broadcast(t.data, src=0, group=group)
     return sync

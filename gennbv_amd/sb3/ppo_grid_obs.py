@@ -218,7 +218,7 @@ class PPO_Grid_Obs:
                            betas=old.defaults.get("betas", (0.9, 0.999)))
             opt.load_torch_adam_state(old)
         self._hip = {"loss": loss, "opt": opt, "batch": batch, "n_mb": n_minibatches, "graph": None}
-        if self._sync is not None and self._sync.world > 1:
+        if self._sync is not None and self._sync.active:
             # the rank's approx-KL rides in the slot behind the flat gradient; the flag is set from
             # the GLOBAL mean after the all-reduce (gnbv_clip_adam_step), not by the loss kernel
             loss.args.kl_out = opt.kl_slot.data_ptr()
@@ -238,7 +238,7 @@ class PPO_Grid_Obs:
         d_logits, d_values = loss(logits, values)
         opt.zero_grad()
         torch.autograd.backward([logits, values], [d_logits, d_values])
-        if self._sync is None or self._sync.world == 1:
+        if self._sync is None or not self._sync.active:
             opt.step(self.max_grad_norm, loss.stop_flag)
 
     def _hip_minibatch_tail(self, st):
@@ -288,7 +288,7 @@ class PPO_Grid_Obs:
                     st["graph"].replay()
                 else:
                     self._hip_minibatch_body(st)
-                if self._sync is not None and self._sync.world > 1:
+                if self._sync is not None and self._sync.active:
                     self._sync.all_reduce_flat(opt.grads_with_slot)  # ONE collective per optimizer step
                     self._hip_minibatch_tail(st)
             epochs_run += 1

@@ -103,3 +103,20 @@ def test_flat_adam_matches_torch_adam_with_clipping():
     before = o2.params.clone()
     o2.step(1.0, flag)  # masked: nothing moves, step count frozen
     assert torch.equal(before, o2.params) and int(o2.step_count.item()) == 25
+
+
+@pytest.mark.parametrize("name", ["F9_ppo_train", "F9_ppo_train_earlystop"])
+def test_data_parallel_code_path_on_one_gpu(name):
+    """The multi-GPU branch (graph body -> RCCL all-reduce of the flat gradient + KL slot -> clip/Adam
+    tail with the global KL decision) with a one-rank NCCL communicator must reproduce the goldens."""
+    import os
+    import torch.distributed as dist
+    from gennbv_amd import parallel
+    if not dist.is_initialized():
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    fx = gu.load(name)
+    ppo = _ppo_from_fixture(fx, device=DEV, backend="hip")
+    parallel.attach(ppo, 1, always_sync=True)
+    _check(ppo, fx)
