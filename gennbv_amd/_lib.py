@@ -36,6 +36,11 @@ SIGNATURES = {
     "gnbv_update_occ_grid": (_i, [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _i64, _p,
                                   _p, _sz, _p]),
     "gnbv_unpack_masks": (_i, [_p, _i, _i, _p, _p, _p]),
+    "gnbv_grid_bit_words": (_i, [_i]),
+    "gnbv_pack_grid_bits": (_i, [_p, _i, _i, _p, _p, _p]),
+    "gnbv_unpack_grid_bits": (_i, [_p, _i, _i, _p, _p]),
+    "gnbv_update_occ_grid_packed": (_i, [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _i64, _p,
+                                         _p, _sz, _p]),
     "gnbv_env_pre_step": (_i, [_p, _p, _p, _i, _p, _p, _p]),
     "gnbv_env_obs_state": (_i, [_p, _p, _p, _p, _i, _i, _p, _i64, _p]),
     "gnbv_env_obs_rgb": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i64, _p]),

@@ -559,6 +559,108 @@ __global__ __launch_bounds__(kGridThreads) void k_grid_update(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Packed variant: the ground truth and the scanned set are BITMASKS ([N, words] u32).  For a
+// binary grid_gt (the reference's GT is an occupancy indicator, env_train_gennbv.py:64-66)
+//   scanned = clip(scanned + occ*gt, 0, 1)   <=>   scanned_bits |= hit_bits & gt_bits
+// exactly, and sum(scanned) is a popcount.  Same results, half the HBM traffic of the streaming
+// pass: prob (R+W) + tri (W) = 12 B/voxel instead of 24.
+// ---------------------------------------------------------------------------
+template <bool VEC4>
+__global__ __launch_bounds__(kGridThreads) void k_grid_update_packed(
+    const uint32_t *__restrict__ hit_mask, const uint32_t *__restrict__ path_mask, const uint32_t *__restrict__ gt_bits,
+    const uint8_t *__restrict__ reset_mask, int n, int g3, int words, int words_gt, float *__restrict__ prob_grid,
+    uint32_t *__restrict__ scanned_bits, float *__restrict__ tri_out, int64_t tri_stride, int32_t *__restrict__ coverage)
+{
+    const int e = blockIdx.y;
+    const bool reset = reset_mask != nullptr && reset_mask[e] != 0;
+    const uint32_t *hm = hit_mask + (size_t)e * words, *pm = path_mask + (size_t)e * words;
+    const uint32_t *gb = gt_bits + (size_t)e * words_gt;
+    uint32_t *sb = scanned_bits + (size_t)e * words_gt;
+    float *prob = prob_grid + (size_t)e * g3;
+    float *tri = tri_out + (size_t)e * tri_stride;
+    int cov = 0;
+    auto voxel = [](float &pr, bool hit, bool path, float &t) {
+        if (path) pr = __fsub_rn(pr, 0.05f);
+        if (hit) pr = 1.0f;
+        t = (pr > 0.5f ? 1.0f : 0.0f) - (pr < 0.0f ? 1.0f : 0.0f);
+    };
+    if (VEC4) {
+        const int nv = g3 >> 2;
+        for (int i = blockIdx.x * kGridThreads + threadIdx.x; i < nv; i += gridDim.x * kGridThreads) {
+            const int v0 = i << 2, wd = v0 >> 5;
+            const uint32_t hw = hm[wd], pw = pm[wd];
+            const uint32_t hb = (hw >> (v0 & 31)) & 0xFu, pb = (pw >> (v0 & 31)) & 0xFu;
+            float4 p4 = reset ? make_float4(0, 0, 0, 0) : reinterpret_cast<const float4 *>(prob)[i];
+            float4 t4;
+            voxel(p4.x, hb & 1u, pb & 1u, t4.x);
+            voxel(p4.y, hb & 2u, pb & 2u, t4.y);
+            voxel(p4.z, hb & 4u, pb & 4u, t4.z);
+            voxel(p4.w, hb & 8u, pb & 8u, t4.w);
+            reinterpret_cast<float4 *>(prob)[i] = p4;
+            reinterpret_cast<float4 *>(tri)[i] = t4;
+            if ((v0 & 31) == 0) {  // one lane in eight owns the 32-voxel word of the scanned set
+                const uint32_t sw = (reset ? 0u : sb[wd]) | (hw & gb[wd]);
+                sb[wd] = sw;
+                cov += __popc(sw);
+            }
+        }
+    } else {
+        for (int v = blockIdx.x * kGridThreads + threadIdx.x; v < g3; v += gridDim.x * kGridThreads) {
+            const int wd = v >> 5;
+            const uint32_t hw = hm[wd];
+            const bool hb = (hw >> (v & 31)) & 1u, pb = (pm[wd] >> (v & 31)) & 1u;
+            float p = reset ? 0.0f : prob[v], t;
+            voxel(p, hb, pb, t);
+            prob[v] = p;
+            tri[v] = t;
+            if ((v & 31) == 0) {
+                const uint32_t sw = (reset ? 0u : sb[wd]) | (hw & gb[wd]);
+                sb[wd] = sw;
+                cov += __popc(sw);
+            }
+        }
+    }
+    __shared__ int s_cov[kGridThreads / kWave];
+    cov = wave_reduce_sum(cov);
+    if ((threadIdx.x & (kWave - 1)) == 0) s_cov[threadIdx.x / kWave] = cov;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < kGridThreads / kWave; ++i) t += s_cov[i];
+        if (t) atomicAdd(&coverage[e], t);
+    }
+}
+
+// f32 grid [N, G^3] -> bitmask [N, words] (bit = value != 0); *not_binary is set when a value is
+// neither 0 nor 1.  One wave-ballot per 64 voxels.
+__global__ void k_pack_bits(const float *__restrict__ grid, int n, int g3, int words, uint32_t *__restrict__ bits, int *__restrict__ not_binary)
+{
+    const int e = blockIdx.y;
+    const float *src = grid + (size_t)e * g3;
+    uint32_t *dst = bits + (size_t)e * words;
+    const int lane = threadIdx.x & 63;
+    const int g3p = (g3 + 63) & ~63;
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < g3p; v += gridDim.x * blockDim.x) {
+        const float x = v < g3 ? src[v] : 0.0f;
+        if (x != 0.0f && x != 1.0f && not_binary) *not_binary = 1;
+        const unsigned long long m = __ballot(x != 0.0f);
+        if (lane == 0) dst[v >> 5] = (uint32_t)m;
+        if (lane == 32 && (v >> 5) < words) dst[v >> 5] = (uint32_t)(m >> 32);
+    }
+}
+
+__global__ void k_unpack_bits_f32(const uint32_t *__restrict__ bits, int n, int64_t g3, int words, float *__restrict__ out)
+{
+    const int64_t total = (int64_t)n * g3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i / g3);
+        const int v = (int)(i - (int64_t)e * g3);
+        out[i] = ((bits[(size_t)e * words + (v >> 5)] >> (v & 31)) & 1u) ? 1.0f : 0.0f;
+    }
+}
+
 // ===========================================================================
 // standalone operators (function-level drop-ins, parity at every stage)
 // ===========================================================================
@@ -782,31 +884,21 @@ GNBV_API int gnbv_grid_tri_cls(const float *grid_prob, int64_t count, float thre
 }
 
 
-GNBV_API int gnbv_update_occ_grid(const float *depth_raw, const float *seg_raw, const float *c2w, const float *inv_intri,
-                                  const float *poses_xyz, int64_t poses_row_stride, const float *range_gt,
-                                  const float *voxel_size, const float *grid_gt, const uint8_t *reset_mask, int n, int h,
-                                  int w, int g, float depth_sense_dist, float *prob_grid, float *scanned_gt_grid,
-                                  float *tri_out, int64_t tri_row_stride, int32_t *coverage_count, void *workspace,
-                                  size_t workspace_bytes, void *stream)
+// launches 1 + 2 (and the memsets): hit mask and path mask of every env into the workspace
+static int launch_masks(const float *depth_raw, const float *seg_raw, const float *c2w, const float *inv_intri,
+                        const float *poses_xyz, int64_t poses_row_stride, const float *range_gt, const float *voxel_size, int n,
+                        int h, int w, int g, float depth_sense_dist, int32_t *coverage_count, const VoxelWorkspace &ws,
+                        hipStream_t st)
 {
-    GNBV_CHECK_ARG(depth_raw && seg_raw && c2w && inv_intri && poses_xyz && range_gt && voxel_size && grid_gt);
-    GNBV_CHECK_ARG(prob_grid && scanned_gt_grid && tri_out && coverage_count && workspace);
-    GNBV_CHECK_ARG(n > 0 && h > 0 && w > 0 && g > 1 && g <= 1024 && poses_row_stride >= 3);
-    const int64_t g3 = (int64_t)g * g * g;
-    GNBV_CHECK_ARG(g3 < (1ll << 31) && tri_row_stride >= g3 && (int64_t)h * w < (1ll << 31));
-    GNBV_CHECK_ARG(workspace_bytes >= gnbv_voxel_workspace_bytes(n, g) && ((uintptr_t)workspace & 255) == 0);
-    hipStream_t st = gnbv_stream(stream);
     Intrinsics K;
     int err = fetch_intrinsics(inv_intri, st, &K);
     if (err) return err;
-    VoxelWorkspace ws = carve(workspace, n, g);
     const int words = ws.words;
     const size_t mask_bytes = (size_t)words * sizeof(uint32_t);
     const bool lds_hit = mask_bytes <= 64 * 1024;
     const bool lds_path = mask_bytes + (kQueueCap + 32) * sizeof(uint32_t) <= 64 * 1024;
-
     // ray-cast workgroups per env: ~4 per CU in total, so that an env with many hit voxels
-    // (measured 4x the mean) is spread over several CUs (A/B in profiles/r01_voxel_ab.txt)
+    // (measured 4x the mean) is spread over several CUs (profiles/r01_notes.md)
     int splits = (1024 + n - 1) / n;
     splits = splits < 1 ? 1 : (splits > 8 ? 8 : splits);
     {
@@ -820,10 +912,9 @@ GNBV_API int gnbv_update_occ_grid(const float *depth_raw, const float *seg_raw, 
     if (err) return err;
     err = (int)hipMemsetAsync(coverage_count, 0, (size_t)n * sizeof(int32_t), st);
     if (err) return err;
-
     // launch 1: hit mask.  chunks: enough workgroups to cover the chip several times.
     const int env_groups = (n + 7) / 8;
-    int chunks = (8 * 256 + n - 1) / n;  // aim at >= 8 workgroups per CU-equivalent
+    int chunks = (8 * 256 + n - 1) / n;
     chunks = chunks < 1 ? 1 : (chunks > 16 ? 16 : chunks);
     const int hit_grid = env_groups * 8 * chunks;
     // inv_intri of a pinhole camera is [[a,0,c],[0,b,d],[0,0,1]]: lets the kernel drop exact-zero terms
@@ -840,8 +931,7 @@ GNBV_API int gnbv_update_occ_grid(const float *depth_raw, const float *seg_raw, 
     }
     err = gnbv_launch_status();
     if (err) return err;
-
-    // launch 2: ray cast, N x splits workgroups (>= ~4 per CU)
+    // launch 2: ray cast, N x splits workgroups
     const int ray_grid = env_groups * 8 * splits;
     const size_t ray_lds = (kQueueCap + 32) * sizeof(uint32_t);
     if (lds_path) {
@@ -851,23 +941,103 @@ GNBV_API int gnbv_update_occ_grid(const float *depth_raw, const float *seg_raw, 
         hipLaunchKernelGGL(k_raycast<false>, dim3(ray_grid), dim3(kRayThreads), ray_lds, st, ws.hit, poses_xyz,
                            poses_row_stride, range_gt, voxel_size, n, g, words, splits, ws.path);
     }
-    err = gnbv_launch_status();
-    if (err) return err;
+    return gnbv_launch_status();
+}
 
+static inline int grid_update_blocks(int64_t items, int n)
+{
+    int bx = (int)((items + kGridThreads - 1) / kGridThreads);
+    const int cap = (4096 + n - 1) / n;  // ~16 workgroups per CU in total, grid-stride beyond
+    return bx > cap ? cap : bx;
+}
+
+GNBV_API int gnbv_update_occ_grid(const float *depth_raw, const float *seg_raw, const float *c2w, const float *inv_intri,
+                                  const float *poses_xyz, int64_t poses_row_stride, const float *range_gt,
+                                  const float *voxel_size, const float *grid_gt, const uint8_t *reset_mask, int n, int h,
+                                  int w, int g, float depth_sense_dist, float *prob_grid, float *scanned_gt_grid,
+                                  float *tri_out, int64_t tri_row_stride, int32_t *coverage_count, void *workspace,
+                                  size_t workspace_bytes, void *stream)
+{
+    GNBV_CHECK_ARG(depth_raw && seg_raw && c2w && inv_intri && poses_xyz && range_gt && voxel_size && grid_gt);
+    GNBV_CHECK_ARG(prob_grid && scanned_gt_grid && tri_out && coverage_count && workspace);
+    GNBV_CHECK_ARG(n > 0 && h > 0 && w > 0 && g > 1 && g <= 1024 && poses_row_stride >= 3);
+    const int64_t g3 = (int64_t)g * g * g;
+    GNBV_CHECK_ARG(g3 < (1ll << 31) && tri_row_stride >= g3 && (int64_t)h * w < (1ll << 31));
+    GNBV_CHECK_ARG(workspace_bytes >= gnbv_voxel_workspace_bytes(n, g) && ((uintptr_t)workspace & 255) == 0);
+    hipStream_t st = gnbv_stream(stream);
+    VoxelWorkspace ws = carve(workspace, n, g);
+    int err = launch_masks(depth_raw, seg_raw, c2w, inv_intri, poses_xyz, poses_row_stride, range_gt, voxel_size, n, h, w, g,
+                           depth_sense_dist, coverage_count, ws, st);
+    if (err) return err;
     // launch 3: grid update
     const bool vec4 = (g3 % 4 == 0) && (tri_row_stride % 4 == 0) && (((uintptr_t)tri_out & 15) == 0) &&
                       (((uintptr_t)prob_grid & 15) == 0) && (((uintptr_t)scanned_gt_grid & 15) == 0) &&
                       (((uintptr_t)grid_gt & 15) == 0);
-    const int64_t items = vec4 ? g3 / 4 : g3;
-    int bx = (int)((items + kGridThreads - 1) / kGridThreads);
-    const int cap = (4096 + n - 1) / n;  // ~16 workgroups per CU in total, grid-stride beyond
-    bx = bx > cap ? cap : bx;
+    const int bx = grid_update_blocks(vec4 ? g3 / 4 : g3, n);
     if (vec4)
         hipLaunchKernelGGL(k_grid_update<true>, dim3(bx, n), dim3(kGridThreads), 0, st, ws.hit, ws.path, grid_gt, reset_mask,
-                           n, (int)g3, words, prob_grid, scanned_gt_grid, tri_out, tri_row_stride, coverage_count);
+                           n, (int)g3, ws.words, prob_grid, scanned_gt_grid, tri_out, tri_row_stride, coverage_count);
     else
         hipLaunchKernelGGL(k_grid_update<false>, dim3(bx, n), dim3(kGridThreads), 0, st, ws.hit, ws.path, grid_gt,
-                           reset_mask, n, (int)g3, words, prob_grid, scanned_gt_grid, tri_out, tri_row_stride,
+                           reset_mask, n, (int)g3, ws.words, prob_grid, scanned_gt_grid, tri_out, tri_row_stride,
+                           coverage_count);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_grid_bit_words(int g) { return g > 0 ? mask_words_padded(g) : 0; }
+
+GNBV_API int gnbv_pack_grid_bits(const float *grid, int n, int g, uint32_t *bits, int *not_binary, void *stream)
+{
+    GNBV_CHECK_ARG(grid && bits && n > 0 && g > 0);
+    const int64_t g3 = (int64_t)g * g * g;
+    const int words = mask_words_padded(g);
+    hipStream_t st = gnbv_stream(stream);
+    int err = (int)hipMemsetAsync(bits, 0, (size_t)n * words * sizeof(uint32_t), st);
+    if (err) return err;
+    if (not_binary && (err = (int)hipMemsetAsync(not_binary, 0, sizeof(int), st))) return err;
+    int bx = (int)((g3 + 255) / 256);
+    bx = bx > 1024 ? 1024 : bx;
+    hipLaunchKernelGGL(k_pack_bits, dim3(bx, n), dim3(256), 0, st, grid, n, (int)g3, words, bits, not_binary);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_unpack_grid_bits(const uint32_t *bits, int n, int g, float *grid, void *stream)
+{
+    GNBV_CHECK_ARG(grid && bits && n > 0 && g > 0);
+    const int64_t g3 = (int64_t)g * g * g;
+    hipLaunchKernelGGL(k_unpack_bits_f32, dim3(grid_for(n * g3, 256)), dim3(256), 0, gnbv_stream(stream), bits, n, g3,
+                       mask_words_padded(g), grid);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_update_occ_grid_packed(const float *depth_raw, const float *seg_raw, const float *c2w, const float *inv_intri,
+                                         const float *poses_xyz, int64_t poses_row_stride, const float *range_gt,
+                                         const float *voxel_size, const uint32_t *gt_bits, const uint8_t *reset_mask, int n,
+                                         int h, int w, int g, float depth_sense_dist, float *prob_grid, uint32_t *scanned_bits,
+                                         float *tri_out, int64_t tri_row_stride, int32_t *coverage_count, void *workspace,
+                                         size_t workspace_bytes, void *stream)
+{
+    GNBV_CHECK_ARG(depth_raw && seg_raw && c2w && inv_intri && poses_xyz && range_gt && voxel_size && gt_bits);
+    GNBV_CHECK_ARG(prob_grid && scanned_bits && tri_out && coverage_count && workspace);
+    GNBV_CHECK_ARG(n > 0 && h > 0 && w > 0 && g > 1 && g <= 1024 && poses_row_stride >= 3);
+    const int64_t g3 = (int64_t)g * g * g;
+    GNBV_CHECK_ARG(g3 < (1ll << 31) && tri_row_stride >= g3 && (int64_t)h * w < (1ll << 31));
+    GNBV_CHECK_ARG(workspace_bytes >= gnbv_voxel_workspace_bytes(n, g) && ((uintptr_t)workspace & 255) == 0);
+    hipStream_t st = gnbv_stream(stream);
+    VoxelWorkspace ws = carve(workspace, n, g);
+    int err = launch_masks(depth_raw, seg_raw, c2w, inv_intri, poses_xyz, poses_row_stride, range_gt, voxel_size, n, h, w, g,
+                           depth_sense_dist, coverage_count, ws, st);
+    if (err) return err;
+    const bool vec4 = (g3 % 4 == 0) && (tri_row_stride % 4 == 0) && (((uintptr_t)tri_out & 15) == 0) &&
+                      (((uintptr_t)prob_grid & 15) == 0);
+    const int bx = grid_update_blocks(vec4 ? g3 / 4 : g3, n);
+    if (vec4)
+        hipLaunchKernelGGL(k_grid_update_packed<true>, dim3(bx, n), dim3(kGridThreads), 0, st, ws.hit, ws.path, gt_bits,
+                           reset_mask, n, (int)g3, ws.words, ws.words, prob_grid, scanned_bits, tri_out, tri_row_stride,
+                           coverage_count);
+    else
+        hipLaunchKernelGGL(k_grid_update_packed<false>, dim3(bx, n), dim3(kGridThreads), 0, st, ws.hit, ws.path, gt_bits,
+                           reset_mask, n, (int)g3, ws.words, ws.words, prob_grid, scanned_bits, tri_out, tri_row_stride,
                            coverage_count);
     return gnbv_launch_status();
 }

@@ -22,7 +22,7 @@ from .. import _lib
 class OccupancyGridUpdater:
     def __init__(self, num_envs: int, grid_size: int, camera_height: int, camera_width: int,
                  inv_intri: torch.Tensor, range_gt: torch.Tensor, voxel_size_gt: torch.Tensor, grid_gt: torch.Tensor,
-                 device, depth_sense_dist: float = -50.0):
+                 device, depth_sense_dist: float = -50.0, packed: Optional[bool] = None):
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -37,7 +37,17 @@ class OccupancyGridUpdater:
         self.grid_gt = grid_gt.to(self.device, torch.float32).contiguous()
         assert self.grid_gt.shape == (num_envs, g, g, g)
         self.prob_grid = torch.zeros(num_envs, g, g, g, dtype=torch.float32, device=self.device)
-        self.scanned_gt_grid = torch.zeros_like(self.prob_grid)
+        # Binary ground truth (the reference's GT is an occupancy indicator): keep grid_gt and the
+        # scanned set as bitmasks -- identical results, half the HBM traffic of the streaming pass.
+        words = self.lib.gnbv_grid_bit_words(g)
+        self.gt_bits = torch.zeros(num_envs, words, dtype=torch.int32, device=self.device)
+        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.gnbv_pack_grid_bits(self.grid_gt.data_ptr(), num_envs, g, self.gt_bits.data_ptr(), flag.data_ptr(),
+                                                _lib.stream_ptr(self.device)), "gnbv_pack_grid_bits")
+        binary = int(flag.item()) == 0
+        self.packed = binary if packed is None else (bool(packed) and binary)
+        self.scanned_bits = torch.zeros(num_envs, words, dtype=torch.int32, device=self.device)
+        self._scanned_f32 = None if self.packed else torch.zeros_like(self.prob_grid)
         self.coverage_count = torch.zeros(num_envs, dtype=torch.int32, device=self.device)
         nbytes = self.lib.gnbv_voxel_workspace_bytes(num_envs, g)
         # torch's caching allocator returns >=512-byte aligned blocks
@@ -64,14 +74,35 @@ class OccupancyGridUpdater:
             tri_out, tri_row_stride = self._own_tri, g ** 3
         if reset_mask is not None:
             assert reset_mask.dtype == torch.uint8 and reset_mask.is_contiguous()
+        if self.packed:
+            _lib.check(self.lib.gnbv_update_occ_grid_packed(
+                depth_raw.data_ptr(), seg_raw.data_ptr(), c2w.data_ptr(), self.inv_intri_host.data_ptr(),
+                poses.data_ptr(), poses.stride(0), self.range_gt.data_ptr(), self.voxel_size_gt.data_ptr(),
+                self.gt_bits.data_ptr(), _lib.ptr(reset_mask), n, self.h, self.w, g, self.depth_sense_dist,
+                self.prob_grid.data_ptr(), self.scanned_bits.data_ptr(), tri_out.data_ptr(), int(tri_row_stride),
+                self.coverage_count.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
+                _lib.stream_ptr(self.device)), "gnbv_update_occ_grid_packed")
+            return tri_out
         _lib.check(self.lib.gnbv_update_occ_grid(
             depth_raw.data_ptr(), seg_raw.data_ptr(), c2w.data_ptr(), self.inv_intri_host.data_ptr(),
             poses.data_ptr(), poses.stride(0), self.range_gt.data_ptr(), self.voxel_size_gt.data_ptr(),
             self.grid_gt.data_ptr(), _lib.ptr(reset_mask), n, self.h, self.w, g, self.depth_sense_dist,
-            self.prob_grid.data_ptr(), self.scanned_gt_grid.data_ptr(), tri_out.data_ptr(), int(tri_row_stride),
+            self.prob_grid.data_ptr(), self._scanned_f32.data_ptr(), tri_out.data_ptr(), int(tri_row_stride),
             self.coverage_count.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
             _lib.stream_ptr(self.device)), "gnbv_update_occ_grid")
         return tri_out
+
+    @property
+    def scanned_gt_grid(self) -> torch.Tensor:
+        """The reference's fp32 [N,G,G,G] tensor (env_train_gennbv.py:182-183); in packed mode it is
+        expanded from the bitmask on demand."""
+        if not self.packed:
+            return self._scanned_f32
+        n, g = self.num_envs, self.grid_size
+        out = torch.empty(n, g, g, g, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.gnbv_unpack_grid_bits(self.scanned_bits.data_ptr(), n, g, out.data_ptr(),
+                                                  _lib.stream_ptr(self.device)), "gnbv_unpack_grid_bits")
+        return out
 
     def masks(self):
         """(hit, path) bool [N,G,G,G] of the last update (parity / debugging)."""

@@ -98,6 +98,21 @@ int gnbv_update_occ_grid(const float *depth_raw, const float *seg_raw, const flo
                          float *prob_grid, float *scanned_gt_grid, float *tri_out, int64_t tri_row_stride,
                          int32_t *coverage_count, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Packed variant of gnbv_update_occ_grid for a BINARY ground truth (the reference's GT is an
+ * occupancy indicator): grid_gt and scanned_gt_grid are bitmasks [N, gnbv_grid_bit_words(G)] u32
+ * (bit v = voxel (x*G+y)*G+z). scanned = clip(scanned + occ*gt, 0, 1) == scanned | (hit & gt)
+ * exactly, coverage = popcount. Identical results, half the HBM traffic of the streaming pass. */
+int gnbv_grid_bit_words(int g);
+int gnbv_pack_grid_bits(const float *grid /*[N,G^3]*/, int n, int g, uint32_t *bits, int *not_binary /*[1] or NULL*/,
+                        void *stream);
+int gnbv_unpack_grid_bits(const uint32_t *bits, int n, int g, float *grid /*[N,G^3] of {0,1}*/, void *stream);
+int gnbv_update_occ_grid_packed(const float *depth_raw, const float *seg_raw, const float *c2w,
+                                const float *inv_intri /*[host] [3,3]*/, const float *poses_xyz, int64_t poses_row_stride,
+                                const float *range_gt, const float *voxel_size, const uint32_t *gt_bits,
+                                const uint8_t *reset_mask, int n, int h, int w, int g, float depth_sense_dist,
+                                float *prob_grid, uint32_t *scanned_bits, float *tri_out, int64_t tri_row_stride,
+                                int32_t *coverage_count, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Debug/parity view of the workspace after gnbv_update_occ_grid: expands the
  * hit / path bitmasks to u8 [N,G^3] (either output may be NULL). */
 int gnbv_unpack_masks(const void *workspace, int n, int g, uint8_t *hit_u8, uint8_t *path_u8, void *stream);

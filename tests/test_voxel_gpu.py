@@ -57,14 +57,16 @@ def test_postprocess_backprojection_voxelidx_vs_golden():
     assert utils.scanned_pts_to_idx_3D([torch.zeros(0, 3, device=DEV)], T(fx["range_gt"]), T(fx["voxel_size"]), g) == [[]]
 
 
-def _run_sequence(n, h, w, g, steps, seed, reset_at=(), pose_override=None):
+def _run_sequence(n, h, w, g, steps, seed, reset_at=(), pose_override=None, packed=None, gt_scale=None):
     """HIP updater vs oracle on the same seeded synthetic frames; returns per-step mismatch info."""
     from gennbv_amd.env.state_encoding import OccupancyGridUpdater
     cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
     scene = S.make_scenes(n, g, seed=seed)
     frames = S.make_frames(scene, cfg, min(steps, 4), seed=seed, with_rgba=False)
     kinv = S.inverse_intrinsics(h, w)
-    upd = OccupancyGridUpdater(n, g, h, w, kinv, scene.range_gt, scene.voxel_size, scene.grid_gt, DEV)
+    if gt_scale is not None:
+        scene.grid_gt = scene.grid_gt * gt_scale
+    upd = OccupancyGridUpdater(n, g, h, w, kinv, scene.range_gt, scene.voxel_size, scene.grid_gt, DEV, packed=packed)
     prob = np.zeros((n, g, g, g), np.float32)
     scan = np.zeros_like(prob)
     rs = np.random.RandomState(seed)
@@ -98,6 +100,18 @@ def _run_sequence(n, h, w, g, steps, seed, reset_at=(), pose_override=None):
                                            (2, 30, 37, 33, 3), (2, 60, 80, 128, 2)])
 def test_fused_update_bit_exact_vs_oracle(n, h, w, g, steps):
     _run_sequence(n, h, w, g, steps, seed=11 + g, reset_at=(2,))
+
+
+def test_f32_path_and_non_binary_ground_truth():
+    """packed=False keeps the reference's fp32 scanned/gt tensors; a non-binary GT (0.4 per voxel:
+    scanned accumulates 0.4, 0.8, then clips at 1) automatically takes that path."""
+    upd = _run_sequence(3, 60, 80, 16, 4, seed=8, reset_at=(2,), packed=False)
+    assert not upd.packed
+    upd = _run_sequence(3, 60, 80, 16, 5, seed=8, gt_scale=0.4)
+    assert not upd.packed and float(upd.scanned_gt_grid.max()) == 1.0
+    assert bool(((upd.scanned_gt_grid > 0) & (upd.scanned_gt_grid < 1)).any())
+    upd = _run_sequence(3, 60, 80, 16, 2, seed=8)
+    assert upd.packed
 
 
 def test_ray_source_far_outside_grid():
