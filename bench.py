@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--backend", default=os.environ.get("GENNBV_ENCODER_BACKEND", "hip"), choices=["hip", "torch"])
     ap.add_argument("--dtype", default="fp32", choices=["fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--save-gemm-tuning", default=None, help="write the TunableOp selections to this file")
     return ap.parse_args()
 
 
@@ -196,6 +197,8 @@ def main():
     torch.cuda.set_device(device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    from gennbv_amd import gemm_tuning
+    gemm_tuning.enable()  # rocBLAS / hipBLASLt algorithm selection for the Linear layers (warm-up tunes new shapes)
     algo, cfg, env = build_algo(args, device, rank, world)
     algo._setup_learn(total_timesteps=10 ** 12)
 
@@ -258,6 +261,8 @@ def main():
             except Exception as ex:  # the baseline must never take the bench line down
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)}
         print(json.dumps(out))
+    if args.save_gemm_tuning and rank == 0:
+        gemm_tuning.save(args.save_gemm_tuning)
     if world > 1:
         dist.destroy_process_group()
 

@@ -787,7 +787,7 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     // ---- conv1 weight gradient (BN1 backward fused) ----
     int nrows1 = batch * O1 * O1;
     int wg1_blocks = (nrows1 + kEncWaves - 1) / kEncWaves;
-    wg1_blocks = wg1_blocks > 512 ? 512 : ((wg1_blocks + 7) & ~7);
+    wg1_blocks = wg1_blocks > 2048 ? 2048 : ((wg1_blocks + 7) & ~7);  // VGPR-light: 32 waves per CU hide the load latency
     hipLaunchKernelGGL(k_conv1_wgrad, dim3(wg1_blocks), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, dz1_scratch, y1, bn1,
                        bn1 + 2 * kC, bn1 + 3 * kC, S1, (double)batch * O1 * O1 * O1, batch, grid, O1, w.wg_part);
     if ((err = gnbv_launch_status())) return err;

@@ -49,6 +49,7 @@ class Hybrid_Encoder(nn.Module):
         self.grid_size = int(grid_size)
         self.backend = backend
         self.compute_dtype = compute_dtype
+        self.overlap_branches = True  # backend="hip": pose branch on a second stream
         o1, o2 = conv_out(self.grid_size)
         self.grid_feat = 16 * o2 ** 3  # 1024 at G=20
         pose_feat = int(state_input_shape[0]) * 4  # 6 -> 24 per pose (sin/cos of x*{1,2})

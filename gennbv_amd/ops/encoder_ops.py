@@ -136,8 +136,32 @@ def hybrid_forward(enc, observations) -> torch.Tensor:
         if base.stride(1) != 1:
             base = base.contiguous()
     num_env = state.shape[0]
-    action_input = enc.positional_encoding(state.view(num_env, -1, 6)).view(num_env, -1)
-    feature_action = enc.naive_encoder_action(action_input)
+    # The pose-history branch (a few small GEMMs and element-wise kernels) is independent of the grid
+    # branch until the concat: fork it onto a second HIP stream so that it overlaps the conv kernels
+    # in the forward AND (autograd replays each op on the stream it was recorded on) in the backward.
+    side = _side_stream(base.device) if enc.overlap_branches else None
+    if side is not None:
+        cur = torch.cuda.current_stream(base.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            action_input = enc.positional_encoding(state.view(num_env, -1, 6)).view(num_env, -1)
+            feature_action = enc.naive_encoder_action(action_input)
+    else:
+        action_input = enc.positional_encoding(state.view(num_env, -1, 6)).view(num_env, -1)
+        feature_action = enc.naive_encoder_action(action_input)
     feature_grid = grid_encoder(base, rows, s, g, enc.naive_encoder_grid, enc.training, getattr(enc, "_bn_skip_flag", None))
     feature_grid = enc.output_layer_grid(feature_grid)
+    if side is not None:
+        torch.cuda.current_stream(base.device).wait_stream(side)
+        feature_action.record_stream(torch.cuda.current_stream(base.device))
     return enc.output_layer(torch.cat((feature_action, feature_grid), dim=-1))
+
+
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = str(device)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device)
+    return _side_streams[key]
