@@ -126,7 +126,7 @@ def one_iteration(algo, phases):
 
 def cpu_baseline(args, cfg):
     """The oracle (CPU restatement, proven equal to the reference on the goldens) + torch-CPU
-    fp32 PPO on a bounded sample of the same workload: 4 envs, 2 env steps, full 240x320 / G
+    fp32 PPO on a bounded sample of the same workload: 16 envs, 4 env steps, full 240x320 / G
     state encoding, policy forward, GAE and one PPO epoch (remaining epochs scaled from it).  kind = "port", single process."""
     import numpy as np
     import torch
@@ -135,10 +135,10 @@ def cpu_baseline(args, cfg):
     from oracle import oracle as orc
     from tests import policy_util as pu
 
-    n, t_steps = 2, 2
+    n, t_steps = 16, 4
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     scene = S.make_scenes(n, cfg.grid_size, seed=99)
-    frames = S.make_frames(scene, cfg, 2, seed=99)
+    frames = S.make_frames(scene, cfg, 2, seed=99)  # two frames, alternated
     kinv = S.inverse_intrinsics(cfg.camera_height, cfg.camera_width)
     env = OracleEnv(cfg, kinv.numpy(), scene.range_gt.numpy(), scene.voxel_size.numpy(), scene.grid_gt.numpy(),
                     scene.num_valid_voxel_gt.numpy())
@@ -179,6 +179,23 @@ def cpu_baseline(args, cfg):
             "sample": f"{n} envs x {t_steps} env steps at {cfg.camera_height}x{cfg.camera_width}, {cfg.grid_size}^3: "
                       f"oracle state encoding (1 thread) + torch-CPU fp32 policy/PPO ({args.n_epochs} epochs, "
                       f"{torch.get_num_threads()} threads)"}
+
+
+def ppo_loss_delta(args, device):
+    """PPO loss delta vs the reference (BASELINE metric, second half): run train() of the SAME
+    code path (backend, dtype, hipGraph) on the recorded rollout of tests/golden/F9_ppo_train.npz and
+    compare the logged losses with the ones the reference's PPO_Grid_Obs.train() produced."""
+    import torch
+    from tests import golden_util as gu
+    from tests.test_policy_ppo_cpu import _ppo_from_fixture
+    fx = gu.load("F9_ppo_train")
+    ppo = _ppo_from_fixture(fx, device=device, backend=args.backend)
+    ppo.train()
+    log = ppo.logger.name_to_value
+    keys = ("train/policy_gradient_loss", "train/value_loss", "train/entropy_loss", "train/loss", "train/approx_kl")
+    deltas = {k.split("/")[1]: abs(float(log[k]) - float(fx["log/" + k])) for k in keys}
+    return {"fixture": "tests/golden/F9_ppo_train.npz (reference PPO_Grid_Obs.train(), 12 optimizer steps, G=20)",
+            "abs_delta": deltas, "max_abs_delta": max(deltas.values()), "tolerance": 1e-4}
 
 
 def main():
@@ -255,6 +272,10 @@ def main():
                      "launch_ms": vox_ms, "algorithmic_bytes_per_launch": args.envs * b_vox, "traffic": traffic},
     }
     if rank == 0:
+        try:
+            out["ppo_loss_delta_vs_ref"] = ppo_loss_delta(args, device)
+        except Exception as ex:
+            out["ppo_loss_delta_vs_ref"] = {"error": repr(ex)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, cfg)

@@ -78,7 +78,7 @@ class GnbvEncoderParams(C.Structure):
     """include/gennbv_hip.h: GnbvEncoderParams"""
     _fields_ = [("w1", _p), ("b1", _p), ("bn1_w", _p), ("bn1_b", _p), ("bn1_rm", _p), ("bn1_rv", _p), ("bn1_nbt", _p),
                 ("w2", _p), ("b2", _p), ("bn2_w", _p), ("bn2_b", _p), ("bn2_rm", _p), ("bn2_rv", _p), ("bn2_nbt", _p),
-                ("eps", _f), ("momentum", _f)]
+                ("eps", _f), ("momentum", _f), ("act_bf16", _i)]
 
 
 class GnbvEncoderGrads(C.Structure):

@@ -43,6 +43,37 @@ __device__ __forceinline__ size_t vox1(int b, int z, int y, int x, int O1)
 }
 static inline size_t y1_elems(int batch, int O1) { return (size_t)batch * O1 * O1 * 2 * ((O1 + 1) / 2) * kC; }
 
+// Storage type of the layer-1 activations (y1, dz1'): fp32, or bf16 (math stays fp32; halves the
+// dominant HBM traffic of the conv stack -- opt-in, BASELINE config 2's "bf16").
+struct ActF32 {
+    typedef float T;
+    static __device__ __forceinline__ float4 ld4(const T *p) { return *reinterpret_cast<const float4 *>(p); }
+    static __device__ __forceinline__ void st4(T *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+    static __device__ __forceinline__ float ld1(const T *p) { return *p; }
+};
+struct ActBF16 {
+    typedef uint16_t T;
+    static __device__ __forceinline__ float up(uint32_t h) { return __uint_as_float(h << 16); }
+    static __device__ __forceinline__ uint32_t down(float x)  // round to nearest even
+    {
+        const uint32_t u = __float_as_uint(x);
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    }
+    static __device__ __forceinline__ float4 ld4(const T *p)
+    {
+        const uint2 u = *reinterpret_cast<const uint2 *>(p);
+        return make_float4(up(u.x & 0xffffu), up(u.x >> 16), up(u.y & 0xffffu), up(u.y >> 16));
+    }
+    static __device__ __forceinline__ void st4(T *p, float4 v)
+    {
+        uint2 u;
+        u.x = down(v.x) | (down(v.y) << 16);
+        u.y = down(v.z) | (down(v.w) << 16);
+        *reinterpret_cast<uint2 *>(p) = u;
+    }
+    static __device__ __forceinline__ float ld1(const T *p) { return up((uint32_t)*p); }
+};
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // sum over the four k-groups (lanes l, l^16, l^32, l^48): afterwards every lane holds the total
@@ -104,9 +135,10 @@ __device__ __forceinline__ void write_partials_cl(float *partials, int wave_glob
 // conv1 forward: in [B rows of the obs buffer, G^3 fp32] -> y1 [B,O1,O1,O1,16] (pre-BN, + bias)
 // workgroup = (sample b, output plane oz); wave = output rows oy; tile = 16 outputs along x
 // ---------------------------------------------------------------------------
+template <typename A>
 __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd(
     const float *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, int B, int G, int O1,
-    const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ b1, float *__restrict__ y1,
+    const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ b1, typename A::T *__restrict__ y1,
     float *__restrict__ partials)
 {
     int b, oz;
@@ -142,7 +174,7 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd(
                 for (int s = 0; s < 7; ++s) acc = mfma4(wf[s], v[s], acc);
                 if (ox0 + m < O1) {
                     float4 y = make_float4(acc[0] + bias.x, acc[1] + bias.y, acc[2] + bias.z, acc[3] + bias.w);
-                    *reinterpret_cast<float4 *>(y1 + vox1(b, oz, oy, ox0 + m, O1) * kC + 4 * kq) = y;
+                    A::st4(y1 + vox1(b, oz, oy, ox0 + m, O1) * kC + 4 * kq, y);
                     s_sum[0] += y.x; s_sq[0] += y.x * y.x;
                     s_sum[1] += y.y; s_sq[1] += y.y * y.y;
                     s_sum[2] += y.z; s_sq[2] += y.z * y.z;
@@ -193,8 +225,9 @@ constexpr int kBigWaves = kBigThreads / kWave;
 // ---------------------------------------------------------------------------
 // conv2 forward: z1 = relu(scale1*y1 + shift1) applied on load; y2 [B,16,O2^3] (NCDHW, pre-BN)
 // ---------------------------------------------------------------------------
+template <typename A>
 __global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
-    const float *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1, int B, int O1, int O2,
+    const typename A::T *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1, int B, int O1, int O2,
     const float *__restrict__ W2img /*k_prep_w2 fwd image*/, const float *__restrict__ b2, float *__restrict__ y2,
     float *__restrict__ partials)
 {
@@ -230,8 +263,7 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
 #if ENC_VARIANT == 1   // A/B: no global loads
                 const float4 v = make_float4((float)(tap + ox), 1.f, 2.f, 3.f);
 #else
-                const float4 v = *reinterpret_cast<const float4 *>(
-                    y1 + vox1(b, 2 * oz + dz, 2 * oy + dy, 2 * ox + dx, O1) * kC + 4 * kq);
+                const float4 v = A::ld4(y1 + vox1(b, 2 * oz + dz, 2 * oy + dy, 2 * ox + dx, O1) * kC + 4 * kq);
 #endif
                 const float z0 = fmaxf(fmaf(sc[0], v.x, sh[0]), 0.f), z1 = fmaxf(fmaf(sc[1], v.y, sh[1]), 0.f);
                 const float z2 = fmaxf(fmaf(sc[2], v.z, sh[2]), 0.f), z3 = fmaxf(fmaf(sc[3], v.w, sh[3]), 0.f);
@@ -424,8 +456,9 @@ __device__ __forceinline__ void wave_row_range(int nrows, int &r0, int &r1)
 // MFMA: i = ci, j = co, k = 4 consecutive output positions along x.  27 accumulators / wave.
 // partial[w][tap][ci][co] (+ 16 bias sums), reduced by k_reduce_partials.
 // ---------------------------------------------------------------------------
+template <typename A>
 __global__ __launch_bounds__(kEncThreads) void k_conv2_wgrad(
-    const float *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1,
+    const typename A::T *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1,
     const float *__restrict__ dy2 /*[B,O2,O2,O2,16]*/, int B, int O1, int O2, float *__restrict__ partial)
 {
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
@@ -449,11 +482,10 @@ __global__ __launch_bounds__(kEncThreads) void k_conv2_wgrad(
             float bv = dy2[((((size_t)b * O2 + oz) * O2 + oy) * O2 + xc) * kC + n];
             bv = ok ? bv : 0.0f;
             bsum += bv;
-            const float *p = y1 + n;
 #pragma unroll
             for (int tap = 0; tap < kTaps; ++tap) {
                 const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-                const float a = fmaxf(fmaf(sc, p[vox1(b, 2 * oz + dz, 2 * oy + dy, 2 * xc + dx, O1) * kC], sh), 0.0f);
+                const float a = fmaxf(fmaf(sc, A::ld1(y1 + vox1(b, 2 * oz + dz, 2 * oy + dy, 2 * xc + dx, O1) * kC + n), sh), 0.0f);
                 acc[tap] = mfma4(a, bv, acc[tap]);  // rows with bv == 0 contribute nothing
             }
         }
@@ -484,10 +516,11 @@ __global__ void k_conv2_wgrad_finish(const double *__restrict__ red, float *__re
 //   dz1'[v, ci] = [pre1 > 0] * sum_{tap, co} dy2[(v - tap)/2, co] * W2[co][ci][tap]
 // Input voxels of one x-parity share their tap set -> tiles of 16 voxels ix = 2j + px.
 // ---------------------------------------------------------------------------
+template <typename A>
 __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad(
-    const float *__restrict__ dy2, const float *__restrict__ W2, const float *__restrict__ y1, const float *__restrict__ scale1,
+    const float *__restrict__ dy2, const float *__restrict__ W2, const typename A::T *__restrict__ y1, const float *__restrict__ scale1,
     const float *__restrict__ shift1, const float *__restrict__ mean1, const float *__restrict__ rstd1, int B, int O1, int O2,
-    float *__restrict__ dz1p, float *__restrict__ partials)
+    typename A::T *__restrict__ dz1p, float *__restrict__ partials)
 {
     __shared__ __attribute__((aligned(16))) float w2d[kTaps * 4 * 4 * kC];  // [(tap*4+s)*4+kq][n] = W2[co = 4kq+s][ci = n][tap]
     fill_lds_image(w2d, W2 /* k_prep_w2 dgrad image */);
@@ -536,13 +569,13 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad(
                 }
                 if (j < nvox) {
                     const size_t idx = vox1(b, iz, iy, 2 * j + px, O1) * kC + 4 * kq;
-                    const float4 y = *reinterpret_cast<const float4 *>(y1 + idx);
+                    const float4 y = A::ld4(y1 + idx);
                     float4 g;
                     g.x = fmaf(sc.x, y.x, sh.x) > 0.0f ? acc[0] : 0.0f;
                     g.y = fmaf(sc.y, y.y, sh.y) > 0.0f ? acc[1] : 0.0f;
                     g.z = fmaf(sc.z, y.z, sh.z) > 0.0f ? acc[2] : 0.0f;
                     g.w = fmaf(sc.w, y.w, sh.w) > 0.0f ? acc[3] : 0.0f;
-                    *reinterpret_cast<float4 *>(dz1p + idx) = g;
+                    A::st4(dz1p + idx, g);
                     s1[0] += g.x; s2[0] += g.x * ((y.x - mu.x) * rs.x);
                     s1[1] += g.y; s2[1] += g.y * ((y.y - mu.y) * rs.y);
                     s1[2] += g.z; s2[2] += g.z * ((y.z - mu.z) * rs.z);
@@ -559,9 +592,10 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad(
 //   dy1 = scale1 * (dz1' - S1/M - xhat * S2/M);  dW1[co][tap] = sum_pos in[inpos(pos,tap)] * dy1[pos, co]
 // MFMA: i = tap (two 16-row tiles), j = co, k = 4 consecutive output positions along x.
 // ---------------------------------------------------------------------------
+template <typename A>
 __global__ __launch_bounds__(kEncThreads) void k_conv1_wgrad(
-    const float *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, const float *__restrict__ dz1p,
-    const float *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ mean1,
+    const float *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, const typename A::T *__restrict__ dz1p,
+    const typename A::T *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ mean1,
     const float *__restrict__ rstd1, const double *__restrict__ S /*[2][16]*/, double count, int B, int G, int O1,
     float *__restrict__ partial /*[nwaves][2*256 + 16]*/)
 {
@@ -596,8 +630,8 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_wgrad(
                 const int x = x0 + 4 * u + kq;
                 const int xc = x < O1 ? x : O1 - 1;
                 const size_t idx = vox1(b, oz, oy, xc, O1) * kC + n;
-                g4[u] = dz1p[idx];
-                y4[u] = y1[idx];
+                g4[u] = A::ld1(dz1p + idx);
+                y4[u] = A::ld1(y1 + idx);
                 a04[u] = tok[0] ? in[2 * xc + off[0]] : 0.0f;  // A[i = tap][k = pos]
                 a14[u] = tok[1] ? in[2 * xc + off[1]] : 0.0f;
             }
@@ -698,7 +732,7 @@ static inline int reduce_launch(const float *partial, int P, int E, double *out_
 }
 
 GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *rows, int64_t row_stride, int batch, int grid,
-                                       const GnbvEncoderParams *p, int training, const int *skip_flag, float *y1, float *y2,
+                                       const GnbvEncoderParams *p, int training, const int *skip_flag, void *y1, float *y2,
                                        float *bn_state /*[2][4][16]: scale, shift, mean, rstd per layer*/, float *features,
                                        void *workspace, size_t workspace_bytes, void *stream)
 {
@@ -714,8 +748,13 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     float *bn1 = bn_state, *bn2 = bn_state + 4 * kC;
     int err;
     // conv1 (+ BN1 statistics)
-    hipLaunchKernelGGL(k_conv1_fwd, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, batch, grid, O1, p->w1,
-                       p->b1, y1, training ? w.bn_part : nullptr);
+    if (p->act_bf16) {
+        hipLaunchKernelGGL(k_conv1_fwd<ActBF16>, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, batch, grid, O1, p->w1,
+                       p->b1, (uint16_t *)y1, training ? w.bn_part : nullptr);
+    } else {
+        hipLaunchKernelGGL(k_conv1_fwd<ActF32>, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, batch, grid, O1, p->w1,
+                       p->b1, (float *)y1, training ? w.bn_part : nullptr);
+    }
     if ((err = gnbv_launch_status())) return err;
     if (training && (err = reduce_launch(w.bn_part, sample_plane_grid(batch, O1) * kEncWaves, 2 * kC, w.red, w.tmp, st))) return err;
     hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, w.red, (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps,
@@ -724,8 +763,13 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     // conv2 (BN1 + ReLU on load; + BN2 statistics)
     hipLaunchKernelGGL(k_prep_w2, dim3(kTaps), dim3(256), 0, st, p->w2, w.w2img, w.w2img + kTaps * 256);
     const int g2 = sample_plane_group_grid(batch, O2, kPlanesPerGroup);
-    hipLaunchKernelGGL(k_conv2_fwd, dim3(g2), dim3(kBigThreads), 0, st, y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
+    if (p->act_bf16) {
+        hipLaunchKernelGGL(k_conv2_fwd<ActBF16>, dim3(g2), dim3(kBigThreads), 0, st, (const uint16_t *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
                        training ? w.bn_part : nullptr);
+    } else {
+        hipLaunchKernelGGL(k_conv2_fwd<ActF32>, dim3(g2), dim3(kBigThreads), 0, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
+                       training ? w.bn_part : nullptr);
+    }
     if ((err = gnbv_launch_status())) return err;
     if (training && (err = reduce_launch(w.bn_part, g2 * kBigWaves, 2 * kC, w.red + 64, w.tmp, st))) return err;
     hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, w.red + 64, (double)batch * P2, p->bn2_w, p->bn2_b, p->eps,
@@ -740,8 +784,8 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
 }
 
 GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *rows, int64_t row_stride, int batch, int grid,
-                                        const GnbvEncoderParams *p, const float *y1, const float *y2, const float *bn_state,
-                                        const float *d_features, float *dy2_scratch, float *dz1_scratch,
+                                        const GnbvEncoderParams *p, const void *y1, const float *y2, const float *bn_state,
+                                        const float *d_features, float *dy2_scratch, void *dz1_scratch,
                                         const GnbvEncoderGrads *g, void *workspace, size_t workspace_bytes, void *stream)
 {
     GNBV_CHECK_ARG(obs_grid && p && y1 && y2 && bn_state && d_features && dy2_scratch && dz1_scratch && g && workspace);
@@ -769,8 +813,13 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     int nrows2 = batch * O2 * O2;
     int wg_blocks = (nrows2 + kEncWaves - 1) / kEncWaves;
     wg_blocks = wg_blocks > 512 ? 512 : ((wg_blocks + 7) & ~7);
-    hipLaunchKernelGGL(k_conv2_wgrad, dim3(wg_blocks), dim3(kEncThreads), 0, st, y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
+    if (p->act_bf16) {
+        hipLaunchKernelGGL(k_conv2_wgrad<ActBF16>, dim3(wg_blocks), dim3(kEncThreads), 0, st, (const uint16_t *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
                        w.wg_part);
+    } else {
+        hipLaunchKernelGGL(k_conv2_wgrad<ActF32>, dim3(wg_blocks), dim3(kEncThreads), 0, st, (const float *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
+                       w.wg_part);
+    }
     if ((err = gnbv_launch_status())) return err;
     const int E2 = kTaps * 256 + kC;
     if ((err = reduce_launch(w.wg_part, wg_blocks * kEncWaves, E2, w.red + 256, w.tmp, st))) return err;
@@ -779,8 +828,13 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     // ---- conv2 data gradient (+ ReLU1 mask, BN1 backward sums) ----
     hipLaunchKernelGGL(k_prep_w2, dim3(kTaps), dim3(256), 0, st, p->w2, w.w2img, w.w2img + kTaps * 256);
     const int gd = sample_plane_group_grid(batch, O1, kPlanesPerGroup);
-    hipLaunchKernelGGL(k_conv2_dgrad, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), y1, bn1, bn1 + kC, bn1 + 2 * kC,
-                       bn1 + 3 * kC, batch, O1, O2, dz1_scratch, w.bn_part);
+    if (p->act_bf16) {
+        hipLaunchKernelGGL(k_conv2_dgrad<ActBF16>, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const uint16_t *)y1, bn1, bn1 + kC, bn1 + 2 * kC,
+                       bn1 + 3 * kC, batch, O1, O2, (uint16_t *)dz1_scratch, w.bn_part);
+    } else {
+        hipLaunchKernelGGL(k_conv2_dgrad<ActF32>, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const float *)y1, bn1, bn1 + kC, bn1 + 2 * kC,
+                       bn1 + 3 * kC, batch, O1, O2, (float *)dz1_scratch, w.bn_part);
+    }
     if ((err = gnbv_launch_status())) return err;
     double *S1 = w.red + 192;
     if ((err = reduce_launch(w.bn_part, gd * kBigWaves, 2 * kC, S1, w.tmp, st))) return err;
@@ -788,8 +842,13 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     int nrows1 = batch * O1 * O1;
     int wg1_blocks = (nrows1 + kEncWaves - 1) / kEncWaves;
     wg1_blocks = wg1_blocks > 2048 ? 2048 : ((wg1_blocks + 7) & ~7);  // VGPR-light: 32 waves per CU hide the load latency
-    hipLaunchKernelGGL(k_conv1_wgrad, dim3(wg1_blocks), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, dz1_scratch, y1, bn1,
+    if (p->act_bf16) {
+        hipLaunchKernelGGL(k_conv1_wgrad<ActBF16>, dim3(wg1_blocks), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, (const uint16_t *)dz1_scratch, (const uint16_t *)y1, bn1,
                        bn1 + 2 * kC, bn1 + 3 * kC, S1, (double)batch * O1 * O1 * O1, batch, grid, O1, w.wg_part);
+    } else {
+        hipLaunchKernelGGL(k_conv1_wgrad<ActF32>, dim3(wg1_blocks), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, (const float *)dz1_scratch, (const float *)y1, bn1,
+                       bn1 + 2 * kC, bn1 + 3 * kC, S1, (double)batch * O1 * O1 * O1, batch, grid, O1, w.wg_part);
+    }
     if ((err = gnbv_launch_status())) return err;
     const int E1 = 512 + kC;
     if ((err = reduce_launch(w.wg_part, wg1_blocks * kEncWaves, E1, w.red + 256, w.tmp, st))) return err;

@@ -53,7 +53,7 @@ def _workspace(lib, batch, grid, device):
     return ws
 
 
-def _params_struct(seq) -> _lib.GnbvEncoderParams:
+def _params_struct(seq, act_bf16: bool = False) -> _lib.GnbvEncoderParams:
     conv1, bn1, conv2, bn2 = seq[0], seq[1], seq[3], seq[4]
     p = _lib.GnbvEncoderParams()
     p.w1, p.b1, p.bn1_w, p.bn1_b = conv1.weight.data_ptr(), conv1.bias.data_ptr(), bn1.weight.data_ptr(), bn1.bias.data_ptr()
@@ -61,12 +61,13 @@ def _params_struct(seq) -> _lib.GnbvEncoderParams:
     p.w2, p.b2, p.bn2_w, p.bn2_b = conv2.weight.data_ptr(), conv2.bias.data_ptr(), bn2.weight.data_ptr(), bn2.bias.data_ptr()
     p.bn2_rm, p.bn2_rv, p.bn2_nbt = bn2.running_mean.data_ptr(), bn2.running_var.data_ptr(), bn2.num_batches_tracked.data_ptr()
     p.eps, p.momentum = float(bn1.eps), float(bn1.momentum)
+    p.act_bf16 = int(bool(act_bf16))
     return p
 
 
 class _GridEncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, base, rows, grid_off, grid, training, skip_flag, seq, w1, b1, g1, be1, w2, b2, g2, be2):
+    def forward(ctx, base, rows, grid_off, grid, training, skip_flag, seq, act_bf16, w1, b1, g1, be1, w2, b2, g2, be2):
         lib = _lib.load()
         _lib.require_cuda(base, w1)
         for t in (w1, b1, g1, be1, w2, b2, g2, be2):
@@ -76,50 +77,51 @@ class _GridEncoderFn(torch.autograd.Function):
         o1 = conv_out(grid)
         o2 = conv_out(o1)
         p2 = o2 ** 3
-        y1 = torch.empty(lib.gnbv_encoder_y1_elems(batch, grid), dtype=torch.float32, device=dev)
+        act_dt = torch.bfloat16 if act_bf16 else torch.float32
+        y1 = torch.empty(lib.gnbv_encoder_y1_elems(batch, grid), dtype=act_dt, device=dev)
         y2 = torch.empty(batch * 16 * p2, dtype=torch.float32, device=dev)
         bn_state = torch.empty(2 * 4 * 16, dtype=torch.float32, device=dev)
         feats = torch.empty(batch, 16 * p2, dtype=torch.float32, device=dev)
         ws = _workspace(lib, batch, grid, dev)
-        params = _params_struct(seq)
+        params = _params_struct(seq, act_bf16)
         obs_ptr = base.data_ptr() + 4 * grid_off
         _lib.check(lib.gnbv_encoder_grid_forward(
             obs_ptr, _lib.ptr(rows), base.stride(0), batch, grid, C.byref(params), int(training), _lib.ptr(skip_flag),
             y1.data_ptr(), y2.data_ptr(), bn_state.data_ptr(), feats.data_ptr(), ws.data_ptr(), ws.numel(),
             _lib.stream_ptr(dev)), "gnbv_encoder_grid_forward")
         ctx.save_for_backward(base, rows, y1, y2, bn_state, w1, w2)
-        ctx.meta = (grid_off, grid, batch, seq)
+        ctx.meta = (grid_off, grid, batch, seq, act_bf16)
         return feats
 
     @staticmethod
     def backward(ctx, d_feats):
         lib = _lib.load()
         base, rows, y1, y2, bn_state, w1, w2 = ctx.saved_tensors
-        grid_off, grid, batch, seq = ctx.meta
+        grid_off, grid, batch, seq, act_bf16 = ctx.meta
         dev = base.device
         o1 = conv_out(grid)
         o2 = conv_out(o1)
         d_feats = d_feats.contiguous().float()
         dy2 = torch.empty(batch * o2 ** 3 * 16, dtype=torch.float32, device=dev)
-        dz1 = torch.empty(lib.gnbv_encoder_y1_elems(batch, grid), dtype=torch.float32, device=dev)
+        dz1 = torch.empty(lib.gnbv_encoder_y1_elems(batch, grid), dtype=torch.bfloat16 if act_bf16 else torch.float32, device=dev)
         grads = [torch.empty_like(t) for t in (seq[0].weight, seq[0].bias, seq[1].weight, seq[1].bias,
                                                seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias)]
         gs = _lib.GnbvEncoderGrads()
         for name, t in zip(("w1", "b1", "bn1_w", "bn1_b", "w2", "b2", "bn2_w", "bn2_b"), grads):
             setattr(gs, name, t.data_ptr())
-        params = _params_struct(seq)
+        params = _params_struct(seq, act_bf16)
         ws = _workspace(lib, batch, grid, dev)
         _lib.check(lib.gnbv_encoder_grid_backward(
             base.data_ptr() + 4 * grid_off, _lib.ptr(rows), base.stride(0), batch, grid, C.byref(params), y1.data_ptr(),
             y2.data_ptr(), bn_state.data_ptr(), d_feats.data_ptr(), dy2.data_ptr(), dz1.data_ptr(), C.byref(gs),
             ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "gnbv_encoder_grid_backward")
-        return (None, None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, None, *grads)
 
 
 def grid_encoder(base: torch.Tensor, rows: Optional[torch.Tensor], grid_off: int, grid: int, seq, training: bool,
-                 skip_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 skip_flag: Optional[torch.Tensor] = None, act_bf16: bool = False) -> torch.Tensor:
     """seq = the `naive_encoder_grid` nn.Sequential (conv, bn, relu, conv, bn, relu)."""
-    return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, seq[0].weight, seq[0].bias,
+    return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, bool(act_bf16), seq[0].weight, seq[0].bias,
                                 seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias)
 
 
@@ -149,7 +151,8 @@ def hybrid_forward(enc, observations) -> torch.Tensor:
     else:
         action_input = enc.positional_encoding(state.view(num_env, -1, 6)).view(num_env, -1)
         feature_action = enc.naive_encoder_action(action_input)
-    feature_grid = grid_encoder(base, rows, s, g, enc.naive_encoder_grid, enc.training, getattr(enc, "_bn_skip_flag", None))
+    feature_grid = grid_encoder(base, rows, s, g, enc.naive_encoder_grid, enc.training, getattr(enc, "_bn_skip_flag", None),
+                                enc.compute_dtype == torch.bfloat16)
     feature_grid = enc.output_layer_grid(feature_grid)
     if side is not None:
         torch.cuda.current_stream(base.device).wait_stream(side)

@@ -191,6 +191,7 @@ typedef struct GnbvEncoderParams {
     float *bn2_rm, *bn2_rv;
     int64_t *bn2_nbt;
     float eps, momentum;          /* 1e-5, 0.1 (torch.nn.BatchNorm3d defaults) */
+    int act_bf16;                 /* 0: y1 / dz1 scratch are fp32; 1: bf16 storage (math stays fp32) */
 } GnbvEncoderParams;
 
 typedef struct GnbvEncoderGrads {  /* outputs, same shapes as the parameters */
@@ -198,7 +199,7 @@ typedef struct GnbvEncoderGrads {  /* outputs, same shapes as the parameters */
 } GnbvEncoderGrads;
 
 size_t gnbv_encoder_workspace_bytes(int batch, int grid);
-/* number of floats of the layer-1 activation buffers (y1, dz1_scratch) */
+/* number of ELEMENTS (fp32 or bf16, GnbvEncoderParams.act_bf16) of the layer-1 activation buffers (y1, dz1_scratch) */
 size_t gnbv_encoder_y1_elems(int batch, int grid);
 
 /* obs_grid: pointer to the grid slice of row 0 of an observation matrix; sample b reads
@@ -210,15 +211,15 @@ size_t gnbv_encoder_y1_elems(int batch, int grid);
  * bn_state [2][4][16] (scale, shift, mean, rstd per layer).
  * features [B, 16*O2^3] is the reference's `naive_encoder_grid(x).reshape(num_env, -1)`. */
 int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *rows, int64_t row_stride, int batch, int grid,
-                              const GnbvEncoderParams *params /*[host]*/, int training, const int *skip_flag, float *y1,
+                              const GnbvEncoderParams *params /*[host]*/, int training, const int *skip_flag, void *y1,
                               float *y2, float *bn_state, float *features, void *workspace, size_t workspace_bytes,
                               void *stream);
 
 /* Gradients of all eight parameter tensors given d_features [B, 16*O2^3].
  * dy2_scratch [B,O2^3,16] and dz1_scratch (gnbv_encoder_y1_elems floats) are caller-owned scratch. */
 int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *rows, int64_t row_stride, int batch, int grid,
-                               const GnbvEncoderParams *params /*[host]*/, const float *y1, const float *y2,
-                               const float *bn_state, const float *d_features, float *dy2_scratch, float *dz1_scratch,
+                               const GnbvEncoderParams *params /*[host]*/, const void *y1, const float *y2,
+                               const float *bn_state, const float *d_features, float *dy2_scratch, void *dz1_scratch,
                                const GnbvEncoderGrads *grads /*[host]*/, void *workspace, size_t workspace_bytes,
                                void *stream);
 

@@ -110,3 +110,31 @@ def test_row_gather_equals_materialised_batch():
         a = pol.extract_features(RowGather(base, rows))
         b = pol.extract_features(base[rows])
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("g,b", [(20, 8), (64, 4)])
+def test_bf16_activation_storage_within_bf16_tolerance(g, b):
+    """compute_dtype=bfloat16 (EXPERIMENTAL, opt-in) stores the layer-1 activations (y1, dz1) in bf16,
+    math stays fp32: forward within 2e-3 of the fp64 reference.  Gradient accuracy in this mode is poor on small
+    batches (BatchNorm backward subtracts batch means from bf16-rounded values, ReLU masks flip near
+    zero) while the speed-up is only ~10 % of the conv time -- the kernels are instruction-bound,
+    not bandwidth-bound (profiles/r01_notes.md) -- so fp32 storage is the default and the only
+    mode bench.py measures."""
+    hip, _, _ = pu.make_policy(g=g, device=DEV, backend="hip", det_weights=True, compute_dtype=torch.bfloat16)
+    ref, _, _ = pu.make_policy(g=g, device="cpu", backend="torch", det_weights=True)
+    ref = ref.double()
+    ref.extract_features = lambda x: ref.features_extractor(x)
+    obs = _obs(b, g, seed=g)
+    actions = torch.stack([torch.randint(0, n, (b,)) for n in pu.NVEC], -1).float()
+    w = torch.linspace(0.5, 1.5, b)
+    outs = []
+    for pol, dev, dt in ((ref, "cpu", torch.float64), (hip, DEV, torch.float32)):
+        pol.set_training_mode(True)
+        pol.zero_grad()
+        values, log_prob, entropy = pol.evaluate_actions(obs.to(dev, dt), actions.to(dev))
+        ww = w.to(dev, dt)
+        ((values.flatten() * ww).sum() + (log_prob * ww.flip(0)).sum() + 0.3 * (entropy * ww).sum()).backward()
+        outs.append([t.detach().double().cpu() for t in (values, log_prob, entropy)])
+    for x, y in zip(*outs):
+        assert float((x - y).abs().max()) <= 2e-3 * float(x.abs().max()) + 1e-4
+    # gradients are NOT asserted in this mode: see the docstring (fp32 storage is the supported path)
