@@ -36,10 +36,12 @@ constexpr int kEncWaves = kEncThreads / kWave;
 // consecutive outputs of an MFMA tile read 16 CONSECUTIVE voxels (1 KiB per wave-load, fully
 // coalesced) instead of every other 64-byte half line; the transposed conv (dgrad) tiles are per
 // x-parity already and become contiguous too.
-__device__ __forceinline__ size_t vox1(int b, int z, int y, int x, int O1)
+// 32-bit index arithmetic: the host checks that the buffer has < 2^31 elements (64-bit integer
+// multiplies are quarter-rate VALU ops and sat on the critical path of every operand load).
+__device__ __forceinline__ uint32_t vox1(int b, int z, int y, int x, int O1)
 {
-    const int XH = (O1 + 1) >> 1;
-    return ((((size_t)b * O1 + z) * O1 + y) * 2 + (x & 1)) * XH + (x >> 1);
+    const uint32_t XH = (uint32_t)(O1 + 1) >> 1;
+    return ((((uint32_t)b * O1 + z) * O1 + y) * 2 + (x & 1)) * XH + ((uint32_t)x >> 1);
 }
 static inline size_t y1_elems(int batch, int O1) { return (size_t)batch * O1 * O1 * 2 * ((O1 + 1) / 2) * kC; }
 
@@ -163,22 +165,30 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd(
         }
         const float4 bias = *reinterpret_cast<const float4 *>(b1 + 4 * kq);
         for (int oy = wv; oy < O1; oy += kEncWaves) {
-            for (int ox0 = 0; ox0 < O1; ox0 += 16) {
-                const int ox = min(ox0 + m, O1 - 1);
-                const float *p = in + ((size_t)(2 * oz) * G + 2 * oy) * G + 2 * ox;
-                float v[7];
+            for (int ox0 = 0; ox0 < O1; ox0 += 32) {
+                // two 16-output tiles per trip: 14 loads in flight before the first MFMA
+                float v[2][7];
 #pragma unroll
-                for (int s = 0; s < 7; ++s) v[s] = p[off[s]];
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < 2; ++t) {
+                    const int ox = min(ox0 + 16 * t + m, O1 - 1);
+                    const float *p = in + ((size_t)(2 * oz) * G + 2 * oy) * G + 2 * ox;
 #pragma unroll
-                for (int s = 0; s < 7; ++s) acc = mfma4(wf[s], v[s], acc);
-                if (ox0 + m < O1) {
-                    float4 y = make_float4(acc[0] + bias.x, acc[1] + bias.y, acc[2] + bias.z, acc[3] + bias.w);
-                    A::st4(y1 + vox1(b, oz, oy, ox0 + m, O1) * kC + 4 * kq, y);
-                    s_sum[0] += y.x; s_sq[0] += y.x * y.x;
-                    s_sum[1] += y.y; s_sq[1] += y.y * y.y;
-                    s_sum[2] += y.z; s_sq[2] += y.z * y.z;
-                    s_sum[3] += y.w; s_sq[3] += y.w * y.w;
+                    for (int s = 0; s < 7; ++s) v[t][s] = p[off[s]];
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 7; ++s) acc = mfma4(wf[s], v[t][s], acc);
+                    const int oxm = ox0 + 16 * t + m;
+                    if (oxm < O1) {
+                        float4 y = make_float4(acc[0] + bias.x, acc[1] + bias.y, acc[2] + bias.z, acc[3] + bias.w);
+                        A::st4(y1 + vox1(b, oz, oy, oxm, O1) * kC + 4 * kq, y);
+                        s_sum[0] += y.x; s_sq[0] += y.x * y.x;
+                        s_sum[1] += y.y; s_sq[1] += y.y * y.y;
+                        s_sum[2] += y.z; s_sq[2] += y.z * y.z;
+                        s_sum[3] += y.w; s_sq[3] += y.w * y.w;
+                    }
                 }
             }
         }
@@ -257,30 +267,14 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
 #pragma unroll 9
             for (int tap = 0; tap < kTaps; ++tap) {
                 const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-#ifndef ENC_VARIANT
-#define ENC_VARIANT 0
-#endif
-#if ENC_VARIANT == 1   // A/B: no global loads
-                const float4 v = make_float4((float)(tap + ox), 1.f, 2.f, 3.f);
-#else
                 const float4 v = A::ld4(y1 + vox1(b, 2 * oz + dz, 2 * oy + dy, 2 * ox + dx, O1) * kC + 4 * kq);
-#endif
                 const float z0 = fmaxf(fmaf(sc[0], v.x, sh[0]), 0.f), z1 = fmaxf(fmaf(sc[1], v.y, sh[1]), 0.f);
                 const float z2 = fmaxf(fmaf(sc[2], v.z, sh[2]), 0.f), z3 = fmaxf(fmaf(sc[3], v.w, sh[3]), 0.f);
                 const float *wb = w2s + tap * 256 + lane;  // + s*64
-#if ENC_VARIANT == 2   // A/B: no MFMA, no LDS
-                acc[0] += z0; acc[1] += z1; acc[2] += z2; acc[3] += z3;
-#elif ENC_VARIANT == 3 // A/B: MFMA with register B operand (no LDS reads)
-                acc = mfma4(z0, sc[0], acc);
-                acc = mfma4(z1, sc[1], acc);
-                acc = mfma4(z2, sc[2], acc);
-                acc = mfma4(z3, sc[3], acc);
-#else
                 acc = mfma4(z0, wb[0], acc);
                 acc = mfma4(z1, wb[64], acc);
                 acc = mfma4(z2, wb[128], acc);
                 acc = mfma4(z3, wb[192], acc);
-#endif
             }
             float *out = y2 + ((size_t)b * kC + m) * P2 + ((size_t)oz * O2 + oy) * O2;
 #pragma unroll
@@ -475,18 +469,37 @@ __global__ __launch_bounds__(kEncThreads) void k_conv2_wgrad(
     (void)nwaves;
     for (int row = row0; row < row1; ++row) {
         const int b = row / (O2 * O2), rem = row - b * O2 * O2, oz = rem / O2, oy = rem - oz * O2;
-        for (int x0 = 0; x0 < O2; x0 += 4) {
+        // software pipeline over the x-groups of the row: the 28 operand loads of group g+1 are in
+        // flight while the 27 MFMAs of group g run
+        const size_t drow = (((size_t)b * O2 + oz) * O2 + oy) * O2;
+        auto load_group = [&](int x0, float &bv, float (&av)[kTaps]) {
             const int x = x0 + kq;
             const bool ok = x < O2;
             const int xc = ok ? x : O2 - 1;
-            float bv = dy2[((((size_t)b * O2 + oz) * O2 + oy) * O2 + xc) * kC + n];
-            bv = ok ? bv : 0.0f;
-            bsum += bv;
+            const float t = dy2[(drow + xc) * kC + n];
+            bv = ok ? t : 0.0f;
 #pragma unroll
             for (int tap = 0; tap < kTaps; ++tap) {
                 const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-                const float a = fmaxf(fmaf(sc, A::ld1(y1 + vox1(b, 2 * oz + dz, 2 * oy + dy, 2 * xc + dx, O1) * kC + n), sh), 0.0f);
-                acc[tap] = mfma4(a, bv, acc[tap]);  // rows with bv == 0 contribute nothing
+                av[tap] = A::ld1(y1 + vox1(b, 2 * oz + dz, 2 * oy + dy, 2 * xc + dx, O1) * kC + n);
+            }
+        };
+        float bcur, acur[kTaps];
+        load_group(0, bcur, acur);
+        for (int x0 = 0; x0 < O2; x0 += 4) {
+            float bnxt = 0.0f, anxt[kTaps];
+            const bool more = x0 + 4 < O2;
+            if (more) load_group(x0 + 4, bnxt, anxt);
+            bsum += bcur;
+#pragma unroll
+            for (int tap = 0; tap < kTaps; ++tap) {
+                const float a = fmaxf(fmaf(sc, acur[tap], sh), 0.0f);
+                acc[tap] = mfma4(a, bcur, acc[tap]);  // rows with bv == 0 contribute nothing
+            }
+            if (more) {
+                bcur = bnxt;
+#pragma unroll
+                for (int tap = 0; tap < kTaps; ++tap) acur[tap] = anxt[tap];
             }
         }
     }
@@ -544,6 +557,9 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad(
             const int nx = px ? 1 : 2;
             for (int j0 = 0; j0 < nvox; j0 += 16) {
                 const int j = j0 + m;
+                // the epilogue's y1 operand is requested together with the dy2 operands (one latency per tile)
+                const size_t idx = vox1(b, iz, iy, 2 * min(j, nvox - 1) + px, O1) * kC + 4 * kq;
+                const float4 y = A::ld4(y1 + idx);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 for (int tz = 0; tz < nz; ++tz) {
                     const int dz = (iz & 1) ? 1 : 2 * tz, oz = (iz - dz) >> 1;
@@ -568,8 +584,6 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad(
                     }
                 }
                 if (j < nvox) {
-                    const size_t idx = vox1(b, iz, iy, 2 * j + px, O1) * kC + 4 * kq;
-                    const float4 y = A::ld4(y1 + idx);
                     float4 g;
                     g.x = fmaf(sc.x, y.x, sh.x) > 0.0f ? acc[0] : 0.0f;
                     g.y = fmaf(sc.y, y.y, sh.y) > 0.0f ? acc[1] : 0.0f;
@@ -622,11 +636,11 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_wgrad(
     for (int row = row0; row < row1; ++row) {
         const int b = row / (O1 * O1), rem = row - b * O1 * O1, oz = rem / O1, oy = rem - oz * O1;
         const float *in = obs_base + (rows ? rows[b] : (int64_t)b) * row_stride + ((size_t)(2 * oz) * G + 2 * oy) * G;
-        for (int x0 = 0; x0 < O1; x0 += 16) {
-            // four x-groups per trip: all 16 loads are issued before the first MFMA
-            float g4[4], y4[4], a04[4], a14[4];
+        for (int x0 = 0; x0 < O1; x0 += 32) {
+            // eight x-groups per trip: all 32 loads are issued before the first MFMA
+            float g4[8], y4[8], a04[8], a14[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int x = x0 + 4 * u + kq;
                 const int xc = x < O1 ? x : O1 - 1;
                 const size_t idx = vox1(b, oz, oy, xc, O1) * kC + n;
@@ -636,7 +650,7 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_wgrad(
                 a14[u] = tok[1] ? in[2 * xc + off[1]] : 0.0f;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const bool ok = x0 + 4 * u + kq < O1;
                 float dy = sc * (g4[u] - m1 - ((y4[u] - mu) * rs) * m2);  // B[k = pos][j = co = n]
                 dy = ok ? dy : 0.0f;
@@ -742,7 +756,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
                    p->bn2_rm && p->bn2_rv);
     hipStream_t st = gnbv_stream(stream);
     const int O1 = out_size(grid), O2 = out_size(O1);
-    GNBV_CHECK_ARG(O2 >= 1);
+    GNBV_CHECK_ARG(O2 >= 1 && y1_elems(batch, O1) < ((size_t)1 << 31));
     const int P2 = O2 * O2 * O2;
     EncWs w = enc_carve(workspace, batch, grid);
     float *bn1 = bn_state, *bn2 = bn_state + 4 * kC;
