@@ -670,6 +670,103 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_wgrad(
     if (lane < kC) out[512 + lane] = bsum;
 }
 
+// LDS-staged variant (used when G % 4 == 0).  The direct kernel issues four 4-byte-per-lane loads per
+// MFMA pair (256 B per wave-load): the vector-memory pipe processes a wave-load in ~16 cycles whatever
+// its width, so those narrow loads -- not HBM bytes, not MFMA -- set the kernel's time.  Here every
+// output row is staged with full-width loads (16 B/lane, 1 KiB per wave-load): the dz1'/y1 row (BN1
+// backward applied on the way in) and the 9 input rows of its receptive field; the MFMA operands
+// are then 4-byte LDS reads.  7 wide loads per row instead of 32 narrow ones.  Each wave owns a
+// private LDS region (no workgroup barrier: rows per wave differ at the tail).
+template <typename A>
+__global__ __launch_bounds__(kEncThreads) void k_conv1_wgrad_lds(
+    const float *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, const typename A::T *__restrict__ dz1p,
+    const typename A::T *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ mean1,
+    const float *__restrict__ rstd1, const double *__restrict__ S /*[2][16]*/, double count, int B, int G, int O1,
+    float *__restrict__ partial /*[nwaves][2*256 + 16]*/)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const int n = lane & 15, kq = lane >> 4;
+    const int wave_global = blockIdx.x * kEncWaves + wv;
+    const int XH = (O1 + 1) >> 1, rowlen = 2 * XH * kC;  // floats of one (b, z, y) row of y1 / dz1'
+    float *s_dy = lds + (size_t)wv * (rowlen + 9 * G), *s_in = s_dy + rowlen;
+    // staging role of this lane: channels c4 .. c4+3 of the voxels it copies
+    const int c4 = 4 * (lane & 3);
+    float sc4[4], mu4[4], rs4[4], m14[4], m24[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sc4[k] = scale1[c4 + k]; mu4[k] = mean1[c4 + k]; rs4[k] = rstd1[c4 + k];
+        m14[k] = (float)(S[c4 + k] / count); m24[k] = (float)(S[kC + c4 + k] / count);
+    }
+    int offl[2];
+    bool tok[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int t = 16 * tt + n;  // A row i = tap
+        tok[tt] = t < kTaps;
+        const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+        offl[tt] = tok[tt] ? (dz * 3 + dy) * G + dx : 0;
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nrows = B * O1 * O1;
+    int row0, row1;
+    wave_row_range(nrows, row0, row1);
+    for (int row = row0; row < row1; ++row) {
+        const int b = row / (O1 * O1), rem = row - b * O1 * O1, oz = rem / O1, oy = rem - oz * O1;
+        const uint32_t rb = vox1(b, oz, oy, 0, O1) * kC;
+        // ---- stage dy1 = BN1-backward(dz1', y1) of the row ----
+        for (int i = lane * 4; i < rowlen; i += kWave * 4) {
+            const float4 g = A::ld4(dz1p + rb + i), y = A::ld4(y1 + rb + i);
+            const int v = i >> 4, plane = v >= XH ? 1 : 0, x = 2 * (v - plane * XH) + plane;
+            float4 d;
+            d.x = sc4[0] * (g.x - m14[0] - ((y.x - mu4[0]) * rs4[0]) * m24[0]);
+            d.y = sc4[1] * (g.y - m14[1] - ((y.y - mu4[1]) * rs4[1]) * m24[1]);
+            d.z = sc4[2] * (g.z - m14[2] - ((y.z - mu4[2]) * rs4[2]) * m24[2]);
+            d.w = sc4[3] * (g.w - m14[3] - ((y.w - mu4[3]) * rs4[3]) * m24[3]);
+            if (x >= O1) d = make_float4(0.f, 0.f, 0.f, 0.f);  // padding slot of the odd plane
+            bs[0] += d.x; bs[1] += d.y; bs[2] += d.z; bs[3] += d.w;
+            *reinterpret_cast<float4 *>(s_dy + i) = d;
+        }
+        // ---- stage the 9 input rows (2oz+dz, 2oy+dy, :) ----
+        const float *in = obs_base + (rows ? rows[b] : (int64_t)b) * row_stride;
+        for (int i = lane * 4; i < 9 * G; i += kWave * 4) {
+            const int dz = i / (3 * G), r = i - dz * 3 * G;  // rows dy = 0..2 of one dz are contiguous
+            *reinterpret_cast<float4 *>(s_in + i) =
+                *reinterpret_cast<const float4 *>(in + ((size_t)(2 * oz + dz) * G + 2 * oy) * G + r);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+        // ---- MFMA: i = tap, j = co, k = 4 consecutive output positions ----
+        for (int x0 = 0; x0 < O1; x0 += 4) {
+            const int pos = x0 + kq;
+            const bool ok = pos < O1;
+            const int pc = ok ? pos : 0;
+            const float bv = ok ? s_dy[((pc & 1) * XH + (pc >> 1)) * kC + n] : 0.0f;  // B[k = pos][j = co]
+            const float a0 = tok[0] ? s_in[offl[0] + 2 * pc] : 0.0f;                  // A[i = tap][k = pos]
+            const float a1 = tok[1] ? s_in[offl[1] + 2 * pc] : 0.0f;
+            acc0 = mfma4(a0, bv, acc0);
+            acc1 = mfma4(a1, bv, acc1);
+        }
+        __builtin_amdgcn_wave_barrier();  // next row overwrites the staging area
+    }
+    float *out = partial + (size_t)wave_global * (2 * 256 + kC);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        out[(4 * kq + r) * kC + n] = acc0[r];          // [tap 0..15][co]
+        out[256 + (4 * kq + r) * kC + n] = acc1[r];    // [tap 16..31][co]
+    }
+    // bias sums: lanes with equal (lane & 3) hold the same channel group
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int d = 4; d < kWave; d <<= 1) bs[k] += __shfl_xor(bs[k], d, kWave);
+    if (lane < 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[512 + 4 * lane + k] = bs[k];
+    }
+}
+
 __global__ void k_conv1_wgrad_finish(const double *__restrict__ red, float *__restrict__ dW1, float *__restrict__ db1)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -856,8 +953,13 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     int nrows1 = batch * O1 * O1;
     int wg1_blocks = (nrows1 + kEncWaves - 1) / kEncWaves;
     wg1_blocks = wg1_blocks > 2048 ? 2048 : ((wg1_blocks + 7) & ~7);  // VGPR-light: 32 waves per CU hide the load latency
+    const size_t c1w_lds = (size_t)kEncWaves * (2 * ((O1 + 1) / 2) * kC + 9 * grid) * sizeof(float);
+    const bool c1w_staged = (grid % 4 == 0) && (row_stride % 4 == 0) && (((uintptr_t)obs_grid & 15) == 0) && c1w_lds <= 64 * 1024;
     if (p->act_bf16) {
         hipLaunchKernelGGL(k_conv1_wgrad<ActBF16>, dim3(wg1_blocks), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, (const uint16_t *)dz1_scratch, (const uint16_t *)y1, bn1,
+                       bn1 + 2 * kC, bn1 + 3 * kC, S1, (double)batch * O1 * O1 * O1, batch, grid, O1, w.wg_part);
+    } else if (c1w_staged) {
+        hipLaunchKernelGGL(k_conv1_wgrad_lds<ActF32>, dim3(wg1_blocks), dim3(kEncThreads), c1w_lds, st, obs_grid, rows, row_stride, (const float *)dz1_scratch, (const float *)y1, bn1,
                        bn1 + 2 * kC, bn1 + 3 * kC, S1, (double)batch * O1 * O1 * O1, batch, grid, O1, w.wg_part);
     } else {
         hipLaunchKernelGGL(k_conv1_wgrad<ActF32>, dim3(wg1_blocks), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, (const float *)dz1_scratch, (const float *)y1, bn1,
