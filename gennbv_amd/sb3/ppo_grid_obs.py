@@ -334,7 +334,8 @@ class PPO_Grid_Obs:
         torch.cuda.current_stream(self.device).wait_stream(side)
         loss.stop_flag.fill_(1)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: the RCCL watchdog thread may touch the HIP runtime while we capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._hip_minibatch_body(st)
         return g
 
