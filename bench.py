@@ -73,9 +73,10 @@ def build_algo(args, device, rank, world):
                                visual_input_shape=(cfg.stack, cfg.camera_height, cfg.camera_width),
                                grid_size=args.grid, backend=args.backend,
                                compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)))
-    if world > 1:
+    if world > 1 or os.environ.get("GENNBV_FORCE_DP") == "1":
         from gennbv_amd import parallel
-        parallel.attach(algo, world)
+        # GENNBV_FORCE_DP=1: run the data-parallel code path with a one-rank communicator (overhead check)
+        parallel.attach(algo, world, always_sync=world == 1)
     return algo, cfg, env
 
 
@@ -206,10 +207,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("GENNBV_FORCE_DP") == "1":
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"

@@ -25,10 +25,11 @@ class FlatAdam:
         n = sum(p.numel() for p in ps)
         self.n = n
         self.params = torch.empty(n, dtype=torch.float32, device=dev)
-        # one extra slot behind the gradient: the rank's approx-KL rides in the same all-reduce
+        # one extra slot IN FRONT of the gradient: the rank's approx-KL rides in the same all-reduce as
+        # the (small) conv-stack gradients, which come first in parameter order
         self.grads_with_slot = torch.zeros(n + 1, dtype=torch.float32, device=dev)
-        self.grads = self.grads_with_slot[:n]
-        self.kl_slot = self.grads_with_slot[n:]
+        self.kl_slot = self.grads_with_slot[:1]
+        self.grads = self.grads_with_slot[1:]
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)

@@ -225,26 +225,65 @@ class PPO_Grid_Obs:
         self.policy.features_extractor._bn_skip_flag = loss.stop_flag
         return self._hip
 
-    def _hip_minibatch_body(self, st):
-        """gather -> forward -> fused loss + d(logits, values) -> backward -> clip + Adam; no host sync."""
+    def _hip_minibatch_body(self, st, phase: str = "all"):
+        """gather -> forward -> fused loss + d(logits, values) -> backward -> clip + Adam; no host sync.
+
+        Data-parallel runs split the backward in two phases so that the all-reduce of the large
+        late-layer gradients (fc_grid: 55 MB of the 58 MB at G=64) overlaps the conv-stack backward:
+          phase "A": everything up to the gradients of all parameters EXCEPT the conv stack, plus
+                     d loss / d (conv-stack output);
+          phase "B": conv-stack backward (encoder.hip kernels) from that gradient."""
         from ..ops.encoder_ops import RowGather
         buf, pol, loss, opt = self.rollout_buffer, self.policy, st["loss"], st["opt"]
-        t, n = buf.buffer_size, buf.n_envs
-        loss.gather(buf)
-        obs = RowGather(buf.observations[:t].view(t * n, -1), loss.rows)
-        features = pol.extract_features(obs)
-        logits = pol.action_net(features)
-        values = pol.value_net(features).flatten()
-        d_logits, d_values = loss(logits, values)
-        opt.zero_grad()
-        torch.autograd.backward([logits, values], [d_logits, d_values])
-        if self._sync is None or not self._sync.active:
-            opt.step(self.max_grad_norm, loss.stop_flag)
+        if phase in ("all", "A"):
+            t, n = buf.buffer_size, buf.n_envs
+            loss.gather(buf)
+            obs = RowGather(buf.observations[:t].view(t * n, -1), loss.rows)
+            features = pol.extract_features(obs)
+            logits = pol.action_net(features)
+            values = pol.value_net(features).flatten()
+            d_logits, d_values = loss(logits, values)
+            opt.zero_grad()
+            if phase == "all":
+                torch.autograd.backward([logits, values], [d_logits, d_values])
+                if self._sync is None or not self._sync.active:
+                    opt.step(self.max_grad_norm, loss.stop_flag)
+                return
+            enc = pol.features_extractor
+            gf = enc._last_grid_feats
+            conv = set(id(p) for p in enc.naive_encoder_grid.parameters())
+            late = [p for p in pol.parameters() if id(p) not in conv]
+            torch.autograd.backward([logits, values], [d_logits, d_values], inputs=late + [gf], retain_graph=True)
+            st["gf"] = gf
+        else:  # phase "B"
+            gf = st["gf"]
+            enc = pol.features_extractor
+            torch.autograd.backward([gf], [gf.grad], inputs=list(enc.naive_encoder_grid.parameters()))
 
     def _hip_minibatch_tail(self, st):
         """data-parallel tail: global KL decision + clip + Adam on the summed gradient."""
         loss, opt = st["loss"], st["opt"]
         opt.step(self.max_grad_norm, loss.stop_flag, grad_scale=1.0 / self._sync.world, kl_slot_target=loss.args.target_kl)
+
+    def _dp_minibatch(self, st, use_graph: bool):
+        """One data-parallel optimizer step: [phase A] -> all-reduce(late grads) overlapped with
+        [phase B] -> all-reduce(KL slot + conv grads) -> clip/Adam tail."""
+        import torch.distributed as dist
+        opt = st["opt"]
+        n_conv = sum(p.numel() for p in self.policy.features_extractor.naive_encoder_grid.parameters())
+        if use_graph:
+            st["graph"][0].replay()
+        else:
+            self._hip_minibatch_body(st, "A")
+        late = opt.grads_with_slot[1 + n_conv:]
+        work = dist.all_reduce(late, op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
+        if use_graph:
+            st["graph"][1].replay()
+        else:
+            self._hip_minibatch_body(st, "B")
+        dist.all_reduce(opt.grads_with_slot[:1 + n_conv], op=dist.ReduceOp.SUM, group=self._sync.group)
+        work.wait()
+        self._hip_minibatch_tail(st)
 
     def _train_hip(self) -> None:
         """train() on the gfx950 kernels: same arithmetic as the reference loop
@@ -284,13 +323,12 @@ class PPO_Grid_Obs:
         for epoch in range(self.n_epochs):
             for k in range(n_mb):
                 loss.rows.copy_(rows_all[k * batch:(k + 1) * batch])
-                if use_graph:
+                if self._sync is not None and self._sync.active:
+                    self._dp_minibatch(st, use_graph)
+                elif use_graph:
                     st["graph"].replay()
                 else:
                     self._hip_minibatch_body(st)
-                if self._sync is not None and self._sync.active:
-                    self._sync.all_reduce_flat(opt.grads_with_slot)  # ONE collective per optimizer step
-                    self._hip_minibatch_tail(st)
             epochs_run += 1
             # the ONLY read-back inside train(): early-stop flag, once per epoch (the reference
             # reads approx_kl on the host after every minibatch, :261-268)
@@ -321,23 +359,36 @@ class PPO_Grid_Obs:
         self.logger.record("time/training", time.time() - training_start)
 
     def _capture_minibatch_graph(self, st):
-        """Capture gather+forward+loss+backward+Adam of one minibatch as a hipGraph.  Warm-up runs
-        happen on a side stream with the update masked (stop_flag = 1), so parameters, Adam state
-        and BatchNorm running statistics are untouched."""
+        """Capture gather+forward+loss+backward+Adam of one minibatch as a hipGraph (two graphs sharing a
+        memory pool -- phase A / phase B -- when data-parallel).  Warm-up runs happen on a side stream with
+        the update masked (stop_flag = 1), so parameters, Adam state and BatchNorm running statistics are
+        untouched."""
         loss = st["loss"]
+        dp = self._sync is not None and self._sync.active
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
             for _ in range(2):
                 loss.stop_flag.fill_(1)
-                self._hip_minibatch_body(st)
+                if dp:
+                    self._hip_minibatch_body(st, "A")
+                    self._hip_minibatch_body(st, "B")
+                else:
+                    self._hip_minibatch_body(st)
         torch.cuda.current_stream(self.device).wait_stream(side)
         loss.stop_flag.fill_(1)
-        g = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread may touch the HIP runtime while we capture
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            self._hip_minibatch_body(st)
-        return g
+        ga = torch.cuda.CUDAGraph()
+        if not dp:
+            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                self._hip_minibatch_body(st)
+            return ga
+        with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+            self._hip_minibatch_body(st, "A")
+        gb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
+            self._hip_minibatch_body(st, "B")
+        return (ga, gb)
 
     # ------------------------------------------------------------------------------
     def _env_step(self, actions, obs_out):
