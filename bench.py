@@ -199,6 +199,15 @@ def ppo_loss_delta(args, device):
             "abs_delta": deltas, "max_abs_delta": max(deltas.values()), "tolerance": 1e-4}
 
 
+def _flush_c_stdio():
+    """RCCL writes a version banner with printf; flush it so that it cannot land after the JSON line."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def main():
     args = parse()
     import torch
@@ -213,6 +222,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        dist.barrier()  # creates the communicator now (RCCL prints its banner through C stdio here)
+        _flush_c_stdio()
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -266,7 +277,7 @@ def main():
                                f"{args.grid}^3 grid, n_steps={args.n_steps}, batch_size={args.batch_size}, "
                                f"n_epochs={args.n_epochs}, one step = one PPO iteration",
                    "global_envs": world * args.envs, "encoder_backend": args.backend,
-                   "parallelism": f"env-sharded dp{world}",
+                   "parallelism": f"env-sharded dp{world}", "dp_graph_mode": getattr(algo, "dp_graph_mode", None),
                    "breakdown_ms_per_step": {"rollout": phases["rollout"].total_ms() / args.steps,
                                              "train": phases["train"].total_ms() / args.steps,
                                              "voxel_update_total": vox.total_ms() / args.steps}},
@@ -284,11 +295,14 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, cfg)
             except Exception as ex:  # the baseline must never take the bench line down
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)}
-        print(json.dumps(out))
     if args.save_gemm_tuning and rank == 0:
         gemm_tuning.save(args.save_gemm_tuning)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
+    _flush_c_stdio()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)  # the ONE JSON line, last thing on stdout
 
 
 if __name__ == "__main__":

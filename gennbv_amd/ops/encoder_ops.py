@@ -153,7 +153,12 @@ def hybrid_forward(enc, observations) -> torch.Tensor:
         feature_action = enc.naive_encoder_action(action_input)
     feature_grid = grid_encoder(base, rows, s, g, enc.naive_encoder_grid, enc.training, getattr(enc, "_bn_skip_flag", None),
                                 enc.compute_dtype == torch.bfloat16)
-    enc._last_grid_feats = feature_grid  # output of the conv stack (the backward can be split here)
+    if getattr(enc, "_split_backward", False) and torch.is_grad_enabled():
+        # data-parallel: cut the autograd graph at the conv-stack output so that the backward runs in
+        # two phases (late layers first, their gradient all-reduce overlaps the conv-stack backward)
+        enc._grid_feats_out = feature_grid
+        feature_grid = feature_grid.detach().requires_grad_(True)
+        enc._grid_feats_leaf = feature_grid
     feature_grid = enc.output_layer_grid(feature_grid)
     if side is not None:
         torch.cuda.current_stream(base.device).wait_stream(side)

@@ -217,7 +217,9 @@ class PPO_Grid_Obs:
             opt = FlatAdam(self.policy, lr=self.lr_schedule(1.0), eps=old.defaults.get("eps", 1e-5),
                            betas=old.defaults.get("betas", (0.9, 0.999)))
             opt.load_torch_adam_state(old)
-        self._hip = {"loss": loss, "opt": opt, "batch": batch, "n_mb": n_minibatches, "graph": None}
+        self._hip = {"loss": loss, "opt": opt, "batch": batch, "n_mb": n_minibatches, "graph": None,
+                     "n_conv": sum(p.numel() for p in self.policy.features_extractor.naive_encoder_grid.parameters())}
+        self.policy.features_extractor._split_backward = self._sync is not None and self._sync.active
         if self._sync is not None and self._sync.active:
             # the rank's approx-KL rides in the slot behind the flat gradient; the flag is set from
             # the GLOBAL mean after the all-reduce (gnbv_clip_adam_step), not by the loss kernel
@@ -249,38 +251,44 @@ class PPO_Grid_Obs:
                 if self._sync is None or not self._sync.active:
                     opt.step(self.max_grad_norm, loss.stop_flag)
                 return
+            # the forward cut the graph at the conv-stack output (enc._split_backward): this backward
+            # stops at that leaf and fills the gradients of every non-conv parameter
+            torch.autograd.backward([logits, values], [d_logits, d_values])
+        else:  # phase "B": conv-stack backward from d loss / d (conv-stack output)
             enc = pol.features_extractor
-            gf = enc._last_grid_feats
-            conv = set(id(p) for p in enc.naive_encoder_grid.parameters())
-            late = [p for p in pol.parameters() if id(p) not in conv]
-            torch.autograd.backward([logits, values], [d_logits, d_values], inputs=late + [gf], retain_graph=True)
-            st["gf"] = gf
-        else:  # phase "B"
-            gf = st["gf"]
-            enc = pol.features_extractor
-            torch.autograd.backward([gf], [gf.grad], inputs=list(enc.naive_encoder_grid.parameters()))
+            torch.autograd.backward([enc._grid_feats_out], [enc._grid_feats_leaf.grad])
 
     def _hip_minibatch_tail(self, st):
         """data-parallel tail: global KL decision + clip + Adam on the summed gradient."""
         loss, opt = st["loss"], st["opt"]
         opt.step(self.max_grad_norm, loss.stop_flag, grad_scale=1.0 / self._sync.world, kl_slot_target=loss.args.target_kl)
 
-    def _dp_minibatch(self, st, use_graph: bool):
-        """One data-parallel optimizer step: [phase A] -> all-reduce(late grads) overlapped with
-        [phase B] -> all-reduce(KL slot + conv grads) -> clip/Adam tail."""
+    def _dp_step_body(self, st):
+        """[phase A] -> all-reduce(late grads) overlapped with [phase B] -> all-reduce(KL slot + conv
+        grads) -> clip/Adam tail.  Capturable: RCCL collectives are recorded into the hipGraph."""
         import torch.distributed as dist
         opt = st["opt"]
-        n_conv = sum(p.numel() for p in self.policy.features_extractor.naive_encoder_grid.parameters())
-        if use_graph:
-            st["graph"][0].replay()
-        else:
-            self._hip_minibatch_body(st, "A")
-        late = opt.grads_with_slot[1 + n_conv:]
-        work = dist.all_reduce(late, op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
-        if use_graph:
-            st["graph"][1].replay()
-        else:
-            self._hip_minibatch_body(st, "B")
+        n_conv = st["n_conv"]
+        self._hip_minibatch_body(st, "A")
+        work = dist.all_reduce(opt.grads_with_slot[1 + n_conv:], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
+        self._hip_minibatch_body(st, "B")
+        dist.all_reduce(opt.grads_with_slot[:1 + n_conv], op=dist.ReduceOp.SUM, group=self._sync.group)
+        work.wait()
+        self._hip_minibatch_tail(st)
+
+    def _dp_minibatch(self, st, use_graph: bool):
+        """One data-parallel optimizer step (see _dp_step_body)."""
+        import torch.distributed as dist
+        g = st["graph"] if use_graph else None
+        if g is None:
+            return self._dp_step_body(st)
+        if not isinstance(g, tuple):
+            return g.replay()  # everything, collectives included, in one hipGraph
+        # fallback when the collectives could not be captured: two graphs, eager collectives + tail
+        opt, n_conv = st["opt"], st["n_conv"]
+        g[0].replay()
+        work = dist.all_reduce(opt.grads_with_slot[1 + n_conv:], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
+        g[1].replay()
         dist.all_reduce(opt.grads_with_slot[:1 + n_conv], op=dist.ReduceOp.SUM, group=self._sync.group)
         work.wait()
         self._hip_minibatch_tail(st)
@@ -371,8 +379,7 @@ class PPO_Grid_Obs:
             for _ in range(2):
                 loss.stop_flag.fill_(1)
                 if dp:
-                    self._hip_minibatch_body(st, "A")
-                    self._hip_minibatch_body(st, "B")
+                    self._dp_step_body(st)
                 else:
                     self._hip_minibatch_body(st)
         torch.cuda.current_stream(self.device).wait_stream(side)
@@ -383,6 +390,17 @@ class PPO_Grid_Obs:
             with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                 self._hip_minibatch_body(st)
             return ga
+        try:
+            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                self._dp_step_body(st)
+            self.dp_graph_mode = "one hipGraph incl. RCCL collectives"
+            return ga
+        except Exception as ex:  # collectives not capturable on this stack: capture the compute only
+            self.dp_graph_mode = f"two compute graphs + eager collectives ({type(ex).__name__})"
+            if self.verbose >= 1:
+                print(f"[gennbv_amd] RCCL capture failed ({ex!r}); using two compute graphs + eager collectives")
+            torch.cuda.synchronize(self.device)
+        ga = torch.cuda.CUDAGraph()
         with torch.cuda.graph(ga, capture_error_mode="thread_local"):
             self._hip_minibatch_body(st, "A")
         gb = torch.cuda.CUDAGraph()
