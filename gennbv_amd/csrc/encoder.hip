@@ -258,36 +258,82 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
     const int P2 = O2 * O2 * O2;
     float s_sum = 0.0f, s_sq = 0.0f;
     const int ntile_x = (O2 + 15) / 16, nwork = (oz1 - oz0) * O2 * ntile_x;
-    for (int wk = wv; wk < nwork; wk += kBigWaves) {
+    const uint32_t XHC = ((uint32_t)(O1 + 1) >> 1) * kC, rowC = 2 * XHC, planeC = rowC * O1;
+    // Register double buffer over dz slabs (9 taps = 9 KiB per wave each): the requests of slab s+1
+    // (possibly the first slab of the wave's next tile) are issued BEFORE the 36 MFMAs of slab s.
+    // Left to itself the compiler sinks every load next to its use (load, s_waitcnt vmcnt(0),
+    // 4 MFMA): one 1 KiB request in flight per wave, latency-bound at ~3.5 TB/s.  The scheduling
+    // barriers pin the request groups where they are written.
+    auto request = [&](int wk, int dz, float4 (&v)[9]) {
         const int oz = oz0 + wk / (O2 * ntile_x), rr = wk % (O2 * ntile_x), oy = rr / ntile_x;
-        {
-            const int ox0 = (rr % ntile_x) * 16;
-            const int ox = min(ox0 + m, O2 - 1);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 9
-            for (int tap = 0; tap < kTaps; ++tap) {
-                const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-                const float4 v = A::ld4(y1 + vox1(b, 2 * oz + dz, 2 * oy + dy, 2 * ox + dx, O1) * kC + 4 * kq);
-                const float z0 = fmaxf(fmaf(sc[0], v.x, sh[0]), 0.f), z1 = fmaxf(fmaf(sc[1], v.y, sh[1]), 0.f);
-                const float z2 = fmaxf(fmaf(sc[2], v.z, sh[2]), 0.f), z3 = fmaxf(fmaf(sc[3], v.w, sh[3]), 0.f);
-                const float *wb = w2s + tap * 256 + lane;  // + s*64
-                acc = mfma4(z0, wb[0], acc);
-                acc = mfma4(z1, wb[64], acc);
-                acc = mfma4(z2, wb[128], acc);
-                acc = mfma4(z3, wb[192], acc);
-            }
-            float *out = y2 + ((size_t)b * kC + m) * P2 + ((size_t)oz * O2 + oy) * O2;
+        const int ox = min((rr % ntile_x) * 16 + m, O2 - 1);
+        const uint32_t base = vox1(b, 2 * oz + dz, 2 * oy, 2 * ox, O1) * kC + 4 * kq;  // even-parity voxel ox
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int oxi = ox0 + 4 * kq + r;
-                if (oxi < O2) {
-                    const float y = acc[r] + bias;
-                    out[oxi] = y;
-                    s_sum += y;
-                    s_sq += y * y;
-                }
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3, dx = t % 3;
+            // dx = 0, 2: even plane, voxels ox, ox + 1; dx = 1: odd plane, voxel ox
+            v[t] = A::ld4(y1 + base + (dy * rowC + (dx == 1 ? XHC : 0) + (dx == 2 ? kC : 0)));
+        }
+    };
+    auto consume = [&](int dz, const float4 (&v)[9], f32x4 &acc) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float z0 = fmaxf(fmaf(sc[0], v[t].x, sh[0]), 0.f), z1 = fmaxf(fmaf(sc[1], v[t].y, sh[1]), 0.f);
+            const float z2 = fmaxf(fmaf(sc[2], v[t].z, sh[2]), 0.f), z3 = fmaxf(fmaf(sc[3], v[t].w, sh[3]), 0.f);
+            const float *wb = w2s + (dz * 9 + t) * 256 + lane;  // + s*64
+            acc = mfma4(z0, wb[0], acc);
+            acc = mfma4(z1, wb[64], acc);
+            acc = mfma4(z2, wb[128], acc);
+            acc = mfma4(z3, wb[192], acc);
+        }
+    };
+    auto finish = [&](int wk, const f32x4 &acc) {
+        const int oz = oz0 + wk / (O2 * ntile_x), rr = wk % (O2 * ntile_x), oy = rr / ntile_x, ox0 = (rr % ntile_x) * 16;
+        float *out = y2 + ((size_t)b * kC + m) * P2 + ((size_t)oz * O2 + oy) * O2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oxi = ox0 + 4 * kq + r;
+            if (oxi < O2) {
+                const float y = acc[r] + bias;
+                out[oxi] = y;
+                s_sum += y;
+                s_sq += y * y;
             }
         }
+    };
+    float4 va[9], vb[9];
+    if (wv < nwork) request(wv, 0, va);
+    for (int wk = wv; wk < nwork; wk += 2 * kBigWaves) {
+        // tile wk: slabs in va, vb, va; tile wk + kBigWaves: vb, va, vb
+        const int wk2 = wk + kBigWaves, wk3 = wk + 2 * kBigWaves;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        request(wk, 1, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(0, va, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        request(wk, 2, va);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(1, vb, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (wk2 < nwork) request(wk2, 0, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(2, va, acc);
+        finish(wk, acc);
+        if (wk2 >= nwork) break;
+        __builtin_amdgcn_sched_barrier(0);
+        acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        request(wk2, 1, va);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(0, vb, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        request(wk2, 2, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(1, va, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (wk3 < nwork) request(wk3, 0, va);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(2, vb, acc);
+        finish(wk2, acc);
     }
     write_partials(partials, blockIdx.x * kBigWaves + wv, s_sum, s_sq);
 }
@@ -529,6 +575,55 @@ __global__ void k_conv2_wgrad_finish(const double *__restrict__ red, float *__re
 //   dz1'[v, ci] = [pre1 > 0] * sum_{tap, co} dy2[(v - tap)/2, co] * W2[co][ci][tap]
 // Input voxels of one x-parity share their tap set -> tiles of 16 voxels ix = 2j + px.
 // ---------------------------------------------------------------------------
+// The transposed conv as 8 sub-convolutions.  A "super-tile" (a, c, j0) is the 2 x 2 x 32 block of
+// layer-1 voxels iz in {2a, 2a+1}, iy in {2c, 2c+1}, ix = 2j + ex (j = j0 .. j0+15, ex in {0, 1}).
+// Along one axis an even index 2a receives taps d = 0 (from output a) and d = 2 (from a-1), an odd
+// index 2a+1 receives d = 1 (from a): the whole block depends on the 2 x 2 x 17 neighbourhood
+// dy2[a-zo][c-yo][j-xo] (zo, yo, xo in {0, 1}) -- EIGHT 16-byte operand requests per lane feed all 27
+// taps (108 MFMAs); per-voxel tiles would request each of them 3.4 times.  The 8 dy2 vectors and the
+// 8 y1 vectors of the epilogues are requested back to back before the first MFMA (16 KiB in flight
+// per wave); out-of-grid neighbours are zeros (select, no branch), so the block is straight-line.
+// Accumulation order per voxel: (zo, yo, xo) lexicographic = taps (dz, dy, dx) ascending.
+template <typename A, int EZ, int EY, int EX>
+__device__ __forceinline__ void dgrad_subtile(
+    const float4 (&L)[8], const float4 &y, const float *w2d, typename A::T *__restrict__ dz1p, uint32_t idx, bool lane_ok,
+    const float4 &sc, const float4 &sh, const float4 &mu, const float4 &rs, float (&s1)[4], float (&s2)[4])
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int zo = 0; zo < (EZ ? 1 : 2); ++zo)
+#pragma unroll
+        for (int yo = 0; yo < (EY ? 1 : 2); ++yo)
+#pragma unroll
+            for (int xo = 0; xo < (EX ? 1 : 2); ++xo) {
+                const int dz = EZ ? 1 : 2 * zo, dy = EY ? 1 : 2 * yo, dx = EX ? 1 : 2 * xo;
+                const float4 &t = L[(zo * 2 + yo) * 2 + xo];
+                const float *wb = w2d + ((dz * 3 + dy) * 3 + dx) * 256 + lane;  // [(tap*4+s)*4+kq][ci = m]
+                acc = mfma4(wb[0], t.x, acc);
+                acc = mfma4(wb[64], t.y, acc);
+                acc = mfma4(wb[128], t.z, acc);
+                acc = mfma4(wb[192], t.w, acc);
+            }
+    if (lane_ok) {
+        float4 g;
+        g.x = fmaf(sc.x, y.x, sh.x) > 0.0f ? acc[0] : 0.0f;
+        g.y = fmaf(sc.y, y.y, sh.y) > 0.0f ? acc[1] : 0.0f;
+        g.z = fmaf(sc.z, y.z, sh.z) > 0.0f ? acc[2] : 0.0f;
+        g.w = fmaf(sc.w, y.w, sh.w) > 0.0f ? acc[3] : 0.0f;
+        A::st4(dz1p + idx, g);
+        s1[0] += g.x; s2[0] += g.x * ((y.x - mu.x) * rs.x);
+        s1[1] += g.y; s2[1] += g.y * ((y.y - mu.y) * rs.y);
+        s1[2] += g.z; s2[2] += g.z * ((y.z - mu.z) * rs.z);
+        s1[3] += g.w; s2[3] += g.w * ((y.w - mu.w) * rs.w);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// conv2 data gradient (transposed conv, stride 2) + ReLU mask of layer 1 + BN1-backward sums.
+//   dz1'[v, ci] = [pre1 > 0] * sum_{tap, co} dy2[(v - tap)/2, co] * W2[co][ci][tap]
+// workgroup = (sample b, kPlanesPerGroup plane pairs a); wave = super-tiles (a, c)
+// ---------------------------------------------------------------------------
 template <typename A>
 __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad(
     const float *__restrict__ dy2, const float *__restrict__ W2, const typename A::T *__restrict__ y1, const float *__restrict__ scale1,
@@ -537,8 +632,9 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad(
 {
     __shared__ __attribute__((aligned(16))) float w2d[kTaps * 4 * 4 * kC];  // [(tap*4+s)*4+kq][n] = W2[co = 4kq+s][ci = n][tap]
     fill_lds_image(w2d, W2 /* k_prep_w2 dgrad image */);
-    int b, iz0, iz1;
-    const bool live = sample_plane_group(B, O1, kPlanesPerGroup, b, iz0, iz1);
+    const int NA = (O1 + 1) >> 1;  // plane pairs / row pairs / voxels per x-parity
+    int b, a0, a1;
+    const bool live = sample_plane_group(B, NA, kPlanesPerGroup, b, a0, a1);
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const int m = lane & 15, kq = lane >> 4;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -547,56 +643,50 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad(
     // a lane owns 4 consecutive channels of one voxel (16-byte load of y1, 16-byte store of dz1')
     const float4 sc = *reinterpret_cast<const float4 *>(scale1 + 4 * kq), sh = *reinterpret_cast<const float4 *>(shift1 + 4 * kq);
     const float4 mu = *reinterpret_cast<const float4 *>(mean1 + 4 * kq), rs = *reinterpret_cast<const float4 *>(rstd1 + 4 * kq);
-    // taps along one axis for input index i: even -> {0, 2}, odd -> {1}; output index (i - d)/2 in [0, O2)
-    for (int wk = wv; wk < (iz1 - iz0) * O1; wk += kBigWaves) {
-        const int iz = iz0 + wk / O1, iy = wk % O1;
-        const int nz = (iz & 1) ? 1 : 2;
-        const int ny = (iy & 1) ? 1 : 2;
-        for (int px = 0; px < 2; ++px) {
-            const int nvox = (O1 - px + 1) / 2;  // voxels ix = 2j + px < O1
-            const int nx = px ? 1 : 2;
-            for (int j0 = 0; j0 < nvox; j0 += 16) {
-                const int j = j0 + m;
-                // the epilogue's y1 operand is requested together with the dy2 operands (one latency per tile)
-                const size_t idx = vox1(b, iz, iy, 2 * min(j, nvox - 1) + px, O1) * kC + 4 * kq;
-                const float4 y = A::ld4(y1 + idx);
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                for (int tz = 0; tz < nz; ++tz) {
-                    const int dz = (iz & 1) ? 1 : 2 * tz, oz = (iz - dz) >> 1;
-                    if (oz < 0 || oz >= O2) continue;
-                    for (int ty = 0; ty < ny; ++ty) {
-                        const int dy = (iy & 1) ? 1 : 2 * ty, oy = (iy - dy) >> 1;
-                        if (oy < 0 || oy >= O2) continue;
-                        for (int tx = 0; tx < nx; ++tx) {
-                            const int dx = px ? 1 : 2 * tx, ox = j - (dx >> 1);
-                            const bool ok = ox >= 0 && ox < O2 && j < nvox;
-                            const int oxc = min(max(ox, 0), O2 - 1);
-                            float4 v = *reinterpret_cast<const float4 *>(
-                                dy2 + ((((size_t)b * O2 + oz) * O2 + oy) * O2 + oxc) * kC + 4 * kq);
-                            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                            const int tap = (dz * 3 + dy) * 3 + dx;
-                            const float *wb = w2d + tap * 256 + lane;  // [(tap*4+s)*4+kq][ci = m]
-                            acc = mfma4(wb[0], v.x, acc);
-                            acc = mfma4(wb[64], v.y, acc);
-                            acc = mfma4(wb[128], v.z, acc);
-                            acc = mfma4(wb[192], v.w, acc);
-                        }
-                    }
+    const int ntx = (NA + 15) / 16, nwork = (a1 - a0) * NA * ntx;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int wk = wv; wk < nwork; wk += kBigWaves) {
+        const int a = a0 + wk / (NA * ntx), rr = wk % (NA * ntx), c = rr / ntx, j = (rr % ntx) * 16 + m;
+        // ---- requests: 8 dy2 neighbours, 8 y1 vectors ----
+        float4 L[8], Y[8];
+        bool okL[8];
+#pragma unroll
+        for (int zo = 0; zo < 2; ++zo)
+#pragma unroll
+            for (int yo = 0; yo < 2; ++yo)
+#pragma unroll
+                for (int xo = 0; xo < 2; ++xo) {
+                    const int oz = a - zo, oy = c - yo, ox = j - xo;
+                    okL[(zo * 2 + yo) * 2 + xo] = oz >= 0 && oz < O2 && oy >= 0 && oy < O2 && ox >= 0 && ox < O2;
+                    const int ozc = min(max(oz, 0), O2 - 1), oyc = min(max(oy, 0), O2 - 1), oxc = min(max(ox, 0), O2 - 1);
+                    L[(zo * 2 + yo) * 2 + xo] = *reinterpret_cast<const float4 *>(
+                        dy2 + ((((uint32_t)b * O2 + ozc) * O2 + oyc) * O2 + oxc) * kC + 4 * kq);
                 }
-                if (j < nvox) {
-                    float4 g;
-                    g.x = fmaf(sc.x, y.x, sh.x) > 0.0f ? acc[0] : 0.0f;
-                    g.y = fmaf(sc.y, y.y, sh.y) > 0.0f ? acc[1] : 0.0f;
-                    g.z = fmaf(sc.z, y.z, sh.z) > 0.0f ? acc[2] : 0.0f;
-                    g.w = fmaf(sc.w, y.w, sh.w) > 0.0f ? acc[3] : 0.0f;
-                    A::st4(dz1p + idx, g);
-                    s1[0] += g.x; s2[0] += g.x * ((y.x - mu.x) * rs.x);
-                    s1[1] += g.y; s2[1] += g.y * ((y.y - mu.y) * rs.y);
-                    s1[2] += g.z; s2[2] += g.z * ((y.z - mu.z) * rs.z);
-                    s1[3] += g.w; s2[3] += g.w * ((y.w - mu.w) * rs.w);
+        uint32_t idx[8];
+        bool okV[8];
+#pragma unroll
+        for (int ez = 0; ez < 2; ++ez)
+#pragma unroll
+            for (int ey = 0; ey < 2; ++ey)
+#pragma unroll
+                for (int ex = 0; ex < 2; ++ex) {
+                    const int iz = 2 * a + ez, iy = 2 * c + ey, ix = 2 * j + ex, e = (ez * 2 + ey) * 2 + ex;
+                    okV[e] = iz < O1 && iy < O1 && ix < O1;
+                    idx[e] = vox1(b, min(iz, O1 - 1), min(iy, O1 - 1), min(ix, O1 - 1 - ((O1 - 1 - ex) & 1)), O1) * kC + 4 * kq;
+                    Y[e] = A::ld4(y1 + idx[e]);
                 }
-            }
-        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (!okL[t]) L[t] = zero4;
+        dgrad_subtile<A, 0, 0, 0>(L, Y[0], w2d, dz1p, idx[0], okV[0], sc, sh, mu, rs, s1, s2);
+        dgrad_subtile<A, 0, 0, 1>(L, Y[1], w2d, dz1p, idx[1], okV[1], sc, sh, mu, rs, s1, s2);
+        dgrad_subtile<A, 0, 1, 0>(L, Y[2], w2d, dz1p, idx[2], okV[2], sc, sh, mu, rs, s1, s2);
+        dgrad_subtile<A, 0, 1, 1>(L, Y[3], w2d, dz1p, idx[3], okV[3], sc, sh, mu, rs, s1, s2);
+        dgrad_subtile<A, 1, 0, 0>(L, Y[4], w2d, dz1p, idx[4], okV[4], sc, sh, mu, rs, s1, s2);
+        dgrad_subtile<A, 1, 0, 1>(L, Y[5], w2d, dz1p, idx[5], okV[5], sc, sh, mu, rs, s1, s2);
+        dgrad_subtile<A, 1, 1, 0>(L, Y[6], w2d, dz1p, idx[6], okV[6], sc, sh, mu, rs, s1, s2);
+        dgrad_subtile<A, 1, 1, 1>(L, Y[7], w2d, dz1p, idx[7], okV[7], sc, sh, mu, rs, s1, s2);
     }
     write_partials_cl(partials, blockIdx.x * kBigWaves + wv, s1, s2);
 }
@@ -938,7 +1028,7 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     if ((err = gnbv_launch_status())) return err;
     // ---- conv2 data gradient (+ ReLU1 mask, BN1 backward sums) ----
     hipLaunchKernelGGL(k_prep_w2, dim3(kTaps), dim3(256), 0, st, p->w2, w.w2img, w.w2img + kTaps * 256);
-    const int gd = sample_plane_group_grid(batch, O1, kPlanesPerGroup);
+    const int gd = sample_plane_group_grid(batch, (O1 + 1) / 2, kPlanesPerGroup);  // groups of plane PAIRS
     if (p->act_bf16) {
         hipLaunchKernelGGL(k_conv2_dgrad<ActBF16>, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const uint16_t *)y1, bn1, bn1 + kC, bn1 + 2 * kC,
                        bn1 + 3 * kC, batch, O1, O2, (uint16_t *)dz1_scratch, w.bn_part);

@@ -1,0 +1,71 @@
+// Micro-benchmark: sustained rate of v_mfma_f32_16x16x4_f32 on gfx950 as a function of
+// waves per SIMD and of the number of independent accumulator chains per wave.
+//   hipcc --offload-arch=gfx950 -O3 -o mfma_rate tools/ubench/mfma_rate.hip && ./mfma_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int CHAINS, bool LDSB>
+__global__ __launch_bounds__(1024) void k(float *out, int iters)
+{
+    __shared__ float w[27 * 256];
+    for (int i = threadIdx.x; i < 27 * 256; i += blockDim.x) w[i] = 1e-3f * (i & 63);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    f32x4 acc[CHAINS];
+    for (int c = 0; c < CHAINS; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float a = 1.0f + lane * 1e-6f, b = 0.5f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float bb = LDSB ? w[t * 256 + s * 64 + lane] : b;
+#pragma unroll
+                for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, acc[c], 0, 0, 0);
+            }
+        }
+    }
+    float r = 0.f;
+    for (int c = 0; c < CHAINS; ++c) r += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+template <int CHAINS, bool LDSB>
+void run(int threads, int blocks_per_cu, float *out)
+{
+    const int iters = 64, blocks = 256 * blocks_per_cu;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    k<CHAINS, LDSB><<<blocks, threads>>>(out, 2);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    k<CHAINS, LDSB><<<blocks, threads>>>(out, iters);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double nmfma = (double)blocks * (threads / 64) * iters * 108.0 * CHAINS;
+    const double tf = nmfma * 2048.0 / (ms * 1e-3) / 1e12;
+    // cycles per MFMA per SIMD at 2.4 GHz: 1024 SIMDs
+    const double cyc = (ms * 1e-3) * 2.4e9 / (nmfma / 1024.0);
+    printf("chains %d ldsB %d threads %4d blocks/CU %d: %.3f ms  %.1f TFLOP/s  %.1f cycles/MFMA/SIMD @2.4GHz\n", CHAINS, (int)LDSB, threads,
+           blocks_per_cu, ms, tf, cyc);
+}
+
+int main()
+{
+    float *out; (void)hipMalloc(&out, 256 * 8 * 1024 * sizeof(float));
+    run<1, false>(256, 1, out);   // 1 wave / SIMD
+    run<1, false>(512, 1, out);   // 2
+    run<1, false>(1024, 1, out);  // 4
+    run<1, false>(1024, 2, out);  // 8
+    run<2, false>(256, 1, out);
+    run<4, false>(256, 1, out);
+    run<4, false>(1024, 1, out);
+    run<1, true>(256, 1, out);
+    run<1, true>(1024, 1, out);
+    run<1, true>(1024, 2, out);
+    run<2, true>(1024, 1, out);
+    run<4, true>(1024, 1, out);
+    return 0;
+}
