@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd(
 {
     int b, oz;
     const bool live = sample_plane(B, O1, b, oz);
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform -> SALU index math
     const int m = lane & 15, kq = lane >> 4;
     float s_sum[4] = {0.f, 0.f, 0.f, 0.f}, s_sq[4] = {0.f, 0.f, 0.f, 0.f};
     if (live) {
@@ -164,33 +164,49 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd(
             off[s] = ok ? (dz * G + dy) * G + dx : 0;
         }
         const float4 bias = *reinterpret_cast<const float4 *>(b1 + 4 * kq);
-        for (int oy = wv; oy < O1; oy += kEncWaves) {
-            for (int ox0 = 0; ox0 < O1; ox0 += 32) {
-                // two 16-output tiles per trip: 14 loads in flight before the first MFMA
-                float v[2][7];
+        // trips = (output row, 32-output x range); the 14 operand requests of trip k+1 are issued
+        // before the MFMAs / stores of trip k (register double buffer, pinned by scheduling barriers)
+        const int nx = (O1 + 31) / 32, nrow = (O1 - wv + kEncWaves - 1) / kEncWaves, ntrip = nrow > 0 ? nrow * nx : 0;
+        auto request = [&](int k, float (&v)[2][7]) {
+            const int oy = wv + kEncWaves * (k / nx), ox0 = 32 * (k % nx);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int ox = min(ox0 + 16 * t + m, O1 - 1);
-                    const float *p = in + ((size_t)(2 * oz) * G + 2 * oy) * G + 2 * ox;
+            for (int t = 0; t < 2; ++t) {
+                const int ox = min(ox0 + 16 * t + m, O1 - 1);
+                const float *p = in + ((size_t)(2 * oz) * G + 2 * oy) * G + 2 * ox;
 #pragma unroll
-                    for (int s = 0; s < 7; ++s) v[t][s] = p[off[s]];
-                }
+                for (int s = 0; s < 7; ++s) v[t][s] = p[off[s]];
+            }
+        };
+        auto consume = [&](int k, const float (&v)[2][7]) {
+            const int oy = wv + kEncWaves * (k / nx), ox0 = 32 * (k % nx);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < 2; ++t) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int s = 0; s < 7; ++s) acc = mfma4(wf[s], v[t][s], acc);
-                    const int oxm = ox0 + 16 * t + m;
-                    if (oxm < O1) {
-                        float4 y = make_float4(acc[0] + bias.x, acc[1] + bias.y, acc[2] + bias.z, acc[3] + bias.w);
-                        A::st4(y1 + vox1(b, oz, oy, oxm, O1) * kC + 4 * kq, y);
-                        s_sum[0] += y.x; s_sq[0] += y.x * y.x;
-                        s_sum[1] += y.y; s_sq[1] += y.y * y.y;
-                        s_sum[2] += y.z; s_sq[2] += y.z * y.z;
-                        s_sum[3] += y.w; s_sq[3] += y.w * y.w;
-                    }
+                for (int s = 0; s < 7; ++s) acc = mfma4(wf[s], v[t][s], acc);
+                const int oxm = ox0 + 16 * t + m;
+                if (oxm < O1) {
+                    float4 y = make_float4(acc[0] + bias.x, acc[1] + bias.y, acc[2] + bias.z, acc[3] + bias.w);
+                    A::st4(y1 + vox1(b, oz, oy, oxm, O1) * kC + 4 * kq, y);
+                    s_sum[0] += y.x; s_sq[0] += y.x * y.x;
+                    s_sum[1] += y.y; s_sq[1] += y.y * y.y;
+                    s_sum[2] += y.z; s_sq[2] += y.z * y.z;
+                    s_sum[3] += y.w; s_sq[3] += y.w * y.w;
                 }
             }
+        };
+        float va[2][7], vb[2][7];
+        if (ntrip > 0) request(0, va);
+        for (int k = 0; k < ntrip; k += 2) {
+            if (k + 1 < ntrip) request(k + 1, vb);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(k, va);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 >= ntrip) break;
+            if (k + 2 < ntrip) request(k + 2, va);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(k + 1, vb);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     write_partials_cl(partials, blockIdx.x * kEncWaves + wv, s_sum, s_sq);
@@ -245,7 +261,7 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
     fill_lds_image(w2s, W2img);
     int b, oz0, oz1;
     const bool live = sample_plane_group(B, O2, kPlanesPerGroup, b, oz0, oz1);
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform -> SALU index math
     const int m = lane & 15, kq = lane >> 4;
     if (!live) { write_partials(partials, blockIdx.x * kBigWaves + wv, 0.f, 0.f); return; }
     float sc[4], sh[4];
@@ -485,7 +501,7 @@ __device__ __forceinline__ void wave_row_range(int nrows, int &r0, int &r1)
 {
     const int nblk = gridDim.x, per_xcd = (nblk + 7) / 8;
     const int chunk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);  // position of this block in row order
-    const int wave = chunk * kEncWaves + (threadIdx.x / kWave), nwaves = per_xcd * 8 * kEncWaves;
+    const int wave = chunk * kEncWaves + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), nwaves = per_xcd * 8 * kEncWaves;
     const int per = (nrows + nwaves - 1) / nwaves;
     r0 = min(nrows, wave * per);
     r1 = min(nrows, r0 + per);
@@ -501,7 +517,7 @@ __global__ __launch_bounds__(kEncThreads) void k_conv2_wgrad(
     const typename A::T *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1,
     const float *__restrict__ dy2 /*[B,O2,O2,O2,16]*/, int B, int O1, int O2, float *__restrict__ partial)
 {
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform -> SALU index math
     const int n = lane & 15, kq = lane >> 4;
     const int wave_global = blockIdx.x * kEncWaves + wv, nwaves = gridDim.x * kEncWaves;
     const float sc = scale1[n], sh = shift1[n];
@@ -635,7 +651,7 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad(
     const int NA = (O1 + 1) >> 1;  // plane pairs / row pairs / voxels per x-parity
     int b, a0, a1;
     const bool live = sample_plane_group(B, NA, kPlanesPerGroup, b, a0, a1);
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform -> SALU index math
     const int m = lane & 15, kq = lane >> 4;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     if (!live) { write_partials_cl(partials, blockIdx.x * kBigWaves + wv, s1, s2); return; }
@@ -703,7 +719,7 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_wgrad(
     const float *__restrict__ rstd1, const double *__restrict__ S /*[2][16]*/, double count, int B, int G, int O1,
     float *__restrict__ partial /*[nwaves][2*256 + 16]*/)
 {
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform -> SALU index math
     const int n = lane & 15, kq = lane >> 4;
     const int wave_global = blockIdx.x * kEncWaves + wv, nwaves = gridDim.x * kEncWaves;
     const float sc = scale1[n], mu = mean1[n], rs = rstd1[n];
@@ -767,15 +783,19 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_wgrad(
 // backward applied on the way in) and the 9 input rows of its receptive field; the MFMA operands
 // are then 4-byte LDS reads.  7 wide loads per row instead of 32 narrow ones.  Each wave owns a
 // private LDS region (no workgroup barrier: rows per wave differ at the tail).
-template <typename A>
-__global__ __launch_bounds__(kEncThreads) void k_conv1_wgrad_lds(
+template <typename A, int NR, int NI>
+__global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_conv1_wgrad_lds(
     const float *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, const typename A::T *__restrict__ dz1p,
     const typename A::T *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ mean1,
     const float *__restrict__ rstd1, const double *__restrict__ S /*[2][16]*/, double count, int B, int G, int O1,
     float *__restrict__ partial /*[nwaves][2*256 + 16]*/)
 {
+    // NR / NI = 16-byte requests per lane that cover one y1 row (rowlen floats) / the 9 input rows
+    // (9 G floats).  All 2 NR + NI requests of row r+1 are issued (clamped addresses, unconditional)
+    // before the MFMA phase of row r and land in LDS after it: one exposed latency per wave, not one
+    // per request as in the first version of this kernel (2 + 1 + 1 + 1 dependent round trips a row).
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform -> SALU index math
     const int n = lane & 15, kq = lane >> 4;
     const int wave_global = blockIdx.x * kEncWaves + wv;
     const int XH = (O1 + 1) >> 1, rowlen = 2 * XH * kC;  // floats of one (b, z, y) row of y1 / dz1'
@@ -802,31 +822,53 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_wgrad_lds(
     const int nrows = B * O1 * O1;
     int row0, row1;
     wave_row_range(nrows, row0, row1);
-    for (int row = row0; row < row1; ++row) {
+    float4 rg[NR], ry[NR], ri[NI];
+    auto request = [&](int row, float4 (&rg)[NR], float4 (&ry)[NR], float4 (&ri)[NI]) {
         const int b = row / (O1 * O1), rem = row - b * O1 * O1, oz = rem / O1, oy = rem - oz * O1;
         const uint32_t rb = vox1(b, oz, oy, 0, O1) * kC;
-        // ---- stage dy1 = BN1-backward(dz1', y1) of the row ----
-        for (int i = lane * 4; i < rowlen; i += kWave * 4) {
-            const float4 g = A::ld4(dz1p + rb + i), y = A::ld4(y1 + rb + i);
-            const int v = i >> 4, plane = v >= XH ? 1 : 0, x = 2 * (v - plane * XH) + plane;
-            float4 d;
-            d.x = sc4[0] * (g.x - m14[0] - ((y.x - mu4[0]) * rs4[0]) * m24[0]);
-            d.y = sc4[1] * (g.y - m14[1] - ((y.y - mu4[1]) * rs4[1]) * m24[1]);
-            d.z = sc4[2] * (g.z - m14[2] - ((y.z - mu4[2]) * rs4[2]) * m24[2]);
-            d.w = sc4[3] * (g.w - m14[3] - ((y.w - mu4[3]) * rs4[3]) * m24[3]);
-            if (x >= O1) d = make_float4(0.f, 0.f, 0.f, 0.f);  // padding slot of the odd plane
-            bs[0] += d.x; bs[1] += d.y; bs[2] += d.z; bs[3] += d.w;
-            *reinterpret_cast<float4 *>(s_dy + i) = d;
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int i = min(lane * 4 + u * kWave * 4, rowlen - 4);
+            rg[u] = A::ld4(dz1p + rb + i);
+            ry[u] = A::ld4(y1 + rb + i);
         }
-        // ---- stage the 9 input rows (2oz+dz, 2oy+dy, :) ----
         const float *in = obs_base + (rows ? rows[b] : (int64_t)b) * row_stride;
-        for (int i = lane * 4; i < 9 * G; i += kWave * 4) {
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = min(lane * 4 + u * kWave * 4, 9 * G - 4);
             const int dz = i / (3 * G), r = i - dz * 3 * G;  // rows dy = 0..2 of one dz are contiguous
-            *reinterpret_cast<float4 *>(s_in + i) =
-                *reinterpret_cast<const float4 *>(in + ((size_t)(2 * oz + dz) * G + 2 * oy) * G + r);
+            ri[u] = ActF32::ld4(in + ((size_t)(2 * oz + dz) * G + 2 * oy) * G + r);
+        }
+    };
+    if (row0 < row1) request(row0, rg, ry, ri);
+    for (int row = row0; row < row1; ++row) {
+        // ---- stage dy1 = BN1-backward(dz1', y1) of the row and its 9 input rows ----
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int i = lane * 4 + u * kWave * 4;
+            if (i < rowlen) {
+                const float4 g = rg[u], y = ry[u];
+                const int v = i >> 4, plane = v >= XH ? 1 : 0, x = 2 * (v - plane * XH) + plane;
+                float4 d;
+                d.x = sc4[0] * (g.x - m14[0] - ((y.x - mu4[0]) * rs4[0]) * m24[0]);
+                d.y = sc4[1] * (g.y - m14[1] - ((y.y - mu4[1]) * rs4[1]) * m24[1]);
+                d.z = sc4[2] * (g.z - m14[2] - ((y.z - mu4[2]) * rs4[2]) * m24[2]);
+                d.w = sc4[3] * (g.w - m14[3] - ((y.w - mu4[3]) * rs4[3]) * m24[3]);
+                if (x >= O1) d = make_float4(0.f, 0.f, 0.f, 0.f);  // padding slot of the odd plane
+                bs[0] += d.x; bs[1] += d.y; bs[2] += d.z; bs[3] += d.w;
+                *reinterpret_cast<float4 *>(s_dy + i) = d;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = lane * 4 + u * kWave * 4;
+            if (i < 9 * G) *reinterpret_cast<float4 *>(s_in + i) = ri[u];
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
         __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (row + 1 < row1) request(row + 1, rg, ry, ri);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- MFMA: i = tap, j = co, k = 4 consecutive output positions ----
         for (int x0 = 0; x0 < O1; x0 += 4) {
             const int pos = x0 + kq;
@@ -1044,13 +1086,22 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     int wg1_blocks = (nrows1 + kEncWaves - 1) / kEncWaves;
     wg1_blocks = wg1_blocks > 2048 ? 2048 : ((wg1_blocks + 7) & ~7);  // VGPR-light: 32 waves per CU hide the load latency
     const size_t c1w_lds = (size_t)kEncWaves * (2 * ((O1 + 1) / 2) * kC + 9 * grid) * sizeof(float);
-    const bool c1w_staged = (grid % 4 == 0) && (row_stride % 4 == 0) && (((uintptr_t)obs_grid & 15) == 0) && c1w_lds <= 64 * 1024;
+    const int c1w_nr = (2 * ((O1 + 1) / 2) * kC + 255) / 256, c1w_ni = (9 * grid + 255) / 256;  // 16-byte requests per lane and row
+    const bool c1w_staged = (grid % 4 == 0) && (row_stride % 4 == 0) && (((uintptr_t)obs_grid & 15) == 0) && c1w_lds <= 64 * 1024 &&
+                            c1w_nr <= 4 && c1w_ni <= 5;
     if (p->act_bf16) {
         hipLaunchKernelGGL(k_conv1_wgrad<ActBF16>, dim3(wg1_blocks), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, (const uint16_t *)dz1_scratch, (const uint16_t *)y1, bn1,
                        bn1 + 2 * kC, bn1 + 3 * kC, S1, (double)batch * O1 * O1 * O1, batch, grid, O1, w.wg_part);
     } else if (c1w_staged) {
-        hipLaunchKernelGGL(k_conv1_wgrad_lds<ActF32>, dim3(wg1_blocks), dim3(kEncThreads), c1w_lds, st, obs_grid, rows, row_stride, (const float *)dz1_scratch, (const float *)y1, bn1,
-                       bn1 + 2 * kC, bn1 + 3 * kC, S1, (double)batch * O1 * O1 * O1, batch, grid, O1, w.wg_part);
+#define GNBV_C1W(NR, NI)                                                                                                          \
+    hipLaunchKernelGGL((k_conv1_wgrad_lds<ActF32, NR, NI>), dim3(wg1_blocks), dim3(kEncThreads), c1w_lds, st, obs_grid, rows,      \
+                       row_stride, (const float *)dz1_scratch, (const float *)y1, bn1, bn1 + 2 * kC, bn1 + 3 * kC, S1,            \
+                       (double)batch * O1 * O1 * O1, batch, grid, O1, w.wg_part)
+        if (c1w_nr <= 1 && c1w_ni <= 1) GNBV_C1W(1, 1);
+        else if (c1w_nr <= 1 && c1w_ni <= 2) GNBV_C1W(1, 2);
+        else if (c1w_nr <= 2 && c1w_ni <= 3) GNBV_C1W(2, 3);  // G = 64
+        else GNBV_C1W(4, 5);
+#undef GNBV_C1W
     } else {
         hipLaunchKernelGGL(k_conv1_wgrad<ActF32>, dim3(wg1_blocks), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, (const float *)dz1_scratch, (const float *)y1, bn1,
                        bn1 + 2 * kC, bn1 + 3 * kC, S1, (double)batch * O1 * O1 * O1, batch, grid, O1, w.wg_part);

@@ -5,7 +5,7 @@
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int CHAINS, bool LDSB>
+template <int CHAINS, bool LDSB, int NVALU = 0>
 __global__ __launch_bounds__(1024) void k(float *out, int iters)
 {
     __shared__ float w[27 * 256];
@@ -21,6 +21,9 @@ __global__ __launch_bounds__(1024) void k(float *out, int iters)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const float bb = LDSB ? w[t * 256 + s * 64 + lane] : b;
+                // NVALU independent-of-the-chain VALU ops feeding the A operand (the BN + ReLU of conv2)
+#pragma unroll
+                for (int u = 0; u < NVALU; ++u) a = fmaxf(fmaf(a, 0.999f, b), 0.25f);
 #pragma unroll
                 for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, acc[c], 0, 0, 0);
             }
@@ -31,16 +34,16 @@ __global__ __launch_bounds__(1024) void k(float *out, int iters)
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
-template <int CHAINS, bool LDSB>
+template <int CHAINS, bool LDSB, int NVALU = 0>
 void run(int threads, int blocks_per_cu, float *out)
 {
     const int iters = 64, blocks = 256 * blocks_per_cu;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    k<CHAINS, LDSB><<<blocks, threads>>>(out, 2);
+    k<CHAINS, LDSB, NVALU><<<blocks, threads>>>(out, 2);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    k<CHAINS, LDSB><<<blocks, threads>>>(out, iters);
+    k<CHAINS, LDSB, NVALU><<<blocks, threads>>>(out, iters);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -48,7 +51,7 @@ void run(int threads, int blocks_per_cu, float *out)
     const double tf = nmfma * 2048.0 / (ms * 1e-3) / 1e12;
     // cycles per MFMA per SIMD at 2.4 GHz: 1024 SIMDs
     const double cyc = (ms * 1e-3) * 2.4e9 / (nmfma / 1024.0);
-    printf("chains %d ldsB %d threads %4d blocks/CU %d: %.3f ms  %.1f TFLOP/s  %.1f cycles/MFMA/SIMD @2.4GHz\n", CHAINS, (int)LDSB, threads,
+    printf("valu-pairs %d chains %d ldsB %d threads %4d blocks/CU %d: %.3f ms  %.1f TFLOP/s  %.1f cycles/MFMA/SIMD @2.4GHz\n", NVALU, CHAINS, (int)LDSB, threads,
            blocks_per_cu, ms, tf, cyc);
 }
 
@@ -67,5 +70,11 @@ int main()
     run<1, true>(1024, 2, out);
     run<2, true>(1024, 1, out);
     run<4, true>(1024, 1, out);
+    run<1, true, 1>(256, 1, out);
+    run<1, true, 1>(1024, 1, out);
+    run<1, true, 1>(1024, 2, out);
+    run<1, true, 2>(1024, 1, out);
+    run<1, true, 4>(1024, 1, out);
+    run<2, true, 1>(1024, 1, out);
     return 0;
 }
