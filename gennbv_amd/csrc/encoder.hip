@@ -195,15 +195,16 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd(
                 }
             }
         };
+        // (requests unconditional: see k_conv2_fwd)
         float va[2][7], vb[2][7];
         if (ntrip > 0) request(0, va);
         for (int k = 0; k < ntrip; k += 2) {
-            if (k + 1 < ntrip) request(k + 1, vb);
+            request(min(k + 1, ntrip - 1), vb);
             __builtin_amdgcn_sched_barrier(0);
             consume(k, va);
             __builtin_amdgcn_sched_barrier(0);
             if (k + 1 >= ntrip) break;
-            if (k + 2 < ntrip) request(k + 2, va);
+            request(min(k + 2, ntrip - 1), va);
             __builtin_amdgcn_sched_barrier(0);
             consume(k + 1, vb);
             __builtin_amdgcn_sched_barrier(0);
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
     const int P2 = O2 * O2 * O2;
     float s_sum = 0.0f, s_sq = 0.0f;
     const int ntile_x = (O2 + 15) / 16, nwork = (oz1 - oz0) * O2 * ntile_x;
-    const uint32_t XHC = ((uint32_t)(O1 + 1) >> 1) * kC, rowC = 2 * XHC, planeC = rowC * O1;
+    const uint32_t XHC = ((uint32_t)(O1 + 1) >> 1) * kC, rowC = 2 * XHC;
     // Register double buffer over dz slabs (9 taps = 9 KiB per wave each): the requests of slab s+1
     // (possibly the first slab of the wave's next tile) are issued BEFORE the 36 MFMAs of slab s.
     // Left to itself the compiler sinks every load next to its use (load, s_waitcnt vmcnt(0),
@@ -317,6 +318,8 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
             }
         }
     };
+    // Requests are unconditional (past the last tile they re-read it): a branch around a request group
+    // makes the s_waitcnt insertion assume the worst case at the join, i.e. wait for the prefetch too.
     float4 va[9], vb[9];
     if (wv < nwork) request(wv, 0, va);
     for (int wk = wv; wk < nwork; wk += 2 * kBigWaves) {
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
         __builtin_amdgcn_sched_barrier(0);
         consume(1, vb, acc);
         __builtin_amdgcn_sched_barrier(0);
-        if (wk2 < nwork) request(wk2, 0, vb);
+        request(min(wk2, nwork - 1), 0, vb);
         __builtin_amdgcn_sched_barrier(0);
         consume(2, va, acc);
         finish(wk, acc);
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
         __builtin_amdgcn_sched_barrier(0);
         consume(1, va, acc);
         __builtin_amdgcn_sched_barrier(0);
-        if (wk3 < nwork) request(wk3, 0, va);
+        request(min(wk3, nwork - 1), 0, va);
         __builtin_amdgcn_sched_barrier(0);
         consume(2, vb, acc);
         finish(wk2, acc);

@@ -125,6 +125,43 @@ def grid_encoder(base: torch.Tensor, rows: Optional[torch.Tensor], grid_off: int
                                 seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias)
 
 
+class _LinearReluFn(torch.autograd.Function):
+    """relu(x @ w.T + b) on the split-K MFMA kernel (csrc/linear.hip); backward = three library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        lib = _lib.load()
+        _lib.require_cuda(x, w, b)
+        x = x.contiguous()
+        m, k = x.shape
+        n = w.shape[0]
+        out = torch.empty(m, n, dtype=torch.float32, device=x.device)
+        key = ("lin", m, n, k, str(x.device))
+        ws = _ws_cache.get(key)
+        if ws is None:
+            ws = torch.empty(lib.gnbv_linear_workspace_bytes(m, n, k), dtype=torch.uint8, device=x.device)
+            _ws_cache[key] = ws
+        _lib.check(lib.gnbv_linear_forward(x.data_ptr(), w.data_ptr(), b.data_ptr(), m, n, k, 1, out.data_ptr(), ws.data_ptr(),
+                                           ws.numel(), _lib.stream_ptr(x.device)), "gnbv_linear_forward")
+        ctx.save_for_backward(x, w, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, w, out = ctx.saved_tensors
+        g = d_out * (out > 0).to(d_out.dtype)
+        dx = g @ w if ctx.needs_input_grad[0] else None
+        return dx, g.t() @ x, g.sum(0)
+
+
+def linear_relu(x: torch.Tensor, lin: torch.nn.Linear) -> torch.Tensor:
+    """Linear + ReLU of the K-dominated fc layer (hybrid_encoder.py:39-42 of the reference)."""
+    n, k = lin.weight.shape
+    if k % 4 or n % 64 or not lin.weight.is_contiguous() or x.dtype != torch.float32:
+        return torch.relu(torch.nn.functional.linear(x, lin.weight, lin.bias))
+    return _LinearReluFn.apply(x, lin.weight, lin.bias)
+
+
 def hybrid_forward(enc, observations) -> torch.Tensor:
     """Hybrid_Encoder.forward with the grid branch on the gfx950 kernels."""
     s = enc.state_input_shape[0]
@@ -159,7 +196,7 @@ def hybrid_forward(enc, observations) -> torch.Tensor:
         enc._grid_feats_out = feature_grid
         feature_grid = feature_grid.detach().requires_grad_(True)
         enc._grid_feats_leaf = feature_grid
-    feature_grid = enc.output_layer_grid(feature_grid)
+    feature_grid = linear_relu(feature_grid, enc.output_layer_grid[0])  # Linear + ReLU, split-K MFMA kernel
     if side is not None:
         torch.cuda.current_stream(base.device).wait_stream(side)
         feature_action.record_stream(torch.cuda.current_stream(base.device))

@@ -223,6 +223,15 @@ int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *rows, int64
                                const GnbvEncoderGrads *grads /*[host]*/, void *workspace, size_t workspace_bytes,
                                void *stream);
 
+/* B1  Hybrid_Encoder.output_layer_grid = Linear(16*o2^3, 256) + ReLU
+ *     (gennbv/network/hybrid_encoder.py:39-42, applied at :87).  out[m][n] = act(bias[n] + sum_k x[m][k] w[n][k]),
+ *     x [M][K], w [N][K] (torch.nn.Linear.weight layout), K % 4 == 0, N % 64 == 0, all pointers 16-byte aligned.
+ *     Deterministic split-K on fp32 MFMA (fixed summation order); relu != 0 fuses the ReLU.
+ *     workspace >= gnbv_linear_workspace_bytes(M, N, K). */
+size_t gnbv_linear_workspace_bytes(int M, int N, int K);
+int gnbv_linear_forward(const float *x, const float *w, const float *bias, int M, int N, int K, int relu, float *out,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------- */
 /* C2  TensorRolloutBuffer_Grid_Obs.compute_returns_and_advantage               */
 /*     stable_baselines3/common/buffers.py:706-724.  All arrays [T,N] (the      */

@@ -138,3 +138,28 @@ def test_bf16_activation_storage_within_bf16_tolerance(g, b):
     for x, y in zip(*outs):
         assert float((x - y).abs().max()) <= 2e-3 * float(x.abs().max()) + 1e-4
     # gradients are NOT asserted in this mode: see the docstring (fp32 storage is the supported path)
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 256, 54000), (256, 256, 54000), (7, 64, 1024), (130, 128, 1000), (1, 64, 4)])
+def test_splitk_linear_relu_vs_fp64(m, n, k):
+    """fc_grid (hybrid_encoder.py:39-42): relu(x W^T + b) on the split-K MFMA kernel vs an fp64 reference;
+    tolerance = fp32 accumulation round-off over K terms.  Backward = library GEMMs on the same mask."""
+    from gennbv_amd.ops.encoder_ops import linear_relu
+    gen = torch.Generator().manual_seed(m + n + k)
+    x = (torch.rand(m, k, generator=gen) * (torch.rand(m, k, generator=gen) < 0.5)).to(DEV).requires_grad_(True)
+    lin = torch.nn.Linear(k, n).to(DEV)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(n, k, generator=gen) / k ** 0.5)
+        lin.bias.copy_(torch.randn(n, generator=gen) * 0.1)
+    out = linear_relu(x, lin)
+    ref = torch.relu(x.detach().double() @ lin.weight.detach().double().t() + lin.bias.detach().double())
+    assert out.shape == (m, n)
+    assert torch.allclose(out.double(), ref, rtol=1e-5, atol=2e-6), float((out.double() - ref).abs().max())
+    # deterministic: identical bits on a second call
+    assert torch.equal(out, linear_relu(x, lin))
+    d = torch.randn(m, n, generator=gen).to(DEV)
+    out.backward(d)
+    g = d.double() * (ref > 0)
+    assert torch.allclose(x.grad.double(), g @ lin.weight.detach().double(), rtol=1e-4, atol=1e-6)
+    assert torch.allclose(lin.weight.grad.double(), g.t() @ x.detach().double(), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(lin.bias.grad.double(), g.sum(0), rtol=1e-4, atol=1e-5)
