@@ -98,22 +98,33 @@ __device__ __forceinline__ bool sample_plane(int B, int O, int &b, int &o)
 }
 static inline int sample_plane_grid(int B, int O) { return ((B + 7) / 8) * 8 * O; }
 
-// per-wave BN partials: part[wave_global][0][c] = sum, [1][c] = sum of squares / second sum
-__device__ __forceinline__ void write_partials(float *partials, int wave_global, float s, float q)
+// BN partial sums: one row of 32 floats per WORKGROUP, part[block][0][c] = sum, [1][c] = sum of squares
+// / second sum.  The waves' 32-vectors meet in LDS and are added in wave order (deterministic).
+// Every thread of the workgroup must call (contains a barrier).
+// lanes 0..15 own channel c = lane after the k-group sum
+__device__ __forceinline__ void write_partials(float *partials, int nwaves, int wv, float s, float q)
 {
+    __shared__ float wsum[16][2 * kC];
     s = kgroup_sum(s);
     q = kgroup_sum(q);
     const int lane = threadIdx.x & (kWave - 1);
-    if (partials != nullptr && lane < kC) {
-        partials[(size_t)wave_global * 2 * kC + lane] = s;
-        partials[(size_t)wave_global * 2 * kC + kC + lane] = q;
+    if (lane < kC) {
+        wsum[wv][lane] = s;
+        wsum[wv][kC + lane] = q;
+    }
+    __syncthreads();
+    if (partials != nullptr && threadIdx.x < 2 * kC) {
+        float t = wsum[0][threadIdx.x];
+        for (int w = 1; w < nwaves; ++w) t += wsum[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * 2 * kC + threadIdx.x] = t;
     }
 }
 
 // same, for kernels whose lanes own channels 4*kq .. 4*kq+3 of position (lane & 15):
-// reduce over the 16 positions (lanes with equal kq), lanes with m == 0 write 4 channels each
-__device__ __forceinline__ void write_partials_cl(float *partials, int wave_global, float (&s)[4], float (&q)[4])
+// reduce over the 16 positions (lanes with equal kq), lanes with m == 0 hold 4 channels each
+__device__ __forceinline__ void write_partials_cl(float *partials, int nwaves, int wv, float (&s)[4], float (&q)[4])
 {
+    __shared__ float wsum[16][2 * kC];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -123,13 +134,19 @@ __device__ __forceinline__ void write_partials_cl(float *partials, int wave_glob
         }
     }
     const int lane = threadIdx.x & (kWave - 1);
-    if (partials != nullptr && (lane & 15) == 0) {
+    if ((lane & 15) == 0) {
         const int kq = lane >> 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            partials[(size_t)wave_global * 2 * kC + 4 * kq + r] = s[r];
-            partials[(size_t)wave_global * 2 * kC + kC + 4 * kq + r] = q[r];
+            wsum[wv][4 * kq + r] = s[r];
+            wsum[wv][kC + 4 * kq + r] = q[r];
         }
+    }
+    __syncthreads();
+    if (partials != nullptr && threadIdx.x < 2 * kC) {
+        float t = wsum[0][threadIdx.x];
+        for (int w = 1; w < nwaves; ++w) t += wsum[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * 2 * kC + threadIdx.x] = t;
     }
 }
 
@@ -210,7 +227,7 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd(
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    write_partials_cl(partials, blockIdx.x * kEncWaves + wv, s_sum, s_sq);
+    write_partials_cl(partials, kEncWaves, wv, s_sum, s_sq);
 }
 
 // W2 [co][ci][27] -> the two LDS images the conv2 kernels use, written once per call so that the
@@ -264,7 +281,7 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
     const bool live = sample_plane_group(B, O2, kPlanesPerGroup, b, oz0, oz1);
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform -> SALU index math
     const int m = lane & 15, kq = lane >> 4;
-    if (!live) { write_partials(partials, blockIdx.x * kBigWaves + wv, 0.f, 0.f); return; }
+    if (!live) { write_partials(partials, kBigWaves, wv, 0.f, 0.f); return; }
     float sc[4], sh[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -354,7 +371,7 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
         consume(2, vb, acc);
         finish(wk2, acc);
     }
-    write_partials(partials, blockIdx.x * kBigWaves + wv, s_sum, s_sq);
+    write_partials(partials, kBigWaves, wv, s_sum, s_sq);
 }
 
 // ---------------------------------------------------------------------------
@@ -364,19 +381,17 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
 //   eval : statistics = running stats
 //   out  : scale = gamma*rstd, shift = beta - mean*scale, mean, rstd
 // ---------------------------------------------------------------------------
-__global__ void k_bn_finalize(const double *__restrict__ sums, double count, const float *__restrict__ gamma,
-                              const float *__restrict__ beta, float eps, float momentum, int training,
-                              float *__restrict__ running_mean, float *__restrict__ running_var,
-                              int64_t *__restrict__ num_batches_tracked, const int *__restrict__ skip_flag,
-                              float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out,
-                              float *__restrict__ rstd_out)
+__device__ __forceinline__ void bn_finalize_channel(int c, double sum, double sumsq, double count, const float *__restrict__ gamma,
+                                                    const float *__restrict__ beta, float eps, float momentum, int training,
+                                                    float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                    int64_t *__restrict__ num_batches_tracked, const int *__restrict__ skip_flag,
+                                                    float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out,
+                                                    float *__restrict__ rstd_out)
 {
-    const int c = threadIdx.x;
-    if (c >= kC) return;
     float mean, var;
     if (training) {
-        const double mu = sums[c] / count;
-        double v = sums[kC + c] / count - mu * mu;
+        const double mu = sum / count;
+        double v = sumsq / count - mu * mu;
         v = v < 0.0 ? 0.0 : v;
         mean = (float)mu;
         var = (float)v;
@@ -397,6 +412,57 @@ __global__ void k_bn_finalize(const double *__restrict__ sums, double count, con
     shift[c] = beta[c] - mean * sc;
     mean_out[c] = mean;
     rstd_out[c] = rstd;
+}
+
+// eval mode: statistics = running stats (no reduction)
+__global__ void k_bn_finalize(double count, const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
+                              float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ scale,
+                              float *__restrict__ shift, float *__restrict__ mean_out, float *__restrict__ rstd_out)
+{
+    const int c = threadIdx.x;
+    if (c < kC)
+        bn_finalize_channel(c, 0.0, 0.0, count, gamma, beta, eps, momentum, 0, running_mean, running_var, nullptr, nullptr, scale, shift,
+                            mean_out, rstd_out);
+}
+
+// One workgroup sums the [P][32] per-workgroup partial rows in fp64 and in a fixed order (128 slices of
+// P, then the slices in order), writes the 32 sums (out_d, optional) and, when gamma != nullptr,
+// finalizes the BatchNorm layer in the same launch (train mode).
+__global__ __launch_bounds__(1024) void k_stats_reduce(const float *__restrict__ partial, int P, double *__restrict__ out_d, double count,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                       float momentum, float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                       int64_t *__restrict__ num_batches_tracked, const int *__restrict__ skip_flag,
+                                                       float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out,
+                                                       float *__restrict__ rstd_out)
+{
+    // thread = (slice of P: 128) x (4 consecutive sums: 8); 8 independent 16-byte requests in flight
+    __shared__ double sh[128][2 * kC];
+    __shared__ double tot[2 * kC];
+    const int e4 = (threadIdx.x & 7) * 4, sl = threadIdx.x >> 3;
+    const int per = (P + 127) / 128, p0 = sl * per, p1 = min(P, p0 + per);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int p = p0; p < p1; p += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ActF32::ld4(partial + (size_t)min(p + u, p1 - 1) * 2 * kC + e4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (p + u < p1) {
+                a0 += (double)v[u].x; a1 += (double)v[u].y; a2 += (double)v[u].z; a3 += (double)v[u].w;
+            }
+    }
+    sh[sl][e4] = a0; sh[sl][e4 + 1] = a1; sh[sl][e4 + 2] = a2; sh[sl][e4 + 3] = a3;
+    __syncthreads();
+    if (threadIdx.x < 2 * kC) {
+        double t = 0.0;
+        for (int i = 0; i < 128; ++i) t += sh[i][threadIdx.x];
+        tot[threadIdx.x] = t;
+        if (out_d != nullptr) out_d[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (gamma != nullptr && threadIdx.x < kC)
+        bn_finalize_channel(threadIdx.x, tot[threadIdx.x], tot[kC + threadIdx.x], count, gamma, beta, eps, momentum, 1, running_mean,
+                            running_var, num_batches_tracked, skip_flag, scale, shift, mean_out, rstd_out);
 }
 
 // out[e] = sum_p partial[p][e] in fp64 and in a fixed order (deterministic), two stages:
@@ -510,6 +576,9 @@ __device__ __forceinline__ void wave_row_range(int nrows, int &r0, int &r1)
     r1 = min(nrows, r0 + per);
 }
 
+// Weight-gradient kernels end with a workgroup-level reduction of the per-wave accumulators through
+// LDS: wave 0 stores, waves 1.. add in order (each lane owns the same slots in every wave), then the
+// workgroup copies the sums to ITS row of the partial buffer -- 4x fewer partial rows to write / reduce.
 // ---------------------------------------------------------------------------
 // conv2 weight gradient: dW2[(tap, ci), co] = sum_pos z1[inpos(pos, tap), ci] * dy2[pos, co]
 // MFMA: i = ci, j = co, k = 4 consecutive output positions along x.  27 accumulators / wave.
@@ -568,32 +637,43 @@ __global__ __launch_bounds__(kEncThreads) void k_conv2_wgrad(
             }
         }
     }
-    float *out = partial + (size_t)wave_global * (kTaps * 256 + kC);
-#pragma unroll
-    for (int tap = 0; tap < kTaps; ++tap)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out[tap * 256 + (4 * kq + r) * kC + n] = acc[tap][r];  // [tap][ci][co]
+    // workgroup-level sum (wave order) in LDS, then one partial row per workgroup: [tap][ci][co] + 16 bias sums
+    __shared__ float red[kTaps * 256 + kC];
     bsum = kgroup_sum(bsum);
-    if (lane < kC) out[kTaps * 256 + lane] = bsum;
+    for (int w = 0; w < kEncWaves; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int tap = 0; tap < kTaps; ++tap)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = tap * 256 + (4 * kq + r) * kC + n;
+                    red[o] = (w == 0 ? 0.0f : red[o]) + acc[tap][r];
+                }
+            if (lane < kC) red[kTaps * 256 + lane] = (w == 0 ? 0.0f : red[kTaps * 256 + lane]) + bsum;
+        }
+        __syncthreads();
+    }
+    float *out = partial + (size_t)blockIdx.x * (kTaps * 256 + kC);
+    for (int o = threadIdx.x; o < kTaps * 256 + kC; o += kEncThreads) out[o] = red[o];
+    (void)wave_global;
 }
 
 // partial-sum layout [tap][ci][co] (+16) -> torch layout dW2 [co][ci][27], db2 [16]
-__global__ void k_conv2_wgrad_finish(const double *__restrict__ red, float *__restrict__ dW2, float *__restrict__ db2)
+__global__ void k_conv2_wgrad_finish(const double *__restrict__ tmp /*[slices][E]*/, int slices, float *__restrict__ dW2,
+                                     float *__restrict__ db2)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, E = kTaps * 256 + kC;
+    if (i >= E) return;
+    double t = 0.0;
+    for (int sl = 0; sl < slices; ++sl) t += tmp[(size_t)sl * E + i];
     if (i < kTaps * 256) {
         const int tap = i >> 8, ci = (i >> 4) & 15, co = i & 15;
-        dW2[((size_t)co * kC + ci) * kTaps + tap] = (float)red[i];
-    } else if (i < kTaps * 256 + kC) {
-        db2[i - kTaps * 256] = (float)red[i];
+        dW2[((size_t)co * kC + ci) * kTaps + tap] = (float)t;
+    } else {
+        db2[i - kTaps * 256] = (float)t;
     }
 }
 
-// ---------------------------------------------------------------------------
-// conv2 data gradient (transposed conv, stride 2) + ReLU mask of layer 1 + BN1-backward sums.
-//   dz1'[v, ci] = [pre1 > 0] * sum_{tap, co} dy2[(v - tap)/2, co] * W2[co][ci][tap]
-// Input voxels of one x-parity share their tap set -> tiles of 16 voxels ix = 2j + px.
-// ---------------------------------------------------------------------------
 // The transposed conv as 8 sub-convolutions.  A "super-tile" (a, c, j0) is the 2 x 2 x 32 block of
 // layer-1 voxels iz in {2a, 2a+1}, iy in {2c, 2c+1}, ix = 2j + ex (j = j0 .. j0+15, ex in {0, 1}).
 // Along one axis an even index 2a receives taps d = 0 (from output a) and d = 2 (from a-1), an odd
@@ -657,7 +737,7 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad(
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform -> SALU index math
     const int m = lane & 15, kq = lane >> 4;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    if (!live) { write_partials_cl(partials, blockIdx.x * kBigWaves + wv, s1, s2); return; }
+    if (!live) { write_partials_cl(partials, kBigWaves, wv, s1, s2); return; }
     // MFMA roles: A[i = ci][k = co] = W2, B[k = co][j = input voxel] = dy2 -> D[i = ci = 4*kq+r][j = voxel m]:
     // a lane owns 4 consecutive channels of one voxel (16-byte load of y1, 16-byte store of dz1')
     const float4 sc = *reinterpret_cast<const float4 *>(scale1 + 4 * kq), sh = *reinterpret_cast<const float4 *>(shift1 + 4 * kq);
@@ -707,7 +787,7 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad(
         dgrad_subtile<A, 1, 1, 0>(L, Y[6], w2d, dz1p, idx[6], okV[6], sc, sh, mu, rs, s1, s2);
         dgrad_subtile<A, 1, 1, 1>(L, Y[7], w2d, dz1p, idx[7], okV[7], sc, sh, mu, rs, s1, s2);
     }
-    write_partials_cl(partials, blockIdx.x * kBigWaves + wv, s1, s2);
+    write_partials_cl(partials, kBigWaves, wv, s1, s2);
 }
 
 // ---------------------------------------------------------------------------
@@ -769,14 +849,23 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_wgrad(
             }
         }
     }
-    float *out = partial + (size_t)wave_global * (2 * 256 + kC);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        out[(4 * kq + r) * kC + n] = acc0[r];          // [tap 0..15][co]
-        out[256 + (4 * kq + r) * kC + n] = acc1[r];    // [tap 16..31][co]
-    }
+    __shared__ float red[2 * 256 + kC];
     bsum = kgroup_sum(bsum);
-    if (lane < kC) out[512 + lane] = bsum;
+    for (int w = 0; w < kEncWaves; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o0 = (4 * kq + r) * kC + n, o1 = 256 + o0;   // [tap 0..15][co], [tap 16..31][co]
+                red[o0] = (w == 0 ? 0.0f : red[o0]) + acc0[r];
+                red[o1] = (w == 0 ? 0.0f : red[o1]) + acc1[r];
+            }
+            if (lane < kC) red[512 + lane] = (w == 0 ? 0.0f : red[512 + lane]) + bsum;
+        }
+        __syncthreads();
+    }
+    float *out = partial + (size_t)blockIdx.x * (2 * 256 + kC);
+    for (int o = threadIdx.x; o < 2 * 256 + kC; o += kEncThreads) out[o] = red[o];
+    (void)wave_global;
 }
 
 // LDS-staged variant (used when G % 4 == 0).  The direct kernel issues four 4-byte-per-lane loads per
@@ -885,31 +974,46 @@ __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(4, 
         }
         __builtin_amdgcn_wave_barrier();  // next row overwrites the staging area
     }
-    float *out = partial + (size_t)wave_global * (2 * 256 + kC);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        out[(4 * kq + r) * kC + n] = acc0[r];          // [tap 0..15][co]
-        out[256 + (4 * kq + r) * kC + n] = acc1[r];    // [tap 16..31][co]
-    }
     // bias sums: lanes with equal (lane & 3) hold the same channel group
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int d = 4; d < kWave; d <<= 1) bs[k] += __shfl_xor(bs[k], d, kWave);
-    if (lane < 4) {
+    // workgroup-level sum (wave order) in the staging LDS, one partial row per workgroup
+    __syncthreads();  // every wave is done with its staging area
+    float *red = lds;
+    for (int w = 0; w < kEncWaves; ++w) {
+        if (wv == w) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) out[512 + 4 * lane + k] = bs[k];
+            for (int r = 0; r < 4; ++r) {
+                const int o0 = (4 * kq + r) * kC + n, o1 = 256 + o0;   // [tap 0..15][co], [tap 16..31][co]
+                red[o0] = (w == 0 ? 0.0f : red[o0]) + acc0[r];
+                red[o1] = (w == 0 ? 0.0f : red[o1]) + acc1[r];
+            }
+            if (lane < 4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) red[512 + 4 * lane + k] = (w == 0 ? 0.0f : red[512 + 4 * lane + k]) + bs[k];
+            }
+        }
+        __syncthreads();
     }
+    float *out = partial + (size_t)blockIdx.x * (2 * 256 + kC);
+    for (int o = threadIdx.x; o < 2 * 256 + kC; o += kEncThreads) out[o] = red[o];
+    (void)wave_global;
 }
 
-__global__ void k_conv1_wgrad_finish(const double *__restrict__ red, float *__restrict__ dW1, float *__restrict__ db1)
+__global__ void k_conv1_wgrad_finish(const double *__restrict__ tmp /*[slices][E]*/, int slices, float *__restrict__ dW1,
+                                     float *__restrict__ db1)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, E = 512 + kC;
+    if (i >= E) return;
+    double t = 0.0;
+    for (int sl = 0; sl < slices; ++sl) t += tmp[(size_t)sl * E + i];
     if (i < 512) {
         const int tap = i >> 4, co = i & 15;
-        if (tap < kTaps) dW1[co * kTaps + tap] = (float)red[i];
-    } else if (i < 512 + kC) {
-        db1[i - 512] = (float)red[i];
+        if (tap < kTaps) dW1[co * kTaps + tap] = (float)t;
+    } else {
+        db1[i - 512] = (float)t;
     }
 }
 
@@ -964,17 +1068,16 @@ static inline EncWs enc_carve(void *ws, int batch, int grid)
 
 constexpr int kReduceSlices = 64;
 
-// tmp: kReduceTmpDoubles fp64 of scratch
-static inline int reduce_launch(const float *partial, int P, int E, double *out_d, double *tmp, hipStream_t st)
+// stage 1 of the deterministic fp64 reduction: partial [P][E] -> tmp [slices][E]; the consumer (a
+// *_finish kernel) adds the <= 64 slices in order.  Returns the number of slices.
+static inline int reduce_stage1(const float *partial, int P, int E, double *tmp, hipStream_t st)
 {
-    int slices = P / 16;
+    int slices = P / 8;
     slices = slices < 1 ? 1 : (slices > kReduceSlices ? kReduceSlices : slices);
     const int per = (P + slices - 1) / slices;
     hipLaunchKernelGGL(k_reduce_partials<float>, dim3((E + 63) / 64, slices), dim3(256), 0, st, partial, P, E, per, tmp,
                        (float *)nullptr);
-    hipLaunchKernelGGL(k_reduce_partials<double>, dim3((E + 63) / 64, 1), dim3(256), 0, st, (const double *)tmp, slices, E,
-                       slices, out_d, (float *)nullptr);
-    return gnbv_launch_status();
+    return slices;
 }
 
 GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *rows, int64_t row_stride, int batch, int grid,
@@ -1002,9 +1105,13 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
                        p->b1, (float *)y1, training ? w.bn_part : nullptr);
     }
     if ((err = gnbv_launch_status())) return err;
-    if (training && (err = reduce_launch(w.bn_part, sample_plane_grid(batch, O1) * kEncWaves, 2 * kC, w.red, w.tmp, st))) return err;
-    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, w.red, (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps,
-                       p->momentum, training, p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC);
+    if (training)
+        hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, st, w.bn_part, sample_plane_grid(batch, O1), (double *)nullptr,
+                           (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps, p->momentum, p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag,
+                           bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC);
+    else
+        hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps, p->momentum,
+                           p->bn1_rm, p->bn1_rv, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC);
     if ((err = gnbv_launch_status())) return err;
     // conv2 (BN1 + ReLU on load; + BN2 statistics)
     hipLaunchKernelGGL(k_prep_w2, dim3(kTaps), dim3(256), 0, st, p->w2, w.w2img, w.w2img + kTaps * 256);
@@ -1017,9 +1124,12 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
                        training ? w.bn_part : nullptr);
     }
     if ((err = gnbv_launch_status())) return err;
-    if (training && (err = reduce_launch(w.bn_part, g2 * kBigWaves, 2 * kC, w.red + 64, w.tmp, st))) return err;
-    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, w.red + 64, (double)batch * P2, p->bn2_w, p->bn2_b, p->eps,
-                       p->momentum, training, p->bn2_rm, p->bn2_rv, p->bn2_nbt, skip_flag, bn2, bn2 + kC, bn2 + 2 * kC, bn2 + 3 * kC);
+    if (training)
+        hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, st, w.bn_part, g2, (double *)nullptr, (double)batch * P2, p->bn2_w, p->bn2_b,
+                           p->eps, p->momentum, p->bn2_rm, p->bn2_rv, p->bn2_nbt, skip_flag, bn2, bn2 + kC, bn2 + 2 * kC, bn2 + 3 * kC);
+    else
+        hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, (double)batch * P2, p->bn2_w, p->bn2_b, p->eps, p->momentum, p->bn2_rm,
+                           p->bn2_rv, bn2, bn2 + kC, bn2 + 2 * kC, bn2 + 3 * kC);
     if ((err = gnbv_launch_status())) return err;
     // BN2 + ReLU -> flat features [B, 16*P2] (C-major, the reference's .reshape(num_env, -1))
     const int64_t total = (int64_t)batch * kC * P2;
@@ -1068,8 +1178,9 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     }
     if ((err = gnbv_launch_status())) return err;
     const int E2 = kTaps * 256 + kC;
-    if ((err = reduce_launch(w.wg_part, wg_blocks * kEncWaves, E2, w.red + 256, w.tmp, st))) return err;
-    hipLaunchKernelGGL(k_conv2_wgrad_finish, dim3((E2 + 255) / 256), dim3(256), 0, st, w.red + 256, g->w2, g->b2);
+    const int sl2 = reduce_stage1(w.wg_part, wg_blocks, E2, w.tmp, st);
+    if ((err = gnbv_launch_status())) return err;
+    hipLaunchKernelGGL(k_conv2_wgrad_finish, dim3((E2 + 255) / 256), dim3(256), 0, st, (const double *)w.tmp, sl2, g->w2, g->b2);
     if ((err = gnbv_launch_status())) return err;
     // ---- conv2 data gradient (+ ReLU1 mask, BN1 backward sums) ----
     hipLaunchKernelGGL(k_prep_w2, dim3(kTaps), dim3(256), 0, st, p->w2, w.w2img, w.w2img + kTaps * 256);
@@ -1083,7 +1194,10 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     }
     if ((err = gnbv_launch_status())) return err;
     double *S1 = w.red + 192;
-    if ((err = reduce_launch(w.bn_part, gd * kBigWaves, 2 * kC, S1, w.tmp, st))) return err;
+    hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, st, w.bn_part, gd, S1, 0.0, (const float *)nullptr, (const float *)nullptr, 0.0f,
+                       0.0f, (float *)nullptr, (float *)nullptr, (int64_t *)nullptr, (const int *)nullptr, (float *)nullptr, (float *)nullptr,
+                       (float *)nullptr, (float *)nullptr);
+    if ((err = gnbv_launch_status())) return err;
     // ---- conv1 weight gradient (BN1 backward fused) ----
     int nrows1 = batch * O1 * O1;
     int wg1_blocks = (nrows1 + kEncWaves - 1) / kEncWaves;
@@ -1111,8 +1225,9 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     }
     if ((err = gnbv_launch_status())) return err;
     const int E1 = 512 + kC;
-    if ((err = reduce_launch(w.wg_part, wg1_blocks * kEncWaves, E1, w.red + 256, w.tmp, st))) return err;
-    hipLaunchKernelGGL(k_conv1_wgrad_finish, dim3((E1 + 255) / 256), dim3(256), 0, st, w.red + 256, g->w1, g->b1);
+    const int sl1 = reduce_stage1(w.wg_part, wg1_blocks, E1, w.tmp, st);
+    if ((err = gnbv_launch_status())) return err;
+    hipLaunchKernelGGL(k_conv1_wgrad_finish, dim3((E1 + 255) / 256), dim3(256), 0, st, (const double *)w.tmp, sl1, g->w1, g->b1);
     if ((err = gnbv_launch_status())) return err;
     // ---- BN affine gradients: d beta = S[0], d gamma = S[1] ----
     hipLaunchKernelGGL(k_bn_grads, dim3(1), dim3(64), 0, st, S1, S2, g->bn1_w, g->bn1_b, g->bn2_w, g->bn2_b);
