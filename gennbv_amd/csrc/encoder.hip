@@ -665,6 +665,7 @@ __global__ void k_conv2_wgrad_finish(const double *__restrict__ tmp /*[slices][E
     const int i = blockIdx.x * blockDim.x + threadIdx.x, E = kTaps * 256 + kC;
     if (i >= E) return;
     double t = 0.0;
+#pragma unroll 8
     for (int sl = 0; sl < slices; ++sl) t += tmp[(size_t)sl * E + i];
     if (i < kTaps * 256) {
         const int tap = i >> 8, ci = (i >> 4) & 15, co = i & 15;
@@ -1008,6 +1009,7 @@ __global__ void k_conv1_wgrad_finish(const double *__restrict__ tmp /*[slices][E
     const int i = blockIdx.x * blockDim.x + threadIdx.x, E = 512 + kC;
     if (i >= E) return;
     double t = 0.0;
+#pragma unroll 8
     for (int sl = 0; sl < slices; ++sl) t += tmp[(size_t)sl * E + i];
     if (i < 512) {
         const int tap = i >> 4, co = i & 15;
@@ -1066,7 +1068,7 @@ static inline EncWs enc_carve(void *ws, int batch, int grid)
     return w;
 }
 
-constexpr int kReduceSlices = 64;
+constexpr int kReduceSlices = 16;
 
 // stage 1 of the deterministic fp64 reduction: partial [P][E] -> tmp [slices][E]; the consumer (a
 // *_finish kernel) adds the <= 64 slices in order.  Returns the number of slices.

@@ -178,7 +178,13 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_dlogits(GnbvPpoLoss a, con
 __global__ __launch_bounds__(256) void k_grad_sqnorm(const float *__restrict__ g, int64_t n, double *__restrict__ partial)
 {
     double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    // 16-byte requests over the aligned body, scalar tail; fixed grid -> fixed summation order
+    const int64_t n4 = (((uintptr_t)g & 15) == 0) ? n / 4 : 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4 *>(g)[i];
+        acc += (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const double v = (double)g[i];
         acc += v * v;
     }
@@ -193,7 +199,8 @@ __global__ __launch_bounds__(256) void k_grad_sqnorm(const float *__restrict__ g
 }
 
 // clip coefficient = min(1, max_norm / (total_norm + 1e-6))  (torch.nn.utils.clip_grad_norm_)
-__global__ __launch_bounds__(256) void k_grad_norm_finalize(const double *__restrict__ partial, int nparts, float max_norm, float grad_scale, float *__restrict__ out /*[2]: norm, coef*/)
+__global__ __launch_bounds__(256) void k_grad_norm_finalize(const double *__restrict__ partial, int nparts, float max_norm, float grad_scale, float *__restrict__ out /*[2]: norm, coef*/,
+                                                            int64_t *step, int *stop_flag, const float *kl_slot, float target_kl)
 {
     __shared__ double sh[256];
     double acc = 0.0;
@@ -211,6 +218,13 @@ __global__ __launch_bounds__(256) void k_grad_norm_finalize(const double *__rest
     coef = coef > 1.0f ? 1.0f : coef;
     out[0] = norm;
     out[1] = coef * grad_scale;  // factor applied to the raw (summed) gradient
+    // (same launch) data-parallel KL decision + optimizer step counter: kl_slot holds the SUM of the ranks'
+    // approx-KL (it rode in front of the gradient in the all-reduce); sets the sticky stop flag before
+    // this step's update
+    if (step != nullptr) {
+        if (stop_flag != nullptr && kl_slot != nullptr && target_kl > 0.f && (*kl_slot) * grad_scale > 1.5f * target_kl) *stop_flag = 1;
+        if (!(stop_flag != nullptr && *stop_flag != 0)) *step += 1;
+    }
 }
 
 __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
@@ -233,15 +247,6 @@ __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, 
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         p[i] = p[i] - step_size * (mi / denom);
     }
-}
-
-// data-parallel: kl_slot holds the SUM of the ranks' approx-KL (it rode behind the gradient in the
-// all-reduce); kl_scale = 1/world.  Sets the sticky stop flag before this step's update.
-__global__ void k_step_increment(int64_t *step, int *stop_flag, const float *kl_slot, float kl_scale, float target_kl)
-{
-    if (stop_flag != nullptr && kl_slot != nullptr && target_kl > 0.f && (*kl_slot) * kl_scale > 1.5f * target_kl) *stop_flag = 1;
-    if (stop_flag != nullptr && *stop_flag != 0) return;
-    *step += 1;
 }
 
 // ===========================================================================
@@ -289,8 +294,8 @@ GNBV_API int gnbv_clip_adam_step(float *params, const float *grads, float *exp_a
     int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
     blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
     hipLaunchKernelGGL(k_grad_sqnorm, dim3(blocks), dim3(256), 0, st, grads, n, partial);
-    hipLaunchKernelGGL(k_grad_norm_finalize, dim3(1), dim3(256), 0, st, partial, blocks, max_grad_norm, grad_scale, norm_out);
-    hipLaunchKernelGGL(k_step_increment, dim3(1), dim3(1), 0, st, step, stop_flag, kl_slot, grad_scale, target_kl);
+    hipLaunchKernelGGL(k_grad_norm_finalize, dim3(1), dim3(256), 0, st, partial, blocks, max_grad_norm, grad_scale, norm_out, step, stop_flag,
+                       kl_slot, target_kl);
     int ab = (int)((n + 255) / 256);
     ab = ab > 4096 ? 4096 : ab;
     hipLaunchKernelGGL(k_adam_flat, dim3(ab), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, (const float *)norm_out,

@@ -67,7 +67,7 @@ def _params_struct(seq, act_bf16: bool = False) -> _lib.GnbvEncoderParams:
 
 class _GridEncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, base, rows, grid_off, grid, training, skip_flag, seq, act_bf16, w1, b1, g1, be1, w2, b2, g2, be2):
+    def forward(ctx, base, rows, grid_off, grid, training, skip_flag, seq, act_bf16, write_through, w1, b1, g1, be1, w2, b2, g2, be2):
         lib = _lib.load()
         _lib.require_cuda(base, w1)
         for t in (w1, b1, g1, be1, w2, b2, g2, be2):
@@ -91,6 +91,7 @@ class _GridEncoderFn(torch.autograd.Function):
             _lib.stream_ptr(dev)), "gnbv_encoder_grid_forward")
         ctx.save_for_backward(base, rows, y1, y2, bn_state, w1, w2)
         ctx.meta = (grid_off, grid, batch, seq, act_bf16)
+        ctx.write_through = write_through
         return feats
 
     @staticmethod
@@ -104,8 +105,10 @@ class _GridEncoderFn(torch.autograd.Function):
         d_feats = d_feats.contiguous().float()
         dy2 = torch.empty(batch * o2 ** 3 * 16, dtype=torch.float32, device=dev)
         dz1 = torch.empty(lib.gnbv_encoder_y1_elems(batch, grid), dtype=torch.bfloat16 if act_bf16 else torch.float32, device=dev)
-        grads = [torch.empty_like(t) for t in (seq[0].weight, seq[0].bias, seq[1].weight, seq[1].bias,
-                                               seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias)]
+        ps = (seq[0].weight, seq[0].bias, seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias)
+        # write-through (ops/direct_grad.py): the kernels store into the parameters' .grad slices
+        direct = bool(ctx.write_through) and all(t.grad is not None and t.grad.is_contiguous() for t in ps)
+        grads = [t.grad if direct else torch.empty_like(t) for t in ps]
         gs = _lib.GnbvEncoderGrads()
         for name, t in zip(("w1", "b1", "bn1_w", "bn1_b", "w2", "b2", "bn2_w", "bn2_b"), grads):
             setattr(gs, name, t.data_ptr())
@@ -115,13 +118,15 @@ class _GridEncoderFn(torch.autograd.Function):
             base.data_ptr() + 4 * grid_off, _lib.ptr(rows), base.stride(0), batch, grid, C.byref(params), y1.data_ptr(),
             y2.data_ptr(), bn_state.data_ptr(), d_feats.data_ptr(), dy2.data_ptr(), dz1.data_ptr(), C.byref(gs),
             ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "gnbv_encoder_grid_backward")
-        return (None, None, None, None, None, None, None, None, *grads)
+        if direct:
+            return (None,) * 17
+        return (None, None, None, None, None, None, None, None, None, *grads)
 
 
 def grid_encoder(base: torch.Tensor, rows: Optional[torch.Tensor], grid_off: int, grid: int, seq, training: bool,
-                 skip_flag: Optional[torch.Tensor] = None, act_bf16: bool = False) -> torch.Tensor:
+                 skip_flag: Optional[torch.Tensor] = None, act_bf16: bool = False, write_through: bool = False) -> torch.Tensor:
     """seq = the `naive_encoder_grid` nn.Sequential (conv, bn, relu, conv, bn, relu)."""
-    return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, bool(act_bf16), seq[0].weight, seq[0].bias,
+    return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, bool(act_bf16), bool(write_through), seq[0].weight, seq[0].bias,
                                 seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias)
 
 
@@ -129,7 +134,8 @@ class _LinearReluFn(torch.autograd.Function):
     """relu(x @ w.T + b) on the split-K MFMA kernel (csrc/linear.hip); backward = three library GEMMs."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, mod=None):
+        ctx.mod = mod  # write-through target (ops/direct_grad.py) or None
         lib = _lib.load()
         _lib.require_cuda(x, w, b)
         x = x.contiguous()
@@ -149,9 +155,14 @@ class _LinearReluFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out):
         x, w, out = ctx.saved_tensors
-        g = d_out * (out > 0).to(d_out.dtype)
+        g = torch.ops.aten.threshold_backward(d_out.contiguous(), out, 0.0)
         dx = g @ w if ctx.needs_input_grad[0] else None
-        return dx, g.t() @ x, g.sum(0)
+        mod = ctx.mod
+        if mod is not None and mod.weight.grad is not None and mod.bias.grad is not None:
+            torch.mm(g.t(), x, out=mod.weight.grad)
+            torch.sum(g, 0, out=mod.bias.grad)
+            return dx, None, None, None
+        return dx, g.t() @ x, g.sum(0), None
 
 
 def linear_relu(x: torch.Tensor, lin: torch.nn.Linear) -> torch.Tensor:
@@ -159,7 +170,7 @@ def linear_relu(x: torch.Tensor, lin: torch.nn.Linear) -> torch.Tensor:
     n, k = lin.weight.shape
     if k % 4 or n % 64 or not lin.weight.is_contiguous() or x.dtype != torch.float32:
         return torch.relu(torch.nn.functional.linear(x, lin.weight, lin.bias))
-    return _LinearReluFn.apply(x, lin.weight, lin.bias)
+    return _LinearReluFn.apply(x, lin.weight, lin.bias, lin if getattr(lin, "_grad_write_through", False) else None)
 
 
 def hybrid_forward(enc, observations) -> torch.Tensor:
@@ -189,7 +200,7 @@ def hybrid_forward(enc, observations) -> torch.Tensor:
         action_input = enc.positional_encoding(state.view(num_env, -1, 6)).view(num_env, -1)
         feature_action = enc.naive_encoder_action(action_input)
     feature_grid = grid_encoder(base, rows, s, g, enc.naive_encoder_grid, enc.training, getattr(enc, "_bn_skip_flag", None),
-                                enc.compute_dtype == torch.bfloat16)
+                                enc.compute_dtype == torch.bfloat16, getattr(enc, "_grad_write_through", False))
     if getattr(enc, "_split_backward", False) and torch.is_grad_enabled():
         # data-parallel: cut the autograd graph at the conv-stack output so that the backward runs in
         # two phases (late layers first, their gradient all-reduce overlaps the conv-stack backward)

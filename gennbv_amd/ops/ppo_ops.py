@@ -17,6 +17,8 @@ class FlatAdam:
     one kernel pair (norm, update) replaces torch's ~60 per-tensor launches
     (stable_baselines3/ppo/ppo_grid_obs.py:271-275; Adam eps 1e-5, policies.py:851-855)."""
 
+    SLOT = 64
+
     def __init__(self, module: torch.nn.Module, lr: float, betas=(0.9, 0.999), eps: float = 1e-5):
         self.lib = _lib.load()
         ps = [p for p in module.parameters() if p.requires_grad]
@@ -27,9 +29,11 @@ class FlatAdam:
         self.params = torch.empty(n, dtype=torch.float32, device=dev)
         # one extra slot IN FRONT of the gradient: the rank's approx-KL rides in the same all-reduce as
         # the (small) conv-stack gradients, which come first in parameter order
-        self.grads_with_slot = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        # (SLOT floats = 256 bytes, so that the gradient itself stays 256-byte aligned: a 4-byte shift
+        # sent every element-wise kernel on the gradients down the unaligned, unvectorised path)
+        self.grads_with_slot = torch.zeros(n + self.SLOT, dtype=torch.float32, device=dev)
         self.kl_slot = self.grads_with_slot[:1]
-        self.grads = self.grads_with_slot[1:]
+        self.grads = self.grads_with_slot[self.SLOT:]
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)

@@ -30,6 +30,8 @@ from __future__ import annotations
 import time
 from typing import Any, Dict, Optional, Union
 
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -85,6 +87,7 @@ class PPO_Grid_Obs:
         self.kl_poll = "minibatch"
         self.train_impl = "hip"   # fused loss / flat Adam / device-side early stop when the encoder backend is "hip"
         self.use_graph = True     # replay the minibatch step as one hipGraph
+        self.grad_write_through = os.environ.get("GENNBV_WRITE_THROUGH", "1") != "0"  # backward kernels store into the flat gradient buffer (ops/direct_grad.py)
         self._hip = None
         self._sync = None         # gennbv_amd.parallel.GradSync when data-parallel
         if _init_setup_model:
@@ -225,6 +228,8 @@ class PPO_Grid_Obs:
             # the GLOBAL mean after the all-reduce (gnbv_clip_adam_step), not by the loss kernel
             loss.args.kl_out = opt.kl_slot.data_ptr()
         self.policy.features_extractor._bn_skip_flag = loss.stop_flag
+        from ..ops import direct_grad
+        direct_grad.enable(self.policy, self.grad_write_through)
         return self._hip
 
     def _hip_minibatch_body(self, st, phase: str = "all"):
@@ -270,9 +275,9 @@ class PPO_Grid_Obs:
         opt = st["opt"]
         n_conv = st["n_conv"]
         self._hip_minibatch_body(st, "A")
-        work = dist.all_reduce(opt.grads_with_slot[1 + n_conv:], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
+        work = dist.all_reduce(opt.grads_with_slot[opt.SLOT + n_conv:], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
         self._hip_minibatch_body(st, "B")
-        dist.all_reduce(opt.grads_with_slot[:1 + n_conv], op=dist.ReduceOp.SUM, group=self._sync.group)
+        dist.all_reduce(opt.grads_with_slot[:opt.SLOT + n_conv], op=dist.ReduceOp.SUM, group=self._sync.group)
         work.wait()
         self._hip_minibatch_tail(st)
 
@@ -287,9 +292,9 @@ class PPO_Grid_Obs:
         # fallback when the collectives could not be captured: two graphs, eager collectives + tail
         opt, n_conv = st["opt"], st["n_conv"]
         g[0].replay()
-        work = dist.all_reduce(opt.grads_with_slot[1 + n_conv:], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
+        work = dist.all_reduce(opt.grads_with_slot[opt.SLOT + n_conv:], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
         g[1].replay()
-        dist.all_reduce(opt.grads_with_slot[:1 + n_conv], op=dist.ReduceOp.SUM, group=self._sync.group)
+        dist.all_reduce(opt.grads_with_slot[:opt.SLOT + n_conv], op=dist.ReduceOp.SUM, group=self._sync.group)
         work.wait()
         self._hip_minibatch_tail(st)
 
