@@ -585,7 +585,7 @@ __device__ __forceinline__ void wave_row_range(int nrows, int &r0, int &r1)
 // partial[w][tap][ci][co] (+ 16 bias sums), reduced by k_reduce_partials.
 // ---------------------------------------------------------------------------
 template <typename A>
-__global__ __launch_bounds__(kEncThreads) void k_conv2_wgrad(
+__global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv2_wgrad(
     const typename A::T *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1,
     const float *__restrict__ dy2 /*[B,O2,O2,O2,16]*/, int B, int O1, int O2, float *__restrict__ partial)
 {
@@ -601,41 +601,44 @@ __global__ __launch_bounds__(kEncThreads) void k_conv2_wgrad(
     int row0, row1;
     wave_row_range(nrows, row0, row1);
     (void)nwaves;
-    for (int row = row0; row < row1; ++row) {
+    // Work items = (row, group of 4 output positions along x), flattened over the wave's rows.  Register
+    // ping-pong: the 28 operand requests of item i+1 (possibly the first group of the NEXT row) are in
+    // flight while the 27 MFMAs of item i run; requests are unconditional (clamped), no copies.
+    const int ng = (O2 + 3) / 4, nitems = (row1 - row0) * ng;
+    auto request = [&](int it, float &bv, float (&av)[kTaps]) {
+        const int row = row0 + it / ng, x0 = 4 * (it % ng);
         const int b = row / (O2 * O2), rem = row - b * O2 * O2, oz = rem / O2, oy = rem - oz * O2;
-        // software pipeline over the x-groups of the row: the 28 operand loads of group g+1 are in
-        // flight while the 27 MFMAs of group g run
-        const size_t drow = (((size_t)b * O2 + oz) * O2 + oy) * O2;
-        auto load_group = [&](int x0, float &bv, float (&av)[kTaps]) {
-            const int x = x0 + kq;
-            const bool ok = x < O2;
-            const int xc = ok ? x : O2 - 1;
-            const float t = dy2[(drow + xc) * kC + n];
-            bv = ok ? t : 0.0f;
+        const int xc = min(x0 + kq, O2 - 1);
+        bv = dy2[((((size_t)b * O2 + oz) * O2 + oy) * O2 + xc) * kC + n];
+        const uint32_t base = vox1(b, 2 * oz, 2 * oy, 2 * xc, O1) * kC + n;  // even-parity voxel xc
+        const uint32_t XHC = ((uint32_t)(O1 + 1) >> 1) * kC, rowC = 2 * XHC, planeC = rowC * O1;
 #pragma unroll
-            for (int tap = 0; tap < kTaps; ++tap) {
-                const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-                av[tap] = A::ld1(y1 + vox1(b, 2 * oz + dz, 2 * oy + dy, 2 * xc + dx, O1) * kC + n);
-            }
-        };
-        float bcur, acur[kTaps];
-        load_group(0, bcur, acur);
-        for (int x0 = 0; x0 < O2; x0 += 4) {
-            float bnxt = 0.0f, anxt[kTaps];
-            const bool more = x0 + 4 < O2;
-            if (more) load_group(x0 + 4, bnxt, anxt);
-            bsum += bcur;
-#pragma unroll
-            for (int tap = 0; tap < kTaps; ++tap) {
-                const float a = fmaxf(fmaf(sc, acur[tap], sh), 0.0f);
-                acc[tap] = mfma4(a, bcur, acc[tap]);  // rows with bv == 0 contribute nothing
-            }
-            if (more) {
-                bcur = bnxt;
-#pragma unroll
-                for (int tap = 0; tap < kTaps; ++tap) acur[tap] = anxt[tap];
-            }
+        for (int tap = 0; tap < kTaps; ++tap) {
+            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+            av[tap] = A::ld1(y1 + base + (dz * planeC + dy * rowC + (dx == 1 ? XHC : 0) + (dx == 2 ? kC : 0)));
         }
+    };
+    auto consume = [&](int it, float bv, const float (&av)[kTaps]) {
+        const bool ok = 4 * (it % ng) + kq < O2 && it < nitems;  // (odd item count: one padded, all-zero item)
+        const float bb = ok ? bv : 0.0f;  // positions past the row end contribute nothing
+        bsum += bb;
+#pragma unroll
+        for (int tap = 0; tap < kTaps; ++tap) {
+            const float a = fmaxf(fmaf(sc, av[tap], sh), 0.0f);
+            acc[tap] = mfma4(a, bb, acc[tap]);
+        }
+    };
+    float b0, a0[kTaps], b1, a1[kTaps];
+    if (nitems > 0) request(0, b0, a0);
+    for (int it = 0; it < nitems; it += 2) {
+        request(min(it + 1, nitems - 1), b1, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(it, b0, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        request(min(it + 2, nitems - 1), b0, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(it + 1, b1, a1);
+        __builtin_amdgcn_sched_barrier(0);
     }
     // workgroup-level sum (wave order) in LDS, then one partial row per workgroup: [tap][ci][co] + 16 bias sums
     __shared__ float red[kTaps * 256 + kC];

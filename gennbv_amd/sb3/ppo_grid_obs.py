@@ -230,6 +230,15 @@ class PPO_Grid_Obs:
         self.policy.features_extractor._bn_skip_flag = loss.stop_flag
         from ..ops import direct_grad
         direct_grad.enable(self.policy, self.grad_write_through)
+        # with write-through every gradient slice is overwritten each step: no zero-fill needed when the
+        # linears + the conv stack cover ALL trainable parameters
+        covered = set()
+        for m in self.policy.modules():
+            if isinstance(m, torch.nn.Linear) and m.bias is not None:
+                covered.update((id(m.weight), id(m.bias)))
+        covered.update(id(p) for p in self.policy.features_extractor.naive_encoder_grid.parameters())
+        self._hip["skip_zero"] = bool(self.grad_write_through) and all(
+            id(p) in covered for p in self.policy.parameters() if p.requires_grad)
         return self._hip
 
     def _hip_minibatch_body(self, st, phase: str = "all"):
@@ -250,7 +259,8 @@ class PPO_Grid_Obs:
             logits = pol.action_net(features)
             values = pol.value_net(features).flatten()
             d_logits, d_values = loss(logits, values)
-            opt.zero_grad()
+            if not st.get("skip_zero"):
+                opt.zero_grad()
             if phase == "all":
                 torch.autograd.backward([logits, values], [d_logits, d_values])
                 if self._sync is None or not self._sync.active:
