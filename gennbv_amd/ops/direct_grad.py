@@ -38,9 +38,11 @@ class _LinearWT(torch.autograd.Function):
 
 
 def _forward(self, x):
-    if (torch.is_grad_enabled() and getattr(self, "_grad_write_through", False) and x.dim() == 2 and self.bias is not None
+    if (torch.is_grad_enabled() and getattr(self, "_grad_write_through", False) and self.bias is not None
             and self.weight.grad is not None and self.bias.grad is not None and self.weight.requires_grad):
-        return _LinearWT.apply(x, self.weight, self.bias, self)
+        if x.dim() == 2:
+            return _LinearWT.apply(x, self.weight, self.bias, self)
+        return _LinearWT.apply(x.reshape(-1, x.shape[-1]), self.weight, self.bias, self).view(*x.shape[:-1], self.weight.shape[0])
     return torch.nn.functional.linear(x, self.weight, self.bias)
 
 

@@ -175,6 +175,13 @@ def linear_relu(x: torch.Tensor, lin: torch.nn.Linear) -> torch.Tensor:
 
 def hybrid_forward(enc, observations) -> torch.Tensor:
     """Hybrid_Encoder.forward with the grid branch on the gfx950 kernels."""
+    feature_action, feature_grid = hybrid_branches(enc, observations)
+    return enc.output_layer(torch.cat((feature_action, feature_grid), dim=-1))
+
+
+def hybrid_branches(enc, observations):
+    """(pose-history features, grid features), each [B, 256]: Hybrid_Encoder.forward up to the concat
+    (hybrid_encoder.py:76-88 of the reference)."""
     s = enc.state_input_shape[0]
     g = enc.grid_size
     if isinstance(observations, RowGather):
@@ -211,7 +218,75 @@ def hybrid_forward(enc, observations) -> torch.Tensor:
     if side is not None:
         torch.cuda.current_stream(base.device).wait_stream(side)
         feature_action.record_stream(torch.cuda.current_stream(base.device))
-    return enc.output_layer(torch.cat((feature_action, feature_grid), dim=-1))
+    return feature_action, feature_grid
+
+
+class _PolicyHeadFn(torch.autograd.Function):
+    """output_layer (Linear + ReLU over the implicit concat) + action_net + value_net, fused
+    (csrc/head.hip): 2 launches forward, 2 backward."""
+
+    @staticmethod
+    def forward(ctx, fa, fg, w_out, b_out, w_act, b_act, w_val, b_val, mods):
+        lib = _lib.load()
+        _lib.require_cuda(fa, fg, w_out)
+        fa, fg = fa.contiguous(), fg.contiguous()
+        m, k1 = fa.shape
+        k2, f, a = fg.shape[1], w_out.shape[0], w_act.shape[0]
+        dev = fa.device
+        feat = torch.empty(m, f, dtype=torch.float32, device=dev)
+        logits = torch.empty(m, a, dtype=torch.float32, device=dev)
+        values = torch.empty(m, dtype=torch.float32, device=dev)
+        _lib.check(lib.gnbv_policy_head_forward(fa.data_ptr(), fg.data_ptr(), m, k1, k2, w_out.data_ptr(), b_out.data_ptr(), f,
+                                                w_act.data_ptr(), b_act.data_ptr(), a, w_val.data_ptr(), b_val.data_ptr(),
+                                                feat.data_ptr(), logits.data_ptr(), values.data_ptr(), _lib.stream_ptr(dev)),
+                   "gnbv_policy_head_forward")
+        ctx.save_for_backward(fa, fg, feat, w_out, w_act, w_val)
+        ctx.mods = mods
+        ctx.mark_non_differentiable(feat)
+        return logits, values, feat
+
+    @staticmethod
+    def backward(ctx, d_logits, d_values, _d_feat):
+        lib = _lib.load()
+        fa, fg, feat, w_out, w_act, w_val = ctx.saved_tensors
+        m, k1 = fa.shape
+        k2, f, a = fg.shape[1], w_out.shape[0], w_act.shape[0]
+        dev = fa.device
+        d_logits, d_values = d_logits.contiguous(), d_values.contiguous()
+        d_fa, d_fg = torch.empty_like(fa), torch.empty_like(fg)
+        dh = torch.empty(m, f, dtype=torch.float32, device=dev)
+        ps = None
+        if ctx.mods is not None:  # write-through (ops/direct_grad.py)
+            lo, la, lv = ctx.mods
+            ps = [lo.weight.grad, lo.bias.grad, la.weight.grad, la.bias.grad, lv.weight.grad, lv.bias.grad]
+            if any(g is None or not g.is_contiguous() for g in ps):
+                ps = None
+        direct = ps is not None
+        if not direct:
+            ps = [torch.empty_like(w_out), torch.empty(f, device=dev), torch.empty_like(w_act), torch.empty(a, device=dev),
+                  torch.empty_like(w_val), torch.empty(1, device=dev)]
+        _lib.check(lib.gnbv_policy_head_backward(fa.data_ptr(), fg.data_ptr(), m, k1, k2, feat.data_ptr(), d_logits.data_ptr(),
+                                                 d_values.data_ptr(), w_out.data_ptr(), f, w_act.data_ptr(), a, w_val.data_ptr(),
+                                                 dh.data_ptr(), d_fa.data_ptr(), d_fg.data_ptr(), *[t.data_ptr() for t in ps],
+                                                 _lib.stream_ptr(dev)), "gnbv_policy_head_backward")
+        if direct:
+            return d_fa, d_fg, None, None, None, None, None, None, None
+        return (d_fa, d_fg, *ps, None)
+
+
+def policy_head_supported(enc, action_net, value_net) -> bool:
+    lo = enc.output_layer[0]
+    return (isinstance(action_net, torch.nn.Linear) and isinstance(value_net, torch.nn.Linear) and value_net.out_features == 1
+            and lo.in_features % 32 == 0 and lo.out_features % 16 == 0 and action_net.in_features == lo.out_features
+            and value_net.in_features == lo.out_features and lo.weight.dtype == torch.float32)
+
+
+def policy_head(enc, action_net, value_net, feature_action, feature_grid):
+    """(logits [B, A], values [B], features [B, F]) from the two encoder branches."""
+    lo = enc.output_layer[0]
+    wt = all(getattr(m, "_grad_write_through", False) for m in (lo, action_net, value_net))
+    return _PolicyHeadFn.apply(feature_action, feature_grid, lo.weight, lo.bias, action_net.weight, action_net.bias, value_net.weight,
+                               value_net.bias, (lo, action_net, value_net) if wt else None)
 
 
 _side_streams = {}

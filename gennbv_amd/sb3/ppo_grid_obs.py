@@ -237,6 +237,12 @@ class PPO_Grid_Obs:
             if isinstance(m, torch.nn.Linear) and m.bias is not None:
                 covered.update((id(m.weight), id(m.bias)))
         covered.update(id(p) for p in self.policy.features_extractor.naive_encoder_grid.parameters())
+        from ..ops import encoder_ops
+        from .policies import _IdentityExtractor
+        enc = self.policy.features_extractor
+        self._hip["fused_head"] = (os.environ.get("GENNBV_FUSED_HEAD", "1") != "0" and getattr(enc, "backend", "") == "hip"
+                                   and isinstance(self.policy.mlp_extractor, _IdentityExtractor)
+                                   and encoder_ops.policy_head_supported(enc, self.policy.action_net, self.policy.value_net))
         self._hip["skip_zero"] = bool(self.grad_write_through) and all(
             id(p) in covered for p in self.policy.parameters() if p.requires_grad)
         return self._hip
@@ -249,15 +255,21 @@ class PPO_Grid_Obs:
           phase "A": everything up to the gradients of all parameters EXCEPT the conv stack, plus
                      d loss / d (conv-stack output);
           phase "B": conv-stack backward (encoder.hip kernels) from that gradient."""
+        from ..ops import encoder_ops
         from ..ops.encoder_ops import RowGather
         buf, pol, loss, opt = self.rollout_buffer, self.policy, st["loss"], st["opt"]
         if phase in ("all", "A"):
             t, n = buf.buffer_size, buf.n_envs
             loss.gather(buf)
             obs = RowGather(buf.observations[:t].view(t * n, -1), loss.rows)
-            features = pol.extract_features(obs)
-            logits = pol.action_net(features)
-            values = pol.value_net(features).flatten()
+            enc = pol.features_extractor
+            if st.get("fused_head"):
+                fa, fg = encoder_ops.hybrid_branches(enc, obs)
+                logits, values, _ = encoder_ops.policy_head(enc, pol.action_net, pol.value_net, fa, fg)
+            else:
+                features = pol.extract_features(obs)
+                logits = pol.action_net(features)
+                values = pol.value_net(features).flatten()
             d_logits, d_values = loss(logits, values)
             if not st.get("skip_zero"):
                 opt.zero_grad()

@@ -232,6 +232,23 @@ size_t gnbv_linear_workspace_bytes(int M, int N, int K);
 int gnbv_linear_forward(const float *x, const float *w, const float *bias, int M, int N, int K, int relu, float *out,
                         void *workspace, size_t workspace_bytes, void *stream);
 
+/* B1/B2  policy head, fused:  feat = relu([fa | fg] W_out^T + b_out)   Hybrid_Encoder.output_layer
+ *                                                     (gennbv/network/hybrid_encoder.py:51-54, :89)
+ *        logits = feat W_act^T + b_act, values = feat W_val^T + b_val      ActorCriticPolicy.action_net / value_net
+ *                                                     (stable_baselines3/common/policies.py:975-979, :1011, :1024)
+ *        fa [M][K1], fg [M][K2] (the two encoder branches, concatenated implicitly), W_out [F][K1+K2],
+ *        W_act [A][F], W_val [1][F]; F, K1, K2 multiples of 16; torch.nn.Linear layouts.
+ *        forward: feat [M][F] (kept for the backward), logits [M][A], values [M].
+ *        backward: from d_logits [M][A], d_values [M]: d_fa, d_fg and the six parameter gradients
+ *        (plain stores: pass the .grad slices for write-through).  dH_scratch: M*F floats. */
+int gnbv_policy_head_forward(const float *fa, const float *fg, int M, int K1, int K2, const float *W_out, const float *b_out, int F,
+                             const float *W_act, const float *b_act, int A, const float *W_val, const float *b_val, float *feat,
+                             float *logits, float *values, void *stream);
+int gnbv_policy_head_backward(const float *fa, const float *fg, int M, int K1, int K2, const float *feat, const float *d_logits,
+                              const float *d_values, const float *W_out, int F, const float *W_act, int A, const float *W_val,
+                              float *dH_scratch, float *d_fa, float *d_fg, float *gW_out, float *gb_out, float *gW_act,
+                              float *gb_act, float *gW_val, float *gb_val, void *stream);
+
 /* ------------------------------------------------------------------------- */
 /* C2  TensorRolloutBuffer_Grid_Obs.compute_returns_and_advantage               */
 /*     stable_baselines3/common/buffers.py:706-724.  All arrays [T,N] (the      */

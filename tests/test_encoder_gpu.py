@@ -163,3 +163,38 @@ def test_splitk_linear_relu_vs_fp64(m, n, k):
     assert torch.allclose(x.grad.double(), g @ lin.weight.detach().double(), rtol=1e-4, atol=1e-6)
     assert torch.allclose(lin.weight.grad.double(), g.t() @ x.detach().double(), rtol=1e-4, atol=1e-5)
     assert torch.allclose(lin.bias.grad.double(), g.sum(0), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("m,a", [(128, 241), (37, 241), (256, 17), (5, 3)])
+def test_fused_policy_head_vs_fp64(m, a):
+    """output_layer + action_net + value_net (hybrid_encoder.py:51-54,:89; sb3 policies.py:975-979) fused in
+    csrc/head.hip, forward and backward, against fp64 torch; tolerance = fp32 round-off of K <= 512 sums."""
+    from gennbv_amd.ops import encoder_ops as eo
+    gen = torch.Generator().manual_seed(m * 1000 + a)
+    k1 = k2 = f = 256
+
+    def rnd(*s, scale=1.0):
+        return (torch.randn(*s, generator=gen) * scale).to(DEV)
+
+    fa, fg = rnd(m, k1).abs().requires_grad_(True), rnd(m, k2).abs().requires_grad_(True)
+    lo, la, lv = torch.nn.Linear(k1 + k2, f).to(DEV), torch.nn.Linear(f, a).to(DEV), torch.nn.Linear(f, 1).to(DEV)
+
+    class Enc:
+        output_layer = torch.nn.Sequential(lo, torch.nn.ReLU())
+
+    logits, values, feat = eo.policy_head(Enc, la, lv, fa, fg)
+    cat = torch.cat((fa, fg), -1).detach().double().requires_grad_(True)
+    wd = [t.detach().double().requires_grad_(True) for t in (lo.weight, lo.bias, la.weight, la.bias, lv.weight, lv.bias)]
+    feat_ref = torch.relu(cat @ wd[0].t() + wd[1])
+    logits_ref, values_ref = feat_ref @ wd[2].t() + wd[3], (feat_ref @ wd[4].t() + wd[5]).flatten()
+    assert torch.allclose(feat.double(), feat_ref, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(logits.double(), logits_ref, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(values.double(), values_ref, rtol=1e-5, atol=1e-5)
+    dl, dv = rnd(m, a), rnd(m)
+    torch.autograd.backward([logits, values], [dl, dv])
+    torch.autograd.backward([logits_ref, values_ref], [dl.double(), dv.double()])
+    got = [fa.grad, fg.grad, lo.weight.grad, lo.bias.grad, la.weight.grad, la.bias.grad, lv.weight.grad, lv.bias.grad]
+    ref = [cat.grad[:, :k1], cat.grad[:, k1:]] + [t.grad for t in wd]
+    for g, r in zip(got, ref):
+        assert g.shape == r.shape
+        assert torch.allclose(g.double(), r, rtol=1e-4, atol=1e-4 * float(r.abs().max()) + 1e-7), float((g.double() - r).abs().max())
