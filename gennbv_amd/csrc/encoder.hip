@@ -230,6 +230,80 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd(
     write_partials_cl(partials, kEncWaves, wv, s_sum, s_sq);
 }
 
+// LDS-staged conv1 forward (used when G % 4 == 0 and the slab fits): the workgroup's input slab -- the
+// first 2*O1+1 rows of planes 2oz, 2oz+1, 2oz+2, each a contiguous run of the observation row -- is
+// fetched ONCE with full-width 16-byte requests (the direct kernel gathers it with 4-byte stride-2
+// requests, every input dword 3.4 times), the MFMA operands are then 4-byte LDS reads.
+template <typename A>
+__global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
+    const float *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, int B, int G, int O1,
+    const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ b1, typename A::T *__restrict__ y1,
+    float *__restrict__ partials)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_in[];  // [3][NR][G]
+    int b, oz;
+    const bool live = sample_plane(B, O1, b, oz);
+    const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int m = lane & 15, kq = lane >> 4;
+    const int NR = 2 * O1 + 1, plane4 = NR * G / 4, total4 = 3 * plane4;
+    float s_sum[4] = {0.f, 0.f, 0.f, 0.f}, s_sq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const float *in = obs_base + (rows ? rows[b] : (int64_t)b) * row_stride + (size_t)(2 * oz) * G * G;
+        // ---- stage the slab: 4 requests per thread in flight ----
+        for (int base = 0; base < total4; base += 4 * kEncThreads) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = min(base + u * kEncThreads + (int)threadIdx.x, total4 - 1);
+                const int p = idx / plane4, r = idx - p * plane4;
+                v[u] = ActF32::ld4(in + (size_t)p * G * G + 4 * r);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * kEncThreads + (int)threadIdx.x;
+                if (idx < total4) reinterpret_cast<float4 *>(s_in)[idx] = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    if (live) {
+        // MFMA roles as in k_conv1_fwd: A[i = co][k = tap] = W1, B[k = tap][j = position] = input voxel
+        float wf[7];
+        int off[7];
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            const int t = 4 * s + kq;
+            const bool ok = t < kTaps;
+            wf[s] = ok ? W1[m * kTaps + t] : 0.0f;
+            const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+            off[s] = ok ? (dz * NR + dy) * G + dx : 0;
+        }
+        const float4 bias = *reinterpret_cast<const float4 *>(b1 + 4 * kq);
+        for (int oy = wv; oy < O1; oy += kEncWaves) {
+            for (int ox0 = 0; ox0 < O1; ox0 += 16) {
+                const int ox = min(ox0 + m, O1 - 1);
+                const float *p = s_in + 2 * oy * G + 2 * ox;
+                float v[7];
+#pragma unroll
+                for (int s = 0; s < 7; ++s) v[s] = p[off[s]];
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 7; ++s) acc = mfma4(wf[s], v[s], acc);
+                const int oxm = ox0 + m;
+                if (oxm < O1) {
+                    float4 y = make_float4(acc[0] + bias.x, acc[1] + bias.y, acc[2] + bias.z, acc[3] + bias.w);
+                    A::st4(y1 + vox1(b, oz, oy, oxm, O1) * kC + 4 * kq, y);
+                    s_sum[0] += y.x; s_sq[0] += y.x * y.x;
+                    s_sum[1] += y.y; s_sq[1] += y.y * y.y;
+                    s_sum[2] += y.z; s_sq[2] += y.z * y.z;
+                    s_sum[3] += y.w; s_sq[3] += y.w * y.w;
+                }
+            }
+        }
+    }
+    write_partials_cl(partials, kEncWaves, wv, s_sum, s_sq);
+}
+
 // W2 [co][ci][27] -> the two LDS images the conv2 kernels use, written once per call so that the
 // workgroups fill their LDS with coalesced 16-byte loads instead of 6912 scattered 4-byte reads:
 //   fwd  image [(tap*4+s)*4+kq][n] = W2[co = n][ci = 4kq+s][tap]
@@ -1006,10 +1080,18 @@ __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(4, 
     (void)wave_global;
 }
 
+// (+ the BN affine gradients: d beta = S[0], d gamma = S[1] of each layer's backward sums)
 __global__ void k_conv1_wgrad_finish(const double *__restrict__ tmp /*[slices][E]*/, int slices, float *__restrict__ dW1,
-                                     float *__restrict__ db1)
+                                     float *__restrict__ db1, const double *__restrict__ S1, const double *__restrict__ S2, float *g1w,
+                                     float *g1b, float *g2w, float *g2b)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, E = 512 + kC;
+    if (i < kC) {
+        g1b[i] = (float)S1[i];
+        g1w[i] = (float)S1[kC + i];
+        g2b[i] = (float)S2[i];
+        g2w[i] = (float)S2[kC + i];
+    }
     if (i >= E) return;
     double t = 0.0;
 #pragma unroll 8
@@ -1020,16 +1102,6 @@ __global__ void k_conv1_wgrad_finish(const double *__restrict__ tmp /*[slices][E
     } else {
         db1[i - 512] = (float)t;
     }
-}
-
-__global__ void k_bn_grads(const double *__restrict__ S1, const double *__restrict__ S2, float *g1w, float *g1b, float *g2w, float *g2b)
-{
-    const int c = threadIdx.x;
-    if (c >= kC) return;
-    g1b[c] = (float)S1[c];
-    g1w[c] = (float)S1[kC + c];
-    g2b[c] = (float)S2[c];
-    g2w[c] = (float)S2[kC + c];
 }
 
 // ===========================================================================
@@ -1071,13 +1143,13 @@ static inline EncWs enc_carve(void *ws, int batch, int grid)
     return w;
 }
 
-constexpr int kReduceSlices = 16;
+constexpr int kReduceSlices = 64;
 
 // stage 1 of the deterministic fp64 reduction: partial [P][E] -> tmp [slices][E]; the consumer (a
 // *_finish kernel) adds the <= 64 slices in order.  Returns the number of slices.
 static inline int reduce_stage1(const float *partial, int P, int E, double *tmp, hipStream_t st)
 {
-    int slices = P / 8;
+    int slices = P / 32;  // ~32 partial rows per workgroup
     slices = slices < 1 ? 1 : (slices > kReduceSlices ? kReduceSlices : slices);
     const int per = (P + slices - 1) / slices;
     hipLaunchKernelGGL(k_reduce_partials<float>, dim3((E + 63) / 64, slices), dim3(256), 0, st, partial, P, E, per, tmp,
@@ -1106,8 +1178,15 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
         hipLaunchKernelGGL(k_conv1_fwd<ActBF16>, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, batch, grid, O1, p->w1,
                        p->b1, (uint16_t *)y1, training ? w.bn_part : nullptr);
     } else {
-        hipLaunchKernelGGL(k_conv1_fwd<ActF32>, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, batch, grid, O1, p->w1,
-                       p->b1, (float *)y1, training ? w.bn_part : nullptr);
+        const size_t c1_lds = (size_t)3 * (2 * O1 + 1) * grid * sizeof(float);
+        const bool c1_staged = (grid % 4 == 0) && (row_stride % 4 == 0) && (((uintptr_t)obs_grid & 15) == 0) && c1_lds <= 64 * 1024 &&
+                               2 * O1 + 1 <= grid;
+        if (c1_staged)
+            hipLaunchKernelGGL(k_conv1_fwd_lds<ActF32>, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, obs_grid, rows,
+                               row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr);
+        else
+            hipLaunchKernelGGL(k_conv1_fwd<ActF32>, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride,
+                               batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr);
     }
     if ((err = gnbv_launch_status())) return err;
     if (training)
@@ -1232,10 +1311,9 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     const int E1 = 512 + kC;
     const int sl1 = reduce_stage1(w.wg_part, wg1_blocks, E1, w.tmp, st);
     if ((err = gnbv_launch_status())) return err;
-    hipLaunchKernelGGL(k_conv1_wgrad_finish, dim3((E1 + 255) / 256), dim3(256), 0, st, (const double *)w.tmp, sl1, g->w1, g->b1);
-    if ((err = gnbv_launch_status())) return err;
-    // ---- BN affine gradients: d beta = S[0], d gamma = S[1] ----
-    hipLaunchKernelGGL(k_bn_grads, dim3(1), dim3(64), 0, st, S1, S2, g->bn1_w, g->bn1_b, g->bn2_w, g->bn2_b);
+    // (+ BN affine gradients: d beta = S[0], d gamma = S[1])
+    hipLaunchKernelGGL(k_conv1_wgrad_finish, dim3((E1 + 255) / 256), dim3(256), 0, st, (const double *)w.tmp, sl1, g->w1, g->b1,
+                       (const double *)S1, (const double *)S2, g->bn1_w, g->bn1_b, g->bn2_w, g->bn2_b);
     return gnbv_launch_status();
 }
 

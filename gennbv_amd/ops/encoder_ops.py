@@ -243,6 +243,7 @@ class _PolicyHeadFn(torch.autograd.Function):
         ctx.save_for_backward(fa, fg, feat, w_out, w_act, w_val)
         ctx.mods = mods
         ctx.mark_non_differentiable(feat)
+        ctx.set_materialize_grads(False)  # no zero-filled gradient tensor for `feat`
         return logits, values, feat
 
     @staticmethod
