@@ -55,6 +55,7 @@ SIGNATURES = {
     "gnbv_policy_head_backward": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnbv_gather_minibatch": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnbv_ppo_loss": (_i, [_p, _p]),
+    "gnbv_multicategorical_sample": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p, _p]),
     "gnbv_adam_workspace_bytes": (_sz, []),
     "gnbv_clip_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _p, _f, _p, _f, _p, _p, _sz, _p]),
     "gnbv_gae_sb3": (_i, [_p, _p, _p, _p, _p, _i, _i, _d, _d, _p, _p, _p]),

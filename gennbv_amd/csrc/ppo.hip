@@ -249,6 +249,53 @@ __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Rollout side of MultiCategoricalDistribution (stable_baselines3/common/distributions.py:299-352 as used
+// by ActorCriticPolicy.forward, policies.py:1024-1030): sample() + log_prob() of the sampled action in
+// ONE launch instead of ~25 element-wise / reduction kernels per head.  thread = (row, head): log-sum-exp
+// of the head's logits, then the inverse CDF of softmax at u[row][head] in [0, 1) (deterministic: the
+// first arg-max, torch.argmax semantics); the row's log-prob is the sum over heads in head order.
+// ---------------------------------------------------------------------------
+struct SampleArgs {
+    int batch, n_logits, n_heads, deterministic;
+    int head_dims[kMaxHeads], head_off[kMaxHeads];
+};
+
+__global__ __launch_bounds__(64) void k_multicategorical_sample(SampleArgs a, const float *__restrict__ logits, const float *__restrict__ uniforms,
+                                                                int64_t *__restrict__ actions, float *__restrict__ log_prob)
+{
+    __shared__ float lp[8][kMaxHeads];
+    const int h = threadIdx.x & 7, r = threadIdx.x >> 3, b = blockIdx.x * 8 + r;
+    if (b < a.batch && h < a.n_heads) {
+        const float *row = logits + (size_t)b * a.n_logits + a.head_off[h];
+        const int d = a.head_dims[h];
+        float mx = row[0];
+        int amax = 0;
+        for (int i = 1; i < d; ++i)
+            if (row[i] > mx) { mx = row[i]; amax = i; }
+        float s = 0.0f;
+        for (int i = 0; i < d; ++i) s += expf(row[i] - mx);
+        int act = amax;
+        if (!a.deterministic) {
+            const float target = uniforms[(size_t)b * a.n_heads + h] * s;
+            float c = 0.0f;
+            act = d - 1;
+            for (int i = 0; i < d; ++i) {
+                c += expf(row[i] - mx);
+                if (c > target) { act = i; break; }
+            }
+        }
+        actions[(size_t)b * a.n_heads + h] = act;
+        lp[r][h] = row[act] - (mx + logf(s));
+    }
+    __syncthreads();
+    if (b < a.batch && h == 0) {
+        float t = lp[r][0];
+        for (int k = 1; k < a.n_heads; ++k) t += lp[r][k];
+        log_prob[b] = t;
+    }
+}
+
 // ===========================================================================
 // C-ABI
 // ===========================================================================
@@ -300,5 +347,26 @@ GNBV_API int gnbv_clip_adam_step(float *params, const float *grads, float *exp_a
     ab = ab > 4096 ? 4096 : ab;
     hipLaunchKernelGGL(k_adam_flat, dim3(ab), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, (const float *)norm_out,
                        (const int *)stop_flag, step, lr, beta1, beta2, eps);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_multicategorical_sample(const float *logits, int batch, int n_logits, int n_heads, const int *head_dims,
+                                          const float *uniforms, int deterministic, int64_t *actions, float *log_prob, void *stream)
+{
+    GNBV_CHECK_ARG(logits && head_dims && actions && log_prob && batch > 0 && n_heads > 0 && n_heads <= kMaxHeads);
+    GNBV_CHECK_ARG(deterministic || uniforms);
+    SampleArgs a;
+    a.batch = batch; a.n_logits = n_logits; a.n_heads = n_heads; a.deterministic = deterministic;
+    int off = 0;
+    for (int h = 0; h < kMaxHeads; ++h) {
+        a.head_dims[h] = h < n_heads ? head_dims[h] : 0;
+        a.head_off[h] = off;
+        if (h < n_heads) {
+            GNBV_CHECK_ARG(head_dims[h] > 0);
+            off += head_dims[h];
+        }
+    }
+    GNBV_CHECK_ARG(off == n_logits);
+    hipLaunchKernelGGL(k_multicategorical_sample, dim3((batch + 7) / 8), dim3(64), 0, gnbv_stream(stream), a, logits, uniforms, actions, log_prob);
     return gnbv_launch_status();
 }

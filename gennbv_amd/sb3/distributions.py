@@ -46,3 +46,25 @@ class MultiCategoricalDistribution:
 
     def get_actions(self, deterministic: bool = False) -> torch.Tensor:
         return self.mode() if deterministic else self.sample()
+
+    def sample_and_log_prob(self, action_logits: torch.Tensor, deterministic: bool = False):
+        """(actions [B, H] int64, log_prob [B]) of the rollout forward in ONE launch on the GPU
+        (gnbv_multicategorical_sample): inverse CDF of softmax at one uniform per (row, head).  Same
+        distribution as `sample()` (torch.multinomial), a different random stream -- the CPU path above keeps
+        the reference's RNG consumption order."""
+        import ctypes as C
+
+        from .. import _lib
+        lib = _lib.load()
+        _lib.require_cuda(action_logits)
+        logits = action_logits.contiguous().float()
+        b, h = logits.shape[0], len(self.action_dims)
+        dev = logits.device
+        u = None if deterministic else torch.rand(b, h, device=dev)
+        actions = torch.empty(b, h, dtype=torch.int64, device=dev)
+        log_prob = torch.empty(b, dtype=torch.float32, device=dev)
+        dims = (C.c_int * h)(*self.action_dims)
+        _lib.check(lib.gnbv_multicategorical_sample(logits.data_ptr(), b, logits.shape[1], h, dims, _lib.ptr(u), int(deterministic),
+                                                    actions.data_ptr(), log_prob.data_ptr(), _lib.stream_ptr(dev)),
+                   "gnbv_multicategorical_sample")
+        return actions, log_prob

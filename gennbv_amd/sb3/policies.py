@@ -83,7 +83,23 @@ class ActorCriticPolicy_Train_Eval(nn.Module):
     def _dist(self, latent_pi):
         return self.action_dist.proba_distribution(action_logits=self.action_net(latent_pi))
 
+    def _fused_head(self, obs):
+        """(logits, values [B]) through the fused policy-head kernels, or None when not applicable
+        (rollout on the gfx950 backend only: no autograd graph is needed there)."""
+        if not getattr(self, "_fused_rollout", False) or torch.is_grad_enabled() or not obs.is_cuda:
+            return None
+        from ..ops import encoder_ops
+        enc = self.features_extractor
+        fa, fg = encoder_ops.hybrid_branches(enc, obs.float())
+        logits, values, _ = encoder_ops.policy_head(enc, self.action_net, self.value_net, fa, fg)
+        return logits, values
+
     def forward(self, obs: torch.Tensor, deterministic: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        fused = self._fused_head(obs)
+        if fused is not None:
+            logits, values = fused
+            actions, log_prob = self.action_dist.sample_and_log_prob(logits, deterministic)
+            return actions, values.unsqueeze(1), log_prob
         features = self.extract_features(obs)
         latent_pi, latent_vf = self.mlp_extractor(features)
         values = self.value_net(latent_vf)
@@ -102,4 +118,7 @@ class ActorCriticPolicy_Train_Eval(nn.Module):
         return self._dist(self.mlp_extractor.forward_actor(self.extract_features(obs)))
 
     def predict_values(self, obs: torch.Tensor) -> torch.Tensor:
+        fused = self._fused_head(obs)
+        if fused is not None:
+            return fused[1].unsqueeze(1)
         return self.value_net(self.mlp_extractor.forward_critic(self.extract_features(obs)))

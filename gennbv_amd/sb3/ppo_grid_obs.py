@@ -446,6 +446,15 @@ class PPO_Grid_Obs:
         """on_policy_algorithm_grid_obs.py:128-221 (tensor-env branch)."""
         assert self._last_obs is not None, "No previous observation was provided"
         self.policy.set_training_mode(False)
+        if not hasattr(self.policy, "_fused_rollout"):
+            from ..ops import encoder_ops
+            from .policies import _IdentityExtractor
+            enc = self.policy.features_extractor
+            self.policy._fused_rollout = (
+                os.environ.get("GENNBV_FUSED_ROLLOUT", "1") != "0" and self.device.type == "cuda"
+                and getattr(enc, "backend", "") == "hip" and isinstance(self.policy.mlp_extractor, _IdentityExtractor)
+                and hasattr(self.policy.action_dist, "sample_and_log_prob")
+                and encoder_ops.policy_head_supported(enc, self.policy.action_net, self.policy.value_net))
         n_steps = 0
         rollout_buffer.reset()
         first = rollout_buffer.first_obs_row()

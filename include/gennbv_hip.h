@@ -301,6 +301,14 @@ typedef struct GnbvPpoLoss {
 
 int gnbv_ppo_loss(const GnbvPpoLoss *args /*[host]*/, void *stream);
 
+/* C5  rollout side of MultiCategoricalDistribution (stable_baselines3/common/distributions.py:299-352 via
+ *     ActorCriticPolicy.forward, policies.py:1024-1030): actions[b][h] ~ Categorical(softmax(logits_h[b])) by
+ *     the inverse CDF at uniforms[b][h] in [0,1) (deterministic != 0: first arg-max = mode()), and
+ *     log_prob[b] = sum_h log softmax(logits_h[b])[actions[b][h]].  head_dims [n_heads] is a HOST array,
+ *     sum(head_dims) == n_logits, n_heads <= 8.  Same distribution as torch.multinomial, different random stream. */
+int gnbv_multicategorical_sample(const float *logits, int batch, int n_logits, int n_heads, const int *head_dims /*[host]*/,
+                                 const float *uniforms, int deterministic, int64_t *actions, float *log_prob, void *stream);
+
 /* torch.nn.utils.clip_grad_norm_(max_grad_norm) + torch.optim.Adam step over ONE flat fp32
  * buffer of n parameters (max_grad_norm <= 0: no clipping). grads is the SUM over ranks,
  * grad_scale = 1/world turns it into the mean (1.0 on one GPU).  kl_slot (may be NULL): sum over

@@ -120,3 +120,29 @@ def test_data_parallel_code_path_on_one_gpu(name):
     ppo = _ppo_from_fixture(fx, device=DEV, backend="hip")
     parallel.attach(ppo, 1, always_sync=True)
     _check(ppo, fx)
+
+
+def test_multicategorical_sample_kernel_distribution_and_log_prob():
+    """gnbv_multicategorical_sample (rollout side of MultiCategoricalDistribution, sb3 distributions.py:299-352):
+    log_prob equals the torch evaluation of the sampled action bit-for-bit up to fp32 round-off, the mode
+    equals torch.argmax, and the empirical frequencies match softmax within sampling error."""
+    from gennbv_amd.sb3.distributions import MultiCategoricalDistribution
+    dims = [81, 81, 51, 1, 13, 13] if False else [7, 5, 3, 1, 4, 2]
+    dist = MultiCategoricalDistribution(dims)
+    gen = torch.Generator().manual_seed(3)
+    logits = (torch.randn(4096, sum(dims), generator=gen) * 2).to("cuda:0")
+    torch.manual_seed(11)
+    actions, lp = dist.sample_and_log_prob(logits)
+    assert actions.shape == (4096, len(dims)) and actions.dtype == torch.int64
+    ref = dist.proba_distribution(logits).log_prob(actions.float())
+    assert torch.allclose(lp, ref, rtol=1e-5, atol=1e-5)
+    for h, d in enumerate(dims):
+        assert int(actions[:, h].min()) >= 0 and int(actions[:, h].max()) < d
+    mode, lpm = dist.sample_and_log_prob(logits, deterministic=True)
+    assert torch.equal(mode, dist.proba_distribution(logits).mode())
+    # frequencies: one row repeated -> empirical distribution of head 0 vs softmax
+    row = logits[:1].repeat(20000, 1)
+    a, _ = dist.sample_and_log_prob(row)
+    p = torch.softmax(row[0, :dims[0]], 0)
+    freq = torch.bincount(a[:, 0], minlength=dims[0]).float() / a.shape[0]
+    assert float((freq - p).abs().max()) < 4 * float((p * (1 - p) / a.shape[0]).sqrt().max()) + 1e-3

@@ -2,19 +2,19 @@
 consecutive k_gather_minibatch launches, with start offset, duration and queue/stream id, plus the
 per-queue busy time and the union (critical-path) time.
 
-    python tools/rocprof_timeline.py <dir-or-db> [which-minibatch=200]
+    python tools/rocprof_timeline.py <dir-or-db> [which-minibatch=200] [marker-kernel-prefix=k_gather_minibatch]
 """
 import glob, os, sqlite3, sys
 
 
-def main(path, which=200):
+def main(path, which=200, marker="k_gather_minibatch"):
     if os.path.isdir(path):
         path = sorted(glob.glob(os.path.join(path, "**", "*_results.db"), recursive=True))[-1]
     db = sqlite3.connect(path)
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
     qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
     scol = "stream_id" if "stream_id" in cols else qcol
-    marks = [r[0] for r in db.execute("select start from kernels where name like 'k_gather_minibatch%' order by start")]
+    marks = [r[0] for r in db.execute("select start from kernels where name like ? order by start", (marker + "%",))]
     if len(marks) < which + 2:
         which = len(marks) // 2
     t0, t1 = marks[which], marks[which + 1]
@@ -42,4 +42,4 @@ def main(path, which=200):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 200)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 200, sys.argv[3] if len(sys.argv) > 3 else "k_gather_minibatch")
