@@ -21,6 +21,8 @@
 //
 // MFMA 16x16x4 fp32 fragment layout (cdna_hip_programming.md section 3), lane l:
 //   A[i = l & 15][k = l >> 4]   B[k = l >> 4][j = l & 15]   D[i = 4*(l >> 4) + r][j = l & 15], r = 0..3
+#include <cstdlib>
+
 #include "common.h"
 #include "../../include/gennbv_hip.h"
 
@@ -1223,6 +1225,29 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     return gnbv_launch_status();
 }
 
+// EXPERIMENT (off unless GENNBV_BWD_CONCURRENT=1): side stream + fork/join events so that the conv2 weight
+// gradient (MFMA/VALU-issue bound) runs beside the conv2 data gradient (HBM bound) -- both only depend on
+// dy2.  Works under stream capture, but measured SLOWER on MI355X (train 1176 vs 1129 ms per iteration:
+// two ~10 us cross-queue joins plus L2 interference outweigh the overlap), hence not the default.
+struct BwdSide {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool enabled = false, init = false;
+};
+static BwdSide &bwd_side()
+{
+    static BwdSide s;
+    if (!s.init) {
+        s.init = true;
+        const char *e = getenv("GENNBV_BWD_CONCURRENT");
+        if ((e && e[0] == '1') && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess)
+            s.enabled = true;
+    }
+    return s;
+}
+
 GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *rows, int64_t row_stride, int batch, int grid,
                                         const GnbvEncoderParams *p, const void *y1, const float *y2, const float *bn_state,
                                         const float *d_features, float *dy2_scratch, void *dz1_scratch,
@@ -1249,23 +1274,33 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     hipLaunchKernelGGL(k_bn2_bwd_apply, dim3(gx), dim3(256), 0, st, d_features, y2, bn2, bn2 + kC, bn2 + 2 * kC, bn2 + 3 * kC, S2,
                        (double)batch * P2, total2, P2, dy2_scratch);
     if ((err = gnbv_launch_status())) return err;
-    // ---- conv2 weight gradient ----
+    // ---- conv2 weight gradient: on the side stream, beside the data gradient ----
+    BwdSide &side = bwd_side();
+    hipStream_t sw = st;
+    if (side.enabled) {
+        if (hipEventRecord(side.fork, st) != hipSuccess || hipStreamWaitEvent(side.stream, side.fork, 0) != hipSuccess) return (int)hipGetLastError();
+        sw = side.stream;
+    }
     int nrows2 = batch * O2 * O2;
     int wg_blocks = (nrows2 + kEncWaves - 1) / kEncWaves;
     wg_blocks = wg_blocks > 512 ? 512 : ((wg_blocks + 7) & ~7);
     if (p->act_bf16) {
-        hipLaunchKernelGGL(k_conv2_wgrad<ActBF16>, dim3(wg_blocks), dim3(kEncThreads), 0, st, (const uint16_t *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
+        hipLaunchKernelGGL(k_conv2_wgrad<ActBF16>, dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const uint16_t *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
                        w.wg_part);
     } else {
-        hipLaunchKernelGGL(k_conv2_wgrad<ActF32>, dim3(wg_blocks), dim3(kEncThreads), 0, st, (const float *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
+        hipLaunchKernelGGL(k_conv2_wgrad<ActF32>, dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
                        w.wg_part);
     }
     if ((err = gnbv_launch_status())) return err;
     const int E2 = kTaps * 256 + kC;
-    const int sl2 = reduce_stage1(w.wg_part, wg_blocks, E2, w.tmp, st);
+    const int sl2 = reduce_stage1(w.wg_part, wg_blocks, E2, w.tmp, sw);  // <= 16 slices: tmp[0, 16 E2)
     if ((err = gnbv_launch_status())) return err;
-    hipLaunchKernelGGL(k_conv2_wgrad_finish, dim3((E2 + 255) / 256), dim3(256), 0, st, (const double *)w.tmp, sl2, g->w2, g->b2);
+    hipLaunchKernelGGL(k_conv2_wgrad_finish, dim3((E2 + 255) / 256), dim3(256), 0, sw, (const double *)w.tmp, sl2, g->w2, g->b2);
     if ((err = gnbv_launch_status())) return err;
+    if (side.enabled && hipEventRecord(side.join, sw) != hipSuccess) return (int)hipGetLastError();
+    // the conv1 weight gradient (main stream) uses its own partial / slice regions of the workspace
+    float *wg1_part = w.wg_part + (size_t)512 * E2;
+    double *tmp1 = w.tmp + (size_t)32 * E2;
     // ---- conv2 data gradient (+ ReLU1 mask, BN1 backward sums) ----
     hipLaunchKernelGGL(k_prep_w2, dim3(kTaps), dim3(256), 0, st, p->w2, w.w2img, w.w2img + kTaps * 256);
     const int gd = sample_plane_group_grid(batch, (O1 + 1) / 2, kPlanesPerGroup);  // groups of plane PAIRS
@@ -1292,12 +1327,12 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
                             c1w_nr <= 4 && c1w_ni <= 5;
     if (p->act_bf16) {
         hipLaunchKernelGGL(k_conv1_wgrad<ActBF16>, dim3(wg1_blocks), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, (const uint16_t *)dz1_scratch, (const uint16_t *)y1, bn1,
-                       bn1 + 2 * kC, bn1 + 3 * kC, S1, (double)batch * O1 * O1 * O1, batch, grid, O1, w.wg_part);
+                       bn1 + 2 * kC, bn1 + 3 * kC, S1, (double)batch * O1 * O1 * O1, batch, grid, O1, wg1_part);
     } else if (c1w_staged) {
 #define GNBV_C1W(NR, NI)                                                                                                          \
     hipLaunchKernelGGL((k_conv1_wgrad_lds<ActF32, NR, NI>), dim3(wg1_blocks), dim3(kEncThreads), c1w_lds, st, obs_grid, rows,      \
                        row_stride, (const float *)dz1_scratch, (const float *)y1, bn1, bn1 + 2 * kC, bn1 + 3 * kC, S1,            \
-                       (double)batch * O1 * O1 * O1, batch, grid, O1, w.wg_part)
+                       (double)batch * O1 * O1 * O1, batch, grid, O1, wg1_part)
         if (c1w_nr <= 1 && c1w_ni <= 1) GNBV_C1W(1, 1);
         else if (c1w_nr <= 1 && c1w_ni <= 2) GNBV_C1W(1, 2);
         else if (c1w_nr <= 2 && c1w_ni <= 3) GNBV_C1W(2, 3);  // G = 64
@@ -1305,15 +1340,17 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
 #undef GNBV_C1W
     } else {
         hipLaunchKernelGGL(k_conv1_wgrad<ActF32>, dim3(wg1_blocks), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, (const float *)dz1_scratch, (const float *)y1, bn1,
-                       bn1 + 2 * kC, bn1 + 3 * kC, S1, (double)batch * O1 * O1 * O1, batch, grid, O1, w.wg_part);
+                       bn1 + 2 * kC, bn1 + 3 * kC, S1, (double)batch * O1 * O1 * O1, batch, grid, O1, wg1_part);
     }
     if ((err = gnbv_launch_status())) return err;
     const int E1 = 512 + kC;
-    const int sl1 = reduce_stage1(w.wg_part, wg1_blocks, E1, w.tmp, st);
+    const int sl1 = reduce_stage1(wg1_part, wg1_blocks, E1, tmp1, st);
     if ((err = gnbv_launch_status())) return err;
     // (+ BN affine gradients: d beta = S[0], d gamma = S[1])
-    hipLaunchKernelGGL(k_conv1_wgrad_finish, dim3((E1 + 255) / 256), dim3(256), 0, st, (const double *)w.tmp, sl1, g->w1, g->b1,
+    hipLaunchKernelGGL(k_conv1_wgrad_finish, dim3((E1 + 255) / 256), dim3(256), 0, st, (const double *)tmp1, sl1, g->w1, g->b1,
                        (const double *)S1, (const double *)S2, g->bn1_w, g->bn1_b, g->bn2_w, g->bn2_b);
+    if ((err = gnbv_launch_status())) return err;
+    if (side.enabled && hipStreamWaitEvent(st, side.join, 0) != hipSuccess) return (int)hipGetLastError();  // join
     return gnbv_launch_status();
 }
 
