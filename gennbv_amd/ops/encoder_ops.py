@@ -186,26 +186,31 @@ def hybrid_branches(enc, observations):
     g = enc.grid_size
     if isinstance(observations, RowGather):
         base, rows = observations.base, observations.rows
-        state = observations.columns(0, s)
+        num_env = int(rows.shape[0])
+        get_state = lambda: observations.columns(0, s)  # noqa: E731  (gather of the pose columns: on the side stream too)
     else:
         base, rows = observations, None
-        state = observations[:, :s]
+        num_env = int(observations.shape[0])
+        get_state = lambda: observations[:, :s]  # noqa: E731
         if base.stride(1) != 1:
             base = base.contiguous()
-    num_env = state.shape[0]
-    # The pose-history branch (a few small GEMMs and element-wise kernels) is independent of the grid
-    # branch until the concat: fork it onto a second HIP stream so that it overlaps the conv kernels
+
+    def pose_branch():
+        state = get_state()
+        action_input = enc.positional_encoding(state.view(num_env, -1, 6)).view(num_env, -1)
+        return enc.naive_encoder_action(action_input)
+
+    # The pose-history branch (a gather, a few small GEMMs and element-wise kernels) is independent of the
+    # grid branch until the concat: fork it onto a second HIP stream so that it overlaps the conv kernels
     # in the forward AND (autograd replays each op on the stream it was recorded on) in the backward.
     side = _side_stream(base.device) if enc.overlap_branches else None
     if side is not None:
         cur = torch.cuda.current_stream(base.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            action_input = enc.positional_encoding(state.view(num_env, -1, 6)).view(num_env, -1)
-            feature_action = enc.naive_encoder_action(action_input)
+            feature_action = pose_branch()
     else:
-        action_input = enc.positional_encoding(state.view(num_env, -1, 6)).view(num_env, -1)
-        feature_action = enc.naive_encoder_action(action_input)
+        feature_action = pose_branch()
     feature_grid = grid_encoder(base, rows, s, g, enc.naive_encoder_grid, enc.training, getattr(enc, "_bn_skip_flag", None),
                                 enc.compute_dtype == torch.bfloat16, getattr(enc, "_grad_write_through", False))
     if getattr(enc, "_split_backward", False) and torch.is_grad_enabled():

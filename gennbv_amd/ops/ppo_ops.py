@@ -103,15 +103,29 @@ class PpoLossOp:
         a.actions, a.old_values, a.old_log_prob = self.actions.data_ptr(), self.old_values.data_ptr(), self.old_log_prob.data_ptr()
         a.advantages, a.returns = self.advantages.data_ptr(), self.returns.data_ptr()
         a.d_logits, a.d_values = self.d_logits.data_ptr(), self.d_values.data_ptr()
-        a.head_entropy, a.head_lse, a.kl_out = None, None, None
+        a.head_entropy, a.head_lse, a.kl_out, a.rows = None, None, None, None
         a.stats, a.stats_row, a.stop_flag = self.stats.data_ptr(), self.stats_row.data_ptr(), self.stop_flag.data_ptr()
         self.scratch = z(3 * batch)
         a.scratch = self.scratch.data_ptr()
         self.args = a
         self.device = device
 
+    def bind(self, buf):
+        """Fused gather: the loss kernel reads actions / values / log_probs / advantages / returns of rows
+        `self.rows` (row = t*N + n) straight out of the rollout buffer (GnbvPpoLoss.rows)."""
+        a = self.args
+        for t in (buf.actions, buf.values, buf.log_probs, buf.advantages, buf.returns):
+            assert t.is_contiguous() and t.dtype == torch.float32
+        a.actions, a.old_values, a.old_log_prob = buf.actions.data_ptr(), buf.values.data_ptr(), buf.log_probs.data_ptr()
+        a.advantages, a.returns = buf.advantages.data_ptr(), buf.returns.data_ptr()
+        a.rows = self.rows.data_ptr()
+
     def gather(self, buf):
         """actions / values / log_probs / advantages / returns of rows `self.rows` (row = t*N + n)."""
+        a = self.args
+        a.actions, a.old_values, a.old_log_prob = self.actions.data_ptr(), self.old_values.data_ptr(), self.old_log_prob.data_ptr()
+        a.advantages, a.returns = self.advantages.data_ptr(), self.returns.data_ptr()
+        a.rows = None
         _lib.check(self.lib.gnbv_gather_minibatch(
             self.rows.data_ptr(), self.batch, self.actions.shape[1], buf.actions.data_ptr(), buf.values.data_ptr(),
             buf.log_probs.data_ptr(), buf.advantages.data_ptr(), buf.returns.data_ptr(), self.actions.data_ptr(),

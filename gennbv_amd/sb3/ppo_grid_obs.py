@@ -260,7 +260,6 @@ class PPO_Grid_Obs:
         buf, pol, loss, opt = self.rollout_buffer, self.policy, st["loss"], st["opt"]
         if phase in ("all", "A"):
             t, n = buf.buffer_size, buf.n_envs
-            loss.gather(buf)
             obs = RowGather(buf.observations[:t].view(t * n, -1), loss.rows)
             enc = pol.features_extractor
             if st.get("fused_head"):
@@ -270,6 +269,7 @@ class PPO_Grid_Obs:
                 features = pol.extract_features(obs)
                 logits = pol.action_net(features)
                 values = pol.value_net(features).flatten()
+            loss.bind(buf)  # fused gather: the loss kernel indexes the rollout arrays through loss.rows
             d_logits, d_values = loss(logits, values)
             if not st.get("skip_zero"):
                 opt.zero_grad()

@@ -297,6 +297,9 @@ typedef struct GnbvPpoLoss {
     float *scratch;             /* [3*B] device scratch */
     float *kl_out;              /* NULL, or [1]: receives approx_kl INSTEAD of setting stop_flag
                                    (data-parallel: decided on the global mean, gnbv_clip_adam_step) */
+    const int64_t *rows;        /* NULL, or [B]: fused minibatch gather (buffers.py:753-762) -- actions, old_values,
+                                   old_log_prob, advantages, returns then point at the whole [T*N] rollout arrays
+                                   and sample i reads row rows[i] */
 } GnbvPpoLoss;
 
 int gnbv_ppo_loss(const GnbvPpoLoss *args /*[host]*/, void *stream);
