@@ -65,6 +65,32 @@ class FlatAdam:
             float(kl_slot_target) if kl_slot_target is not None else -1.0, self.norm_out.data_ptr(),
             self.ws.data_ptr(), self.ws.numel(), _lib.stream_ptr(self.params.device)), "gnbv_clip_adam_step")
 
+    def torch_state_dict(self, template: torch.optim.Adam) -> dict:
+        """This optimizer's state in torch.optim.Adam.state_dict() format (checkpoints: policy.optimizer.pth);
+        `template` = the policy's (idle) torch Adam, which supplies the param_groups."""
+        sd = template.state_dict()
+        step = int(self.step_count.item())
+        sd["state"] = {}
+        if step > 0:
+            for i, ((off, k), p) in enumerate(zip(self.slices, self.module_params)):
+                sd["state"][i] = {"step": torch.tensor(float(step)), "exp_avg": self.exp_avg[off:off + k].view_as(p).clone(),
+                                  "exp_avg_sq": self.exp_avg_sq[off:off + k].view_as(p).clone()}
+        for g in sd["param_groups"]:
+            g["lr"] = float(self.lr)
+        return sd
+
+    def load_torch_state_dict(self, sd: dict) -> None:
+        """Adopt exp_avg / exp_avg_sq / step from a torch.optim.Adam.state_dict() over the same parameters."""
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.step_count.zero_()
+        for i, (off, k) in enumerate(self.slices):
+            st = sd["state"].get(i)
+            if st:
+                self.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                self.step_count.fill_(int(st["step"]))
+
     def load_torch_adam_state(self, opt: torch.optim.Adam):
         """Adopt exp_avg / exp_avg_sq / step of a torch Adam over the same parameters (checkpoints)."""
         for (off, k), p in zip(self.slices, self.module_params):

@@ -125,6 +125,83 @@ class PPO_Grid_Obs:
                 assert self.clip_range_vf > 0, "`clip_range_vf` must be positive, pass `None` to deactivate vf clipping"
             self.clip_range_vf = _schedule(self.clip_range_vf)
 
+    # ------------------------------------------------------------------------------
+    # SB3-zip checkpoints (base_class_grid_obs.py:616-854, on_policy_algorithm_grid_obs.py:300-303)
+    def _get_torch_save_params(self):
+        # Reference quirk kept: its on-policy class overrides `_get_th_save_params` (a misspelt name,
+        # on_policy_algorithm_grid_obs.py:299-302), so the base list ["policy"] is what save()/set_parameters()
+        # use -- the reference's checkpoints carry NO optimizer state and its exact-match check rejects archives
+        # that do.  save(include_optimizer=True) adds policy.optimizer.pth for this build's own resume.
+        return ["policy"], []
+
+    def get_parameters(self) -> Dict[str, Dict]:
+        """{"policy": state_dict, "policy.optimizer": torch.optim.Adam-format state dict}."""
+        opt_sd = self.policy.optimizer.state_dict()
+        if self._hip and self._hip.get("opt") is not None:
+            opt_sd = self._hip["opt"].torch_state_dict(self.policy.optimizer)  # the flat HIP Adam owns the moments
+        return {"policy": self.policy.state_dict(), "policy.optimizer": opt_sd}
+
+    def set_parameters(self, load_path_or_dict, exact_match: bool = True, device="auto") -> None:
+        """In-place load of a zip written by this class OR by the reference's PPO_Grid_Obs.save()."""
+        from . import save_util
+        params = load_path_or_dict
+        if not isinstance(load_path_or_dict, dict):
+            _, params, _, _ = save_util.load_from_zip_file(load_path_or_dict, load_data=False,
+                                                           device=self.device if device == "auto" else device)
+        updated = set()
+        for name, sd in params.items():
+            if name == "policy":
+                self.policy.load_state_dict(sd, strict=exact_match)
+            elif name == "policy.optimizer":
+                self.policy.optimizer.load_state_dict(sd)
+                if self._hip and self._hip.get("opt") is not None:
+                    self._hip["opt"].load_torch_state_dict(sd)
+                    self._hip["graph"] = None
+            else:
+                raise ValueError(f"Key {name} is an invalid object name.")
+            updated.add(name)
+        if exact_match and not ({"policy"} <= updated <= {"policy", "policy.optimizer"}):
+            raise ValueError(f"Names of parameters do not match agents' parameters: expected "
+                             f"{set(self._get_torch_save_params()[0])} (+ optionally 'policy.optimizer'), got {updated}")
+
+    def save(self, path, exclude=None, include=None, include_optimizer: bool = False) -> None:
+        """base_class_grid_obs.py:806-854: `data` JSON + policy.pth (+ policy.optimizer.pth on request) in one zip."""
+        from . import save_util
+        excl = set(exclude or []) | save_util.EXCLUDED
+        if include is not None:
+            excl -= set(include)
+        data = {k: v for k, v in self.__dict__.items() if k not in excl}
+        params = {k: ({kk: vv.detach().cpu() for kk, vv in v.items()} if k == "policy" else v) for k, v in self.get_parameters().items()
+                  if k == "policy" or include_optimizer}
+        save_util.save_to_zip_file(path, data=data, params=params, pytorch_variables={})
+
+    @classmethod
+    def load(cls, path, env=None, device="auto", custom_objects=None, policy=None, **kwargs) -> "PPO_Grid_Obs":
+        """Re-create the algorithm from a zip.  Plain hyper-parameters come from `data`; entries pickled with
+        classes that are not importable here (the reference's policy class, spaces, schedules) are replaced by
+        `policy` / the env's spaces / kwargs."""
+        from . import save_util
+        data, params, _, skipped = save_util.load_from_zip_file(path, custom_objects=custom_objects, device="cpu")
+        data = data or {}
+        if env is None:
+            raise ValueError("PPO_Grid_Obs.load needs the (replay-feed) env: stored environments are not restored")
+        policy_class = policy or data.get("policy_class")
+        if policy_class is None or isinstance(policy_class, dict):
+            from .policies import ActorCriticPolicy_Train_Eval
+            policy_class = ActorCriticPolicy_Train_Eval
+        ctor = {}
+        for k in ("learning_rate", "n_steps", "batch_size", "n_epochs", "gamma", "gae_lambda", "clip_range", "clip_range_vf",
+                  "normalize_advantage", "ent_coef", "vf_coef", "max_grad_norm", "target_kl", "policy_kwargs", "verbose", "seed"):
+            if k in data and k not in skipped:
+                ctor[k] = data[k]
+        ctor.update(kwargs)
+        model = cls(policy_class, env, device=device, **ctor)
+        for k in ("num_timesteps", "_n_updates", "_current_progress_remaining"):
+            if k in data:
+                setattr(model, k, data[k])
+        model.set_parameters(params, exact_match=True)
+        return model
+
     def _update_learning_rate(self, optimizer) -> None:
         lr = self.lr_schedule(self._current_progress_remaining)
         self.logger.record("train/learning_rate", lr)
@@ -563,12 +640,3 @@ class PPO_Grid_Obs:
         if callback is not None:
             callback.on_training_end()
         return self
-
-    # checkpoint plumbing: the reference's zip holds `policy` and `policy.optimizer` state_dicts
-    def get_parameters(self):
-        return {"policy": self.policy.state_dict(), "policy.optimizer": self.policy.optimizer.state_dict()}
-
-    def set_parameters(self, params, exact_match: bool = True):
-        self.policy.load_state_dict(params["policy"], strict=exact_match)
-        if "policy.optimizer" in params:
-            self.policy.optimizer.load_state_dict(params["policy.optimizer"])

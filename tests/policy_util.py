@@ -13,17 +13,24 @@ def obs_dim(g=G):
     return STACK * 6 + g ** 3 + 8192
 
 
-def make_policy(g=G, device="cpu", backend="torch", det_weights=True, **enc_kw):
+def spaces(g=G):
+    return Box(-np.inf, np.inf, shape=(obs_dim(g),), dtype=np.float32), MultiDiscrete(NVEC)
+
+
+def policy_kwargs(g=G, backend="torch", **enc_kw):
     from gennbv_amd.network.hybrid_encoder import Hybrid_Encoder
+    return dict(net_arch=[], features_extractor_class=Hybrid_Encoder,
+                features_extractor_kwargs=dict(encoder_param={"hidden_shapes": [256, 256], "visual_dim": 256},
+                                               net_param={"transformer_params": [[1, 256], [1, 256]],
+                                                          "append_hidden_shapes": [256, 256]},
+                                               state_input_shape=(STACK * 6,), visual_input_shape=(STACK, 400, 400),
+                                               grid_size=g, backend=backend, **enc_kw))
+
+
+def make_policy(g=G, device="cpu", backend="torch", det_weights=True, **enc_kw):
     from gennbv_amd.sb3.policies import ActorCriticPolicy_Train_Eval
-    obs_space = Box(-np.inf, np.inf, shape=(obs_dim(g),), dtype=np.float32)
-    act_space = MultiDiscrete(NVEC)
-    kw = dict(net_arch=[], features_extractor_class=Hybrid_Encoder,
-              features_extractor_kwargs=dict(encoder_param={"hidden_shapes": [256, 256], "visual_dim": 256},
-                                             net_param={"transformer_params": [[1, 256], [1, 256]],
-                                                        "append_hidden_shapes": [256, 256]},
-                                             state_input_shape=(STACK * 6,), visual_input_shape=(STACK, 400, 400),
-                                             grid_size=g, backend=backend, **enc_kw))
+    obs_space, act_space = spaces(g)
+    kw = policy_kwargs(g, backend, **enc_kw)
     pol = ActorCriticPolicy_Train_Eval(obs_space, act_space, lambda _: 1e-4, **kw)
     if det_weights:
         shapes = {k: tuple(v.shape) for k, v in pol.state_dict().items()}

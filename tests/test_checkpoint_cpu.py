@@ -1,0 +1,92 @@
+"""SB3-zip checkpoints: gennbv_amd reads the archive the REFERENCE's PPO_Grid_Obs.save() wrote
+(tests/golden/F10_ref_checkpoint.zip, oracle/gen_golden_ckpt.py) and round-trips its own."""
+import os
+import zipfile
+
+import numpy as np
+import torch
+
+from tests import golden_util as gu
+from tests import policy_util as pu
+
+FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "F10_ref_checkpoint.zip")
+
+
+def pattern(shape, dtype=torch.float32, shift=0):
+    n = int(np.prod(shape)) if len(shape) else 1
+    v = ((torch.arange(n) + shift) % 13 - 6).to(torch.float32) / 64.0
+    return v.reshape(shape).to(dtype)
+
+
+class _Env:
+    """the attributes PPO_Grid_Obs reads from an env at construction"""
+    num_envs, device = 4, "cpu"
+
+    def __init__(self):
+        self.observation_space, self.action_space = pu.spaces(20)
+
+    def seed(self, s):
+        pass
+
+
+def make_algo(**kw):
+    from gennbv_amd.sb3.ppo_grid_obs import PPO_Grid_Obs
+    from gennbv_amd.sb3.policies import ActorCriticPolicy_Train_Eval
+    args = dict(learning_rate=1e-4, n_steps=8, batch_size=8, n_epochs=3, ent_coef=0.01, vf_coef=0.8, max_grad_norm=1.0,
+                target_kl=0.05, policy_kwargs=pu.policy_kwargs(20, backend="torch"), device="cpu", seed=1)
+    args.update(kw)
+    return PPO_Grid_Obs(ActorCriticPolicy_Train_Eval, _Env(), **args)
+
+
+def test_reads_reference_checkpoint():
+    from gennbv_amd.sb3 import save_util
+    data, params, variables, skipped = save_util.load_from_zip_file(FIX)
+    # reference quirk: only the policy is saved (misspelt _get_th_save_params, on_policy_algorithm_grid_obs.py:299-302)
+    assert set(params) == {"policy"}
+    assert data["n_steps"] == 8 and data["batch_size"] == 8 and data["n_epochs"] == 3 and data["num_timesteps"] == 4096
+    assert abs(data["gae_lambda"] - 0.95) < 1e-12 and data["_n_updates"] == 30
+    algo = make_algo()
+    algo.set_parameters(FIX, exact_match=True)
+    sd = algo.policy.state_dict()
+    assert list(sd.keys()) == list(params["policy"].keys())  # same names, same order as the reference's policy
+    for i, (k, v) in enumerate(sd.items()):
+        assert v.shape == params["policy"][k].shape and torch.equal(v, params["policy"][k]), k
+        if "num_batches_tracked" in k:
+            assert int(v) == 3
+        elif "running_var" in k:
+            assert torch.equal(v, pattern(v.shape, shift=i).abs() + 0.5), k
+        else:
+            # one Adam step (lr 1e-4) was applied by the reference after the pattern was set
+            assert torch.allclose(v, pattern(v.shape, v.dtype, shift=i), atol=2e-4), k
+
+
+def test_load_classmethod_restores_hyperparameters_and_counters():
+    from gennbv_amd.sb3.ppo_grid_obs import PPO_Grid_Obs
+    algo = PPO_Grid_Obs.load(FIX, env=_Env(), device="cpu", policy_kwargs=pu.policy_kwargs(20, backend="torch"))
+    assert (algo.n_steps, algo.batch_size, algo.n_epochs) == (8, 8, 3)
+    assert algo.num_timesteps == 4096 and algo._n_updates == 30 and abs(algo._current_progress_remaining - 0.75) < 1e-12
+    assert abs(algo.ent_coef - 0.01) < 1e-12 and abs(algo.vf_coef - 0.8) < 1e-12 and abs(algo.target_kl - 0.05) < 1e-12
+
+
+def test_own_roundtrip_and_layout(tmp_path):
+    a = make_algo()
+    for i, p in enumerate(a.policy.parameters()):
+        p.grad = pattern(p.shape, shift=i)
+    a.policy.optimizer.step()
+    a.num_timesteps, a._n_updates = 123, 7
+    path = str(tmp_path / "ckpt")
+    a.save(path)  # default: the reference's layout (policy only)
+    with zipfile.ZipFile(path + ".zip") as z, zipfile.ZipFile(FIX) as zr:
+        assert set(z.namelist()) == set(zr.namelist()) == {"data", "pytorch_variables.pth", "policy.pth",
+                                                           "_stable_baselines3_version", "system_info.txt"}
+    full = str(tmp_path / "ckpt_full")
+    a.save(full, include_optimizer=True)
+    from gennbv_amd.sb3.ppo_grid_obs import PPO_Grid_Obs
+    b = PPO_Grid_Obs.load(full, env=_Env(), device="cpu")
+    assert b.num_timesteps == 123 and b._n_updates == 7 and b.n_steps == a.n_steps
+    for (k, x), (_, y) in zip(a.policy.state_dict().items(), b.policy.state_dict().items()):
+        assert torch.equal(x, y), k
+    sa, sb = a.policy.optimizer.state_dict()["state"], b.policy.optimizer.state_dict()["state"]
+    assert len(sa) == len(sb) > 0
+    for i in sa:
+        assert torch.equal(sa[i]["exp_avg"], sb[i]["exp_avg"]) and torch.equal(sa[i]["exp_avg_sq"], sb[i]["exp_avg_sq"])

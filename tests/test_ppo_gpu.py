@@ -146,3 +146,26 @@ def test_multicategorical_sample_kernel_distribution_and_log_prob():
     p = torch.softmax(row[0, :dims[0]], 0)
     freq = torch.bincount(a[:, 0], minlength=dims[0]).float() / a.shape[0]
     assert float((freq - p).abs().max()) < 4 * float((p * (1 - p) / a.shape[0]).sqrt().max()) + 1e-3
+
+
+def test_checkpoint_roundtrip_of_the_hip_train_state(tmp_path):
+    """SB3-zip save/load on the gfx950 train path: policy weights and the flat HIP Adam's moments / step survive
+    save(include_optimizer=True) -> load(), and training continues bit-identically from the checkpoint."""
+    from gennbv_amd.sb3 import save_util
+    fx = gu.load("F9_ppo_train")
+    a = _ppo_from_fixture(fx, device=DEV, backend="hip")
+    a.train()
+    path = str(tmp_path / "ck")
+    a.save(path, include_optimizer=True)
+    _, params, _, _ = save_util.load_from_zip_file(path)
+    assert set(params) == {"policy", "policy.optimizer"}
+    b = _ppo_from_fixture(fx, device=DEV, backend="hip")
+    b.set_parameters(path)
+    for (k, x), (_, y) in zip(a.policy.state_dict().items(), b.policy.state_dict().items()):
+        assert torch.equal(x, y), k
+    a.train()
+    b.train()  # builds its flat Adam from the loaded torch-format state
+    oa, ob = a._hip["opt"], b._hip["opt"]
+    assert int(oa.step_count) == int(ob.step_count) > 0
+    assert torch.equal(oa.exp_avg, ob.exp_avg) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq)
+    assert torch.equal(oa.params, ob.params)
