@@ -908,8 +908,12 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
     // zero the hit masks (OR-accumulated by atomics); the path masks only when they are
     // OR-accumulated too (several splits, or no LDS staging)
     const bool path_needs_zero = !lds_path || splits > 1;
-    err = (int)hipMemsetAsync(ws.hit, 0, (path_needs_zero ? 2 : 1) * (size_t)n * mask_bytes, st);
+    err = (int)hipMemsetAsync(ws.hit, 0, (size_t)n * mask_bytes, st);
     if (err) return err;
+    if (path_needs_zero) {
+        err = (int)hipMemsetAsync(ws.path, 0, (size_t)n * mask_bytes, st);  // (hit / path of an env RANGE are not adjacent)
+        if (err) return err;
+    }
     err = (int)hipMemsetAsync(coverage_count, 0, (size_t)n * sizeof(int32_t), st);
     if (err) return err;
     // launch 1: hit mask.  chunks: enough workgroups to cover the chip several times.
@@ -1010,21 +1014,22 @@ GNBV_API int gnbv_unpack_grid_bits(const uint32_t *bits, int n, int g, float *gr
     return gnbv_launch_status();
 }
 
-GNBV_API int gnbv_update_occ_grid_packed(const float *depth_raw, const float *seg_raw, const float *c2w, const float *inv_intri,
-                                         const float *poses_xyz, int64_t poses_row_stride, const float *range_gt,
-                                         const float *voxel_size, const uint32_t *gt_bits, const uint8_t *reset_mask, int n,
-                                         int h, int w, int g, float depth_sense_dist, float *prob_grid, uint32_t *scanned_bits,
-                                         float *tri_out, int64_t tri_row_stride, int32_t *coverage_count, void *workspace,
-                                         size_t workspace_bytes, void *stream)
+// one chain (hit mask -> ray cast -> grid update) over the env range [e0, e0 + n) of the batch
+static int update_packed_range(const float *depth_raw, const float *seg_raw, const float *c2w, const float *inv_intri,
+                               const float *poses_xyz, int64_t poses_row_stride, const float *range_gt, const float *voxel_size,
+                               const uint32_t *gt_bits, const uint8_t *reset_mask, int e0, int n, int h, int w, int g,
+                               float depth_sense_dist, float *prob_grid, uint32_t *scanned_bits, float *tri_out,
+                               int64_t tri_row_stride, int32_t *coverage_count, const VoxelWorkspace &full, hipStream_t st)
 {
-    GNBV_CHECK_ARG(depth_raw && seg_raw && c2w && inv_intri && poses_xyz && range_gt && voxel_size && gt_bits);
-    GNBV_CHECK_ARG(prob_grid && scanned_bits && tri_out && coverage_count && workspace);
-    GNBV_CHECK_ARG(n > 0 && h > 0 && w > 0 && g > 1 && g <= 1024 && poses_row_stride >= 3);
-    const int64_t g3 = (int64_t)g * g * g;
-    GNBV_CHECK_ARG(g3 < (1ll << 31) && tri_row_stride >= g3 && (int64_t)h * w < (1ll << 31));
-    GNBV_CHECK_ARG(workspace_bytes >= gnbv_voxel_workspace_bytes(n, g) && ((uintptr_t)workspace & 255) == 0);
-    hipStream_t st = gnbv_stream(stream);
-    VoxelWorkspace ws = carve(workspace, n, g);
+    const int64_t g3 = (int64_t)g * g * g, hw = (int64_t)h * w;
+    VoxelWorkspace ws = full;
+    ws.hit = full.hit + (size_t)e0 * full.words;
+    ws.path = full.path + (size_t)e0 * full.words;
+    depth_raw += e0 * hw; seg_raw += e0 * hw; c2w += (size_t)e0 * 16; poses_xyz += (size_t)e0 * poses_row_stride;
+    range_gt += (size_t)e0 * 6; voxel_size += (size_t)e0 * 3; gt_bits += (size_t)e0 * full.words;
+    if (reset_mask) reset_mask += e0;
+    prob_grid += (size_t)e0 * g3; scanned_bits += (size_t)e0 * full.words; tri_out += (size_t)e0 * tri_row_stride;
+    coverage_count += e0;
     int err = launch_masks(depth_raw, seg_raw, c2w, inv_intri, poses_xyz, poses_row_stride, range_gt, voxel_size, n, h, w, g,
                            depth_sense_dist, coverage_count, ws, st);
     if (err) return err;
@@ -1040,6 +1045,62 @@ GNBV_API int gnbv_update_occ_grid_packed(const float *depth_raw, const float *se
                            reset_mask, n, (int)g3, ws.words, ws.words, prob_grid, scanned_bits, tri_out, tri_row_stride,
                            coverage_count);
     return gnbv_launch_status();
+}
+
+// EXPERIMENT (GENNBV_VOXEL_CHAINS=2): the batch as two independent chains on two streams, so that the
+// HBM-bound grid update of one half overlaps the ALU-bound hit-mask / ray-cast launches of the other.
+struct VoxelSide {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool enabled = false, init = false;
+};
+static VoxelSide &voxel_side()
+{
+    static VoxelSide s;
+    if (!s.init) {
+        s.init = true;
+        const char *e = getenv("GENNBV_VOXEL_CHAINS");
+        if ((e && e[0] == '2') && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess)
+            s.enabled = true;
+    }
+    return s;
+}
+
+GNBV_API int gnbv_update_occ_grid_packed(const float *depth_raw, const float *seg_raw, const float *c2w, const float *inv_intri,
+                                         const float *poses_xyz, int64_t poses_row_stride, const float *range_gt,
+                                         const float *voxel_size, const uint32_t *gt_bits, const uint8_t *reset_mask, int n,
+                                         int h, int w, int g, float depth_sense_dist, float *prob_grid, uint32_t *scanned_bits,
+                                         float *tri_out, int64_t tri_row_stride, int32_t *coverage_count, void *workspace,
+                                         size_t workspace_bytes, void *stream)
+{
+    GNBV_CHECK_ARG(depth_raw && seg_raw && c2w && inv_intri && poses_xyz && range_gt && voxel_size && gt_bits);
+    GNBV_CHECK_ARG(prob_grid && scanned_bits && tri_out && coverage_count && workspace);
+    GNBV_CHECK_ARG(n > 0 && h > 0 && w > 0 && g > 1 && g <= 1024 && poses_row_stride >= 3);
+    const int64_t g3 = (int64_t)g * g * g;
+    GNBV_CHECK_ARG(g3 < (1ll << 31) && tri_row_stride >= g3 && (int64_t)h * w < (1ll << 31));
+    GNBV_CHECK_ARG(workspace_bytes >= gnbv_voxel_workspace_bytes(n, g) && ((uintptr_t)workspace & 255) == 0);
+    hipStream_t st = gnbv_stream(stream);
+    VoxelWorkspace ws = carve(workspace, n, g);
+    VoxelSide &side = voxel_side();
+    if (!side.enabled || n < 16) {
+        return update_packed_range(depth_raw, seg_raw, c2w, inv_intri, poses_xyz, poses_row_stride, range_gt, voxel_size, gt_bits,
+                                   reset_mask, 0, n, h, w, g, depth_sense_dist, prob_grid, scanned_bits, tri_out, tri_row_stride,
+                                   coverage_count, ws, st);
+    }
+    const int n0 = ((n / 2) + 7) & ~7;  // halves on 8-env boundaries (XCD mapping)
+    if (hipEventRecord(side.fork, st) != hipSuccess || hipStreamWaitEvent(side.stream, side.fork, 0) != hipSuccess) return (int)hipGetLastError();
+    int err = update_packed_range(depth_raw, seg_raw, c2w, inv_intri, poses_xyz, poses_row_stride, range_gt, voxel_size, gt_bits,
+                                  reset_mask, 0, n0, h, w, g, depth_sense_dist, prob_grid, scanned_bits, tri_out, tri_row_stride,
+                                  coverage_count, ws, st);
+    if (err) return err;
+    err = update_packed_range(depth_raw, seg_raw, c2w, inv_intri, poses_xyz, poses_row_stride, range_gt, voxel_size, gt_bits,
+                              reset_mask, n0, n - n0, h, w, g, depth_sense_dist, prob_grid, scanned_bits, tri_out, tri_row_stride,
+                              coverage_count, ws, side.stream);
+    if (err) return err;
+    if (hipEventRecord(side.join, side.stream) != hipSuccess || hipStreamWaitEvent(st, side.join, 0) != hipSuccess) return (int)hipGetLastError();
+    return 0;
 }
 
 GNBV_API int gnbv_unpack_masks(const void *workspace, int n, int g, uint8_t *hit_u8, uint8_t *path_u8, void *stream)
