@@ -63,6 +63,12 @@ class ReplayFeed:
                           c2w.contiguous())
 
     @staticmethod
+    def from_file(path: str, device, first: int = 0, count: Optional[int] = None):
+        """Frames of a recorded-feed container (env/feed_file.py), decoded on `device`."""
+        from . import feed_file
+        return feed_file.load_feed(feed_file.FeedFile(path), device, first, count)
+
+    @staticmethod
     def synthetic(scene: S.Scene, cfg: TaskConfig, num_frames: int, seed: int = 1, with_rgba: bool = True):
         frames = S.make_frames(scene, cfg, num_frames, seed=seed, with_rgba=with_rgba)
         return ReplayFeed.from_views(torch.stack([f.depth_raw for f in frames]), torch.stack([f.seg_raw for f in frames]),
@@ -71,6 +77,16 @@ class ReplayFeed:
 
 
 class ReplayFeedEnv:
+    @classmethod
+    def from_file(cls, cfg: TaskConfig, path: str, device="cuda:0", max_episode_length: Optional[int] = None):
+        """Env over a recorded-feed container: scene block + frames (env/feed_file.py)."""
+        import dataclasses
+
+        from . import feed_file
+        ff = feed_file.FeedFile(path)
+        cfg = dataclasses.replace(cfg, camera_height=ff.height, camera_width=ff.width, grid_size=ff.grid_size)
+        return cls(cfg, feed_file.load_scene(ff, "cpu"), feed_file.load_feed(ff, device), device, max_episode_length)
+
     def __init__(self, cfg: TaskConfig, scene: S.Scene, feed: ReplayFeed, device="cuda:0",
                  max_episode_length: Optional[int] = None):
         self.lib = _lib.load()

@@ -91,3 +91,33 @@ def test_replay_env_writes_into_caller_rows_and_tracks_episodes():
     np.testing.assert_allclose(ei["episode_reward"], np.mean(rew_host[-100:]), rtol=1e-6)
     np.testing.assert_allclose(ei["episode_length"], np.mean(len_host[-100:]), rtol=1e-6)
     assert int(env.ring_state.item()) == len(rew_host)
+
+
+@pytest.mark.parametrize("depth_dtype", ["f32", "f16"])
+def test_env_over_a_recorded_feed_file(tmp_path, depth_dtype):
+    """an env fed from the on-disk container (env/feed_file.py) steps exactly like one fed from the
+    same frames in memory (f32: identical tensors; f16: the in-memory feed is rounded the same way)."""
+    from gennbv_amd.env import feed_file as FF
+    from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
+    n, h, w, g = 5, 48, 64, 16
+    cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
+    scene = S.make_scenes(n, g, seed=4)
+    frames = S.make_frames(scene, cfg, 5, seed=4)
+    path = str(tmp_path / "rec.gnbv")
+    FF.record(path, scene, frames, S.inverse_intrinsics(h, w, cfg.horizontal_fov), depth_dtype=depth_dtype)
+    depth = torch.stack([f.depth_raw for f in frames])
+    if depth_dtype == "f16":
+        depth = depth.half().float()
+    mem = ReplayFeed.from_views(depth.to(DEV), torch.stack([f.seg_raw for f in frames]).to(DEV),
+                                torch.stack([f.rgba for f in frames]).to(DEV), torch.stack([f.view for f in frames]).to(DEV),
+                                scene.env_origins.to(DEV))
+    a_env = ReplayFeedEnv(cfg, scene, mem, DEV, max_episode_length=4)
+    b_env = ReplayFeedEnv.from_file(TaskConfig(), path, DEV, max_episode_length=4)
+    assert b_env.grid_size == g and b_env.num_envs == n
+    oa, ob = a_env.reset(), b_env.reset()
+    assert torch.equal(oa, ob)
+    gen = torch.Generator().manual_seed(1)
+    for _ in range(7):
+        act = S.sample_actions(n, cfg, gen).to(DEV)
+        ra, rb = a_env.step(act), b_env.step(act)
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and torch.equal(ra[2], rb[2])
