@@ -324,6 +324,16 @@ int gnbv_clip_adam_step(float *params, const float *grads, float *exp_avg, float
                         const float *kl_slot, float target_kl, float *norm_out, void *workspace, size_t workspace_bytes,
                         void *stream);
 
+/* ------------------------------------------------------------------------- */
+/* 8f.3  evaluation metric: reconstruction accuracy of Env_Eval_GenNBV          */
+/*       (gennbv/env/env_eval_gennbv.py:253-262): pytorch3d.loss.chamfer_distance */
+/*       (x[None], y[None])[0] with pytorch3d 0.7.8 defaults = mean_i min_j |x_i-y_j|^2 */
+/*       + mean_j min_i |x_i-y_j|^2 (squared distances).  x [n,3], y [m,3] fp32.  */
+/* ------------------------------------------------------------------------- */
+size_t gnbv_chamfer_workspace_bytes(int n, int m);
+int gnbv_chamfer_distance(const float *x, int n, const float *y, int m, float *out /*[1]*/, void *workspace,
+                          size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

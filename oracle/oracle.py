@@ -155,6 +155,37 @@ def gae_rsl(rewards, values, dones, last_values, gamma=0.99, lam=0.95):
     return ret, adv
 
 
+def chamfer_distance_ref(x, y, chunk=2048):
+    """TEST ORACLE, parity UNPINNED against the third-party library: pytorch3d (0.7.8, the version the reference's
+    README names) is not in this image.  Restates its documented definition of
+    `pytorch3d.loss.chamfer_distance(x[None], y[None])[0]` with default arguments (point_reduction="mean",
+    batch_reduction="mean", norm=2, both directions): mean_i min_j |x_i-y_j|^2 + mean_j min_i |x_i-y_j|^2,
+    as the reference uses it at gennbv/env/env_eval_gennbv.py:260-261.  float64 brute force."""
+    import numpy as np
+    x = np.asarray(x, np.float64)
+    y = np.asarray(y, np.float64)
+
+    def one_way(a, b):
+        out = np.empty(a.shape[0])
+        for s0 in range(0, a.shape[0], chunk):
+            d = a[s0:s0 + chunk, None, :] - b[None, :, :]
+            out[s0:s0 + chunk] = (d * d).sum(-1).min(1)
+        return out.mean()
+    return one_way(x, y) + one_way(y, x)
+
+
+def auc_update_ref(auc_rews, cur_rewards, cur_length, dones, episode_done_flag):
+    """AUC_update of the reference, env by env (stable_baselines3/common/evaluation.py:358-378)."""
+    import numpy as np
+    a = np.array(auc_rews, dtype=np.float32, copy=True)
+    for e in range(a.shape[0]):
+        if episode_done_flag[e]:
+            a[e, cur_length - 1] = a[e, cur_length - 2]
+        elif dones[e] == 0:
+            a[e, cur_length - 1] = cur_rewards[e]
+    return a
+
+
 # --------------------------------------------------------------------------- #
 # the REFERENCE's own kernel text compiled as host C++ (oracle/build_ref.py)
 # --------------------------------------------------------------------------- #

@@ -121,3 +121,47 @@ def test_env_over_a_recorded_feed_file(tmp_path, depth_dtype):
         act = S.sample_actions(n, cfg, gen).to(DEV)
         ra, rb = a_env.step(act), b_env.step(act)
         assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and torch.equal(ra[2], rb[2])
+
+
+def test_evaluate_policy_loop_on_the_replay_env():
+    """evaluation.py:136-355 for tensor envs: one episode per env, AUC of the per-step reward curve, accuracies."""
+    from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
+    from gennbv_amd.eval import evaluate_policy_grid_obs, mean_auc
+    n, h, w, g, L = 5, 48, 64, 16, 4
+    cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
+    scene = S.make_scenes(n, g, seed=3)
+    feed = ReplayFeed.synthetic(scene, cfg, 3, seed=3)
+    feed = ReplayFeed(feed.depth_raw.to(DEV), feed.seg_raw.to(DEV), feed.rgba.to(DEV), feed.c2w.to(DEV))
+    env = ReplayFeedEnv(cfg, scene, feed, DEV, max_episode_length=L)
+    gen = torch.Generator().manual_seed(0)
+    seen = []
+
+    class _Model:
+        @staticmethod
+        def policy(obs, deterministic=True):
+            a = S.sample_actions(n, cfg, gen).to(DEV)
+            return a, None, None
+
+    orig_step = env.step
+
+    def step(a):
+        out = orig_step(a)
+        seen.append((out[1].cpu().clone(), out[2].cpu().clone()))
+        return out
+    env.step = step
+    rews, lens, auc, acc = evaluate_policy_grid_obs(_Model, env, n_eval_episodes=n, max_length=L, accuracy_fn=lambda i: 10.0 + i)
+    assert len(rews) == len(lens) == len(acc) == n and auc.shape == (n,)
+    assert sorted(acc) == [10.0 + i for i in range(n)]
+    # host recomputation of the AUC curve from the recorded (reward, done) stream
+    curve, flag = torch.zeros(n, L), torch.zeros(n)
+    tot = torch.zeros(n)
+    for t, (r, d) in enumerate(seen[:L]):
+        for e in range(n):
+            if flag[e]:
+                curve[e, t] = curve[e, t - 1]
+            elif not d[e]:
+                curve[e, t] = r[e]
+        tot += r * (flag == 0)
+        flag += d.float()
+    assert torch.allclose(auc, mean_auc(curve))
+    assert all(1 <= x <= L for x in lens)

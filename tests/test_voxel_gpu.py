@@ -254,3 +254,22 @@ def test_special_depth_values_in_fused_path():
                                    scene.voxel_size.numpy(), scene.grid_gt.numpy(), prob, scan)
     assert tri.cpu().numpy().tobytes() == tri_o.tobytes()
     assert upd.prob_grid.cpu().numpy().tobytes() == prob.tobytes()
+
+
+@pytest.mark.parametrize("n,m", [(5000, 3000), (1, 1), (1025, 7), (3, 4097)])
+def test_chamfer_distance_vs_float64_brute_force(n, m):
+    """gnbv_chamfer_distance (eval accuracy, env_eval_gennbv.py:253-262 / pytorch3d definition) against the float64
+    oracle; tolerance = fp32 rounding of the squared distances (difference form, no cancellation)."""
+    from gennbv_amd.eval import metrics as M
+    from oracle import oracle
+    gen = torch.Generator().manual_seed(n * 31 + m)
+    x = (torch.rand(n, 3, generator=gen) - 0.5) * 16.0
+    y = x[torch.randint(0, n, (m,), generator=gen)] + 0.01 * torch.randn(m, 3, generator=gen) if n > 1 else torch.rand(m, 3, generator=gen)
+    ref = oracle.chamfer_distance_ref(x.numpy(), y.numpy())
+    got = float(M.chamfer_distance(x.to("cuda:0"), y.to("cuda:0")))
+    assert abs(got - ref) <= 2e-6 * max(ref, 1e-12) + 1e-12, (got, ref)
+    assert float(M.chamfer_distance(x.to("cuda:0"), x.to("cuda:0"))) == 0.0
+    # the accuracy metric: 1 cm rounding + unique + chamfer, x 100
+    acc = float(M.reconstruction_accuracy_cm(x.to("cuda:0"), y.to("cuda:0")))
+    xr = np.unique(np.round(x.numpy().astype(np.float32) * np.float32(100.0)) / np.float32(100.0), axis=0)
+    assert abs(acc - 100.0 * oracle.chamfer_distance_ref(xr, y.numpy())) <= 1e-4 * max(acc, 1e-9) + 1e-9
