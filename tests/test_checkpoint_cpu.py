@@ -90,3 +90,35 @@ def test_own_roundtrip_and_layout(tmp_path):
     assert len(sa) == len(sb) > 0
     for i in sa:
         assert torch.equal(sa[i]["exp_avg"], sb[i]["exp_avg"]) and torch.equal(sa[i]["exp_avg_sq"], sb[i]["exp_avg_sq"])
+
+
+def test_best_checkpoint_callback_protocol(tmp_path):
+    """gennbv/callback.py:25-70: periodic checkpoint at rollout end + `<prefix>_best_<key>` on a new maximum of the
+    mean episode-info value; driven through the hooks learn()/collect_rollouts() call."""
+    from collections import deque
+    from gennbv_amd.callback import BestCKPTCallback
+    saved = []
+
+    class _Model:
+        num_timesteps = 0
+        ep_info_buffer = deque(maxlen=100)
+        logger = type("L", (), {})()
+
+        def save(self, path):
+            saved.append(os.path.basename(path))
+
+    m = _Model()
+    cb = BestCKPTCallback(save_freq=4, save_path=str(tmp_path), name_prefix="gennbv", key_list=["episode_reward"])
+    cb.on_training_start({"self": m}, {})
+    for rollout, rew in enumerate([1.0, 3.0, 2.0]):
+        cb.on_rollout_start()
+        for _ in range(2):
+            m.num_timesteps += 8
+            cb.update_locals({})
+            assert cb.on_step() is True
+        m.ep_info_buffer.append({"episode_reward": torch.tensor(rew), "episode_length": 4.0})
+        cb.on_rollout_end()
+    cb.on_training_end()
+    # rollout 0: mean 1 -> best; rollout 1: n_calls = 4 -> periodic, mean 2 -> best; rollout 2: mean 2 -> no new best
+    assert saved == ["gennbv_best_episode_reward", "gennbv_32_steps", "gennbv_best_episode_reward"]
+    assert abs(cb.key_highest_value["episode_reward"] - 2.0) < 1e-6
