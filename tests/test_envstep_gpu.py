@@ -165,3 +165,54 @@ def test_evaluate_policy_loop_on_the_replay_env():
         flag += d.float()
     assert torch.allclose(auc, mean_auc(curve))
     assert all(1 <= x <= L for x in lens)
+
+
+def test_eval_env_accuracy_metric_and_five_tuple():
+    """Env_Eval_GenNBV protocol (env_eval_gennbv.py:104-111,:150-164,:253-263): 5-tuples, per-episode point
+    accumulation, accuracy = 100 x chamfer(unique(round(points, 2)), GT cloud) for the first finished episode of an env,
+    recomputed here from the same frames with the float64 oracle."""
+    from oracle import oracle as orc
+    from gennbv_amd import utils as U
+    from gennbv_amd.env.replay_feed import ReplayFeed
+    from gennbv_amd.env.replay_feed_eval import ReplayFeedEvalEnv, gt_cloud_from_grid
+    from gennbv_amd.eval import evaluate_policy_grid_obs
+    n, h, w, g, L = 3, 48, 64, 16, 3
+    cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
+    scene = S.make_scenes(n, g, seed=6)
+    feed = ReplayFeed.synthetic(scene, cfg, 4, seed=6)
+    feed = ReplayFeed(feed.depth_raw.to(DEV), feed.seg_raw.to(DEV), feed.rgba.to(DEV), feed.c2w.to(DEV))
+    env = ReplayFeedEvalEnv(cfg, scene, feed, DEV, max_episode_length=L)
+    out = env.reset()  # frame 0
+    assert len(out) == 5 and out[0].shape == (n, cfg.obs_dim) and out[4] == {}
+    gen = torch.Generator().manual_seed(0)
+    done_step = {}
+    for t in range(1, 8):  # step t consumes frame t % 4
+        o = env.step(S.sample_actions(n, cfg, gen).to(DEV))
+        assert len(o) == 5
+        for e in torch.nonzero(o[2]).flatten().tolist():
+            done_step.setdefault(e, t)
+        if len(done_step) == n:
+            break
+    assert set(env.ratios_accuracy) == {str(e) for e in range(n)}
+    kinv = S.inverse_intrinsics(h, w, cfg.horizontal_fov)
+    pc = gt_cloud_from_grid(scene.grid_gt, scene.range_gt, scene.voxel_size)
+    for e in range(n):
+        pts = []
+        for f in range(0, done_step[e] + 1):
+            d, s_ = U.post_process_depth(feed.depth_raw[f % 4], feed.seg_raw[f % 4])
+            pts.append(U.back_projection_fg(d, s_, feed.c2w[f % 4], kinv)[e])
+        cloud = torch.cat(pts, 0).cpu().numpy()
+        xr = np.unique(np.round(cloud.astype(np.float32) * np.float32(100.0)) / np.float32(100.0), axis=0)
+        ref = 100.0 * orc.chamfer_distance_ref(xr, pc[e].numpy())
+        assert abs(env.ratios_accuracy[str(e)] - ref) <= 1e-4 * ref + 1e-6, (e, env.ratios_accuracy[str(e)], ref)
+
+    # the evaluation loop consumes the 5-tuples
+    env2 = ReplayFeedEvalEnv(cfg, scene, ReplayFeed(feed.depth_raw, feed.seg_raw, feed.rgba, feed.c2w), DEV, max_episode_length=L)
+
+    class _Model:
+        @staticmethod
+        def policy(obs, deterministic=True):
+            return S.sample_actions(n, cfg, gen).to(DEV), None, None
+
+    rews, lens, auc, acc = evaluate_policy_grid_obs(_Model, env2, n_eval_episodes=n, max_length=L)
+    assert len(acc) == n and all(a > 0 for a in acc) and auc.shape == (n,)
