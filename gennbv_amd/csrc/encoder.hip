@@ -310,13 +310,17 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
 // workgroups fill their LDS with coalesced 16-byte loads instead of 6912 scattered 4-byte reads:
 //   fwd  image [(tap*4+s)*4+kq][n] = W2[co = n][ci = 4kq+s][tap]
 //   dgrad image [(tap*4+s)*4+kq][n] = W2[co = 4kq+s][ci = n][tap]
-__global__ void k_prep_w2(const float *__restrict__ W2, float *__restrict__ img_fwd, float *__restrict__ img_dgrad)
+__device__ __forceinline__ void prep_w2_element(int i, const float *__restrict__ W2, float *__restrict__ img_fwd, float *__restrict__ img_dgrad)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= kTaps * 256) return;
     const int n = i & 15, kq = (i >> 4) & 3, s = (i >> 6) & 3, tap = i >> 8;
     img_fwd[i] = W2[((size_t)n * kC + 4 * kq + s) * kTaps + tap];
     img_dgrad[i] = W2[((size_t)(4 * kq + s) * kC + n) * kTaps + tap];
+}
+
+__global__ void k_prep_w2(const float *__restrict__ W2, float *__restrict__ img_fwd, float *__restrict__ img_dgrad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < kTaps * 256) prep_w2_element(i, W2, img_fwd, img_dgrad);
 }
 
 __device__ __forceinline__ void fill_lds_image(float *lds, const float *__restrict__ img)
@@ -509,8 +513,11 @@ __global__ __launch_bounds__(1024) void k_stats_reduce(const float *__restrict__
                                                        float momentum, float *__restrict__ running_mean, float *__restrict__ running_var,
                                                        int64_t *__restrict__ num_batches_tracked, const int *__restrict__ skip_flag,
                                                        float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out,
-                                                       float *__restrict__ rstd_out)
+                                                       float *__restrict__ rstd_out, const float *__restrict__ W2, float *__restrict__ w2img)
 {
+    // (same launch, independent work) the two LDS weight images of the conv2 kernels: saves a dependent launch
+    if (W2 != nullptr)
+        for (int i = threadIdx.x; i < kTaps * 256; i += 1024) prep_w2_element(i, W2, w2img, w2img + kTaps * 256);
     // thread = (slice of P: 128) x (4 consecutive sums: 8); 8 independent 16-byte requests in flight
     __shared__ double sh[128][2 * kC];
     __shared__ double tot[2 * kC];
@@ -738,10 +745,12 @@ __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(2, 
 }
 
 // partial-sum layout [tap][ci][co] (+16) -> torch layout dW2 [co][ci][27], db2 [16]
+// (+ the conv2 weight images for the data-gradient kernel that follows: saves a dependent launch)
 __global__ void k_conv2_wgrad_finish(const double *__restrict__ tmp /*[slices][E]*/, int slices, float *__restrict__ dW2,
-                                     float *__restrict__ db2)
+                                     float *__restrict__ db2, const float *__restrict__ W2, float *__restrict__ w2img)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, E = kTaps * 256 + kC;
+    if (W2 != nullptr && i < kTaps * 256) prep_w2_element(i, W2, w2img, w2img + kTaps * 256);
     if (i >= E) return;
     double t = 0.0;
 #pragma unroll 8
@@ -1194,12 +1203,13 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     if (training)
         hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, st, w.bn_part, sample_plane_grid(batch, O1), (double *)nullptr,
                            (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps, p->momentum, p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag,
-                           bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC);
+                           bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, (const float *)nullptr, (float *)nullptr);
     else
         hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps, p->momentum,
                            p->bn1_rm, p->bn1_rv, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC);
     if ((err = gnbv_launch_status())) return err;
-    // conv2 (BN1 + ReLU on load; + BN2 statistics)
+    // conv2 (BN1 + ReLU on load; + BN2 statistics).  (Folding the weight-image prep into the single-workgroup
+    // k_stats_reduce was measured: +8.5 us there vs 6.3 us for this launch -- kept separate.)
     hipLaunchKernelGGL(k_prep_w2, dim3(kTaps), dim3(256), 0, st, p->w2, w.w2img, w.w2img + kTaps * 256);
     const int g2 = sample_plane_group_grid(batch, O2, kPlanesPerGroup);
     if (p->act_bf16) {
@@ -1212,7 +1222,8 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     if ((err = gnbv_launch_status())) return err;
     if (training)
         hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, st, w.bn_part, g2, (double *)nullptr, (double)batch * P2, p->bn2_w, p->bn2_b,
-                           p->eps, p->momentum, p->bn2_rm, p->bn2_rv, p->bn2_nbt, skip_flag, bn2, bn2 + kC, bn2 + 2 * kC, bn2 + 3 * kC);
+                           p->eps, p->momentum, p->bn2_rm, p->bn2_rv, p->bn2_nbt, skip_flag, bn2, bn2 + kC, bn2 + 2 * kC, bn2 + 3 * kC,
+                           (const float *)nullptr, (float *)nullptr);
     else
         hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, (double)batch * P2, p->bn2_w, p->bn2_b, p->eps, p->momentum, p->bn2_rm,
                            p->bn2_rv, bn2, bn2 + kC, bn2 + 2 * kC, bn2 + 3 * kC);
@@ -1295,14 +1306,16 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     const int E2 = kTaps * 256 + kC;
     const int sl2 = reduce_stage1(w.wg_part, wg_blocks, E2, w.tmp, sw);  // <= 16 slices: tmp[0, 16 E2)
     if ((err = gnbv_launch_status())) return err;
-    hipLaunchKernelGGL(k_conv2_wgrad_finish, dim3((E2 + 255) / 256), dim3(256), 0, sw, (const double *)w.tmp, sl2, g->w2, g->b2);
+    // (the weight images ride in the finish launch unless it runs on the side stream)
+    hipLaunchKernelGGL(k_conv2_wgrad_finish, dim3((E2 + 255) / 256), dim3(256), 0, sw, (const double *)w.tmp, sl2, g->w2, g->b2,
+                       side.enabled ? (const float *)nullptr : p->w2, w.w2img);
     if ((err = gnbv_launch_status())) return err;
     if (side.enabled && hipEventRecord(side.join, sw) != hipSuccess) return (int)hipGetLastError();
     // the conv1 weight gradient (main stream) uses its own partial / slice regions of the workspace
     float *wg1_part = w.wg_part + (size_t)512 * E2;
     double *tmp1 = w.tmp + (size_t)32 * E2;
     // ---- conv2 data gradient (+ ReLU1 mask, BN1 backward sums) ----
-    hipLaunchKernelGGL(k_prep_w2, dim3(kTaps), dim3(256), 0, st, p->w2, w.w2img, w.w2img + kTaps * 256);
+    if (side.enabled) hipLaunchKernelGGL(k_prep_w2, dim3(kTaps), dim3(256), 0, st, p->w2, w.w2img, w.w2img + kTaps * 256);
     const int gd = sample_plane_group_grid(batch, (O1 + 1) / 2, kPlanesPerGroup);  // groups of plane PAIRS
     if (p->act_bf16) {
         hipLaunchKernelGGL(k_conv2_dgrad<ActBF16>, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const uint16_t *)y1, bn1, bn1 + kC, bn1 + 2 * kC,
@@ -1315,7 +1328,7 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     double *S1 = w.red + 192;
     hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, st, w.bn_part, gd, S1, 0.0, (const float *)nullptr, (const float *)nullptr, 0.0f,
                        0.0f, (float *)nullptr, (float *)nullptr, (int64_t *)nullptr, (const int *)nullptr, (float *)nullptr, (float *)nullptr,
-                       (float *)nullptr, (float *)nullptr);
+                       (float *)nullptr, (float *)nullptr, (const float *)nullptr, (float *)nullptr);
     if ((err = gnbv_launch_status())) return err;
     // ---- conv1 weight gradient (BN1 backward fused) ----
     int nrows1 = batch * O1 * O1;

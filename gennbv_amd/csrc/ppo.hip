@@ -276,48 +276,63 @@ __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, 
 // ---------------------------------------------------------------------------
 // Rollout side of MultiCategoricalDistribution (stable_baselines3/common/distributions.py:299-352 as used
 // by ActorCriticPolicy.forward, policies.py:1024-1030): sample() + log_prob() of the sampled action in
-// ONE launch instead of ~25 element-wise / reduction kernels per head.  thread = (row, head): log-sum-exp
-// of the head's logits, then the inverse CDF of softmax at u[row][head] in [0, 1) (deterministic: the
-// first arg-max, torch.argmax semantics); the row's log-prob is the sum over heads in head order.
+// ONE launch instead of ~25 element-wise / reduction kernels per head.  wave = row: log-sum-exp of each head's
+// logits, then the inverse CDF of softmax at u[row][head] in [0, 1) (deterministic: the first arg-max,
+// torch.argmax semantics); the row's log-prob is the sum over heads in head order.
 // ---------------------------------------------------------------------------
 struct SampleArgs {
     int batch, n_logits, n_heads, deterministic;
     int head_dims[kMaxHeads], head_off[kMaxHeads];
 };
 
-__global__ __launch_bounds__(64) void k_multicategorical_sample(SampleArgs a, const float *__restrict__ logits, const float *__restrict__ uniforms,
-                                                                int64_t *__restrict__ actions, float *__restrict__ log_prob)
+// one WAVE per row: lanes stride over a head's logits (wave-parallel max / sum-exp, inclusive scan for the CDF)
+__global__ __launch_bounds__(256) void k_multicategorical_sample(SampleArgs a, const float *__restrict__ logits, const float *__restrict__ uniforms,
+                                                                 int64_t *__restrict__ actions, float *__restrict__ log_prob)
 {
-    __shared__ float lp[8][kMaxHeads];
-    const int h = threadIdx.x & 7, r = threadIdx.x >> 3, b = blockIdx.x * 8 + r;
-    if (b < a.batch && h < a.n_heads) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= a.batch) return;
+    float lp = 0.0f;
+    for (int h = 0; h < a.n_heads; ++h) {
         const float *row = logits + (size_t)b * a.n_logits + a.head_off[h];
         const int d = a.head_dims[h];
-        float mx = row[0];
-        int amax = 0;
-        for (int i = 1; i < d; ++i)
-            if (row[i] > mx) { mx = row[i]; amax = i; }
+        // max and first arg-max (torch.argmax semantics: lowest index among equals)
+        float mx = -INFINITY;
+        int amax = 0x7fffffff;
+        for (int j = lane; j < d; j += 64) {
+            const float v = row[j];
+            if (v > mx) { mx = v; amax = j; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float om = __shfl_xor(mx, o, 64);
+            const int oa = __shfl_xor(amax, o, 64);
+            if (om > mx || (om == mx && oa < amax)) { mx = om; amax = oa; }
+        }
         float s = 0.0f;
-        for (int i = 0; i < d; ++i) s += expf(row[i] - mx);
+        for (int j = lane; j < d; j += 64) s += expf(row[j] - mx);
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         int act = amax;
         if (!a.deterministic) {
+            // inverse CDF: first index whose inclusive prefix sum of exp(l - max) exceeds u * sum
             const float target = uniforms[(size_t)b * a.n_heads + h] * s;
-            float c = 0.0f;
+            float carry = 0.0f;
             act = d - 1;
-            for (int i = 0; i < d; ++i) {
-                c += expf(row[i] - mx);
-                if (c > target) { act = i; break; }
+            for (int j0 = 0; j0 < d; j0 += 64) {
+                const int j = j0 + lane;
+                float c = j < d ? expf(row[j] - mx) : 0.0f;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const float up = __shfl_up(c, o, 64);
+                    if (lane >= o) c += up;
+                }
+                c += carry;
+                const unsigned long long hit = __ballot(j < d && c > target);
+                if (hit) { act = j0 + __ffsll((long long)hit) - 1; break; }
+                carry = __shfl(c, 63, 64);
             }
         }
-        actions[(size_t)b * a.n_heads + h] = act;
-        lp[r][h] = row[act] - (mx + logf(s));
+        if (lane == 0) actions[(size_t)b * a.n_heads + h] = act;
+        lp += row[act] - (mx + logf(s));
     }
-    __syncthreads();
-    if (b < a.batch && h == 0) {
-        float t = lp[r][0];
-        for (int k = 1; k < a.n_heads; ++k) t += lp[r][k];
-        log_prob[b] = t;
-    }
+    if (lane == 0) log_prob[b] = lp;
 }
 
 // ===========================================================================
@@ -391,6 +406,6 @@ GNBV_API int gnbv_multicategorical_sample(const float *logits, int batch, int n_
         }
     }
     GNBV_CHECK_ARG(off == n_logits);
-    hipLaunchKernelGGL(k_multicategorical_sample, dim3((batch + 7) / 8), dim3(64), 0, gnbv_stream(stream), a, logits, uniforms, actions, log_prob);
+    hipLaunchKernelGGL(k_multicategorical_sample, dim3((batch + 3) / 4), dim3(256), 0, gnbv_stream(stream), a, logits, uniforms, actions, log_prob);
     return gnbv_launch_status();
 }

@@ -1,13 +1,13 @@
 """Timeline of ONE PPO minibatch step out of a rocprofv3 kernel-trace database: every kernel between two
-consecutive k_gather_minibatch launches, with start offset, duration and queue/stream id, plus the
+consecutive launches of a marker kernel (default k_ppo_logp: once per minibatch), with start offset, duration and queue/stream id, plus the
 per-queue busy time and the union (critical-path) time.
 
-    python tools/rocprof_timeline.py <dir-or-db> [which-minibatch=200] [marker-kernel-prefix=k_gather_minibatch]
+    python tools/rocprof_timeline.py <dir-or-db> [which-minibatch=200] [marker-kernel-prefix=k_ppo_logp]
 """
 import glob, os, sqlite3, sys
 
 
-def main(path, which=200, marker="k_gather_minibatch"):
+def main(path, which=200, marker="k_ppo_logp"):
     if os.path.isdir(path):
         path = sorted(glob.glob(os.path.join(path, "**", "*_results.db"), recursive=True))[-1]
     db = sqlite3.connect(path)
@@ -42,4 +42,4 @@ def main(path, which=200, marker="k_gather_minibatch"):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 200, sys.argv[3] if len(sys.argv) > 3 else "k_gather_minibatch")
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 200, sys.argv[3] if len(sys.argv) > 3 else "k_ppo_logp")
