@@ -199,6 +199,65 @@ def ppo_loss_delta(args, device):
             "abs_delta": deltas, "max_abs_delta": max(deltas.values()), "tolerance": 1e-4}
 
 
+def encoder_roofline(algo, args, device, iters: int = 20):
+    """Second roofline object: the conv stack of the PPO update (conv1/conv2 forward + backward through the C-ABI,
+    csrc/encoder.hip) at the minibatch size, timed live with events on the launch stream, priced against BOTH roofs:
+    fp32 MFMA (157 TFLOP/s dense) and HBM (8 TB/s).  Algorithmic figures per minibatch of B samples at grid G
+    (DESIGN.md section 4): flops = 3 x 2 x B x (27*16*o1^3 + 432*16*o2^3) (forward + two backward contractions);
+    bytes = x (R fwd, R wgrad) + y1 (W, 3 R) + dz1 (W, R) + y2-sized tensors."""
+    import torch
+    from gennbv_amd.ops import encoder_ops
+    enc = algo.policy.features_extractor
+    if getattr(enc, "backend", "") != "hip":
+        return None
+    b, g = args.batch_size, args.grid
+    o1 = (g - 3) // 2 + 1
+    o2 = (o1 - 3) // 2 + 1
+    buf = algo.rollout_buffer
+    t, n = buf.buffer_size, buf.n_envs
+    rows = torch.randint(0, t * n, (b,), device=device, dtype=torch.int64)
+    base = buf.observations[:t].view(t * n, -1)
+    s_dim = enc.state_input_shape[0]
+    was_training = enc.training
+    enc.train(True)
+    seq = enc.naive_encoder_grid
+    stats = [(m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone()) for m in (seq[1], seq[4])]
+    grads = [p.grad for p in seq.parameters()]
+    for p_ in seq.parameters():
+        p_.grad = None
+
+    def step():
+        f = encoder_ops.grid_encoder(base, rows, s_dim, g, seq, True)
+        f.backward(torch.ones_like(f))
+
+    for _ in range(3):
+        step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    for m, (rm, rv, nb) in zip((seq[1], seq[4]), stats):  # leave the policy exactly as it was
+        m.running_mean.copy_(rm); m.running_var.copy_(rv); m.num_batches_tracked.copy_(nb)
+    for p_, g_ in zip(seq.parameters(), grads):
+        p_.grad = g_
+    enc.train(was_training)
+    flops = 3 * 2 * b * (27 * 16 * o1 ** 3 + 432 * 16 * o2 ** 3)
+    y1 = b * o1 ** 3 * 16 * 4
+    x = b * g ** 3 * 4
+    y2 = b * o2 ** 3 * 16 * 4
+    nbytes = 2 * x + 4 * y1 + 2 * y1 + 8 * y2
+    tf, gbs = flops / (ms * 1e-3) / 1e12, nbytes / (ms * 1e-3) / 1e9
+    return {"kernel": "conv stack of one PPO minibatch: gnbv_encoder_grid_forward + _backward (k_conv1_fwd_lds, k_conv2_fwd, "
+                      "k_conv2_wgrad, k_conv2_dgrad, k_conv1_wgrad_lds + BN/reduction launches)",
+            "ms": ms, "batch": b, "algorithmic_flops": flops, "algorithmic_bytes": nbytes,
+            "mfma": {"achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "dtype": "f32"},
+            "hbm": {"achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0}}
+
+
 def _flush_c_stdio():
     """RCCL writes a version banner with printf; flush it so that it cannot land after the JSON line."""
     import ctypes
@@ -286,6 +345,10 @@ def main():
                      "launch_ms": vox_ms, "algorithmic_bytes_per_launch": args.envs * b_vox, "traffic": traffic},
     }
     if rank == 0:
+        try:
+            out["encoder_roofline"] = encoder_roofline(algo, args, device)
+        except Exception as ex:
+            out["encoder_roofline"] = {"error": repr(ex)}
         try:
             out["ppo_loss_delta_vs_ref"] = ppo_loss_delta(args, device)
         except Exception as ex:
