@@ -27,7 +27,7 @@ def _obs(b, g, seed=0):
     return o.to(DEV)
 
 
-@pytest.mark.parametrize("g,b", [(20, 8), (16, 5), (33, 3), (64, 4)])
+@pytest.mark.parametrize("g,b", [(20, 8), (16, 5), (33, 3), (64, 4), (128, 1)])
 def test_encoder_forward_backward_vs_torch_reference(g, b):
     """Reference = the same torch modules in fp64 on the CPU (ground truth), tolerance = fp32 round-off.
     (torch-GPU fp32 is NOT used as the reference: MIOpen's conv/BN backward is off by 0.7-4.6 % at
