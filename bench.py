@@ -340,7 +340,7 @@ def main():
                    "breakdown_ms_per_step": {"rollout": phases["rollout"].total_ms() / args.steps,
                                              "train": phases["train"].total_ms() / args.steps,
                                              "voxel_update_total": vox.total_ms() / args.steps}},
-        "roofline": {"bound": "hbm", "kernel": "gnbv_update_occ_grid (k_hit_mask + k_raycast + k_grid_update)",
+        "roofline": {"bound": "hbm", "kernel": "gnbv_update_occ_grid_coded (k_hit_mask + k_raycast + k_grid_update_coded; 1-byte coded probability grid)",
                      "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                      "launch_ms": vox_ms, "algorithmic_bytes_per_launch": args.envs * b_vox, "traffic": traffic},
     }

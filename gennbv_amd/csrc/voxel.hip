@@ -633,6 +633,100 @@ __global__ __launch_bounds__(kGridThreads) void k_grid_update_packed(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Coded variant: prob_grid as ONE BYTE per voxel.  Between two resets a voxel's probability is the result of
+// "set to 1.0 on a hit" and "x <- fl32(x - 0.05) on a path step" (env_train_gennbv.py:305-312), i.e. a pure
+// function of (base, k): base = 1 after a hit / 0 since the reset, k = path steps since then.
+//   code = base << 7 | k   (k <= 127: an episode is at most max_episode_length <= 127 steps; saturation sets
+//   *overflow).  value = prob_lut[code] (exact fp32 iteration, gnbv_prob_code_tables), tri = tri_lut[code].
+// Traffic per voxel: code R+W (2 B) + tri W (4 B) + mask bits, instead of 12 B: the grid update is HBM-bound.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t step_code(uint32_t c, bool hit, bool path, int &ovf)
+{
+    if (path) {
+        const uint32_t k = c & 127u;
+        if (k == 127u) ovf = 1;
+        c = (c & 128u) | (k < 127u ? k + 1u : 127u);
+    }
+    if (hit) c = 128u;
+    return c;
+}
+
+template <bool VEC16>
+__global__ __launch_bounds__(kGridThreads) void k_grid_update_coded(
+    const uint32_t *__restrict__ hit_mask, const uint32_t *__restrict__ path_mask, const uint32_t *__restrict__ gt_bits,
+    const uint8_t *__restrict__ reset_mask, int n, int g3, int words, int words_gt, uint8_t *__restrict__ prob_code,
+    const float *__restrict__ tri_lut, uint32_t *__restrict__ scanned_bits, float *__restrict__ tri_out, int64_t tri_stride,
+    int32_t *__restrict__ coverage, int32_t *__restrict__ overflow)
+{
+    __shared__ float lut[256];
+    __shared__ int s_cov[kGridThreads / kWave];
+    for (int i = threadIdx.x; i < 256; i += kGridThreads) lut[i] = tri_lut[i];
+    __syncthreads();
+    const int e = blockIdx.y;
+    const bool reset = reset_mask != nullptr && reset_mask[e] != 0;
+    const uint32_t *hm = hit_mask + (size_t)e * words, *pm = path_mask + (size_t)e * words;
+    const uint32_t *gb = gt_bits + (size_t)e * words_gt;
+    uint32_t *sb = scanned_bits + (size_t)e * words_gt;
+    uint8_t *code = prob_code + (size_t)e * g3;
+    float *tri = tri_out + (size_t)e * tri_stride;
+    int cov = 0, ovf = 0;
+    if (VEC16) {  // (4 voxels per lane and trip: one 4-byte code word in, one 16-byte tri vector out, both coalesced)
+        const int nv = g3 >> 2;
+        for (int i = blockIdx.x * kGridThreads + threadIdx.x; i < nv; i += gridDim.x * kGridThreads) {
+            const int v0 = i << 2, wd = v0 >> 5, sh = v0 & 31;
+            const uint32_t hw = hm[wd], pw = pm[wd];
+            const uint32_t hb = (hw >> sh) & 0xFu, pb = (pw >> sh) & 0xFu;
+            const uint32_t cw = reset ? 0u : reinterpret_cast<const uint32_t *>(code)[i];
+            uint32_t out = 0;
+            float4 t4;
+            float *tp = &t4.x;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t c = step_code((cw >> (8 * b)) & 255u, (hb >> b) & 1u, (pb >> b) & 1u, ovf);
+                out |= c << (8 * b);
+                tp[b] = lut[c];
+            }
+            reinterpret_cast<uint32_t *>(code)[i] = out;
+            reinterpret_cast<float4 *>(tri)[i] = t4;
+            if (sh == 0) {  // one lane in eight owns the 32-voxel word of the scanned set
+                const uint32_t sw = (reset ? 0u : sb[wd]) | (hw & gb[wd]);
+                sb[wd] = sw;
+                cov += __popc(sw);
+            }
+        }
+    } else {
+        for (int v = blockIdx.x * kGridThreads + threadIdx.x; v < g3; v += gridDim.x * kGridThreads) {
+            const int wd = v >> 5;
+            const uint32_t hw = hm[wd];
+            const bool hb = (hw >> (v & 31)) & 1u, pb = (pm[wd] >> (v & 31)) & 1u;
+            const uint32_t c = step_code(reset ? 0u : code[v], hb, pb, ovf);
+            code[v] = (uint8_t)c;
+            tri[v] = lut[c];
+            if ((v & 31) == 0) {
+                const uint32_t sw = (reset ? 0u : sb[wd]) | (hw & gb[wd]);
+                sb[wd] = sw;
+                cov += __popc(sw);
+            }
+        }
+    }
+    if (ovf && overflow != nullptr) *overflow = 1;
+    cov = wave_reduce_sum(cov);
+    if ((threadIdx.x & (kWave - 1)) == 0) s_cov[threadIdx.x / kWave] = cov;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < kGridThreads / kWave; ++i) t += s_cov[i];
+        if (t) atomicAdd(&coverage[e], t);
+    }
+}
+
+__global__ void k_decode_prob(const uint8_t *__restrict__ code, int64_t count, const float *__restrict__ prob_lut, float *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) out[i] = prob_lut[code[i]];
+}
+
 // f32 grid [N, G^3] -> bitmask [N, words] (bit = value != 0); *not_binary is set when a value is
 // neither 0 nor 1.  One wave-ballot per 64 voxels.
 __global__ void k_pack_bits(const float *__restrict__ grid, int n, int g3, int words, uint32_t *__restrict__ bits, int *__restrict__ not_binary)
@@ -1101,6 +1195,59 @@ GNBV_API int gnbv_update_occ_grid_packed(const float *depth_raw, const float *se
     if (err) return err;
     if (hipEventRecord(side.join, side.stream) != hipSuccess || hipStreamWaitEvent(st, side.join, 0) != hipSuccess) return (int)hipGetLastError();
     return 0;
+}
+
+// host helper: the two 256-entry tables of the coded probability grid, by the exact fp32 iteration of the reference
+// update (x <- x - 0.05f from base 0 / 1): prob_lut[code] = value, tri_lut[code] = (value > 0.5) - (value < 0)
+GNBV_API void gnbv_prob_code_tables(float *prob_lut, float *tri_lut)
+{
+    for (int base = 0; base < 2; ++base) {
+        volatile float x = (float)base;
+        for (int k = 0; k < 128; ++k) {
+            const float v = x;
+            if (prob_lut) prob_lut[base * 128 + k] = v;
+            if (tri_lut) tri_lut[base * 128 + k] = (v > 0.5f ? 1.0f : 0.0f) - (v < 0.0f ? 1.0f : 0.0f);
+            x = v - 0.05f;
+        }
+    }
+}
+
+GNBV_API int gnbv_decode_prob_grid(const uint8_t *prob_code, int64_t count, const float *prob_lut, float *prob_out, void *stream)
+{
+    GNBV_CHECK_ARG(prob_code && prob_lut && prob_out && count >= 0);
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(k_decode_prob, dim3(grid_for(count, 256)), dim3(256), 0, gnbv_stream(stream), prob_code, count, prob_lut, prob_out);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_update_occ_grid_coded(const float *depth_raw, const float *seg_raw, const float *c2w, const float *inv_intri,
+                                        const float *poses_xyz, int64_t poses_row_stride, const float *range_gt,
+                                        const float *voxel_size, const uint32_t *gt_bits, const uint8_t *reset_mask, int n,
+                                        int h, int w, int g, float depth_sense_dist, uint8_t *prob_code, const float *tri_lut,
+                                        uint32_t *scanned_bits, float *tri_out, int64_t tri_row_stride, int32_t *coverage_count,
+                                        int32_t *overflow, void *workspace, size_t workspace_bytes, void *stream)
+{
+    GNBV_CHECK_ARG(depth_raw && seg_raw && c2w && inv_intri && poses_xyz && range_gt && voxel_size && gt_bits);
+    GNBV_CHECK_ARG(prob_code && tri_lut && scanned_bits && tri_out && coverage_count && workspace);
+    GNBV_CHECK_ARG(n > 0 && h > 0 && w > 0 && g > 1 && g <= 1024 && poses_row_stride >= 3);
+    const int64_t g3 = (int64_t)g * g * g;
+    GNBV_CHECK_ARG(g3 < (1ll << 31) && tri_row_stride >= g3 && (int64_t)h * w < (1ll << 31));
+    GNBV_CHECK_ARG(workspace_bytes >= gnbv_voxel_workspace_bytes(n, g) && ((uintptr_t)workspace & 255) == 0);
+    hipStream_t st = gnbv_stream(stream);
+    VoxelWorkspace ws = carve(workspace, n, g);
+    int err = launch_masks(depth_raw, seg_raw, c2w, inv_intri, poses_xyz, poses_row_stride, range_gt, voxel_size, n, h, w, g,
+                           depth_sense_dist, coverage_count, ws, st);
+    if (err) return err;
+    const bool vec16 = (g3 % 4 == 0) && (tri_row_stride % 4 == 0) && (((uintptr_t)tri_out & 15) == 0) &&
+                       (((uintptr_t)prob_code & 3) == 0);
+    const int bx = grid_update_blocks(vec16 ? g3 / 4 : g3, n);
+    if (vec16)
+        hipLaunchKernelGGL(k_grid_update_coded<true>, dim3(bx, n), dim3(kGridThreads), 0, st, ws.hit, ws.path, gt_bits, reset_mask, n,
+                           (int)g3, ws.words, ws.words, prob_code, tri_lut, scanned_bits, tri_out, tri_row_stride, coverage_count, overflow);
+    else
+        hipLaunchKernelGGL(k_grid_update_coded<false>, dim3(bx, n), dim3(kGridThreads), 0, st, ws.hit, ws.path, gt_bits, reset_mask, n,
+                           (int)g3, ws.words, ws.words, prob_code, tri_lut, scanned_bits, tri_out, tri_row_stride, coverage_count, overflow);
+    return gnbv_launch_status();
 }
 
 GNBV_API int gnbv_unpack_masks(const void *workspace, int n, int g, uint8_t *hit_u8, uint8_t *path_u8, void *stream)

@@ -103,7 +103,8 @@ class ReplayFeedEnv:
         dev = self.device
         self.updater = OccupancyGridUpdater(n, cfg.grid_size, cfg.camera_height, cfg.camera_width,
                                             S.inverse_intrinsics(cfg.camera_height, cfg.camera_width, cfg.horizontal_fov),
-                                            scene.range_gt, scene.voxel_size, scene.grid_gt, dev, cfg.depth_sense_dist)
+                                            scene.range_gt, scene.voxel_size, scene.grid_gt, dev, cfg.depth_sense_dist,
+                                            max_steps_between_resets=self.max_episode_length + 1)  # (+1: the reset observation)
         self.num_valid_voxel_gt = scene.num_valid_voxel_gt.to(dev, torch.float32).contiguous()
         # spaces (update_observation_space :459-492 flattened by the wrapper :59-88)
         self.action_space = MultiDiscrete(cfg.action_nvec)

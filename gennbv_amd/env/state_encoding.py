@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 
 from .. import _lib
@@ -22,7 +24,8 @@ from .. import _lib
 class OccupancyGridUpdater:
     def __init__(self, num_envs: int, grid_size: int, camera_height: int, camera_width: int,
                  inv_intri: torch.Tensor, range_gt: torch.Tensor, voxel_size_gt: torch.Tensor, grid_gt: torch.Tensor,
-                 device, depth_sense_dist: float = -50.0, packed: Optional[bool] = None):
+                 device, depth_sense_dist: float = -50.0, packed: Optional[bool] = None,
+                 max_steps_between_resets: Optional[int] = None):
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -36,7 +39,8 @@ class OccupancyGridUpdater:
         self.voxel_size_gt = voxel_size_gt.to(self.device, torch.float32).contiguous()
         self.grid_gt = grid_gt.to(self.device, torch.float32).contiguous()
         assert self.grid_gt.shape == (num_envs, g, g, g)
-        self.prob_grid = torch.zeros(num_envs, g, g, g, dtype=torch.float32, device=self.device)
+        self.coded = False
+        self._prob_f32 = torch.zeros(num_envs, g, g, g, dtype=torch.float32, device=self.device)
         # Binary ground truth (the reference's GT is an occupancy indicator): keep grid_gt and the
         # scanned set as bitmasks -- identical results, half the HBM traffic of the streaming pass.
         words = self.lib.gnbv_grid_bit_words(g)
@@ -47,13 +51,41 @@ class OccupancyGridUpdater:
         binary = int(flag.item()) == 0
         self.packed = binary if packed is None else (bool(packed) and binary)
         self.scanned_bits = torch.zeros(num_envs, words, dtype=torch.int32, device=self.device)
-        self._scanned_f32 = None if self.packed else torch.zeros_like(self.prob_grid)
+        self._scanned_f32 = None if self.packed else torch.zeros_like(self._prob_f32)
         self.coverage_count = torch.zeros(num_envs, dtype=torch.int32, device=self.device)
         nbytes = self.lib.gnbv_voxel_workspace_bytes(num_envs, g)
         # torch's caching allocator returns >=512-byte aligned blocks
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         assert self.workspace.data_ptr() % 256 == 0
         self._own_tri = None
+        # Coded probability grid (1 byte per voxel, exact): only when the GT is binary (packed mode) and the caller
+        # guarantees that no voxel sees more than 127 path steps between two resets (episode length <= 127).
+        self.coded = bool(self.packed and max_steps_between_resets is not None and 0 < int(max_steps_between_resets) <= 127
+                          and os.environ.get("GENNBV_PROB_CODED", "1") != "0")
+        if self.coded:
+            import ctypes as C
+            pl, tl = (C.c_float * 256)(), (C.c_float * 256)()
+            self.lib.gnbv_prob_code_tables(pl, tl)
+            self._prob_lut = torch.tensor(list(pl), dtype=torch.float32, device=self.device)
+            self._tri_lut = torch.tensor(list(tl), dtype=torch.float32, device=self.device)
+            self.prob_code = torch.zeros(num_envs, g ** 3, dtype=torch.uint8, device=self.device)
+            self.code_overflow = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._prob_f32 = None
+
+    @property
+    def prob_grid(self) -> torch.Tensor:
+        """The reference's fp32 [N,G,G,G] probability grid (env_train_gennbv.py:180-181); in coded mode it is
+        decoded from the byte codes on demand (and the saturation flag is checked)."""
+        if not self.coded:
+            return self._prob_f32
+        if int(self.code_overflow.item()) != 0:
+            raise _lib.GennbvHipError("coded probability grid: a voxel saw more than 127 path steps between resets "
+                                      "(pass a correct max_steps_between_resets or GENNBV_PROB_CODED=0)")
+        n, g = self.num_envs, self.grid_size
+        out = torch.empty(n, g, g, g, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.gnbv_decode_prob_grid(self.prob_code.data_ptr(), out.numel(), self._prob_lut.data_ptr(), out.data_ptr(),
+                                                  _lib.stream_ptr(self.device)), "gnbv_decode_prob_grid")
+        return out
 
     def update(self, depth_raw: torch.Tensor, seg_raw: torch.Tensor, c2w: torch.Tensor, poses: torch.Tensor,
                reset_mask: Optional[torch.Tensor] = None, tri_out: Optional[torch.Tensor] = None,
@@ -74,12 +106,21 @@ class OccupancyGridUpdater:
             tri_out, tri_row_stride = self._own_tri, g ** 3
         if reset_mask is not None:
             assert reset_mask.dtype == torch.uint8 and reset_mask.is_contiguous()
+        if self.coded:
+            _lib.check(self.lib.gnbv_update_occ_grid_coded(
+                depth_raw.data_ptr(), seg_raw.data_ptr(), c2w.data_ptr(), self.inv_intri_host.data_ptr(),
+                poses.data_ptr(), poses.stride(0), self.range_gt.data_ptr(), self.voxel_size_gt.data_ptr(),
+                self.gt_bits.data_ptr(), _lib.ptr(reset_mask), n, self.h, self.w, g, self.depth_sense_dist,
+                self.prob_code.data_ptr(), self._tri_lut.data_ptr(), self.scanned_bits.data_ptr(), tri_out.data_ptr(),
+                int(tri_row_stride), self.coverage_count.data_ptr(), self.code_overflow.data_ptr(), self.workspace.data_ptr(),
+                self.workspace.numel(), _lib.stream_ptr(self.device)), "gnbv_update_occ_grid_coded")
+            return tri_out
         if self.packed:
             _lib.check(self.lib.gnbv_update_occ_grid_packed(
                 depth_raw.data_ptr(), seg_raw.data_ptr(), c2w.data_ptr(), self.inv_intri_host.data_ptr(),
                 poses.data_ptr(), poses.stride(0), self.range_gt.data_ptr(), self.voxel_size_gt.data_ptr(),
                 self.gt_bits.data_ptr(), _lib.ptr(reset_mask), n, self.h, self.w, g, self.depth_sense_dist,
-                self.prob_grid.data_ptr(), self.scanned_bits.data_ptr(), tri_out.data_ptr(), int(tri_row_stride),
+                self._prob_f32.data_ptr(), self.scanned_bits.data_ptr(), tri_out.data_ptr(), int(tri_row_stride),
                 self.coverage_count.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
                 _lib.stream_ptr(self.device)), "gnbv_update_occ_grid_packed")
             return tri_out
@@ -87,7 +128,7 @@ class OccupancyGridUpdater:
             depth_raw.data_ptr(), seg_raw.data_ptr(), c2w.data_ptr(), self.inv_intri_host.data_ptr(),
             poses.data_ptr(), poses.stride(0), self.range_gt.data_ptr(), self.voxel_size_gt.data_ptr(),
             self.grid_gt.data_ptr(), _lib.ptr(reset_mask), n, self.h, self.w, g, self.depth_sense_dist,
-            self.prob_grid.data_ptr(), self._scanned_f32.data_ptr(), tri_out.data_ptr(), int(tri_row_stride),
+            self._prob_f32.data_ptr(), self._scanned_f32.data_ptr(), tri_out.data_ptr(), int(tri_row_stride),
             self.coverage_count.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
             _lib.stream_ptr(self.device)), "gnbv_update_occ_grid")
         return tri_out

@@ -117,6 +117,21 @@ int gnbv_update_occ_grid_packed(const float *depth_raw, const float *seg_raw, co
  * hit / path bitmasks to u8 [N,G^3] (either output may be NULL). */
 int gnbv_unpack_masks(const void *workspace, int n, int g, uint8_t *hit_u8, uint8_t *path_u8, void *stream);
 
+/* Coded probability grid (same A1-A7 step, 1 byte per voxel instead of an fp32 prob_grid): between two resets a voxel's
+ * probability is a function of (base, k) -- base = 1 after a hit (prob = 1.0, env_train_gennbv.py:311) / 0 since the
+ * reset, k = number of "prob -= 0.05" path steps since (:308) -- so code = base << 7 | k is exact for episodes of at
+ * most 127 steps (*overflow is set to 1 if a counter saturates).  gnbv_prob_code_tables fills the 256-entry HOST
+ * tables prob_lut[code] (the exact fp32 iteration) and tri_lut[code] (A7); pass DEVICE copies to the kernels. */
+void gnbv_prob_code_tables(float *prob_lut /*[256] host or NULL*/, float *tri_lut /*[256] host or NULL*/);
+int gnbv_decode_prob_grid(const uint8_t *prob_code, int64_t count, const float *prob_lut /*[256] device*/, float *prob_out,
+                          void *stream);
+int gnbv_update_occ_grid_coded(const float *depth_raw, const float *seg_raw, const float *c2w, const float *inv_intri /*[host]*/,
+                               const float *poses_xyz, int64_t poses_row_stride, const float *range_gt, const float *voxel_size,
+                               const uint32_t *gt_bits, const uint8_t *reset_mask, int n, int h, int w, int g,
+                               float depth_sense_dist, uint8_t *prob_code /*[N,G^3]*/, const float *tri_lut /*[256] device*/,
+                               uint32_t *scanned_bits, float *tri_out, int64_t tri_row_stride, int32_t *coverage_count,
+                               int32_t *overflow /*[1] device or NULL*/, void *workspace, size_t workspace_bytes, void *stream);
+
 
 /* ------------------------------------------------------------------------- */
 /* A8/A9  environment-step bookkeeping (no simulator: recorded/synthetic feed)  */

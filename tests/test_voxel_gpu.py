@@ -57,7 +57,7 @@ def test_postprocess_backprojection_voxelidx_vs_golden():
     assert utils.scanned_pts_to_idx_3D([torch.zeros(0, 3, device=DEV)], T(fx["range_gt"]), T(fx["voxel_size"]), g) == [[]]
 
 
-def _run_sequence(n, h, w, g, steps, seed, reset_at=(), pose_override=None, packed=None, gt_scale=None):
+def _run_sequence(n, h, w, g, steps, seed, reset_at=(), pose_override=None, packed=None, gt_scale=None, max_steps=None):
     """HIP updater vs oracle on the same seeded synthetic frames; returns per-step mismatch info."""
     from gennbv_amd.env.state_encoding import OccupancyGridUpdater
     cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
@@ -66,7 +66,9 @@ def _run_sequence(n, h, w, g, steps, seed, reset_at=(), pose_override=None, pack
     kinv = S.inverse_intrinsics(h, w)
     if gt_scale is not None:
         scene.grid_gt = scene.grid_gt * gt_scale
-    upd = OccupancyGridUpdater(n, g, h, w, kinv, scene.range_gt, scene.voxel_size, scene.grid_gt, DEV, packed=packed)
+    upd = OccupancyGridUpdater(n, g, h, w, kinv, scene.range_gt, scene.voxel_size, scene.grid_gt, DEV, packed=packed,
+                               max_steps_between_resets=max_steps)
+    assert upd.coded == (max_steps is not None)
     prob = np.zeros((n, g, g, g), np.float32)
     scan = np.zeros_like(prob)
     rs = np.random.RandomState(seed)
@@ -100,6 +102,43 @@ def _run_sequence(n, h, w, g, steps, seed, reset_at=(), pose_override=None, pack
                                            (2, 30, 37, 33, 3), (2, 60, 80, 128, 2)])
 def test_fused_update_bit_exact_vs_oracle(n, h, w, g, steps):
     _run_sequence(n, h, w, g, steps, seed=11 + g, reset_at=(2,))
+
+
+@pytest.mark.parametrize("n,h,w,g,steps", [(4, 120, 160, 16, 14), (3, 100, 100, 20, 6), (5, 120, 160, 64, 5), (2, 30, 37, 33, 4)])
+def test_coded_probability_grid_bit_exact_vs_oracle(n, h, w, g, steps):
+    """1-byte coded prob grid (code = base << 7 | #path steps): decoded grid, tri-class grid, scanned set and coverage
+    equal the oracle bit for bit over a sequence with resets (repeated -0.05 steps reach the fp32 values the reference
+    reaches: -0.05, -0.1, -0.15000001, ...)."""
+    _run_sequence(n, h, w, g, steps, seed=23 + g, reset_at=(2, 5), max_steps=100)
+
+
+def test_coded_probability_grid_tables_and_saturation():
+    import ctypes as C
+    from gennbv_amd import _lib
+    lib = _lib.load()
+    pl, tl = (C.c_float * 256)(), (C.c_float * 256)()
+    lib.gnbv_prob_code_tables(pl, tl)
+    x = np.float32(0.0)
+    for k in range(128):
+        assert np.float32(pl[k]) == x and tl[k] == float(x > 0.5) - float(x < 0.0)
+        x = np.float32(x - np.float32(0.05))
+    x = np.float32(1.0)
+    for k in range(128):
+        assert np.float32(pl[128 + k]) == x and tl[128 + k] == float(x > 0.5) - float(x < 0.0)
+        x = np.float32(x - np.float32(0.05))
+    # more path steps than the declared bound: the saturation flag turns reading the grid into an error
+    from gennbv_amd.env.state_encoding import OccupancyGridUpdater
+    n, h, w, g = 2, 60, 80, 16
+    cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
+    scene = S.make_scenes(n, g, seed=3)
+    f = S.make_frames(scene, cfg, 1, seed=3, with_rgba=False)[0]
+    upd = OccupancyGridUpdater(n, g, h, w, S.inverse_intrinsics(h, w), scene.range_gt, scene.voxel_size, scene.grid_gt, DEV,
+                               max_steps_between_resets=100)
+    c2w = S.c2w_from_view(f.view, scene.env_origins).to(DEV)
+    for _ in range(130):
+        upd.update(f.depth_raw.to(DEV), f.seg_raw.to(DEV), c2w, f.poses.to(DEV).contiguous())
+    with pytest.raises(_lib.GennbvHipError):
+        upd.prob_grid
 
 
 def test_f32_path_and_non_binary_ground_truth():

@@ -14,12 +14,15 @@ ap.add_argument("--h", type=int, default=240)
 ap.add_argument("--w", type=int, default=320)
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--frames", type=int, default=4)
+ap.add_argument("--prob", default="coded", choices=["coded", "f32"], help="1-byte coded probability grid (what ReplayFeedEnv uses) or fp32")
 a = ap.parse_args()
 dev = "cuda:0"
 cfg = TaskConfig(camera_width=a.w, camera_height=a.h, grid_size=a.g)
 scene = S.make_scenes(a.n, a.g, seed=1, device=dev)
 frames = S.make_frames(scene, cfg, a.frames, seed=1, with_rgba=False)
-upd = OccupancyGridUpdater(a.n, a.g, a.h, a.w, S.inverse_intrinsics(a.h, a.w), scene.range_gt, scene.voxel_size, scene.grid_gt, dev)
+upd = OccupancyGridUpdater(a.n, a.g, a.h, a.w, S.inverse_intrinsics(a.h, a.w), scene.range_gt, scene.voxel_size, scene.grid_gt, dev,
+                           max_steps_between_resets=100 if a.prob == "coded" else None)
+all_reset = torch.ones(a.n, dtype=torch.uint8, device=dev)
 c2ws = [S.c2w_from_view(f.view, scene.env_origins) for f in frames]
 poses = [f.poses.contiguous() for f in frames]
 for i in range(5):
@@ -33,7 +36,7 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for i in range(a.iters):
     k = i % a.frames
-    upd.update(frames[k].depth_raw, frames[k].seg_raw, c2ws[k], poses[k])
+    upd.update(frames[k].depth_raw, frames[k].seg_raw, c2ws[k], poses[k], reset_mask=all_reset if i % 64 == 63 else None)  # episodes end
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
