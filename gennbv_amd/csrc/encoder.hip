@@ -236,9 +236,12 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd(
 // first 2*O1+1 rows of planes 2oz, 2oz+1, 2oz+2, each a contiguous run of the observation row -- is
 // fetched ONCE with full-width 16-byte requests (the direct kernel gathers it with 4-byte stride-2
 // requests, every input dword 3.4 times), the MFMA operands are then 4-byte LDS reads.
-template <typename A>
+// IN = float: the grid slice of the fp32 observation rows; IN = int8_t: the compact side copy of the tri-class
+// grid the state-encoding kernel writes next to it (values -1/0/1: the conversion is exact, the slab is
+// fetched with a quarter of the bytes and widened while it is written to LDS).
+template <typename A, typename IN>
 __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
-    const float *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, int B, int G, int O1,
+    const IN *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, int B, int G, int O1,
     const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ b1, typename A::T *__restrict__ y1,
     float *__restrict__ partials)
 {
@@ -250,20 +253,46 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
     const int NR = 2 * O1 + 1, plane4 = NR * G / 4, total4 = 3 * plane4;
     float s_sum[4] = {0.f, 0.f, 0.f, 0.f}, s_sq[4] = {0.f, 0.f, 0.f, 0.f};
     if (live) {
-        const float *in = obs_base + (rows ? rows[b] : (int64_t)b) * row_stride + (size_t)(2 * oz) * G * G;
-        // ---- stage the slab: 4 requests per thread in flight ----
-        for (int base = 0; base < total4; base += 4 * kEncThreads) {
-            float4 v[4];
+        const IN *in = obs_base + (rows ? rows[b] : (int64_t)b) * row_stride + (size_t)(2 * oz) * G * G;
+        if constexpr (sizeof(IN) == 4) {
+            // ---- stage the slab: 4 requests per thread in flight ----
+            for (int base = 0; base < total4; base += 4 * kEncThreads) {
+                float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = min(base + u * kEncThreads + (int)threadIdx.x, total4 - 1);
-                const int p = idx / plane4, r = idx - p * plane4;
-                v[u] = ActF32::ld4(in + (size_t)p * G * G + 4 * r);
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = min(base + u * kEncThreads + (int)threadIdx.x, total4 - 1);
+                    const int p = idx / plane4, r = idx - p * plane4;
+                    v[u] = ActF32::ld4(reinterpret_cast<const float *>(in) + (size_t)p * G * G + 4 * r);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = base + u * kEncThreads + (int)threadIdx.x;
+                    if (idx < total4) reinterpret_cast<float4 *>(s_in)[idx] = v[u];
+                }
             }
+        } else {
+            // int8 grid: 16 voxels per 16-byte request (G % 16 == 0), widened on the way into LDS
+            const int plane16 = plane4 / 4, total16 = 3 * plane16;
+            for (int base = 0; base < total16; base += 2 * kEncThreads) {
+                uint4 v[2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = base + u * kEncThreads + (int)threadIdx.x;
-                if (idx < total4) reinterpret_cast<float4 *>(s_in)[idx] = v[u];
+                for (int u = 0; u < 2; ++u) {
+                    const int idx = min(base + u * kEncThreads + (int)threadIdx.x, total16 - 1);
+                    const int p = idx / plane16, r = idx - p * plane16;
+                    v[u] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const int8_t *>(in) + (size_t)p * G * G + 16 * r);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int idx = base + u * kEncThreads + (int)threadIdx.x;
+                    if (idx < total16) {
+                        const uint32_t wd[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            reinterpret_cast<float4 *>(s_in)[4 * idx + q] =
+                                make_float4((float)(int8_t)(wd[q] & 255u), (float)(int8_t)((wd[q] >> 8) & 255u),
+                                            (float)(int8_t)((wd[q] >> 16) & 255u), (float)(int8_t)(wd[q] >> 24));
+                    }
+                }
             }
         }
     }
@@ -964,9 +993,9 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_wgrad(
 // backward applied on the way in) and the 9 input rows of its receptive field; the MFMA operands
 // are then 4-byte LDS reads.  7 wide loads per row instead of 32 narrow ones.  Each wave owns a
 // private LDS region (no workgroup barrier: rows per wave differ at the tail).
-template <typename A, int NR, int NI>
+template <typename A, int NR, int NI, typename IN>
 __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_conv1_wgrad_lds(
-    const float *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, const typename A::T *__restrict__ dz1p,
+    const IN *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, const typename A::T *__restrict__ dz1p,
     const typename A::T *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ mean1,
     const float *__restrict__ rstd1, const double *__restrict__ S /*[2][16]*/, double count, int B, int G, int O1,
     float *__restrict__ partial /*[nwaves][2*256 + 16]*/)
@@ -1003,7 +1032,10 @@ __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(4, 
     const int nrows = B * O1 * O1;
     int row0, row1;
     wave_row_range(nrows, row0, row1);
+    // int8 grid: the 9 input rows are 9 G bytes = one 16-byte request for the first 9 G / 16 lanes (G % 16 == 0)
+    constexpr bool kI8 = sizeof(IN) == 1;
     float4 rg[NR], ry[NR], ri[NI];
+    uint4 ri8 = make_uint4(0, 0, 0, 0);
     auto request = [&](int row, float4 (&rg)[NR], float4 (&ry)[NR], float4 (&ri)[NI]) {
         const int b = row / (O1 * O1), rem = row - b * O1 * O1, oz = rem / O1, oy = rem - oz * O1;
         const uint32_t rb = vox1(b, oz, oy, 0, O1) * kC;
@@ -1013,12 +1045,18 @@ __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(4, 
             rg[u] = A::ld4(dz1p + rb + i);
             ry[u] = A::ld4(y1 + rb + i);
         }
-        const float *in = obs_base + (rows ? rows[b] : (int64_t)b) * row_stride;
-#pragma unroll
-        for (int u = 0; u < NI; ++u) {
-            const int i = min(lane * 4 + u * kWave * 4, 9 * G - 4);
+        const IN *in = obs_base + (rows ? rows[b] : (int64_t)b) * row_stride;
+        if constexpr (kI8) {
+            const int i = min(lane * 16, 9 * G - 16);
             const int dz = i / (3 * G), r = i - dz * 3 * G;  // rows dy = 0..2 of one dz are contiguous
-            ri[u] = ActF32::ld4(in + ((size_t)(2 * oz + dz) * G + 2 * oy) * G + r);
+            ri8 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const int8_t *>(in) + ((size_t)(2 * oz + dz) * G + 2 * oy) * G + r);
+        } else {
+#pragma unroll
+            for (int u = 0; u < NI; ++u) {
+                const int i = min(lane * 4 + u * kWave * 4, 9 * G - 4);
+                const int dz = i / (3 * G), r = i - dz * 3 * G;  // rows dy = 0..2 of one dz are contiguous
+                ri[u] = ActF32::ld4(reinterpret_cast<const float *>(in) + ((size_t)(2 * oz + dz) * G + 2 * oy) * G + r);
+            }
         }
     };
     if (row0 < row1) request(row0, rg, ry, ri);
@@ -1040,10 +1078,21 @@ __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(4, 
                 *reinterpret_cast<float4 *>(s_dy + i) = d;
             }
         }
+        if constexpr (kI8) {
+            if (lane * 16 < 9 * G) {
+                const uint32_t wd[4] = {ri8.x, ri8.y, ri8.z, ri8.w};
 #pragma unroll
-        for (int u = 0; u < NI; ++u) {
-            const int i = lane * 4 + u * kWave * 4;
-            if (i < 9 * G) *reinterpret_cast<float4 *>(s_in + i) = ri[u];
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4 *>(s_in + lane * 16 + 4 * q) =
+                        make_float4((float)(int8_t)(wd[q] & 255u), (float)(int8_t)((wd[q] >> 8) & 255u),
+                                    (float)(int8_t)((wd[q] >> 16) & 255u), (float)(int8_t)(wd[q] >> 24));
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NI; ++u) {
+                const int i = lane * 4 + u * kWave * 4;
+                if (i < 9 * G) *reinterpret_cast<float4 *>(s_in + i) = ri[u];
+            }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
         __builtin_amdgcn_wave_barrier();
@@ -1192,8 +1241,13 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
         const size_t c1_lds = (size_t)3 * (2 * O1 + 1) * grid * sizeof(float);
         const bool c1_staged = (grid % 4 == 0) && (row_stride % 4 == 0) && (((uintptr_t)obs_grid & 15) == 0) && c1_lds <= 64 * 1024 &&
                                2 * O1 + 1 <= grid;
-        if (c1_staged)
-            hipLaunchKernelGGL(k_conv1_fwd_lds<ActF32>, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, obs_grid, rows,
+        const bool c1_i8 = p->grid_i8 != nullptr && grid % 16 == 0 && p->grid_i8_row_stride % 16 == 0 && (((uintptr_t)p->grid_i8 & 15) == 0) &&
+                           c1_lds <= 64 * 1024 && 2 * O1 + 1 <= grid;
+        if (c1_i8)  // compact int8 copy of the tri-class grid: a quarter of the input bytes
+            hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, int8_t>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, p->grid_i8, rows,
+                               p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr);
+        else if (c1_staged)
+            hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, float>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, obs_grid, rows,
                                row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr);
         else
             hipLaunchKernelGGL(k_conv1_fwd<ActF32>, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride,
@@ -1341,9 +1395,19 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     if (p->act_bf16) {
         hipLaunchKernelGGL(k_conv1_wgrad<ActBF16>, dim3(wg1_blocks), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, (const uint16_t *)dz1_scratch, (const uint16_t *)y1, bn1,
                        bn1 + 2 * kC, bn1 + 3 * kC, S1, (double)batch * O1 * O1 * O1, batch, grid, O1, wg1_part);
+    } else if (p->grid_i8 != nullptr && grid % 16 == 0 && 9 * grid <= 1024 && p->grid_i8_row_stride % 16 == 0 &&
+               (((uintptr_t)p->grid_i8 & 15) == 0) && c1w_lds <= 64 * 1024 && c1w_nr <= 4) {
+#define GNBV_C1W8(NR)                                                                                                             \
+    hipLaunchKernelGGL((k_conv1_wgrad_lds<ActF32, NR, 1, int8_t>), dim3(wg1_blocks), dim3(kEncThreads), c1w_lds, st, p->grid_i8,  \
+                       rows, p->grid_i8_row_stride, (const float *)dz1_scratch, (const float *)y1, bn1, bn1 + 2 * kC,            \
+                       bn1 + 3 * kC, S1, (double)batch * O1 * O1 * O1, batch, grid, O1, wg1_part)
+        if (c1w_nr <= 1) GNBV_C1W8(1);
+        else if (c1w_nr <= 2) GNBV_C1W8(2);  // G = 64
+        else GNBV_C1W8(4);
+#undef GNBV_C1W8
     } else if (c1w_staged) {
 #define GNBV_C1W(NR, NI)                                                                                                          \
-    hipLaunchKernelGGL((k_conv1_wgrad_lds<ActF32, NR, NI>), dim3(wg1_blocks), dim3(kEncThreads), c1w_lds, st, obs_grid, rows,      \
+    hipLaunchKernelGGL((k_conv1_wgrad_lds<ActF32, NR, NI, float>), dim3(wg1_blocks), dim3(kEncThreads), c1w_lds, st, obs_grid, rows,\
                        row_stride, (const float *)dz1_scratch, (const float *)y1, bn1, bn1 + 2 * kC, bn1 + 3 * kC, S1,            \
                        (double)batch * O1 * O1 * O1, batch, grid, O1, wg1_part)
         if (c1w_nr <= 1 && c1w_ni <= 1) GNBV_C1W(1, 1);

@@ -657,7 +657,7 @@ __global__ __launch_bounds__(kGridThreads) void k_grid_update_coded(
     const uint32_t *__restrict__ hit_mask, const uint32_t *__restrict__ path_mask, const uint32_t *__restrict__ gt_bits,
     const uint8_t *__restrict__ reset_mask, int n, int g3, int words, int words_gt, uint8_t *__restrict__ prob_code,
     const float *__restrict__ tri_lut, uint32_t *__restrict__ scanned_bits, float *__restrict__ tri_out, int64_t tri_stride,
-    int32_t *__restrict__ coverage, int32_t *__restrict__ overflow)
+    int8_t *__restrict__ tri_i8, int64_t tri_i8_stride, int32_t *__restrict__ coverage, int32_t *__restrict__ overflow)
 {
     __shared__ float lut[256];
     __shared__ int s_cov[kGridThreads / kWave];
@@ -670,6 +670,7 @@ __global__ __launch_bounds__(kGridThreads) void k_grid_update_coded(
     uint32_t *sb = scanned_bits + (size_t)e * words_gt;
     uint8_t *code = prob_code + (size_t)e * g3;
     float *tri = tri_out + (size_t)e * tri_stride;
+    int8_t *tri8 = tri_i8 ? tri_i8 + (size_t)e * tri_i8_stride : nullptr;  // optional compact copy for the conv1 kernels
     int cov = 0, ovf = 0;
     if (VEC16) {  // (4 voxels per lane and trip: one 4-byte code word in, one 16-byte tri vector out, both coalesced)
         const int nv = g3 >> 2;
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(kGridThreads) void k_grid_update_coded(
             const uint32_t hw = hm[wd], pw = pm[wd];
             const uint32_t hb = (hw >> sh) & 0xFu, pb = (pw >> sh) & 0xFu;
             const uint32_t cw = reset ? 0u : reinterpret_cast<const uint32_t *>(code)[i];
-            uint32_t out = 0;
+            uint32_t out = 0, t8 = 0;
             float4 t4;
             float *tp = &t4.x;
 #pragma unroll
@@ -686,9 +687,11 @@ __global__ __launch_bounds__(kGridThreads) void k_grid_update_coded(
                 const uint32_t c = step_code((cw >> (8 * b)) & 255u, (hb >> b) & 1u, (pb >> b) & 1u, ovf);
                 out |= c << (8 * b);
                 tp[b] = lut[c];
+                t8 |= ((uint32_t)(int)tp[b] & 255u) << (8 * b);
             }
             reinterpret_cast<uint32_t *>(code)[i] = out;
             reinterpret_cast<float4 *>(tri)[i] = t4;
+            if (tri8) reinterpret_cast<uint32_t *>(tri8)[i] = t8;
             if (sh == 0) {  // one lane in eight owns the 32-voxel word of the scanned set
                 const uint32_t sw = (reset ? 0u : sb[wd]) | (hw & gb[wd]);
                 sb[wd] = sw;
@@ -703,6 +706,7 @@ __global__ __launch_bounds__(kGridThreads) void k_grid_update_coded(
             const uint32_t c = step_code(reset ? 0u : code[v], hb, pb, ovf);
             code[v] = (uint8_t)c;
             tri[v] = lut[c];
+            if (tri8) tri8[v] = (int8_t)(int)lut[c];
             if ((v & 31) == 0) {
                 const uint32_t sw = (reset ? 0u : sb[wd]) | (hw & gb[wd]);
                 sb[wd] = sw;
@@ -1224,8 +1228,9 @@ GNBV_API int gnbv_update_occ_grid_coded(const float *depth_raw, const float *seg
                                         const float *poses_xyz, int64_t poses_row_stride, const float *range_gt,
                                         const float *voxel_size, const uint32_t *gt_bits, const uint8_t *reset_mask, int n,
                                         int h, int w, int g, float depth_sense_dist, uint8_t *prob_code, const float *tri_lut,
-                                        uint32_t *scanned_bits, float *tri_out, int64_t tri_row_stride, int32_t *coverage_count,
-                                        int32_t *overflow, void *workspace, size_t workspace_bytes, void *stream)
+                                        uint32_t *scanned_bits, float *tri_out, int64_t tri_row_stride, int8_t *tri_i8,
+                                        int64_t tri_i8_row_stride, int32_t *coverage_count, int32_t *overflow, void *workspace,
+                                        size_t workspace_bytes, void *stream)
 {
     GNBV_CHECK_ARG(depth_raw && seg_raw && c2w && inv_intri && poses_xyz && range_gt && voxel_size && gt_bits);
     GNBV_CHECK_ARG(prob_code && tri_lut && scanned_bits && tri_out && coverage_count && workspace);
@@ -1238,15 +1243,18 @@ GNBV_API int gnbv_update_occ_grid_coded(const float *depth_raw, const float *seg
     int err = launch_masks(depth_raw, seg_raw, c2w, inv_intri, poses_xyz, poses_row_stride, range_gt, voxel_size, n, h, w, g,
                            depth_sense_dist, coverage_count, ws, st);
     if (err) return err;
+    GNBV_CHECK_ARG(tri_i8 == nullptr || tri_i8_row_stride >= g3);
     const bool vec16 = (g3 % 4 == 0) && (tri_row_stride % 4 == 0) && (((uintptr_t)tri_out & 15) == 0) &&
-                       (((uintptr_t)prob_code & 3) == 0);
+                       (((uintptr_t)prob_code & 3) == 0) && (tri_i8 == nullptr || ((((uintptr_t)tri_i8 | (uintptr_t)tri_i8_row_stride) & 3) == 0));
     const int bx = grid_update_blocks(vec16 ? g3 / 4 : g3, n);
     if (vec16)
         hipLaunchKernelGGL(k_grid_update_coded<true>, dim3(bx, n), dim3(kGridThreads), 0, st, ws.hit, ws.path, gt_bits, reset_mask, n,
-                           (int)g3, ws.words, ws.words, prob_code, tri_lut, scanned_bits, tri_out, tri_row_stride, coverage_count, overflow);
+                           (int)g3, ws.words, ws.words, prob_code, tri_lut, scanned_bits, tri_out, tri_row_stride, tri_i8, tri_i8_row_stride,
+                           coverage_count, overflow);
     else
         hipLaunchKernelGGL(k_grid_update_coded<false>, dim3(bx, n), dim3(kGridThreads), 0, st, ws.hit, ws.path, gt_bits, reset_mask, n,
-                           (int)g3, ws.words, ws.words, prob_code, tri_lut, scanned_bits, tri_out, tri_row_stride, coverage_count, overflow);
+                           (int)g3, ws.words, ws.words, prob_code, tri_lut, scanned_bits, tri_out, tri_row_stride, tri_i8, tri_i8_row_stride,
+                           coverage_count, overflow);
     return gnbv_launch_status();
 }
 

@@ -181,7 +181,7 @@ class ReplayFeedEnv:
         pass
 
     # ------------------------------------------------------------------------
-    def _observe_and_finish(self, actions_in: torch.Tensor, obs_out: Optional[torch.Tensor]):
+    def _observe_and_finish(self, actions_in: torch.Tensor, obs_out: Optional[torch.Tensor], grid_i8_out: Optional[torch.Tensor] = None):
         cfg, n, lib = self.cfg, self.num_envs, self.lib
         st = _lib.stream_ptr(self.device)
         obs = self._obs if obs_out is None else obs_out
@@ -206,12 +206,18 @@ class ReplayFeedEnv:
                                         obs.data_ptr() + 4 * rgb_off, stride, st), "gnbv_env_obs_rgb")
         # obs["grid"]: tri-class grid straight into the observation rows
         self.updater.update(depth_raw, seg_raw, c2w, self.poses, reset_mask=self.reset_mask,
-                            tri_out=obs[:, cfg.state_dim:], tri_row_stride=stride)
+                            tri_out=obs[:, cfg.state_dim:], tri_row_stride=stride,
+                            tri_i8_out=grid_i8_out if self.updater.coded else None)
         # rewards / termination / reset bookkeeping
         _lib.check(lib.gnbv_env_post_step(C.byref(self._post), st), "gnbv_env_post_step")
         return obs
 
-    def reset(self, obs_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    @property
+    def supports_grid_i8(self) -> bool:
+        """step(..., grid_i8_out=rows) also writes an int8 copy of the tri-class grid (coded update only)."""
+        return bool(self.updater.coded)
+
+    def reset(self, obs_out: Optional[torch.Tensor] = None, grid_i8_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Env_Train_GenNBV.reset (:229-244): reset every env, observe at the init pose."""
         n = self.num_envs
         self.episode_length_buf.zero_()
@@ -220,12 +226,12 @@ class ReplayFeedEnv:
         self.extras_time_outs.zero_()
         self.gray_prev.zero_()
         init = torch.tensor(self.cfg.init_action, dtype=torch.int64, device=self.device).repeat(n, 1)
-        return self._observe_and_finish(init, obs_out)
+        return self._observe_and_finish(init, obs_out, grid_i8_out)
 
-    def step(self, actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None):
+    def step(self, actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None, grid_i8_out: Optional[torch.Tensor] = None):
         _lib.require_cuda(actions)
         a = actions.to(torch.int64).contiguous()
-        obs = self._observe_and_finish(a, obs_out)
+        obs = self._observe_and_finish(a, obs_out, grid_i8_out)
         self.extras["time_outs"] = self.extras_time_outs.bool()
         self.extras["episode"] = _LazyEpisodeInfo(self)
         return obs, self.rew_buf, self.reset_buf.bool(), self.extras

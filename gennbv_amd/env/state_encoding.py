@@ -89,7 +89,7 @@ class OccupancyGridUpdater:
 
     def update(self, depth_raw: torch.Tensor, seg_raw: torch.Tensor, c2w: torch.Tensor, poses: torch.Tensor,
                reset_mask: Optional[torch.Tensor] = None, tri_out: Optional[torch.Tensor] = None,
-               tri_row_stride: Optional[int] = None) -> torch.Tensor:
+               tri_row_stride: Optional[int] = None, tri_i8_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """depth_raw/seg_raw [N,H,W] f32 RAW camera tensors, c2w [N,4,4] f32, poses [N,>=3]
         f32 (xyz first).  `tri_out`: optional destination whose row e starts at
         tri_out.data_ptr() + e*tri_row_stride*4 (e.g. the grid slice of the flat obs)."""
@@ -106,13 +106,17 @@ class OccupancyGridUpdater:
             tri_out, tri_row_stride = self._own_tri, g ** 3
         if reset_mask is not None:
             assert reset_mask.dtype == torch.uint8 and reset_mask.is_contiguous()
+        if tri_i8_out is not None:
+            assert self.coded, "the int8 copy of the tri-class grid is produced by the coded update only"
+            assert tri_i8_out.dtype == torch.int8 and tri_i8_out.shape == (n, g ** 3) and tri_i8_out.stride(1) == 1
         if self.coded:
             _lib.check(self.lib.gnbv_update_occ_grid_coded(
                 depth_raw.data_ptr(), seg_raw.data_ptr(), c2w.data_ptr(), self.inv_intri_host.data_ptr(),
                 poses.data_ptr(), poses.stride(0), self.range_gt.data_ptr(), self.voxel_size_gt.data_ptr(),
                 self.gt_bits.data_ptr(), _lib.ptr(reset_mask), n, self.h, self.w, g, self.depth_sense_dist,
                 self.prob_code.data_ptr(), self._tri_lut.data_ptr(), self.scanned_bits.data_ptr(), tri_out.data_ptr(),
-                int(tri_row_stride), self.coverage_count.data_ptr(), self.code_overflow.data_ptr(), self.workspace.data_ptr(),
+                int(tri_row_stride), _lib.ptr(tri_i8_out), 0 if tri_i8_out is None else int(tri_i8_out.stride(0)),
+                self.coverage_count.data_ptr(), self.code_overflow.data_ptr(), self.workspace.data_ptr(),
                 self.workspace.numel(), _lib.stream_ptr(self.device)), "gnbv_update_occ_grid_coded")
             return tri_out
         if self.packed:

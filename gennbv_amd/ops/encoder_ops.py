@@ -19,9 +19,14 @@ from .. import _lib
 class RowGather:
     """A lazily gathered observation batch: rows `rows` of the 2-D fp32 matrix `base`."""
 
-    def __init__(self, base: torch.Tensor, rows: torch.Tensor):
+    def __init__(self, base: torch.Tensor, rows: torch.Tensor, grid_i8: Optional[torch.Tensor] = None):
         assert base.dim() == 2 and base.stride(1) == 1 and rows.dtype == torch.int64
         self.base, self.rows = base, rows.contiguous()
+        # optional compact copy of the grid slices ([R, G^3] int8, same row numbering): the conv1 kernels read it
+        # instead of the fp32 slice of `base`
+        assert grid_i8 is None or (grid_i8.dtype == torch.int8 and grid_i8.dim() == 2 and grid_i8.stride(1) == 1
+                                   and grid_i8.shape[0] == base.shape[0])
+        self.grid_i8 = grid_i8
         self.shape = (rows.shape[0], base.shape[1])
         self.device = base.device
 
@@ -33,6 +38,26 @@ class RowGather:
 
     def columns(self, a: int, b: int) -> torch.Tensor:
         return self.base[:, a:b][self.rows]
+
+
+class DenseObs:
+    """A whole observation matrix [N, D_obs] together with the compact int8 copy of its grid slices [N, G^3]
+    (rollout forward: every row is used, no gather)."""
+
+    def __init__(self, base: torch.Tensor, grid_i8: Optional[torch.Tensor] = None):
+        assert base.dim() == 2 and base.stride(1) == 1
+        assert grid_i8 is None or (grid_i8.dtype == torch.int8 and grid_i8.shape[0] == base.shape[0] and grid_i8.stride(1) == 1)
+        self.base, self.rows, self.grid_i8 = base, None, grid_i8
+        self.shape, self.device, self.is_cuda = base.shape, base.device, base.is_cuda
+
+    def float(self):
+        return self
+
+    def materialize(self) -> torch.Tensor:
+        return self.base
+
+    def columns(self, a: int, b: int) -> torch.Tensor:
+        return self.base[:, a:b]
 
 
 def conv_out(g: int) -> int:
@@ -53,7 +78,7 @@ def _workspace(lib, batch, grid, device):
     return ws
 
 
-def _params_struct(seq, act_bf16: bool = False) -> _lib.GnbvEncoderParams:
+def _params_struct(seq, act_bf16: bool = False, grid_i8: Optional[torch.Tensor] = None) -> _lib.GnbvEncoderParams:
     conv1, bn1, conv2, bn2 = seq[0], seq[1], seq[3], seq[4]
     p = _lib.GnbvEncoderParams()
     p.w1, p.b1, p.bn1_w, p.bn1_b = conv1.weight.data_ptr(), conv1.bias.data_ptr(), bn1.weight.data_ptr(), bn1.bias.data_ptr()
@@ -62,12 +87,14 @@ def _params_struct(seq, act_bf16: bool = False) -> _lib.GnbvEncoderParams:
     p.bn2_rm, p.bn2_rv, p.bn2_nbt = bn2.running_mean.data_ptr(), bn2.running_var.data_ptr(), bn2.num_batches_tracked.data_ptr()
     p.eps, p.momentum = float(bn1.eps), float(bn1.momentum)
     p.act_bf16 = int(bool(act_bf16))
+    p.grid_i8 = None if grid_i8 is None else grid_i8.data_ptr()
+    p.grid_i8_row_stride = 0 if grid_i8 is None else int(grid_i8.stride(0))
     return p
 
 
 class _GridEncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, base, rows, grid_off, grid, training, skip_flag, seq, act_bf16, write_through, w1, b1, g1, be1, w2, b2, g2, be2):
+    def forward(ctx, base, rows, grid_off, grid, training, skip_flag, seq, act_bf16, write_through, grid_i8, w1, b1, g1, be1, w2, b2, g2, be2):
         lib = _lib.load()
         _lib.require_cuda(base, w1)
         for t in (w1, b1, g1, be1, w2, b2, g2, be2):
@@ -83,7 +110,7 @@ class _GridEncoderFn(torch.autograd.Function):
         bn_state = torch.empty(2 * 4 * 16, dtype=torch.float32, device=dev)
         feats = torch.empty(batch, 16 * p2, dtype=torch.float32, device=dev)
         ws = _workspace(lib, batch, grid, dev)
-        params = _params_struct(seq, act_bf16)
+        params = _params_struct(seq, act_bf16, grid_i8)
         obs_ptr = base.data_ptr() + 4 * grid_off
         _lib.check(lib.gnbv_encoder_grid_forward(
             obs_ptr, _lib.ptr(rows), base.stride(0), batch, grid, C.byref(params), int(training), _lib.ptr(skip_flag),
@@ -92,6 +119,7 @@ class _GridEncoderFn(torch.autograd.Function):
         ctx.save_for_backward(base, rows, y1, y2, bn_state, w1, w2)
         ctx.meta = (grid_off, grid, batch, seq, act_bf16)
         ctx.write_through = write_through
+        ctx.grid_i8 = grid_i8
         return feats
 
     @staticmethod
@@ -112,21 +140,22 @@ class _GridEncoderFn(torch.autograd.Function):
         gs = _lib.GnbvEncoderGrads()
         for name, t in zip(("w1", "b1", "bn1_w", "bn1_b", "w2", "b2", "bn2_w", "bn2_b"), grads):
             setattr(gs, name, t.data_ptr())
-        params = _params_struct(seq, act_bf16)
+        params = _params_struct(seq, act_bf16, ctx.grid_i8)
         ws = _workspace(lib, batch, grid, dev)
         _lib.check(lib.gnbv_encoder_grid_backward(
             base.data_ptr() + 4 * grid_off, _lib.ptr(rows), base.stride(0), batch, grid, C.byref(params), y1.data_ptr(),
             y2.data_ptr(), bn_state.data_ptr(), d_feats.data_ptr(), dy2.data_ptr(), dz1.data_ptr(), C.byref(gs),
             ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "gnbv_encoder_grid_backward")
         if direct:
-            return (None,) * 17
-        return (None, None, None, None, None, None, None, None, None, *grads)
+            return (None,) * 18
+        return (None, None, None, None, None, None, None, None, None, None, *grads)
 
 
 def grid_encoder(base: torch.Tensor, rows: Optional[torch.Tensor], grid_off: int, grid: int, seq, training: bool,
-                 skip_flag: Optional[torch.Tensor] = None, act_bf16: bool = False, write_through: bool = False) -> torch.Tensor:
+                 skip_flag: Optional[torch.Tensor] = None, act_bf16: bool = False, write_through: bool = False,
+                 grid_i8: Optional[torch.Tensor] = None) -> torch.Tensor:
     """seq = the `naive_encoder_grid` nn.Sequential (conv, bn, relu, conv, bn, relu)."""
-    return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, bool(act_bf16), bool(write_through), seq[0].weight, seq[0].bias,
+    return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, bool(act_bf16), bool(write_through), grid_i8, seq[0].weight, seq[0].bias,
                                 seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias)
 
 
@@ -184,9 +213,10 @@ def hybrid_branches(enc, observations):
     (hybrid_encoder.py:76-88 of the reference)."""
     s = enc.state_input_shape[0]
     g = enc.grid_size
-    if isinstance(observations, RowGather):
-        base, rows = observations.base, observations.rows
-        num_env = int(rows.shape[0])
+    grid_i8 = None
+    if isinstance(observations, (RowGather, DenseObs)):
+        base, rows, grid_i8 = observations.base, observations.rows, observations.grid_i8
+        num_env = int(rows.shape[0]) if rows is not None else int(base.shape[0])
         get_state = lambda: observations.columns(0, s)  # noqa: E731  (gather of the pose columns: on the side stream too)
     else:
         base, rows = observations, None
@@ -212,7 +242,7 @@ def hybrid_branches(enc, observations):
     else:
         feature_action = pose_branch()
     feature_grid = grid_encoder(base, rows, s, g, enc.naive_encoder_grid, enc.training, getattr(enc, "_bn_skip_flag", None),
-                                enc.compute_dtype == torch.bfloat16, getattr(enc, "_grad_write_through", False))
+                                enc.compute_dtype == torch.bfloat16, getattr(enc, "_grad_write_through", False), grid_i8)
     if getattr(enc, "_split_backward", False) and torch.is_grad_enabled():
         # data-parallel: cut the autograd graph at the conv-stack output so that the backward runs in
         # two phases (late layers first, their gradient all-reduce overlaps the conv-stack backward)

@@ -56,12 +56,24 @@ class TensorRolloutBuffer_Grid_Obs:
         self.advantages = torch.zeros(t, n, 1, device=dev)
         self.privileged_observations = None
         self.lazy_obs = False  # True: minibatch observations are RowGather views (gather fused into conv1)
+        self.grid_i8 = None    # optional [T+1, N, G^3] int8 copy of the grid slices (enable_grid_i8)
         self.reset()
+
+    def enable_grid_i8(self, grid_elems: int) -> None:
+        """Allocate the compact copy of the tri-class grid slices: the env's state-encoding kernel fills its rows
+        next to the fp32 observation rows, the conv1 kernels of the PPO update read it (a quarter of the bytes)."""
+        if self.grid_i8 is None:
+            self.grid_i8 = torch.zeros(self.buffer_size + 1, self.n_envs, int(grid_elems), dtype=torch.int8, device=self.device)
+
+    def next_grid_i8_row(self):
+        return None if self.grid_i8 is None else self.grid_i8[self.step + 1]
 
     def reset(self) -> None:
         if getattr(self, "step", 0) == self.buffer_size:
             # the observation that followed the last transition opens the next rollout
             self.observations[0].copy_(self.observations[self.buffer_size])
+            if self.grid_i8 is not None:
+                self.grid_i8[0].copy_(self.grid_i8[self.buffer_size])
         self.step = 0
         self.pos = 0
         self.full = False
@@ -125,7 +137,7 @@ class TensorRolloutBuffer_Grid_Obs:
         flat = lambda x: x.view(x.shape[0] * n, *x.shape[2:])  # noqa: E731
         if self.lazy_obs:
             from ..ops.encoder_ops import RowGather
-            obs = RowGather(flat(self.observations[:t]), rows)
+            obs = RowGather(flat(self.observations[:t]), rows, None if self.grid_i8 is None else flat(self.grid_i8[:t]))
         else:
             obs = flat(self.observations[:t])[rows]
         return RolloutBufferSamples(

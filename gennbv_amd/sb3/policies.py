@@ -87,7 +87,7 @@ class ActorCriticPolicy_Train_Eval(nn.Module):
         """(logits, values [B]) through the fused policy-head kernels, or None when not applicable
         (rollout on the gfx950 backend only: no autograd graph is needed there)."""
         if not getattr(self, "_fused_rollout", False) or torch.is_grad_enabled() or not obs.is_cuda:
-            return None
+            return None if isinstance(obs, torch.Tensor) else self._fused_head(obs.materialize())
         from ..ops import encoder_ops
         enc = self.features_extractor
         fa, fg = encoder_ops.hybrid_branches(enc, obs.float())

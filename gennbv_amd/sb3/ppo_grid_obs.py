@@ -337,7 +337,8 @@ class PPO_Grid_Obs:
         buf, pol, loss, opt = self.rollout_buffer, self.policy, st["loss"], st["opt"]
         if phase in ("all", "A"):
             t, n = buf.buffer_size, buf.n_envs
-            obs = RowGather(buf.observations[:t].view(t * n, -1), loss.rows)
+            obs = RowGather(buf.observations[:t].view(t * n, -1), loss.rows,
+                            None if buf.grid_i8 is None else buf.grid_i8[:t].view(t * n, -1))
             enc = pol.features_extractor
             if st.get("fused_head"):
                 fa, fg = encoder_ops.hybrid_branches(enc, obs)
@@ -514,10 +515,37 @@ class PPO_Grid_Obs:
 
     # ------------------------------------------------------------------------------
     def _env_step(self, actions, obs_out):
+        g8 = self.rollout_buffer.next_grid_i8_row()
+        if g8 is not None:
+            return self.env.step(actions, obs_out=obs_out, grid_i8_out=g8)
         try:
             return self.env.step(actions, obs_out=obs_out)
         except TypeError:
             return self.env.step(actions)
+
+    def _with_grid_i8(self, obs, row: int):
+        """The rollout forward reads the compact grid copy of buffer row `row` when there is one (fused path only)."""
+        buf = self.rollout_buffer
+        if buf.grid_i8 is None or not getattr(self.policy, "_fused_rollout", False) or obs.data_ptr() != buf.observations[row].data_ptr():
+            return obs
+        from ..ops.encoder_ops import DenseObs
+        return DenseObs(obs, buf.grid_i8[row])
+
+    def _maybe_enable_grid_i8(self) -> None:
+        """Compact int8 copy of the tri-class grid rows (written by the env's coded state-encoding kernel, read by the
+        conv1 kernels of the update): on when the env offers it, the encoder runs on the gfx950 kernels and G % 16 == 0."""
+        enc = self.policy.features_extractor
+        g = getattr(enc, "grid_size", 0)
+        if (os.environ.get("GENNBV_GRID_I8", "1") != "0" and getattr(self.env, "supports_grid_i8", False)
+                and getattr(enc, "backend", "") == "hip" and g % 16 == 0 and self.rollout_buffer.grid_i8 is None):
+            self.rollout_buffer.enable_grid_i8(g ** 3)
+
+    def _refresh_grid_i8_row0(self) -> None:
+        """row 0 of the int8 copy from the fp32 observation row 0 (only when that row was not written by the env)."""
+        buf, enc = self.rollout_buffer, self.policy.features_extractor
+        if buf.grid_i8 is not None:
+            s0 = enc.state_input_shape[0]
+            buf.grid_i8[0].copy_(buf.observations[0][:, s0:s0 + enc.grid_size ** 3].to(torch.int8))
 
     def collect_rollouts(self, env, callback, rollout_buffer, n_rollout_steps: int) -> bool:
         """on_policy_algorithm_grid_obs.py:128-221 (tensor-env branch)."""
@@ -538,6 +566,7 @@ class PPO_Grid_Obs:
         if self._last_obs.data_ptr() != first.data_ptr():
             first.copy_(self._last_obs)
             self._last_obs = first
+            self._refresh_grid_i8_row0()
         if callback is not None:
             callback.on_rollout_start()
         dones = None
@@ -545,7 +574,7 @@ class PPO_Grid_Obs:
         while n_steps < n_rollout_steps:
             with torch.no_grad():
                 if self._pending is None:
-                    actions, values, log_probs = self.policy(self._last_obs)
+                    actions, values, log_probs = self.policy(self._with_grid_i8(self._last_obs, rollout_buffer.step))
                 else:
                     actions, values, log_probs = self._pending
             new_obs, rewards, dones, infos = self._env_step(actions, rollout_buffer.next_obs_row())
@@ -560,12 +589,13 @@ class PPO_Grid_Obs:
                 # ONE policy evaluation of new_obs: its value is the time-out bootstrap of this
                 # step (:205-208) and its action / value / log-prob are next step's (:168).
                 # The last step only needs the value (:213-215) and must not draw from the RNG.
+                new_in = self._with_grid_i8(new_obs, rollout_buffer.step + 1)  # (the buffer's step counter advances in add())
                 if n_steps < n_rollout_steps:
-                    nxt = self.policy(new_obs)
+                    nxt = self.policy(new_in)
                     terminal_value = nxt[1]
                 else:
                     nxt = None
-                    terminal_value = self.policy.predict_values(new_obs)
+                    terminal_value = self.policy.predict_values(new_in)
             rewards = rewards + self.gamma * torch.squeeze(terminal_value * infos["time_outs"].unsqueeze(1).to(self.device), 1)
             rollout_buffer.add(self._last_obs, actions, rewards, self._last_episode_starts, values, log_probs)
             self._last_obs = new_obs
@@ -592,9 +622,13 @@ class PPO_Grid_Obs:
         else:
             total_timesteps += self.num_timesteps
         self._total_timesteps = total_timesteps
+        self._maybe_enable_grid_i8()
         if reset_num_timesteps or self._last_obs is None:
             try:
-                self._last_obs = self.env.reset(obs_out=self.rollout_buffer.first_obs_row())
+                if self.rollout_buffer.grid_i8 is not None:
+                    self._last_obs = self.env.reset(obs_out=self.rollout_buffer.first_obs_row(), grid_i8_out=self.rollout_buffer.grid_i8[0])
+                else:
+                    self._last_obs = self.env.reset(obs_out=self.rollout_buffer.first_obs_row())
             except TypeError:
                 self._last_obs = self.env.reset()
             self._last_episode_starts = torch.ones(self.env.num_envs, dtype=torch.bool, device=self.device)

@@ -129,7 +129,9 @@ int gnbv_update_occ_grid_coded(const float *depth_raw, const float *seg_raw, con
                                const float *poses_xyz, int64_t poses_row_stride, const float *range_gt, const float *voxel_size,
                                const uint32_t *gt_bits, const uint8_t *reset_mask, int n, int h, int w, int g,
                                float depth_sense_dist, uint8_t *prob_code /*[N,G^3]*/, const float *tri_lut /*[256] device*/,
-                               uint32_t *scanned_bits, float *tri_out, int64_t tri_row_stride, int32_t *coverage_count,
+                               uint32_t *scanned_bits, float *tri_out, int64_t tri_row_stride,
+                               int8_t *tri_i8 /*NULL, or a second, int8 copy of the tri-class grid: row e at tri_i8 + e*stride*/,
+                               int64_t tri_i8_row_stride /*bytes*/, int32_t *coverage_count,
                                int32_t *overflow /*[1] device or NULL*/, void *workspace, size_t workspace_bytes, void *stream);
 
 
@@ -207,6 +209,11 @@ typedef struct GnbvEncoderParams {
     int64_t *bn2_nbt;
     float eps, momentum;          /* 1e-5, 0.1 (torch.nn.BatchNorm3d defaults) */
     int act_bf16;                 /* 0: y1 / dz1 scratch are fp32; 1: bf16 storage (math stays fp32) */
+    const int8_t *grid_i8;        /* NULL, or an int8 copy of the grid slices (values -1/0/1, as written by
+                                     gnbv_update_occ_grid_coded): sample b reads grid_i8 + (rows ? rows[b] : b) *
+                                     grid_i8_row_stride bytes instead of obs_grid (a quarter of the input traffic);
+                                     used when grid % 16 == 0, otherwise obs_grid is read */
+    int64_t grid_i8_row_stride;
 } GnbvEncoderParams;
 
 typedef struct GnbvEncoderGrads {  /* outputs, same shapes as the parameters */

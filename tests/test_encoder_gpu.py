@@ -198,3 +198,24 @@ def test_fused_policy_head_vs_fp64(m, a):
     for g, r in zip(got, ref):
         assert g.shape == r.shape
         assert torch.allclose(g.double(), r, rtol=1e-4, atol=1e-4 * float(r.abs().max()) + 1e-7), float((g.double() - r).abs().max())
+
+
+@pytest.mark.parametrize("g,b", [(64, 6), (16, 5), (32, 3)])
+def test_int8_grid_copy_gives_identical_results(g, b):
+    """GnbvEncoderParams.grid_i8: conv1 forward / weight gradient reading the compact int8 copy of the tri-class grid
+    ({-1,0,1}: exact conversion) produce the same bits as reading the fp32 observation slice."""
+    from gennbv_amd.ops.encoder_ops import RowGather
+    _, hip = _pair(g)
+    hip.train()
+    base = _obs(2 * b, g, seed=3)
+    rows = torch.randperm(2 * b)[:b].to(DEV)
+    grid_i8 = base[:, 600:600 + g ** 3].to(torch.int8).contiguous()
+    outs = []
+    for gi in (None, grid_i8):
+        hip.zero_grad()
+        f = hip.features_extractor(RowGather(base, rows, gi))
+        f.backward(torch.ones_like(f) * 0.01)
+        outs.append((f.detach().clone(), [p.grad.clone() for p in hip.features_extractor.naive_encoder_grid.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, c in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, c)

@@ -169,3 +169,42 @@ def test_checkpoint_roundtrip_of_the_hip_train_state(tmp_path):
     assert int(oa.step_count) == int(ob.step_count) > 0
     assert torch.equal(oa.exp_avg, ob.exp_avg) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq)
     assert torch.equal(oa.params, ob.params)
+
+
+def test_learn_with_int8_grid_copy_matches_fp32_rows(monkeypatch):
+    """End to end over the replay env: every row of the buffer's int8 grid copy equals the grid slice of the fp32
+    observation row the env wrote (rows 0..T, two rollouts incl. the carry-over of the last row), and a learn() with the
+    copy enabled ends with exactly the parameters of a learn() that reads the fp32 rows."""
+    from gennbv_amd.env import synthetic as S
+    from gennbv_amd.env.config import TaskConfig
+    from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
+    from gennbv_amd.network.hybrid_encoder import Hybrid_Encoder
+    from gennbv_amd.sb3.policies import ActorCriticPolicy_Train_Eval
+    from gennbv_amd.sb3.ppo_grid_obs import PPO_Grid_Obs
+    n, g, t = 8, 16, 4
+
+    def run(i8: bool):
+        monkeypatch.setenv("GENNBV_GRID_I8", "1" if i8 else "0")
+        torch.manual_seed(0)
+        np.random.seed(0)
+        cfg = TaskConfig(camera_width=64, camera_height=48, grid_size=g)
+        scene = S.make_scenes(n, g, seed=2, device=DEV)
+        feed = ReplayFeed.synthetic(scene, cfg, 5, seed=2)
+        env = ReplayFeedEnv(cfg, scene, feed, DEV, max_episode_length=6)
+        algo = PPO_Grid_Obs(ActorCriticPolicy_Train_Eval, env, learning_rate=1e-4, n_steps=t, batch_size=8, n_epochs=2, ent_coef=0.01,
+                            vf_coef=0.8, max_grad_norm=1.0, target_kl=None, seed=1, device=DEV,
+                            policy_kwargs=dict(net_arch=[], features_extractor_class=Hybrid_Encoder, features_extractor_kwargs=dict(
+                                encoder_param={"hidden_shapes": [256, 256], "visual_dim": 256},
+                                net_param={"transformer_params": [[1, 256], [1, 256]], "append_hidden_shapes": [256, 256]},
+                                state_input_shape=(cfg.state_dim,), visual_input_shape=(cfg.stack, 48, 64), grid_size=g, backend="hip")))
+        algo.learn(total_timesteps=2 * n * t)
+        buf = algo.rollout_buffer
+        assert (buf.grid_i8 is not None) == i8
+        if i8:
+            s0 = cfg.state_dim
+            assert torch.equal(buf.grid_i8.float(), buf.observations[:, :, s0:s0 + g ** 3])
+        return [p.detach().clone() for p in algo.policy.parameters()]
+
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
