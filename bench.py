@@ -226,8 +226,10 @@ def encoder_roofline(algo, args, device, iters: int = 20):
     for p_ in seq.parameters():
         p_.grad = None
 
+    gi8 = None if buf.grid_i8 is None else buf.grid_i8[:t].view(t * n, -1)  # what the update reads when the env provides it
+
     def step():
-        f = encoder_ops.grid_encoder(base, rows, s_dim, g, seq, True)
+        f = encoder_ops.grid_encoder(base, rows, s_dim, g, seq, True, grid_i8=gi8)
         f.backward(torch.ones_like(f))
 
     for _ in range(3):
@@ -247,13 +249,14 @@ def encoder_roofline(algo, args, device, iters: int = 20):
     enc.train(was_training)
     flops = 3 * 2 * b * (27 * 16 * o1 ** 3 + 432 * 16 * o2 ** 3)
     y1 = b * o1 ** 3 * 16 * 4
-    x = b * g ** 3 * 4
+    x = b * g ** 3 * (4 if gi8 is None else 1)
     y2 = b * o2 ** 3 * 16 * 4
     nbytes = 2 * x + 4 * y1 + 2 * y1 + 8 * y2
     tf, gbs = flops / (ms * 1e-3) / 1e12, nbytes / (ms * 1e-3) / 1e9
     return {"kernel": "conv stack of one PPO minibatch: gnbv_encoder_grid_forward + _backward (k_conv1_fwd_lds, k_conv2_fwd, "
                       "k_conv2_wgrad, k_conv2_dgrad, k_conv1_wgrad_lds + BN/reduction launches)",
-            "ms": ms, "batch": b, "algorithmic_flops": flops, "algorithmic_bytes": nbytes,
+            "ms": ms, "batch": b, "grid_input": "fp32 rows" if gi8 is None else "int8 copy", "algorithmic_flops": flops,
+            "algorithmic_bytes": nbytes,
             "mfma": {"achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "dtype": "f32"},
             "hbm": {"achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0}}
 
