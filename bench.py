@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=8, help="frames in the synthetic feed pool")
     ap.add_argument("--backend", default=os.environ.get("GENNBV_ENCODER_BACKEND", "hip"), choices=["hip", "torch"])
     ap.add_argument("--dtype", default="fp32", choices=["fp32"])
+    ap.add_argument("--obs", default=os.environ.get("GENNBV_BENCH_OBS", "compact"), choices=["flat", "compact"],
+                    help="rollout-buffer rows: the reference's flat fp32 rows, or compact rows (grid as int8 only; same values)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save-gemm-tuning", default=None, help="write the TunableOp selections to this file")
     return ap.parse_args()
@@ -64,7 +66,7 @@ def build_algo(args, device, rank, world):
         ActorCriticPolicy_Train_Eval, env, learning_rate=pc.learning_rate, n_steps=args.n_steps, batch_size=args.batch_size,
         n_epochs=args.n_epochs, gamma=pc.gamma, gae_lambda=pc.gae_lambda, clip_range=pc.clip_range,
         clip_range_vf=pc.clip_range_vf, ent_coef=pc.ent_coef, vf_coef=pc.vf_coef, max_grad_norm=pc.max_grad_norm,
-        target_kl=pc.target_kl, seed=1, device=device,
+        target_kl=pc.target_kl, seed=1, device=device, compact_obs=args.obs == "compact",
         policy_kwargs=dict(net_arch=[], features_extractor_class=Hybrid_Encoder,
                            features_extractor_kwargs=dict(
                                encoder_param={"hidden_shapes": [256, 256], "visual_dim": 256},
@@ -229,7 +231,7 @@ def encoder_roofline(algo, args, device, iters: int = 20):
     gi8 = None if buf.grid_i8 is None else buf.grid_i8[:t].view(t * n, -1)  # what the update reads when the env provides it
 
     def step():
-        f = encoder_ops.grid_encoder(base, rows, s_dim, g, seq, True, grid_i8=gi8)
+        f = encoder_ops.grid_encoder(base, rows, s_dim, g, seq, True, grid_i8=gi8, compact=buf.compact_state_dim is not None)
         f.backward(torch.ones_like(f))
 
     for _ in range(3):
@@ -328,7 +330,7 @@ def main():
     if os.path.exists(tf):
         tj = json.load(open(tf))
         c = tj["config"]
-        if (c["envs"], c["height"], c["width"], c["grid"]) == (args.envs, args.height, args.width, args.grid):
+        if (c["envs"], c["height"], c["width"], c["grid"], c.get("obs", "flat")) == (args.envs, args.height, args.width, args.grid, args.obs):
             traffic = tj["traffic_bytes_per_launch"]  # rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (profiles/r01_voxel_pmc.txt)
     out = {
         "metric": "env-steps/sec at 256 envs x 64^3 grid (state encoding + policy forward + GAE + PPO update)",
@@ -338,7 +340,8 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: {args.envs} envs/GPU x {args.height}x{args.width} depth x "
                                f"{args.grid}^3 grid, n_steps={args.n_steps}, batch_size={args.batch_size}, "
                                f"n_epochs={args.n_epochs}, one step = one PPO iteration",
-                   "global_envs": world * args.envs, "encoder_backend": args.backend,
+                   "global_envs": world * args.envs, "encoder_backend": args.backend, "obs_rows": args.obs,
+                   "hbm_peak_allocated_gb": torch.cuda.max_memory_allocated(device) / 1e9,
                    "parallelism": f"env-sharded dp{world}", "dp_graph_mode": getattr(algo, "dp_graph_mode", None),
                    "breakdown_ms_per_step": {"rollout": phases["rollout"].total_ms() / args.steps,
                                              "train": phases["train"].total_ms() / args.steps,

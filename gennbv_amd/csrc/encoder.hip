@@ -156,9 +156,9 @@ __device__ __forceinline__ void write_partials_cl(float *partials, int nwaves, i
 // conv1 forward: in [B rows of the obs buffer, G^3 fp32] -> y1 [B,O1,O1,O1,16] (pre-BN, + bias)
 // workgroup = (sample b, output plane oz); wave = output rows oy; tile = 16 outputs along x
 // ---------------------------------------------------------------------------
-template <typename A>
+template <typename A, typename IN = float>
 __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd(
-    const float *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, int B, int G, int O1,
+    const IN *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, int B, int G, int O1,
     const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ b1, typename A::T *__restrict__ y1,
     float *__restrict__ partials)
 {
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd(
     const int m = lane & 15, kq = lane >> 4;
     float s_sum[4] = {0.f, 0.f, 0.f, 0.f}, s_sq[4] = {0.f, 0.f, 0.f, 0.f};
     if (live) {
-        const float *in = obs_base + (rows ? rows[b] : (int64_t)b) * row_stride;
+        const IN *in = obs_base + (rows ? rows[b] : (int64_t)b) * row_stride;
         // MFMA roles: A[i = co][k = tap] = W1, B[k = tap][j = output position] = input voxel
         //   -> D[i = co = 4*kq + r][j = position m]: a lane owns 4 consecutive channels of one
         //      voxel = one 16-byte channels-last store.
@@ -191,9 +191,9 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd(
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int ox = min(ox0 + 16 * t + m, O1 - 1);
-                const float *p = in + ((size_t)(2 * oz) * G + 2 * oy) * G + 2 * ox;
+                const IN *p = in + ((size_t)(2 * oz) * G + 2 * oy) * G + 2 * ox;
 #pragma unroll
-                for (int s = 0; s < 7; ++s) v[t][s] = p[off[s]];
+                for (int s = 0; s < 7; ++s) v[t][s] = (float)p[off[s]];
             }
         };
         auto consume = [&](int k, const float (&v)[2][7]) {
@@ -913,9 +913,9 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad(
 //   dy1 = scale1 * (dz1' - S1/M - xhat * S2/M);  dW1[co][tap] = sum_pos in[inpos(pos,tap)] * dy1[pos, co]
 // MFMA: i = tap (two 16-row tiles), j = co, k = 4 consecutive output positions along x.
 // ---------------------------------------------------------------------------
-template <typename A>
+template <typename A, typename IN = float>
 __global__ __launch_bounds__(kEncThreads) void k_conv1_wgrad(
-    const float *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, const typename A::T *__restrict__ dz1p,
+    const IN *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, const typename A::T *__restrict__ dz1p,
     const typename A::T *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ mean1,
     const float *__restrict__ rstd1, const double *__restrict__ S /*[2][16]*/, double count, int B, int G, int O1,
     float *__restrict__ partial /*[nwaves][2*256 + 16]*/)
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_wgrad(
     (void)nwaves;
     for (int row = row0; row < row1; ++row) {
         const int b = row / (O1 * O1), rem = row - b * O1 * O1, oz = rem / O1, oy = rem - oz * O1;
-        const float *in = obs_base + (rows ? rows[b] : (int64_t)b) * row_stride + ((size_t)(2 * oz) * G + 2 * oy) * G;
+        const IN *in = obs_base + (rows ? rows[b] : (int64_t)b) * row_stride + ((size_t)(2 * oz) * G + 2 * oy) * G;
         for (int x0 = 0; x0 < O1; x0 += 32) {
             // eight x-groups per trip: all 32 loads are issued before the first MFMA
             float g4[8], y4[8], a04[8], a14[8];
@@ -953,8 +953,8 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_wgrad(
                 const size_t idx = vox1(b, oz, oy, xc, O1) * kC + n;
                 g4[u] = A::ld1(dz1p + idx);
                 y4[u] = A::ld1(y1 + idx);
-                a04[u] = tok[0] ? in[2 * xc + off[0]] : 0.0f;  // A[i = tap][k = pos]
-                a14[u] = tok[1] ? in[2 * xc + off[1]] : 0.0f;
+                a04[u] = tok[0] ? (float)in[2 * xc + off[0]] : 0.0f;  // A[i = tap][k = pos]
+                a14[u] = tok[1] ? (float)in[2 * xc + off[1]] : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -1222,7 +1222,9 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
                                        float *bn_state /*[2][4][16]: scale, shift, mean, rstd per layer*/, float *features,
                                        void *workspace, size_t workspace_bytes, void *stream)
 {
-    GNBV_CHECK_ARG(obs_grid && p && y1 && y2 && bn_state && features && workspace && batch > 0 && grid >= 7);
+    // obs_grid == NULL: compact observations, the grid exists only as the int8 rows p->grid_i8 (fp32 activations only)
+    GNBV_CHECK_ARG(p && (obs_grid || (p->grid_i8 && !p->act_bf16)) && y1 && y2 && bn_state && features && workspace && batch > 0 && grid >= 7);
+    GNBV_CHECK_ARG(p->grid_i8 == nullptr || p->grid_i8_row_stride >= (int64_t)grid * grid * grid);
     GNBV_CHECK_ARG(workspace_bytes >= gnbv_encoder_workspace_bytes(batch, grid) && ((uintptr_t)workspace & 255) == 0);
     GNBV_CHECK_ARG(p->w1 && p->b1 && p->bn1_w && p->bn1_b && p->bn1_rm && p->bn1_rv && p->w2 && p->b2 && p->bn2_w && p->bn2_b &&
                    p->bn2_rm && p->bn2_rv);
@@ -1239,7 +1241,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
                        p->b1, (uint16_t *)y1, training ? w.bn_part : nullptr);
     } else {
         const size_t c1_lds = (size_t)3 * (2 * O1 + 1) * grid * sizeof(float);
-        const bool c1_staged = (grid % 4 == 0) && (row_stride % 4 == 0) && (((uintptr_t)obs_grid & 15) == 0) && c1_lds <= 64 * 1024 &&
+        const bool c1_staged = obs_grid != nullptr && (grid % 4 == 0) && (row_stride % 4 == 0) && (((uintptr_t)obs_grid & 15) == 0) && c1_lds <= 64 * 1024 &&
                                2 * O1 + 1 <= grid;
         const bool c1_i8 = p->grid_i8 != nullptr && grid % 16 == 0 && p->grid_i8_row_stride % 16 == 0 && (((uintptr_t)p->grid_i8 & 15) == 0) &&
                            c1_lds <= 64 * 1024 && 2 * O1 + 1 <= grid;
@@ -1249,6 +1251,9 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
         else if (c1_staged)
             hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, float>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, obs_grid, rows,
                                row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr);
+        else if (obs_grid == nullptr)  // compact rows at a size the staged kernel does not take
+            hipLaunchKernelGGL((k_conv1_fwd<ActF32, int8_t>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, p->grid_i8, rows,
+                               p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr);
         else
             hipLaunchKernelGGL(k_conv1_fwd<ActF32>, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride,
                                batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr);
@@ -1318,7 +1323,8 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
                                         const float *d_features, float *dy2_scratch, void *dz1_scratch,
                                         const GnbvEncoderGrads *g, void *workspace, size_t workspace_bytes, void *stream)
 {
-    GNBV_CHECK_ARG(obs_grid && p && y1 && y2 && bn_state && d_features && dy2_scratch && dz1_scratch && g && workspace);
+    GNBV_CHECK_ARG(p && (obs_grid || (p->grid_i8 && !p->act_bf16)) && y1 && y2 && bn_state && d_features && dy2_scratch && dz1_scratch && g && workspace);
+    GNBV_CHECK_ARG(p->grid_i8 == nullptr || p->grid_i8_row_stride >= (int64_t)grid * grid * grid);
     GNBV_CHECK_ARG(batch > 0 && grid >= 7 && workspace_bytes >= gnbv_encoder_workspace_bytes(batch, grid));
     GNBV_CHECK_ARG(g->w1 && g->b1 && g->bn1_w && g->bn1_b && g->w2 && g->b2 && g->bn2_w && g->bn2_b);
     hipStream_t st = gnbv_stream(stream);
@@ -1390,7 +1396,7 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     wg1_blocks = wg1_blocks > 2048 ? 2048 : ((wg1_blocks + 7) & ~7);  // VGPR-light: 32 waves per CU hide the load latency
     const size_t c1w_lds = (size_t)kEncWaves * (2 * ((O1 + 1) / 2) * kC + 9 * grid) * sizeof(float);
     const int c1w_nr = (2 * ((O1 + 1) / 2) * kC + 255) / 256, c1w_ni = (9 * grid + 255) / 256;  // 16-byte requests per lane and row
-    const bool c1w_staged = (grid % 4 == 0) && (row_stride % 4 == 0) && (((uintptr_t)obs_grid & 15) == 0) && c1w_lds <= 64 * 1024 &&
+    const bool c1w_staged = obs_grid != nullptr && (grid % 4 == 0) && (row_stride % 4 == 0) && (((uintptr_t)obs_grid & 15) == 0) && c1w_lds <= 64 * 1024 &&
                             c1w_nr <= 4 && c1w_ni <= 5;
     if (p->act_bf16) {
         hipLaunchKernelGGL(k_conv1_wgrad<ActBF16>, dim3(wg1_blocks), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, (const uint16_t *)dz1_scratch, (const uint16_t *)y1, bn1,
@@ -1415,6 +1421,10 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
         else if (c1w_nr <= 2 && c1w_ni <= 3) GNBV_C1W(2, 3);  // G = 64
         else GNBV_C1W(4, 5);
 #undef GNBV_C1W
+    } else if (obs_grid == nullptr) {
+        hipLaunchKernelGGL((k_conv1_wgrad<ActF32, int8_t>), dim3(wg1_blocks), dim3(kEncThreads), 0, st, p->grid_i8, rows, p->grid_i8_row_stride,
+                           (const float *)dz1_scratch, (const float *)y1, bn1, bn1 + 2 * kC, bn1 + 3 * kC, S1, (double)batch * O1 * O1 * O1, batch,
+                           grid, O1, wg1_part);
     } else {
         hipLaunchKernelGGL(k_conv1_wgrad<ActF32>, dim3(wg1_blocks), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, (const float *)dz1_scratch, (const float *)y1, bn1,
                        bn1 + 2 * kC, bn1 + 3 * kC, S1, (double)batch * O1 * O1 * O1, batch, grid, O1, wg1_part);

@@ -652,7 +652,10 @@ __device__ __forceinline__ uint32_t step_code(uint32_t c, bool hit, bool path, i
     return c;
 }
 
-template <bool VEC16>
+// VPL voxels per lane and trip: 1 (unaligned rows), 4 (one 4-byte code word in, one 16-byte fp32 tri vector out) or
+// 16 (int8-only observations, tri_out == NULL: 16-byte code vector in/out, 16-byte int8 tri vector out).  Every
+// request is coalesced.  Either tri_out (fp32 observation rows) or tri_i8 (compact rows) may be NULL, not both.
+template <int VPL>
 __global__ __launch_bounds__(kGridThreads) void k_grid_update_coded(
     const uint32_t *__restrict__ hit_mask, const uint32_t *__restrict__ path_mask, const uint32_t *__restrict__ gt_bits,
     const uint8_t *__restrict__ reset_mask, int n, int g3, int words, int words_gt, uint8_t *__restrict__ prob_code,
@@ -669,30 +672,48 @@ __global__ __launch_bounds__(kGridThreads) void k_grid_update_coded(
     const uint32_t *gb = gt_bits + (size_t)e * words_gt;
     uint32_t *sb = scanned_bits + (size_t)e * words_gt;
     uint8_t *code = prob_code + (size_t)e * g3;
-    float *tri = tri_out + (size_t)e * tri_stride;
-    int8_t *tri8 = tri_i8 ? tri_i8 + (size_t)e * tri_i8_stride : nullptr;  // optional compact copy for the conv1 kernels
+    float *tri = tri_out ? tri_out + (size_t)e * tri_stride : nullptr;
+    int8_t *tri8 = tri_i8 ? tri_i8 + (size_t)e * tri_i8_stride : nullptr;  // compact rows for the conv1 kernels
     int cov = 0, ovf = 0;
-    if (VEC16) {  // (4 voxels per lane and trip: one 4-byte code word in, one 16-byte tri vector out, both coalesced)
-        const int nv = g3 >> 2;
+    if constexpr (VPL > 1) {
+        constexpr int NW = VPL / 4;  // 4-voxel words per lane
+        constexpr uint32_t kBits = (1u << VPL) - 1u;
+        const int nv = g3 / VPL;
         for (int i = blockIdx.x * kGridThreads + threadIdx.x; i < nv; i += gridDim.x * kGridThreads) {
-            const int v0 = i << 2, wd = v0 >> 5, sh = v0 & 31;
+            const int v0 = i * VPL, wd = v0 >> 5, sh = v0 & 31;
             const uint32_t hw = hm[wd], pw = pm[wd];
-            const uint32_t hb = (hw >> sh) & 0xFu, pb = (pw >> sh) & 0xFu;
-            const uint32_t cw = reset ? 0u : reinterpret_cast<const uint32_t *>(code)[i];
-            uint32_t out = 0, t8 = 0;
-            float4 t4;
-            float *tp = &t4.x;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const uint32_t c = step_code((cw >> (8 * b)) & 255u, (hb >> b) & 1u, (pb >> b) & 1u, ovf);
-                out |= c << (8 * b);
-                tp[b] = lut[c];
-                t8 |= ((uint32_t)(int)tp[b] & 255u) << (8 * b);
+            const uint32_t hb = (hw >> sh) & kBits, pb = (pw >> sh) & kBits;
+            uint32_t cw[NW], out[NW], t8[NW];
+            if constexpr (NW == 4) {
+                const uint4 c4 = reset ? make_uint4(0u, 0u, 0u, 0u) : reinterpret_cast<const uint4 *>(code)[i];
+                cw[0] = c4.x; cw[1] = c4.y; cw[2] = c4.z; cw[3] = c4.w;
+            } else {
+                cw[0] = reset ? 0u : reinterpret_cast<const uint32_t *>(code)[i];
             }
-            reinterpret_cast<uint32_t *>(code)[i] = out;
-            reinterpret_cast<float4 *>(tri)[i] = t4;
-            if (tri8) reinterpret_cast<uint32_t *>(tri8)[i] = t8;
-            if (sh == 0) {  // one lane in eight owns the 32-voxel word of the scanned set
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+                float4 t4;
+                float *tp = &t4.x;
+                out[q] = 0;
+                t8[q] = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t c = step_code((cw[q] >> (8 * b)) & 255u, (hb >> (4 * q + b)) & 1u, (pb >> (4 * q + b)) & 1u, ovf);
+                    out[q] |= c << (8 * b);
+                    tp[b] = lut[c];
+                    t8[q] |= ((uint32_t)(int)tp[b] & 255u) << (8 * b);
+                }
+                if constexpr (NW == 1)
+                    if (tri) reinterpret_cast<float4 *>(tri)[i] = t4;
+            }
+            if constexpr (NW == 4) {
+                reinterpret_cast<uint4 *>(code)[i] = make_uint4(out[0], out[1], out[2], out[3]);
+                reinterpret_cast<uint4 *>(tri8)[i] = make_uint4(t8[0], t8[1], t8[2], t8[3]);
+            } else {
+                reinterpret_cast<uint32_t *>(code)[i] = out[0];
+                if (tri8) reinterpret_cast<uint32_t *>(tri8)[i] = t8[0];
+            }
+            if (sh == 0) {  // one lane in 32 / VPL owns the 32-voxel word of the scanned set
                 const uint32_t sw = (reset ? 0u : sb[wd]) | (hw & gb[wd]);
                 sb[wd] = sw;
                 cov += __popc(sw);
@@ -705,7 +726,7 @@ __global__ __launch_bounds__(kGridThreads) void k_grid_update_coded(
             const bool hb = (hw >> (v & 31)) & 1u, pb = (pm[wd] >> (v & 31)) & 1u;
             const uint32_t c = step_code(reset ? 0u : code[v], hb, pb, ovf);
             code[v] = (uint8_t)c;
-            tri[v] = lut[c];
+            if (tri) tri[v] = lut[c];
             if (tri8) tri8[v] = (int8_t)(int)lut[c];
             if ((v & 31) == 0) {
                 const uint32_t sw = (reset ? 0u : sb[wd]) | (hw & gb[wd]);
@@ -1233,10 +1254,10 @@ GNBV_API int gnbv_update_occ_grid_coded(const float *depth_raw, const float *seg
                                         size_t workspace_bytes, void *stream)
 {
     GNBV_CHECK_ARG(depth_raw && seg_raw && c2w && inv_intri && poses_xyz && range_gt && voxel_size && gt_bits);
-    GNBV_CHECK_ARG(prob_code && tri_lut && scanned_bits && tri_out && coverage_count && workspace);
+    GNBV_CHECK_ARG(prob_code && tri_lut && scanned_bits && (tri_out || tri_i8) && coverage_count && workspace);
     GNBV_CHECK_ARG(n > 0 && h > 0 && w > 0 && g > 1 && g <= 1024 && poses_row_stride >= 3);
     const int64_t g3 = (int64_t)g * g * g;
-    GNBV_CHECK_ARG(g3 < (1ll << 31) && tri_row_stride >= g3 && (int64_t)h * w < (1ll << 31));
+    GNBV_CHECK_ARG(g3 < (1ll << 31) && (tri_out == nullptr || tri_row_stride >= g3) && (int64_t)h * w < (1ll << 31));
     GNBV_CHECK_ARG(workspace_bytes >= gnbv_voxel_workspace_bytes(n, g) && ((uintptr_t)workspace & 255) == 0);
     hipStream_t st = gnbv_stream(stream);
     VoxelWorkspace ws = carve(workspace, n, g);
@@ -1244,17 +1265,20 @@ GNBV_API int gnbv_update_occ_grid_coded(const float *depth_raw, const float *seg
                            depth_sense_dist, coverage_count, ws, st);
     if (err) return err;
     GNBV_CHECK_ARG(tri_i8 == nullptr || tri_i8_row_stride >= g3);
-    const bool vec16 = (g3 % 4 == 0) && (tri_row_stride % 4 == 0) && (((uintptr_t)tri_out & 15) == 0) &&
-                       (((uintptr_t)prob_code & 3) == 0) && (tri_i8 == nullptr || ((((uintptr_t)tri_i8 | (uintptr_t)tri_i8_row_stride) & 3) == 0));
-    const int bx = grid_update_blocks(vec16 ? g3 / 4 : g3, n);
-    if (vec16)
-        hipLaunchKernelGGL(k_grid_update_coded<true>, dim3(bx, n), dim3(kGridThreads), 0, st, ws.hit, ws.path, gt_bits, reset_mask, n,
-                           (int)g3, ws.words, ws.words, prob_code, tri_lut, scanned_bits, tri_out, tri_row_stride, tri_i8, tri_i8_row_stride,
-                           coverage_count, overflow);
-    else
-        hipLaunchKernelGGL(k_grid_update_coded<false>, dim3(bx, n), dim3(kGridThreads), 0, st, ws.hit, ws.path, gt_bits, reset_mask, n,
-                           (int)g3, ws.words, ws.words, prob_code, tri_lut, scanned_bits, tri_out, tri_row_stride, tri_i8, tri_i8_row_stride,
-                           coverage_count, overflow);
+    const bool vec4 = (g3 % 4 == 0) && (tri_out == nullptr || ((tri_row_stride % 4 == 0) && (((uintptr_t)tri_out & 15) == 0))) &&
+                      (((uintptr_t)prob_code & 3) == 0) && (tri_i8 == nullptr || ((((uintptr_t)tri_i8 | (uintptr_t)tri_i8_row_stride) & 3) == 0));
+    const bool vec16 = tri_out == nullptr && (g3 % 16 == 0) && (((uintptr_t)prob_code & 15) == 0) &&
+                       ((((uintptr_t)tri_i8 | (uintptr_t)tri_i8_row_stride) & 15) == 0);
+    const int vpl = vec16 ? 16 : vec4 ? 4 : 1;
+    const int bx = grid_update_blocks(g3 / vpl, n);
+#define GNBV_LAUNCH_CODED(V)                                                                                                          \
+    hipLaunchKernelGGL(k_grid_update_coded<V>, dim3(bx, n), dim3(kGridThreads), 0, st, ws.hit, ws.path, gt_bits, reset_mask, n, (int)g3, \
+                       ws.words, ws.words, prob_code, tri_lut, scanned_bits, tri_out, tri_row_stride, tri_i8, tri_i8_row_stride,        \
+                       coverage_count, overflow)
+    if (vpl == 16) GNBV_LAUNCH_CODED(16);
+    else if (vpl == 4) GNBV_LAUNCH_CODED(4);
+    else GNBV_LAUNCH_CODED(1);
+#undef GNBV_LAUNCH_CODED
     return gnbv_launch_status();
 }
 

@@ -185,7 +185,11 @@ class ReplayFeedEnv:
         cfg, n, lib = self.cfg, self.num_envs, self.lib
         st = _lib.stream_ptr(self.device)
         obs = self._obs if obs_out is None else obs_out
-        assert obs.shape == (n, cfg.obs_dim) and obs.dtype == torch.float32 and obs.stride(1) == 1
+        # compact rows [state | state_rgb]: the grid goes to `grid_i8_out` only (coded update)
+        compact = obs.shape == (n, cfg.obs_dim - cfg.grid_dim)
+        if compact and (grid_i8_out is None or not self.updater.coded):
+            raise _lib.GennbvHipError("compact observation rows need grid_i8_out and the coded grid update")
+        assert (compact or obs.shape == (n, cfg.obs_dim)) and obs.dtype == torch.float32 and obs.stride(1) == 1
         stride = obs.stride(0)
         depth_raw, seg_raw, rgba, c2w = self.feed.next()
         # step(): clip, forced init action, poses; episode_length_buf += 1
@@ -200,14 +204,17 @@ class ReplayFeedEnv:
             if self._zero_rgba is None:
                 self._zero_rgba = torch.zeros(n, cfg.camera_height, cfg.camera_width, 4, dtype=torch.uint8, device=self.device)
             rgba = self._zero_rgba
-        rgb_off = cfg.state_dim + cfg.grid_dim
+        rgb_off = cfg.state_dim + (0 if compact else cfg.grid_dim)
         _lib.check(lib.gnbv_env_obs_rgb(rgba.data_ptr(), self.gray_prev.data_ptr(), self.reset_mask.data_ptr(), n,
                                         cfg.camera_height, cfg.camera_width, cfg.rgb_h, cfg.rgb_w,
                                         obs.data_ptr() + 4 * rgb_off, stride, st), "gnbv_env_obs_rgb")
         # obs["grid"]: tri-class grid straight into the observation rows
-        self.updater.update(depth_raw, seg_raw, c2w, self.poses, reset_mask=self.reset_mask,
-                            tri_out=obs[:, cfg.state_dim:], tri_row_stride=stride,
-                            tri_i8_out=grid_i8_out if self.updater.coded else None)
+        if compact:
+            self.updater.update(depth_raw, seg_raw, c2w, self.poses, reset_mask=self.reset_mask, tri_i8_out=grid_i8_out, fp32_out=False)
+        else:
+            self.updater.update(depth_raw, seg_raw, c2w, self.poses, reset_mask=self.reset_mask,
+                                tri_out=obs[:, cfg.state_dim:], tri_row_stride=stride,
+                                tri_i8_out=grid_i8_out if self.updater.coded else None)
         # rewards / termination / reset bookkeeping
         _lib.check(lib.gnbv_env_post_step(C.byref(self._post), st), "gnbv_env_post_step")
         return obs

@@ -89,10 +89,13 @@ class OccupancyGridUpdater:
 
     def update(self, depth_raw: torch.Tensor, seg_raw: torch.Tensor, c2w: torch.Tensor, poses: torch.Tensor,
                reset_mask: Optional[torch.Tensor] = None, tri_out: Optional[torch.Tensor] = None,
-               tri_row_stride: Optional[int] = None, tri_i8_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+               tri_row_stride: Optional[int] = None, tri_i8_out: Optional[torch.Tensor] = None,
+               fp32_out: bool = True) -> Optional[torch.Tensor]:
         """depth_raw/seg_raw [N,H,W] f32 RAW camera tensors, c2w [N,4,4] f32, poses [N,>=3]
         f32 (xyz first).  `tri_out`: optional destination whose row e starts at
-        tri_out.data_ptr() + e*tri_row_stride*4 (e.g. the grid slice of the flat obs)."""
+        tri_out.data_ptr() + e*tri_row_stride*4 (e.g. the grid slice of the flat obs).
+        `fp32_out=False` (coded mode with `tri_i8_out`): compact observations, the tri-class grid is written
+        only as int8."""
         n, g = self.num_envs, self.grid_size
         _lib.require_cuda(depth_raw, seg_raw, c2w, poses, reset_mask, tri_out)
         _lib.require_contig(depth_raw, seg_raw, c2w)
@@ -100,7 +103,9 @@ class OccupancyGridUpdater:
         assert seg_raw.shape == (n, self.h, self.w) and seg_raw.dtype == torch.float32
         assert c2w.shape == (n, 4, 4) and c2w.dtype == torch.float32
         assert poses.dtype == torch.float32 and poses.stride(-1) == 1 and poses.shape[0] == n
-        if tri_out is None:
+        if not fp32_out:
+            assert self.coded and tri_i8_out is not None and tri_out is None, "int8-only output needs the coded update and tri_i8_out"
+        elif tri_out is None:
             if self._own_tri is None:
                 self._own_tri = torch.empty(n, g, g, g, dtype=torch.float32, device=self.device)
             tri_out, tri_row_stride = self._own_tri, g ** 3
@@ -114,8 +119,8 @@ class OccupancyGridUpdater:
                 depth_raw.data_ptr(), seg_raw.data_ptr(), c2w.data_ptr(), self.inv_intri_host.data_ptr(),
                 poses.data_ptr(), poses.stride(0), self.range_gt.data_ptr(), self.voxel_size_gt.data_ptr(),
                 self.gt_bits.data_ptr(), _lib.ptr(reset_mask), n, self.h, self.w, g, self.depth_sense_dist,
-                self.prob_code.data_ptr(), self._tri_lut.data_ptr(), self.scanned_bits.data_ptr(), tri_out.data_ptr(),
-                int(tri_row_stride), _lib.ptr(tri_i8_out), 0 if tri_i8_out is None else int(tri_i8_out.stride(0)),
+                self.prob_code.data_ptr(), self._tri_lut.data_ptr(), self.scanned_bits.data_ptr(), _lib.ptr(tri_out),
+                int(tri_row_stride or 0), _lib.ptr(tri_i8_out), 0 if tri_i8_out is None else int(tri_i8_out.stride(0)),
                 self.coverage_count.data_ptr(), self.code_overflow.data_ptr(), self.workspace.data_ptr(),
                 self.workspace.numel(), _lib.stream_ptr(self.device)), "gnbv_update_occ_grid_coded")
             return tri_out

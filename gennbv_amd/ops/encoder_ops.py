@@ -16,47 +16,64 @@ import torch
 from .. import _lib
 
 
-class RowGather:
-    """A lazily gathered observation batch: rows `rows` of the 2-D fp32 matrix `base`."""
+def _flat_rows(small: torch.Tensor, grid_i8: torch.Tensor, state_dim: int) -> torch.Tensor:
+    """compact rows [state | state_rgb] + int8 grid -> the reference's flat fp32 rows [state | grid | state_rgb]."""
+    return torch.cat((small[:, :state_dim], grid_i8.to(torch.float32), small[:, state_dim:]), dim=1)
 
-    def __init__(self, base: torch.Tensor, rows: torch.Tensor, grid_i8: Optional[torch.Tensor] = None):
+
+class RowGather:
+    """A lazily gathered observation batch: rows `rows` of the 2-D fp32 matrix `base`.
+
+    `grid_i8` ([R, G^3] int8, same row numbering): compact copy of the tri-class grid slices; the conv1 kernels read
+    it instead of the fp32 slice of `base`.  `compact_state_dim = s`: COMPACT observations -- `base` rows are
+    [state (s) | state_rgb] only, the grid exists solely as `grid_i8` (a quarter of the bytes of a flat fp32 row)."""
+
+    def __init__(self, base: torch.Tensor, rows: torch.Tensor, grid_i8: Optional[torch.Tensor] = None,
+                 compact_state_dim: Optional[int] = None):
         assert base.dim() == 2 and base.stride(1) == 1 and rows.dtype == torch.int64
         self.base, self.rows = base, rows.contiguous()
-        # optional compact copy of the grid slices ([R, G^3] int8, same row numbering): the conv1 kernels read it
-        # instead of the fp32 slice of `base`
         assert grid_i8 is None or (grid_i8.dtype == torch.int8 and grid_i8.dim() == 2 and grid_i8.stride(1) == 1
                                    and grid_i8.shape[0] == base.shape[0])
-        self.grid_i8 = grid_i8
-        self.shape = (rows.shape[0], base.shape[1])
+        assert compact_state_dim is None or grid_i8 is not None
+        self.grid_i8, self.compact_state_dim = grid_i8, compact_state_dim
+        self.shape = (rows.shape[0], base.shape[1] + (0 if compact_state_dim is None else grid_i8.shape[1]))
         self.device = base.device
 
     def float(self):
         return self
 
     def materialize(self) -> torch.Tensor:
+        if self.compact_state_dim is not None:
+            return _flat_rows(self.base[self.rows], self.grid_i8[self.rows], self.compact_state_dim)
         return self.base[self.rows]
 
     def columns(self, a: int, b: int) -> torch.Tensor:
+        assert self.compact_state_dim is None or b <= self.compact_state_dim
         return self.base[:, a:b][self.rows]
 
 
 class DenseObs:
     """A whole observation matrix [N, D_obs] together with the compact int8 copy of its grid slices [N, G^3]
-    (rollout forward: every row is used, no gather)."""
+    (rollout forward: every row is used, no gather).  `compact_state_dim`: see RowGather."""
 
-    def __init__(self, base: torch.Tensor, grid_i8: Optional[torch.Tensor] = None):
+    def __init__(self, base: torch.Tensor, grid_i8: Optional[torch.Tensor] = None, compact_state_dim: Optional[int] = None):
         assert base.dim() == 2 and base.stride(1) == 1
         assert grid_i8 is None or (grid_i8.dtype == torch.int8 and grid_i8.shape[0] == base.shape[0] and grid_i8.stride(1) == 1)
-        self.base, self.rows, self.grid_i8 = base, None, grid_i8
-        self.shape, self.device, self.is_cuda = base.shape, base.device, base.is_cuda
+        assert compact_state_dim is None or grid_i8 is not None
+        self.base, self.rows, self.grid_i8, self.compact_state_dim = base, None, grid_i8, compact_state_dim
+        self.shape = (base.shape[0], base.shape[1] + (0 if compact_state_dim is None else grid_i8.shape[1]))
+        self.device, self.is_cuda = base.device, base.is_cuda
 
     def float(self):
         return self
 
     def materialize(self) -> torch.Tensor:
+        if self.compact_state_dim is not None:
+            return _flat_rows(self.base, self.grid_i8, self.compact_state_dim)
         return self.base
 
     def columns(self, a: int, b: int) -> torch.Tensor:
+        assert self.compact_state_dim is None or b <= self.compact_state_dim
         return self.base[:, a:b]
 
 
@@ -94,7 +111,7 @@ def _params_struct(seq, act_bf16: bool = False, grid_i8: Optional[torch.Tensor] 
 
 class _GridEncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, base, rows, grid_off, grid, training, skip_flag, seq, act_bf16, write_through, grid_i8, w1, b1, g1, be1, w2, b2, g2, be2):
+    def forward(ctx, base, rows, grid_off, grid, training, skip_flag, seq, act_bf16, write_through, grid_i8, compact, w1, b1, g1, be1, w2, b2, g2, be2):
         lib = _lib.load()
         _lib.require_cuda(base, w1)
         for t in (w1, b1, g1, be1, w2, b2, g2, be2):
@@ -111,7 +128,9 @@ class _GridEncoderFn(torch.autograd.Function):
         feats = torch.empty(batch, 16 * p2, dtype=torch.float32, device=dev)
         ws = _workspace(lib, batch, grid, dev)
         params = _params_struct(seq, act_bf16, grid_i8)
-        obs_ptr = base.data_ptr() + 4 * grid_off
+        # compact observations: `base` has no grid slice, the kernels read the int8 rows only (obs pointer NULL)
+        assert not compact or grid_i8 is not None
+        obs_ptr = None if compact else base.data_ptr() + 4 * grid_off
         _lib.check(lib.gnbv_encoder_grid_forward(
             obs_ptr, _lib.ptr(rows), base.stride(0), batch, grid, C.byref(params), int(training), _lib.ptr(skip_flag),
             y1.data_ptr(), y2.data_ptr(), bn_state.data_ptr(), feats.data_ptr(), ws.data_ptr(), ws.numel(),
@@ -120,6 +139,7 @@ class _GridEncoderFn(torch.autograd.Function):
         ctx.meta = (grid_off, grid, batch, seq, act_bf16)
         ctx.write_through = write_through
         ctx.grid_i8 = grid_i8
+        ctx.obs_ptr = obs_ptr
         return feats
 
     @staticmethod
@@ -143,19 +163,20 @@ class _GridEncoderFn(torch.autograd.Function):
         params = _params_struct(seq, act_bf16, ctx.grid_i8)
         ws = _workspace(lib, batch, grid, dev)
         _lib.check(lib.gnbv_encoder_grid_backward(
-            base.data_ptr() + 4 * grid_off, _lib.ptr(rows), base.stride(0), batch, grid, C.byref(params), y1.data_ptr(),
+            ctx.obs_ptr, _lib.ptr(rows), base.stride(0), batch, grid, C.byref(params), y1.data_ptr(),
             y2.data_ptr(), bn_state.data_ptr(), d_feats.data_ptr(), dy2.data_ptr(), dz1.data_ptr(), C.byref(gs),
             ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "gnbv_encoder_grid_backward")
         if direct:
-            return (None,) * 18
-        return (None, None, None, None, None, None, None, None, None, None, *grads)
+            return (None,) * 19
+        return (None,) * 11 + tuple(grads)
 
 
 def grid_encoder(base: torch.Tensor, rows: Optional[torch.Tensor], grid_off: int, grid: int, seq, training: bool,
                  skip_flag: Optional[torch.Tensor] = None, act_bf16: bool = False, write_through: bool = False,
-                 grid_i8: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """seq = the `naive_encoder_grid` nn.Sequential (conv, bn, relu, conv, bn, relu)."""
-    return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, bool(act_bf16), bool(write_through), grid_i8, seq[0].weight, seq[0].bias,
+                 grid_i8: Optional[torch.Tensor] = None, compact: bool = False) -> torch.Tensor:
+    """seq = the `naive_encoder_grid` nn.Sequential (conv, bn, relu, conv, bn, relu).  `compact`: `base` rows carry
+    no grid slice, the grid is read from `grid_i8` only."""
+    return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, bool(act_bf16), bool(write_through), grid_i8, bool(compact), seq[0].weight, seq[0].bias,
                                 seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias)
 
 
@@ -213,9 +234,10 @@ def hybrid_branches(enc, observations):
     (hybrid_encoder.py:76-88 of the reference)."""
     s = enc.state_input_shape[0]
     g = enc.grid_size
-    grid_i8 = None
+    grid_i8, compact = None, False
     if isinstance(observations, (RowGather, DenseObs)):
         base, rows, grid_i8 = observations.base, observations.rows, observations.grid_i8
+        compact = observations.compact_state_dim is not None
         num_env = int(rows.shape[0]) if rows is not None else int(base.shape[0])
         get_state = lambda: observations.columns(0, s)  # noqa: E731  (gather of the pose columns: on the side stream too)
     else:
@@ -242,7 +264,7 @@ def hybrid_branches(enc, observations):
     else:
         feature_action = pose_branch()
     feature_grid = grid_encoder(base, rows, s, g, enc.naive_encoder_grid, enc.training, getattr(enc, "_bn_skip_flag", None),
-                                enc.compute_dtype == torch.bfloat16, getattr(enc, "_grad_write_through", False), grid_i8)
+                                enc.compute_dtype == torch.bfloat16, getattr(enc, "_grad_write_through", False), grid_i8, compact)
     if getattr(enc, "_split_backward", False) and torch.is_grad_enabled():
         # data-parallel: cut the autograd graph at the conv-stack output so that the backward runs in
         # two phases (late layers first, their gradient all-reduce overlaps the conv-stack backward)

@@ -37,7 +37,10 @@ class RolloutBufferSamples(NamedTuple):
 
 class TensorRolloutBuffer_Grid_Obs:
     def __init__(self, buffer_size: int, observation_space, action_space, device="cpu", gae_lambda: float = 1,
-                 gamma: float = 0.99, n_envs: int = 1):
+                 gamma: float = 0.99, n_envs: int = 1, compact=None):
+        """compact = (state_dim, grid_elems): COMPACT observation storage -- `observations` rows hold only
+        [state | state_rgb] in fp32 and the tri-class grid (values -1/0/1) lives solely in `grid_i8`
+        ([T+1, N, G^3] int8): D_obs*4 -> (D_obs - G^3)*4 + G^3 bytes per row (1.08 MB -> 0.30 MB at G = 64)."""
         self.buffer_size, self.n_envs = int(buffer_size), int(n_envs)
         self.num_transitions_per_env, self.num_envs = self.buffer_size, self.n_envs
         self.observation_space, self.action_space = observation_space, action_space
@@ -46,7 +49,13 @@ class TensorRolloutBuffer_Grid_Obs:
         self.device = torch.device(device)
         self.gae_lambda, self.gamma = gae_lambda, gamma
         t, n, dev = self.buffer_size, self.n_envs, self.device
-        self.observations = torch.zeros(t + 1, n, *self.obs_shape, device=dev)
+        self.compact_state_dim = None
+        if compact is not None:
+            assert len(self.obs_shape) == 1
+            self.compact_state_dim, self.grid_elems = int(compact[0]), int(compact[1])
+            self.observations = torch.zeros(t + 1, n, self.obs_shape[0] - self.grid_elems, device=dev)
+        else:
+            self.observations = torch.zeros(t + 1, n, *self.obs_shape, device=dev)
         self.rewards = torch.zeros(t, n, 1, device=dev)
         self.actions = torch.zeros(t, n, self.actions_shape, device=dev)
         self.episode_starts = torch.zeros(t, n, 1, device=dev, dtype=torch.uint8)
@@ -57,6 +66,8 @@ class TensorRolloutBuffer_Grid_Obs:
         self.privileged_observations = None
         self.lazy_obs = False  # True: minibatch observations are RowGather views (gather fused into conv1)
         self.grid_i8 = None    # optional [T+1, N, G^3] int8 copy of the grid slices (enable_grid_i8)
+        if compact is not None:
+            self.enable_grid_i8(self.grid_elems)
         self.reset()
 
     def enable_grid_i8(self, grid_elems: int) -> None:
@@ -97,7 +108,13 @@ class TensorRolloutBuffer_Grid_Obs:
             obs = obs[0]
         row = self.observations[self.step]
         if obs.data_ptr() != row.data_ptr():
-            row.copy_(obs)
+            if self.compact_state_dim is not None and obs.shape[-1] == self.obs_shape[0]:  # a flat fp32 row: split it
+                s0, ge = self.compact_state_dim, self.grid_elems
+                row[:, :s0].copy_(obs[:, :s0])
+                row[:, s0:].copy_(obs[:, s0 + ge:])
+                self.grid_i8[self.step].copy_(obs[:, s0:s0 + ge].to(torch.int8))
+            else:
+                row.copy_(obs)
         self.actions[self.step].copy_(action)
         self.rewards[self.step].copy_(reward.view(-1, 1))
         self.episode_starts[self.step].copy_(episode_start.view(-1, 1))
@@ -137,7 +154,11 @@ class TensorRolloutBuffer_Grid_Obs:
         flat = lambda x: x.view(x.shape[0] * n, *x.shape[2:])  # noqa: E731
         if self.lazy_obs:
             from ..ops.encoder_ops import RowGather
-            obs = RowGather(flat(self.observations[:t]), rows, None if self.grid_i8 is None else flat(self.grid_i8[:t]))
+            obs = RowGather(flat(self.observations[:t]), rows, None if self.grid_i8 is None else flat(self.grid_i8[:t]),
+                            self.compact_state_dim)
+        elif self.compact_state_dim is not None:
+            from ..ops.encoder_ops import _flat_rows
+            obs = _flat_rows(flat(self.observations[:t])[rows], flat(self.grid_i8[:t])[rows], self.compact_state_dim)
         else:
             obs = flat(self.observations[:t])[rows]
         return RolloutBufferSamples(

@@ -55,7 +55,9 @@ class PPO_Grid_Obs:
                  use_sde: bool = False, sde_sample_freq: int = -1, target_kl: Optional[float] = None,
                  tensorboard_log: Optional[str] = None, create_eval_env: bool = False,
                  policy_kwargs: Optional[Dict[str, Any]] = None, verbose: int = 0, seed: Optional[int] = None,
-                 device: Union[torch.device, str] = "auto", _init_setup_model: bool = True):
+                 device: Union[torch.device, str] = "auto", _init_setup_model: bool = True, compact_obs: Optional[bool] = None):
+        """`compact_obs` (additive; default: env GENNBV_COMPACT_OBS, off): keep the tri-class grid of every stored
+        observation as int8 only (sb3/buffers.py `compact`) -- same values, 3.6x less HBM for the rollout buffer."""
         assert not use_sde, "gSDE is not on the GenNBV path"
         if normalize_advantage:
             assert batch_size > 1, "`batch_size` must be greater than 1. See https://github.com/DLR-RM/stable-baselines3/issues/440"
@@ -88,6 +90,7 @@ class PPO_Grid_Obs:
         self.train_impl = "hip"   # fused loss / flat Adam / device-side early stop when the encoder backend is "hip"
         self.use_graph = True     # replay the minibatch step as one hipGraph
         self.grad_write_through = os.environ.get("GENNBV_WRITE_THROUGH", "1") != "0"  # backward kernels store into the flat gradient buffer (ops/direct_grad.py)
+        self.compact_obs = (os.environ.get("GENNBV_COMPACT_OBS", "0") == "1") if compact_obs is None else bool(compact_obs)
         self._hip = None
         self._sync = None         # gennbv_amd.parallel.GradSync when data-parallel
         if _init_setup_model:
@@ -113,9 +116,17 @@ class PPO_Grid_Obs:
     def _setup_model(self) -> None:
         self.lr_schedule = _schedule(self.learning_rate)
         self.set_random_seed(self.seed)
+        compact = None
+        if self.compact_obs:
+            fek = self.policy_kwargs.get("features_extractor_kwargs", {})
+            g, s0 = int(fek.get("grid_size", 20)), int(fek["state_input_shape"][0])
+            if not (getattr(self.env, "supports_grid_i8", False) and fek.get("backend", "torch") == "hip" and self.device.type == "cuda"):
+                raise ValueError("compact_obs needs an env that writes the int8 grid rows (supports_grid_i8), the encoder "
+                                 "backend 'hip' and a GPU device")
+            compact = (s0, g ** 3)
         self.rollout_buffer = TensorRolloutBuffer_Grid_Obs(self.n_steps, self.observation_space, self.action_space,
                                                            device=self.device, gamma=self.gamma,
-                                                           gae_lambda=self.gae_lambda, n_envs=self.n_envs)
+                                                           gae_lambda=self.gae_lambda, n_envs=self.n_envs, compact=compact)
         self.policy = self.policy_class(self.observation_space, self.action_space, self.lr_schedule, use_sde=False,
                                         **self.policy_kwargs).to(self.device)
         self.rollout_buffer.lazy_obs = getattr(self.policy.features_extractor, "backend", "torch") == "hip"
@@ -338,7 +349,7 @@ class PPO_Grid_Obs:
         if phase in ("all", "A"):
             t, n = buf.buffer_size, buf.n_envs
             obs = RowGather(buf.observations[:t].view(t * n, -1), loss.rows,
-                            None if buf.grid_i8 is None else buf.grid_i8[:t].view(t * n, -1))
+                            None if buf.grid_i8 is None else buf.grid_i8[:t].view(t * n, -1), buf.compact_state_dim)
             enc = pol.features_extractor
             if st.get("fused_head"):
                 fa, fg = encoder_ops.hybrid_branches(enc, obs)
@@ -526,9 +537,12 @@ class PPO_Grid_Obs:
     def _with_grid_i8(self, obs, row: int):
         """The rollout forward reads the compact grid copy of buffer row `row` when there is one (fused path only)."""
         buf = self.rollout_buffer
+        from ..ops.encoder_ops import DenseObs
+        if buf.compact_state_dim is not None:  # compact rows: the grid exists only in the int8 rows
+            assert obs.data_ptr() == buf.observations[row].data_ptr(), "compact observations live in the rollout buffer"
+            return DenseObs(obs, buf.grid_i8[row], buf.compact_state_dim)
         if buf.grid_i8 is None or not getattr(self.policy, "_fused_rollout", False) or obs.data_ptr() != buf.observations[row].data_ptr():
             return obs
-        from ..ops.encoder_ops import DenseObs
         return DenseObs(obs, buf.grid_i8[row])
 
     def _maybe_enable_grid_i8(self) -> None:
@@ -543,7 +557,7 @@ class PPO_Grid_Obs:
     def _refresh_grid_i8_row0(self) -> None:
         """row 0 of the int8 copy from the fp32 observation row 0 (only when that row was not written by the env)."""
         buf, enc = self.rollout_buffer, self.policy.features_extractor
-        if buf.grid_i8 is not None:
+        if buf.grid_i8 is not None and buf.compact_state_dim is None:
             s0 = enc.state_input_shape[0]
             buf.grid_i8[0].copy_(buf.observations[0][:, s0:s0 + enc.grid_size ** 3].to(torch.int8))
 

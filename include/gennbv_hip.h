@@ -129,8 +129,10 @@ int gnbv_update_occ_grid_coded(const float *depth_raw, const float *seg_raw, con
                                const float *poses_xyz, int64_t poses_row_stride, const float *range_gt, const float *voxel_size,
                                const uint32_t *gt_bits, const uint8_t *reset_mask, int n, int h, int w, int g,
                                float depth_sense_dist, uint8_t *prob_code /*[N,G^3]*/, const float *tri_lut /*[256] device*/,
-                               uint32_t *scanned_bits, float *tri_out, int64_t tri_row_stride,
-                               int8_t *tri_i8 /*NULL, or a second, int8 copy of the tri-class grid: row e at tri_i8 + e*stride*/,
+                               uint32_t *scanned_bits, float *tri_out /*NULL: compact observations, int8 rows only*/,
+                               int64_t tri_row_stride,
+                               int8_t *tri_i8 /*NULL, or the tri-class grid as int8 rows (-1/0/1): row e at tri_i8 + e*stride;
+                                                at least one of tri_out / tri_i8 must be given*/,
                                int64_t tri_i8_row_stride /*bytes*/, int32_t *coverage_count,
                                int32_t *overflow /*[1] device or NULL*/, void *workspace, size_t workspace_bytes, void *stream);
 
@@ -212,7 +214,9 @@ typedef struct GnbvEncoderParams {
     const int8_t *grid_i8;        /* NULL, or an int8 copy of the grid slices (values -1/0/1, as written by
                                      gnbv_update_occ_grid_coded): sample b reads grid_i8 + (rows ? rows[b] : b) *
                                      grid_i8_row_stride bytes instead of obs_grid (a quarter of the input traffic);
-                                     used when grid % 16 == 0, otherwise obs_grid is read */
+                                     used by the LDS-staged kernels when grid % 16 == 0, otherwise obs_grid is read --
+                                     unless obs_grid == NULL (compact observations: the grid exists only as these
+                                     rows; any grid size, fp32 activations) */
     int64_t grid_i8_row_stride;
 } GnbvEncoderParams;
 
@@ -224,7 +228,8 @@ size_t gnbv_encoder_workspace_bytes(int batch, int grid);
 /* number of ELEMENTS (fp32 or bf16, GnbvEncoderParams.act_bf16) of the layer-1 activation buffers (y1, dz1_scratch) */
 size_t gnbv_encoder_y1_elems(int batch, int grid);
 
-/* obs_grid: pointer to the grid slice of row 0 of an observation matrix; sample b reads
+/* obs_grid: pointer to the grid slice of row 0 of an observation matrix (NULL with params->grid_i8 set: compact
+ * observations); sample b reads
  * obs_grid + (rows ? rows[b] : b) * row_stride floats (the minibatch gather of
  * buffers.py:753-762 is fused into the read).  training != 0: BatchNorm uses batch statistics
  * and updates the running stats (unless *skip_flag != 0), else the running stats.

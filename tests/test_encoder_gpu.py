@@ -219,3 +219,39 @@ def test_int8_grid_copy_gives_identical_results(g, b):
     assert torch.equal(outs[0][0], outs[1][0])
     for a, c in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("g,b,train", [(20, 5, True), (20, 8, False), (33, 3, True), (64, 4, True), (128, 2, True)])
+def test_compact_observation_rows_match_flat_rows(g, b, train):
+    """Compact rows ([state | state_rgb] fp32 + the grid as int8 only, obs pointer NULL at the C-ABI): features and
+    gradients equal those of the flat fp32 rows -- bit for bit where both take the LDS-staged kernels (G % 16 == 0 and
+    the slab fits), to fp32 round-off where the compact rows take the direct int8 kernels (other summation order)."""
+    from gennbv_amd.ops.encoder_ops import RowGather, DenseObs
+    _, hip = _pair(g)
+    hip.train(train)
+    base = _obs(2 * b, g, seed=5)
+    rows = torch.randperm(2 * b)[:b].to(DEV)
+    s0 = 600
+    grid_i8 = base[:, s0:s0 + g ** 3].to(torch.int8).contiguous()
+    small = torch.cat((base[:, :s0], base[:, s0 + g ** 3:]), dim=1).contiguous()
+    compact = RowGather(small, rows, grid_i8, compact_state_dim=s0)
+    assert torch.equal(compact.materialize(), base[rows])
+    assert torch.equal(DenseObs(small, grid_i8, s0).materialize(), base)
+    outs = []
+    for obs in (RowGather(base, rows), compact):
+        hip.zero_grad()
+        with torch.set_grad_enabled(train):
+            f = hip.features_extractor(obs)
+        if train:
+            f.backward(torch.ones_like(f) * 0.01)
+        outs.append((f.detach().clone(), [p.grad.clone() for p in hip.features_extractor.naive_encoder_grid.parameters()] if train else []))
+    exact = g == 64
+    if exact:
+        assert torch.equal(outs[0][0], outs[1][0])
+    else:
+        assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6), float((outs[0][0] - outs[1][0]).abs().max())
+    for a, c in zip(outs[0][1], outs[1][1]):
+        if exact:
+            assert torch.equal(a, c)
+        else:
+            assert torch.allclose(a, c, rtol=1e-4, atol=1e-6), float((a - c).abs().max())

@@ -208,3 +208,71 @@ def test_learn_with_int8_grid_copy_matches_fp32_rows(monkeypatch):
     a, b = run(True), run(False)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("g", [16, 20])
+def test_learn_with_compact_observations_matches_flat_rows(monkeypatch, g):
+    """compact_obs=True (rows = [state | state_rgb] fp32, grid as int8 only): the stored rows equal the flat rows of a
+    run without it.  G = 16: both runs use the LDS-staged conv1 kernels (int8 / fp32 slab, same arithmetic) and
+    learn() ends with exactly the same parameters; G = 20: the compact run takes the direct int8 conv1 kernels (other
+    summation order than the staged fp32 ones), so one iteration is compared with a round-off tolerance."""
+    from gennbv_amd.env import synthetic as S
+    from gennbv_amd.env.config import TaskConfig
+    from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
+    from gennbv_amd.network.hybrid_encoder import Hybrid_Encoder
+    from gennbv_amd.sb3.policies import ActorCriticPolicy_Train_Eval
+    from gennbv_amd.sb3.ppo_grid_obs import PPO_Grid_Obs
+    n, t = 8, 4
+    monkeypatch.setenv("GENNBV_GRID_I8", "0")
+
+    def run(compact: bool):
+        torch.manual_seed(0)
+        np.random.seed(0)
+        cfg = TaskConfig(camera_width=64, camera_height=48, grid_size=g)
+        scene = S.make_scenes(n, g, seed=2, device=DEV)
+        feed = ReplayFeed.synthetic(scene, cfg, 5, seed=2)
+        env = ReplayFeedEnv(cfg, scene, feed, DEV, max_episode_length=6)
+        algo = PPO_Grid_Obs(ActorCriticPolicy_Train_Eval, env, learning_rate=1e-4, n_steps=t, batch_size=8, n_epochs=2, ent_coef=0.01,
+                            vf_coef=0.8, max_grad_norm=1.0, target_kl=None, seed=1, device=DEV, compact_obs=compact,
+                            policy_kwargs=dict(net_arch=[], features_extractor_class=Hybrid_Encoder, features_extractor_kwargs=dict(
+                                encoder_param={"hidden_shapes": [256, 256], "visual_dim": 256},
+                                net_param={"transformer_params": [[1, 256], [1, 256]], "append_hidden_shapes": [256, 256]},
+                                state_input_shape=(cfg.state_dim,), visual_input_shape=(cfg.stack, 48, 64), grid_size=g, backend="hip")))
+        algo.learn(total_timesteps=(2 if g == 16 else 1) * n * t)
+        buf = algo.rollout_buffer
+        s0 = cfg.state_dim
+        if compact:
+            assert buf.observations.shape[-1] == cfg.obs_dim - g ** 3 and buf.grid_i8 is not None
+            rows = torch.cat((buf.observations[..., :s0], buf.grid_i8.float(), buf.observations[..., s0:]), dim=-1)
+            mb = next(iter(buf.get(8))).observations  # minibatch view -> the reference's flat rows
+            assert mb.materialize().shape == (8, cfg.obs_dim)
+        else:
+            assert buf.grid_i8 is None
+            rows = buf.observations.clone()
+        return [p.detach().clone() for p in algo.policy.parameters()], rows
+
+    (pa, ra), (pb, rb) = run(True), run(False)
+    assert torch.equal(ra, rb)
+    for x, y in zip(pa, pb):
+        if g == 16:
+            assert torch.equal(x, y)
+        else:
+            assert torch.allclose(x, y, rtol=0, atol=2e-6), float((x - y).abs().max())
+
+
+def test_compact_observations_need_an_int8_capable_env():
+    from gennbv_amd.network.hybrid_encoder import Hybrid_Encoder
+    from gennbv_amd.sb3.policies import ActorCriticPolicy_Train_Eval
+    from gennbv_amd.sb3.ppo_grid_obs import PPO_Grid_Obs
+    from gennbv_amd.spaces import Box, MultiDiscrete
+
+    class Env:
+        num_envs, device = 2, DEV
+        observation_space = Box(-np.inf, np.inf, (600 + 8000 + 8192,))
+        action_space = MultiDiscrete([81, 81, 51, 1, 13, 13])
+
+    with pytest.raises(ValueError, match="compact_obs"):
+        PPO_Grid_Obs(ActorCriticPolicy_Train_Eval, Env(), n_steps=4, batch_size=4, device=DEV, compact_obs=True,
+                     policy_kwargs=dict(net_arch=[], features_extractor_class=Hybrid_Encoder, features_extractor_kwargs=dict(
+                         encoder_param={}, net_param={"append_hidden_shapes": [256, 256]}, state_input_shape=(600,),
+                         visual_input_shape=(2, 64, 64), grid_size=20, backend="hip")))

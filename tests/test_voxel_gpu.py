@@ -57,7 +57,8 @@ def test_postprocess_backprojection_voxelidx_vs_golden():
     assert utils.scanned_pts_to_idx_3D([torch.zeros(0, 3, device=DEV)], T(fx["range_gt"]), T(fx["voxel_size"]), g) == [[]]
 
 
-def _run_sequence(n, h, w, g, steps, seed, reset_at=(), pose_override=None, packed=None, gt_scale=None, max_steps=None):
+def _run_sequence(n, h, w, g, steps, seed, reset_at=(), pose_override=None, packed=None, gt_scale=None, max_steps=None,
+                  int8_only=False):
     """HIP updater vs oracle on the same seeded synthetic frames; returns per-step mismatch info."""
     from gennbv_amd.env.state_encoding import OccupancyGridUpdater
     cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
@@ -85,8 +86,14 @@ def _run_sequence(n, h, w, g, steps, seed, reset_at=(), pose_override=None, pack
         tri_o, cov_o, hit_o, path_o = orc.update_occ_grid(
             dp, sp, c2w.numpy(), kinv.numpy(), f.poses[:, :3].numpy(), scene.range_gt.numpy(), scene.voxel_size.numpy(),
             scene.grid_gt.numpy(), prob, scan, reset_mask=reset, return_masks=True)
-        tri = upd.update(f.depth_raw.to(DEV), f.seg_raw.to(DEV), c2w.to(DEV), f.poses.to(DEV).contiguous(),
-                         reset_mask=None if reset is None else torch.from_numpy(reset).to(DEV))
+        if int8_only:  # compact observations: the tri-class grid is written as int8 rows only
+            t8 = torch.full((n, g ** 3), 99, dtype=torch.int8, device=DEV)
+            assert upd.update(f.depth_raw.to(DEV), f.seg_raw.to(DEV), c2w.to(DEV), f.poses.to(DEV).contiguous(),
+                              reset_mask=None if reset is None else torch.from_numpy(reset).to(DEV), tri_i8_out=t8, fp32_out=False) is None
+            tri = t8.view(n, g, g, g).float()
+        else:
+            tri = upd.update(f.depth_raw.to(DEV), f.seg_raw.to(DEV), c2w.to(DEV), f.poses.to(DEV).contiguous(),
+                             reset_mask=None if reset is None else torch.from_numpy(reset).to(DEV))
         hit, path = upd.masks()
         assert np.array_equal(hit.cpu().numpy(), hit_o), f"step {s}: hit mask differs"
         assert np.array_equal(path.cpu().numpy(), path_o), f"step {s}: path mask differs"
@@ -110,6 +117,14 @@ def test_coded_probability_grid_bit_exact_vs_oracle(n, h, w, g, steps):
     equal the oracle bit for bit over a sequence with resets (repeated -0.05 steps reach the fp32 values the reference
     reaches: -0.05, -0.1, -0.15000001, ...)."""
     _run_sequence(n, h, w, g, steps, seed=23 + g, reset_at=(2, 5), max_steps=100)
+
+
+@pytest.mark.parametrize("n,h,w,g,steps", [(4, 120, 160, 16, 8), (3, 100, 100, 20, 6), (3, 120, 160, 64, 4), (2, 30, 37, 33, 4),
+                                           (2, 30, 37, 18, 4)])
+def test_coded_update_int8_only_rows_bit_exact_vs_oracle(n, h, w, g, steps):
+    """Compact observation rows (no fp32 tri-class output): G^3 % 16 == 0 takes the 16-voxels-per-lane kernel,
+    G = 18 the 4-per-lane one, G = 33 the scalar one."""
+    _run_sequence(n, h, w, g, steps, seed=31 + g, reset_at=(2, 5), max_steps=100, int8_only=True)
 
 
 def test_coded_probability_grid_tables_and_saturation():

@@ -15,7 +15,12 @@ ap.add_argument("--w", type=int, default=320)
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--frames", type=int, default=4)
 ap.add_argument("--prob", default="coded", choices=["coded", "f32"], help="1-byte coded probability grid (what ReplayFeedEnv uses) or fp32")
+ap.add_argument("--out", default="i8", choices=["f32", "f32+i8", "i8"],
+                help="tri-class output: fp32 rows (flat observations), fp32 + int8 copy, or int8 rows only (compact observations, "
+                     "coded update; the bench default)")
 a = ap.parse_args()
+if a.prob != "coded":
+    a.out = "f32"
 dev = "cuda:0"
 cfg = TaskConfig(camera_width=a.w, camera_height=a.h, grid_size=a.g)
 scene = S.make_scenes(a.n, a.g, seed=1, device=dev)
@@ -23,10 +28,13 @@ frames = S.make_frames(scene, cfg, a.frames, seed=1, with_rgba=False)
 upd = OccupancyGridUpdater(a.n, a.g, a.h, a.w, S.inverse_intrinsics(a.h, a.w), scene.range_gt, scene.voxel_size, scene.grid_gt, dev,
                            max_steps_between_resets=100 if a.prob == "coded" else None)
 all_reset = torch.ones(a.n, dtype=torch.uint8, device=dev)
+t8 = torch.zeros(a.n, a.g ** 3, dtype=torch.int8, device=dev) if "i8" in a.out else None
+kw = dict(tri_i8_out=t8, fp32_out=a.out != "i8") if t8 is not None else {}
+print("tri-class output:", a.out)
 c2ws = [S.c2w_from_view(f.view, scene.env_origins) for f in frames]
 poses = [f.poses.contiguous() for f in frames]
 for i in range(5):
-    upd.update(frames[i % a.frames].depth_raw, frames[i % a.frames].seg_raw, c2ws[i % a.frames], poses[i % a.frames])
+    upd.update(frames[i % a.frames].depth_raw, frames[i % a.frames].seg_raw, c2ws[i % a.frames], poses[i % a.frames], **kw)
 hit, path = upd.masks()
 print("fg frac", float((frames[0].seg_raw > 50).float().mean()), "hit voxels/env", float(hit.flatten(1).sum(1).float().mean()),
       "path voxels/env", float(path.flatten(1).sum(1).float().mean()), "max hit/env", int(hit.flatten(1).sum(1).max()),
@@ -36,7 +44,7 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for i in range(a.iters):
     k = i % a.frames
-    upd.update(frames[k].depth_raw, frames[k].seg_raw, c2ws[k], poses[k], reset_mask=all_reset if i % 64 == 63 else None)  # episodes end
+    upd.update(frames[k].depth_raw, frames[k].seg_raw, c2ws[k], poses[k], reset_mask=all_reset if i % 64 == 63 else None, **kw)  # episodes end
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters

@@ -2,7 +2,8 @@
 gnbv_update_occ_grid launch from the FETCH_SIZE / WRITE_SIZE passes (KB units; FETCH_SIZE doubled on gfx950 as
 /opt/skills/guides/MI355X_MICROARCH.md section HBM prescribes for wide coalesced streaming reads).
 
-    python tools/pmc_to_traffic.py profiles/r01_voxel_pmc.txt > profiles/r01_voxel_traffic.json
+    python tools/pmc_to_traffic.py profiles/r01_voxel_pmc.txt [flat|compact] > profiles/r01_voxel_traffic.json
+(second argument: the observation rows the microbenchmark wrote -- compact = int8 tri-class rows only, the bench default)
 """
 import json, re, sys
 
@@ -24,7 +25,7 @@ out = {"_comment": "HBM traffic of one gnbv_update_occ_grid call of the bench co
                    "bit-packed gt/scanned; 1-byte coded probability grid when the kernel list shows k_grid_update_coded): separate "
                    "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, KB units). FETCH_SIZE is doubled per MI355X_MICROARCH.md "
                    "section HBM (gfx950 reports half the bytes of wide coalesced streaming reads); WRITE_SIZE as reported.",
-       "config": {"envs": 256, "height": 240, "width": 320, "grid": 64},
+       "config": {"envs": 256, "height": 240, "width": 320, "grid": 64, "obs": sys.argv[2] if len(sys.argv) > 2 else "compact"},
        "fetch_bytes": fb, "write_bytes": wb, "traffic_bytes_per_launch": sum(fb.values()) + sum(wb.values()),
        "algorithmic_bytes_per_launch": 256 * (240 * 320 * 8 + 64 ** 3 * 4 * 6 + 200)}
 print(json.dumps(out, indent=2))
