@@ -909,6 +909,232 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad(
 }
 
 // ---------------------------------------------------------------------------
+// Fused conv2 data gradient + conv1 weight gradient (fp32 activations, int8 grid rows, G % 16 == 0): dz1' is never
+// written.  BN1 backward is linear in the two batch sums m1 = S1/M, m2 = S2/M that are only known after the whole
+// data gradient exists, so the conv1 weight gradient is split into sums that do not need them:
+//   dy1 = scale1 * (g - m1 - xhat*m2)          g = dz1' (ReLU-masked), xhat = (y1 - mean1) * rstd1
+//   dW1[co][tap] = sum_pos x[pos, tap] * dy1[pos, co] = scale1[co] * (T1[tap][co] - m1[co]*T2[tap] - m2[co]*T3[tap][co])
+//   T1 = sum x*g,  T2 = sum x,  T3 = sum x*xhat,  S1 = sum g,  S2 = sum g*xhat
+// (db1 = sum dy1 = scale1 * (S1 - M m1 - m2 sum xhat) is identically zero: a bias in front of BatchNorm has no gradient)
+// T1 and T3 are two more MFMA contractions (i = tap, j = co, k = voxel) on the data-gradient tile while it is still
+// in registers; k_c1w_fused_finish combines the fp64 sums.  Saves the 244 MB write + 488 MB of reads of dz1'/y1 that
+// the separate conv1 weight-gradient kernel costs (two HBM-bound launches -> one MFMA-bound launch).
+//
+// The data-gradient MFMA runs with its operands swapped (A = dy2, B = W2): D[i = voxel 4kq+r][j = ci = lane & 15],
+// i.e. the tile arrives transposed, in exactly the B-operand layout of the second contraction (B[k = voxel][j = co]);
+// y1 is read with 4-byte requests in the same layout (mask + xhat).  The input operand x[voxel][tap] comes from a
+// per-wave int8 slab in LDS: the 5 x 5 x 65 input voxels under one 2 x 2 x 32 super-tile.
+// ---------------------------------------------------------------------------
+constexpr int kSlabRow = 80, kSlabBytes = 25 * kSlabRow;  // 5 planes x 5 rows x (65 -> 80) bytes
+constexpr int kE1F = 2 * 512 + 32 + 2 * kC;               // T1, T3 [32 taps][16], T2 [32], S1, S2 [16]
+
+template <int EZ, int EY, int EX>
+__device__ __forceinline__ void dgrad_c1w_subtile(
+    const float4 (&L)[8], const float (&Y)[4], const float *w2d, const int8_t *slab0, const int8_t *slab1, const bool (&ok0)[4],
+    const bool (&ok1)[4], float sc, float sh, float mu, float rs, float &s1, float &s2, float (&t2)[2], f32x4 (&T1)[2], f32x4 (&T3)[2])
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int zo = 0; zo < (EZ ? 1 : 2); ++zo)
+#pragma unroll
+        for (int yo = 0; yo < (EY ? 1 : 2); ++yo)
+#pragma unroll
+            for (int xo = 0; xo < (EX ? 1 : 2); ++xo) {
+                const int dz = EZ ? 1 : 2 * zo, dy = EY ? 1 : 2 * yo, dx = EX ? 1 : 2 * xo;
+                const float4 &t = L[(zo * 2 + yo) * 2 + xo];
+                const float *wb = w2d + ((dz * 3 + dy) * 3 + dx) * 256 + lane;  // [(tap*4+s)*4+kq][ci = m]
+                acc = mfma4(t.x, wb[0], acc);  // A[i = voxel][k = co], B[k = co][j = ci]
+                acc = mfma4(t.y, wb[64], acc);
+                acc = mfma4(t.z, wb[128], acc);
+                acc = mfma4(t.w, wb[192], acc);
+            }
+    constexpr int kOff = ((2 * EZ) * 5 + 2 * EY) * kSlabRow + 2 * EX;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        // Out-of-grid voxels (x only: out-of-grid planes / rows skip the sub-tile) are masked in the A operand, so
+        // their g and xhat values never reach T1 / T3; g is masked as well for the channel sums.
+        const float y = Y[r];
+        const float g = (ok0[r] && fmaf(sc, y, sh) > 0.0f) ? acc[r] : 0.0f;
+        const float xh = (y - mu) * rs;
+        s1 += g;
+        s2 = fmaf(g, xh, s2);
+        const float a0v = (float)slab0[kOff + 4 * r], a1v = (float)slab1[kOff + 4 * r];  // unconditional reads, then selects
+        const float a0 = ok0[r] ? a0v : 0.0f, a1 = ok1[r] ? a1v : 0.0f;                  // A[i = tap][k = voxel]
+        t2[0] += a0;
+        t2[1] += a1;
+        T1[0] = mfma4(a0, g, T1[0]);
+        T1[1] = mfma4(a1, g, T1[1]);
+        T3[0] = mfma4(a0, xh, T3[0]);
+        T3[1] = mfma4(a1, xh, T3[1]);
+    }
+}
+
+__global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad_c1w(
+    const float *__restrict__ dy2, const float *__restrict__ W2 /*dgrad image*/, const float *__restrict__ y1, const float *__restrict__ scale1,
+    const float *__restrict__ shift1, const float *__restrict__ mean1, const float *__restrict__ rstd1, const int8_t *__restrict__ grid_i8,
+    const int64_t *__restrict__ rows, int64_t grid_row_stride, int B, int G, int O1, int O2, float *__restrict__ partial /*[blocks][kE1F]*/)
+{
+    __shared__ __attribute__((aligned(16))) float w2d[kTaps * 4 * 4 * kC];
+    __shared__ __attribute__((aligned(16))) int8_t slabs[kBigWaves][kSlabBytes];
+    fill_lds_image(w2d, W2);
+    const int NA = (O1 + 1) >> 1;  // == XH: plane pairs / row pairs / voxels per x-parity (a multiple of 4 when G % 16 == 0)
+    int b, a0, a1;
+    const bool live = sample_plane_group(B, NA, kPlanesPerGroup, b, a0, a1);
+    const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int m = lane & 15, kq = lane >> 4;
+    float s1 = 0.f, s2 = 0.f, t2[2] = {0.f, 0.f};
+    f32x4 T1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, T3[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (live) {
+        const float sc = scale1[m], sh = shift1[m], mu = mean1[m], rs = rstd1[m];
+        // lane's taps m and 16 + m: byte offset of the tap inside the slab, plus this lane's k-slot (4 voxels = 16 bytes apart)
+        const bool tok1 = 16 + m < kTaps;
+        const int t1 = tok1 ? 16 + m : 0;
+        const int8_t *slab = slabs[wv];
+        const int8_t *slab0 = slab + ((m / 9) * 5 + (m / 3) % 3) * kSlabRow + m % 3 + 16 * kq;
+        const int8_t *slab1 = slab + ((t1 / 9) * 5 + (t1 / 3) % 3) * kSlabRow + t1 % 3 + 16 * kq;
+        const int8_t *in = grid_i8 + (rows ? rows[b] : (int64_t)b) * grid_row_stride;
+        const int g3m16 = G * G * G - 16;
+        const int ntx = (NA + 15) / 16, nwork = (a1 - a0) * NA * ntx;
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int wk = wv; wk < nwork; wk += kBigWaves) {
+            const int a = a0 + wk / (NA * ntx), rr = wk % (NA * ntx), c = rr / ntx, j0 = (rr % ntx) * 16, j = j0 + m;
+            // ---- requests: 8 dy2 neighbours (lane = voxel j, channels 4kq..), 2 slab vectors, y1 values ----
+            float4 L[8];
+            bool okL[8];
+#pragma unroll
+            for (int zo = 0; zo < 2; ++zo)
+#pragma unroll
+                for (int yo = 0; yo < 2; ++yo)
+#pragma unroll
+                    for (int xo = 0; xo < 2; ++xo) {
+                        const int oz = a - zo, oy = c - yo, ox = j - xo;
+                        okL[(zo * 2 + yo) * 2 + xo] = oz >= 0 && oz < O2 && oy >= 0 && oy < O2 && ox >= 0 && ox < O2;
+                        const int ozc = min(max(oz, 0), O2 - 1), oyc = min(max(oy, 0), O2 - 1), oxc = min(max(ox, 0), O2 - 1);
+                        L[(zo * 2 + yo) * 2 + xo] = *reinterpret_cast<const float4 *>(
+                            dy2 + ((((uint32_t)b * O2 + ozc) * O2 + oyc) * O2 + oxc) * kC + 4 * kq);
+                    }
+            uint4 sv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = min(lane + 64 * u, 124), row = idx / 5, seg = idx - 5 * row, zr = row / 5, yr = row - 5 * zr;
+                const int off = (min(4 * a + zr, G - 1) * G + min(4 * c + yr, G - 1)) * G + 4 * j0 + 16 * seg;
+                sv[u] = *reinterpret_cast<const uint4 *>(in + min(off, g3m16));
+            }
+            // x validity of this lane's voxels j0 + 4kq + r (x = 2j + ex); ok1 also folds in the validity of tap 16 + m
+            bool ok0[2][4], ok1[2][4];
+#pragma unroll
+            for (int ex = 0; ex < 2; ++ex)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ok0[ex][r] = 2 * (j0 + 4 * kq + r) + ex < O1;
+                    ok1[ex][r] = ok0[ex][r] && tok1;
+                }
+            // y1 values of sub-tile e (this lane: channel m of voxels jb + r, four 64-byte lines apart: one base address,
+            // immediate offsets; jb is clamped so that the four stay inside the row -- lanes it moves are out of grid).
+            // Requested in three groups so that at most 16 + 8 of the 32 are live beside the 32 dy2 registers.
+            const int jb = min(j0 + 4 * kq, NA - 4);
+            float Y[8][4];
+            auto request_y = [&](int e, float (&dst)[4]) {
+                const int ez = e >> 2, ey = (e >> 1) & 1, ex = e & 1;
+                const int iz = min(2 * a + ez, O1 - 1), iy = min(2 * c + ey, O1 - 1);
+                const float *p = y1 + (((((uint32_t)b * O1 + iz) * O1 + iy) * 2 + ex) * NA + jb) * kC + m;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[r] = p[r * kC];
+            };
+            request_y(0, Y[0]);
+            request_y(1, Y[1]);
+            request_y(2, Y[2]);
+            request_y(3, Y[3]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (!okL[t]) L[t] = zero4;
+            // the wave's private slab (the previous super-tile's reads are done: program order inside a wave)
+            reinterpret_cast<uint4 *>(slabs[wv])[lane] = sv[0];
+            if (lane + 64 < 125) reinterpret_cast<uint4 *>(slabs[wv])[lane + 64] = sv[1];
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+            __builtin_amdgcn_wave_barrier();
+            // sub-tiles on out-of-grid planes / rows are skipped (wave-uniform)
+            const bool z0 = 2 * a < O1, z1 = 2 * a + 1 < O1, y0 = 2 * c < O1, y1ok = 2 * c + 1 < O1;
+            if (z0 && y0) dgrad_c1w_subtile<0, 0, 0>(L, Y[0], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, t2, T1, T3);
+            if (z0 && y0) dgrad_c1w_subtile<0, 0, 1>(L, Y[1], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, t2, T1, T3);
+            __builtin_amdgcn_sched_barrier(0);
+            request_y(4, Y[4]);
+            request_y(5, Y[5]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (z0 && y1ok) dgrad_c1w_subtile<0, 1, 0>(L, Y[2], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, t2, T1, T3);
+            if (z0 && y1ok) dgrad_c1w_subtile<0, 1, 1>(L, Y[3], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, t2, T1, T3);
+            __builtin_amdgcn_sched_barrier(0);
+            request_y(6, Y[6]);
+            request_y(7, Y[7]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (z1 && y0) dgrad_c1w_subtile<1, 0, 0>(L, Y[4], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, t2, T1, T3);
+            if (z1 && y0) dgrad_c1w_subtile<1, 0, 1>(L, Y[5], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, t2, T1, T3);
+            if (z1 && y1ok) dgrad_c1w_subtile<1, 1, 0>(L, Y[6], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, t2, T1, T3);
+            if (z1 && y1ok) dgrad_c1w_subtile<1, 1, 1>(L, Y[7], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, t2, T1, T3);
+            __builtin_amdgcn_wave_barrier();  // the next super-tile overwrites the slab
+        }
+    }
+    // ---- workgroup-level sums in wave order (deterministic), one partial row per workgroup ----
+    s1 = kgroup_sum(s1);
+    s2 = kgroup_sum(s2);
+    t2[0] = kgroup_sum(t2[0]);
+    t2[1] = kgroup_sum(t2[1]);
+    __syncthreads();  // every wave is done with the weight image (reused as the reduction buffer)
+    float *red = w2d;
+    for (int w = 0; w < kBigWaves; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = (16 * tt + 4 * kq + r) * kC + m;  // [tap][co]
+                    red[o] = (w == 0 ? 0.0f : red[o]) + T1[tt][r];
+                    red[512 + o] = (w == 0 ? 0.0f : red[512 + o]) + T3[tt][r];
+                }
+            if (lane < kC) {
+                red[1024 + lane] = (w == 0 ? 0.0f : red[1024 + lane]) + t2[0];            // lane = tap
+                red[1024 + 16 + lane] = (w == 0 ? 0.0f : red[1024 + 16 + lane]) + t2[1];
+                red[1056 + lane] = (w == 0 ? 0.0f : red[1056 + lane]) + s1;               // lane = channel
+                red[1056 + kC + lane] = (w == 0 ? 0.0f : red[1056 + kC + lane]) + s2;
+            }
+        }
+        __syncthreads();
+    }
+    float *out = partial + (size_t)blockIdx.x * kE1F;
+    for (int o = threadIdx.x; o < kE1F; o += kBigThreads) out[o] = red[o];
+}
+
+// dW1, db1 and the BN affine gradients from the fused kernel's sums (slices added in order, fp64)
+__global__ void k_c1w_fused_finish(const double *__restrict__ tmp /*[slices][kE1F]*/, int slices, double count, const float *__restrict__ scale1,
+                                   float *__restrict__ dW1, float *__restrict__ db1, const double *__restrict__ S2 /*BN2 sums*/, float *g1w,
+                                   float *g1b, float *g2w, float *g2b)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 512) return;
+    const int tap = i >> 4, co = i & 15;
+    double T1 = 0.0, T3 = 0.0, T2 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int sl = 0; sl < slices; ++sl) {
+        const double *t = tmp + (size_t)sl * kE1F;
+        T1 += t[i];
+        T3 += t[512 + i];
+        T2 += t[1024 + tap];
+        s1 += t[1056 + co];
+        s2 += t[1056 + kC + co];
+    }
+    const double sc = (double)scale1[co], m1 = s1 / count, m2 = s2 / count;
+    if (tap < kTaps) dW1[co * kTaps + tap] = (float)(sc * (T1 - m1 * T2 - m2 * T3));
+    if (tap == 0) {
+        db1[co] = 0.0f;
+        g1b[co] = (float)s1;
+        g1w[co] = (float)s2;
+        g2b[co] = (float)S2[co];
+        g2w[co] = (float)S2[kC + co];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // conv1 weight gradient with BN1 backward fused into the operand load:
 //   dy1 = scale1 * (dz1' - S1/M - xhat * S2/M);  dW1[co][tap] = sum_pos in[inpos(pos,tap)] * dy1[pos, co]
 // MFMA: i = tap (two 16-row tiles), j = co, k = 4 consecutive output positions along x.
@@ -1377,6 +1603,22 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     // ---- conv2 data gradient (+ ReLU1 mask, BN1 backward sums) ----
     if (side.enabled) hipLaunchKernelGGL(k_prep_w2, dim3(kTaps), dim3(256), 0, st, p->w2, w.w2img, w.w2img + kTaps * 256);
     const int gd = sample_plane_group_grid(batch, (O1 + 1) / 2, kPlanesPerGroup);  // groups of plane PAIRS
+    // fused with the conv1 weight gradient when the grid exists as aligned int8 rows: dz1' is never stored
+    const char *fenv = getenv("GENNBV_FUSED_BWD");  // "0": the separate kernels (A/B runs, bit-equality tests)
+    const bool fused_off = fenv && fenv[0] == '0';
+    if (!fused_off && !p->act_bf16 && p->grid_i8 != nullptr && grid % 16 == 0 && p->grid_i8_row_stride % 16 == 0 &&
+        (((uintptr_t)p->grid_i8 & 15) == 0)) {
+        hipLaunchKernelGGL(k_conv2_dgrad_c1w, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const float *)y1, bn1,
+                           bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->grid_i8, rows, p->grid_i8_row_stride, batch, grid, O1, O2, wg1_part);
+        if ((err = gnbv_launch_status())) return err;
+        const int slf = reduce_stage1(wg1_part, gd, kE1F, tmp1, st);
+        if ((err = gnbv_launch_status())) return err;
+        hipLaunchKernelGGL(k_c1w_fused_finish, dim3(2), dim3(256), 0, st, (const double *)tmp1, slf, (double)batch * O1 * O1 * O1, bn1, g->w1, g->b1,
+                           (const double *)S2, g->bn1_w, g->bn1_b, g->bn2_w, g->bn2_b);
+        if ((err = gnbv_launch_status())) return err;
+        if (side.enabled && hipStreamWaitEvent(st, side.join, 0) != hipSuccess) return (int)hipGetLastError();  // join
+        return gnbv_launch_status();
+    }
     if (p->act_bf16) {
         hipLaunchKernelGGL(k_conv2_dgrad<ActBF16>, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const uint16_t *)y1, bn1, bn1 + kC, bn1 + 2 * kC,
                        bn1 + 3 * kC, batch, O1, O2, (uint16_t *)dz1_scratch, w.bn_part);

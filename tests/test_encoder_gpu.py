@@ -71,6 +71,37 @@ def test_encoder_forward_backward_vs_torch_reference(g, b):
     assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("g,b", [(16, 5), (32, 3), (48, 2), (64, 4), (128, 1)])
+def test_fused_dgrad_conv1_wgrad_vs_fp64_reference(g, b):
+    """With the int8 grid rows present (G % 16 == 0) the backward runs k_conv2_dgrad_c1w: conv2 data gradient and conv1
+    weight gradient in one launch, BN1 backward applied to fp64 sums afterwards (dz1' is never stored).  All conv / BN
+    gradients against the fp64 torch reference, tolerance = fp32 round-off; rows are gathered (RowGather)."""
+    from gennbv_amd.ops.encoder_ops import RowGather
+    hip, _, _ = pu.make_policy(g=g, device=DEV, backend="hip", det_weights=True)
+    ref, _, _ = pu.make_policy(g=g, device="cpu", backend="torch", det_weights=True)
+    ref = ref.double()
+    base = _obs(2 * b + 1, g, seed=g + 1)
+    rows = torch.randperm(2 * b + 1)[:b].to(DEV)
+    grid_i8 = base[:, 600:600 + g ** 3].to(torch.int8).contiguous()
+    w = torch.linspace(0.5, 1.5, 256)
+    outs = []
+    for pol, obs, dev, dt in ((ref, base[rows].cpu().double(), "cpu", torch.float64), (hip, RowGather(base, rows, grid_i8), DEV, torch.float32)):
+        pol.train()
+        pol.zero_grad()
+        f = pol.features_extractor(obs)
+        (f * w.to(dev, dt)).sum().backward()
+        outs.append(f.detach().double().cpu())
+    assert float((outs[0] - outs[1]).abs().max()) <= 2e-5 * float(outs[0].abs().max()) + 1e-6
+    for (n1, p1), (n2, p2) in zip(ref.features_extractor.named_parameters(), hip.features_extractor.named_parameters()):
+        r = p1.grad.double()
+        scale = float(r.abs().max())
+        err = float((r - p2.grad.double().cpu()).abs().max())
+        if scale < 1e-9:  # conv bias in front of BatchNorm: analytically zero gradient
+            assert err < 1e-4, (n1, err)
+        else:
+            assert err <= 2e-5 * scale, (n1, err, scale)
+
+
 def test_encoder_matches_reference_golden_f7():
     fx = gu.load("F7_policy")
     pol, _, _ = pu.make_policy(g=20, device=DEV, backend="hip", det_weights=True)
@@ -201,10 +232,12 @@ def test_fused_policy_head_vs_fp64(m, a):
 
 
 @pytest.mark.parametrize("g,b", [(64, 6), (16, 5), (32, 3)])
-def test_int8_grid_copy_gives_identical_results(g, b):
+def test_int8_grid_copy_gives_identical_results(g, b, monkeypatch):
     """GnbvEncoderParams.grid_i8: conv1 forward / weight gradient reading the compact int8 copy of the tri-class grid
-    ({-1,0,1}: exact conversion) produce the same bits as reading the fp32 observation slice."""
+    ({-1,0,1}: exact conversion) produce the same bits as reading the fp32 observation slice (separate backward
+    kernels; the fused data-gradient + weight-gradient kernel sums in another order)."""
     from gennbv_amd.ops.encoder_ops import RowGather
+    monkeypatch.setenv("GENNBV_FUSED_BWD", "0")
     _, hip = _pair(g)
     hip.train()
     base = _obs(2 * b, g, seed=3)
@@ -222,11 +255,12 @@ def test_int8_grid_copy_gives_identical_results(g, b):
 
 
 @pytest.mark.parametrize("g,b,train", [(20, 5, True), (20, 8, False), (33, 3, True), (64, 4, True), (128, 2, True)])
-def test_compact_observation_rows_match_flat_rows(g, b, train):
+def test_compact_observation_rows_match_flat_rows(g, b, train, monkeypatch):
     """Compact rows ([state | state_rgb] fp32 + the grid as int8 only, obs pointer NULL at the C-ABI): features and
     gradients equal those of the flat fp32 rows -- bit for bit where both take the LDS-staged kernels (G % 16 == 0 and
     the slab fits), to fp32 round-off where the compact rows take the direct int8 kernels (other summation order)."""
     from gennbv_amd.ops.encoder_ops import RowGather, DenseObs
+    monkeypatch.setenv("GENNBV_FUSED_BWD", "0")
     _, hip = _pair(g)
     hip.train(train)
     base = _obs(2 * b, g, seed=5)
