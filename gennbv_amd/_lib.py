@@ -49,6 +49,8 @@ SIGNATURES = {
     "gnbv_env_obs_state": (_i, [_p, _p, _p, _p, _i, _i, _p, _i64, _p]),
     "gnbv_env_obs_rgb": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i64, _p]),
     "gnbv_env_post_step": (_i, [_p, _p]),
+    "gnbv_input_autocorr_row_ints": (_i, []),
+    "gnbv_input_autocorr": (_i, [_p, _i64, _i, _i, _p, _i64, _p]),
     "gnbv_encoder_workspace_bytes": (_sz, [_i, _i]),
     "gnbv_encoder_y1_elems": (_sz, [_i, _i]),
     "gnbv_encoder_grid_forward": (_i, [_p, _p, _i64, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
@@ -89,7 +91,8 @@ class GnbvEncoderParams(C.Structure):
     """include/gennbv_hip.h: GnbvEncoderParams"""
     _fields_ = [("w1", _p), ("b1", _p), ("bn1_w", _p), ("bn1_b", _p), ("bn1_rm", _p), ("bn1_rv", _p), ("bn1_nbt", _p),
                 ("w2", _p), ("b2", _p), ("bn2_w", _p), ("bn2_b", _p), ("bn2_rm", _p), ("bn2_rv", _p), ("bn2_nbt", _p),
-                ("eps", _f), ("momentum", _f), ("act_bf16", _i), ("grid_i8", _p), ("grid_i8_row_stride", _i64)]
+                ("eps", _f), ("momentum", _f), ("act_bf16", _i), ("grid_i8", _p), ("grid_i8_row_stride", _i64),
+                ("autocorr", _p), ("autocorr_row_stride", _i64)]
 
 
 class GnbvEncoderGrads(C.Structure):

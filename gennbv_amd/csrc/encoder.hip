@@ -916,9 +916,12 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad(
 //   dW1[co][tap] = sum_pos x[pos, tap] * dy1[pos, co] = scale1[co] * (T1[tap][co] - m1[co]*T2[tap] - m2[co]*T3[tap][co])
 //   T1 = sum x*g,  T2 = sum x,  T3 = sum x*xhat,  S1 = sum g,  S2 = sum g*xhat
 // (db1 = sum dy1 = scale1 * (S1 - M m1 - m2 sum xhat) is identically zero: a bias in front of BatchNorm has no gradient)
-// T1 and T3 are two more MFMA contractions (i = tap, j = co, k = voxel) on the data-gradient tile while it is still
-// in registers; k_c1w_fused_finish combines the fp64 sums.  Saves the 244 MB write + 488 MB of reads of dz1'/y1 that
-// the separate conv1 weight-gradient kernel costs (two HBM-bound launches -> one MFMA-bound launch).
+// T1 is one more MFMA contraction (i = tap, j = co, k = voxel) on the data-gradient tile while it is still in
+// registers.  T2 and T3 do not depend on the gradient at all: y1 = W1 * x + b1 is linear in the input, so
+//   T3[tap][co] = rstd1[co] * sum_tap' W1[co][tap'] * (R[tap][tap'] - T2[tap] T2[tap'] / M),   R = sum_pos x[pos,tap] x[pos,tap']
+// with R the 27 x 27 autocorrelation of the minibatch's input patches -- exact integers from k_input_autocorr (int8
+// MFMA, runs beside the other backward kernels on a second stream).  k_c1w_fused_finish combines everything in fp64.
+// Saves the 244 MB write + 488 MB of reads of dz1'/y1 that the separate conv1 weight-gradient kernel costs.
 //
 // The data-gradient MFMA runs with its operands swapped (A = dy2, B = W2): D[i = voxel 4kq+r][j = ci = lane & 15],
 // i.e. the tile arrives transposed, in exactly the B-operand layout of the second contraction (B[k = voxel][j = co]);
@@ -926,12 +929,12 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad(
 // per-wave int8 slab in LDS: the 5 x 5 x 65 input voxels under one 2 x 2 x 32 super-tile.
 // ---------------------------------------------------------------------------
 constexpr int kSlabRow = 80, kSlabBytes = 25 * kSlabRow;  // 5 planes x 5 rows x (65 -> 80) bytes
-constexpr int kE1F = 2 * 512 + 32 + 2 * kC;               // T1, T3 [32 taps][16], T2 [32], S1, S2 [16]
+constexpr int kE1F = 512 + 2 * kC;                        // T1 [32 taps][16], S1, S2 [16]
 
 template <int EZ, int EY, int EX>
 __device__ __forceinline__ void dgrad_c1w_subtile(
     const float4 (&L)[8], const float (&Y)[4], const float *w2d, const int8_t *slab0, const int8_t *slab1, const bool (&ok0)[4],
-    const bool (&ok1)[4], float sc, float sh, float mu, float rs, float &s1, float &s2, float (&t2)[2], f32x4 (&T1)[2], f32x4 (&T3)[2])
+    const bool (&ok1)[4], float sc, float sh, float mu, float rs, float &s1, float &s2, f32x4 (&T1)[2])
 {
     const int lane = threadIdx.x & (kWave - 1);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -953,20 +956,14 @@ __device__ __forceinline__ void dgrad_c1w_subtile(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         // Out-of-grid voxels (x only: out-of-grid planes / rows skip the sub-tile) are masked in the A operand, so
-        // their g and xhat values never reach T1 / T3; g is masked as well for the channel sums.
-        const float y = Y[r];
+        // their g never reaches T1; g is masked as well for the channel sums.
+        const float y = ok0[r] ? Y[r] : 0.0f;  // (out-of-grid slots of y1 are never written: may hold Inf / NaN)
         const float g = (ok0[r] && fmaf(sc, y, sh) > 0.0f) ? acc[r] : 0.0f;
-        const float xh = (y - mu) * rs;
         s1 += g;
-        s2 = fmaf(g, xh, s2);
+        s2 = fmaf(g, (y - mu) * rs, s2);
         const float a0v = (float)slab0[kOff + 4 * r], a1v = (float)slab1[kOff + 4 * r];  // unconditional reads, then selects
-        const float a0 = ok0[r] ? a0v : 0.0f, a1 = ok1[r] ? a1v : 0.0f;                  // A[i = tap][k = voxel]
-        t2[0] += a0;
-        t2[1] += a1;
-        T1[0] = mfma4(a0, g, T1[0]);
-        T1[1] = mfma4(a1, g, T1[1]);
-        T3[0] = mfma4(a0, xh, T3[0]);
-        T3[1] = mfma4(a1, xh, T3[1]);
+        T1[0] = mfma4(ok0[r] ? a0v : 0.0f, g, T1[0]);  // A[i = tap][k = voxel]
+        T1[1] = mfma4(ok1[r] ? a1v : 0.0f, g, T1[1]);
     }
 }
 
@@ -983,8 +980,8 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad_c1w(
     const bool live = sample_plane_group(B, NA, kPlanesPerGroup, b, a0, a1);
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int m = lane & 15, kq = lane >> 4;
-    float s1 = 0.f, s2 = 0.f, t2[2] = {0.f, 0.f};
-    f32x4 T1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, T3[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float s1 = 0.f, s2 = 0.f;
+    f32x4 T1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if (live) {
         const float sc = scale1[m], sh = shift1[m], mu = mean1[m], rs = rstd1[m];
         // lane's taps m and 16 + m: byte offset of the tap inside the slab, plus this lane's k-slot (4 voxels = 16 bytes apart)
@@ -1057,30 +1054,28 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad_c1w(
             __builtin_amdgcn_wave_barrier();
             // sub-tiles on out-of-grid planes / rows are skipped (wave-uniform)
             const bool z0 = 2 * a < O1, z1 = 2 * a + 1 < O1, y0 = 2 * c < O1, y1ok = 2 * c + 1 < O1;
-            if (z0 && y0) dgrad_c1w_subtile<0, 0, 0>(L, Y[0], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, t2, T1, T3);
-            if (z0 && y0) dgrad_c1w_subtile<0, 0, 1>(L, Y[1], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, t2, T1, T3);
+            if (z0 && y0) dgrad_c1w_subtile<0, 0, 0>(L, Y[0], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, T1);
+            if (z0 && y0) dgrad_c1w_subtile<0, 0, 1>(L, Y[1], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, T1);
             __builtin_amdgcn_sched_barrier(0);
             request_y(4, Y[4]);
             request_y(5, Y[5]);
             __builtin_amdgcn_sched_barrier(0);
-            if (z0 && y1ok) dgrad_c1w_subtile<0, 1, 0>(L, Y[2], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, t2, T1, T3);
-            if (z0 && y1ok) dgrad_c1w_subtile<0, 1, 1>(L, Y[3], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, t2, T1, T3);
+            if (z0 && y1ok) dgrad_c1w_subtile<0, 1, 0>(L, Y[2], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, T1);
+            if (z0 && y1ok) dgrad_c1w_subtile<0, 1, 1>(L, Y[3], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, T1);
             __builtin_amdgcn_sched_barrier(0);
             request_y(6, Y[6]);
             request_y(7, Y[7]);
             __builtin_amdgcn_sched_barrier(0);
-            if (z1 && y0) dgrad_c1w_subtile<1, 0, 0>(L, Y[4], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, t2, T1, T3);
-            if (z1 && y0) dgrad_c1w_subtile<1, 0, 1>(L, Y[5], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, t2, T1, T3);
-            if (z1 && y1ok) dgrad_c1w_subtile<1, 1, 0>(L, Y[6], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, t2, T1, T3);
-            if (z1 && y1ok) dgrad_c1w_subtile<1, 1, 1>(L, Y[7], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, t2, T1, T3);
+            if (z1 && y0) dgrad_c1w_subtile<1, 0, 0>(L, Y[4], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, T1);
+            if (z1 && y0) dgrad_c1w_subtile<1, 0, 1>(L, Y[5], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, T1);
+            if (z1 && y1ok) dgrad_c1w_subtile<1, 1, 0>(L, Y[6], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, T1);
+            if (z1 && y1ok) dgrad_c1w_subtile<1, 1, 1>(L, Y[7], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, T1);
             __builtin_amdgcn_wave_barrier();  // the next super-tile overwrites the slab
         }
     }
     // ---- workgroup-level sums in wave order (deterministic), one partial row per workgroup ----
     s1 = kgroup_sum(s1);
     s2 = kgroup_sum(s2);
-    t2[0] = kgroup_sum(t2[0]);
-    t2[1] = kgroup_sum(t2[1]);
     __syncthreads();  // every wave is done with the weight image (reused as the reduction buffer)
     float *red = w2d;
     for (int w = 0; w < kBigWaves; ++w) {
@@ -1091,13 +1086,10 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad_c1w(
                 for (int r = 0; r < 4; ++r) {
                     const int o = (16 * tt + 4 * kq + r) * kC + m;  // [tap][co]
                     red[o] = (w == 0 ? 0.0f : red[o]) + T1[tt][r];
-                    red[512 + o] = (w == 0 ? 0.0f : red[512 + o]) + T3[tt][r];
                 }
             if (lane < kC) {
-                red[1024 + lane] = (w == 0 ? 0.0f : red[1024 + lane]) + t2[0];            // lane = tap
-                red[1024 + 16 + lane] = (w == 0 ? 0.0f : red[1024 + 16 + lane]) + t2[1];
-                red[1056 + lane] = (w == 0 ? 0.0f : red[1056 + lane]) + s1;               // lane = channel
-                red[1056 + kC + lane] = (w == 0 ? 0.0f : red[1056 + kC + lane]) + s2;
+                red[512 + lane] = (w == 0 ? 0.0f : red[512 + lane]) + s1;  // lane = channel
+                red[512 + kC + lane] = (w == 0 ? 0.0f : red[512 + kC + lane]) + s2;
             }
         }
         __syncthreads();
@@ -1106,25 +1098,163 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad_c1w(
     for (int o = threadIdx.x; o < kE1F; o += kBigThreads) out[o] = red[o];
 }
 
-// dW1, db1 and the BN affine gradients from the fused kernel's sums (slices added in order, fp64)
-__global__ void k_c1w_fused_finish(const double *__restrict__ tmp /*[slices][kE1F]*/, int slices, double count, const float *__restrict__ scale1,
-                                   float *__restrict__ dW1, float *__restrict__ db1, const double *__restrict__ S2 /*BN2 sums*/, float *g1w,
-                                   float *g1b, float *g2w, float *g2b)
+// Input autocorrelation: R[t][t'] = sum over output positions of x[pos, t] * x[pos, t'], t, t' in 0..26 the conv1
+// taps, t = 27 a pseudo-tap that is 1 on every valid position (so R[t][27] = T2[t] = sum x and R[27][27] = #positions).
+// x in {-1, 0, 1}: int8 MFMA (v_mfma_i32_16x16x64_i8), exact.  A and B operands are the SAME registers (R = X^T X:
+// lane (tap, k-group) holds 16 positions of its tap), so the k <-> position mapping of the instruction does not
+// matter.  Workgroup = (sample, group of P output planes): its 2P+1 input planes are fetched once into LDS as bytes
+// (one barrier); a work item = (plane, k-step of 4 units of 16 positions along x).  Results are ADDED to
+// out + sample * out_row_stride with integer atomics (order-independent, deterministic; the caller zeroes):
+// one row per sample (gnbv_input_autocorr: a property of the observation, computed once when the env produces the
+// grid) or, with out_row_stride == 0, the sum over the minibatch.
+// Row layout: 3 tiles of 16 x 16 ints = R[0..15][0..15], R[0..15][16..31], R[16..31][16..31].
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int kAcThreads = 512, kAcWaves = kAcThreads / kWave, kAcRow = 3 * 256;
+static inline int autocorr_planes(int grid)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 512) return;
+    const int p = (64 * 1024 / (grid * grid) - 1) / 2;
+    return p < 1 ? 1 : (p > 4 ? 4 : p);
+}
+
+__global__ __launch_bounds__(kAcThreads) void k_input_autocorr(const int8_t *__restrict__ grid_i8, const int64_t *__restrict__ rows,
+                                                             int64_t row_stride, int B, int G, int O1, int P, int *__restrict__ out,
+                                                             int64_t out_row_stride)
+{
+    // LDS rows are de-interleaved by x parity ([even bytes | odd bytes], G/2 each): the 16 positions of a unit read
+    // input x = 2(16 xg + j) + dx, i.e. 16 CONSECUTIVE bytes of the even half (dx = 0), the odd half (dx = 1) or the even
+    // half one byte on (dx = 2): two 8-byte reads + one dword, aligned, and a funnel shift -- not 16 byte gathers.
+    extern __shared__ __attribute__((aligned(16))) int8_t s_x[];  // (2P+1) planes x G rows x G
+    __shared__ int red[kAcRow];
+    int b, z0, z1;
+    const bool live = sample_plane_group(B, O1, P, b, z0, z1);
+    if (!live) return;
+    const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int m = lane & 15, kq = lane >> 4, H = G >> 1;
+    const int8_t *in = grid_i8 + (rows ? rows[b] : (int64_t)b) * row_stride + (size_t)(2 * z0) * G * G;
+    const int nload = (2 * (z1 - z0) + 1) * G * G / 16, per_row = G / 16;
+    for (int i = threadIdx.x; i < nload; i += kAcThreads) {
+        const uint4 v = reinterpret_cast<const uint4 *>(in)[i];
+        const int row = i / per_row, c = i - row * per_row;
+        uint2 ev, od;
+        ev.x = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u);
+        ev.y = __builtin_amdgcn_perm(v.w, v.z, 0x06040200u);
+        od.x = __builtin_amdgcn_perm(v.y, v.x, 0x07050301u);
+        od.y = __builtin_amdgcn_perm(v.w, v.z, 0x07050301u);
+        *reinterpret_cast<uint2 *>(s_x + row * G + 8 * c) = ev;
+        *reinterpret_cast<uint2 *>(s_x + row * G + H + 8 * c) = od;
+    }
+    for (int i = threadIdx.x; i < kAcRow; i += kAcThreads) red[i] = 0;
+    // this lane's two taps: byte offset of the tap's (plane, row, parity half) inside a 3-plane window and its funnel
+    // shift (dx = 2: one byte); tap 27 = ones, taps 28..31 = zeros
+    const int t1 = 16 + m;
+    const bool real1 = t1 < kTaps;
+    auto tap_off = [&](int t) { return ((t / 9) * G + (t / 3) % 3) * G + (t % 3 == 1 ? H : 0); };
+    const int off0 = tap_off(m), off1 = real1 ? tap_off(t1) : 0;
+    const uint32_t sh0 = (m % 3 == 2) ? 1u : 0u, sh1 = (real1 && t1 % 3 == 2) ? 1u : 0u;
+    const uint32_t ones1 = t1 == kTaps ? 0x01010101u : 0u;
+    i32x4 r00 = {0, 0, 0, 0}, r01 = {0, 0, 0, 0}, r11 = {0, 0, 0, 0};
+    // units = (output row y, group of 16 positions along x); a k-step takes 4 consecutive units (k-group kq each)
+    const int nxg = (O1 + 15) / 16, nunit = O1 * nxg, nstep = (nunit + 3) / 4, nitem = (z1 - z0) * nstep;
+    __syncthreads();
+    for (int it = wv; it < nitem; it += kAcWaves) {
+        const int zl = it / nstep, st = it - zl * nstep;
+        const int u = min(4 * st + kq, nunit - 1), y = u / nxg, xg = u - y * nxg;
+        const bool uok = 4 * st + kq < nunit;
+        const int8_t *p = s_x + (2 * zl * G + 2 * y) * G + 16 * xg;
+        const uint2 a = *reinterpret_cast<const uint2 *>(p + off0), c = *reinterpret_cast<const uint2 *>(p + off0 + 8);
+        const uint32_t e = *reinterpret_cast<const uint32_t *>(p + off0 + 16);
+        const uint2 a2 = *reinterpret_cast<const uint2 *>(p + off1), c2 = *reinterpret_cast<const uint2 *>(p + off1 + 8);
+        const uint32_t e2 = *reinterpret_cast<const uint32_t *>(p + off1 + 16);
+        const uint32_t d0[5] = {a.x, a.y, c.x, c.y, e}, d1[5] = {a2.x, a2.y, c2.x, c2.y, e2};
+        i32x4 a0, a1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // bytes of positions x = 16 xg + 4q + k >= O1 (and of units past the plane) are zero in every tap
+            const int nv = uok ? min(max(O1 - 16 * xg - 4 * q, 0), 4) : 0;
+            const uint32_t msk = nv >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nv)) - 1u);
+            a0[q] = (int)(__builtin_amdgcn_alignbyte(d0[q + 1], d0[q], sh0) & msk);
+            a1[q] = (int)((real1 ? __builtin_amdgcn_alignbyte(d1[q + 1], d1[q], sh1) : ones1) & msk);
+        }
+        r00 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, a0, r00, 0, 0, 0);
+        r01 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, a1, r01, 0, 0, 0);
+        r11 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, a1, r11, 0, 0, 0);
+    }
+    // workgroup sum in LDS (integers), then one atomic per non-zero element
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = (4 * kq + r) * 16 + m;  // D[i = 4kq + r][j = m]
+        atomicAdd(&red[o], r00[r]);
+        atomicAdd(&red[256 + o], r01[r]);
+        atomicAdd(&red[512 + o], r11[r]);
+    }
+    __syncthreads();
+    int *dst = out + (size_t)b * out_row_stride;
+    for (int i = threadIdx.x; i < kAcRow; i += kAcThreads)
+        if (red[i] != 0) atomicAdd(&dst[i], red[i]);
+}
+
+// dW1, db1 and the BN affine gradients from the fused kernel's sums and the input autocorrelation (fp64).
+// One workgroup of 1024 threads.  ac: per-sample autocorrelation rows (summed here over the minibatch's rows: four
+// row groups per column, 16 requests in flight per thread; integers, so the order does not matter) or, with
+// nrows == 0, the minibatch total.
+__global__ __launch_bounds__(1024) void k_c1w_fused_finish(const double *__restrict__ tmp /*[slices][kE1F]*/, int slices, const int *__restrict__ ac,
+                                                          int64_t ac_row_stride, const int64_t *__restrict__ rows, int nrows,
+                                                          const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ scale1,
+                                                          const float *__restrict__ rstd1, float *__restrict__ dW1, float *__restrict__ db1,
+                                                          const double *__restrict__ S2 /*BN2 sums*/, float *g1w, float *g1b, float *g2w,
+                                                          float *g2b)
+{
+    __shared__ int Ri[kAcRow];
+    __shared__ double R[kAcRow];
+    for (int i = threadIdx.x; i < kAcRow; i += 1024) Ri[i] = nrows == 0 ? ac[i] : 0;
+    __syncthreads();
+    if (nrows > 0) {
+        // wave w sums rows w, w + 16, ...: 16-byte requests (the vector-memory pipe of the one CU this kernel runs on
+        // takes ~16 cycles per wave request whatever its width), row index wave-uniform
+        const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+        int4 t[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        for (int b = wv; b < nrows; b += 16) {
+            const int4 *row = reinterpret_cast<const int4 *>(ac + (rows ? rows[b] : (int64_t)b) * ac_row_stride);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int4 v = row[lane + 64 * k];
+                t[k].x += v.x; t[k].y += v.y; t[k].z += v.z; t[k].w += v.w;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int c = 4 * (lane + 64 * k);
+            atomicAdd(&Ri[c], t[k].x);
+            atomicAdd(&Ri[c + 1], t[k].y);
+            atomicAdd(&Ri[c + 2], t[k].z);
+            atomicAdd(&Ri[c + 3], t[k].w);
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < kAcRow; i += 1024) R[i] = (double)Ri[i];
+    __syncthreads();
+    if (threadIdx.x >= 512) return;
+    const int i = threadIdx.x;
     const int tap = i >> 4, co = i & 15;
-    double T1 = 0.0, T3 = 0.0, T2 = 0.0, s1 = 0.0, s2 = 0.0;
+    double T1 = 0.0, s1 = 0.0, s2 = 0.0;
     for (int sl = 0; sl < slices; ++sl) {
         const double *t = tmp + (size_t)sl * kE1F;
         T1 += t[i];
-        T3 += t[512 + i];
-        T2 += t[1024 + tap];
-        s1 += t[1056 + co];
-        s2 += t[1056 + kC + co];
+        s1 += t[512 + co];
+        s2 += t[512 + kC + co];
     }
-    const double sc = (double)scale1[co], m1 = s1 / count, m2 = s2 / count;
-    if (tap < kTaps) dW1[co * kTaps + tap] = (float)(sc * (T1 - m1 * T2 - m2 * T3));
+    auto Rs = [&](int t, int u) {  // symmetric; stored tiles: (0,0), (0,1), (1,1)
+        if ((t >> 4) > (u >> 4)) { const int v = t; t = u; u = v; }
+        return R[((t >> 4) + (u >> 4)) * 256 + (t & 15) * 16 + (u & 15)];
+    };
+    const double count = Rs(kTaps, kTaps), inv_count = 1.0 / count;
+    if (tap < kTaps) {
+        const double T2 = Rs(tap, kTaps), T2m = T2 * inv_count;
+        double cw = 0.0;  // sum_tap' W1[co][tap'] * (R[tap][tap'] - T2[tap] T2[tap'] / M)
+        for (int u = 0; u < kTaps; ++u) cw += (double)W1[co * kTaps + u] * (Rs(tap, u) - T2m * Rs(u, kTaps));
+        const double T3 = (double)rstd1[co] * cw;
+        dW1[co * kTaps + tap] = (float)((double)scale1[co] * (T1 - (s1 * inv_count) * T2 - (s2 * inv_count) * T3));
+    }
     if (tap == 0) {
         db1[co] = 0.0f;
         g1b[co] = (float)s1;
@@ -1558,6 +1688,22 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     EncWs w = enc_carve(workspace, batch, grid);
     const float *bn1 = bn_state, *bn2 = bn_state + 4 * kC;
     int err;
+    // conv2 data gradient fused with the conv1 weight gradient (dz1' never stored) when the grid exists as aligned
+    // int8 rows; the input autocorrelation it needs runs on a second stream beside the kernels below
+    const char *fenv = getenv("GENNBV_FUSED_BWD");  // "0": the separate kernels (A/B runs, bit-equality tests)
+    const bool fused = !(fenv && fenv[0] == '0') && !p->act_bf16 && p->grid_i8 != nullptr && grid % 16 == 0 && 3 * grid * grid <= 64 * 1024 &&
+                       p->grid_i8_row_stride % 16 == 0 && (((uintptr_t)p->grid_i8 & 15) == 0);
+    GNBV_CHECK_ARG(p->autocorr == nullptr || (p->autocorr_row_stride >= kAcRow && p->autocorr_row_stride % 4 == 0 && ((uintptr_t)p->autocorr & 15) == 0));
+    // the input autocorrelation: per-sample rows computed when the observation was produced (p->autocorr), or
+    // the minibatch total computed here
+    int *Rac = (int *)(w.red + 1024);  // [kAcRow]
+    if (fused && p->autocorr == nullptr) {
+        if (hipMemsetAsync(Rac, 0, kAcRow * sizeof(int), st) != hipSuccess) return (int)hipGetLastError();
+        const int P = autocorr_planes(grid);
+        hipLaunchKernelGGL(k_input_autocorr, dim3(sample_plane_group_grid(batch, O1, P)), dim3(kAcThreads), (size_t)(2 * P + 1) * grid * grid, st,
+                           p->grid_i8, rows, p->grid_i8_row_stride, batch, grid, O1, P, Rac, (int64_t)0);
+        if ((err = gnbv_launch_status())) return err;
+    }
     // ---- BN2 + ReLU backward ----
     hipLaunchKernelGGL(k_bn2_bwd_reduce, dim3(batch * kC), dim3(256), 0, st, d_features, y2, bn2, bn2 + kC, bn2 + 2 * kC,
                        bn2 + 3 * kC, P2, w.bn_part);
@@ -1603,18 +1749,15 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     // ---- conv2 data gradient (+ ReLU1 mask, BN1 backward sums) ----
     if (side.enabled) hipLaunchKernelGGL(k_prep_w2, dim3(kTaps), dim3(256), 0, st, p->w2, w.w2img, w.w2img + kTaps * 256);
     const int gd = sample_plane_group_grid(batch, (O1 + 1) / 2, kPlanesPerGroup);  // groups of plane PAIRS
-    // fused with the conv1 weight gradient when the grid exists as aligned int8 rows: dz1' is never stored
-    const char *fenv = getenv("GENNBV_FUSED_BWD");  // "0": the separate kernels (A/B runs, bit-equality tests)
-    const bool fused_off = fenv && fenv[0] == '0';
-    if (!fused_off && !p->act_bf16 && p->grid_i8 != nullptr && grid % 16 == 0 && p->grid_i8_row_stride % 16 == 0 &&
-        (((uintptr_t)p->grid_i8 & 15) == 0)) {
+    if (fused) {
         hipLaunchKernelGGL(k_conv2_dgrad_c1w, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const float *)y1, bn1,
                            bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->grid_i8, rows, p->grid_i8_row_stride, batch, grid, O1, O2, wg1_part);
         if ((err = gnbv_launch_status())) return err;
         const int slf = reduce_stage1(wg1_part, gd, kE1F, tmp1, st);
         if ((err = gnbv_launch_status())) return err;
-        hipLaunchKernelGGL(k_c1w_fused_finish, dim3(2), dim3(256), 0, st, (const double *)tmp1, slf, (double)batch * O1 * O1 * O1, bn1, g->w1, g->b1,
-                           (const double *)S2, g->bn1_w, g->bn1_b, g->bn2_w, g->bn2_b);
+        hipLaunchKernelGGL(k_c1w_fused_finish, dim3(1), dim3(1024), 0, st, (const double *)tmp1, slf,
+                           p->autocorr ? (const int *)p->autocorr : (const int *)Rac, p->autocorr_row_stride, rows, p->autocorr ? batch : 0,
+                           p->w1, bn1, bn1 + 3 * kC, g->w1, g->b1, (const double *)S2, g->bn1_w, g->bn1_b, g->bn2_w, g->bn2_b);
         if ((err = gnbv_launch_status())) return err;
         if (side.enabled && hipStreamWaitEvent(st, side.join, 0) != hipSuccess) return (int)hipGetLastError();  // join
         return gnbv_launch_status();
@@ -1683,3 +1826,18 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     return gnbv_launch_status();
 }
 
+GNBV_API int gnbv_input_autocorr_row_ints(void) { return kAcRow; }
+
+GNBV_API int gnbv_input_autocorr(const int8_t *grid_i8, int64_t grid_i8_row_stride, int n, int grid, int32_t *out, int64_t out_row_stride,
+                                 void *stream)
+{
+    GNBV_CHECK_ARG(grid_i8 && out && n > 0 && grid >= 16 && grid % 16 == 0 && 3 * grid * grid <= 64 * 1024);
+    GNBV_CHECK_ARG(grid_i8_row_stride >= (int64_t)grid * grid * grid && grid_i8_row_stride % 16 == 0 && (((uintptr_t)grid_i8 & 15) == 0));
+    GNBV_CHECK_ARG(out_row_stride >= kAcRow);
+    hipStream_t st = gnbv_stream(stream);
+    if (hipMemset2DAsync(out, out_row_stride * sizeof(int), 0, kAcRow * sizeof(int), n, st) != hipSuccess) return (int)hipGetLastError();
+    const int O1 = out_size(grid), P = autocorr_planes(grid);
+    hipLaunchKernelGGL(k_input_autocorr, dim3(sample_plane_group_grid(n, O1, P)), dim3(kAcThreads), (size_t)(2 * P + 1) * grid * grid, st, grid_i8,
+                       (const int64_t *)nullptr, grid_i8_row_stride, n, grid, O1, P, (int *)out, out_row_stride);
+    return gnbv_launch_status();
+}

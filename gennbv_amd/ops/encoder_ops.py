@@ -29,8 +29,12 @@ class RowGather:
     [state (s) | state_rgb] only, the grid exists solely as `grid_i8` (a quarter of the bytes of a flat fp32 row)."""
 
     def __init__(self, base: torch.Tensor, rows: torch.Tensor, grid_i8: Optional[torch.Tensor] = None,
-                 compact_state_dim: Optional[int] = None):
+                 compact_state_dim: Optional[int] = None, autocorr: Optional[torch.Tensor] = None):
         assert base.dim() == 2 and base.stride(1) == 1 and rows.dtype == torch.int64
+        # per-row input autocorrelation of the int8 grid rows (input_autocorr(): [R, 768] int32, same row numbering)
+        assert autocorr is None or (grid_i8 is not None and autocorr.dtype == torch.int32 and autocorr.shape[0] == base.shape[0]
+                                    and autocorr.stride(1) == 1)
+        self.autocorr = autocorr
         self.base, self.rows = base, rows.contiguous()
         assert grid_i8 is None or (grid_i8.dtype == torch.int8 and grid_i8.dim() == 2 and grid_i8.stride(1) == 1
                                    and grid_i8.shape[0] == base.shape[0])
@@ -61,6 +65,7 @@ class DenseObs:
         assert grid_i8 is None or (grid_i8.dtype == torch.int8 and grid_i8.shape[0] == base.shape[0] and grid_i8.stride(1) == 1)
         assert compact_state_dim is None or grid_i8 is not None
         self.base, self.rows, self.grid_i8, self.compact_state_dim = base, None, grid_i8, compact_state_dim
+        self.autocorr = None  # (rollout forward: no backward, no autocorrelation needed)
         self.shape = (base.shape[0], base.shape[1] + (0 if compact_state_dim is None else grid_i8.shape[1]))
         self.device, self.is_cuda = base.device, base.is_cuda
 
@@ -95,7 +100,27 @@ def _workspace(lib, batch, grid, device):
     return ws
 
 
-def _params_struct(seq, act_bf16: bool = False, grid_i8: Optional[torch.Tensor] = None) -> _lib.GnbvEncoderParams:
+def input_autocorr(grid_i8: torch.Tensor, grid: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Per-row autocorrelation of the conv1 input patches of int8 grid rows [n, G^3] -> [n, 768] int32
+    (include/gennbv_hip.h: gnbv_input_autocorr)."""
+    lib = _lib.load()
+    _lib.require_cuda(grid_i8)
+    n = grid_i8.shape[0]
+    assert grid_i8.dtype == torch.int8 and grid_i8.dim() == 2 and grid_i8.stride(1) == 1 and grid_i8.shape[1] >= grid ** 3
+    if out is None:
+        out = torch.empty(n, lib.gnbv_input_autocorr_row_ints(), dtype=torch.int32, device=grid_i8.device)
+    assert out.dtype == torch.int32 and out.shape[0] == n and out.stride(1) == 1
+    _lib.check(lib.gnbv_input_autocorr(grid_i8.data_ptr(), grid_i8.stride(0), n, grid, out.data_ptr(), out.stride(0),
+                                       _lib.stream_ptr(grid_i8.device)), "gnbv_input_autocorr")
+    return out
+
+
+def autocorr_supported(grid: int) -> bool:
+    return grid >= 16 and grid % 16 == 0 and 3 * grid * grid <= 64 * 1024
+
+
+def _params_struct(seq, act_bf16: bool = False, grid_i8: Optional[torch.Tensor] = None,
+                   autocorr: Optional[torch.Tensor] = None) -> _lib.GnbvEncoderParams:
     conv1, bn1, conv2, bn2 = seq[0], seq[1], seq[3], seq[4]
     p = _lib.GnbvEncoderParams()
     p.w1, p.b1, p.bn1_w, p.bn1_b = conv1.weight.data_ptr(), conv1.bias.data_ptr(), bn1.weight.data_ptr(), bn1.bias.data_ptr()
@@ -106,12 +131,14 @@ def _params_struct(seq, act_bf16: bool = False, grid_i8: Optional[torch.Tensor] 
     p.act_bf16 = int(bool(act_bf16))
     p.grid_i8 = None if grid_i8 is None else grid_i8.data_ptr()
     p.grid_i8_row_stride = 0 if grid_i8 is None else int(grid_i8.stride(0))
+    p.autocorr = None if autocorr is None else autocorr.data_ptr()
+    p.autocorr_row_stride = 0 if autocorr is None else int(autocorr.stride(0))
     return p
 
 
 class _GridEncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, base, rows, grid_off, grid, training, skip_flag, seq, act_bf16, write_through, grid_i8, compact, w1, b1, g1, be1, w2, b2, g2, be2):
+    def forward(ctx, base, rows, grid_off, grid, training, skip_flag, seq, act_bf16, write_through, grid_i8, compact, autocorr, w1, b1, g1, be1, w2, b2, g2, be2):
         lib = _lib.load()
         _lib.require_cuda(base, w1)
         for t in (w1, b1, g1, be1, w2, b2, g2, be2):
@@ -139,6 +166,7 @@ class _GridEncoderFn(torch.autograd.Function):
         ctx.meta = (grid_off, grid, batch, seq, act_bf16)
         ctx.write_through = write_through
         ctx.grid_i8 = grid_i8
+        ctx.autocorr = autocorr
         ctx.obs_ptr = obs_ptr
         return feats
 
@@ -160,23 +188,23 @@ class _GridEncoderFn(torch.autograd.Function):
         gs = _lib.GnbvEncoderGrads()
         for name, t in zip(("w1", "b1", "bn1_w", "bn1_b", "w2", "b2", "bn2_w", "bn2_b"), grads):
             setattr(gs, name, t.data_ptr())
-        params = _params_struct(seq, act_bf16, ctx.grid_i8)
+        params = _params_struct(seq, act_bf16, ctx.grid_i8, ctx.autocorr)
         ws = _workspace(lib, batch, grid, dev)
         _lib.check(lib.gnbv_encoder_grid_backward(
             ctx.obs_ptr, _lib.ptr(rows), base.stride(0), batch, grid, C.byref(params), y1.data_ptr(),
             y2.data_ptr(), bn_state.data_ptr(), d_feats.data_ptr(), dy2.data_ptr(), dz1.data_ptr(), C.byref(gs),
             ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "gnbv_encoder_grid_backward")
         if direct:
-            return (None,) * 19
-        return (None,) * 11 + tuple(grads)
+            return (None,) * 20
+        return (None,) * 12 + tuple(grads)
 
 
 def grid_encoder(base: torch.Tensor, rows: Optional[torch.Tensor], grid_off: int, grid: int, seq, training: bool,
                  skip_flag: Optional[torch.Tensor] = None, act_bf16: bool = False, write_through: bool = False,
-                 grid_i8: Optional[torch.Tensor] = None, compact: bool = False) -> torch.Tensor:
+                 grid_i8: Optional[torch.Tensor] = None, compact: bool = False, autocorr: Optional[torch.Tensor] = None) -> torch.Tensor:
     """seq = the `naive_encoder_grid` nn.Sequential (conv, bn, relu, conv, bn, relu).  `compact`: `base` rows carry
-    no grid slice, the grid is read from `grid_i8` only."""
-    return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, bool(act_bf16), bool(write_through), grid_i8, bool(compact), seq[0].weight, seq[0].bias,
+    no grid slice, the grid is read from `grid_i8` only.  `autocorr`: per-row input autocorrelation (input_autocorr)."""
+    return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, bool(act_bf16), bool(write_through), grid_i8, bool(compact), autocorr, seq[0].weight, seq[0].bias,
                                 seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias)
 
 
@@ -234,9 +262,9 @@ def hybrid_branches(enc, observations):
     (hybrid_encoder.py:76-88 of the reference)."""
     s = enc.state_input_shape[0]
     g = enc.grid_size
-    grid_i8, compact = None, False
+    grid_i8, compact, autocorr = None, False, None
     if isinstance(observations, (RowGather, DenseObs)):
-        base, rows, grid_i8 = observations.base, observations.rows, observations.grid_i8
+        base, rows, grid_i8, autocorr = observations.base, observations.rows, observations.grid_i8, observations.autocorr
         compact = observations.compact_state_dim is not None
         num_env = int(rows.shape[0]) if rows is not None else int(base.shape[0])
         get_state = lambda: observations.columns(0, s)  # noqa: E731  (gather of the pose columns: on the side stream too)
@@ -264,7 +292,7 @@ def hybrid_branches(enc, observations):
     else:
         feature_action = pose_branch()
     feature_grid = grid_encoder(base, rows, s, g, enc.naive_encoder_grid, enc.training, getattr(enc, "_bn_skip_flag", None),
-                                enc.compute_dtype == torch.bfloat16, getattr(enc, "_grad_write_through", False), grid_i8, compact)
+                                enc.compute_dtype == torch.bfloat16, getattr(enc, "_grad_write_through", False), grid_i8, compact, autocorr)
     if getattr(enc, "_split_backward", False) and torch.is_grad_enabled():
         # data-parallel: cut the autograd graph at the conv-stack output so that the backward runs in
         # two phases (late layers first, their gradient all-reduce overlaps the conv-stack backward)

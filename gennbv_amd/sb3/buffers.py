@@ -66,6 +66,7 @@ class TensorRolloutBuffer_Grid_Obs:
         self.privileged_observations = None
         self.lazy_obs = False  # True: minibatch observations are RowGather views (gather fused into conv1)
         self.grid_i8 = None    # optional [T+1, N, G^3] int8 copy of the grid slices (enable_grid_i8)
+        self.autocorr = None   # optional [T+1, N, 768] int32 (enable_grid_i8, G % 16 == 0)
         if compact is not None:
             self.enable_grid_i8(self.grid_elems)
         self.reset()
@@ -75,6 +76,19 @@ class TensorRolloutBuffer_Grid_Obs:
         next to the fp32 observation rows, the conv1 kernels of the PPO update read it (a quarter of the bytes)."""
         if self.grid_i8 is None:
             self.grid_i8 = torch.zeros(self.buffer_size + 1, self.n_envs, int(grid_elems), dtype=torch.int8, device=self.device)
+            # per-row autocorrelation of the conv1 input patches (3 KiB per row): a property of the stored grid, computed
+            # once per env step (update_autocorr), read by the fused backward kernel of every epoch
+            from ..ops import encoder_ops
+            g = round(int(grid_elems) ** (1.0 / 3.0))
+            if g ** 3 == int(grid_elems) and encoder_ops.autocorr_supported(g) and self.device.type == "cuda":
+                self._autocorr_grid = g
+                self.autocorr = torch.zeros(self.buffer_size + 1, self.n_envs, 768, dtype=torch.int32, device=self.device)
+
+    def update_autocorr(self, row: int) -> None:
+        """(Re)compute the autocorrelation rows of observation row `row` from its int8 grid rows."""
+        if self.autocorr is not None:
+            from ..ops import encoder_ops
+            encoder_ops.input_autocorr(self.grid_i8[row], self._autocorr_grid, out=self.autocorr[row])
 
     def next_grid_i8_row(self):
         return None if self.grid_i8 is None else self.grid_i8[self.step + 1]
@@ -85,6 +99,8 @@ class TensorRolloutBuffer_Grid_Obs:
             self.observations[0].copy_(self.observations[self.buffer_size])
             if self.grid_i8 is not None:
                 self.grid_i8[0].copy_(self.grid_i8[self.buffer_size])
+            if self.autocorr is not None:
+                self.autocorr[0].copy_(self.autocorr[self.buffer_size])
         self.step = 0
         self.pos = 0
         self.full = False
@@ -113,6 +129,7 @@ class TensorRolloutBuffer_Grid_Obs:
                 row[:, :s0].copy_(obs[:, :s0])
                 row[:, s0:].copy_(obs[:, s0 + ge:])
                 self.grid_i8[self.step].copy_(obs[:, s0:s0 + ge].to(torch.int8))
+                self.update_autocorr(self.step)
             else:
                 row.copy_(obs)
         self.actions[self.step].copy_(action)
@@ -155,7 +172,7 @@ class TensorRolloutBuffer_Grid_Obs:
         if self.lazy_obs:
             from ..ops.encoder_ops import RowGather
             obs = RowGather(flat(self.observations[:t]), rows, None if self.grid_i8 is None else flat(self.grid_i8[:t]),
-                            self.compact_state_dim)
+                            self.compact_state_dim, None if self.autocorr is None else flat(self.autocorr[:t]))
         elif self.compact_state_dim is not None:
             from ..ops.encoder_ops import _flat_rows
             obs = _flat_rows(flat(self.observations[:t])[rows], flat(self.grid_i8[:t])[rows], self.compact_state_dim)

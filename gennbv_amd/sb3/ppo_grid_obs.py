@@ -349,7 +349,8 @@ class PPO_Grid_Obs:
         if phase in ("all", "A"):
             t, n = buf.buffer_size, buf.n_envs
             obs = RowGather(buf.observations[:t].view(t * n, -1), loss.rows,
-                            None if buf.grid_i8 is None else buf.grid_i8[:t].view(t * n, -1), buf.compact_state_dim)
+                            None if buf.grid_i8 is None else buf.grid_i8[:t].view(t * n, -1), buf.compact_state_dim,
+                            None if buf.autocorr is None else buf.autocorr[:t].view(t * n, -1))
             enc = pol.features_extractor
             if st.get("fused_head"):
                 fa, fg = encoder_ops.hybrid_branches(enc, obs)
@@ -528,7 +529,9 @@ class PPO_Grid_Obs:
     def _env_step(self, actions, obs_out):
         g8 = self.rollout_buffer.next_grid_i8_row()
         if g8 is not None:
-            return self.env.step(actions, obs_out=obs_out, grid_i8_out=g8)
+            out = self.env.step(actions, obs_out=obs_out, grid_i8_out=g8)
+            self.rollout_buffer.update_autocorr(self.rollout_buffer.step + 1)
+            return out
         try:
             return self.env.step(actions, obs_out=obs_out)
         except TypeError:
@@ -560,6 +563,7 @@ class PPO_Grid_Obs:
         if buf.grid_i8 is not None and buf.compact_state_dim is None:
             s0 = enc.state_input_shape[0]
             buf.grid_i8[0].copy_(buf.observations[0][:, s0:s0 + enc.grid_size ** 3].to(torch.int8))
+            buf.update_autocorr(0)
 
     def collect_rollouts(self, env, callback, rollout_buffer, n_rollout_steps: int) -> bool:
         """on_policy_algorithm_grid_obs.py:128-221 (tensor-env branch)."""
@@ -641,6 +645,7 @@ class PPO_Grid_Obs:
             try:
                 if self.rollout_buffer.grid_i8 is not None:
                     self._last_obs = self.env.reset(obs_out=self.rollout_buffer.first_obs_row(), grid_i8_out=self.rollout_buffer.grid_i8[0])
+                    self.rollout_buffer.update_autocorr(0)
                 else:
                     self._last_obs = self.env.reset(obs_out=self.rollout_buffer.first_obs_row())
             except TypeError:

@@ -218,11 +218,26 @@ typedef struct GnbvEncoderParams {
                                      unless obs_grid == NULL (compact observations: the grid exists only as these
                                      rows; any grid size, fp32 activations) */
     int64_t grid_i8_row_stride;
+    const int32_t *autocorr;      /* NULL, or per-sample input autocorrelation rows (gnbv_input_autocorr over the same
+                                     int8 rows, same row numbering): the fused backward sums rows[b]'s rows instead of
+                                     recomputing the minibatch's autocorrelation */
+    int64_t autocorr_row_stride;  /* ints */
 } GnbvEncoderParams;
 
 typedef struct GnbvEncoderGrads {  /* outputs, same shapes as the parameters */
     float *w1, *b1, *bn1_w, *bn1_b, *w2, *b2, *bn2_w, *bn2_b;
 } GnbvEncoderGrads;
+
+/* Input autocorrelation of the conv1 patches of n int8 grid rows (values -1/0/1): out row e (gnbv_input_autocorr_row_ints()
+ * = 768 ints: the 16x16 tiles [0..15][0..15], [0..15][16..31], [16..31][16..31] of the symmetric R[32][32]) holds
+ * R[t][t'] = sum over the O1^3 conv1 output positions of x[pos, t] * x[pos, t'], t = 0..26 the taps of
+ * hybrid_encoder.py:39's Conv3d(1, 16, k3, s2), t = 27 a constant 1 (R[t][27] = sum x, R[27][27] = O1^3).  Exact (int8
+ * MFMA).  BatchNorm-backward of that layer is linear in the input, so these rows replace every reduction over the
+ * layer's activations that does not involve the incoming gradient (encoder.hip, k_conv2_dgrad_c1w).  G % 16 == 0,
+ * 3 G^2 <= 64 KiB. */
+int gnbv_input_autocorr_row_ints(void);
+int gnbv_input_autocorr(const int8_t *grid_i8, int64_t grid_i8_row_stride, int n, int grid, int32_t *out, int64_t out_row_stride,
+                        void *stream);
 
 size_t gnbv_encoder_workspace_bytes(int batch, int grid);
 /* number of ELEMENTS (fp32 or bf16, GnbvEncoderParams.act_bf16) of the layer-1 activation buffers (y1, dz1_scratch) */

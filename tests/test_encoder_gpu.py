@@ -76,7 +76,7 @@ def test_fused_dgrad_conv1_wgrad_vs_fp64_reference(g, b):
     """With the int8 grid rows present (G % 16 == 0) the backward runs k_conv2_dgrad_c1w: conv2 data gradient and conv1
     weight gradient in one launch, BN1 backward applied to fp64 sums afterwards (dz1' is never stored).  All conv / BN
     gradients against the fp64 torch reference, tolerance = fp32 round-off; rows are gathered (RowGather)."""
-    from gennbv_amd.ops.encoder_ops import RowGather
+    from gennbv_amd.ops.encoder_ops import RowGather, input_autocorr
     hip, _, _ = pu.make_policy(g=g, device=DEV, backend="hip", det_weights=True)
     ref, _, _ = pu.make_policy(g=g, device="cpu", backend="torch", det_weights=True)
     ref = ref.double()
@@ -84,6 +84,14 @@ def test_fused_dgrad_conv1_wgrad_vs_fp64_reference(g, b):
     rows = torch.randperm(2 * b + 1)[:b].to(DEV)
     grid_i8 = base[:, 600:600 + g ** 3].to(torch.int8).contiguous()
     w = torch.linspace(0.5, 1.5, 256)
+    # the input autocorrelation is either computed by the backward call (minibatch total) or gathered from per-row
+    # results stored with the observations: exact integers both ways -> identical gradients
+    hip.train()
+    for _ in range(2):  # (first pass: warm-up, the library GEMMs of the fc layer may be auto-tuned on their first call)
+        hip.zero_grad()
+        f = hip.features_extractor(RowGather(base, rows, grid_i8, autocorr=input_autocorr(grid_i8, g)))
+        (f * w.to(DEV)).sum().backward()
+    stored = [p.grad.clone() for p in hip.features_extractor.parameters()]
     outs = []
     for pol, obs, dev, dt in ((ref, base[rows].cpu().double(), "cpu", torch.float64), (hip, RowGather(base, rows, grid_i8), DEV, torch.float32)):
         pol.train()
@@ -91,6 +99,8 @@ def test_fused_dgrad_conv1_wgrad_vs_fp64_reference(g, b):
         f = pol.features_extractor(obs)
         (f * w.to(dev, dt)).sum().backward()
         outs.append(f.detach().double().cpu())
+    for a, c in zip(stored, hip.features_extractor.parameters()):
+        assert torch.equal(a, c.grad)
     assert float((outs[0] - outs[1]).abs().max()) <= 2e-5 * float(outs[0].abs().max()) + 1e-6
     for (n1, p1), (n2, p2) in zip(ref.features_extractor.named_parameters(), hip.features_extractor.named_parameters()):
         r = p1.grad.double()
@@ -100,6 +110,25 @@ def test_fused_dgrad_conv1_wgrad_vs_fp64_reference(g, b):
             assert err < 1e-4, (n1, err)
         else:
             assert err <= 2e-5 * scale, (n1, err, scale)
+
+
+@pytest.mark.parametrize("g,n", [(16, 3), (32, 2), (48, 2), (64, 3), (128, 1)])
+def test_input_autocorrelation_rows_exact(g, n):
+    """gnbv_input_autocorr: R[t][t'] = sum over conv1 output positions of x[pos,t] x[pos,t'] per row (t = 27: ones),
+    exact integers, vs torch unfold on the CPU."""
+    from gennbv_amd.ops.encoder_ops import input_autocorr
+    gen = torch.Generator().manual_seed(g)
+    x = (torch.randint(-1, 2, (n, g ** 3), generator=gen) * (torch.rand(n, g ** 3, generator=gen) < 0.6)).to(torch.int8)
+    rows = input_autocorr(x.to(DEV), g).cpu()
+    assert rows.shape == (n, 768)
+    o1 = (g - 3) // 2 + 1
+    v = x.view(n, g, g, g).to(torch.int64)
+    pat = v.unfold(1, 3, 2).unfold(2, 3, 2).unfold(3, 3, 2).reshape(n, o1 ** 3, 27)  # [n, pos, tap = (dz, dy, dx)]
+    pat = torch.cat((pat, torch.ones(n, o1 ** 3, 1, dtype=torch.int64), torch.zeros(n, o1 ** 3, 4, dtype=torch.int64)), dim=2)
+    R = torch.einsum("npt,npu->ntu", pat, pat)  # [n, 32, 32]
+    tiles = torch.stack((R[:, :16, :16], R[:, :16, 16:], R[:, 16:, 16:]), dim=1).reshape(n, 768)
+    assert torch.equal(rows.to(torch.int64), tiles)
+    assert int(rows[0, 512 + 11 * 16 + 11]) == o1 ** 3  # R[27][27] = number of positions
 
 
 def test_encoder_matches_reference_golden_f7():
