@@ -243,7 +243,8 @@ template <typename A, typename IN>
 __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
     const IN *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, int B, int G, int O1,
     const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ b1, typename A::T *__restrict__ y1,
-    float *__restrict__ partials)
+    float *__restrict__ partials, const float *__restrict__ zscale /*NULL: store y1 (pre-BN); else z1 = relu(zscale*y1 + zshift)*/,
+    const float *__restrict__ zshift)
 {
     extern __shared__ __attribute__((aligned(16))) float s_in[];  // [3][NR][G]
     int b, oz;
@@ -310,6 +311,9 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
             off[s] = ok ? (dz * NR + dy) * G + dx : 0;
         }
         const float4 bias = *reinterpret_cast<const float4 *>(b1 + 4 * kq);
+        const bool z1 = zscale != nullptr;  // BN1 scale / shift known up front (analytic batch statistics, or eval mode)
+        const float4 zs = z1 ? *reinterpret_cast<const float4 *>(zscale + 4 * kq) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 zh = z1 ? *reinterpret_cast<const float4 *>(zshift + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int oy = wv; oy < O1; oy += kEncWaves) {
             for (int ox0 = 0; ox0 < O1; ox0 += 16) {
                 const int ox = min(ox0 + m, O1 - 1);
@@ -323,16 +327,21 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
                 const int oxm = ox0 + m;
                 if (oxm < O1) {
                     float4 y = make_float4(acc[0] + bias.x, acc[1] + bias.y, acc[2] + bias.z, acc[3] + bias.w);
+                    if (z1) {
+                        y = make_float4(fmaxf(fmaf(zs.x, y.x, zh.x), 0.f), fmaxf(fmaf(zs.y, y.y, zh.y), 0.f),
+                                        fmaxf(fmaf(zs.z, y.z, zh.z), 0.f), fmaxf(fmaf(zs.w, y.w, zh.w), 0.f));
+                    } else {
+                        s_sum[0] += y.x; s_sq[0] += y.x * y.x;
+                        s_sum[1] += y.y; s_sq[1] += y.y * y.y;
+                        s_sum[2] += y.z; s_sq[2] += y.z * y.z;
+                        s_sum[3] += y.w; s_sq[3] += y.w * y.w;
+                    }
                     A::st4(y1 + vox1(b, oz, oy, oxm, O1) * kC + 4 * kq, y);
-                    s_sum[0] += y.x; s_sq[0] += y.x * y.x;
-                    s_sum[1] += y.y; s_sq[1] += y.y * y.y;
-                    s_sum[2] += y.z; s_sq[2] += y.z * y.z;
-                    s_sum[3] += y.w; s_sq[3] += y.w * y.w;
                 }
             }
         }
     }
-    write_partials_cl(partials, kEncWaves, wv, s_sum, s_sq);
+    if (partials != nullptr) write_partials_cl(partials, kEncWaves, wv, s_sum, s_sq);
 }
 
 // W2 [co][ci][27] -> the two LDS images the conv2 kernels use, written once per call so that the
@@ -378,7 +387,7 @@ constexpr int kBigWaves = kBigThreads / kWave;
 // ---------------------------------------------------------------------------
 // conv2 forward: z1 = relu(scale1*y1 + shift1) applied on load; y2 [B,16,O2^3] (NCDHW, pre-BN)
 // ---------------------------------------------------------------------------
-template <typename A>
+template <typename A, bool Z1 = false /*the layer-1 buffer holds z1 = relu(bn1(y1)) already*/>
 __global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
     const typename A::T *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1, int B, int O1, int O2,
     const float *__restrict__ W2img /*k_prep_w2 fwd image*/, const float *__restrict__ b2, float *__restrict__ y2,
@@ -421,8 +430,8 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
     auto consume = [&](int dz, const float4 (&v)[9], f32x4 &acc) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const float z0 = fmaxf(fmaf(sc[0], v[t].x, sh[0]), 0.f), z1 = fmaxf(fmaf(sc[1], v[t].y, sh[1]), 0.f);
-            const float z2 = fmaxf(fmaf(sc[2], v[t].z, sh[2]), 0.f), z3 = fmaxf(fmaf(sc[3], v[t].w, sh[3]), 0.f);
+            const float z0 = Z1 ? v[t].x : fmaxf(fmaf(sc[0], v[t].x, sh[0]), 0.f), z1 = Z1 ? v[t].y : fmaxf(fmaf(sc[1], v[t].y, sh[1]), 0.f);
+            const float z2 = Z1 ? v[t].z : fmaxf(fmaf(sc[2], v[t].z, sh[2]), 0.f), z3 = Z1 ? v[t].w : fmaxf(fmaf(sc[3], v[t].w, sh[3]), 0.f);
             const float *wb = w2s + (dz * 9 + t) * 256 + lane;  // + s*64
             acc = mfma4(z0, wb[0], acc);
             acc = mfma4(z1, wb[64], acc);
@@ -696,7 +705,7 @@ __device__ __forceinline__ void wave_row_range(int nrows, int &r0, int &r1)
 // MFMA: i = ci, j = co, k = 4 consecutive output positions along x.  27 accumulators / wave.
 // partial[w][tap][ci][co] (+ 16 bias sums), reduced by k_reduce_partials.
 // ---------------------------------------------------------------------------
-template <typename A>
+template <typename A, bool Z1 = false>
 __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv2_wgrad(
     const typename A::T *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1,
     const float *__restrict__ dy2 /*[B,O2,O2,O2,16]*/, int B, int O1, int O2, float *__restrict__ partial)
@@ -736,7 +745,7 @@ __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(2, 
         bsum += bb;
 #pragma unroll
         for (int tap = 0; tap < kTaps; ++tap) {
-            const float a = fmaxf(fmaf(sc, av[tap], sh), 0.0f);
+            const float a = Z1 ? av[tap] : fmaxf(fmaf(sc, av[tap], sh), 0.0f);
             acc[tap] = mfma4(a, bb, acc[tap]);
         }
     };
@@ -931,7 +940,7 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad(
 constexpr int kSlabRow = 80, kSlabBytes = 25 * kSlabRow;  // 5 planes x 5 rows x (65 -> 80) bytes
 constexpr int kE1F = 512 + 2 * kC;                        // T1 [32 taps][16], S1, S2 [16]
 
-template <int EZ, int EY, int EX>
+template <bool Z1, int EZ, int EY, int EX>
 __device__ __forceinline__ void dgrad_c1w_subtile(
     const float4 (&L)[8], const float (&Y)[4], const float *w2d, const int8_t *slab0, const int8_t *slab1, const bool (&ok0)[4],
     const bool (&ok1)[4], float sc, float sh, float mu, float rs, float &s1, float &s2, f32x4 (&T1)[2])
@@ -958,15 +967,18 @@ __device__ __forceinline__ void dgrad_c1w_subtile(
         // Out-of-grid voxels (x only: out-of-grid planes / rows skip the sub-tile) are masked in the A operand, so
         // their g never reaches T1; g is masked as well for the channel sums.
         const float y = ok0[r] ? Y[r] : 0.0f;  // (out-of-grid slots of y1 are never written: may hold Inf / NaN)
-        const float g = (ok0[r] && fmaf(sc, y, sh) > 0.0f) ? acc[r] : 0.0f;
+        // Z1: the buffer holds z1 = relu(bn1(y1)); the ReLU mask is z1 > 0 and s2 accumulates sum g*z1 (the finish kernel
+        // turns it into sum g*xhat = (sum g*z1 - beta*S1) / gamma)
+        const float g = (ok0[r] && (Z1 ? y : fmaf(sc, y, sh)) > 0.0f) ? acc[r] : 0.0f;
         s1 += g;
-        s2 = fmaf(g, (y - mu) * rs, s2);
+        s2 = fmaf(g, Z1 ? y : (y - mu) * rs, s2);
         const float a0v = (float)slab0[kOff + 4 * r], a1v = (float)slab1[kOff + 4 * r];  // unconditional reads, then selects
         T1[0] = mfma4(ok0[r] ? a0v : 0.0f, g, T1[0]);  // A[i = tap][k = voxel]
         T1[1] = mfma4(ok1[r] ? a1v : 0.0f, g, T1[1]);
     }
 }
 
+template <bool Z1>
 __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad_c1w(
     const float *__restrict__ dy2, const float *__restrict__ W2 /*dgrad image*/, const float *__restrict__ y1, const float *__restrict__ scale1,
     const float *__restrict__ shift1, const float *__restrict__ mean1, const float *__restrict__ rstd1, const int8_t *__restrict__ grid_i8,
@@ -1054,22 +1066,22 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad_c1w(
             __builtin_amdgcn_wave_barrier();
             // sub-tiles on out-of-grid planes / rows are skipped (wave-uniform)
             const bool z0 = 2 * a < O1, z1 = 2 * a + 1 < O1, y0 = 2 * c < O1, y1ok = 2 * c + 1 < O1;
-            if (z0 && y0) dgrad_c1w_subtile<0, 0, 0>(L, Y[0], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, T1);
-            if (z0 && y0) dgrad_c1w_subtile<0, 0, 1>(L, Y[1], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, T1);
+            if (z0 && y0) dgrad_c1w_subtile<Z1, 0, 0, 0>(L, Y[0], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, T1);
+            if (z0 && y0) dgrad_c1w_subtile<Z1, 0, 0, 1>(L, Y[1], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, T1);
             __builtin_amdgcn_sched_barrier(0);
             request_y(4, Y[4]);
             request_y(5, Y[5]);
             __builtin_amdgcn_sched_barrier(0);
-            if (z0 && y1ok) dgrad_c1w_subtile<0, 1, 0>(L, Y[2], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, T1);
-            if (z0 && y1ok) dgrad_c1w_subtile<0, 1, 1>(L, Y[3], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, T1);
+            if (z0 && y1ok) dgrad_c1w_subtile<Z1, 0, 1, 0>(L, Y[2], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, T1);
+            if (z0 && y1ok) dgrad_c1w_subtile<Z1, 0, 1, 1>(L, Y[3], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, T1);
             __builtin_amdgcn_sched_barrier(0);
             request_y(6, Y[6]);
             request_y(7, Y[7]);
             __builtin_amdgcn_sched_barrier(0);
-            if (z1 && y0) dgrad_c1w_subtile<1, 0, 0>(L, Y[4], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, T1);
-            if (z1 && y0) dgrad_c1w_subtile<1, 0, 1>(L, Y[5], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, T1);
-            if (z1 && y1ok) dgrad_c1w_subtile<1, 1, 0>(L, Y[6], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, T1);
-            if (z1 && y1ok) dgrad_c1w_subtile<1, 1, 1>(L, Y[7], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, T1);
+            if (z1 && y0) dgrad_c1w_subtile<Z1, 1, 0, 0>(L, Y[4], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, T1);
+            if (z1 && y0) dgrad_c1w_subtile<Z1, 1, 0, 1>(L, Y[5], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, T1);
+            if (z1 && y1ok) dgrad_c1w_subtile<Z1, 1, 1, 0>(L, Y[6], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, T1);
+            if (z1 && y1ok) dgrad_c1w_subtile<Z1, 1, 1, 1>(L, Y[7], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, T1);
             __builtin_amdgcn_wave_barrier();  // the next super-tile overwrites the slab
         }
     }
@@ -1193,24 +1205,16 @@ __global__ __launch_bounds__(kAcThreads) void k_input_autocorr(const int8_t *__r
         if (red[i] != 0) atomicAdd(&dst[i], red[i]);
 }
 
-// dW1, db1 and the BN affine gradients from the fused kernel's sums and the input autocorrelation (fp64).
-// One workgroup of 1024 threads.  ac: per-sample autocorrelation rows (summed here over the minibatch's rows: four
-// row groups per column, 16 requests in flight per thread; integers, so the order does not matter) or, with
-// nrows == 0, the minibatch total.
-__global__ __launch_bounds__(1024) void k_c1w_fused_finish(const double *__restrict__ tmp /*[slices][kE1F]*/, int slices, const int *__restrict__ ac,
-                                                          int64_t ac_row_stride, const int64_t *__restrict__ rows, int nrows,
-                                                          const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ scale1,
-                                                          const float *__restrict__ rstd1, float *__restrict__ dW1, float *__restrict__ db1,
-                                                          const double *__restrict__ S2 /*BN2 sums*/, float *g1w, float *g1b, float *g2w,
-                                                          float *g2b)
+// sum over the minibatch's autocorrelation rows (wave w sums rows w, w + 16, ...: 16-byte requests -- the vector-memory
+// pipe of the one CU these single-workgroup kernels run on takes ~16 cycles per wave request whatever its width -- row
+// index wave-uniform; integers, so the order does not matter) or, with nrows == 0, the minibatch total at ac.
+// 1024 threads; result in Ri[kAcRow] after the trailing barrier.
+__device__ __forceinline__ void gather_autocorr(const int *__restrict__ ac, int64_t ac_row_stride, const int64_t *__restrict__ rows, int nrows,
+                                                int *Ri)
 {
-    __shared__ int Ri[kAcRow];
-    __shared__ double R[kAcRow];
     for (int i = threadIdx.x; i < kAcRow; i += 1024) Ri[i] = nrows == 0 ? ac[i] : 0;
     __syncthreads();
     if (nrows > 0) {
-        // wave w sums rows w, w + 16, ...: 16-byte requests (the vector-memory pipe of the one CU this kernel runs on
-        // takes ~16 cycles per wave request whatever its width), row index wave-uniform
         const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
         int4 t[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
         for (int b = wv; b < nrows; b += 16) {
@@ -1231,6 +1235,63 @@ __global__ __launch_bounds__(1024) void k_c1w_fused_finish(const double *__restr
         }
         __syncthreads();
     }
+}
+__device__ __forceinline__ int ac_index(int t, int u)  // symmetric R[32][32]; stored tiles: (0,0), (0,1), (1,1)
+{
+    if ((t >> 4) > (u >> 4)) { const int v = t; t = u; u = v; }
+    return ((t >> 4) + (u >> 4)) * 256 + (t & 15) * 16 + (u & 15);
+}
+
+// BatchNorm-1 batch statistics WITHOUT the activations: y1 = W1 x + b1 is linear in the input patches, so
+//   sum_pos y1[c]   = W1[c] . T2 + M b1[c]
+//   sum_pos y1[c]^2 = W1[c]^T R W1[c] + 2 b1[c] W1[c] . T2 + M b1[c]^2
+// with R / T2 / M from the input autocorrelation (exact integers) -- known BEFORE conv1 runs, so conv1 can apply
+// BN + ReLU in its epilogue.  fp64; same finalize (running statistics, scale / shift / mean / rstd) as the measured path.
+__global__ __launch_bounds__(1024) void k_bn1_analytic(const int *__restrict__ ac, int64_t ac_row_stride, const int64_t *__restrict__ rows, int nrows,
+                                                      const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ b1,
+                                                      const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
+                                                      float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                      int64_t *__restrict__ num_batches_tracked, const int *__restrict__ skip_flag,
+                                                      float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out,
+                                                      float *__restrict__ rstd_out)
+{
+    __shared__ int Ri[kAcRow];
+    __shared__ double q[kC][kTaps];
+    gather_autocorr(ac, ac_row_stride, rows, nrows, Ri);
+    if (threadIdx.x < kC * kTaps) {  // q[c][t] = W1[c][t] * sum_u W1[c][u] R[t][u]
+        const int c = threadIdx.x / kTaps, t = threadIdx.x - c * kTaps;
+        double a = 0.0;
+        for (int u = 0; u < kTaps; ++u) a += (double)W1[c * kTaps + u] * (double)Ri[ac_index(t, u)];
+        q[c][t] = (double)W1[c * kTaps + t] * a;
+    }
+    __syncthreads();
+    if (threadIdx.x < kC) {
+        const int c = threadIdx.x;
+        const double count = (double)Ri[ac_index(kTaps, kTaps)], bb = (double)b1[c];
+        double wt = 0.0, quad = 0.0;
+        for (int t = 0; t < kTaps; ++t) {
+            wt += (double)W1[c * kTaps + t] * (double)Ri[ac_index(t, kTaps)];
+            quad += q[c][t];
+        }
+        bn_finalize_channel(c, wt + count * bb, quad + 2.0 * bb * wt + count * bb * bb, count, gamma, beta, eps, momentum, 1, running_mean,
+                            running_var, num_batches_tracked, skip_flag, scale, shift, mean_out, rstd_out);
+    }
+}
+
+// dW1, db1 and the BN affine gradients from the fused kernel's sums and the input autocorrelation (fp64).
+// One workgroup of 1024 threads.  ac: per-sample autocorrelation rows (gather_autocorr) or, with nrows == 0, the
+// minibatch total.
+__global__ __launch_bounds__(1024) void k_c1w_fused_finish(const double *__restrict__ tmp /*[slices][kE1F]*/, int slices, const int *__restrict__ ac,
+                                                          int64_t ac_row_stride, const int64_t *__restrict__ rows, int nrows,
+                                                          const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ scale1,
+                                                          const float *__restrict__ rstd1, const float *__restrict__ gamma1 /*NULL unless z1 mode*/,
+                                                          const float *__restrict__ beta1, float *__restrict__ dW1, float *__restrict__ db1,
+                                                          const double *__restrict__ S2 /*BN2 sums*/, float *g1w, float *g1b, float *g2w,
+                                                          float *g2b)
+{
+    __shared__ int Ri[kAcRow];
+    __shared__ double R[kAcRow];
+    gather_autocorr(ac, ac_row_stride, rows, nrows, Ri);
     for (int i = threadIdx.x; i < kAcRow; i += 1024) R[i] = (double)Ri[i];
     __syncthreads();
     if (threadIdx.x >= 512) return;
@@ -1243,10 +1304,11 @@ __global__ __launch_bounds__(1024) void k_c1w_fused_finish(const double *__restr
         s1 += t[512 + co];
         s2 += t[512 + kC + co];
     }
-    auto Rs = [&](int t, int u) {  // symmetric; stored tiles: (0,0), (0,1), (1,1)
-        if ((t >> 4) > (u >> 4)) { const int v = t; t = u; u = v; }
-        return R[((t >> 4) + (u >> 4)) * 256 + (t & 15) * 16 + (u & 15)];
-    };
+    if (gamma1 != nullptr) {  // z1 mode: s2 holds sum g*z1 over the unmasked voxels, z1 = gamma*xhat + beta there
+        const double ga = (double)gamma1[co];
+        s2 = ga != 0.0 ? (s2 - (double)beta1[co] * s1) / ga : 0.0;  // (gamma == 0: xhat is not recoverable from z1)
+    }
+    auto Rs = [&](int t, int u) { return R[ac_index(t, u)]; };
     const double count = Rs(kTaps, kTaps), inv_count = 1.0 / count;
     if (tap < kTaps) {
         const double T2 = Rs(tap, kTaps), T2m = T2 * inv_count;
@@ -1573,6 +1635,46 @@ static inline int reduce_stage1(const float *partial, int P, int E, double *tmp,
     return slices;
 }
 
+// Kernel-path predicates shared by forward and backward (they must agree on what the layer-1 buffer holds).
+//   fused_path: conv2 data gradient fused with the conv1 weight gradient (needs the grid as aligned int8 rows)
+//   z1_path   : additionally, BatchNorm-1's scale / shift are known before conv1 runs (analytic batch statistics from
+//               the input autocorrelation, or eval mode), conv1 applies BN + ReLU in its epilogue and the buffer holds
+//               z1 = relu(bn1(y1)) instead of y1
+static inline bool env_off(const char *name)
+{
+    const char *e = getenv(name);
+    return e && e[0] == '0';
+}
+static inline bool fused_path(const GnbvEncoderParams *p, int grid)
+{
+    return !env_off("GENNBV_FUSED_BWD") && !p->act_bf16 && p->grid_i8 != nullptr && grid % 16 == 0 && 3 * grid * grid <= 64 * 1024 &&
+           p->grid_i8_row_stride % 16 == 0 && (((uintptr_t)p->grid_i8 & 15) == 0);
+}
+static inline bool conv1_i8_staged(const GnbvEncoderParams *p, int grid)
+{
+    const int O1 = out_size(grid);
+    return p->grid_i8 != nullptr && grid % 16 == 0 && p->grid_i8_row_stride % 16 == 0 && (((uintptr_t)p->grid_i8 & 15) == 0) &&
+           (size_t)3 * (2 * O1 + 1) * grid * sizeof(float) <= 64 * 1024 && 2 * O1 + 1 <= grid;
+}
+// z1_path is OPT-IN (GENNBV_Z1=1): correct (tests) but measured slower on MI355X -- train 1144-1149 vs 1119-1122 ms per
+// iteration, same box: without the fma+max in front of their MFMAs conv2 forward / weight gradient do not get faster
+// (95 / 105 us: they wait on operand latency, not on the issue slot), so the saving is conv1's statistics only.
+static inline bool z1_path(const GnbvEncoderParams *p, int grid)
+{
+    const char *e = getenv("GENNBV_Z1");
+    return e && e[0] == '1' && fused_path(p, grid) && conv1_i8_staged(p, grid);
+}
+
+// minibatch total of the input autocorrelation into `Rac` (when the caller has no per-row results)
+static int launch_autocorr_total(const GnbvEncoderParams *p, const int64_t *rows, int batch, int grid, int *Rac, hipStream_t st)
+{
+    if (hipMemsetAsync(Rac, 0, kAcRow * sizeof(int), st) != hipSuccess) return (int)hipGetLastError();
+    const int P = autocorr_planes(grid), O1 = out_size(grid);
+    hipLaunchKernelGGL(k_input_autocorr, dim3(sample_plane_group_grid(batch, O1, P)), dim3(kAcThreads), (size_t)(2 * P + 1) * grid * grid, st,
+                       p->grid_i8, rows, p->grid_i8_row_stride, batch, grid, O1, P, Rac, (int64_t)0);
+    return gnbv_launch_status();
+}
+
 GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *rows, int64_t row_stride, int batch, int grid,
                                        const GnbvEncoderParams *p, int training, const int *skip_flag, void *y1, float *y2,
                                        float *bn_state /*[2][4][16]: scale, shift, mean, rstd per layer*/, float *features,
@@ -1591,6 +1693,27 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     EncWs w = enc_carve(workspace, batch, grid);
     float *bn1 = bn_state, *bn2 = bn_state + 4 * kC;
     int err;
+    GNBV_CHECK_ARG(p->autocorr == nullptr || (p->autocorr_row_stride >= kAcRow && p->autocorr_row_stride % 4 == 0 && ((uintptr_t)p->autocorr & 15) == 0));
+    const bool z1 = z1_path(p, grid);
+    if (z1) {
+        // BN1 scale / shift first (training: analytic batch statistics from the input autocorrelation; eval: running
+        // statistics), then conv1 with the BN + ReLU epilogue: the layer-1 buffer holds z1
+        if (training) {
+            int *Rac = (int *)(w.red + 1024);
+            if (p->autocorr == nullptr && (err = launch_autocorr_total(p, rows, batch, grid, Rac, st))) return err;
+            hipLaunchKernelGGL(k_bn1_analytic, dim3(1), dim3(1024), 0, st, p->autocorr ? (const int *)p->autocorr : (const int *)Rac,
+                               p->autocorr_row_stride, rows, p->autocorr ? batch : 0, p->w1, p->b1, p->bn1_w, p->bn1_b, p->eps, p->momentum,
+                               p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC);
+        } else {
+            hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps, p->momentum,
+                               p->bn1_rm, p->bn1_rv, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC);
+        }
+        if ((err = gnbv_launch_status())) return err;
+        hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, int8_t>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads),
+                           (size_t)3 * (2 * O1 + 1) * grid * sizeof(float), st, p->grid_i8, rows, p->grid_i8_row_stride, batch, grid, O1, p->w1,
+                           p->b1, (float *)y1, (float *)nullptr, (const float *)bn1, (const float *)(bn1 + kC));
+        if ((err = gnbv_launch_status())) return err;
+    } else {
     // conv1 (+ BN1 statistics)
     if (p->act_bf16) {
         hipLaunchKernelGGL(k_conv1_fwd<ActBF16>, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, batch, grid, O1, p->w1,
@@ -1599,14 +1722,13 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
         const size_t c1_lds = (size_t)3 * (2 * O1 + 1) * grid * sizeof(float);
         const bool c1_staged = obs_grid != nullptr && (grid % 4 == 0) && (row_stride % 4 == 0) && (((uintptr_t)obs_grid & 15) == 0) && c1_lds <= 64 * 1024 &&
                                2 * O1 + 1 <= grid;
-        const bool c1_i8 = p->grid_i8 != nullptr && grid % 16 == 0 && p->grid_i8_row_stride % 16 == 0 && (((uintptr_t)p->grid_i8 & 15) == 0) &&
-                           c1_lds <= 64 * 1024 && 2 * O1 + 1 <= grid;
-        if (c1_i8)  // compact int8 copy of the tri-class grid: a quarter of the input bytes
+        const float *nozs = nullptr;
+        if (conv1_i8_staged(p, grid))  // compact int8 copy of the tri-class grid: a quarter of the input bytes
             hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, int8_t>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, p->grid_i8, rows,
-                               p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr);
+                               p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr, nozs, nozs);
         else if (c1_staged)
             hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, float>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, obs_grid, rows,
-                               row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr);
+                               row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr, nozs, nozs);
         else if (obs_grid == nullptr)  // compact rows at a size the staged kernel does not take
             hipLaunchKernelGGL((k_conv1_fwd<ActF32, int8_t>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, p->grid_i8, rows,
                                p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr);
@@ -1623,12 +1745,16 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
         hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps, p->momentum,
                            p->bn1_rm, p->bn1_rv, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC);
     if ((err = gnbv_launch_status())) return err;
+    }
     // conv2 (BN1 + ReLU on load; + BN2 statistics).  (Folding the weight-image prep into the single-workgroup
     // k_stats_reduce was measured: +8.5 us there vs 6.3 us for this launch -- kept separate.)
     hipLaunchKernelGGL(k_prep_w2, dim3(kTaps), dim3(256), 0, st, p->w2, w.w2img, w.w2img + kTaps * 256);
     const int g2 = sample_plane_group_grid(batch, O2, kPlanesPerGroup);
     if (p->act_bf16) {
         hipLaunchKernelGGL(k_conv2_fwd<ActBF16>, dim3(g2), dim3(kBigThreads), 0, st, (const uint16_t *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
+                       training ? w.bn_part : nullptr);
+    } else if (z1) {
+        hipLaunchKernelGGL((k_conv2_fwd<ActF32, true>), dim3(g2), dim3(kBigThreads), 0, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
                        training ? w.bn_part : nullptr);
     } else {
         hipLaunchKernelGGL(k_conv2_fwd<ActF32>, dim3(g2), dim3(kBigThreads), 0, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
@@ -1690,20 +1816,12 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     int err;
     // conv2 data gradient fused with the conv1 weight gradient (dz1' never stored) when the grid exists as aligned
     // int8 rows; the input autocorrelation it needs runs on a second stream beside the kernels below
-    const char *fenv = getenv("GENNBV_FUSED_BWD");  // "0": the separate kernels (A/B runs, bit-equality tests)
-    const bool fused = !(fenv && fenv[0] == '0') && !p->act_bf16 && p->grid_i8 != nullptr && grid % 16 == 0 && 3 * grid * grid <= 64 * 1024 &&
-                       p->grid_i8_row_stride % 16 == 0 && (((uintptr_t)p->grid_i8 & 15) == 0);
+    const bool fused = fused_path(p, grid), z1 = z1_path(p, grid);  // (GENNBV_FUSED_BWD=0: A/B runs, bit-equality tests; GENNBV_Z1=1: opt-in)
     GNBV_CHECK_ARG(p->autocorr == nullptr || (p->autocorr_row_stride >= kAcRow && p->autocorr_row_stride % 4 == 0 && ((uintptr_t)p->autocorr & 15) == 0));
     // the input autocorrelation: per-sample rows computed when the observation was produced (p->autocorr), or
     // the minibatch total computed here
     int *Rac = (int *)(w.red + 1024);  // [kAcRow]
-    if (fused && p->autocorr == nullptr) {
-        if (hipMemsetAsync(Rac, 0, kAcRow * sizeof(int), st) != hipSuccess) return (int)hipGetLastError();
-        const int P = autocorr_planes(grid);
-        hipLaunchKernelGGL(k_input_autocorr, dim3(sample_plane_group_grid(batch, O1, P)), dim3(kAcThreads), (size_t)(2 * P + 1) * grid * grid, st,
-                           p->grid_i8, rows, p->grid_i8_row_stride, batch, grid, O1, P, Rac, (int64_t)0);
-        if ((err = gnbv_launch_status())) return err;
-    }
+    if (fused && p->autocorr == nullptr && (err = launch_autocorr_total(p, rows, batch, grid, Rac, st))) return err;
     // ---- BN2 + ReLU backward ----
     hipLaunchKernelGGL(k_bn2_bwd_reduce, dim3(batch * kC), dim3(256), 0, st, d_features, y2, bn2, bn2 + kC, bn2 + 2 * kC,
                        bn2 + 3 * kC, P2, w.bn_part);
@@ -1730,6 +1848,9 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     if (p->act_bf16) {
         hipLaunchKernelGGL(k_conv2_wgrad<ActBF16>, dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const uint16_t *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
                        w.wg_part);
+    } else if (z1) {
+        hipLaunchKernelGGL((k_conv2_wgrad<ActF32, true>), dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
+                       w.wg_part);
     } else {
         hipLaunchKernelGGL(k_conv2_wgrad<ActF32>, dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
                        w.wg_part);
@@ -1750,14 +1871,19 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     if (side.enabled) hipLaunchKernelGGL(k_prep_w2, dim3(kTaps), dim3(256), 0, st, p->w2, w.w2img, w.w2img + kTaps * 256);
     const int gd = sample_plane_group_grid(batch, (O1 + 1) / 2, kPlanesPerGroup);  // groups of plane PAIRS
     if (fused) {
-        hipLaunchKernelGGL(k_conv2_dgrad_c1w, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const float *)y1, bn1,
-                           bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->grid_i8, rows, p->grid_i8_row_stride, batch, grid, O1, O2, wg1_part);
+        if (z1)
+            hipLaunchKernelGGL(k_conv2_dgrad_c1w<true>, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const float *)y1, bn1,
+                               bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->grid_i8, rows, p->grid_i8_row_stride, batch, grid, O1, O2, wg1_part);
+        else
+            hipLaunchKernelGGL(k_conv2_dgrad_c1w<false>, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const float *)y1, bn1,
+                               bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->grid_i8, rows, p->grid_i8_row_stride, batch, grid, O1, O2, wg1_part);
         if ((err = gnbv_launch_status())) return err;
         const int slf = reduce_stage1(wg1_part, gd, kE1F, tmp1, st);
         if ((err = gnbv_launch_status())) return err;
         hipLaunchKernelGGL(k_c1w_fused_finish, dim3(1), dim3(1024), 0, st, (const double *)tmp1, slf,
                            p->autocorr ? (const int *)p->autocorr : (const int *)Rac, p->autocorr_row_stride, rows, p->autocorr ? batch : 0,
-                           p->w1, bn1, bn1 + 3 * kC, g->w1, g->b1, (const double *)S2, g->bn1_w, g->bn1_b, g->bn2_w, g->bn2_b);
+                           p->w1, bn1, bn1 + 3 * kC, z1 ? p->bn1_w : (const float *)nullptr, p->bn1_b, g->w1, g->b1, (const double *)S2, g->bn1_w,
+                           g->bn1_b, g->bn2_w, g->bn2_b);
         if ((err = gnbv_launch_status())) return err;
         if (side.enabled && hipStreamWaitEvent(st, side.join, 0) != hipSuccess) return (int)hipGetLastError();  // join
         return gnbv_launch_status();

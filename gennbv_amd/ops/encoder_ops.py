@@ -154,7 +154,7 @@ class _GridEncoderFn(torch.autograd.Function):
         bn_state = torch.empty(2 * 4 * 16, dtype=torch.float32, device=dev)
         feats = torch.empty(batch, 16 * p2, dtype=torch.float32, device=dev)
         ws = _workspace(lib, batch, grid, dev)
-        params = _params_struct(seq, act_bf16, grid_i8)
+        params = _params_struct(seq, act_bf16, grid_i8, autocorr)
         # compact observations: `base` has no grid slice, the kernels read the int8 rows only (obs pointer NULL)
         assert not compact or grid_i8 is not None
         obs_ptr = None if compact else base.data_ptr() + 4 * grid_off

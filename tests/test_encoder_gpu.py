@@ -71,11 +71,15 @@ def test_encoder_forward_backward_vs_torch_reference(g, b):
     assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("z1", ["0", "1"])
 @pytest.mark.parametrize("g,b", [(16, 5), (32, 3), (48, 2), (64, 4), (128, 1)])
-def test_fused_dgrad_conv1_wgrad_vs_fp64_reference(g, b):
+def test_fused_dgrad_conv1_wgrad_vs_fp64_reference(g, b, z1, monkeypatch):
     """With the int8 grid rows present (G % 16 == 0) the backward runs k_conv2_dgrad_c1w: conv2 data gradient and conv1
     weight gradient in one launch, BN1 backward applied to fp64 sums afterwards (dz1' is never stored).  All conv / BN
-    gradients against the fp64 torch reference, tolerance = fp32 round-off; rows are gathered (RowGather)."""
+    gradients against the fp64 torch reference, tolerance = fp32 round-off; rows are gathered (RowGather).
+    z1 = "1" (opt-in GENNBV_Z1): BN1 batch statistics analytically from the input autocorrelation, conv1 stores
+    relu(bn1(y1)) (G <= 64; G = 128 keeps the y1 layout)."""
+    monkeypatch.setenv("GENNBV_Z1", z1)
     from gennbv_amd.ops.encoder_ops import RowGather, input_autocorr
     hip, _, _ = pu.make_policy(g=g, device=DEV, backend="hip", det_weights=True)
     ref, _, _ = pu.make_policy(g=g, device="cpu", backend="torch", det_weights=True)
@@ -110,6 +114,22 @@ def test_fused_dgrad_conv1_wgrad_vs_fp64_reference(g, b):
             assert err < 1e-4, (n1, err)
         else:
             assert err <= 2e-5 * scale, (n1, err, scale)
+    # BatchNorm running statistics (z1 mode, G <= 64: analytic batch statistics from the input autocorrelation; three training
+    # forwards on the GPU side, so compare after bringing the reference to the same count) and the eval-mode forward
+    # (conv1 with the BN + ReLU epilogue on the running statistics)
+    for _ in range(2):
+        ref.features_extractor(base[rows].cpu().double())
+    for (k1, v1), (k2, v2) in zip(ref.state_dict().items(), hip.state_dict().items()):
+        if "running" in k1:
+            torch.testing.assert_close(v2.double().cpu(), v1.double(), rtol=2e-5, atol=1e-6)
+        if "num_batches" in k1:
+            assert int(v1) == int(v2) == 3
+    ref.eval()
+    hip.eval()
+    with torch.no_grad():
+        a = hip.features_extractor(RowGather(base, rows, grid_i8)).double().cpu()
+        r = ref.features_extractor(base[rows].cpu().double())
+    assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-6
 
 
 @pytest.mark.parametrize("g,n", [(16, 3), (32, 2), (48, 2), (64, 3), (128, 1)])
