@@ -346,14 +346,17 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
 
 // W2 [co][ci][27] -> the two LDS images the conv2 kernels use, written once per call so that the
 // workgroups fill their LDS with coalesced 16-byte loads instead of 6912 scattered 4-byte reads:
-//   fwd  image [(tap*4+s)*4+kq][n] = W2[co = n][ci = 4kq+s][tap]
-//   dgrad image [(tap*4+s)*4+kq][n] = W2[co = 4kq+s][ci = n][tap]
+//   fwd  image [tap][lane = 16kq + n][s] = W2[co = n][ci = 4kq+s][tap]
+//   dgrad image [tap][lane = 16kq + n][s] = W2[co = 4kq+s][ci = n][tap]
+// i.e. the four k-steps (s) of a tap are ONE 16-byte LDS read per lane (ds_read_b128), which the kernels issue one tap
+// ahead of the MFMAs that use it (w2_tap below).
 __device__ __forceinline__ void prep_w2_element(int i, const float *__restrict__ W2, float *__restrict__ img_fwd, float *__restrict__ img_dgrad)
 {
-    const int n = i & 15, kq = (i >> 4) & 3, s = (i >> 6) & 3, tap = i >> 8;
+    const int s = i & 3, n = (i >> 2) & 15, kq = (i >> 6) & 3, tap = i >> 8;
     img_fwd[i] = W2[((size_t)n * kC + 4 * kq + s) * kTaps + tap];
     img_dgrad[i] = W2[((size_t)(4 * kq + s) * kC + n) * kTaps + tap];
 }
+__device__ __forceinline__ float4 w2_tap(const float *img_lds, int tap, int lane) { return reinterpret_cast<const float4 *>(img_lds)[tap * kWave + lane]; }
 
 __global__ void k_prep_w2(const float *__restrict__ W2, float *__restrict__ img_fwd, float *__restrict__ img_dgrad)
 {
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
     const float *__restrict__ W2img /*k_prep_w2 fwd image*/, const float *__restrict__ b2, float *__restrict__ y2,
     float *__restrict__ partials)
 {
-    __shared__ __attribute__((aligned(16))) float w2s[kTaps * 4 * 4 * kC];  // [(tap*4+s)*4+kq][n] = W2[n][4kq+s][tap]
+    __shared__ __attribute__((aligned(16))) float w2s[kTaps * 4 * 4 * kC];  // [tap][lane = 16kq + n][s] = W2[n][4kq+s][tap]
     fill_lds_image(w2s, W2img);
     int b, oz0, oz1;
     const bool live = sample_plane_group(B, O2, kPlanesPerGroup, b, oz0, oz1);
@@ -428,15 +431,22 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
         }
     };
     auto consume = [&](int dz, const float4 (&v)[9], f32x4 &acc) {
+        // weights: one 16-byte LDS read per tap, issued ONE TAP AHEAD of its MFMAs and pinned there (left alone the
+        // compiler puts every LDS read right in front of its use: ds_read, s_waitcnt lgkmcnt(0), 2 MFMAs -- the LDS
+        // latency exposed 54 times per tile)
+        float4 wq = w2_tap(w2s, dz * 9, lane);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
+            const float4 wn = w2_tap(w2s, dz * 9 + (t < 8 ? t + 1 : t), lane);
+            __builtin_amdgcn_sched_barrier(0);
             const float z0 = Z1 ? v[t].x : fmaxf(fmaf(sc[0], v[t].x, sh[0]), 0.f), z1 = Z1 ? v[t].y : fmaxf(fmaf(sc[1], v[t].y, sh[1]), 0.f);
             const float z2 = Z1 ? v[t].z : fmaxf(fmaf(sc[2], v[t].z, sh[2]), 0.f), z3 = Z1 ? v[t].w : fmaxf(fmaf(sc[3], v[t].w, sh[3]), 0.f);
-            const float *wb = w2s + (dz * 9 + t) * 256 + lane;  // + s*64
-            acc = mfma4(z0, wb[0], acc);
-            acc = mfma4(z1, wb[64], acc);
-            acc = mfma4(z2, wb[128], acc);
-            acc = mfma4(z3, wb[192], acc);
+            acc = mfma4(z0, wq.x, acc);
+            acc = mfma4(z1, wq.y, acc);
+            acc = mfma4(z2, wq.z, acc);
+            acc = mfma4(z3, wq.w, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            wq = wn;
         }
     };
     auto finish = [&](int wk, const f32x4 &acc) {
@@ -825,11 +835,11 @@ __device__ __forceinline__ void dgrad_subtile(
             for (int xo = 0; xo < (EX ? 1 : 2); ++xo) {
                 const int dz = EZ ? 1 : 2 * zo, dy = EY ? 1 : 2 * yo, dx = EX ? 1 : 2 * xo;
                 const float4 &t = L[(zo * 2 + yo) * 2 + xo];
-                const float *wb = w2d + ((dz * 3 + dy) * 3 + dx) * 256 + lane;  // [(tap*4+s)*4+kq][ci = m]
-                acc = mfma4(wb[0], t.x, acc);
-                acc = mfma4(wb[64], t.y, acc);
-                acc = mfma4(wb[128], t.z, acc);
-                acc = mfma4(wb[192], t.w, acc);
+                const float4 wq = w2_tap(w2d, (dz * 3 + dy) * 3 + dx, lane);  // [tap][lane (kq, ci = m)][s]
+                acc = mfma4(wq.x, t.x, acc);
+                acc = mfma4(wq.y, t.y, acc);
+                acc = mfma4(wq.z, t.z, acc);
+                acc = mfma4(wq.w, t.w, acc);
             }
     if (lane_ok) {
         float4 g;
@@ -856,7 +866,7 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad(
     const float *__restrict__ shift1, const float *__restrict__ mean1, const float *__restrict__ rstd1, int B, int O1, int O2,
     typename A::T *__restrict__ dz1p, float *__restrict__ partials)
 {
-    __shared__ __attribute__((aligned(16))) float w2d[kTaps * 4 * 4 * kC];  // [(tap*4+s)*4+kq][n] = W2[co = 4kq+s][ci = n][tap]
+    __shared__ __attribute__((aligned(16))) float w2d[kTaps * 4 * 4 * kC];  // [tap][lane = 16kq + n][s] = W2[co = 4kq+s][ci = n][tap]
     fill_lds_image(w2d, W2 /* k_prep_w2 dgrad image */);
     const int NA = (O1 + 1) >> 1;  // plane pairs / row pairs / voxels per x-parity
     int b, a0, a1;
@@ -955,11 +965,11 @@ __device__ __forceinline__ void dgrad_c1w_subtile(
             for (int xo = 0; xo < (EX ? 1 : 2); ++xo) {
                 const int dz = EZ ? 1 : 2 * zo, dy = EY ? 1 : 2 * yo, dx = EX ? 1 : 2 * xo;
                 const float4 &t = L[(zo * 2 + yo) * 2 + xo];
-                const float *wb = w2d + ((dz * 3 + dy) * 3 + dx) * 256 + lane;  // [(tap*4+s)*4+kq][ci = m]
-                acc = mfma4(t.x, wb[0], acc);  // A[i = voxel][k = co], B[k = co][j = ci]
-                acc = mfma4(t.y, wb[64], acc);
-                acc = mfma4(t.z, wb[128], acc);
-                acc = mfma4(t.w, wb[192], acc);
+                const float4 wq = w2_tap(w2d, (dz * 3 + dy) * 3 + dx, lane);  // [tap][lane (kq, ci = m)][s]
+                acc = mfma4(t.x, wq.x, acc);  // A[i = voxel][k = co], B[k = co][j = ci]
+                acc = mfma4(t.y, wq.y, acc);
+                acc = mfma4(t.z, wq.z, acc);
+                acc = mfma4(t.w, wq.w, acc);
             }
     constexpr int kOff = ((2 * EZ) * 5 + 2 * EY) * kSlabRow + 2 * EX;
 #pragma unroll
