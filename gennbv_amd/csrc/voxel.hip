@@ -191,19 +191,26 @@ __device__ __forceinline__ float voxel_axis_fast(float p, float vmin, float v, f
     return fl;
 }
 
-template <bool KFAST>
+// WIN: the env's bitmask does not fit the 160 KiB of LDS a workgroup may use (G > 104): `windows` workgroups per
+// (env, chunk), each keeps the mask words [win * nw, win * nw + nw) in LDS and drops the bits outside (every
+// workgroup still evaluates all pixels of the chunk: 2x the arithmetic at G = 128, but no device-scope atomic per pixel).
+template <bool KFAST, bool WIN = false>
 __global__ __launch_bounds__(kHitThreads) void k_hit_mask(
     const float *__restrict__ depth_raw, const float *__restrict__ seg_raw, const float *__restrict__ c2w,
     Intrinsics K, const float *__restrict__ range_gt, const float *__restrict__ voxel_size,
-    int n, int h, int w, int g, float sense_dist, int chunks, int words, uint32_t *__restrict__ hit_mask)
+    int n, int h, int w, int g, float sense_dist, int chunks, int words, uint32_t *__restrict__ hit_mask, int windows, int nw)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mask[];
-    // XCD-aware block -> (env, chunk): all chunks of env e run on XCD e % 8
+    // XCD-aware block -> (env, chunk[, window]): all workgroups of env e run on XCD e % 8
     const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
-    const int e = (slot / chunks) * 8 + xcd;
-    const int c = slot % chunks;
+    const int per_env = chunks * (WIN ? windows : 1);
+    const int e = (slot / per_env) * 8 + xcd;
+    const int c = (slot % per_env) % chunks;
+    const int w0 = WIN ? ((slot % per_env) / chunks) * nw : 0;
     if (e >= n) return;
-    for (int i = threadIdx.x; i < words; i += kHitThreads) s_mask[i] = 0u;
+    if (WIN) nw = min(nw, words - w0);
+    else nw = words;
+    for (int i = threadIdx.x; i < nw; i += kHitThreads) s_mask[i] = 0u;
 
     float M[12];
 #pragma unroll
@@ -257,7 +264,12 @@ __global__ __launch_bounds__(kHitThreads) void k_hit_mask(
         const int iy = (int)__builtin_fminf(__builtin_fmaxf(voxel_axis_fast(wp[1], hf.vmin[1], hf.vox[1], hf.inv_vox[1]), 0.0f), hf.gmax);
         const int iz = (int)__builtin_fminf(__builtin_fmaxf(voxel_axis_fast(wp[2], hf.vmin[2], hf.vox[2], hf.inv_vox[2]), 0.0f), hf.gmax);
         const int lin = ix * gg + iy * g + iz;
-        atomicOr(&s_mask[lin >> 5], 1u << (lin & 31));
+        if (WIN) {
+            const unsigned wi = (unsigned)((lin >> 5) - w0);
+            if (wi < (unsigned)nw) atomicOr(&s_mask[wi], 1u << (lin & 31));
+        } else {
+            atomicOr(&s_mask[lin >> 5], 1u << (lin & 31));
+        }
     };
 
     if ((w & 3) == 0 && hw < (1 << 23)) {
@@ -278,14 +290,14 @@ __global__ __launch_bounds__(kHitThreads) void k_hit_mask(
         }
     }
     __syncthreads();
-    uint32_t *gm = hit_mask + (size_t)e * words;
-    for (int i = threadIdx.x; i < words; i += kHitThreads) {
+    uint32_t *gm = hit_mask + (size_t)e * words + w0;
+    for (int i = threadIdx.x; i < nw; i += kHitThreads) {
         const uint32_t v = s_mask[i];
         if (v) atomicOr(&gm[i], v);
     }
 }
 
-// fallback for grids whose bitmask does not fit LDS (G > 96): straight to L2 atomics
+// device-scope-atomic variant (GENNBV_MASK_LDS=0, A/B runs): straight to L2 atomics
 __global__ __launch_bounds__(kHitThreads) void k_hit_mask_global(
     const float *__restrict__ depth_raw, const float *__restrict__ seg_raw, const float *__restrict__ c2w,
     Intrinsics K, const float *__restrict__ range_gt, const float *__restrict__ voxel_size,
@@ -353,8 +365,9 @@ constexpr int kRayWordsPerLane = 8;
 constexpr int kRayChunkWords = kRayThreads * kRayWordsPerLane;
 constexpr int kQueueCap = 4096;  // targets per round (16 KiB of LDS)
 
-template <bool LDS_PATH>
-__device__ __forceinline__ void trace_ray_lane(const int (&src)[3], int lin_t, int g, int gg, uint32_t *s_path, uint32_t *pm)
+template <bool LDS_PATH, bool WIN = false>
+__device__ __forceinline__ void trace_ray_lane(const int (&src)[3], int lin_t, int g, int gg, uint32_t *s_path, uint32_t *pm, int w0 = 0,
+                                               int nw = 0)
 {
     const unsigned ug = (unsigned)g;
     int tgt[3];
@@ -378,8 +391,14 @@ __device__ __forceinline__ void trace_ray_lane(const int (&src)[3], int lin_t, i
     const int la = sa * st_a, lb = sb * st_b, lc = sc * st_c;
     for (int i = 0; i <= da; ++i) {
         if ((unsigned)pa < ug && (unsigned)pb < ug && (unsigned)pc < ug) {
-            if (LDS_PATH) atomicOr(&s_path[l >> 5], 1u << (l & 31));
-            else atomicOr(&pm[l >> 5], 1u << (l & 31));
+            if (LDS_PATH && WIN) {
+                const unsigned wi = (unsigned)((l >> 5) - w0);
+                if (wi < (unsigned)nw) atomicOr(&s_path[wi], 1u << (l & 31));
+            } else if (LDS_PATH) {
+                atomicOr(&s_path[l >> 5], 1u << (l & 31));
+            } else {
+                atomicOr(&pm[l >> 5], 1u << (l & 31));
+            }
         }
         const bool ib = p1 >= 0, ic = p2 >= 0;
         pb += ib ? sb : 0; l += ib ? lb : 0; p1 -= ib ? 2 * da : 0;
@@ -389,11 +408,13 @@ __device__ __forceinline__ void trace_ray_lane(const int (&src)[3], int lin_t, i
     }
 }
 
-template <bool LDS_PATH>
+// WIN (LDS_PATH only): the path mask does not fit LDS either -- `windows` workgroups per (env, split) trace the same
+// rays and each keeps the words [win * nw, ...) of the path mask (see k_hit_mask).
+template <bool LDS_PATH, bool WIN = false>
 __global__ __launch_bounds__(kRayThreads) void k_raycast(
     const uint32_t *__restrict__ hit_mask, const float *__restrict__ poses_xyz, int64_t pose_stride,
     const float *__restrict__ range_gt, const float *__restrict__ voxel_size, int n, int g, int words, int splits,
-    uint32_t *__restrict__ path_mask)
+    uint32_t *__restrict__ path_mask, int windows, int nw)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *s_queue = smem;                      // kQueueCap
@@ -401,13 +422,16 @@ __global__ __launch_bounds__(kRayThreads) void k_raycast(
     uint32_t *s_path = smem + kQueueCap + 32;      // words (LDS_PATH only)
     // block -> (env, split); all splits of env e sit on XCD e % 8 like k_hit_mask's chunks
     const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
-    const int e = (slot / splits) * 8 + xcd;
-    const int sp = slot % splits;
+    const int per_env = splits * (WIN ? windows : 1);
+    const int e = (slot / per_env) * 8 + xcd;
+    const int sp = (slot % per_env) % splits;
+    const int w0 = WIN ? ((slot % per_env) / splits) * nw : 0;
     if (e >= n) return;
+    nw = WIN ? min(nw, words - w0) : words;
     const uint32_t *hm = hit_mask + (size_t)e * words;
     uint32_t *pm = path_mask + (size_t)e * words;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
-    if (LDS_PATH) for (int i = tid; i < words; i += kRayThreads) s_path[i] = 0u;
+    if (LDS_PATH) for (int i = tid; i < nw; i += kRayThreads) s_path[i] = 0u;
 
     // source voxel (pose_coord_to_idx_3D, no clamp)
     const float *pp = poses_xyz + (size_t)e * pose_stride;
@@ -469,7 +493,7 @@ __global__ __launch_bounds__(kRayThreads) void k_raycast(
 #endif
 #if RAY_VARIANT != 1
             for (int q = tid; q < nq; q += kRayThreads)
-                trace_ray_lane<LDS_PATH>(src, (int)s_queue[q], g, gg, s_path, pm);
+                trace_ray_lane<LDS_PATH, WIN>(src, (int)s_queue[q], g, gg, s_path, pm, w0, nw);
 #else
             (void)nq;
 #endif
@@ -479,11 +503,11 @@ __global__ __launch_bounds__(kRayThreads) void k_raycast(
     if (LDS_PATH) {
         __syncthreads();
         if (splits == 1) {
-            for (int i = tid; i < words; i += kRayThreads) pm[i] = s_path[i];
+            for (int i = tid; i < nw; i += kRayThreads) pm[w0 + i] = s_path[i];
         } else {
-            for (int i = tid; i < words; i += kRayThreads) {
+            for (int i = tid; i < nw; i += kRayThreads) {
                 const uint32_t v = s_path[i];
-                if (v) atomicOr(&pm[i], v);
+                if (v) atomicOr(&pm[w0 + i], v);
             }
         }
     }
@@ -1014,8 +1038,15 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
     if (err) return err;
     const int words = ws.words;
     const size_t mask_bytes = (size_t)words * sizeof(uint32_t);
-    const bool lds_hit = mask_bytes <= 64 * 1024;
-    const bool lds_path = mask_bytes + (kQueueCap + 32) * sizeof(uint32_t) <= 64 * 1024;
+    // LDS staging of the masks: a gfx950 workgroup may use all 160 KiB.  Larger masks (G > 104) are split into windows
+    // of <= 128 KiB, one workgroup per window (GENNBV_MASK_LDS=0: the old device-scope-atomic fallbacks, for A/B runs).
+    static const bool lds_off = [] { const char *v = getenv("GENNBV_MASK_LDS"); return v && v[0] == '0'; }();
+    const size_t kLdsMax = 160 * 1024, ray_fixed = (kQueueCap + 32) * sizeof(uint32_t);
+    const bool lds_hit = !lds_off, lds_path = !lds_off;
+    const int hit_windows = mask_bytes <= kLdsMax ? 1 : (int)((mask_bytes + 128 * 1024 - 1) / (128 * 1024));
+    const int path_windows = mask_bytes + ray_fixed <= kLdsMax ? 1 : (int)((mask_bytes + 128 * 1024 - 1) / (128 * 1024));
+    const int hit_nw = (words + hit_windows - 1) / hit_windows, path_nw = (words + path_windows - 1) / path_windows;
+    const size_t hit_lds = (size_t)hit_nw * sizeof(uint32_t), path_lds = ray_fixed + (size_t)path_nw * sizeof(uint32_t);
     // ray-cast workgroups per env: ~4 per CU in total, so that an env with many hit voxels
     // (measured 4x the mean) is spread over several CUs (profiles/r01_notes.md)
     int splits = (1024 + n - 1) / n;
@@ -1026,7 +1057,7 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
     }
     // zero the hit masks (OR-accumulated by atomics); the path masks only when they are
     // OR-accumulated too (several splits, or no LDS staging)
-    const bool path_needs_zero = !lds_path || splits > 1;
+    const bool path_needs_zero = !lds_path || splits > 1;  // (windows write disjoint word ranges)
     err = (int)hipMemsetAsync(ws.hit, 0, (size_t)n * mask_bytes, st);
     if (err) return err;
     if (path_needs_zero) {
@@ -1039,31 +1070,49 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
     const int env_groups = (n + 7) / 8;
     int chunks = (8 * 256 + n - 1) / n;
     chunks = chunks < 1 ? 1 : (chunks > 16 ? 16 : chunks);
-    const int hit_grid = env_groups * 8 * chunks;
+    const int hit_grid = env_groups * 8 * chunks * (lds_hit ? hit_windows : 1);
     // inv_intri of a pinhole camera is [[a,0,c],[0,b,d],[0,0,1]]: lets the kernel drop exact-zero terms
     const bool kfast = K.k[1] == 0.0f && K.k[3] == 0.0f && K.k[6] == 0.0f && K.k[7] == 0.0f && K.k[8] == 1.0f;
-    if (lds_hit && kfast) {
-        hipLaunchKernelGGL(k_hit_mask<true>, dim3(hit_grid), dim3(kHitThreads), mask_bytes, st, depth_raw, seg_raw, c2w, K,
-                           range_gt, voxel_size, n, h, w, g, depth_sense_dist, chunks, words, ws.hit);
-    } else if (lds_hit) {
-        hipLaunchKernelGGL(k_hit_mask<false>, dim3(hit_grid), dim3(kHitThreads), mask_bytes, st, depth_raw, seg_raw, c2w, K,
-                           range_gt, voxel_size, n, h, w, g, depth_sense_dist, chunks, words, ws.hit);
-    } else {
+#define GNBV_HIT(KF, WIN)                                                                                                            \
+    do {                                                                                                                             \
+        if (hit_lds > 64 * 1024 &&                                                                                                   \
+            hipFuncSetAttribute((const void *)k_hit_mask<KF, WIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hit_lds) != hipSuccess) \
+            return (int)hipGetLastError();                                                                                           \
+        hipLaunchKernelGGL((k_hit_mask<KF, WIN>), dim3(hit_grid), dim3(kHitThreads), hit_lds, st, depth_raw, seg_raw, c2w, K, range_gt, \
+                           voxel_size, n, h, w, g, depth_sense_dist, chunks, words, ws.hit, hit_windows, hit_nw);                    \
+    } while (0)
+    if (!lds_hit) {
         hipLaunchKernelGGL(k_hit_mask_global, dim3(hit_grid), dim3(kHitThreads), 0, st, depth_raw, seg_raw, c2w, K,
                            range_gt, voxel_size, n, h, w, g, depth_sense_dist, chunks, words, ws.hit);
+    } else if (hit_windows > 1) {
+        if (kfast) GNBV_HIT(true, true);
+        else GNBV_HIT(false, true);
+    } else {
+        if (kfast) GNBV_HIT(true, false);
+        else GNBV_HIT(false, false);
     }
+#undef GNBV_HIT
     err = gnbv_launch_status();
     if (err) return err;
-    // launch 2: ray cast, N x splits workgroups
-    const int ray_grid = env_groups * 8 * splits;
-    const size_t ray_lds = (kQueueCap + 32) * sizeof(uint32_t);
-    if (lds_path) {
-        hipLaunchKernelGGL(k_raycast<true>, dim3(ray_grid), dim3(kRayThreads), ray_lds + mask_bytes, st, ws.hit, poses_xyz,
-                           poses_row_stride, range_gt, voxel_size, n, g, words, splits, ws.path);
+    // launch 2: ray cast, N x splits (x windows) workgroups
+    const int ray_grid = env_groups * 8 * splits * (lds_path ? path_windows : 1);
+#define GNBV_RAY(WIN)                                                                                                                \
+    do {                                                                                                                             \
+        if (path_lds > 64 * 1024 &&                                                                                                  \
+            hipFuncSetAttribute((const void *)k_raycast<true, WIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)path_lds) != hipSuccess) \
+            return (int)hipGetLastError();                                                                                           \
+        hipLaunchKernelGGL((k_raycast<true, WIN>), dim3(ray_grid), dim3(kRayThreads), path_lds, st, ws.hit, poses_xyz, poses_row_stride, \
+                           range_gt, voxel_size, n, g, words, splits, ws.path, path_windows, path_nw);                               \
+    } while (0)
+    if (!lds_path) {
+        hipLaunchKernelGGL((k_raycast<false, false>), dim3(ray_grid), dim3(kRayThreads), ray_fixed, st, ws.hit, poses_xyz,
+                           poses_row_stride, range_gt, voxel_size, n, g, words, splits, ws.path, 1, words);
+    } else if (path_windows > 1) {
+        GNBV_RAY(true);
     } else {
-        hipLaunchKernelGGL(k_raycast<false>, dim3(ray_grid), dim3(kRayThreads), ray_lds, st, ws.hit, poses_xyz,
-                           poses_row_stride, range_gt, voxel_size, n, g, words, splits, ws.path);
+        GNBV_RAY(false);
     }
+#undef GNBV_RAY
     return gnbv_launch_status();
 }
 

@@ -106,8 +106,9 @@ def _run_sequence(n, h, w, g, steps, seed, reset_at=(), pose_override=None, pack
 
 
 @pytest.mark.parametrize("n,h,w,g,steps", [(4, 240, 320, 16, 6), (3, 100, 100, 20, 5), (9, 120, 160, 64, 4),
-                                           (2, 30, 37, 33, 3), (2, 60, 80, 128, 2)])
+                                           (2, 30, 37, 33, 3), (2, 60, 80, 96, 2), (2, 60, 80, 128, 2), (9, 48, 64, 128, 2)])
 def test_fused_update_bit_exact_vs_oracle(n, h, w, g, steps):
+    # (G = 96: 110 KiB LDS masks; G = 128: two 128 KiB windows per env; n = 9: more than one XCD group)
     _run_sequence(n, h, w, g, steps, seed=11 + g, reset_at=(2,))
 
 
