@@ -239,7 +239,9 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd(
 // IN = float: the grid slice of the fp32 observation rows; IN = int8_t: the compact side copy of the tri-class
 // grid the state-encoding kernel writes next to it (values -1/0/1: the conversion is exact, the slab is
 // fetched with a quarter of the bytes and widened while it is written to LDS).
-template <typename A, typename IN>
+// LDS8 (int8 input only): the slab stays int8 in LDS (a quarter of the bytes: G = 128 fits, 48 KiB) and is widened
+// when the MFMA operand is read; no faster than the fp32 slab where that fits (measured at G = 64), so only used beyond.
+template <typename A, typename IN, bool LDS8 = false>
 __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
     const IN *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, int B, int G, int O1,
     const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ b1, typename A::T *__restrict__ y1,
@@ -285,7 +287,9 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int idx = base + u * kEncThreads + (int)threadIdx.x;
-                    if (idx < total16) {
+                    if (LDS8) {
+                        if (idx < total16) reinterpret_cast<uint4 *>(s_in)[idx] = v[u];
+                    } else if (idx < total16) {
                         const uint32_t wd[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
@@ -317,10 +321,16 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
         for (int oy = wv; oy < O1; oy += kEncWaves) {
             for (int ox0 = 0; ox0 < O1; ox0 += 16) {
                 const int ox = min(ox0 + m, O1 - 1);
-                const float *p = s_in + 2 * oy * G + 2 * ox;
                 float v[7];
+                if (LDS8) {
+                    const int8_t *p = reinterpret_cast<const int8_t *>(s_in) + 2 * oy * G + 2 * ox;
 #pragma unroll
-                for (int s = 0; s < 7; ++s) v[s] = p[off[s]];
+                    for (int s = 0; s < 7; ++s) v[s] = (float)p[off[s]];
+                } else {
+                    const float *p = s_in + 2 * oy * G + 2 * ox;
+#pragma unroll
+                    for (int s = 0; s < 7; ++s) v[s] = p[off[s]];
+                }
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 7; ++s) acc = mfma4(wf[s], v[s], acc);
@@ -1739,7 +1749,11 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
         else if (c1_staged)
             hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, float>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, obs_grid, rows,
                                row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr, nozs, nozs);
-        else if (obs_grid == nullptr)  // compact rows at a size the staged kernel does not take
+        else if (p->grid_i8 != nullptr && grid % 16 == 0 && p->grid_i8_row_stride % 16 == 0 && (((uintptr_t)p->grid_i8 & 15) == 0) &&
+                 c1_lds / 4 <= 64 * 1024 && 2 * O1 + 1 <= grid)  // int8 rows, fp32 slab too large (G = 128): int8 slab
+            hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, int8_t, true>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds / 4, st, p->grid_i8,
+                               rows, p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr, nozs, nozs);
+        else if (obs_grid == nullptr)  // compact rows at a size the staged kernels do not take
             hipLaunchKernelGGL((k_conv1_fwd<ActF32, int8_t>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, p->grid_i8, rows,
                                p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr);
         else
