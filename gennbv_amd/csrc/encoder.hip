@@ -152,6 +152,35 @@ __device__ __forceinline__ void write_partials_cl(float *partials, int nwaves, i
     }
 }
 
+// W2 [co][ci][27] -> the two LDS images the conv2 kernels use, written once per call so that the
+// workgroups fill their LDS with coalesced 16-byte loads instead of 6912 scattered 4-byte reads:
+//   fwd  image [tap][lane = 16kq + n][s] = W2[co = n][ci = 4kq+s][tap]
+//   dgrad image [tap][lane = 16kq + n][s] = W2[co = 4kq+s][ci = n][tap]
+// i.e. the four k-steps (s) of a tap are ONE 16-byte LDS read per lane (ds_read_b128), which the kernels issue one tap
+// ahead of the MFMAs that use it (w2_tap below).
+__device__ __forceinline__ void prep_w2_element(int i, const float *__restrict__ W2, float *__restrict__ img_fwd, float *__restrict__ img_dgrad)
+{
+    const int s = i & 3, n = (i >> 2) & 15, kq = (i >> 6) & 3, tap = i >> 8;
+    img_fwd[i] = W2[((size_t)n * kC + 4 * kq + s) * kTaps + tap];
+    img_dgrad[i] = W2[((size_t)(4 * kq + s) * kC + n) * kTaps + tap];
+}
+__device__ __forceinline__ float4 w2_tap(const float *img_lds, int tap, int lane) { return reinterpret_cast<const float4 *>(img_lds)[tap * kWave + lane]; }
+
+__global__ void k_prep_w2(const float *__restrict__ W2, float *__restrict__ img_fwd, float *__restrict__ img_dgrad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < kTaps * 256) prep_w2_element(i, W2, img_fwd, img_dgrad);
+}
+
+// (the images only depend on W2: the conv1 forward kernel, which runs before every conv2 forward, writes them in
+// passing -- a few hundred extra stores in an HBM-bound launch instead of a dependent 5 us launch)
+__device__ __forceinline__ void prep_w2_in_passing(const float *__restrict__ W2, float *__restrict__ w2img)
+{
+    if (W2 != nullptr)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kTaps * 256; i += gridDim.x * blockDim.x)
+            prep_w2_element(i, W2, w2img, w2img + kTaps * 256);
+}
+
 // ---------------------------------------------------------------------------
 // conv1 forward: in [B rows of the obs buffer, G^3 fp32] -> y1 [B,O1,O1,O1,16] (pre-BN, + bias)
 // workgroup = (sample b, output plane oz); wave = output rows oy; tile = 16 outputs along x
@@ -160,8 +189,9 @@ template <typename A, typename IN = float>
 __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd(
     const IN *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, int B, int G, int O1,
     const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ b1, typename A::T *__restrict__ y1,
-    float *__restrict__ partials)
+    float *__restrict__ partials, const float *__restrict__ W2 = nullptr, float *__restrict__ w2img = nullptr)
 {
+    prep_w2_in_passing(W2, w2img);
     int b, oz;
     const bool live = sample_plane(B, O1, b, oz);
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform -> SALU index math
@@ -246,8 +276,9 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
     const IN *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, int B, int G, int O1,
     const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ b1, typename A::T *__restrict__ y1,
     float *__restrict__ partials, const float *__restrict__ zscale /*NULL: store y1 (pre-BN); else z1 = relu(zscale*y1 + zshift)*/,
-    const float *__restrict__ zshift)
+    const float *__restrict__ zshift, const float *__restrict__ W2 = nullptr, float *__restrict__ w2img = nullptr)
 {
+    prep_w2_in_passing(W2, w2img);
     extern __shared__ __attribute__((aligned(16))) float s_in[];  // [3][NR][G]
     int b, oz;
     const bool live = sample_plane(B, O1, b, oz);
@@ -352,26 +383,6 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
         }
     }
     if (partials != nullptr) write_partials_cl(partials, kEncWaves, wv, s_sum, s_sq);
-}
-
-// W2 [co][ci][27] -> the two LDS images the conv2 kernels use, written once per call so that the
-// workgroups fill their LDS with coalesced 16-byte loads instead of 6912 scattered 4-byte reads:
-//   fwd  image [tap][lane = 16kq + n][s] = W2[co = n][ci = 4kq+s][tap]
-//   dgrad image [tap][lane = 16kq + n][s] = W2[co = 4kq+s][ci = n][tap]
-// i.e. the four k-steps (s) of a tap are ONE 16-byte LDS read per lane (ds_read_b128), which the kernels issue one tap
-// ahead of the MFMAs that use it (w2_tap below).
-__device__ __forceinline__ void prep_w2_element(int i, const float *__restrict__ W2, float *__restrict__ img_fwd, float *__restrict__ img_dgrad)
-{
-    const int s = i & 3, n = (i >> 2) & 15, kq = (i >> 6) & 3, tap = i >> 8;
-    img_fwd[i] = W2[((size_t)n * kC + 4 * kq + s) * kTaps + tap];
-    img_dgrad[i] = W2[((size_t)(4 * kq + s) * kC + n) * kTaps + tap];
-}
-__device__ __forceinline__ float4 w2_tap(const float *img_lds, int tap, int lane) { return reinterpret_cast<const float4 *>(img_lds)[tap * kWave + lane]; }
-
-__global__ void k_prep_w2(const float *__restrict__ W2, float *__restrict__ img_fwd, float *__restrict__ img_dgrad)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < kTaps * 256) prep_w2_element(i, W2, img_fwd, img_dgrad);
 }
 
 __device__ __forceinline__ void fill_lds_image(float *lds, const float *__restrict__ img)
@@ -687,21 +698,39 @@ __global__ __launch_bounds__(256) void k_bn2_bwd_finalize(const float *__restric
 }
 
 // pass 2: dy2 (channels-last [B,P2,16]) = scale*(dz' - S1/M - xhat*S2/M)
-__global__ void k_bn2_bwd_apply(const float *__restrict__ dz2, const float *__restrict__ y2, const float *__restrict__ scale,
-                                const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ rstd,
-                                const double *__restrict__ S, double count, int64_t total, int P2, float *__restrict__ dy2)
+// Workgroup = (sample b, tile of 64 positions): the 16 channel rows of y2 / dz2 (NCDHW) are read with coalesced
+// requests (a wave = 64 consecutive positions of one channel), transposed through LDS and written as contiguous
+// channels-last vectors.  (The first version read both inputs with a 16-way channel stride: 26 us for 83 MB.)
+__global__ __launch_bounds__(256) void k_bn2_bwd_apply(const float *__restrict__ dz2, const float *__restrict__ y2, const float *__restrict__ scale,
+                                                      const float *__restrict__ shift, const float *__restrict__ mean,
+                                                      const float *__restrict__ rstd, const double *__restrict__ S, double count, int P2,
+                                                      float *__restrict__ dy2)
 {
-    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(o & (kC - 1));
-        const int64_t bp = o >> 4;  // b*P2 + pos
-        const int64_t b = bp / P2, pos = bp - b * P2;
-        const size_t i = ((size_t)b * kC + c) * P2 + pos;
-        const float y = y2[i];
-        const float g = fmaf(scale[c], y, shift[c]) > 0.0f ? dz2[i] : 0.0f;
+    __shared__ float tile[64][kC + 1];
+    const int tiles = (P2 + 63) / 64, b = blockIdx.x / tiles, pos0 = (blockIdx.x - b * tiles) * 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int pos = min(pos0 + lane, P2 - 1);
+    float yv[4], gv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t i = ((size_t)b * kC + (wv + 4 * k)) * P2 + pos;
+        yv[k] = y2[i];
+        gv[k] = dz2[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = wv + 4 * k;
+        const float y = yv[k];
+        const float g = fmaf(scale[c], y, shift[c]) > 0.0f ? gv[k] : 0.0f;
         const float xhat = (y - mean[c]) * rstd[c];
         const float m1 = (float)(S[c] / count), m2 = (float)(S[kC + c] / count);
-        dy2[o] = scale[c] * (g - m1 - xhat * m2);
+        tile[lane][c] = scale[c] * (g - m1 - xhat * m2);
     }
+    __syncthreads();
+    const int p = threadIdx.x >> 2, c4 = (threadIdx.x & 3) * 4;
+    if (pos0 + p < P2)
+        *reinterpret_cast<float4 *>(dy2 + ((size_t)b * P2 + pos0 + p) * kC + c4) =
+            make_float4(tile[p][c4], tile[p][c4 + 1], tile[p][c4 + 2], tile[p][c4 + 3]);
 }
 
 // Weight-gradient kernels walk output rows (b, oz, oy).  Every wave owns a CONTIGUOUS range of rows
@@ -1731,13 +1760,13 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
         if ((err = gnbv_launch_status())) return err;
         hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, int8_t>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads),
                            (size_t)3 * (2 * O1 + 1) * grid * sizeof(float), st, p->grid_i8, rows, p->grid_i8_row_stride, batch, grid, O1, p->w1,
-                           p->b1, (float *)y1, (float *)nullptr, (const float *)bn1, (const float *)(bn1 + kC));
+                           p->b1, (float *)y1, (float *)nullptr, (const float *)bn1, (const float *)(bn1 + kC), p->w2, w.w2img);
         if ((err = gnbv_launch_status())) return err;
     } else {
     // conv1 (+ BN1 statistics)
     if (p->act_bf16) {
         hipLaunchKernelGGL(k_conv1_fwd<ActBF16>, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, batch, grid, O1, p->w1,
-                       p->b1, (uint16_t *)y1, training ? w.bn_part : nullptr);
+                       p->b1, (uint16_t *)y1, training ? w.bn_part : nullptr, p->w2, w.w2img);
     } else {
         const size_t c1_lds = (size_t)3 * (2 * O1 + 1) * grid * sizeof(float);
         const bool c1_staged = obs_grid != nullptr && (grid % 4 == 0) && (row_stride % 4 == 0) && (((uintptr_t)obs_grid & 15) == 0) && c1_lds <= 64 * 1024 &&
@@ -1745,20 +1774,20 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
         const float *nozs = nullptr;
         if (conv1_i8_staged(p, grid))  // compact int8 copy of the tri-class grid: a quarter of the input bytes
             hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, int8_t>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, p->grid_i8, rows,
-                               p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr, nozs, nozs);
+                               p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr, nozs, nozs, p->w2, w.w2img);
         else if (c1_staged)
             hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, float>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, obs_grid, rows,
-                               row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr, nozs, nozs);
+                               row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr, nozs, nozs, p->w2, w.w2img);
         else if (p->grid_i8 != nullptr && grid % 16 == 0 && p->grid_i8_row_stride % 16 == 0 && (((uintptr_t)p->grid_i8 & 15) == 0) &&
                  c1_lds / 4 <= 64 * 1024 && 2 * O1 + 1 <= grid)  // int8 rows, fp32 slab too large (G = 128): int8 slab
             hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, int8_t, true>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds / 4, st, p->grid_i8,
-                               rows, p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr, nozs, nozs);
+                               rows, p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr, nozs, nozs, p->w2, w.w2img);
         else if (obs_grid == nullptr)  // compact rows at a size the staged kernels do not take
             hipLaunchKernelGGL((k_conv1_fwd<ActF32, int8_t>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, p->grid_i8, rows,
-                               p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr);
+                               p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr, p->w2, w.w2img);
         else
             hipLaunchKernelGGL(k_conv1_fwd<ActF32>, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride,
-                               batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr);
+                               batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr, p->w2, w.w2img);
     }
     if ((err = gnbv_launch_status())) return err;
     if (training)
@@ -1770,9 +1799,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
                            p->bn1_rm, p->bn1_rv, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC);
     if ((err = gnbv_launch_status())) return err;
     }
-    // conv2 (BN1 + ReLU on load; + BN2 statistics).  (Folding the weight-image prep into the single-workgroup
-    // k_stats_reduce was measured: +8.5 us there vs 6.3 us for this launch -- kept separate.)
-    hipLaunchKernelGGL(k_prep_w2, dim3(kTaps), dim3(256), 0, st, p->w2, w.w2img, w.w2img + kTaps * 256);
+    // conv2 (BN1 + ReLU on load; + BN2 statistics).  Its LDS weight images were written by the conv1 kernel in passing.
     const int g2 = sample_plane_group_grid(batch, O2, kPlanesPerGroup);
     if (p->act_bf16) {
         hipLaunchKernelGGL(k_conv2_fwd<ActBF16>, dim3(g2), dim3(kBigThreads), 0, st, (const uint16_t *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
@@ -1853,11 +1880,8 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     double *S2 = w.red + 128;
     hipLaunchKernelGGL(k_bn2_bwd_finalize, dim3(1), dim3(256), 0, st, w.bn_part, batch, S2);
     if ((err = gnbv_launch_status())) return err;
-    const int64_t total2 = (int64_t)batch * P2 * kC;
-    int gx = (int)((total2 + 255) / 256);
-    gx = gx > 4096 ? 4096 : gx;
-    hipLaunchKernelGGL(k_bn2_bwd_apply, dim3(gx), dim3(256), 0, st, d_features, y2, bn2, bn2 + kC, bn2 + 2 * kC, bn2 + 3 * kC, S2,
-                       (double)batch * P2, total2, P2, dy2_scratch);
+    hipLaunchKernelGGL(k_bn2_bwd_apply, dim3(batch * ((P2 + 63) / 64)), dim3(256), 0, st, d_features, y2, bn2, bn2 + kC, bn2 + 2 * kC, bn2 + 3 * kC, S2,
+                       (double)batch * P2, P2, dy2_scratch);
     if ((err = gnbv_launch_status())) return err;
     // ---- conv2 weight gradient: on the side stream, beside the data gradient ----
     BwdSide &side = bwd_side();
