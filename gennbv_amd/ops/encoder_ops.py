@@ -237,10 +237,34 @@ class _LinearReluFn(torch.autograd.Function):
         dx = g @ w if ctx.needs_input_grad[0] else None
         mod = ctx.mod
         if mod is not None and mod.weight.grad is not None and mod.bias.grad is not None:
-            torch.mm(g.t(), x, out=mod.weight.grad)
-            torch.sum(g, 0, out=mod.bias.grad)
+            if getattr(mod, "_async_wgrad", False):
+                # Nothing downstream of this node needs dW / db (only the optimizer does): compute them on a second
+                # stream beside the rest of the backward; the owner of the flag joins before it reads the gradients
+                # (join_async_wgrads()).
+                cur = torch.cuda.current_stream(g.device)
+                side = _side_stream(g.device, 0)  # the pose branch's stream: a third stream makes the graph scheduler serialise branches
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    torch.mm(g.t(), x, out=mod.weight.grad)
+                    torch.sum(g, 0, out=mod.bias.grad)
+                g.record_stream(side)
+                x.record_stream(side)
+                _pending_wgrad.append(side.record_event())
+            else:
+                torch.mm(g.t(), x, out=mod.weight.grad)
+                torch.sum(g, 0, out=mod.bias.grad)
             return dx, None, None, None
         return dx, g.t() @ x, g.sum(0), None
+
+
+_pending_wgrad = []
+
+
+def join_async_wgrads(device) -> None:
+    """Make the current stream wait for weight gradients that were computed on the second stream (`_async_wgrad`)."""
+    cur = torch.cuda.current_stream(device)
+    while _pending_wgrad:
+        cur.wait_event(_pending_wgrad.pop())
 
 
 def linear_relu(x: torch.Tensor, lin: torch.nn.Linear) -> torch.Tensor:
@@ -378,8 +402,8 @@ def policy_head(enc, action_net, value_net, feature_action, feature_grid):
 _side_streams = {}
 
 
-def _side_stream(device):
-    key = str(device)
+def _side_stream(device, which: int = 0):
+    key = (str(device), which)
     if key not in _side_streams:
         _side_streams[key] = torch.cuda.Stream(device)
     return _side_streams[key]

@@ -331,6 +331,11 @@ class PPO_Grid_Obs:
         self._hip["fused_head"] = (os.environ.get("GENNBV_FUSED_HEAD", "1") != "0" and getattr(enc, "backend", "") == "hip"
                                    and isinstance(self.policy.mlp_extractor, _IdentityExtractor)
                                    and encoder_ops.policy_head_supported(enc, self.policy.action_net, self.policy.value_net))
+        # fc_grid's weight gradient on a second stream (only the optimizer needs it; joined in _hip_minibatch_body).  Only
+        # without data parallelism: there phase A ends right behind it and the all-reduce needs it at once.
+        if getattr(enc, "backend", "") == "hip":
+            enc.output_layer_grid[0]._async_wgrad = (bool(self.grad_write_through) and os.environ.get("GENNBV_ASYNC_WGRAD", "1") != "0"
+                                                     and (self._sync is None or not self._sync.active))
         self._hip["skip_zero"] = bool(self.grad_write_through) and all(
             id(p) in covered for p in self.policy.parameters() if p.requires_grad)
         return self._hip
@@ -365,12 +370,14 @@ class PPO_Grid_Obs:
                 opt.zero_grad()
             if phase == "all":
                 torch.autograd.backward([logits, values], [d_logits, d_values])
+                encoder_ops.join_async_wgrads(self.device)  # fc_grid's dW / db ran on a second stream beside the conv backward
                 if self._sync is None or not self._sync.active:
                     opt.step(self.max_grad_norm, loss.stop_flag)
                 return
             # the forward cut the graph at the conv-stack output (enc._split_backward): this backward
             # stops at that leaf and fills the gradients of every non-conv parameter
             torch.autograd.backward([logits, values], [d_logits, d_values])
+            encoder_ops.join_async_wgrads(self.device)
         else:  # phase "B": conv-stack backward from d loss / d (conv-stack output)
             enc = pol.features_extractor
             torch.autograd.backward([enc._grid_feats_out], [enc._grid_feats_leaf.grad])
