@@ -228,3 +228,39 @@ GNBV_API int gnbv_env_post_step(const GnbvEnvPost *args, void *stream)
     hipLaunchKernelGGL(k_env_post_step, dim3(1), dim3(kPostThreads), 0, gnbv_stream(stream), *args);
     return gnbv_launch_status();
 }
+
+// ---------------------------------------------------------------------------
+// One launch for the tail of a rollout step (on_policy_algorithm_grid_obs.py:205-211 + buffers.py:676-704): the
+// time-out bootstrap  rewards += gamma * squeeze(terminal_value * time_outs)  (same fp32 operation order: the product
+// with the 0/1 mask, times gamma, plus the reward, each rounded) and rollout_buffer.add()'s five copies (actions int64 ->
+// fp32, episode_starts bool -> u8) straight into row `step` of the buffer arrays.
+// ---------------------------------------------------------------------------
+__global__ void k_rollout_add(int n, int adim, const int64_t *__restrict__ actions, const float *__restrict__ rewards,
+                              const uint8_t *__restrict__ time_outs, const float *__restrict__ terminal_value, float gamma,
+                              const uint8_t *__restrict__ episode_starts, const float *__restrict__ values, const float *__restrict__ log_probs,
+                              float *__restrict__ buf_actions, float *__restrict__ buf_rewards, uint8_t *__restrict__ buf_starts,
+                              float *__restrict__ buf_values, float *__restrict__ buf_log_probs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float boot = __fmul_rn(gamma, __fmul_rn(terminal_value[i], time_outs[i] ? 1.0f : 0.0f));
+    buf_rewards[i] = __fadd_rn(rewards[i], boot);
+    buf_starts[i] = episode_starts[i] ? 1 : 0;
+    buf_values[i] = values[i];
+    buf_log_probs[i] = log_probs[i];
+    for (int a = 0; a < adim; ++a) buf_actions[(size_t)i * adim + a] = (float)actions[(size_t)i * adim + a];
+}
+
+GNBV_API int gnbv_rollout_add(int n, int action_dim, const int64_t *actions, const float *rewards, const uint8_t *time_outs,
+                              const float *terminal_value, float gamma, const uint8_t *episode_starts, const float *values,
+                              const float *log_probs, float *buf_actions, float *buf_rewards, uint8_t *buf_episode_starts, float *buf_values,
+                              float *buf_log_probs, void *stream)
+{
+    GNBV_CHECK_ARG(n > 0 && action_dim > 0 && actions && rewards && time_outs && terminal_value && episode_starts && values && log_probs);
+    GNBV_CHECK_ARG(buf_actions && buf_rewards && buf_episode_starts && buf_values && buf_log_probs);
+    hipLaunchKernelGGL(k_rollout_add, dim3((n + 255) / 256), dim3(256), 0, gnbv_stream(stream), n, action_dim, actions, rewards, time_outs,
+                       terminal_value, gamma, episode_starts, values, log_probs, buf_actions, buf_rewards, buf_episode_starts, buf_values,
+                       buf_log_probs);
+    return gnbv_launch_status();
+}
+

@@ -142,6 +142,33 @@ class TensorRolloutBuffer_Grid_Obs:
         if self.pos == self.buffer_size:
             self.full = True
 
+    def add_bootstrapped(self, obs, action, reward, time_outs, terminal_value, gamma: float, episode_start, value, log_prob) -> None:
+        """`rewards += gamma * squeeze(terminal_value * time_outs)` (on_policy_algorithm_grid_obs.py:205-208) followed by
+        `add()`, as ONE launch (csrc/envstep.hip: gnbv_rollout_add; same fp32 operation order) -- the observation must
+        already sit in its buffer row (in-place env).  GPU tensors only."""
+        from .. import _lib
+        if self.step >= self.num_transitions_per_env:
+            raise AssertionError("Rollout buffer overflow")
+        assert obs.data_ptr() == self.observations[self.step].data_ptr(), "add_bootstrapped needs the in-place observation row"
+        n, t = self.n_envs, self.step
+        a = action if (action.dtype == torch.int64 and action.is_contiguous()) else action.to(torch.int64).contiguous()
+        es = episode_start if episode_start.dtype in (torch.bool, torch.uint8) else episode_start.bool()
+        to = time_outs if time_outs.dtype in (torch.bool, torch.uint8) else time_outs.bool()
+        r, tv = reward.reshape(-1), terminal_value.reshape(-1)
+        v, lp = value.reshape(-1), log_prob.reshape(-1)
+        for x in (r, tv, v, lp):
+            assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() == n
+        _lib.require_cuda(a, r, to, tv, es, v, lp)
+        _lib.check(_lib.load().gnbv_rollout_add(
+            n, self.actions_shape, a.data_ptr(), r.data_ptr(), to.contiguous().data_ptr(), tv.data_ptr(), float(gamma),
+            es.contiguous().data_ptr(), v.data_ptr(), lp.data_ptr(), self.actions[t].data_ptr(), self.rewards[t].data_ptr(),
+            self.episode_starts[t].data_ptr(), self.values[t].data_ptr(), self.log_probs[t].data_ptr(), _lib.stream_ptr(self.device)),
+            "gnbv_rollout_add")
+        self.step += 1
+        self.pos += 1
+        if self.pos == self.buffer_size:
+            self.full = True
+
     def compute_returns_and_advantage(self, last_values: torch.Tensor, dones) -> None:
         gae_ops.compute_returns_and_advantage(self.rewards, self.values, self.episode_starts, last_values.detach(), dones,
                                               self.gamma, self.gae_lambda, advantages=self.advantages, returns=self.returns)

@@ -585,6 +585,8 @@ class PPO_Grid_Obs:
                 and getattr(enc, "backend", "") == "hip" and isinstance(self.policy.mlp_extractor, _IdentityExtractor)
                 and hasattr(self.policy.action_dist, "sample_and_log_prob")
                 and encoder_ops.policy_head_supported(enc, self.policy.action_net, self.policy.value_net))
+        fused_add = (self.device.type == "cuda" and getattr(self.policy, "_fused_rollout", False)
+                     and os.environ.get("GENNBV_FUSED_ADD", "1") != "0")
         n_steps = 0
         rollout_buffer.reset()
         first = rollout_buffer.first_obs_row()
@@ -621,8 +623,13 @@ class PPO_Grid_Obs:
                 else:
                     nxt = None
                     terminal_value = self.policy.predict_values(new_in)
-            rewards = rewards + self.gamma * torch.squeeze(terminal_value * infos["time_outs"].unsqueeze(1).to(self.device), 1)
-            rollout_buffer.add(self._last_obs, actions, rewards, self._last_episode_starts, values, log_probs)
+            if fused_add and self._last_obs.data_ptr() == rollout_buffer.observations[rollout_buffer.step].data_ptr():
+                # time-out bootstrap + the five buffer copies as one launch (instead of ~9)
+                rollout_buffer.add_bootstrapped(self._last_obs, actions, rewards, infos["time_outs"], terminal_value, self.gamma,
+                                                self._last_episode_starts, values, log_probs)
+            else:
+                rewards = rewards + self.gamma * torch.squeeze(terminal_value * infos["time_outs"].unsqueeze(1).to(self.device), 1)
+                rollout_buffer.add(self._last_obs, actions, rewards, self._last_episode_starts, values, log_probs)
             self._last_obs = new_obs
             self._last_episode_starts = dones
             self._pending = nxt

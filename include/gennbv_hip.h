@@ -189,7 +189,17 @@ typedef struct GnbvEnvPost {
     float *cur_episode_length;      /* in/out */
     float *ring_reward;             /* in/out [ring_len]: rewbuffer (deque maxlen 100) */
     float *ring_length;             /* in/out [ring_len]: lenbuffer */
-    int64_t *ring_state;            /* in/out [1]: episodes finished so far */
+    int64_t *ring_state;            /* Tail of one rollout step in one launch: the time-out bootstrap `rewards += gamma * squeeze(terminal_value * time_outs)`
+ * (on_policy_algorithm_grid_obs.py:205-208; same fp32 operation order) and the five copies of
+ * TensorRolloutBuffer_Grid_Obs.add (stable_baselines3/common/buffers.py:676-704) into row `step` of the buffer arrays
+ * (caller passes the row pointers): actions int64 [N,A] -> f32, episode_starts bool/u8 [N] -> u8, rewards / values /
+ * log_probs f32 [N].  time_outs: bool/u8 [N]. */
+int gnbv_rollout_add(int n, int action_dim, const int64_t *actions, const float *rewards, const uint8_t *time_outs,
+                     const float *terminal_value, float gamma, const uint8_t *episode_starts, const float *values,
+                     const float *log_probs, float *buf_actions, float *buf_rewards, uint8_t *buf_episode_starts, float *buf_values,
+                     float *buf_log_probs, void *stream);
+
+/* in/out [1]: episodes finished so far */
     int ring_len;
 } GnbvEnvPost;
 

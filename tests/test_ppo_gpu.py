@@ -278,3 +278,30 @@ def test_compact_observations_need_an_int8_capable_env():
                      policy_kwargs=dict(net_arch=[], features_extractor_class=Hybrid_Encoder, features_extractor_kwargs=dict(
                          encoder_param={}, net_param={"append_hidden_shapes": [256, 256]}, state_input_shape=(600,),
                          visual_input_shape=(2, 64, 64), grid_size=20, backend="hip")))
+
+
+def test_fused_rollout_add_equals_bootstrap_plus_add():
+    """gnbv_rollout_add: `rewards += gamma * squeeze(terminal_value * time_outs)` + the five copies of add() in one launch
+    leave the buffer rows bit-identical to the reference sequence."""
+    from gennbv_amd.sb3.buffers import TensorRolloutBuffer_Grid_Obs
+    from gennbv_amd.spaces import Box, MultiDiscrete
+    n, t, d = 37, 3, 50
+    gen = torch.Generator().manual_seed(3)
+    space, aspace = Box(-np.inf, np.inf, (d,)), MultiDiscrete([81, 81, 51, 1, 13, 13])
+    bufs = [TensorRolloutBuffer_Grid_Obs(t, space, aspace, device=DEV, n_envs=n) for _ in range(2)]
+    gamma = 0.99
+    for step in range(t):
+        actions = torch.stack([torch.randint(0, k, (n,), generator=gen) for k in (81, 81, 51, 1, 13, 13)], -1).to(DEV)
+        rewards = torch.randn(n, generator=gen).to(DEV)
+        time_outs = (torch.rand(n, generator=gen) < 0.3).to(DEV)
+        tv = torch.randn(n, 1, generator=gen).to(DEV)
+        starts = (torch.rand(n, generator=gen) < 0.2).to(DEV)
+        values, lp = torch.randn(n, 1, generator=gen).to(DEV), torch.randn(n, generator=gen).to(DEV)
+        for b in bufs:
+            b.observations[step].normal_(generator=None)
+        r_ref = rewards + gamma * torch.squeeze(tv * time_outs.unsqueeze(1), 1)
+        bufs[0].add(bufs[0].observations[step], actions, r_ref, starts, values, lp)
+        bufs[1].add_bootstrapped(bufs[1].observations[step], actions, rewards, time_outs, tv, gamma, starts, values, lp)
+    for name in ("actions", "rewards", "episode_starts", "values", "log_probs"):
+        assert torch.equal(getattr(bufs[0], name), getattr(bufs[1], name)), name
+    assert bufs[1].step == t and bufs[1].full
