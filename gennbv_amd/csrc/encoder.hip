@@ -775,21 +775,55 @@ __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(2, 
     // ping-pong: the 28 operand requests of item i+1 (possibly the first group of the NEXT row) are in
     // flight while the 27 MFMAs of item i run; requests are unconditional (clamped), no copies.
     const int ng = (O2 + 3) / 4, nitems = (row1 - row0) * ng;
-    auto request = [&](int it, float &bv, float (&av)[kTaps]) {
-        const int row = row0 + it / ng, x0 = 4 * (it % ng);
-        const int b = row / (O2 * O2), rem = row - b * O2 * O2, oz = rem / O2, oy = rem - oz * O2;
-        const int xc = min(x0 + kq, O2 - 1);
-        bv = dy2[((((size_t)b * O2 + oz) * O2 + oy) * O2 + xc) * kC + n];
-        const uint32_t base = vox1(b, 2 * oz, 2 * oy, 2 * xc, O1) * kC + n;  // even-parity voxel xc
-        const uint32_t XHC = ((uint32_t)(O1 + 1) >> 1) * kC, rowC = 2 * XHC, planeC = rowC * O1;
+    // Index math: the items are walked in order, so (sample, plane, row, x-group) are carried as wave-uniform counters and
+    // advanced incrementally -- the divisions of the first version cost ~75 SALU instructions per item (27 MFMAs), and
+    // every instruction, scalar ones included, takes an issue slot of the SIMD the MFMAs need.  The 27 operand addresses
+    // are 9 wave-uniform (dz, dy) bases + one 32-bit lane offset (dx = 2: +64 B immediate, dx = 1: a second lane offset).
+    const uint32_t XHC = ((uint32_t)(O1 + 1) >> 1) * kC, rowC = 2 * XHC, planeC = rowC * O1;
+    const typename A::T *tapp[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tapp[t] = y1 + (size_t)(t / 3) * planeC + (size_t)(t % 3) * rowC;
+    struct Cursor {
+        int xg, oy, oz, b;
+        uint32_t ybase, dbase;  // element offsets of (b, 2oz, 2oy, x = 0) in y1 and of (b, oz, oy, 0) in dy2
+    };
+    auto cursor_at = [&](int row) {
+        Cursor c;
+        c.b = row / (O2 * O2);
+        const int rem = row - c.b * O2 * O2;
+        c.oz = rem / O2;
+        c.oy = rem - c.oz * O2;
+        c.xg = 0;
+        c.ybase = vox1(c.b, 2 * c.oz, 2 * c.oy, 0, O1) * kC;
+        c.dbase = (uint32_t)row * O2 * kC;
+        return c;
+    };
+    auto advance = [&](Cursor &c) {
+        if (++c.xg < ng) return;
+        c.xg = 0;
+        c.dbase += O2 * kC;
+        if (++c.oy == O2) {
+            c.oy = 0;
+            if (++c.oz == O2) { c.oz = 0; ++c.b; }
+        }
+        c.ybase = vox1(c.b, 2 * c.oz, 2 * c.oy, 0, O1) * kC;
+    };
+    Cursor rq = cursor_at(row0);  // the next item to request
+    int requested = 0, cxg = 0;    // items requested so far; x-group of the next item to consume
+    auto request = [&](float &bv, float (&av)[kTaps]) {
+        const int xc = min(4 * rq.xg + kq, O2 - 1);
+        bv = dy2[rq.dbase + xc * kC + n];
+        const uint32_t off = rq.ybase + xc * kC + n, off1 = off + XHC;  // voxel 2xc of the even plane / voxel xc of the odd plane
 #pragma unroll
         for (int tap = 0; tap < kTaps; ++tap) {
-            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-            av[tap] = A::ld1(y1 + base + (dz * planeC + dy * rowC + (dx == 1 ? XHC : 0) + (dx == 2 ? kC : 0)));
+            const int dx = tap % 3;
+            av[tap] = A::ld1(tapp[tap / 3] + (dx == 1 ? off1 : off) + (dx == 2 ? kC : 0));
         }
+        if (++requested < nitems) advance(rq);  // (past the last item the same one is requested again: unconditional requests)
     };
     auto consume = [&](int it, float bv, const float (&av)[kTaps]) {
-        const bool ok = 4 * (it % ng) + kq < O2 && it < nitems;  // (odd item count: one padded, all-zero item)
+        const bool ok = 4 * cxg + kq < O2 && it < nitems;  // (odd item count: one padded, all-zero item)
+        if (++cxg == ng) cxg = 0;
         const float bb = ok ? bv : 0.0f;  // positions past the row end contribute nothing
         bsum += bb;
 #pragma unroll
@@ -799,13 +833,13 @@ __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(2, 
         }
     };
     float b0, a0[kTaps], b1, a1[kTaps];
-    if (nitems > 0) request(0, b0, a0);
+    if (nitems > 0) request(b0, a0);
     for (int it = 0; it < nitems; it += 2) {
-        request(min(it + 1, nitems - 1), b1, a1);
+        request(b1, a1);
         __builtin_amdgcn_sched_barrier(0);
         consume(it, b0, a0);
         __builtin_amdgcn_sched_barrier(0);
-        request(min(it + 2, nitems - 1), b0, a0);
+        request(b0, a0);
         __builtin_amdgcn_sched_barrier(0);
         consume(it + 1, b1, a1);
         __builtin_amdgcn_sched_barrier(0);
