@@ -85,7 +85,9 @@ def test_fused_dgrad_conv1_wgrad_vs_fp64_reference(g, b, z1, monkeypatch):
     ref, _, _ = pu.make_policy(g=g, device="cpu", backend="torch", det_weights=True)
     ref = ref.double()
     base = _obs(2 * b + 1, g, seed=g + 1)
-    rows = torch.randperm(2 * b + 1)[:b].to(DEV)
+    # fixed row subset: with an unseeded permutation one run in ~5 hit a batch in which a layer-1 pre-activation lies within
+    # fp32 round-off of zero, where the fp32 kernels and the fp64 reference take different sides of the ReLU
+    rows = torch.randperm(2 * b + 1, generator=torch.Generator().manual_seed(100 + g))[:b].to(DEV)
     grid_i8 = base[:, 600:600 + g ** 3].to(torch.int8).contiguous()
     w = torch.linspace(0.5, 1.5, 256)
     # the input autocorrelation is either computed by the backward call (minibatch total) or gathered from per-row
