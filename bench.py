@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--dtype", default="fp32", choices=["fp32"])
     ap.add_argument("--obs", default=os.environ.get("GENNBV_BENCH_OBS", "compact"), choices=["flat", "compact"],
                     help="rollout-buffer rows: the reference's flat fp32 rows, or compact rows (grid as int8 only; same values)")
+    ap.add_argument("--target-kl", default="off", help="'off' (default): the KL early stop of PPO_Grid_Obs.train (ppo_grid_obs.py:261-268) can never "
+                    "trigger, so every timed iteration runs all n_epochs x minibatches (the check itself still runs on the device); "
+                    "'ref': the reference's 0.05, under which a random-init policy on the synthetic feed stops some iterations early")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save-gemm-tuning", default=None, help="write the TunableOp selections to this file")
     return ap.parse_args()
@@ -66,7 +69,7 @@ def build_algo(args, device, rank, world):
         ActorCriticPolicy_Train_Eval, env, learning_rate=pc.learning_rate, n_steps=args.n_steps, batch_size=args.batch_size,
         n_epochs=args.n_epochs, gamma=pc.gamma, gae_lambda=pc.gae_lambda, clip_range=pc.clip_range,
         clip_range_vf=pc.clip_range_vf, ent_coef=pc.ent_coef, vf_coef=pc.vf_coef, max_grad_norm=pc.max_grad_norm,
-        target_kl=pc.target_kl, seed=1, device=device, compact_obs=args.obs == "compact",
+        target_kl=pc.target_kl if args.target_kl == "ref" else 1e9, seed=1, device=device, compact_obs=args.obs == "compact",
         policy_kwargs=dict(net_arch=[], features_extractor_class=Hybrid_Encoder,
                            features_extractor_kwargs=dict(
                                encoder_param={"hidden_shapes": [256, 256], "visual_dim": 256},
@@ -341,6 +344,8 @@ def main():
                                f"{args.grid}^3 grid, n_steps={args.n_steps}, batch_size={args.batch_size}, "
                                f"n_epochs={args.n_epochs}, one step = one PPO iteration",
                    "global_envs": world * args.envs, "encoder_backend": args.backend, "obs_rows": args.obs,
+                   "kl_early_stop": "reference (0.05)" if args.target_kl == "ref" else "never triggers (full work every iteration)",
+                   "minibatches_last_iteration": int(len(algo.last_train_stats)) if getattr(algo, "last_train_stats", None) is not None else None,
                    "hbm_peak_allocated_gb": torch.cuda.max_memory_allocated(device) / 1e9,
                    "parallelism": f"env-sharded dp{world}", "dp_graph_mode": getattr(algo, "dp_graph_mode", None),
                    "breakdown_ms_per_step": {"rollout": phases["rollout"].total_ms() / args.steps,

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
                     if (z1) {
                         y = make_float4(fmaxf(fmaf(zs.x, y.x, zh.x), 0.f), fmaxf(fmaf(zs.y, y.y, zh.y), 0.f),
                                         fmaxf(fmaf(zs.z, y.z, zh.z), 0.f), fmaxf(fmaf(zs.w, y.w, zh.w), 0.f));
-                    } else {
+                    } else if (partials != nullptr) {
                         s_sum[0] += y.x; s_sq[0] += y.x * y.x;
                         s_sum[1] += y.y; s_sq[1] += y.y * y.y;
                         s_sum[2] += y.z; s_sq[2] += y.z * y.z;
@@ -1819,10 +1819,21 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
                            p->b1, (float *)y1, (float *)nullptr, (const float *)bn1, (const float *)(bn1 + kC), p->w2, w.w2img);
         if ((err = gnbv_launch_status())) return err;
     } else {
+    // BN1 batch statistics analytically from the stored input autocorrelation rows (k_bn1_analytic: 6 us, independent of
+    // conv1) instead of partial sums in conv1 + a 12 us reduction behind it; y1 is stored as before
+    const bool analytic = training && p->autocorr != nullptr && !p->act_bf16 && conv1_i8_staged(p, grid) && 3 * grid * grid <= 64 * 1024 &&
+                          !env_off("GENNBV_ANALYTIC_BN1");
+    if (analytic) {
+        hipLaunchKernelGGL(k_bn1_analytic, dim3(1), dim3(1024), 0, st, (const int *)p->autocorr, p->autocorr_row_stride, rows, batch, p->w1, p->b1,
+                           p->bn1_w, p->bn1_b, p->eps, p->momentum, p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag, bn1, bn1 + kC, bn1 + 2 * kC,
+                           bn1 + 3 * kC);
+        if ((err = gnbv_launch_status())) return err;
+    }
+    float *c1_part = (training && !analytic) ? w.bn_part : nullptr;
     // conv1 (+ BN1 statistics)
     if (p->act_bf16) {
         hipLaunchKernelGGL(k_conv1_fwd<ActBF16>, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, batch, grid, O1, p->w1,
-                       p->b1, (uint16_t *)y1, training ? w.bn_part : nullptr, p->w2, w.w2img);
+                       p->b1, (uint16_t *)y1, c1_part, p->w2, w.w2img);
     } else {
         const size_t c1_lds = (size_t)3 * (2 * O1 + 1) * grid * sizeof(float);
         const bool c1_staged = obs_grid != nullptr && (grid % 4 == 0) && (row_stride % 4 == 0) && (((uintptr_t)obs_grid & 15) == 0) && c1_lds <= 64 * 1024 &&
@@ -1830,23 +1841,24 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
         const float *nozs = nullptr;
         if (conv1_i8_staged(p, grid))  // compact int8 copy of the tri-class grid: a quarter of the input bytes
             hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, int8_t>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, p->grid_i8, rows,
-                               p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr, nozs, nozs, p->w2, w.w2img);
+                               p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, nozs, nozs, p->w2, w.w2img);
         else if (c1_staged)
             hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, float>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, obs_grid, rows,
-                               row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr, nozs, nozs, p->w2, w.w2img);
+                               row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, nozs, nozs, p->w2, w.w2img);
         else if (p->grid_i8 != nullptr && grid % 16 == 0 && p->grid_i8_row_stride % 16 == 0 && (((uintptr_t)p->grid_i8 & 15) == 0) &&
                  c1_lds / 4 <= 64 * 1024 && 2 * O1 + 1 <= grid)  // int8 rows, fp32 slab too large (G = 128): int8 slab
             hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, int8_t, true>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds / 4, st, p->grid_i8,
-                               rows, p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr, nozs, nozs, p->w2, w.w2img);
+                               rows, p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, nozs, nozs, p->w2, w.w2img);
         else if (obs_grid == nullptr)  // compact rows at a size the staged kernels do not take
             hipLaunchKernelGGL((k_conv1_fwd<ActF32, int8_t>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, p->grid_i8, rows,
-                               p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr, p->w2, w.w2img);
+                               p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, p->w2, w.w2img);
         else
             hipLaunchKernelGGL(k_conv1_fwd<ActF32>, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride,
-                               batch, grid, O1, p->w1, p->b1, (float *)y1, training ? w.bn_part : nullptr, p->w2, w.w2img);
+                               batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, p->w2, w.w2img);
     }
     if ((err = gnbv_launch_status())) return err;
-    if (training)
+    if (analytic) {
+    } else if (training)
         hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, st, w.bn_part, sample_plane_grid(batch, O1), (double *)nullptr,
                            (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps, p->momentum, p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag,
                            bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, (const float *)nullptr, (float *)nullptr);

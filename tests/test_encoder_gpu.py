@@ -91,7 +91,7 @@ def test_fused_dgrad_conv1_wgrad_vs_fp64_reference(g, b, z1, monkeypatch):
     grid_i8 = base[:, 600:600 + g ** 3].to(torch.int8).contiguous()
     w = torch.linspace(0.5, 1.5, 256)
     # the input autocorrelation is either computed by the backward call (minibatch total) or gathered from per-row
-    # results stored with the observations: exact integers both ways -> identical gradients
+    # results stored with the observations (exact integers both ways)
     hip.train()
     for _ in range(2):  # (first pass: warm-up, the library GEMMs of the fc layer may be auto-tuned on their first call)
         hip.zero_grad()
@@ -105,8 +105,10 @@ def test_fused_dgrad_conv1_wgrad_vs_fp64_reference(g, b, z1, monkeypatch):
         f = pol.features_extractor(obs)
         (f * w.to(dev, dt)).sum().backward()
         outs.append(f.detach().double().cpu())
+    # (with stored rows BatchNorm-1's batch statistics come analytically from the autocorrelation, without them from the
+    # activations: equal to fp32 round-off, not bit for bit)
     for a, c in zip(stored, hip.features_extractor.parameters()):
-        assert torch.equal(a, c.grad)
+        assert float((a - c.grad).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-5  # (+ the noise floor of the analytically zero bias gradients)
     assert float((outs[0] - outs[1]).abs().max()) <= 2e-5 * float(outs[0].abs().max()) + 1e-6
     for (n1, p1), (n2, p2) in zip(ref.features_extractor.named_parameters(), hip.features_extractor.named_parameters()):
         r = p1.grad.double()

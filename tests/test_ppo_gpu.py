@@ -182,7 +182,8 @@ def test_learn_with_int8_grid_copy_matches_fp32_rows(monkeypatch):
     from gennbv_amd.sb3.policies import ActorCriticPolicy_Train_Eval
     from gennbv_amd.sb3.ppo_grid_obs import PPO_Grid_Obs
     n, g, t = 8, 16, 4
-    monkeypatch.setenv("GENNBV_FUSED_BWD", "0")  # bit equality: the separate backward kernels on both sides
+    monkeypatch.setenv("GENNBV_FUSED_BWD", "0")  # bit equality: the separate backward kernels on both sides,
+    monkeypatch.setenv("GENNBV_ANALYTIC_BN1", "0")  # BatchNorm-1 statistics from the activations on both sides
 
     def run(i8: bool):
         monkeypatch.setenv("GENNBV_GRID_I8", "1" if i8 else "0")
@@ -225,7 +226,8 @@ def test_learn_with_compact_observations_matches_flat_rows(monkeypatch, g):
     from gennbv_amd.sb3.ppo_grid_obs import PPO_Grid_Obs
     n, t = 8, 4
     monkeypatch.setenv("GENNBV_GRID_I8", "0")
-    monkeypatch.setenv("GENNBV_FUSED_BWD", "0")  # bit equality at G = 16: the separate backward kernels on both sides
+    monkeypatch.setenv("GENNBV_FUSED_BWD", "0")  # bit equality at G = 16: the separate backward kernels on both sides,
+    monkeypatch.setenv("GENNBV_ANALYTIC_BN1", "0")  # BatchNorm-1 statistics from the activations on both sides
 
     def run(compact: bool):
         torch.manual_seed(0)
