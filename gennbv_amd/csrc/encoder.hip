@@ -1190,27 +1190,46 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad_c1w(
             __builtin_amdgcn_wave_barrier();  // the next super-tile overwrites the slab
         }
     }
-    // ---- workgroup-level sums in wave order (deterministic), one partial row per workgroup ----
+    // ---- workgroup-level sums: binary tree over the 16 waves (fixed order -> deterministic), one partial row per
+    // workgroup.  Slot w of the buffer = two 16-byte vectors per lane (T1) + 32 floats (S1, S2 of channel lane & 15).
     s1 = kgroup_sum(s1);
     s2 = kgroup_sum(s2);
     __syncthreads();  // every wave is done with the weight image (reused as the reduction buffer)
+    constexpr int kSlot = 2 * kWave * 4 + 2 * kC;  // floats per wave slot
+    static_assert(8 * kSlot <= kTaps * 4 * 4 * kC && kBigWaves == 16, "tree reduction buffer");
     float *red = w2d;
-    for (int w = 0; w < kBigWaves; ++w) {
-        if (wv == w) {
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = (16 * tt + 4 * kq + r) * kC + m;  // [tap][co]
-                    red[o] = (w == 0 ? 0.0f : red[o]) + T1[tt][r];
-                }
+    for (int half = kBigWaves / 2; half >= 1; half >>= 1) {
+        if (wv >= half && wv < 2 * half) {
+            float *slot = red + (wv - half) * kSlot;
+            reinterpret_cast<f32x4 *>(slot)[lane] = T1[0];
+            reinterpret_cast<f32x4 *>(slot)[kWave + lane] = T1[1];
             if (lane < kC) {
-                red[512 + lane] = (w == 0 ? 0.0f : red[512 + lane]) + s1;  // lane = channel
-                red[512 + kC + lane] = (w == 0 ? 0.0f : red[512 + kC + lane]) + s2;
+                slot[2 * kWave * 4 + lane] = s1;
+                slot[2 * kWave * 4 + kC + lane] = s2;
             }
         }
         __syncthreads();
+        if (wv < half) {
+            const float *slot = red + wv * kSlot;
+            T1[0] += reinterpret_cast<const f32x4 *>(slot)[lane];
+            T1[1] += reinterpret_cast<const f32x4 *>(slot)[kWave + lane];
+            s1 += slot[2 * kWave * 4 + m];
+            s2 += slot[2 * kWave * 4 + kC + m];
+        }
+        __syncthreads();
     }
+    if (wv == 0) {  // final layout: [tap][co], S1, S2
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(16 * tt + 4 * kq + r) * kC + m] = T1[tt][r];
+        if (lane < kC) {
+            red[512 + lane] = s1;
+            red[512 + kC + lane] = s2;
+        }
+    }
+    __syncthreads();
     float *out = partial + (size_t)blockIdx.x * kE1F;
     for (int o = threadIdx.x; o < kE1F; o += kBigThreads) out[o] = red[o];
 }
