@@ -1377,11 +1377,13 @@ __global__ __launch_bounds__(1024) void k_bn1_analytic(const int *__restrict__ a
                                                       float *__restrict__ running_mean, float *__restrict__ running_var,
                                                       int64_t *__restrict__ num_batches_tracked, const int *__restrict__ skip_flag,
                                                       float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out,
-                                                      float *__restrict__ rstd_out)
+                                                      float *__restrict__ rstd_out, int *__restrict__ total_out /*[kAcRow]: saved for backward*/)
 {
     __shared__ int Ri[kAcRow];
     __shared__ double q[kC][kTaps];
     gather_autocorr(ac, ac_row_stride, rows, nrows, Ri);
+    if (total_out != nullptr)
+        for (int i = threadIdx.x; i < kAcRow; i += 1024) total_out[i] = Ri[i];
     if (threadIdx.x < kC * kTaps) {  // q[c][t] = W1[c][t] * sum_u W1[c][u] R[t][u]
         const int c = threadIdx.x / kTaps, t = threadIdx.x - c * kTaps;
         double a = 0.0;
@@ -1789,6 +1791,15 @@ static inline bool z1_path(const GnbvEncoderParams *p, int grid)
     return e && e[0] == '1' && fused_path(p, grid) && conv1_i8_staged(p, grid);
 }
 
+// bn_state = [2][4][16] floats (scale, shift, mean, rstd per layer) + kAcRow ints: the minibatch total of the input
+// autocorrelation, written by the forward whenever it computed BN1's statistics from it (analytic_bn1 / z1_path) and read
+// back by the backward instead of gathering the rows again
+constexpr int kBnStateFloats = 2 * 4 * kC;
+static inline bool analytic_bn1(const GnbvEncoderParams *p, int grid)
+{
+    return p->autocorr != nullptr && !p->act_bf16 && conv1_i8_staged(p, grid) && 3 * grid * grid <= 64 * 1024 && !env_off("GENNBV_ANALYTIC_BN1");
+}
+
 // minibatch total of the input autocorrelation into `Rac` (when the caller has no per-row results)
 static int launch_autocorr_total(const GnbvEncoderParams *p, const int64_t *rows, int batch, int grid, int *Rac, hipStream_t st)
 {
@@ -1827,7 +1838,8 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
             if (p->autocorr == nullptr && (err = launch_autocorr_total(p, rows, batch, grid, Rac, st))) return err;
             hipLaunchKernelGGL(k_bn1_analytic, dim3(1), dim3(1024), 0, st, p->autocorr ? (const int *)p->autocorr : (const int *)Rac,
                                p->autocorr_row_stride, rows, p->autocorr ? batch : 0, p->w1, p->b1, p->bn1_w, p->bn1_b, p->eps, p->momentum,
-                               p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC);
+                               p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC,
+                               (int *)(bn_state + kBnStateFloats));
         } else {
             hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps, p->momentum,
                                p->bn1_rm, p->bn1_rv, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC);
@@ -1840,12 +1852,11 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     } else {
     // BN1 batch statistics analytically from the stored input autocorrelation rows (k_bn1_analytic: 6 us, independent of
     // conv1) instead of partial sums in conv1 + a 12 us reduction behind it; y1 is stored as before
-    const bool analytic = training && p->autocorr != nullptr && !p->act_bf16 && conv1_i8_staged(p, grid) && 3 * grid * grid <= 64 * 1024 &&
-                          !env_off("GENNBV_ANALYTIC_BN1");
+    const bool analytic = training && analytic_bn1(p, grid);
     if (analytic) {
         hipLaunchKernelGGL(k_bn1_analytic, dim3(1), dim3(1024), 0, st, (const int *)p->autocorr, p->autocorr_row_stride, rows, batch, p->w1, p->b1,
                            p->bn1_w, p->bn1_b, p->eps, p->momentum, p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag, bn1, bn1 + kC, bn1 + 2 * kC,
-                           bn1 + 3 * kC);
+                           bn1 + 3 * kC, (int *)(bn_state + kBnStateFloats));
         if ((err = gnbv_launch_status())) return err;
     }
     float *c1_part = (training && !analytic) ? w.bn_part : nullptr;
@@ -1959,7 +1970,9 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     // the input autocorrelation: per-sample rows computed when the observation was produced (p->autocorr), or
     // the minibatch total computed here
     int *Rac = (int *)(w.red + 1024);  // [kAcRow]
-    if (fused && p->autocorr == nullptr && (err = launch_autocorr_total(p, rows, batch, grid, Rac, st))) return err;
+    // (a training forward that computed BN1's statistics from the autocorrelation left the minibatch total in bn_state)
+    const bool saved_total = fused && (z1 || analytic_bn1(p, grid));
+    if (fused && !saved_total && p->autocorr == nullptr && (err = launch_autocorr_total(p, rows, batch, grid, Rac, st))) return err;
     // ---- BN2 + ReLU backward ----
     hipLaunchKernelGGL(k_bn2_bwd_reduce, dim3(batch * kC), dim3(256), 0, st, d_features, y2, bn2, bn2 + kC, bn2 + 2 * kC,
                        bn2 + 3 * kC, P2, w.bn_part);
@@ -2016,7 +2029,8 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
         const int slf = reduce_stage1(wg1_part, gd, kE1F, tmp1, st);
         if ((err = gnbv_launch_status())) return err;
         hipLaunchKernelGGL(k_c1w_fused_finish, dim3(1), dim3(1024), 0, st, (const double *)tmp1, slf,
-                           p->autocorr ? (const int *)p->autocorr : (const int *)Rac, p->autocorr_row_stride, rows, p->autocorr ? batch : 0,
+                           saved_total ? (const int *)(bn_state + kBnStateFloats) : (p->autocorr ? (const int *)p->autocorr : (const int *)Rac),
+                           p->autocorr_row_stride, rows, (!saved_total && p->autocorr) ? batch : 0,
                            p->w1, bn1, bn1 + 3 * kC, z1 ? p->bn1_w : (const float *)nullptr, p->bn1_b, g->w1, g->b1, (const double *)S2, g->bn1_w,
                            g->bn1_b, g->bn2_w, g->bn2_b);
         if ((err = gnbv_launch_status())) return err;

@@ -151,7 +151,7 @@ class _GridEncoderFn(torch.autograd.Function):
         act_dt = torch.bfloat16 if act_bf16 else torch.float32
         y1 = torch.empty(lib.gnbv_encoder_y1_elems(batch, grid), dtype=act_dt, device=dev)
         y2 = torch.empty(batch * 16 * p2, dtype=torch.float32, device=dev)
-        bn_state = torch.empty(2 * 4 * 16, dtype=torch.float32, device=dev)
+        bn_state = torch.empty(2 * 4 * 16 + 768, dtype=torch.float32, device=dev)  # + the minibatch's autocorrelation total (ints)
         feats = torch.empty(batch, 16 * p2, dtype=torch.float32, device=dev)
         ws = _workspace(lib, batch, grid, dev)
         params = _params_struct(seq, act_bf16, grid_i8, autocorr)

@@ -260,7 +260,9 @@ size_t gnbv_encoder_y1_elems(int batch, int grid);
  * and updates the running stats (unless *skip_flag != 0), else the running stats.
  * Saved for backward: y1 (gnbv_encoder_y1_elems floats: channels-last, x-parity-split, pre-BN),
  * y2 [B,16,O2^3] (pre-BN),
- * bn_state [2][4][16] (scale, shift, mean, rstd per layer).
+ * bn_state: 128 floats [2][4][16] (scale, shift, mean, rstd per layer) + 768 ints (the minibatch total of the input
+ * autocorrelation, written when the forward derived BatchNorm-1's statistics from it and read back by the backward):
+ * 896 four-byte words.
  * features [B, 16*O2^3] is the reference's `naive_encoder_grid(x).reshape(num_env, -1)`. */
 int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *rows, int64_t row_stride, int batch, int grid,
                               const GnbvEncoderParams *params /*[host]*/, int training, const int *skip_flag, void *y1,
