@@ -1381,22 +1381,26 @@ __global__ __launch_bounds__(1024) void k_bn1_analytic(const int *__restrict__ a
 {
     __shared__ int Ri[kAcRow];
     __shared__ double q[kC][kTaps];
+    __shared__ float w1s[kC * kTaps];  // (staged: the loops below would otherwise chain 27 global loads per thread)
+    if (threadIdx.x < kC * kTaps) w1s[threadIdx.x] = W1[threadIdx.x];
     gather_autocorr(ac, ac_row_stride, rows, nrows, Ri);
     if (total_out != nullptr)
         for (int i = threadIdx.x; i < kAcRow; i += 1024) total_out[i] = Ri[i];
     if (threadIdx.x < kC * kTaps) {  // q[c][t] = W1[c][t] * sum_u W1[c][u] R[t][u]
         const int c = threadIdx.x / kTaps, t = threadIdx.x - c * kTaps;
         double a = 0.0;
-        for (int u = 0; u < kTaps; ++u) a += (double)W1[c * kTaps + u] * (double)Ri[ac_index(t, u)];
-        q[c][t] = (double)W1[c * kTaps + t] * a;
+#pragma unroll
+        for (int u = 0; u < kTaps; ++u) a += (double)w1s[c * kTaps + u] * (double)Ri[ac_index(t, u)];
+        q[c][t] = (double)w1s[c * kTaps + t] * a;
     }
     __syncthreads();
     if (threadIdx.x < kC) {
         const int c = threadIdx.x;
         const double count = (double)Ri[ac_index(kTaps, kTaps)], bb = (double)b1[c];
         double wt = 0.0, quad = 0.0;
+#pragma unroll
         for (int t = 0; t < kTaps; ++t) {
-            wt += (double)W1[c * kTaps + t] * (double)Ri[ac_index(t, kTaps)];
+            wt += (double)w1s[c * kTaps + t] * (double)Ri[ac_index(t, kTaps)];
             quad += q[c][t];
         }
         bn_finalize_channel(c, wt + count * bb, quad + 2.0 * bb * wt + count * bb * bb, count, gamma, beta, eps, momentum, 1, running_mean,
