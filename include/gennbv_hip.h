@@ -269,7 +269,9 @@ int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *rows, int64_
                               float *y2, float *bn_state, float *features, void *workspace, size_t workspace_bytes,
                               void *stream);
 
-/* Gradients of all eight parameter tensors given d_features [B, 16*O2^3].
+/* Gradients of all eight parameter tensors given d_features [B, 16*O2^3].  Must follow a gnbv_encoder_grid_forward call
+ * with training != 0 and the same obs / rows / params arguments (it consumes that call's y1, y2 and bn_state, including the
+ * autocorrelation total when the forward left one there).
  * dy2_scratch [B,O2^3,16] and dz1_scratch (gnbv_encoder_y1_elems floats) are caller-owned scratch. */
 int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *rows, int64_t row_stride, int batch, int grid,
                                const GnbvEncoderParams *params /*[host]*/, const void *y1, const float *y2,
