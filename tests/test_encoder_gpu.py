@@ -294,7 +294,7 @@ def test_int8_grid_copy_gives_identical_results(g, b, monkeypatch):
     _, hip = _pair(g)
     hip.train()
     base = _obs(2 * b, g, seed=3)
-    rows = torch.randperm(2 * b)[:b].to(DEV)
+    rows = torch.randperm(2 * b, generator=torch.Generator().manual_seed(7 + g))[:b].to(DEV)  # (fixed subset: reproducible)
     grid_i8 = base[:, 600:600 + g ** 3].to(torch.int8).contiguous()
     outs = []
     for gi in (None, grid_i8):
@@ -317,7 +317,7 @@ def test_compact_observation_rows_match_flat_rows(g, b, train, monkeypatch):
     _, hip = _pair(g)
     hip.train(train)
     base = _obs(2 * b, g, seed=5)
-    rows = torch.randperm(2 * b)[:b].to(DEV)
+    rows = torch.randperm(2 * b, generator=torch.Generator().manual_seed(7 + g))[:b].to(DEV)  # (fixed subset: reproducible)
     s0 = 600
     grid_i8 = base[:, s0:s0 + g ** 3].to(torch.int8).contiguous()
     small = torch.cat((base[:, :s0], base[:, s0 + g ** 3:]), dim=1).contiguous()
