@@ -55,8 +55,56 @@ void run(int threads, int blocks_per_cu, float *out)
            blocks_per_cu, ms, tf, cyc);
 }
 
+// Operands from DISTINCT registers (the split-K / conv kernels' situation), 8 accumulator chains, optionally a long run
+// (sustained clock) -- does the pipe still take one MFMA per ~32 cycles?
+template <int NREG>
+__global__ __launch_bounds__(1024) void k_regs(float *out, const float *in, int iters)
+{
+    const int lane = threadIdx.x & 63;
+    float av[NREG], bv[NREG];
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) { av[i] = in[i * 64 + lane]; bv[i] = in[(NREG + i) * 64 + lane]; }
+    f32x4 acc[8];
+    for (int c = 0; c < 8; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NREG; ++i)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(i + c) % NREG], bv[(i * 3 + c) % NREG], acc[c], 0, 0, 0);
+    }
+    float r = 0.f;
+    for (int c = 0; c < 8; ++c) r += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+template <int NREG>
+void run_regs(int threads, int blocks_per_cu, int iters, float *out, const float *in)
+{
+    const int blocks = 256 * blocks_per_cu;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    k_regs<NREG><<<blocks, threads>>>(out, in, 2);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    k_regs<NREG><<<blocks, threads>>>(out, in, iters);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double nmfma = (double)blocks * (threads / 64) * iters * 8.0 * NREG;
+    printf("distinct operand registers %2d, 8 chains, threads %4d blocks/CU %d, %8.0f MFMA/wave: %.3f ms  %.1f TFLOP/s  %.1f cycles/MFMA/SIMD @2.4GHz\n", NREG,
+           threads, blocks_per_cu, (double)iters * 8 * NREG, ms, nmfma * 2048.0 / (ms * 1e-3) / 1e12, (ms * 1e-3) * 2.4e9 / (nmfma / 1024.0));
+}
+
 int main()
 {
+    {
+        float *out, *in; (void)hipMalloc(&out, 256 * 8 * 1024 * sizeof(float)); (void)hipMalloc(&in, 64 * 64 * sizeof(float));
+        (void)hipMemset(in, 0, 64 * 64 * sizeof(float));
+        run_regs<16>(256, 1, 64, out, in);      // 1 wave / SIMD, short
+        run_regs<16>(512, 1, 64, out, in);      // 2 waves / SIMD
+        run_regs<16>(512, 1, 4096, out, in);    // 2 waves / SIMD, ~50 ms: sustained clock
+        run_regs<16>(1024, 1, 4096, out, in);   // 4 waves / SIMD, long
+        (void)hipFree(out); (void)hipFree(in);
+    }
     float *out; (void)hipMalloc(&out, 256 * 8 * 1024 * sizeof(float));
     run<1, false>(256, 1, out);   // 1 wave / SIMD
     run<1, false>(512, 1, out);   // 2
