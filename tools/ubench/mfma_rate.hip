@@ -76,6 +76,59 @@ __global__ __launch_bounds__(1024) void k_regs(float *out, const float *in, int 
     for (int c = 0; c < 8; ++c) r += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
+// Same, but the operands are RE-LOADED every pass (register double buffer: NL 16-byte requests per lane in flight while the
+// 8 * NREG MFMAs of the previous pass run; source = a cache-resident buffer) -- the conv kernels' steady state.
+template <int NREG, int NL>
+__global__ __launch_bounds__(1024) void k_regs_ld(float *out, const float *in, int iters)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float4 *src = reinterpret_cast<const float4 *>(in) + (size_t)(blockIdx.x % 64) * 4096 + wv * 64 + lane;
+    float4 va[NL], vb[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) va[i] = src[i * 1024];
+    f32x4 acc[8];
+    for (int c = 0; c < 8; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto consume = [&](const float4 (&v)[NL]) {
+        const float *f = reinterpret_cast<const float *>(v);
+#pragma unroll
+        for (int i = 0; i < NREG; ++i)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[(i + c) % (4 * NL)], f[(i * 3 + c + 1) % (4 * NL)], acc[c], 0, 0, 0);
+    };
+    for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) vb[i] = src[i * 1024 + ((it + 1) & 3) * 256];
+        __builtin_amdgcn_sched_barrier(0);
+        consume(va);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) va[i] = src[i * 1024 + ((it + 2) & 3) * 256];
+        __builtin_amdgcn_sched_barrier(0);
+        consume(vb);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float r = 0.f;
+    for (int c = 0; c < 8; ++c) r += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+template <int NREG, int NL>
+void run_regs_ld(int threads, int blocks_per_cu, int iters, float *out, const float *in)
+{
+    const int blocks = 256 * blocks_per_cu;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    k_regs_ld<NREG, NL><<<blocks, threads>>>(out, in, 2);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    k_regs_ld<NREG, NL><<<blocks, threads>>>(out, in, iters);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double nmfma = (double)blocks * (threads / 64) * iters * 8.0 * NREG;
+    printf("operands re-loaded each pass: %2d x 16 B per lane per %3d MFMAs, threads %4d blocks/CU %d: %.3f ms  %.1f TFLOP/s  %.1f cycles/MFMA/SIMD @2.4GHz\n", NL,
+           8 * NREG, threads, blocks_per_cu, ms, nmfma * 2048.0 / (ms * 1e-3) / 1e12, (ms * 1e-3) * 2.4e9 / (nmfma / 1024.0));
+}
+
 template <int NREG>
 void run_regs(int threads, int blocks_per_cu, int iters, float *out, const float *in)
 {
@@ -103,6 +156,13 @@ int main()
         run_regs<16>(512, 1, 64, out, in);      // 2 waves / SIMD
         run_regs<16>(512, 1, 4096, out, in);    // 2 waves / SIMD, ~50 ms: sustained clock
         run_regs<16>(1024, 1, 4096, out, in);   // 4 waves / SIMD, long
+        float *big; (void)hipMalloc(&big, (size_t)64 * 4096 * 16 + 65536 * 16); (void)hipMemset(big, 0, (size_t)64 * 4096 * 16 + 65536 * 16);
+        run_regs_ld<16, 4>(256, 1, 512, out, big);    // 1 wave / SIMD, 4 KiB per wave per 128 MFMAs
+        run_regs_ld<16, 16>(256, 1, 512, out, big);   // 16 KiB per wave per 128 MFMAs (conv2_fwd: 27 KiB per 108)
+        run_regs_ld<4, 8>(256, 1, 2048, out, big);    // 8 KiB per wave per 32 MFMAs (conv2_fwd's ratio)
+        run_regs_ld<16, 4>(1024, 1, 512, out, big);   // 4 waves / SIMD
+        run_regs_ld<4, 8>(1024, 1, 2048, out, big);
+        (void)hipFree(big);
         (void)hipFree(out); (void)hipFree(in);
     }
     float *out; (void)hipMalloc(&out, 256 * 8 * 1024 * sizeof(float));
