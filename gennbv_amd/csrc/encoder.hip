@@ -451,21 +451,33 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
             v[t] = A::ld4(y1 + base + (dy * rowC + (dx == 1 ? XHC : 0) + (dx == 2 ? kC : 0)));
         }
     };
-    auto consume = [&](int dz, const float4 (&v)[9], f32x4 &acc) {
+    auto consume = [&](int dz, float4 (&v)[9], f32x4 &acc) {
+        // BN + ReLU of the whole slab IN PLACE first, then the 36 MFMAs back to back: left to the compiler every MFMA is
+        // preceded by its own v_fma, v_max, s_nop (46 cycles per MFMA in tools/ubench/mfma_valu_groups.hip against 37-38
+        // when the vector work is grouped in front of >= 8 MFMAs: what costs is the MFMA -> VALU -> MFMA turn-around, not
+        // the vector instructions themselves).
+        if (!Z1) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                v[t].x = fmaxf(fmaf(sc[0], v[t].x, sh[0]), 0.f);
+                v[t].y = fmaxf(fmaf(sc[1], v[t].y, sh[1]), 0.f);
+                v[t].z = fmaxf(fmaf(sc[2], v[t].z, sh[2]), 0.f);
+                v[t].w = fmaxf(fmaf(sc[3], v[t].w, sh[3]), 0.f);
+            }
+        }
         // weights: one 16-byte LDS read per tap, issued ONE TAP AHEAD of its MFMAs and pinned there (left alone the
         // compiler puts every LDS read right in front of its use: ds_read, s_waitcnt lgkmcnt(0), 2 MFMAs -- the LDS
         // latency exposed 54 times per tile)
         float4 wq = w2_tap(w2s, dz * 9, lane);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const float4 wn = w2_tap(w2s, dz * 9 + (t < 8 ? t + 1 : t), lane);
             __builtin_amdgcn_sched_barrier(0);
-            const float z0 = Z1 ? v[t].x : fmaxf(fmaf(sc[0], v[t].x, sh[0]), 0.f), z1 = Z1 ? v[t].y : fmaxf(fmaf(sc[1], v[t].y, sh[1]), 0.f);
-            const float z2 = Z1 ? v[t].z : fmaxf(fmaf(sc[2], v[t].z, sh[2]), 0.f), z3 = Z1 ? v[t].w : fmaxf(fmaf(sc[3], v[t].w, sh[3]), 0.f);
-            acc = mfma4(z0, wq.x, acc);
-            acc = mfma4(z1, wq.y, acc);
-            acc = mfma4(z2, wq.z, acc);
-            acc = mfma4(z3, wq.w, acc);
+            acc = mfma4(v[t].x, wq.x, acc);
+            acc = mfma4(v[t].y, wq.y, acc);
+            acc = mfma4(v[t].z, wq.z, acc);
+            acc = mfma4(v[t].w, wq.w, acc);
             __builtin_amdgcn_sched_barrier(0);
             wq = wn;
         }
@@ -821,15 +833,23 @@ __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(2, 
         }
         if (++requested < nitems) advance(rq);  // (past the last item the same one is requested again: unconditional requests)
     };
-    auto consume = [&](int it, float bv, const float (&av)[kTaps]) {
+    auto consume = [&](int it, float bv, float (&av)[kTaps]) {
         const bool ok = 4 * cxg + kq < O2 && it < nitems;  // (odd item count: one padded, all-zero item)
         if (++cxg == ng) cxg = 0;
         const float bb = ok ? bv : 0.0f;  // positions past the row end contribute nothing
         bsum += bb;
+        // BN + ReLU in place, nine taps at a time, then their nine MFMAs back to back (see k_conv2_fwd: a v_fma + v_max in
+        // front of EVERY MFMA costs ~12 cycles per MFMA, grouped in front of nine ~4)
 #pragma unroll
-        for (int tap = 0; tap < kTaps; ++tap) {
-            const float a = Z1 ? av[tap] : fmaxf(fmaf(sc, av[tap], sh), 0.0f);
-            acc[tap] = mfma4(a, bb, acc[tap]);
+        for (int g = 0; g < kTaps; g += 9) {
+            if (!Z1) {
+#pragma unroll
+                for (int tap = g; tap < g + 9; ++tap) av[tap] = fmaxf(fmaf(sc, av[tap], sh), 0.0f);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tap = g; tap < g + 9; ++tap) acc[tap] = mfma4(av[tap], bb, acc[tap]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     float b0, a0[kTaps], b1, a1[kTaps];

@@ -78,7 +78,9 @@ __global__ __launch_bounds__(1024) void k_regs(float *out, const float *in, int 
 }
 // Same, but the operands are RE-LOADED every pass (register double buffer: NL 16-byte requests per lane in flight while the
 // 8 * NREG MFMAs of the previous pass run; source = a cache-resident buffer) -- the conv kernels' steady state.
-template <int NREG, int NL>
+// UPFRONT: one s_waitcnt for the whole operand set in front of each MFMA block instead of the compiler's descending vmcnt(N) between the MFMAs.
+constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14); }
+template <int NREG, int NL, bool UPFRONT = false>
 __global__ __launch_bounds__(1024) void k_regs_ld(float *out, const float *in, int iters)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -99,11 +101,13 @@ __global__ __launch_bounds__(1024) void k_regs_ld(float *out, const float *in, i
 #pragma unroll
         for (int i = 0; i < NL; ++i) vb[i] = src[i * 1024 + ((it + 1) & 3) * 256];
         __builtin_amdgcn_sched_barrier(0);
+        if (UPFRONT) { __builtin_amdgcn_s_waitcnt(vmcnt_imm(NL)); __builtin_amdgcn_sched_barrier(0); }
         consume(va);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NL; ++i) va[i] = src[i * 1024 + ((it + 2) & 3) * 256];
         __builtin_amdgcn_sched_barrier(0);
+        if (UPFRONT) { __builtin_amdgcn_s_waitcnt(vmcnt_imm(NL)); __builtin_amdgcn_sched_barrier(0); }
         consume(vb);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -111,21 +115,21 @@ __global__ __launch_bounds__(1024) void k_regs_ld(float *out, const float *in, i
     for (int c = 0; c < 8; ++c) r += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
-template <int NREG, int NL>
+template <int NREG, int NL, bool UPFRONT = false>
 void run_regs_ld(int threads, int blocks_per_cu, int iters, float *out, const float *in)
 {
     const int blocks = 256 * blocks_per_cu;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    k_regs_ld<NREG, NL><<<blocks, threads>>>(out, in, 2);
+    k_regs_ld<NREG, NL, UPFRONT><<<blocks, threads>>>(out, in, 2);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    k_regs_ld<NREG, NL><<<blocks, threads>>>(out, in, iters);
+    k_regs_ld<NREG, NL, UPFRONT><<<blocks, threads>>>(out, in, iters);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     const double nmfma = (double)blocks * (threads / 64) * iters * 8.0 * NREG;
-    printf("operands re-loaded each pass: %2d x 16 B per lane per %3d MFMAs, threads %4d blocks/CU %d: %.3f ms  %.1f TFLOP/s  %.1f cycles/MFMA/SIMD @2.4GHz\n", NL,
+    printf("%soperands re-loaded each pass: %2d x 16 B per lane per %3d MFMAs, threads %4d blocks/CU %d: %.3f ms  %.1f TFLOP/s  %.1f cycles/MFMA/SIMD @2.4GHz\n", UPFRONT ? "[one up-front wait] " : "", NL,
            8 * NREG, threads, blocks_per_cu, ms, nmfma * 2048.0 / (ms * 1e-3) / 1e12, (ms * 1e-3) * 2.4e9 / (nmfma / 1024.0));
 }
 
@@ -162,6 +166,10 @@ int main()
         run_regs_ld<4, 8>(256, 1, 2048, out, big);    // 8 KiB per wave per 32 MFMAs (conv2_fwd's ratio)
         run_regs_ld<16, 4>(1024, 1, 512, out, big);   // 4 waves / SIMD
         run_regs_ld<4, 8>(1024, 1, 2048, out, big);
+        run_regs_ld<16, 16, true>(256, 1, 512, out, big);
+        run_regs_ld<4, 8, true>(256, 1, 2048, out, big);
+        run_regs_ld<16, 4, true>(1024, 1, 512, out, big);
+        run_regs_ld<4, 8, true>(1024, 1, 2048, out, big);
         (void)hipFree(big);
         (void)hipFree(out); (void)hipFree(in);
     }
