@@ -411,8 +411,10 @@ constexpr int kBigWaves = kBigThreads / kWave;
 // ---------------------------------------------------------------------------
 // conv2 forward: z1 = relu(scale1*y1 + shift1) applied on load; y2 [B,16,O2^3] (NCDHW, pre-BN)
 // ---------------------------------------------------------------------------
+// Workgroup = 12 waves (three per SIMD, <= 168 VGPRs each): room for the third slab buffer; 4 planes x 15 rows = 60 tiles = 5 per wave.
+constexpr int kFwdThreads = 768, kFwdWaves = kFwdThreads / kWave;
 template <typename A, bool Z1 = false /*the layer-1 buffer holds z1 = relu(bn1(y1)) already*/>
-__global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
+__global__ __launch_bounds__(kFwdThreads) void k_conv2_fwd(
     const typename A::T *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1, int B, int O1, int O2,
     const float *__restrict__ W2img /*k_prep_w2 fwd image*/, const float *__restrict__ b2, float *__restrict__ y2,
     float *__restrict__ partials)
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
     const bool live = sample_plane_group(B, O2, kPlanesPerGroup, b, oz0, oz1);
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform -> SALU index math
     const int m = lane & 15, kq = lane >> 4;
-    if (!live) { write_partials(partials, kBigWaves, wv, 0.f, 0.f); return; }
+    if (!live) { write_partials(partials, kFwdWaves, wv, 0.f, 0.f); return; }
     float sc[4], sh[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -435,8 +437,8 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
     float s_sum = 0.0f, s_sq = 0.0f;
     const int ntile_x = (O2 + 15) / 16, nwork = (oz1 - oz0) * O2 * ntile_x;
     const uint32_t XHC = ((uint32_t)(O1 + 1) >> 1) * kC, rowC = 2 * XHC;
-    // Register double buffer over dz slabs (9 taps = 9 KiB per wave each): the requests of slab s+1
-    // (possibly the first slab of the wave's next tile) are issued BEFORE the 36 MFMAs of slab s.
+    // Register ring over dz slabs (9 taps = 9 KiB per wave each), one buffer per dz: the requests of slab s+2
+    // (possibly a slab of the wave's next tile) are issued BEFORE the 36 MFMAs of slab s.
     // Left to itself the compiler sinks every load next to its use (load, s_waitcnt vmcnt(0),
     // 4 MFMA): one 1 KiB request in flight per wave, latency-bound at ~3.5 TB/s.  The scheduling
     // barriers pin the request groups where they are written.
@@ -498,41 +500,30 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_fwd(
     };
     // Requests are unconditional (past the last tile they re-read it): a branch around a request group
     // makes the s_waitcnt insertion assume the worst case at the join, i.e. wait for the prefetch too.
-    float4 va[9], vb[9];
-    if (wv < nwork) request(wv, 0, va);
-    for (int wk = wv; wk < nwork; wk += 2 * kBigWaves) {
-        // tile wk: slabs in va, vb, va; tile wk + kBigWaves: vb, va, vb
-        const int wk2 = wk + kBigWaves, wk3 = wk + 2 * kBigWaves;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        request(wk, 1, vb);
-        __builtin_amdgcn_sched_barrier(0);
-        consume(0, va, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        request(wk, 2, va);
-        __builtin_amdgcn_sched_barrier(0);
-        consume(1, vb, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        request(min(wk2, nwork - 1), 0, vb);
-        __builtin_amdgcn_sched_barrier(0);
-        consume(2, va, acc);
-        finish(wk, acc);
-        if (wk2 >= nwork) break;
-        __builtin_amdgcn_sched_barrier(0);
-        acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        request(wk2, 1, va);
-        __builtin_amdgcn_sched_barrier(0);
-        consume(0, vb, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        request(wk2, 2, vb);
-        __builtin_amdgcn_sched_barrier(0);
-        consume(1, va, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        request(min(wk3, nwork - 1), 0, va);
-        __builtin_amdgcn_sched_barrier(0);
-        consume(2, vb, acc);
-        finish(wk2, acc);
+    // Three slab buffers, one per dz: slab (tile, dz) is requested TWO slabs (72 MFMAs) before it is consumed.
+    float4 v0[9], v1[9], v2[9];
+    if (wv < nwork) {
+        request(wv, 0, v0);
+        request(wv, 1, v1);
     }
-    write_partials(partials, kBigWaves, wv, s_sum, s_sq);
+    for (int wk = wv; wk < nwork; wk += kFwdWaves) {
+        const int nxt = min(wk + kFwdWaves, nwork - 1);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        request(wk, 2, v2);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(0, v0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        request(nxt, 0, v0);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(1, v1, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        request(nxt, 1, v1);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(2, v2, acc);
+        finish(wk, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    write_partials(partials, kFwdWaves, wv, s_sum, s_sq);
 }
 
 // ---------------------------------------------------------------------------
@@ -1924,13 +1915,13 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     // conv2 (BN1 + ReLU on load; + BN2 statistics).  Its LDS weight images were written by the conv1 kernel in passing.
     const int g2 = sample_plane_group_grid(batch, O2, kPlanesPerGroup);
     if (p->act_bf16) {
-        hipLaunchKernelGGL(k_conv2_fwd<ActBF16>, dim3(g2), dim3(kBigThreads), 0, st, (const uint16_t *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
+        hipLaunchKernelGGL(k_conv2_fwd<ActBF16>, dim3(g2), dim3(kFwdThreads), 0, st, (const uint16_t *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
                        training ? w.bn_part : nullptr);
     } else if (z1) {
-        hipLaunchKernelGGL((k_conv2_fwd<ActF32, true>), dim3(g2), dim3(kBigThreads), 0, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
+        hipLaunchKernelGGL((k_conv2_fwd<ActF32, true>), dim3(g2), dim3(kFwdThreads), 0, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
                        training ? w.bn_part : nullptr);
     } else {
-        hipLaunchKernelGGL(k_conv2_fwd<ActF32>, dim3(g2), dim3(kBigThreads), 0, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
+        hipLaunchKernelGGL(k_conv2_fwd<ActF32>, dim3(g2), dim3(kFwdThreads), 0, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
                        training ? w.bn_part : nullptr);
     }
     if ((err = gnbv_launch_status())) return err;
