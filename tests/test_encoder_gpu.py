@@ -27,11 +27,16 @@ def _obs(b, g, seed=0):
     return o.to(DEV)
 
 
+@pytest.mark.parametrize("conv2_lds", ["0", "1"])
 @pytest.mark.parametrize("g,b", [(20, 8), (16, 5), (33, 3), (64, 4), (128, 1)])
-def test_encoder_forward_backward_vs_torch_reference(g, b):
+def test_encoder_forward_backward_vs_torch_reference(g, b, conv2_lds, monkeypatch):
     """Reference = the same torch modules in fp64 on the CPU (ground truth), tolerance = fp32 round-off.
     (torch-GPU fp32 is NOT used as the reference: MIOpen's conv/BN backward is off by 0.7-4.6 % at
-    G=64 against fp64, tools/check_conv_grads.py; the hand-written kernels are within 1e-6.)"""
+    G=64 against fp64, tools/check_conv_grads.py; the hand-written kernels are within 1e-6.)
+    conv2_lds = "1": the opt-in LDS-staged conv2 forward (k_conv2_fwd_lds; G <= 66, else the default kernel runs)."""
+    if conv2_lds == "1" and g > 66:
+        pytest.skip("k_conv2_fwd_lds covers O2 <= 15 only")
+    monkeypatch.setenv("GENNBV_CONV2_LDS", conv2_lds)
     hip, _, _ = pu.make_policy(g=g, device=DEV, backend="hip", det_weights=True)
     ref, _, _ = pu.make_policy(g=g, device="cpu", backend="torch", det_weights=True)
     ref = ref.double()
