@@ -212,6 +212,10 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd(
             const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
             off[s] = ok ? (dz * G + dy) * G + dx : 0;
         }
+        // The weights are SrcA of every MFMA below.  A register last written by a global load is a slow MFMA source when waves
+        // share the SIMD (tools/ubench/README.md: 50-58 instead of 34 cycles per MFMA); one VALU move each puts them on the fast path.
+#pragma unroll
+        for (int s = 0; s < 7; ++s) asm volatile("v_mov_b32 %0, %0" : "+v"(wf[s]));
         const float4 bias = *reinterpret_cast<const float4 *>(b1 + 4 * kq);
         // trips = (output row, 32-output x range); the 14 operand requests of trip k+1 are issued
         // before the MFMAs / stores of trip k (register double buffer, pinned by scheduling barriers)
@@ -345,6 +349,9 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
             const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
             off[s] = ok ? (dz * NR + dy) * G + dx : 0;
         }
+        // (SrcA registers re-written by the VALU after their global load: see k_conv1_fwd)
+#pragma unroll
+        for (int s = 0; s < 7; ++s) asm volatile("v_mov_b32 %0, %0" : "+v"(wf[s]));
         const float4 bias = *reinterpret_cast<const float4 *>(b1 + 4 * kq);
         const bool z1 = zscale != nullptr;  // BN1 scale / shift known up front (analytic batch statistics, or eval mode)
         const float4 zs = z1 ? *reinterpret_cast<const float4 *>(zscale + 4 * kq) : make_float4(1.f, 1.f, 1.f, 1.f);
@@ -973,23 +980,18 @@ __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(2, 
         }
         if (++requested < nitems) advance(rq);  // (past the last item the same one is requested again: unconditional requests)
     };
-    auto consume = [&](int it, float bv, float (&av)[kTaps]) {
+    auto consume = [&](int it, float bv, const float (&av)[kTaps]) {
         const bool ok = 4 * cxg + kq < O2 && it < nitems;  // (odd item count: one padded, all-zero item)
         if (++cxg == ng) cxg = 0;
         const float bb = ok ? bv : 0.0f;  // positions past the row end contribute nothing
         bsum += bb;
-        // BN + ReLU in place, nine taps at a time, then their nine MFMAs back to back (see k_conv2_fwd: a v_fma + v_max in
-        // front of EVERY MFMA costs ~12 cycles per MFMA, grouped in front of nine ~4)
+        // (BN + ReLU per tap right in front of its MFMA: grouping nine taps' VALU work in front of nine back-to-back MFMAs, as
+        // k_conv2_fwd does, measured no faster alone and 5 % slower beside the data-gradient kernel in the PPO minibatch -- this
+        // kernel is bound by its 28 four-byte requests per 27 MFMAs, profiles/r01_notes.md)
 #pragma unroll
-        for (int g = 0; g < kTaps; g += 9) {
-            if (!Z1) {
-#pragma unroll
-                for (int tap = g; tap < g + 9; ++tap) av[tap] = fmaxf(fmaf(sc, av[tap], sh), 0.0f);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int tap = g; tap < g + 9; ++tap) acc[tap] = mfma4(av[tap], bb, acc[tap]);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int tap = 0; tap < kTaps; ++tap) {
+            const float a = Z1 ? av[tap] : fmaxf(fmaf(sc, av[tap], sh), 0.0f);
+            acc[tap] = mfma4(a, bb, acc[tap]);
         }
     };
     float b0, a0[kTaps], b1, a1[kTaps];
