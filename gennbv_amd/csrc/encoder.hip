@@ -2113,7 +2113,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
 struct BwdSide {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
-    bool enabled = false, init = false;
+    bool enabled = false, init = false, own_stream = false;
 };
 static BwdSide &bwd_side()
 {
@@ -2124,9 +2124,22 @@ static BwdSide &bwd_side()
         if ((e && e[0] == '1') && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess)
-            s.enabled = true;
+            s.enabled = s.own_stream = true;
     }
     return s;
+}
+// The caller's own second stream for the same purpose (NULL: off again).  In a captured PPO minibatch this is the stream the
+// pose-history branch already runs on, so that the graph keeps two parallel branches instead of growing a third.
+GNBV_API int gnbv_encoder_set_backward_side_stream(void *stream)
+{
+    BwdSide &s = bwd_side();
+    if (s.own_stream) return 0;  // GENNBV_BWD_CONCURRENT=1 keeps its private stream
+    if (s.fork == nullptr && (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
+                              hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess))
+        return (int)hipGetLastError();
+    s.stream = gnbv_stream(stream);
+    s.enabled = stream != nullptr;
+    return 0;
 }
 
 GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *rows, int64_t row_stride, int batch, int grid,

@@ -336,6 +336,12 @@ class PPO_Grid_Obs:
         if getattr(enc, "backend", "") == "hip":
             enc.output_layer_grid[0]._async_wgrad = (bool(self.grad_write_through) and os.environ.get("GENNBV_ASYNC_WGRAD", "1") != "0"
                                                      and (self._sync is None or not self._sync.active))
+        # EXPERIMENT (GENNBV_BWD_SIDE=1): conv2 weight gradient on the pose branch's stream beside the conv2 data gradient
+        if getattr(enc, "backend", "") == "hip" and self.device.type == "cuda":
+            from .. import _lib
+            on = os.environ.get("GENNBV_BWD_SIDE", "0") == "1" and (self._sync is None or not self._sync.active)
+            side = encoder_ops._side_stream(self.device, 0).cuda_stream if on else None
+            _lib.load().gnbv_encoder_set_backward_side_stream(side)
         self._hip["skip_zero"] = bool(self.grad_write_through) and all(
             id(p) in covered for p in self.policy.parameters() if p.requires_grad)
         return self._hip
