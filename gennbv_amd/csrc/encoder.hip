@@ -45,6 +45,16 @@ __device__ __forceinline__ uint32_t vox1(int b, int z, int y, int x, int O1)
     const uint32_t XH = (uint32_t)(O1 + 1) >> 1;
     return ((((uint32_t)b * O1 + z) * O1 + y) * 2 + (x & 1)) * XH + ((uint32_t)x >> 1);
 }
+// QUAD-MAJOR variant of the same buffer (fp32, fused-backward path): inside a (row, x-parity) block of XH voxels the four channel
+// quads are separate runs, [quad][voxel][4 channels]: element offset of channel 4*quad of voxel (b, z, y, x).  The 16-byte operand
+// load of MFMA lane (m = voxel, kq = quad) is then 16 bytes from its neighbour m + 1 -- a wave-wide dwordx4 load whose lane quads
+// read one contiguous 64-byte segment goes through the CU's load path at twice the rate of one whose lanes are 64 bytes apart
+// (tools/ubench/vmem_quad_rate.hip: 15.9 vs 29.6 cycles), and that path is what bounds the conv2 kernels.
+__device__ __forceinline__ uint32_t y1q(int b, int z, int y, int x, int O1, int quad)
+{
+    const uint32_t XH = (uint32_t)(O1 + 1) >> 1;
+    return ((((((uint32_t)b * O1 + z) * O1 + y) * 2 + (x & 1)) * 4 + quad) * XH + ((uint32_t)x >> 1)) * 4;
+}
 static inline size_t y1_elems(int batch, int O1) { return (size_t)batch * O1 * O1 * 2 * ((O1 + 1) / 2) * kC; }
 
 // Storage type of the layer-1 activations (y1, dz1'): fp32, or bf16 (math stays fp32; halves the
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd(
 // fetched with a quarter of the bytes and widened while it is written to LDS).
 // LDS8 (int8 input only): the slab stays int8 in LDS (a quarter of the bytes: G = 128 fits, 48 KiB) and is widened
 // when the MFMA operand is read; no faster than the fp32 slab where that fits (measured at G = 64), so only used beyond.
-template <typename A, typename IN, bool LDS8 = false>
+template <typename A, typename IN, bool LDS8 = false, bool QM = false /*quad-major y1*/>
 __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
     const IN *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, int B, int G, int O1,
     const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ b1, typename A::T *__restrict__ y1,
@@ -384,7 +394,7 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
                         s_sum[2] += y.z; s_sq[2] += y.z * y.z;
                         s_sum[3] += y.w; s_sq[3] += y.w * y.w;
                     }
-                    A::st4(y1 + vox1(b, oz, oy, oxm, O1) * kC + 4 * kq, y);
+                    A::st4(y1 + (QM ? y1q(b, oz, oy, oxm, O1, kq) : vox1(b, oz, oy, oxm, O1) * kC + 4 * kq), y);
                 }
             }
         }
@@ -420,7 +430,7 @@ constexpr int kBigWaves = kBigThreads / kWave;
 // ---------------------------------------------------------------------------
 // Workgroup = 12 waves (three per SIMD, <= 168 VGPRs each): room for the third slab buffer; 4 planes x 15 rows = 60 tiles = 5 per wave.
 constexpr int kFwdThreads = 768, kFwdWaves = kFwdThreads / kWave;
-template <typename A, bool Z1 = false /*the layer-1 buffer holds z1 = relu(bn1(y1)) already*/>
+template <typename A, bool Z1 = false /*the layer-1 buffer holds z1 = relu(bn1(y1)) already*/, bool QM = false /*quad-major y1*/>
 __global__ __launch_bounds__(kFwdThreads) void k_conv2_fwd(
     const typename A::T *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1, int B, int O1, int O2,
     const float *__restrict__ W2img /*k_prep_w2 fwd image*/, const float *__restrict__ b2, float *__restrict__ y2,
@@ -452,12 +462,12 @@ __global__ __launch_bounds__(kFwdThreads) void k_conv2_fwd(
     auto request = [&](int wk, int dz, float4 (&v)[9]) {
         const int oz = oz0 + wk / (O2 * ntile_x), rr = wk % (O2 * ntile_x), oy = rr / ntile_x;
         const int ox = min((rr % ntile_x) * 16 + m, O2 - 1);
-        const uint32_t base = vox1(b, 2 * oz + dz, 2 * oy, 2 * ox, O1) * kC + 4 * kq;  // even-parity voxel ox
+        const uint32_t base = QM ? y1q(b, 2 * oz + dz, 2 * oy, 2 * ox, O1, kq) : vox1(b, 2 * oz + dz, 2 * oy, 2 * ox, O1) * kC + 4 * kq;  // even-parity voxel ox
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int dy = t / 3, dx = t % 3;
             // dx = 0, 2: even plane, voxels ox, ox + 1; dx = 1: odd plane, voxel ox
-            v[t] = A::ld4(y1 + base + (dy * rowC + (dx == 1 ? XHC : 0) + (dx == 2 ? kC : 0)));
+            v[t] = A::ld4(y1 + base + (dy * rowC + (dx == 1 ? XHC : 0) + (dx == 2 ? (QM ? 4 : kC) : 0)));
         }
     };
     auto consume = [&](int dz, float4 (&v)[9], f32x4 &acc) {
@@ -551,6 +561,7 @@ constexpr int kStageRegions = 63;                                 // (2 np + 1)(
 constexpr int kStageBytes = kStageRegions * 2 * 1024 + 16;        // + 16: lane m = 15 of the last quad reads one voxel past its row
 constexpr int kW2ImgBytes = kTaps * 4 * 4 * kC * 4;               // 27 648
 constexpr int kFwdLdsBytes = kW2ImgBytes + kStageBytes;
+template <bool QM /*quad-major y1*/>
 __global__ __launch_bounds__(kFwdThreads) void k_conv2_fwd_lds(
     const float *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1, int B, int O1, int O2,
     const float *__restrict__ W2img, const float *__restrict__ b2, float *__restrict__ y2, float *__restrict__ partials)
@@ -578,7 +589,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_conv2_fwd_lds(
     const int np = oz1 - oz0, NP = 2 * np + 1;
     const int RY = min(kFwdWaves / np, (kStageRegions / NP - 1) / 2), NR = 2 * RY + 1;  // rows per round; NR = region row stride
     const int nchunks = (O2 + RY - 1) / RY;
-    const float *ybase = y1 + (size_t)b * O1 * planeC + (size_t)(2 * oz0) * planeC + min(m, XH - 1) * kC + 4 * kq;
+    const float *ybase = y1 + (size_t)b * O1 * planeC + (size_t)(2 * oz0) * planeC + (QM ? kq * XH * 4 + min(m, XH - 1) * 4 : min(m, XH - 1) * kC + 4 * kq);
     constexpr int kSlots = (2 * kStageRegions + kFwdWaves - 1) / kFwdWaves;  // 11 requests per lane and round
     float4 regs[kSlots];
     // request j of a round = (plane pi, row ri, parity): j = (pi * nr + ri) * 2 + par, nr = rows of the round (NR but for a
@@ -913,7 +924,7 @@ __device__ __forceinline__ void wave_row_range(int nrows, int &r0, int &r1)
 // MFMA: i = ci, j = co, k = 4 consecutive output positions along x.  27 accumulators / wave.
 // partial[w][tap][ci][co] (+ 16 bias sums), reduced by k_reduce_partials.
 // ---------------------------------------------------------------------------
-template <typename A, bool Z1 = false>
+template <typename A, bool Z1 = false, bool QM = false /*quad-major y1*/>
 __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv2_wgrad(
     const typename A::T *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1,
     const float *__restrict__ dy2 /*[B,O2,O2,O2,16]*/, int B, int O1, int O2, float *__restrict__ partial)
@@ -972,11 +983,12 @@ __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(2, 
     auto request = [&](float &bv, float (&av)[kTaps]) {
         const int xc = min(4 * rq.xg + kq, O2 - 1);
         bv = dy2[rq.dbase + xc * kC + n];
-        const uint32_t off = rq.ybase + xc * kC + n, off1 = off + XHC;  // voxel 2xc of the even plane / voxel xc of the odd plane
+        // voxel 2xc of the even plane / voxel xc of the odd plane
+        const uint32_t off = rq.ybase + (QM ? (uint32_t)(n >> 2) * (XHC / 4) + xc * 4 + (n & 3) : (uint32_t)xc * kC + n), off1 = off + XHC;
 #pragma unroll
         for (int tap = 0; tap < kTaps; ++tap) {
             const int dx = tap % 3;
-            av[tap] = A::ld1(tapp[tap / 3] + (dx == 1 ? off1 : off) + (dx == 2 ? kC : 0));
+            av[tap] = A::ld1(tapp[tap / 3] + (dx == 1 ? off1 : off) + (dx == 2 ? (QM ? 4 : kC) : 0));
         }
         if (++requested < nitems) advance(rq);  // (past the last item the same one is requested again: unconditional requests)
     };
@@ -1245,7 +1257,7 @@ __device__ __forceinline__ void dgrad_c1w_subtile(
     }
 }
 
-template <bool Z1>
+template <bool Z1, bool QM = false /*quad-major y1*/>
 __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad_c1w(
     const float *__restrict__ dy2, const float *__restrict__ W2 /*dgrad image*/, const float *__restrict__ y1, const float *__restrict__ scale1,
     const float *__restrict__ shift1, const float *__restrict__ mean1, const float *__restrict__ rstd1, const int8_t *__restrict__ grid_i8,
@@ -1314,9 +1326,10 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad_c1w(
             auto request_y = [&](int e, float (&dst)[4]) {
                 const int ez = e >> 2, ey = (e >> 1) & 1, ex = e & 1;
                 const int iz = min(2 * a + ez, O1 - 1), iy = min(2 * c + ey, O1 - 1);
-                const float *p = y1 + (((((uint32_t)b * O1 + iz) * O1 + iy) * 2 + ex) * NA + jb) * kC + m;
+                const uint32_t blk = ((((uint32_t)b * O1 + iz) * O1 + iy) * 2 + ex) * NA * kC;  // the (row, parity) block
+                const float *p = y1 + blk + (QM ? (uint32_t)(m >> 2) * NA * 4 + jb * 4 + (m & 3) : (uint32_t)jb * kC + m);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[r] = p[r * kC];
+                for (int r = 0; r < 4; ++r) dst[r] = p[r * (QM ? 4 : kC)];
             };
             request_y(0, Y[0]);
             request_y(1, Y[1]);
@@ -1956,6 +1969,17 @@ static inline bool conv1_i8_staged(const GnbvEncoderParams *p, int grid)
 // z1_path is OPT-IN (GENNBV_Z1=1): correct (tests) but measured slower on MI355X -- train 1144-1149 vs 1119-1122 ms per
 // iteration, same box: without the fma+max in front of their MFMAs conv2 forward / weight gradient do not get faster
 // (95 / 105 us: they wait on operand latency, not on the issue slot), so the saving is conv1's statistics only.
+// y1 / z1 stored quad-major (see y1q): the fp32 fused-backward path at the sizes the fp32-slab conv1 kernel takes; every kernel
+// that touches y1 on that path (conv1_fwd_lds, conv2_fwd(_lds), conv2_wgrad, conv2_dgrad_c1w) has the layout as a template flag.
+static inline bool y1_quad_major(const GnbvEncoderParams *p, int grid)
+{
+    // OPT-IN (GENNBV_Y1_QM=1).  Same-box A/B at B = 128, G = 64: k_conv2_fwd 98.3 -> 92.8 us, k_conv1_fwd_lds 73.8 -> 69.0 (contiguous
+    // 16-byte stores), k_conv2_dgrad_c1w unchanged, but k_conv2_wgrad 98.8 -> 118.7: its lanes are (channel, position) and now read
+    // 16 scattered 16-byte pieces per load instead of 256 contiguous bytes.  Becomes the default once the weight gradient loads
+    // [voxel][quad] vectors and transposes them through LDS (7 dwordx4 requests per item instead of 28 dword requests).
+    const char *z = getenv("GENNBV_Z1"), *q = getenv("GENNBV_Y1_QM");
+    return q && q[0] == '1' && fused_path(p, grid) && conv1_i8_staged(p, grid) && !(z && z[0] == '1');
+}
 static inline bool z1_path(const GnbvEncoderParams *p, int grid)
 {
     const char *e = getenv("GENNBV_Z1");
@@ -2000,7 +2024,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     float *bn1 = bn_state, *bn2 = bn_state + 4 * kC;
     int err;
     GNBV_CHECK_ARG(p->autocorr == nullptr || (p->autocorr_row_stride >= kAcRow && p->autocorr_row_stride % 4 == 0 && ((uintptr_t)p->autocorr & 15) == 0));
-    const bool z1 = z1_path(p, grid);
+    const bool z1 = z1_path(p, grid), qm = y1_quad_major(p, grid);
     if (z1) {
         // BN1 scale / shift first (training: analytic batch statistics from the input autocorrelation; eval: running
         // statistics), then conv1 with the BN + ReLU epilogue: the layer-1 buffer holds z1
@@ -2040,7 +2064,10 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
         const bool c1_staged = obs_grid != nullptr && (grid % 4 == 0) && (row_stride % 4 == 0) && (((uintptr_t)obs_grid & 15) == 0) && c1_lds <= 64 * 1024 &&
                                2 * O1 + 1 <= grid;
         const float *nozs = nullptr;
-        if (conv1_i8_staged(p, grid))  // compact int8 copy of the tri-class grid: a quarter of the input bytes
+        if (qm)
+            hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, int8_t, false, true>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, p->grid_i8, rows,
+                               p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, nozs, nozs, p->w2, w.w2img);
+        else if (conv1_i8_staged(p, grid))  // compact int8 copy of the tri-class grid: a quarter of the input bytes
             hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, int8_t>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, p->grid_i8, rows,
                                p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, nozs, nozs, p->w2, w.w2img);
         else if (c1_staged)
@@ -2076,14 +2103,26 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     } else if (z1) {
         hipLaunchKernelGGL((k_conv2_fwd<ActF32, true>), dim3(g2), dim3(kFwdThreads), 0, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
                        training ? w.bn_part : nullptr);
+    } else if (conv2_fwd_lds_path(O1, O2) && qm) {
+        static bool attr_set_q = false;
+        if (!attr_set_q) {
+            const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_fwd_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLdsBytes);
+            if (e != hipSuccess) return (int)e;
+            attr_set_q = true;
+        }
+        hipLaunchKernelGGL(k_conv2_fwd_lds<true>, dim3(g2), dim3(kFwdThreads), kFwdLdsBytes, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
+                           training ? w.bn_part : nullptr);
+    } else if (qm) {
+        hipLaunchKernelGGL((k_conv2_fwd<ActF32, false, true>), dim3(g2), dim3(kFwdThreads), 0, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
+                           training ? w.bn_part : nullptr);
     } else if (conv2_fwd_lds_path(O1, O2)) {
         static bool attr_set = false;
         if (!attr_set) {
-            const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_fwd_lds, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLdsBytes);
+            const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_fwd_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLdsBytes);
             if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_conv2_fwd_lds, dim3(g2), dim3(kFwdThreads), kFwdLdsBytes, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
+        hipLaunchKernelGGL(k_conv2_fwd_lds<false>, dim3(g2), dim3(kFwdThreads), kFwdLdsBytes, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
                            training ? w.bn_part : nullptr);
     } else {
         hipLaunchKernelGGL(k_conv2_fwd<ActF32>, dim3(g2), dim3(kFwdThreads), 0, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
@@ -2158,7 +2197,7 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     int err;
     // conv2 data gradient fused with the conv1 weight gradient (dz1' never stored) when the grid exists as aligned
     // int8 rows; the input autocorrelation it needs runs on a second stream beside the kernels below
-    const bool fused = fused_path(p, grid), z1 = z1_path(p, grid);  // (GENNBV_FUSED_BWD=0: A/B runs, bit-equality tests; GENNBV_Z1=1: opt-in)
+    const bool fused = fused_path(p, grid), z1 = z1_path(p, grid), qm = y1_quad_major(p, grid);  // (GENNBV_FUSED_BWD=0: A/B runs, bit-equality tests; GENNBV_Z1=1: opt-in)
     GNBV_CHECK_ARG(p->autocorr == nullptr || (p->autocorr_row_stride >= kAcRow && p->autocorr_row_stride % 4 == 0 && ((uintptr_t)p->autocorr & 15) == 0));
     // the input autocorrelation: per-sample rows computed when the observation was produced (p->autocorr), or
     // the minibatch total computed here
@@ -2192,6 +2231,9 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     } else if (z1) {
         hipLaunchKernelGGL((k_conv2_wgrad<ActF32, true>), dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
                        w.wg_part);
+    } else if (qm) {
+        hipLaunchKernelGGL((k_conv2_wgrad<ActF32, false, true>), dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
+                           w.wg_part);
     } else {
         hipLaunchKernelGGL(k_conv2_wgrad<ActF32>, dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
                        w.wg_part);
@@ -2214,6 +2256,9 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     if (fused) {
         if (z1)
             hipLaunchKernelGGL(k_conv2_dgrad_c1w<true>, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const float *)y1, bn1,
+                               bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->grid_i8, rows, p->grid_i8_row_stride, batch, grid, O1, O2, wg1_part);
+        else if (qm)
+            hipLaunchKernelGGL((k_conv2_dgrad_c1w<false, true>), dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const float *)y1, bn1,
                                bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->grid_i8, rows, p->grid_i8_row_stride, batch, grid, O1, O2, wg1_part);
         else
             hipLaunchKernelGGL(k_conv2_dgrad_c1w<false>, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const float *)y1, bn1,

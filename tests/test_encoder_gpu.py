@@ -76,7 +76,7 @@ def test_encoder_forward_backward_vs_torch_reference(g, b, conv2_lds, monkeypatc
     assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-6
 
 
-@pytest.mark.parametrize("z1", ["0", "1"])
+@pytest.mark.parametrize("z1", ["0", "1", "qm"])  # "qm": y1 stored quad-major (GENNBV_Y1_QM=1, opt-in layout of the same path)
 @pytest.mark.parametrize("g,b", [(16, 5), (32, 3), (48, 2), (64, 4), (128, 1)])
 def test_fused_dgrad_conv1_wgrad_vs_fp64_reference(g, b, z1, monkeypatch):
     """With the int8 grid rows present (G % 16 == 0) the backward runs k_conv2_dgrad_c1w: conv2 data gradient and conv1
@@ -84,7 +84,8 @@ def test_fused_dgrad_conv1_wgrad_vs_fp64_reference(g, b, z1, monkeypatch):
     gradients against the fp64 torch reference, tolerance = fp32 round-off; rows are gathered (RowGather).
     z1 = "1" (opt-in GENNBV_Z1): BN1 batch statistics analytically from the input autocorrelation, conv1 stores
     relu(bn1(y1)) (G <= 64; G = 128 keeps the y1 layout)."""
-    monkeypatch.setenv("GENNBV_Z1", z1)
+    monkeypatch.setenv("GENNBV_Z1", "1" if z1 == "1" else "0")
+    monkeypatch.setenv("GENNBV_Y1_QM", "1" if z1 == "qm" else "0")
     from gennbv_amd.ops.encoder_ops import RowGather, input_autocorr
     hip, _, _ = pu.make_policy(g=g, device=DEV, backend="hip", det_weights=True)
     ref, _, _ = pu.make_policy(g=g, device="cpu", backend="torch", det_weights=True)
