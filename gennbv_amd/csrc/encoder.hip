@@ -924,6 +924,51 @@ __device__ __forceinline__ void wave_row_range(int nrows, int &r0, int &r1)
 // MFMA: i = ci, j = co, k = 4 consecutive output positions along x.  27 accumulators / wave.
 // partial[w][tap][ci][co] (+ 16 bias sums), reduced by k_reduce_partials.
 // ---------------------------------------------------------------------------
+// The epilogue of the conv2 weight-gradient kernels (see k_conv2_wgrad): `red` = two buffers of kTaps * 256 + kC floats in LDS.
+__device__ __forceinline__ void wgrad_reduce_store(f32x4 (&acc)[kTaps], float bsum, float (*red)[kTaps * 256 + kC], float *__restrict__ partial, int lane,
+                                                   int wv, int n, int kq)
+{
+    // Workgroup-level sum in LDS, fixed order (w0 + w2) + (w1 + w3), then one partial row per workgroup: [tap][ci][co] +
+    // 16 bias sums.  Exchanges use one 16-byte LDS access per accumulator ([tap][lane] layout); only the final result is
+    // laid out for the row.  (The first version chained four read-modify-write passes of 108 dwords each: ~12 us.)
+    static_assert(kEncWaves == 4, "pairwise reduction below assumes four waves");
+    bsum = kgroup_sum(bsum);  // every lane: total of channel n
+    if (wv >= 2) {
+        f32x4 *dst = reinterpret_cast<f32x4 *>(red[wv - 2]);
+#pragma unroll
+        for (int tap = 0; tap < kTaps; ++tap) dst[tap * kWave + lane] = acc[tap];
+        if (lane < kC) red[wv - 2][kTaps * 256 + lane] = bsum;
+    }
+    __syncthreads();
+    if (wv < 2) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(red[wv]);
+#pragma unroll
+        for (int tap = 0; tap < kTaps; ++tap) acc[tap] += src[tap * kWave + lane];
+        bsum += red[wv][kTaps * 256 + n];
+    }
+    __syncthreads();
+    if (wv == 1) {
+        f32x4 *dst = reinterpret_cast<f32x4 *>(red[0]);
+#pragma unroll
+        for (int tap = 0; tap < kTaps; ++tap) dst[tap * kWave + lane] = acc[tap];
+        if (lane < kC) red[0][kTaps * 256 + lane] = bsum;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(red[0]);
+#pragma unroll
+        for (int tap = 0; tap < kTaps; ++tap) {
+            const f32x4 t = acc[tap] + src[tap * kWave + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[1][tap * 256 + (4 * kq + r) * kC + n] = t[r];
+        }
+        if (lane < kC) red[1][kTaps * 256 + lane] = bsum + red[0][kTaps * 256 + lane];
+    }
+    __syncthreads();
+    float *out = partial + (size_t)blockIdx.x * (kTaps * 256 + kC);
+    for (int o = threadIdx.x; o < kTaps * 256 + kC; o += kEncThreads) out[o] = red[1][o];
+}
+
 template <typename A, bool Z1 = false, bool QM = false /*quad-major y1*/>
 __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv2_wgrad(
     const typename A::T *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1,
@@ -1059,6 +1104,131 @@ __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(2, 
     float *out = partial + (size_t)blockIdx.x * (kTaps * 256 + kC);
     for (int o = threadIdx.x; o < kTaps * 256 + kC; o += kEncThreads) out[o] = red[1][o];
     (void)wave_global;
+}
+
+// ---------------------------------------------------------------------------
+// conv2 weight gradient for QUAD-MAJOR y1 (fp32).  Same work split, accumulators and epilogue as k_conv2_wgrad; what changes is
+// how the z1 operands reach the MFMAs.  k_conv2_wgrad's lanes are (channel n, position kq) and fetch 27 dwords each per item --
+// 28 wave-wide requests per 27 MFMAs, which is what bounds it (the CU's load path: profiles/r01_notes.md).  Here the 81 distinct
+// (row of 9, voxel of 5 even + 4 odd) x 16-channel pieces under an item are fetched as 16-byte [voxel][quad] vectors -- lane =
+// (quad a, piece i16 + 16 j): 6 requests whose neighbouring lanes read neighbouring voxels of one quad run = contiguous bytes --
+// BN + ReLU'd once, written to a per-wave LDS slab [piece][16 channels (+4 pad)] and read back in MFMA layout (lane (n, kq):
+// one ds_read_b32 per tap at an immediate offset).  Per item: 6 + 1 global requests, 6 LDS writes, 27 LDS reads, 27 MFMAs, and
+// no VALU between the MFMAs.
+// ---------------------------------------------------------------------------
+constexpr int kWgPieces = 81, kWgPieceStride = 20, kWgWaveLds = kWgPieces * kWgPieceStride;
+__global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv2_wgrad_qm(
+    const float *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1,
+    const float *__restrict__ dy2 /*[B,O2,O2,O2,16]*/, int B, int O1, int O2, float *__restrict__ partial)
+{
+    __shared__ __attribute__((aligned(16))) float smem[2 * (kTaps * 256 + kC)];  // the reduction buffers; the operand slabs alias their front
+    static_assert(kEncWaves * kWgWaveLds <= 2 * (kTaps * 256 + kC), "slabs must fit");
+    const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int n = lane & 15, kq = lane >> 4;  // MFMA roles: channel n, position kq
+    const int a = lane >> 4, i16 = lane & 15;  // staging roles: channel quad a, pieces i16 + 16 j
+    float sc4[4], sh4[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        sc4[s] = scale1[4 * a + s];
+        sh4[s] = shift1[4 * a + s];
+    }
+    f32x4 acc[kTaps];
+#pragma unroll
+    for (int t = 0; t < kTaps; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.0f;
+    const int nrows = B * O2 * O2;
+    int row0, row1;
+    wave_row_range(nrows, row0, row1);
+    const int ng = (O2 + 3) / 4, nitems = (row1 - row0) * ng;
+    const int XH = (O1 + 1) >> 1;
+    const uint32_t XHC = (uint32_t)XH * kC, rowC = 2 * XHC, planeC = rowC * O1;
+    // this lane's six pieces: p = i16 + 16 j -> (row = (dz, dy), w): w < 5 even-parity voxel e0 + w, else odd-parity voxel e0 + w - 5
+    constexpr int kSlots = (kWgPieces + 15) / 16;
+    uint32_t poff[kSlots];
+    int pw[kSlots];
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) {
+        const int pc = min(i16 + 16 * j, kWgPieces - 1), row = pc / 9, w = pc - 9 * row;
+        poff[j] = (uint32_t)(row / 3) * planeC + (uint32_t)(row % 3) * rowC + (w >= 5 ? XHC : 0) + (uint32_t)a * XH * 4;
+        pw[j] = w >= 5 ? w - 5 : w;
+    }
+    float *slab = smem + wv * kWgWaveLds;
+    struct Cursor {
+        int xg, oy, oz, b;
+        uint32_t ybase, dbase;
+    };
+    auto cursor_at = [&](int row) {
+        Cursor c;
+        c.b = row / (O2 * O2);
+        const int rem = row - c.b * O2 * O2;
+        c.oz = rem / O2;
+        c.oy = rem - c.oz * O2;
+        c.xg = 0;
+        c.ybase = vox1(c.b, 2 * c.oz, 2 * c.oy, 0, O1) * kC;  // (x = 0, parity 0: the same offset in both layouts)
+        c.dbase = (uint32_t)row * O2 * kC;
+        return c;
+    };
+    auto advance = [&](Cursor &c) {
+        if (++c.xg < ng) return;
+        c.xg = 0;
+        c.dbase += O2 * kC;
+        if (++c.oy == O2) {
+            c.oy = 0;
+            if (++c.oz == O2) { c.oz = 0; ++c.b; }
+        }
+        c.ybase = vox1(c.b, 2 * c.oz, 2 * c.oy, 0, O1) * kC;
+    };
+    Cursor rq = cursor_at(row0);
+    int requested = 0, cxg = 0;
+    auto request = [&](float &bv, float4 (&pc)[kSlots]) {
+        const int xc = min(4 * rq.xg + kq, O2 - 1);
+        bv = dy2[rq.dbase + xc * kC + n];
+        const int e0 = 4 * rq.xg;
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j)
+            pc[j] = *reinterpret_cast<const float4 *>(y1 + rq.ybase + poff[j] + (uint32_t)min(e0 + pw[j], XH - 1) * 4);
+        if (++requested < nitems) advance(rq);
+    };
+    auto consume = [&](int it, float bv, const float4 (&pc)[kSlots]) {
+        const bool ok = 4 * cxg + kq < O2 && it < nitems;
+        if (++cxg == ng) cxg = 0;
+        const float bb = ok ? bv : 0.0f;
+        bsum += bb;
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {
+            if (i16 + 16 * j < kWgPieces) {
+                float4 z;
+                z.x = fmaxf(fmaf(sc4[0], pc[j].x, sh4[0]), 0.f);
+                z.y = fmaxf(fmaf(sc4[1], pc[j].y, sh4[1]), 0.f);
+                z.z = fmaxf(fmaf(sc4[2], pc[j].z, sh4[2]), 0.f);
+                z.w = fmaxf(fmaf(sc4[3], pc[j].w, sh4[3]), 0.f);
+                *reinterpret_cast<float4 *>(slab + (i16 + 16 * j) * kWgPieceStride + 4 * a) = z;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float *rd = slab + kq * kWgPieceStride + n;
+#pragma unroll
+        for (int tap = 0; tap < kTaps; ++tap) {
+            const int row = tap / 3, dx = tap % 3, w0 = dx == 1 ? 5 : (dx == 2 ? 1 : 0);
+            acc[tap] = mfma4(rd[(row * 9 + w0) * kWgPieceStride], bb, acc[tap]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    float b0, b1;
+    float4 p0[kSlots], p1[kSlots];
+    if (nitems > 0) request(b0, p0);
+    for (int it = 0; it < nitems; it += 2) {
+        request(b1, p1);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(it, b0, p0);
+        __builtin_amdgcn_sched_barrier(0);
+        request(b0, p0);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(it + 1, b1, p1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();  // every wave is done with its slab before the reduction buffers are written over them
+    wgrad_reduce_store(acc, bsum, reinterpret_cast<float (*)[kTaps * 256 + kC]>(smem), partial, lane, wv, n, kq);
 }
 
 // partial-sum layout [tap][ci][co] (+16) -> torch layout dW2 [co][ci][27], db2 [16]
@@ -2231,6 +2401,8 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     } else if (z1) {
         hipLaunchKernelGGL((k_conv2_wgrad<ActF32, true>), dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
                        w.wg_part);
+    } else if (qm && !env_off("GENNBV_WGRAD_QM_LDS")) {
+        hipLaunchKernelGGL(k_conv2_wgrad_qm, dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2, w.wg_part);
     } else if (qm) {
         hipLaunchKernelGGL((k_conv2_wgrad<ActF32, false, true>), dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
                            w.wg_part);
