@@ -1063,46 +1063,8 @@ __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(2, 
         consume(it + 1, b1, a1);
         __builtin_amdgcn_sched_barrier(0);
     }
-    // Workgroup-level sum in LDS, fixed order (w0 + w2) + (w1 + w3), then one partial row per workgroup: [tap][ci][co] +
-    // 16 bias sums.  Exchanges use one 16-byte LDS access per accumulator ([tap][lane] layout); only the final result is
-    // laid out for the row.  (The first version chained four read-modify-write passes of 108 dwords each: ~12 us.)
-    static_assert(kEncWaves == 4, "pairwise reduction below assumes four waves");
     __shared__ __attribute__((aligned(16))) float red[2][kTaps * 256 + kC];
-    bsum = kgroup_sum(bsum);  // every lane: total of channel n
-    if (wv >= 2) {
-        f32x4 *dst = reinterpret_cast<f32x4 *>(red[wv - 2]);
-#pragma unroll
-        for (int tap = 0; tap < kTaps; ++tap) dst[tap * kWave + lane] = acc[tap];
-        if (lane < kC) red[wv - 2][kTaps * 256 + lane] = bsum;
-    }
-    __syncthreads();
-    if (wv < 2) {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(red[wv]);
-#pragma unroll
-        for (int tap = 0; tap < kTaps; ++tap) acc[tap] += src[tap * kWave + lane];
-        bsum += red[wv][kTaps * 256 + n];
-    }
-    __syncthreads();
-    if (wv == 1) {
-        f32x4 *dst = reinterpret_cast<f32x4 *>(red[0]);
-#pragma unroll
-        for (int tap = 0; tap < kTaps; ++tap) dst[tap * kWave + lane] = acc[tap];
-        if (lane < kC) red[0][kTaps * 256 + lane] = bsum;
-    }
-    __syncthreads();
-    if (wv == 0) {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(red[0]);
-#pragma unroll
-        for (int tap = 0; tap < kTaps; ++tap) {
-            const f32x4 t = acc[tap] + src[tap * kWave + lane];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[1][tap * 256 + (4 * kq + r) * kC + n] = t[r];
-        }
-        if (lane < kC) red[1][kTaps * 256 + lane] = bsum + red[0][kTaps * 256 + lane];
-    }
-    __syncthreads();
-    float *out = partial + (size_t)blockIdx.x * (kTaps * 256 + kC);
-    for (int o = threadIdx.x; o < kTaps * 256 + kC; o += kEncThreads) out[o] = red[1][o];
+    wgrad_reduce_store(acc, bsum, red, partial, lane, wv, n, kq);
     (void)wave_global;
 }
 
