@@ -57,6 +57,8 @@ def build_algo(args, device, rank, world):
     from gennbv_amd.env.config import TaskConfig, PPOConfig
     from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
     from gennbv_amd.network.hybrid_encoder import Hybrid_Encoder
+    if args.backend == "torch":  # A/B only: the test suite's plain-torch (MIOpen) reference encoder
+        from tests.torch_reference import TorchHybridEncoder as Hybrid_Encoder
     from gennbv_amd.sb3.policies import ActorCriticPolicy_Train_Eval
     from gennbv_amd.sb3.ppo_grid_obs import PPO_Grid_Obs
 
@@ -76,7 +78,6 @@ def build_algo(args, device, rank, world):
                                net_param={"transformer_params": [[1, 256], [1, 256]], "append_hidden_shapes": [256, 256]},
                                state_input_shape=(cfg.state_dim,),
                                visual_input_shape=(cfg.stack, cfg.camera_height, cfg.camera_width),
-                               grid_size=args.grid, backend=args.backend,
                                compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)))
     if world > 1 or os.environ.get("GENNBV_FORCE_DP") == "1":
         from gennbv_amd import parallel

@@ -86,7 +86,7 @@ class GnbvEnvPost(C.Structure):
                 ("coverage_count", _p), ("num_valid_voxel_gt", _p), ("prev_ratio", _p), ("episode_length_buf", _p),
                 ("rewards", _p), ("dones", _p), ("reset_mask", _p), ("step_time_out", _p), ("extras_time_outs", _p),
                 ("coverage_ratio", _p), ("episode_sums", _p), ("cur_reward_sum", _p), ("cur_episode_length", _p),
-                ("ring_reward", _p), ("ring_length", _p), ("ring_state", _p), ("ring_len", _i)]
+                ("ring_reward", _p), ("ring_length", _p), ("ring_state", _p), ("ring_len", _i), ("episode_means", _p)]
 
 
 class GnbvEncoderParams(C.Structure):

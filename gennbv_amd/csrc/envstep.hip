@@ -176,7 +176,21 @@ __global__ __launch_bounds__(kPostThreads) void k_env_post_step(GnbvEnvPost a)
         base_count += tile_total;
         __syncthreads();
     }
-    if (tid == 0) a.ring_state[0] += base_count;  // total finished episodes so far
+    if (tid == 0) {
+        const int64_t total = a.ring_state[0] + base_count;  // total finished episodes so far
+        a.ring_state[0] = total;
+        if (a.episode_means) {  // extras["episode"] snapshot of this step (np.mean of the two deques, base:638-639)
+            const int k = (int)(total < a.ring_len ? total : a.ring_len);
+            double sr = 0.0, sl = 0.0;
+            for (int i = 0; i < k; ++i) {  // deque order: oldest -> newest (this thread's own ring stores are visible to it;
+                const int64_t pos = total - k + i;  // the other lanes' were made before the last __syncthreads)
+                sr += (double)((const volatile float *)a.ring_reward)[pos % a.ring_len];
+                sl += (double)((const volatile float *)a.ring_length)[pos % a.ring_len];
+            }
+            a.episode_means[0] = k ? sr / k : 0.0;
+            a.episode_means[1] = k ? sl / k : 0.0;
+        }
+    }
     // infos["time_outs"]: refreshed only on steps where some env resets (reference quirk,
     // reset_idx returns early on an empty id list :390-391)
     const bool any = s_any != 0;

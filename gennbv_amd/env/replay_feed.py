@@ -85,10 +85,13 @@ class ReplayFeedEnv:
         from . import feed_file
         ff = feed_file.FeedFile(path)
         cfg = dataclasses.replace(cfg, camera_height=ff.height, camera_width=ff.width, grid_size=ff.grid_size)
-        return cls(cfg, feed_file.load_scene(ff, "cpu"), feed_file.load_feed(ff, device), device, max_episode_length)
+        # the recording's own inverse intrinsics (a different FOV than cfg's must not be back-projected with cfg's K)
+        kinv = torch.from_numpy(np.array(ff.scene("inv_intrinsics"), dtype=np.float32))
+        return cls(cfg, feed_file.load_scene(ff, "cpu"), feed_file.load_feed(ff, device), device, max_episode_length,
+                   inv_intrinsics=kinv)
 
     def __init__(self, cfg: TaskConfig, scene: S.Scene, feed: ReplayFeed, device="cuda:0",
-                 max_episode_length: Optional[int] = None):
+                 max_episode_length: Optional[int] = None, inv_intrinsics: Optional[torch.Tensor] = None):
         self.lib = _lib.load()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -102,7 +105,8 @@ class ReplayFeedEnv:
         self.max_episode_length_s = cfg.episode_length_s
         dev = self.device
         self.updater = OccupancyGridUpdater(n, cfg.grid_size, cfg.camera_height, cfg.camera_width,
-                                            S.inverse_intrinsics(cfg.camera_height, cfg.camera_width, cfg.horizontal_fov),
+                                            S.inverse_intrinsics(cfg.camera_height, cfg.camera_width, cfg.horizontal_fov)
+                                            if inv_intrinsics is None else inv_intrinsics,
                                             scene.range_gt, scene.voxel_size, scene.grid_gt, dev, cfg.depth_sense_dist,
                                             max_steps_between_resets=self.max_episode_length + 1)  # (+1: the reset observation)
         self.num_valid_voxel_gt = scene.num_valid_voxel_gt.to(dev, torch.float32).contiguous()
@@ -158,6 +162,11 @@ class ReplayFeedEnv:
         p.cur_episode_length = self.cur_episode_length.data_ptr()
         p.ring_reward, p.ring_length = self.ring_reward.data_ptr(), self.ring_length.data_ptr()
         p.ring_state, p.ring_len = self.ring_state.data_ptr(), self.ring_len
+        # extras["episode"] snapshots: k_env_post_step writes this step's (mean reward, mean length) into slot
+        # step % H; the dict handed out with the step reads its own slot on demand (no per-step host sync)
+        self._ep_hist = 1024
+        self.episode_means = z(self._ep_hist, 2, dt=torch.float64)
+        self._ep_step = 0
         self._post = p
         self.extras = {}
 
@@ -216,6 +225,8 @@ class ReplayFeedEnv:
                                 tri_out=obs[:, cfg.state_dim:], tri_row_stride=stride,
                                 tri_i8_out=grid_i8_out if self.updater.coded else None)
         # rewards / termination / reset bookkeeping
+        self._ep_step += 1
+        self._post.episode_means = self.episode_means[self._ep_step % self._ep_hist].data_ptr()
         _lib.check(lib.gnbv_env_post_step(C.byref(self._post), st), "gnbv_env_post_step")
         return obs
 
@@ -240,31 +251,33 @@ class ReplayFeedEnv:
         a = actions.to(torch.int64).contiguous()
         obs = self._observe_and_finish(a, obs_out, grid_i8_out)
         self.extras["time_outs"] = self.extras_time_outs.bool()
-        self.extras["episode"] = _LazyEpisodeInfo(self)
+        self.extras["episode"] = _LazyEpisodeInfo(self, self._ep_step)
         return obs, self.rew_buf, self.reset_buf.bool(), self.extras
 
     # ------------------------------------------------------------------------
-    def episode_info(self):
-        """extras["episode"] of the reference (reset_idx :424-428, update_extra_episode_info
-        base:629-639), evaluated on demand from device state (the reference pays a .cpu() per step)."""
-        k = int(min(int(self.ring_state.item()), self.ring_len))
-        out = {"episode_reward": float(self.ring_reward[:k].mean()) if k else 0.0,
-               "episode_length": float(self.ring_length[:k].mean()) if k else 0.0}
-        return out
+    def episode_info(self, step: Optional[int] = None):
+        """extras["episode"] of the reference (reset_idx :424-428, update_extra_episode_info base:629-639) as it was
+        at env step `step` (default: the latest), read on demand from the device snapshot the post-step kernel wrote
+        (the reference pays a .cpu() per step)."""
+        step = self._ep_step if step is None else step
+        if self._ep_step - step >= self._ep_hist:
+            raise _lib.GennbvHipError("episode info of a step older than the snapshot history")
+        m = self.episode_means[step % self._ep_hist].cpu()
+        return {"episode_reward": float(m[0]), "episode_length": float(m[1])}
 
 
 class _LazyEpisodeInfo(dict):
-    """Behaves like the reference's extras["episode"] dict but costs nothing unless read."""
+    """The reference's extras["episode"] dict of ONE env step; filled from the device snapshot of that step the
+    first time anything reads it (every dict accessor fills first)."""
 
-    def __init__(self, env):
+    def __init__(self, env, step):
         super().__init__()
-        self._env = env
-        self._done = False
+        self._env, self._step, self._done = env, step, False
 
     def _fill(self):
         if not self._done:
             self._done = True
-            super().update(self._env.episode_info())
+            super().update(self._env.episode_info(self._step))
 
     def __getitem__(self, k):
         self._fill()
@@ -274,9 +287,21 @@ class _LazyEpisodeInfo(dict):
         self._fill()
         return super().__iter__()
 
+    def __contains__(self, k):
+        self._fill()
+        return super().__contains__(k)
+
+    def __len__(self):
+        self._fill()
+        return super().__len__()
+
     def keys(self):
         self._fill()
         return super().keys()
+
+    def values(self):
+        self._fill()
+        return super().values()
 
     def items(self):
         self._fill()
@@ -285,3 +310,21 @@ class _LazyEpisodeInfo(dict):
     def get(self, k, d=None):
         self._fill()
         return super().get(k, d)
+
+    def __repr__(self):
+        self._fill()
+        return super().__repr__()
+
+    def __eq__(self, o):
+        self._fill()
+        return super().__eq__(o)
+
+    def copy(self):
+        self._fill()
+        return super().copy()
+
+    __hash__ = None
+
+    def __bool__(self):
+        self._fill()
+        return super().__len__() > 0

@@ -1,7 +1,7 @@
 """Hybrid_Encoder: the multi-source (pose history + occupancy grid) features extractor.
 
 Drop-in for `gennbv/network/hybrid_encoder.py:18-98` behind the SB3 features-extractor
-protocol (constructor kwargs of gennbv/train/train_gennbv.py:152-168, `.features_dim`,
+protocol (constructor kwargs of gennbv/train/train_gennbv.py:152-168 unchanged, `.features_dim`,
 `forward(observations[B, D_obs]) -> [B, features_dim]`), with the reference's
 `state_dict` key names so its checkpoints load unchanged:
 
@@ -10,20 +10,26 @@ protocol (constructor kwargs of gennbv/train/train_gennbv.py:152-168, `.features
     naive_encoder_action.{0,2}.*     Linear(stack*24, 256), Linear(256, 256)
     output_layer.0.*                 Linear(512, 256)
 
-Differences, all additive: the grid edge G is a parameter (the reference hard-codes
-20^3 / 8000 / 1024, hybrid_encoder.py:47,90-91; G=20 reproduces it exactly), and the
-heavy layers can run on the hand-written gfx950 kernels (`backend="hip"`, see
-gennbv_amd/ops) instead of torch's library kernels (`backend="torch"`, the fp32
-parity reference for the floating-point kernels).
-The released encoder never reads the `state_rgb` slice of the observation (:76-98);
-neither does this one.
+The modules only HOLD the parameters (torch layouts, reference keys); every forward / backward
+runs on the hand-written gfx950 kernels through the C-ABI (gennbv_amd/ops/encoder_ops.py).  There is
+no second implementation in the product: a CPU tensor is refused (`GennbvHipError`).  The plain-torch
+restatement of the reference forward that the floating-point parity tests compare against lives in
+tests/torch_reference.py.
+
+Additive: the grid edge G is inferred from `observation_space` (flat row = state | G^3 | two 64x64 gray
+frames, env_wrapper_gennbv_train.py:104-110) or given as `grid_size`; the reference hard-codes
+20^3 / 8000 / 1024 (hybrid_encoder.py:47,90-91) and G=20 reproduces it exactly.
+The released encoder never reads the `state_rgb` slice of the observation (:76-98); neither does this one.
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+import copy
+from typing import List, Optional, Tuple
 
 import torch
 from torch import nn
+
+RGB_DIM = 2 * 64 * 64  # obs["state_rgb"]: the two most recent 64x64 gray frames (env_train_gennbv.py:363)
 
 
 def conv_out(g: int) -> Tuple[int, int]:
@@ -31,9 +37,24 @@ def conv_out(g: int) -> Tuple[int, int]:
     return o1, (o1 - 3) // 2 + 1
 
 
+def infer_grid_size(observation_space, state_dim: int) -> int:
+    """G from the flat observation width; 20 (the reference's literal) when the space does not say."""
+    shape = getattr(observation_space, "shape", None)
+    if not shape:
+        return 20
+    cells = int(shape[-1]) - int(state_dim) - RGB_DIM
+    g = round(max(cells, 0) ** (1.0 / 3.0))
+    for c in (g - 1, g, g + 1):
+        if c > 0 and c ** 3 == cells:
+            return c
+    return 20
+
+
 class Hybrid_Encoder(nn.Module):
+    backend = "hip"  # the only implementation of the product class (tests/torch_reference.py subclasses it as "torch")
+
     def __init__(self, observation_space, encoder_param=None, net_param=None, visual_input_shape=None,
-                 state_input_shape=None, grid_size: int = 20, backend: str = "torch", compute_dtype=torch.float32):
+                 state_input_shape=None, grid_size: Optional[int] = None, compute_dtype=torch.float32):
         assert encoder_param is not None, "Need parameters !"
         assert net_param is not None, "Need parameters !"
         assert isinstance(visual_input_shape, (List, Tuple, list, tuple)), "Use tuple or list"
@@ -42,14 +63,13 @@ class Hybrid_Encoder(nn.Module):
         self.image_channel = visual_input_shape[0]
         self.image_shape = visual_input_shape[1:]
         self.state_input_shape = state_input_shape
-        # the reference pops the last entry in place (hybrid_encoder.py:32-33)
-        self._features_dim = net_param["append_hidden_shapes"][-1]
-        net_param["append_hidden_shapes"].pop()
+        # the reference pops the last entry of the CALLER's list in place (hybrid_encoder.py:32-33), which breaks a
+        # second construction from the same policy_kwargs (save -> load -> save); read it without mutating
+        self._features_dim = copy.deepcopy(net_param)["append_hidden_shapes"][-1]
         self._observation_space = observation_space
-        self.grid_size = int(grid_size)
-        self.backend = backend
+        self.grid_size = int(grid_size) if grid_size is not None else infer_grid_size(observation_space, state_input_shape[0])
         self.compute_dtype = compute_dtype
-        self.overlap_branches = True  # backend="hip": pose branch on a second stream
+        self.overlap_branches = True  # pose branch on a second stream
         o1, o2 = conv_out(self.grid_size)
         self.grid_feat = 16 * o2 ** 3  # 1024 at G=20
         pose_feat = int(state_input_shape[0]) * 4  # 6 -> 24 per pose (sin/cos of x*{1,2})
@@ -77,18 +97,5 @@ class Hybrid_Encoder(nn.Module):
         return torch.cat([torch.sin(pts), torch.cos(pts)], dim=-1)
 
     def forward(self, observations) -> torch.Tensor:
-        if self.backend == "hip":
-            from ..ops import encoder_ops
-            return encoder_ops.hybrid_forward(self, observations)
-        if not isinstance(observations, torch.Tensor):  # ops.encoder_ops.RowGather
-            observations = observations.materialize()
-        num_env = observations.shape[0]
-        s = self.state_input_shape[0]
-        g = self.grid_size
-        action_input = observations[:, :s].view(num_env, -1, 6)
-        action_input = self.positional_encoding(action_input).view(num_env, -1)
-        grid_input = observations[:, s:s + g ** 3].reshape(num_env, 1, g, g, g)
-        feature_action = self.naive_encoder_action(action_input)
-        feature_grid = self.naive_encoder_grid(grid_input).reshape(num_env, -1)
-        feature_grid = self.output_layer_grid(feature_grid)
-        return self.output_layer(torch.cat((feature_action, feature_grid), dim=-1))
+        from ..ops import encoder_ops
+        return encoder_ops.hybrid_forward(self, observations)

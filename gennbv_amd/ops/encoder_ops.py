@@ -293,6 +293,7 @@ def hybrid_branches(enc, observations):
         num_env = int(rows.shape[0]) if rows is not None else int(base.shape[0])
         get_state = lambda: observations.columns(0, s)  # noqa: E731  (gather of the pose columns: on the side stream too)
     else:
+        _lib.require_cuda(observations)  # no CPU implementation in the product (tests/torch_reference.py is the checker)
         base, rows = observations, None
         num_env = int(observations.shape[0])
         get_state = lambda: observations[:, :s]  # noqa: E731

@@ -116,20 +116,21 @@ class PPO_Grid_Obs:
     def _setup_model(self) -> None:
         self.lr_schedule = _schedule(self.learning_rate)
         self.set_random_seed(self.seed)
+        # (the reference builds the buffer first, :base 408-477; neither step draws from an RNG the other uses)
+        self.policy = self.policy_class(self.observation_space, self.action_space, self.lr_schedule, use_sde=False,
+                                        **self.policy_kwargs).to(self.device)
+        enc = self.policy.features_extractor
+        hip = getattr(enc, "backend", "torch") == "hip"
         compact = None
         if self.compact_obs:
-            fek = self.policy_kwargs.get("features_extractor_kwargs", {})
-            g, s0 = int(fek.get("grid_size", 20)), int(fek["state_input_shape"][0])
-            if not (getattr(self.env, "supports_grid_i8", False) and fek.get("backend", "torch") == "hip" and self.device.type == "cuda"):
-                raise ValueError("compact_obs needs an env that writes the int8 grid rows (supports_grid_i8), the encoder "
-                                 "backend 'hip' and a GPU device")
-            compact = (s0, g ** 3)
+            if not (getattr(self.env, "supports_grid_i8", False) and hip and self.device.type == "cuda"):
+                raise ValueError("compact_obs needs an env that writes the int8 grid rows (supports_grid_i8), the gfx950 "
+                                 "encoder and a GPU device")
+            compact = (int(enc.state_input_shape[0]), int(enc.grid_size) ** 3)
         self.rollout_buffer = TensorRolloutBuffer_Grid_Obs(self.n_steps, self.observation_space, self.action_space,
                                                            device=self.device, gamma=self.gamma,
                                                            gae_lambda=self.gae_lambda, n_envs=self.n_envs, compact=compact)
-        self.policy = self.policy_class(self.observation_space, self.action_space, self.lr_schedule, use_sde=False,
-                                        **self.policy_kwargs).to(self.device)
-        self.rollout_buffer.lazy_obs = getattr(self.policy.features_extractor, "backend", "torch") == "hip"
+        self.rollout_buffer.lazy_obs = hip
         self.clip_range = _schedule(self.clip_range)
         if self.clip_range_vf is not None:
             if isinstance(self.clip_range_vf, (float, int)):
@@ -187,12 +188,13 @@ class PPO_Grid_Obs:
         save_util.save_to_zip_file(path, data=data, params=params, pytorch_variables={})
 
     @classmethod
-    def load(cls, path, env=None, device="auto", custom_objects=None, policy=None, **kwargs) -> "PPO_Grid_Obs":
+    def load(cls, path, env=None, device="auto", custom_objects=None, policy=None, trusted: bool = False, **kwargs) -> "PPO_Grid_Obs":
         """Re-create the algorithm from a zip.  Plain hyper-parameters come from `data`; entries pickled with
         classes that are not importable here (the reference's policy class, spaces, schedules) are replaced by
-        `policy` / the env's spaces / kwargs."""
+        `policy` / the env's spaces / kwargs.  Pickled entries of `data` pass a restricted unpickler unless
+        `trusted=True` (sb3/save_util.py)."""
         from . import save_util
-        data, params, _, skipped = save_util.load_from_zip_file(path, custom_objects=custom_objects, device="cpu")
+        data, params, _, skipped = save_util.load_from_zip_file(path, custom_objects=custom_objects, device="cpu", trusted=trusted)
         data = data or {}
         if env is None:
             raise ValueError("PPO_Grid_Obs.load needs the (replay-feed) env: stored environments are not restored")
@@ -206,6 +208,9 @@ class PPO_Grid_Obs:
             if k in data and k not in skipped:
                 ctor[k] = data[k]
         ctor.update(kwargs)
+        if "policy_kwargs" not in ctor:
+            raise ValueError("the archive's policy_kwargs could not be restored (entries skipped by the restricted unpickler: "
+                             f"{skipped}); pass policy_kwargs=... or, for an archive you trust, trusted=True")
         model = cls(policy_class, env, device=device, **ctor)
         for k in ("num_timesteps", "_n_updates", "_current_progress_remaining"):
             if k in data:

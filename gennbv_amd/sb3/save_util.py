@@ -11,9 +11,12 @@ Layout (stable_baselines3/common/save_util.py:289-330 of the reference): a ZIP_S
   _stable_baselines3_version   text
   system_info.txt              text
 
-Reading never needs the reference's classes: the two state dicts are plain tensors and from `data` only
-JSON-plain hyper-parameters are consumed (":serialized:" blobs are unpickled when cloudpickle can resolve
-their classes, otherwise skipped and listed in the returned `skipped`).
+Reading never needs the reference's classes: the two state dicts are plain tensors (`weights_only=True`) and from
+`data` only JSON-plain hyper-parameters are consumed.  ":serialized:" blobs go through a RESTRICTED unpickler
+(`_SafeUnpickler`: plain containers / numbers, numpy arrays and dtypes, torch dtypes, and this package's own classes)
+-- anything else (the reference's own classes, cloudpickled lambdas, arbitrary callables) is skipped and listed in
+the returned `skipped`, so loading an untrusted archive cannot execute code from it.  `trusted=True` restores SB3's
+behaviour (full cloudpickle) for archives you wrote yourself.
 """
 from __future__ import annotations
 
@@ -63,19 +66,47 @@ def data_to_json(data: Dict[str, Any]) -> str:
     return json.dumps(out, indent=4)
 
 
-def json_to_data(text: str, custom_objects: Optional[Dict[str, Any]] = None) -> Tuple[Dict[str, Any], list]:
-    """save_util.py:129-172; entries that cannot be unpickled here are skipped (returned by name)."""
-    try:
-        import cloudpickle as pk
-    except ImportError:  # pragma: no cover
-        pk = pickle
+_SAFE_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray", "complex",
+                  "slice", "range", "NoneType"}
+_SAFE_GLOBALS = {("collections", "OrderedDict"), ("collections", "deque"),
+                 ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy", "float32"), ("numpy", "float64"), ("numpy", "int64"),
+                 ("numpy", "int32"), ("numpy", "bool_"),
+                 ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+                 ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+                 ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),
+                 ("torch", "float32"), ("torch", "float64"), ("torch", "bfloat16"), ("torch", "float16"), ("torch", "Size")}
+
+
+class _SafeUnpickler(pickle.Unpickler):
+    """Resolves only data-like globals; classes of this package are allowed by module prefix."""
+
+    def find_class(self, module, name):
+        if module == "builtins" and name in _SAFE_BUILTINS:
+            return super().find_class(module, name)
+        if (module, name) in _SAFE_GLOBALS or module == "gennbv_amd" or module.startswith("gennbv_amd."):
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"global {module}.{name} is not on the allow-list")
+
+
+def _loads(blob: bytes, trusted: bool):
+    if trusted:
+        try:
+            import cloudpickle as pk
+        except ImportError:  # pragma: no cover
+            pk = pickle
+        return pk.loads(blob)
+    return _SafeUnpickler(io.BytesIO(blob)).load()
+
+
+def json_to_data(text: str, custom_objects: Optional[Dict[str, Any]] = None, trusted: bool = False) -> Tuple[Dict[str, Any], list]:
+    """save_util.py:129-172; entries that cannot be (or may not be) unpickled here are skipped (returned by name)."""
     data, skipped = {}, []
     for key, item in json.loads(text).items():
         if custom_objects is not None and key in custom_objects:
             data[key] = custom_objects[key]
         elif isinstance(item, dict) and ":serialized:" in item:
             try:
-                data[key] = pk.loads(base64.b64decode(item[":serialized:"].encode()))
+                data[key] = _loads(base64.b64decode(item[":serialized:"].encode()), trusted)
             except Exception:  # class not importable here (the reference's own modules)
                 skipped.append(key)
         else:
@@ -102,7 +133,7 @@ def save_to_zip_file(path, data: Optional[Dict[str, Any]], params: Dict[str, Any
                                       f"GPU Enabled: {torch.cuda.is_available()}\nwritten by: gennbv_amd\n")
 
 
-def load_from_zip_file(path, load_data: bool = True, custom_objects=None, device="cpu"):
+def load_from_zip_file(path, load_data: bool = True, custom_objects=None, device="cpu", trusted: bool = False):
     """-> (data or None, {name: state_dict}, pytorch_variables or None, skipped data keys)."""
     if isinstance(path, (str, os.PathLike)):
         path = os.fspath(path)
@@ -113,7 +144,7 @@ def load_from_zip_file(path, load_data: bool = True, custom_objects=None, device
         with zipfile.ZipFile(path) as z:
             names = z.namelist()
             if "data" in names and load_data:
-                data, skipped = json_to_data(z.read("data").decode(), custom_objects)
+                data, skipped = json_to_data(z.read("data").decode(), custom_objects, trusted)
             for n in names:
                 if os.path.splitext(n)[1] != ".pth":
                     continue

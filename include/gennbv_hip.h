@@ -194,7 +194,15 @@ typedef struct GnbvEnvPost {
     float *cur_episode_length;      /* in/out */
     float *ring_reward;             /* in/out [ring_len]: rewbuffer (deque maxlen 100) */
     float *ring_length;             /* in/out [ring_len]: lenbuffer */
-    int64_t *ring_state;            /* Tail of one rollout step in one launch: the time-out bootstrap `rewards += gamma * squeeze(terminal_value * time_outs)`
+    int64_t *ring_state;            /* in/out [1]: episodes finished so far */
+    int ring_len;
+    double *episode_means;          /* out [2] or NULL: extras["episode"] of THIS step -- mean of rewbuffer / lenbuffer
+                                       (np.mean over the deques, env_train_base.py:638-639; 0 when empty), fp64 */
+} GnbvEnvPost;
+
+int gnbv_env_post_step(const GnbvEnvPost *args /*[host]*/, void *stream);
+
+/* Tail of one rollout step in one launch: the time-out bootstrap `rewards += gamma * squeeze(terminal_value * time_outs)`
  * (on_policy_algorithm_grid_obs.py:205-208; same fp32 operation order) and the five copies of
  * TensorRolloutBuffer_Grid_Obs.add (stable_baselines3/common/buffers.py:676-704) into row `step` of the buffer arrays
  * (caller passes the row pointers): actions int64 [N,A] -> f32, episode_starts bool/u8 [N] -> u8, rewards / values /
@@ -203,12 +211,6 @@ int gnbv_rollout_add(int n, int action_dim, const int64_t *actions, const float 
                      const float *terminal_value, float gamma, const uint8_t *episode_starts, const float *values,
                      const float *log_probs, float *buf_actions, float *buf_rewards, uint8_t *buf_episode_starts, float *buf_values,
                      float *buf_log_probs, void *stream);
-
-/* in/out [1]: episodes finished so far */
-    int ring_len;
-} GnbvEnvPost;
-
-int gnbv_env_post_step(const GnbvEnvPost *args /*[host]*/, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* B1  Hybrid_Encoder grid branch (gennbv/network/hybrid_encoder.py:38-45,90-94): */

@@ -238,6 +238,7 @@ def gen_envstep(ref, name, n, h, w, g, num_frames, num_steps, max_ep_len, seed, 
     # _setup_learn overwrites episode_length_buf (base_class_grid_obs.py:471-475); we use a fixed stagger
     env.episode_length_buf = init_len.clone()
     rewards, dones, timeouts, cover, tri_sha, prob_sha, scan_sha, obs_sha, c2w_all = [], [], [], [], [], [], [], [], []
+    ep_info = []  # extras["episode"] of every step: np.mean of the rewbuffer / lenbuffer deques (env_train_base.py:638-639)
     keep = {}
     for s in range(num_steps):
         fi = (s + 1) % num_frames
@@ -258,6 +259,7 @@ def gen_envstep(ref, name, n, h, w, g, num_frames, num_steps, max_ep_len, seed, 
         rewards.append(rew.numpy().copy()); dones.append(done.numpy().copy())
         timeouts.append(info["time_outs"].numpy().copy())
         cover.append(env.reward_ratio_buf[-1].numpy().copy())
+        ep_info.append([float(info["episode"]["episode_reward"]), float(info["episode"]["episode_length"])])
         tri = obs["grid"].numpy()
         tri_sha.append(sha(tri.astype(np.float32))); prob_sha.append(sha(snap["prob"])); scan_sha.append(sha(snap["scan"]))
         obs_sha.append(sha(flat))
@@ -271,7 +273,7 @@ def gen_envstep(ref, name, n, h, w, g, num_frames, num_steps, max_ep_len, seed, 
     out.update(keep)
     out.update(rewards=np.stack(rewards), dones=np.stack(dones), time_outs=np.stack(timeouts), coverage=np.stack(cover),
                tri_sha=np.array(tri_sha), prob_sha=np.array(prob_sha), scan_sha=np.array(scan_sha),
-               flat_obs_sha=np.array(obs_sha))
+               flat_obs_sha=np.array(obs_sha), episode_info=np.array(ep_info, np.float64))
     np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
     print(name, "saved; mean fg", float((out["seg"] > 50).mean()), "resets", int(np.stack(dones).sum()))
 

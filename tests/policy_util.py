@@ -18,13 +18,13 @@ def spaces(g=G):
 
 
 def policy_kwargs(g=G, backend="torch", **enc_kw):
-    from gennbv_amd.network.hybrid_encoder import Hybrid_Encoder
-    return dict(net_arch=[], features_extractor_class=Hybrid_Encoder,
+    from tests.torch_reference import encoder_class
+    return dict(net_arch=[], features_extractor_class=encoder_class(backend),
                 features_extractor_kwargs=dict(encoder_param={"hidden_shapes": [256, 256], "visual_dim": 256},
                                                net_param={"transformer_params": [[1, 256], [1, 256]],
                                                           "append_hidden_shapes": [256, 256]},
                                                state_input_shape=(STACK * 6,), visual_input_shape=(STACK, 400, 400),
-                                               grid_size=g, backend=backend, **enc_kw))
+                                               grid_size=g, **enc_kw))
 
 
 def make_policy(g=G, device="cpu", backend="torch", det_weights=True, **enc_kw):

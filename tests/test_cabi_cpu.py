@@ -48,3 +48,20 @@ def test_product_package_never_imports_oracle():
                 src = open(os.path.join(dp, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
                 assert "liboracle" not in src, fn
+
+
+@pytest.mark.parametrize("cc,lang", [("gcc", "c"), ("g++", "c++")])
+def test_public_header_compiles_as_c_and_cxx(cc, lang, tmp_path):
+    """include/gennbv_hip.h is the drop-in boundary: it must parse as plain C and as C++, and a consumer must be able
+    to name every declared function and fill the structs."""
+    import shutil
+    import subprocess
+    if shutil.which(cc) is None:
+        pytest.skip(cc + " not installed")
+    src = tmp_path / ("use." + ("c" if lang == "c" else "cpp"))
+    calls = "\n".join(f"    p[{i}] = (void *){s};" for i, s in enumerate(declared_symbols()))
+    src.write_text('#include "gennbv_hip.h"\n#include <stddef.h>\nint main(void) {\n    void *p[128];\n' + calls +
+                   "\n    GnbvEnvPost e; e.ring_state = NULL; e.ring_len = 100; e.episode_means = NULL;\n"
+                   "    GnbvEncoderParams q; q.grid_i8 = NULL;\n    return p[0] == NULL && e.ring_len == 0 && q.grid_i8 != NULL;\n}\n")
+    subprocess.check_call([cc, "-fsyntax-only", "-Wall", "-Werror", "-Wno-unused-but-set-variable", "-x", lang,
+                           "-I", os.path.join(ROOT, "include"), str(src)])

@@ -4,6 +4,7 @@ import os
 import zipfile
 
 import numpy as np
+import pytest
 import torch
 
 from tests import golden_util as gu
@@ -82,7 +83,9 @@ def test_own_roundtrip_and_layout(tmp_path):
     full = str(tmp_path / "ckpt_full")
     a.save(full, include_optimizer=True)
     from gennbv_amd.sb3.ppo_grid_obs import PPO_Grid_Obs
-    b = PPO_Grid_Obs.load(full, env=_Env(), device="cpu")
+    with pytest.raises(ValueError):  # policy_kwargs names a class outside the allow-list (tests.torch_reference)
+        PPO_Grid_Obs.load(full, env=_Env(), device="cpu")
+    b = PPO_Grid_Obs.load(full, env=_Env(), device="cpu", trusted=True)
     assert b.num_timesteps == 123 and b._n_updates == 7 and b.n_steps == a.n_steps
     for (k, x), (_, y) in zip(a.policy.state_dict().items(), b.policy.state_dict().items()):
         assert torch.equal(x, y), k
@@ -122,3 +125,19 @@ def test_best_checkpoint_callback_protocol(tmp_path):
     # rollout 0: mean 1 -> best; rollout 1: n_calls = 4 -> periodic, mean 2 -> best; rollout 2: mean 2 -> no new best
     assert saved == ["gennbv_best_episode_reward", "gennbv_32_steps", "gennbv_best_episode_reward"]
     assert abs(cb.key_highest_value["episode_reward"] - 2.0) < 1e-6
+
+
+def test_untrusted_archive_cannot_execute_code(tmp_path):
+    """A ':serialized:' blob whose pickle calls os.system must be skipped by the restricted unpickler."""
+    import base64, json, pickle
+    from gennbv_amd.sb3 import save_util
+    marker = tmp_path / "pwned"
+
+    class _Evil:
+        def __reduce__(self):
+            return (os.system, (f"touch {marker}",))
+    text = json.dumps({"n_steps": 8, "policy_kwargs": {":type:": "x", ":serialized:": base64.b64encode(pickle.dumps(_Evil())).decode()},
+                       "plain": {":type:": "dict", ":serialized:": base64.b64encode(pickle.dumps({"a": [1, 2.5, "s"]})).decode()}})
+    data, skipped = save_util.json_to_data(text)
+    assert skipped == ["policy_kwargs"] and data["plain"] == {"a": [1, 2.5, "s"]} and data["n_steps"] == 8
+    assert not marker.exists()

@@ -45,10 +45,14 @@ def test_replay_env_matches_reference_env_bit_exact(name):
     assert sha(obs.cpu().numpy()) == str(fx["reset_flat_obs_sha"])
     assert env.prob_grid.cpu().numpy().tobytes() == fx["reset_prob"].tobytes()
     env.episode_length_buf.copy_(torch.from_numpy(fx["init_episode_length"].astype(np.int64)))
+    lazy = []
     for s in range(int(fx["num_steps"])):
         fi = (s + 1) % nf
         env.feed.cursor = fi
         obs, rew, done, info = env.step(torch.from_numpy(fx["actions"][fi]).to(DEV))
+        lazy.append(info["episode"])  # read only after the loop: must still show THIS step's deque means
+        if s % 3 == 0:  # ... and some are read at once
+            assert abs(info["episode"]["episode_reward"] - fx["episode_info"][s][0]) < 1e-9
         assert rew.cpu().numpy().tobytes() == fx["rewards"][s].tobytes(), f"step {s}"
         assert np.array_equal(done.cpu().numpy(), fx["dones"][s].astype(bool)), f"step {s}"
         assert np.array_equal(info["time_outs"].cpu().numpy(), fx["time_outs"][s]), f"step {s}"
@@ -57,6 +61,13 @@ def test_replay_env_matches_reference_env_bit_exact(name):
         assert sha(obs.cpu().numpy()) == str(fx["flat_obs_sha"][s]), f"step {s} flat obs"
         assert sha(env.prob_grid.cpu().numpy()) == str(fx["prob_sha"][s])
         assert sha(env.scanned_gt_grid.cpu().numpy()) == str(fx["scan_sha"][s])
+    # extras["episode"] (env_train_base.py:629-639) of every step, materialised late from the device snapshots; every
+    # dict accessor must fill the entry (BestCKPTCallback asserts `key in buf[0]` on a never-read one)
+    for s, e in enumerate(lazy):
+        if s % 2:
+            assert "episode_reward" in e and len(e) == 2 and bool(e)
+        got = [e["episode_reward"], e["episode_length"]] if s % 4 else list(e.values())
+        np.testing.assert_allclose(got, fx["episode_info"][s], rtol=0, atol=1e-9, err_msg=f"step {s}")
 
 
 def test_replay_env_writes_into_caller_rows_and_tracks_episodes():
@@ -216,3 +227,37 @@ def test_eval_env_accuracy_metric_and_five_tuple():
 
     rews, lens, auc, acc = evaluate_policy_grid_obs(_Model, env2, n_eval_episodes=n, max_length=L)
     assert len(acc) == n and all(a > 0 for a in acc) and auc.shape == (n,)
+
+
+def test_best_checkpoint_callback_over_real_env_infos(tmp_path):
+    """gennbv/callback.py:25-70 driven by the env's own (lazy) extras["episode"] entries: the mean over the buffer
+    equals the mean of the reference's per-step values (F5 c0 has 12 episode ends in 30 steps)."""
+    from collections import deque
+    from gennbv_amd.callback import BestCKPTCallback
+    fx = gu.load("F5_envstep_c0")
+    env, cfg = make_env_from_fixture(fx)
+    nf = int(fx["num_frames"])
+    env.feed.cursor = 0
+    env.reset()
+    env.episode_length_buf.copy_(torch.from_numpy(fx["init_episode_length"].astype(np.int64)))
+    saved = []
+
+    class _Model:
+        num_timesteps = 0
+        ep_info_buffer = deque(maxlen=100)
+        logger = type("L", (), {})()
+
+        def save(self, path):
+            saved.append(os.path.basename(path))
+    m = _Model()
+    cb = BestCKPTCallback(save_freq=10 ** 9, save_path=str(tmp_path), name_prefix="t", key_list=["episode_reward"])
+    cb.init_callback(m)
+    steps = int(fx["num_steps"])
+    for s in range(steps):
+        env.feed.cursor = (s + 1) % nf
+        _, _, _, info = env.step(torch.from_numpy(fx["actions"][(s + 1) % nf]).to(DEV))
+        m.ep_info_buffer.append(info["episode"])  # never read before the callback looks at it
+    cb.on_rollout_end()
+    assert saved == ["t_best_episode_reward"]
+    want = float(np.mean(fx["episode_info"][:steps, 0].astype(np.float32)))
+    assert abs(cb.key_highest_value["episode_reward"] - want) < 1e-5

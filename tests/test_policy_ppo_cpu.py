@@ -64,7 +64,7 @@ def test_policy_forward_eval_and_train_mode_vs_reference():
 def _ppo_from_fixture(fx, device="cpu", backend="torch"):
     from gennbv_amd.sb3.ppo_grid_obs import PPO_Grid_Obs
     from gennbv_amd.sb3.policies import ActorCriticPolicy_Train_Eval
-    from gennbv_amd.network.hybrid_encoder import Hybrid_Encoder
+    from tests.torch_reference import encoder_class
     t, n = int(fx["T"]), int(fx["N"])
     _, obs_space, act_space = pu.make_policy(det_weights=False)
 
@@ -78,13 +78,13 @@ def _ppo_from_fixture(fx, device="cpu", backend="torch"):
                        batch_size=int(fx["batch_size"]), n_epochs=int(fx["n_epochs"]), gamma=0.99, gae_lambda=0.95,
                        clip_range=0.2, clip_range_vf=0.2, ent_coef=0.01, vf_coef=0.8, max_grad_norm=1.0,
                        target_kl=None if tkl < 0 else tkl, device=device,
-                       policy_kwargs=dict(net_arch=[], features_extractor_class=Hybrid_Encoder,
+                       policy_kwargs=dict(net_arch=[], features_extractor_class=encoder_class(backend),
                                           features_extractor_kwargs=dict(
                                               encoder_param={"hidden_shapes": [256, 256], "visual_dim": 256},
                                               net_param={"transformer_params": [[1, 256], [1, 256]],
                                                          "append_hidden_shapes": [256, 256]},
                                               state_input_shape=(600,), visual_input_shape=(100, 400, 400),
-                                              grid_size=20, backend=backend)))
+                                              grid_size=20)))
     shapes = {k: tuple(v.shape) for k, v in ppo.policy.state_dict().items()}
     ppo.policy.load_state_dict({k: torch.from_numpy(v).to(device) for k, v in gu.det_state_dict(shapes).items()})
     buf = ppo.rollout_buffer

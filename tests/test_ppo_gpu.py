@@ -198,7 +198,7 @@ def test_learn_with_int8_grid_copy_matches_fp32_rows(monkeypatch):
                             policy_kwargs=dict(net_arch=[], features_extractor_class=Hybrid_Encoder, features_extractor_kwargs=dict(
                                 encoder_param={"hidden_shapes": [256, 256], "visual_dim": 256},
                                 net_param={"transformer_params": [[1, 256], [1, 256]], "append_hidden_shapes": [256, 256]},
-                                state_input_shape=(cfg.state_dim,), visual_input_shape=(cfg.stack, 48, 64), grid_size=g, backend="hip")))
+                                state_input_shape=(cfg.state_dim,), visual_input_shape=(cfg.stack, 48, 64), grid_size=g)))
         algo.learn(total_timesteps=2 * n * t)
         buf = algo.rollout_buffer
         assert (buf.grid_i8 is not None) == i8
@@ -241,7 +241,7 @@ def test_learn_with_compact_observations_matches_flat_rows(monkeypatch, g):
                             policy_kwargs=dict(net_arch=[], features_extractor_class=Hybrid_Encoder, features_extractor_kwargs=dict(
                                 encoder_param={"hidden_shapes": [256, 256], "visual_dim": 256},
                                 net_param={"transformer_params": [[1, 256], [1, 256]], "append_hidden_shapes": [256, 256]},
-                                state_input_shape=(cfg.state_dim,), visual_input_shape=(cfg.stack, 48, 64), grid_size=g, backend="hip")))
+                                state_input_shape=(cfg.state_dim,), visual_input_shape=(cfg.stack, 48, 64), grid_size=g)))
         algo.learn(total_timesteps=(2 if g == 16 else 1) * n * t)
         buf = algo.rollout_buffer
         s0 = cfg.state_dim
@@ -279,7 +279,7 @@ def test_compact_observations_need_an_int8_capable_env():
         PPO_Grid_Obs(ActorCriticPolicy_Train_Eval, Env(), n_steps=4, batch_size=4, device=DEV, compact_obs=True,
                      policy_kwargs=dict(net_arch=[], features_extractor_class=Hybrid_Encoder, features_extractor_kwargs=dict(
                          encoder_param={}, net_param={"append_hidden_shapes": [256, 256]}, state_input_shape=(600,),
-                         visual_input_shape=(2, 64, 64), grid_size=20, backend="hip")))
+                         visual_input_shape=(2, 64, 64), grid_size=20)))
 
 
 def test_fused_rollout_add_equals_bootstrap_plus_add():

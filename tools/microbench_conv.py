@@ -17,7 +17,7 @@ a = ap.parse_args()
 dev, g, b = "cuda:0", a.grid, a.batch
 n = a.rows or 2 * b
 enc = Hybrid_Encoder(Box(-np.inf, np.inf, (600 + g ** 3 + 8192,)), encoder_param={}, net_param={"append_hidden_shapes": [256, 256]},
-                     state_input_shape=(600,), visual_input_shape=(2, 64, 64), grid_size=g, backend="hip").to(dev)
+                     state_input_shape=(600,), visual_input_shape=(2, 64, 64), grid_size=g).to(dev)
 gen = torch.Generator().manual_seed(0)
 grid_i8 = (torch.randint(-1, 2, (n, g ** 3), generator=gen) * (torch.rand(n, g ** 3, generator=gen) < 0.4)).to(torch.int8).to(dev)
 small = torch.randn(n, 600 + 8192, generator=gen).to(dev)
