@@ -50,7 +50,7 @@ SIGNATURES = {
     "gnbv_env_obs_rgb": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i64, _p]),
     "gnbv_env_post_step": (_i, [_p, _p]),
     "gnbv_encoder_set_backward_side_stream": (_i, [_p]),
-    "gnbv_rollout_add": (_i, [_i, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "gnbv_rollout_add": (_i, [_i, _i, _p, _p, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnbv_input_autocorr_row_ints": (_i, []),
     "gnbv_input_autocorr": (_i, [_p, _i64, _i, _i, _p, _i64, _p]),
     "gnbv_encoder_workspace_bytes": (_sz, [_i, _i]),
@@ -86,7 +86,8 @@ class GnbvEnvPost(C.Structure):
                 ("coverage_count", _p), ("num_valid_voxel_gt", _p), ("prev_ratio", _p), ("episode_length_buf", _p),
                 ("rewards", _p), ("dones", _p), ("reset_mask", _p), ("step_time_out", _p), ("extras_time_outs", _p),
                 ("coverage_ratio", _p), ("episode_sums", _p), ("cur_reward_sum", _p), ("cur_episode_length", _p),
-                ("ring_reward", _p), ("ring_length", _p), ("ring_state", _p), ("ring_len", _i), ("episode_means", _p)]
+                ("ring_reward", _p), ("ring_length", _p), ("ring_state", _p), ("ring_len", _i), ("episode_info", _p), ("episode_state", _p),
+                ("max_episode_length_s", _f)]
 
 
 class GnbvEncoderParams(C.Structure):

@@ -111,8 +111,10 @@ __global__ __launch_bounds__(kPostThreads) void k_env_post_step(GnbvEnvPost a)
 {
     __shared__ int s_wave[kPostThreads / kWave + 1];
     __shared__ int s_any;
+    __shared__ double s_sum[3];  // sums of episode_sums[name] over the envs that reset at this step
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
     if (tid == 0) s_any = 0;
+    if (tid < 3) s_sum[tid] = 0.0;
     __syncthreads();
     int base_count = 0;  // dones seen in earlier tiles (ring-buffer order = env order)
     for (int e0 = 0; e0 < a.n; e0 += kPostThreads) {
@@ -140,9 +142,18 @@ __global__ __launch_bounds__(kPostThreads) void k_env_post_step(GnbvEnvPost a)
             a.rewards[e] = rew;
             a.dones[e] = reset ? 1 : 0;
             a.coverage_ratio[e] = ratio;
-            a.episode_sums[e] = __fadd_rn(a.episode_sums[e], r_cov);
-            a.episode_sums[a.n + e] = __fadd_rn(a.episode_sums[a.n + e], r_short);
-            a.episode_sums[2 * a.n + e] = __fadd_rn(a.episode_sums[2 * a.n + e], r_term);
+            // episode_sums += rew (base:387,398); reset_idx logs their mean over the reset envs and zeroes them (:425-427)
+            const float s0 = __fadd_rn(a.episode_sums[e], r_cov);
+            const float s1 = __fadd_rn(a.episode_sums[a.n + e], r_short);
+            const float s2 = __fadd_rn(a.episode_sums[2 * a.n + e], r_term);
+            a.episode_sums[e] = reset ? 0.0f : s0;
+            a.episode_sums[a.n + e] = reset ? 0.0f : s1;
+            a.episode_sums[2 * a.n + e] = reset ? 0.0f : s2;
+            if (reset) {
+                atomicAdd(&s_sum[0], (double)s0);
+                atomicAdd(&s_sum[1], (double)s1);
+                atomicAdd(&s_sum[2], (double)s2);
+            }
             // reset_idx :377-436
             a.prev_ratio[e] = reset ? 0.0f : ratio;
             a.reset_mask[e] = reset ? 1 : 0;
@@ -179,16 +190,23 @@ __global__ __launch_bounds__(kPostThreads) void k_env_post_step(GnbvEnvPost a)
     if (tid == 0) {
         const int64_t total = a.ring_state[0] + base_count;  // total finished episodes so far
         a.ring_state[0] = total;
-        if (a.episode_means) {  // extras["episode"] snapshot of this step (np.mean of the two deques, base:638-639)
+        if (a.episode_info) {  // extras["episode"] as it stands after this step
+            if (base_count > 0) {  // some env reset: the reference creates a NEW dict (reset_idx :424-427)
+                a.episode_state[0] += 1.0;
+                for (int k = 0; k < 3; ++k)
+                    a.episode_state[1 + k] = (double)__fdiv_rn((float)(s_sum[k] / (double)base_count), a.max_episode_length_s);
+            }
             const int k = (int)(total < a.ring_len ? total : a.ring_len);
             double sr = 0.0, sl = 0.0;
-            for (int i = 0; i < k; ++i) {  // deque order: oldest -> newest (this thread's own ring stores are visible to it;
-                const int64_t pos = total - k + i;  // the other lanes' were made before the last __syncthreads)
+            for (int i = 0; i < k; ++i) {  // deque order: oldest -> newest
+                const int64_t pos = total - k + i;
                 sr += (double)((const volatile float *)a.ring_reward)[pos % a.ring_len];
                 sl += (double)((const volatile float *)a.ring_length)[pos % a.ring_len];
             }
-            a.episode_means[0] = k ? sr / k : 0.0;
-            a.episode_means[1] = k ? sl / k : 0.0;
+            a.episode_info[0] = a.episode_state[0];
+            a.episode_info[1] = k ? sr / k : 0.0;
+            a.episode_info[2] = k ? sl / k : 0.0;
+            for (int j = 0; j < 3; ++j) a.episode_info[3 + j] = a.episode_state[1 + j];
         }
     }
     // infos["time_outs"]: refreshed only on steps where some env resets (reference quirk,
@@ -239,6 +257,7 @@ GNBV_API int gnbv_env_post_step(const GnbvEnvPost *args, void *stream)
     GNBV_CHECK_ARG(args->rewards && args->dones && args->reset_mask && args->step_time_out && args->extras_time_outs);
     GNBV_CHECK_ARG(args->coverage_ratio && args->episode_sums && args->cur_reward_sum && args->cur_episode_length);
     GNBV_CHECK_ARG(args->ring_reward && args->ring_length && args->ring_state);
+    GNBV_CHECK_ARG(!args->episode_info || (args->episode_state && args->max_episode_length_s > 0.0f));
     hipLaunchKernelGGL(k_env_post_step, dim3(1), dim3(kPostThreads), 0, gnbv_stream(stream), *args);
     return gnbv_launch_status();
 }
@@ -250,14 +269,14 @@ GNBV_API int gnbv_env_post_step(const GnbvEnvPost *args, void *stream)
 // fp32, episode_starts bool -> u8) straight into row `step` of the buffer arrays.
 // ---------------------------------------------------------------------------
 __global__ void k_rollout_add(int n, int adim, const int64_t *__restrict__ actions, const float *__restrict__ rewards,
-                              const uint8_t *__restrict__ time_outs, const float *__restrict__ terminal_value, float gamma,
+                              const uint8_t *__restrict__ time_outs, const float *__restrict__ terminal_value, int tv_stride, float gamma,
                               const uint8_t *__restrict__ episode_starts, const float *__restrict__ values, const float *__restrict__ log_probs,
                               float *__restrict__ buf_actions, float *__restrict__ buf_rewards, uint8_t *__restrict__ buf_starts,
                               float *__restrict__ buf_values, float *__restrict__ buf_log_probs)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float boot = __fmul_rn(gamma, __fmul_rn(terminal_value[i], time_outs[i] ? 1.0f : 0.0f));
+    const float boot = __fmul_rn(gamma, __fmul_rn(terminal_value[(size_t)i * tv_stride], time_outs[i] ? 1.0f : 0.0f));
     buf_rewards[i] = __fadd_rn(rewards[i], boot);
     buf_starts[i] = episode_starts[i] ? 1 : 0;
     buf_values[i] = values[i];
@@ -266,14 +285,15 @@ __global__ void k_rollout_add(int n, int adim, const int64_t *__restrict__ actio
 }
 
 GNBV_API int gnbv_rollout_add(int n, int action_dim, const int64_t *actions, const float *rewards, const uint8_t *time_outs,
-                              const float *terminal_value, float gamma, const uint8_t *episode_starts, const float *values,
-                              const float *log_probs, float *buf_actions, float *buf_rewards, uint8_t *buf_episode_starts, float *buf_values,
-                              float *buf_log_probs, void *stream)
+                              const float *terminal_value, int terminal_value_stride, float gamma, const uint8_t *episode_starts,
+                              const float *values, const float *log_probs, float *buf_actions, float *buf_rewards,
+                              uint8_t *buf_episode_starts, float *buf_values, float *buf_log_probs, void *stream)
 {
+    GNBV_CHECK_ARG(terminal_value_stride == 0 || terminal_value_stride == 1);
     GNBV_CHECK_ARG(n > 0 && action_dim > 0 && actions && rewards && time_outs && terminal_value && episode_starts && values && log_probs);
     GNBV_CHECK_ARG(buf_actions && buf_rewards && buf_episode_starts && buf_values && buf_log_probs);
     hipLaunchKernelGGL(k_rollout_add, dim3((n + 255) / 256), dim3(256), 0, gnbv_stream(stream), n, action_dim, actions, rewards, time_outs,
-                       terminal_value, gamma, episode_starts, values, log_probs, buf_actions, buf_rewards, buf_episode_starts, buf_values,
+                       terminal_value, terminal_value_stride, gamma, episode_starts, values, log_probs, buf_actions, buf_rewards, buf_episode_starts, buf_values,
                        buf_log_probs);
     return gnbv_launch_status();
 }

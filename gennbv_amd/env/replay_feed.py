@@ -165,8 +165,11 @@ class ReplayFeedEnv:
         # extras["episode"] snapshots: k_env_post_step writes this step's (mean reward, mean length) into slot
         # step % H; the dict handed out with the step reads its own slot on demand (no per-step host sync)
         self._ep_hist = 1024
-        self.episode_means = z(self._ep_hist, 2, dt=torch.float64)
+        self.episode_info_hist = z(self._ep_hist, 6, dt=torch.float64)  # per step: generation, 2 deque means, 3 rew_<name>
+        self.episode_state = z(4, dt=torch.float64)
+        p.episode_state, p.max_episode_length_s = self.episode_state.data_ptr(), float(np.float32(self.max_episode_length_s))
         self._ep_step = 0
+        self._ep_cache = (-1, None)
         self._post = p
         self.extras = {}
 
@@ -226,7 +229,7 @@ class ReplayFeedEnv:
                                 tri_i8_out=grid_i8_out if self.updater.coded else None)
         # rewards / termination / reset bookkeeping
         self._ep_step += 1
-        self._post.episode_means = self.episode_means[self._ep_step % self._ep_hist].data_ptr()
+        self._post.episode_info = self.episode_info_hist[self._ep_step % self._ep_hist].data_ptr()
         _lib.check(lib.gnbv_env_post_step(C.byref(self._post), st), "gnbv_env_post_step")
         return obs
 
@@ -243,6 +246,10 @@ class ReplayFeedEnv:
         self.prev_ratio.zero_()
         self.extras_time_outs.zero_()
         self.gray_prev.zero_()
+        # reset_idx(all envs) (:231): a new extras["episode"] dict with rew_<name> = mean(episode_sums) / episode_length_s
+        self.episode_state[0] += 1
+        self.episode_state[1:] = (self.episode_sums.mean(dim=1) / np.float32(self.max_episode_length_s)).double()
+        self.episode_sums.zero_()
         init = torch.tensor(self.cfg.init_action, dtype=torch.int64, device=self.device).repeat(n, 1)
         return self._observe_and_finish(init, obs_out, grid_i8_out)
 
@@ -255,28 +262,42 @@ class ReplayFeedEnv:
         return obs, self.rew_buf, self.reset_buf.bool(), self.extras
 
     # ------------------------------------------------------------------------
+    REWARD_NAMES = ("surface_coverage", "short_path", "termination")  # cfg.rewards.scales order = episode_sums order
+
     def episode_info(self, step: Optional[int] = None):
-        """extras["episode"] of the reference (reset_idx :424-428, update_extra_episode_info base:629-639) as it was
-        at env step `step` (default: the latest), read on demand from the device snapshot the post-step kernel wrote
-        (the reference pays a .cpu() per step)."""
+        """extras["episode"] of the reference as a reader of the entry handed out at env step `step` sees it NOW
+        (default: the latest step).  The reference creates a new dict only on steps where some env resets
+        (reset_idx :424-428) and otherwise keeps mutating the same object (update_extra_episode_info base:629-639), so
+        an older buffer entry shows the values of the LAST step its dict was alive.  Resolved on demand from the
+        per-step device snapshots the post-step kernel wrote (one read-back per env step at most; the reference pays
+        a .cpu() per step)."""
         step = self._ep_step if step is None else step
-        if self._ep_step - step >= self._ep_hist:
-            raise _lib.GennbvHipError("episode info of a step older than the snapshot history")
-        m = self.episode_means[step % self._ep_hist].cpu()
-        return {"episode_reward": float(m[0]), "episode_length": float(m[1])}
+        if self._ep_step - step >= self._ep_hist or step < 1:
+            raise _lib.GennbvHipError("episode info of a step outside the snapshot history")
+        if self._ep_cache[0] != self._ep_step:
+            self._ep_cache = (self._ep_step, self.episode_info_hist.cpu().numpy())
+        hist = self._ep_cache[1]
+        gen = hist[step % self._ep_hist][0]
+        last = step
+        while last < self._ep_step and hist[(last + 1) % self._ep_hist][0] == gen:
+            last += 1
+        row = hist[last % self._ep_hist]
+        out = {"rew_" + k: float(row[3 + i]) for i, k in enumerate(self.REWARD_NAMES)}
+        out["episode_reward"], out["episode_length"] = float(row[1]), float(row[2])
+        return out
 
 
 class _LazyEpisodeInfo(dict):
-    """The reference's extras["episode"] dict of ONE env step; filled from the device snapshot of that step the
-    first time anything reads it (every dict accessor fills first)."""
+    """The reference's extras["episode"] dict handed out with ONE env step; filled from the device snapshots when
+    something reads it (every dict accessor fills first; see ReplayFeedEnv.episode_info for the aliasing rule)."""
 
     def __init__(self, env, step):
         super().__init__()
-        self._env, self._step, self._done = env, step, False
+        self._env, self._step, self._seen = env, step, -1
 
     def _fill(self):
-        if not self._done:
-            self._done = True
+        if self._seen != self._env._ep_step:  # (the reference keeps mutating the dict while it is alive: refresh per env step)
+            self._seen = self._env._ep_step
             super().update(self._env.episode_info(self._step))
 
     def __getitem__(self, k):

@@ -142,10 +142,12 @@ class TensorRolloutBuffer_Grid_Obs:
         if self.pos == self.buffer_size:
             self.full = True
 
-    def add_bootstrapped(self, obs, action, reward, time_outs, terminal_value, gamma: float, episode_start, value, log_prob) -> None:
+    def add_bootstrapped(self, obs, action, reward, time_outs, terminal_value, gamma: float, episode_start, value, log_prob,
+                         broadcast_first: bool = False) -> None:
         """`rewards += gamma * squeeze(terminal_value * time_outs)` (on_policy_algorithm_grid_obs.py:205-208) followed by
         `add()`, as ONE launch (csrc/envstep.hip: gnbv_rollout_add; same fp32 operation order) -- the observation must
-        already sit in its buffer row (in-place env).  GPU tensors only."""
+        already sit in its buffer row (in-place env).  GPU tensors only.  `broadcast_first`: every env is bootstrapped
+        with terminal_value[0] (the reference's `predict_values(new_obs)[0]`, :206-207)."""
         from .. import _lib
         if self.step >= self.num_transitions_per_env:
             raise AssertionError("Rollout buffer overflow")
@@ -160,7 +162,7 @@ class TensorRolloutBuffer_Grid_Obs:
             assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() == n
         _lib.require_cuda(a, r, to, tv, es, v, lp)
         _lib.check(_lib.load().gnbv_rollout_add(
-            n, self.actions_shape, a.data_ptr(), r.data_ptr(), to.contiguous().data_ptr(), tv.data_ptr(), float(gamma),
+            n, self.actions_shape, a.data_ptr(), r.data_ptr(), to.contiguous().data_ptr(), tv.data_ptr(), 0 if broadcast_first else 1, float(gamma),
             es.contiguous().data_ptr(), v.data_ptr(), lp.data_ptr(), self.actions[t].data_ptr(), self.rewards[t].data_ptr(),
             self.episode_starts[t].data_ptr(), self.values[t].data_ptr(), self.log_probs[t].data_ptr(), _lib.stream_ptr(self.device)),
             "gnbv_rollout_add")

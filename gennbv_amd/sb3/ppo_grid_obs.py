@@ -91,6 +91,10 @@ class PPO_Grid_Obs:
         self.use_graph = True     # replay the minibatch step as one hipGraph
         self.grad_write_through = os.environ.get("GENNBV_WRITE_THROUGH", "1") != "0"  # backward kernels store into the flat gradient buffer (ops/direct_grad.py)
         self.compact_obs = (os.environ.get("GENNBV_COMPACT_OBS", "0") == "1") if compact_obs is None else bool(compact_obs)
+        # Time-out bootstrap (on_policy_algorithm_grid_obs.py:205-208).  "reference": what the reference computes --
+        # `predict_values(new_obs)[0]` is ROW 0 of the [N, 1] values, so every timed-out env is bootstrapped with env 0's
+        # value (pinned by fixture F11).  "per_env": each env's own V(new_obs), SB3's evident intent (not the reference).
+        self.timeout_bootstrap = "reference"
         self._hip = None
         self._sync = None         # gennbv_amd.parallel.GradSync when data-parallel
         if _init_setup_model:
@@ -634,12 +638,15 @@ class PPO_Grid_Obs:
                 else:
                     nxt = None
                     terminal_value = self.policy.predict_values(new_in)
+            assert self.timeout_bootstrap in ("reference", "per_env")
+            first = self.timeout_bootstrap == "reference"
             if fused_add and self._last_obs.data_ptr() == rollout_buffer.observations[rollout_buffer.step].data_ptr():
                 # time-out bootstrap + the five buffer copies as one launch (instead of ~9)
                 rollout_buffer.add_bootstrapped(self._last_obs, actions, rewards, infos["time_outs"], terminal_value, self.gamma,
-                                                self._last_episode_starts, values, log_probs)
+                                                self._last_episode_starts, values, log_probs, broadcast_first=first)
             else:
-                rewards = rewards + self.gamma * torch.squeeze(terminal_value * infos["time_outs"].unsqueeze(1).to(self.device), 1)
+                tv = terminal_value[0] if first else terminal_value  # (:206: `predict_values(new_obs)[0]`)
+                rewards = rewards + self.gamma * torch.squeeze(tv * infos["time_outs"].unsqueeze(1).to(self.device), 1)
                 rollout_buffer.add(self._last_obs, actions, rewards, self._last_episode_starts, values, log_probs)
             self._last_obs = new_obs
             self._last_episode_starts = dones

@@ -196,21 +196,31 @@ typedef struct GnbvEnvPost {
     float *ring_length;             /* in/out [ring_len]: lenbuffer */
     int64_t *ring_state;            /* in/out [1]: episodes finished so far */
     int ring_len;
-    double *episode_means;          /* out [2] or NULL: extras["episode"] of THIS step -- mean of rewbuffer / lenbuffer
-                                       (np.mean over the deques, env_train_base.py:638-639; 0 when empty), fp64 */
+    double *episode_info;           /* out [6] or NULL: extras["episode"] as it stands after THIS step, fp64:
+                                       [0] generation = number of dict objects the reference has created so far (a new
+                                           one on every step where some env resets, env_train_gennbv.py:424; steps in
+                                           between mutate and re-emit the SAME dict, so earlier buffer entries alias it),
+                                       [1] episode_reward, [2] episode_length = np.mean of the rewbuffer / lenbuffer
+                                           deques (env_train_base.py:638-639; 0 when empty),
+                                       [3..5] rew_<name> = mean(episode_sums[name][reset envs]) / max_episode_length_s
+                                           of the dict's creation step (:425-427) */
+    double *episode_state;          /* in/out [4], required with episode_info: generation, rew_<name> x 3 */
+    float max_episode_length_s;     /* cfg.env.episode_length_s */
 } GnbvEnvPost;
 
 int gnbv_env_post_step(const GnbvEnvPost *args /*[host]*/, void *stream);
 
 /* Tail of one rollout step in one launch: the time-out bootstrap `rewards += gamma * squeeze(terminal_value * time_outs)`
- * (on_policy_algorithm_grid_obs.py:205-208; same fp32 operation order) and the five copies of
+ * (on_policy_algorithm_grid_obs.py:205-208; same fp32 operation order; terminal_value_stride = 1: env i uses
+ * terminal_value[i]; 0: every env uses terminal_value[0] -- what the reference computes, its `predict_values(new_obs)[0]`
+ * takes ROW 0 of the [N,1] values and broadcasts it over the envs) and the five copies of
  * TensorRolloutBuffer_Grid_Obs.add (stable_baselines3/common/buffers.py:676-704) into row `step` of the buffer arrays
  * (caller passes the row pointers): actions int64 [N,A] -> f32, episode_starts bool/u8 [N] -> u8, rewards / values /
  * log_probs f32 [N].  time_outs: bool/u8 [N]. */
 int gnbv_rollout_add(int n, int action_dim, const int64_t *actions, const float *rewards, const uint8_t *time_outs,
-                     const float *terminal_value, float gamma, const uint8_t *episode_starts, const float *values,
-                     const float *log_probs, float *buf_actions, float *buf_rewards, uint8_t *buf_episode_starts, float *buf_values,
-                     float *buf_log_probs, void *stream);
+                     const float *terminal_value, int terminal_value_stride, float gamma, const uint8_t *episode_starts,
+                     const float *values, const float *log_probs, float *buf_actions, float *buf_rewards, uint8_t *buf_episode_starts,
+                     float *buf_values, float *buf_log_probs, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* B1  Hybrid_Encoder grid branch (gennbv/network/hybrid_encoder.py:38-45,90-94): */

@@ -238,7 +238,13 @@ def gen_envstep(ref, name, n, h, w, g, num_frames, num_steps, max_ep_len, seed, 
     # _setup_learn overwrites episode_length_buf (base_class_grid_obs.py:471-475); we use a fixed stagger
     env.episode_length_buf = init_len.clone()
     rewards, dones, timeouts, cover, tri_sha, prob_sha, scan_sha, obs_sha, c2w_all = [], [], [], [], [], [], [], [], []
-    ep_info = []  # extras["episode"] of every step: np.mean of the rewbuffer / lenbuffer deques (env_train_base.py:638-639)
+    # extras["episode"] of every step (reset_idx :424-427 rew_<name>, update_extra_episode_info base:638-639), the identity
+    # of the dict object (a new one only on steps with resets: buffer entries in between alias it) and what the reference's
+    # BestCKPTCallback.calculate_value computes over the ep_info_buffer the on-policy loop fills
+    ep_info, ep_gen, ep_ids = [], [], {}
+    from collections import deque
+    ep_buffer = deque(maxlen=100)
+    ep_keys = None
     keep = {}
     for s in range(num_steps):
         fi = (s + 1) % num_frames
@@ -259,7 +265,13 @@ def gen_envstep(ref, name, n, h, w, g, num_frames, num_steps, max_ep_len, seed, 
         rewards.append(rew.numpy().copy()); dones.append(done.numpy().copy())
         timeouts.append(info["time_outs"].numpy().copy())
         cover.append(env.reward_ratio_buf[-1].numpy().copy())
-        ep_info.append([float(info["episode"]["episode_reward"]), float(info["episode"]["episode_length"])])
+        d = info["episode"]
+        if ep_keys is None:
+            ep_keys = sorted(d.keys())
+        assert sorted(d.keys()) == ep_keys
+        ep_info.append([float(d[k]) for k in ep_keys])
+        ep_gen.append(ep_ids.setdefault(id(d), len(ep_ids)))
+        ep_buffer.extend([d])  # base_class_grid_obs.py:491-493
         tri = obs["grid"].numpy()
         tri_sha.append(sha(tri.astype(np.float32))); prob_sha.append(sha(snap["prob"])); scan_sha.append(sha(snap["scan"]))
         obs_sha.append(sha(flat))
@@ -273,7 +285,12 @@ def gen_envstep(ref, name, n, h, w, g, num_frames, num_steps, max_ep_len, seed, 
     out.update(keep)
     out.update(rewards=np.stack(rewards), dones=np.stack(dones), time_outs=np.stack(timeouts), coverage=np.stack(cover),
                tri_sha=np.array(tri_sha), prob_sha=np.array(prob_sha), scan_sha=np.array(scan_sha),
-               flat_obs_sha=np.array(obs_sha), episode_info=np.array(ep_info, np.float64))
+               flat_obs_sha=np.array(obs_sha), episode_info=np.array(ep_info, np.float64), episode_keys=np.array(ep_keys),
+               episode_dict_generation=np.array(ep_gen, np.int64))
+    # the reference's own callback arithmetic over the (aliased) buffer entries (gennbv/callback.py:58-70)
+    cb = object.__new__(ref.callback.BestCKPTCallback)
+    cb.locals = {"self": types.SimpleNamespace(ep_info_buffer=ep_buffer, device="cpu")}
+    out["best_ckpt_value_episode_reward"] = np.float64(ref.callback.BestCKPTCallback.calculate_value(cb, "episode_reward"))
     np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
     print(name, "saved; mean fg", float((out["seg"] > 50).mean()), "resets", int(np.stack(dones).sum()))
 

@@ -301,6 +301,8 @@ def import_reference():
     ns.on_policy = importlib.import_module("stable_baselines3.common.on_policy_algorithm_grid_obs")
     ns.rsl_storage = importlib.import_module("rsl_rl.storage.rollout_storage")
     ns.rsl_ppo = importlib.import_module("rsl_rl.algorithms.ppo")
+    ns.callback = importlib.import_module("gennbv.callback")
+    ns.evaluation = importlib.import_module("stable_baselines3.common.evaluation")
     return ns
 
 

@@ -28,7 +28,7 @@ def _obs(b, g, seed=0):
 
 
 @pytest.mark.parametrize("conv2_lds", ["0", "1"])
-@pytest.mark.parametrize("g,b", [(20, 8), (16, 5), (33, 3), (64, 4), (128, 1)])
+@pytest.mark.parametrize("g,b", [(20, 8), (16, 5), (33, 3), (64, 4), (128, 1), (64, 128)])  # last: the bench's minibatch
 def test_encoder_forward_backward_vs_torch_reference(g, b, conv2_lds, monkeypatch):
     """Reference = the same torch modules in fp64 on the CPU (ground truth), tolerance = fp32 round-off.
     (torch-GPU fp32 is NOT used as the reference: MIOpen's conv/BN backward is off by 0.7-4.6 % at
@@ -36,6 +36,8 @@ def test_encoder_forward_backward_vs_torch_reference(g, b, conv2_lds, monkeypatc
     conv2_lds = "1": the opt-in LDS-staged conv2 forward (k_conv2_fwd_lds; G <= 66, else the default kernel runs)."""
     if conv2_lds == "1" and g > 66:
         pytest.skip("k_conv2_fwd_lds covers O2 <= 15 only")
+    if conv2_lds == "1" and b > 64:
+        pytest.skip("the full-minibatch case runs on the default kernel set only")
     monkeypatch.setenv("GENNBV_CONV2_LDS", conv2_lds)
     hip, _, _ = pu.make_policy(g=g, device=DEV, backend="hip", det_weights=True)
     ref, _, _ = pu.make_policy(g=g, device="cpu", backend="torch", det_weights=True)
@@ -59,8 +61,8 @@ def test_encoder_forward_backward_vs_torch_reference(g, b, conv2_lds, monkeypatc
         r = p1.grad.double()
         scale = float(r.abs().max())
         err = float((r - p2.grad.double().cpu()).abs().max())
-        if scale < 1e-9:  # conv bias in front of BatchNorm: analytically zero gradient
-            assert err < 1e-4, (n1, err)
+        if scale < 1e-9:  # conv bias in front of BatchNorm: analytically zero gradient (rounding noise, grows with the batch)
+            assert err < 1e-4 * max(1.0, b / 8), (n1, err)
         else:
             assert err <= 2e-5 * scale, (n1, err, scale)
     for (k1, v1), (k2, v2) in zip(ref.state_dict().items(), hip.state_dict().items()):
@@ -77,13 +79,15 @@ def test_encoder_forward_backward_vs_torch_reference(g, b, conv2_lds, monkeypatc
 
 
 @pytest.mark.parametrize("z1", ["0", "1", "qm"])  # "qm": y1 stored quad-major (GENNBV_Y1_QM=1, opt-in layout of the same path)
-@pytest.mark.parametrize("g,b", [(16, 5), (32, 3), (48, 2), (64, 4), (128, 1)])
+@pytest.mark.parametrize("g,b", [(16, 5), (32, 3), (48, 2), (64, 4), (128, 1), (64, 128)])  # last: the bench's minibatch
 def test_fused_dgrad_conv1_wgrad_vs_fp64_reference(g, b, z1, monkeypatch):
     """With the int8 grid rows present (G % 16 == 0) the backward runs k_conv2_dgrad_c1w: conv2 data gradient and conv1
     weight gradient in one launch, BN1 backward applied to fp64 sums afterwards (dz1' is never stored).  All conv / BN
     gradients against the fp64 torch reference, tolerance = fp32 round-off; rows are gathered (RowGather).
     z1 = "1" (opt-in GENNBV_Z1): BN1 batch statistics analytically from the input autocorrelation, conv1 stores
     relu(bn1(y1)) (G <= 64; G = 128 keeps the y1 layout)."""
+    if b > 64 and z1 == "1":
+        pytest.skip("the full-minibatch case runs on the default and quad-major kernel sets")
     monkeypatch.setenv("GENNBV_Z1", "1" if z1 == "1" else "0")
     monkeypatch.setenv("GENNBV_Y1_QM", "1" if z1 == "qm" else "0")
     from gennbv_amd.ops.encoder_ops import RowGather, input_autocorr
@@ -114,14 +118,15 @@ def test_fused_dgrad_conv1_wgrad_vs_fp64_reference(g, b, z1, monkeypatch):
     # (with stored rows BatchNorm-1's batch statistics come analytically from the autocorrelation, without them from the
     # activations: equal to fp32 round-off, not bit for bit)
     for a, c in zip(stored, hip.features_extractor.parameters()):
-        assert float((a - c.grad).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-5  # (+ the noise floor of the analytically zero bias gradients)
+        # (+ the noise floor of the analytically zero conv-bias gradients: a sum of B*O^3 rounded terms, it grows with the batch)
+        assert float((a - c.grad).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-5 * max(1.0, b / 4)
     assert float((outs[0] - outs[1]).abs().max()) <= 2e-5 * float(outs[0].abs().max()) + 1e-6
     for (n1, p1), (n2, p2) in zip(ref.features_extractor.named_parameters(), hip.features_extractor.named_parameters()):
         r = p1.grad.double()
         scale = float(r.abs().max())
         err = float((r - p2.grad.double().cpu()).abs().max())
-        if scale < 1e-9:  # conv bias in front of BatchNorm: analytically zero gradient
-            assert err < 1e-4, (n1, err)
+        if scale < 1e-9:  # conv bias in front of BatchNorm: analytically zero gradient (rounding noise, grows with the batch)
+            assert err < 1e-4 * max(1.0, b / 8), (n1, err)
         else:
             assert err <= 2e-5 * scale, (n1, err, scale)
     # BatchNorm running statistics (z1 mode, G <= 64: analytic batch statistics from the input autocorrelation; three training

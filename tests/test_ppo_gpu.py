@@ -122,12 +122,13 @@ def test_data_parallel_code_path_on_one_gpu(name):
     _check(ppo, fx)
 
 
-def test_multicategorical_sample_kernel_distribution_and_log_prob():
+@pytest.mark.parametrize("dims", [(81, 81, 51, 1, 13, 13), (7, 5, 3, 1, 4, 2), (200, 1, 65)])  # the reference's action lattice first (81-way heads > one wave)
+def test_multicategorical_sample_kernel_distribution_and_log_prob(dims):
     """gnbv_multicategorical_sample (rollout side of MultiCategoricalDistribution, sb3 distributions.py:299-352):
     log_prob equals the torch evaluation of the sampled action bit-for-bit up to fp32 round-off, the mode
     equals torch.argmax, and the empirical frequencies match softmax within sampling error."""
     from gennbv_amd.sb3.distributions import MultiCategoricalDistribution
-    dims = [81, 81, 51, 1, 13, 13] if False else [7, 5, 3, 1, 4, 2]
+    dims = list(dims)
     dist = MultiCategoricalDistribution(dims)
     gen = torch.Generator().manual_seed(3)
     logits = (torch.randn(4096, sum(dims), generator=gen) * 2).to("cuda:0")
@@ -282,7 +283,8 @@ def test_compact_observations_need_an_int8_capable_env():
                          visual_input_shape=(2, 64, 64), grid_size=20)))
 
 
-def test_fused_rollout_add_equals_bootstrap_plus_add():
+@pytest.mark.parametrize("first", [True, False])  # True: the reference's `predict_values(new_obs)[0]` (env 0's value for every env)
+def test_fused_rollout_add_equals_bootstrap_plus_add(first):
     """gnbv_rollout_add: `rewards += gamma * squeeze(terminal_value * time_outs)` + the five copies of add() in one launch
     leave the buffer rows bit-identical to the reference sequence."""
     from gennbv_amd.sb3.buffers import TensorRolloutBuffer_Grid_Obs
@@ -301,9 +303,9 @@ def test_fused_rollout_add_equals_bootstrap_plus_add():
         values, lp = torch.randn(n, 1, generator=gen).to(DEV), torch.randn(n, generator=gen).to(DEV)
         for b in bufs:
             b.observations[step].normal_(generator=None)
-        r_ref = rewards + gamma * torch.squeeze(tv * time_outs.unsqueeze(1), 1)
+        r_ref = rewards + gamma * torch.squeeze((tv[0] if first else tv) * time_outs.unsqueeze(1), 1)
         bufs[0].add(bufs[0].observations[step], actions, r_ref, starts, values, lp)
-        bufs[1].add_bootstrapped(bufs[1].observations[step], actions, rewards, time_outs, tv, gamma, starts, values, lp)
+        bufs[1].add_bootstrapped(bufs[1].observations[step], actions, rewards, time_outs, tv, gamma, starts, values, lp, broadcast_first=first)
     for name in ("actions", "rewards", "episode_starts", "values", "log_probs"):
         assert torch.equal(getattr(bufs[0], name), getattr(bufs[1], name)), name
     assert bufs[1].step == t and bufs[1].full
