@@ -189,20 +189,48 @@ def cpu_baseline(args, cfg):
 
 
 def ppo_loss_delta(args, device):
-    """PPO loss delta vs the reference (BASELINE metric, second half): run train() of the SAME
-    code path (backend, dtype, hipGraph) on the recorded rollout of tests/golden/F9_ppo_train.npz and
-    compare the logged losses with the ones the reference's PPO_Grid_Obs.train() produced."""
+    """PPO loss delta vs the reference (BASELINE metric, second half), two measurements:
+
+    * `reference_fixture`: train() of the same code path (hipGraph, fused kernels) on the recorded rollout of
+      tests/golden/F9_ppo_train.npz against the losses the REFERENCE's own PPO_Grid_Obs.train() logged.  The reference
+      hard-codes 20^3 (hybrid_encoder.py:47,90-91), so this runs the G = 20 kernel set, not the timed one;
+    * `timed_kernel_set`: train() at the timed configuration's kernel set -- G = 64, minibatch 128, compact int8 rows,
+      hipGraph (k_conv1_fwd_lds<int8>, analytic BN1, k_conv2_fwd, k_conv2_wgrad, k_conv2_dgrad_c1w, split-K fc_grid,
+      fused head / loss / Adam) -- on a rollout recorded from ReplayFeedEnv, 20 optimizer steps, against the plain-torch
+      train() loop of the same class in fp64 on the CPU (the statement proven equal to the reference on F9;
+      tests/test_ppo_g64_gpu.py is the same check with assertions)."""
+    import numpy as np
     import torch
     from tests import golden_util as gu
     from tests.test_policy_ppo_cpu import _ppo_from_fixture
+    out = {"tolerance": 1e-4}
     fx = gu.load("F9_ppo_train")
     ppo = _ppo_from_fixture(fx, device=device, backend=args.backend)
     ppo.train()
     log = ppo.logger.name_to_value
     keys = ("train/policy_gradient_loss", "train/value_loss", "train/entropy_loss", "train/loss", "train/approx_kl")
     deltas = {k.split("/")[1]: abs(float(log[k]) - float(fx["log/" + k])) for k in keys}
-    return {"fixture": "tests/golden/F9_ppo_train.npz (reference PPO_Grid_Obs.train(), 12 optimizer steps, G=20)",
-            "abs_delta": deltas, "max_abs_delta": max(deltas.values()), "tolerance": 1e-4}
+    out["reference_fixture"] = {"fixture": "tests/golden/F9_ppo_train.npz (reference PPO_Grid_Obs.train(), 12 optimizer steps, G=20)",
+                                "abs_delta": deltas, "max_abs_delta": max(deltas.values())}
+    out["max_abs_delta"] = max(deltas.values())
+    if args.backend == "hip" and (args.grid, args.batch_size) == (64, 128) and device.endswith(":0"):
+        from tests import test_ppo_g64_gpu as t64
+        rec = t64._Recorded()
+        ref = rec.oracle(None)
+        hip = t64._fresh_hip(rec, None, True)
+        hip.train()
+        s_h, s_r = hip.last_train_stats, ref.last_train_stats
+        names = ("policy_gradient_loss", "value_loss", "entropy_loss", "approx_kl", "clip_fraction", "loss")
+        d = np.abs(s_h - s_r[:, :s_h.shape[1]])[:, :6] / np.maximum(1.0, np.abs(s_r[:, :6]))
+        out["timed_kernel_set"] = {
+            "what": "G=64, batch 128, compact int8 rows, hipGraph; 20 optimizer steps on a ReplayFeedEnv rollout vs the fp64 CPU torch loop",
+            "optimizer_steps": int(hip._hip["opt"].step_count.item()),
+            "max_rel_delta_per_scalar": {n: float(d[:, j].max()) for j, n in enumerate(names)},
+            "max_rel_delta": float(d.max()), "oracle_kl_max": float(np.abs(s_r[:, 3]).max())}
+        out["max_abs_delta"] = max(out["max_abs_delta"], float(d.max()))
+        del rec, ref, hip
+        torch.cuda.empty_cache()
+    return out
 
 
 def encoder_roofline(algo, args, device, iters: int = 20):

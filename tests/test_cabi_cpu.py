@@ -61,7 +61,7 @@ def test_public_header_compiles_as_c_and_cxx(cc, lang, tmp_path):
     src = tmp_path / ("use." + ("c" if lang == "c" else "cpp"))
     calls = "\n".join(f"    p[{i}] = (void *){s};" for i, s in enumerate(declared_symbols()))
     src.write_text('#include "gennbv_hip.h"\n#include <stddef.h>\nint main(void) {\n    void *p[128];\n' + calls +
-                   "\n    GnbvEnvPost e; e.ring_state = NULL; e.ring_len = 100; e.episode_means = NULL;\n"
+                   "\n    GnbvEnvPost e; e.ring_state = NULL; e.ring_len = 100; e.episode_info = NULL; e.episode_state = NULL;\n"
                    "    GnbvEncoderParams q; q.grid_i8 = NULL;\n    return p[0] == NULL && e.ring_len == 0 && q.grid_i8 != NULL;\n}\n")
     subprocess.check_call([cc, "-fsyntax-only", "-Wall", "-Werror", "-Wno-unused-but-set-variable", "-x", lang,
                            "-I", os.path.join(ROOT, "include"), str(src)])

@@ -263,6 +263,6 @@ def test_best_checkpoint_callback_over_real_env_infos(tmp_path):
         _, _, _, info = env.step(torch.from_numpy(fx["actions"][(s + 1) % nf]).to(DEV))
         m.ep_info_buffer.append(info["episode"])  # never read before the callback looks at it
     cb.on_rollout_end()
-    assert saved == ["t_best_episode_reward"]
+    assert saved == ["t_0_steps", "t_best_episode_reward"]  # (n_calls = 0: the periodic branch fires too, as in the reference)
     # the reference's own calculate_value over its own (aliased) ep_info_buffer, recorded by oracle/gen_golden.py
     assert abs(cb.key_highest_value["episode_reward"] - float(fx["best_ckpt_value_episode_reward"])) < 1e-5

@@ -20,7 +20,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-G, N_ENVS, T, BATCH, EPOCHS, LR = 64, 16, 32, 128, 5, 3e-4
+G, N_ENVS, T, BATCH, EPOCHS, LR = 64, 16, 32, 128, 5, 1e-4  # lr, clip ranges, coefficients: train_gennbv.py's PPO settings
 HW = (60, 80)
 
 
@@ -56,10 +56,9 @@ class _Recorded:
                                         policy_kwargs=_kwargs(cfg, Hybrid_Encoder), **_ppo_args(None))
         assert algo.policy.features_extractor.grid_size == G  # inferred from the observation space
         algo._setup_learn(total_timesteps=10 ** 9)
-        # de-randomise the policy a little: a random-init action_net (gain 0.01) gives a flat loss surface; scale it up so
-        # that ratios / clipping / KL actually move during the 20 steps
-        with torch.no_grad():
-            algo.policy.action_net.weight.mul_(30.0)
+        # (default SB3 initialisation -- the state the bench times.  Do NOT sharpen the policy artificially: with
+        # action_net x30 and lr 3e-4 the update is chaotic and torch-CPU fp32 itself drifts 5e-2 from torch-CPU fp64
+        # within 8 steps; at these settings fp32-vs-fp64 stays <= 2e-5 while KL reaches 1e-2 and a fifth of the ratios clip.)
         algo.collect_rollouts(env, None, algo.rollout_buffer, n_rollout_steps=T)
         torch.cuda.synchronize()
         buf = algo.rollout_buffer
@@ -133,7 +132,7 @@ def _compare(hip, ref, n_steps_expected):
         worst = max(worst, float(d.max()))
         assert float(d.max()) <= 1e-4, (nm, int(d.argmax()), float(d.max()), s_h[d.argmax(), j], s_r[d.argmax(), j])
     # the update must have done something measurable (not a degenerate all-zero comparison)
-    assert float(np.abs(s_r[:, 3]).max()) > 1e-4 and float(s_r[:, 4].max()) > 0.0
+    assert float(np.abs(s_r[:, 3]).max()) > 1e-4 and float(np.abs(s_r[:, 5] - s_r[0, 5]).max()) > 1e-2  # KL and loss move >> tolerance
     for k in ("train/entropy_loss", "train/policy_gradient_loss", "train/value_loss", "train/approx_kl", "train/clip_fraction",
               "train/loss", "train/explained_variance"):
         a, b = float(hip.logger.name_to_value[k]), float(ref.logger.name_to_value[k])
