@@ -33,6 +33,7 @@ SIGNATURES = {
     "gnbv_bresenham3d": (_i, [_p, _p, _i, _i, _p, _p, _p]),
     "gnbv_grid_tri_cls": (_i, [_p, _i64, _f, _f, _p, _p]),
     "gnbv_voxel_workspace_bytes": (_sz, [_i, _i]),
+    "gnbv_voxel_workspace_bytes_hw": (_sz, [_i, _i, _i, _i]),
     "gnbv_update_occ_grid": (_i, [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _i64, _p,
                                   _p, _sz, _p]),
     "gnbv_unpack_masks": (_i, [_p, _i, _i, _p, _p, _p]),

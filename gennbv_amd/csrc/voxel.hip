@@ -32,6 +32,7 @@
 #include "common.h"
 #include "../../include/gennbv_hip.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 // ---------------------------------------------------------------------------
 // canonical fp32 arithmetic (DESIGN.md "canonical order"); file is built with
@@ -395,6 +396,8 @@ __device__ __forceinline__ void trace_ray_lane(const int (&src)[3], int lin_t, i
                 const unsigned wi = (unsigned)((l >> 5) - w0);
                 if (wi < (unsigned)nw) atomicOr(&s_path[wi], 1u << (l & 31));
             } else if (LDS_PATH) {
+                // (testing the bit first -- same-address reads broadcast -- so that only the first ray through a voxel pays the
+                // atomic was slower: 32.5 against 28.6 us, the read's latency sits on the walk's critical path)
                 atomicOr(&s_path[l >> 5], 1u << (l & 31));
             } else {
                 atomicOr(&pm[l >> 5], 1u << (l & 31));
@@ -488,15 +491,8 @@ __global__ __launch_bounds__(kRayThreads) void k_raycast(
             }
             __syncthreads();
             const int nq = min(kQueueCap, my_total - base);
-#ifndef RAY_VARIANT
-#define RAY_VARIANT 0
-#endif
-#if RAY_VARIANT != 1
             for (int q = tid; q < nq; q += kRayThreads)
                 trace_ray_lane<LDS_PATH, WIN>(src, (int)s_queue[q], g, gg, s_path, pm, w0, nw);
-#else
-            (void)nq;
-#endif
             __syncthreads();
         }
     }
@@ -510,6 +506,325 @@ __global__ __launch_bounds__(kRayThreads) void k_raycast(
                 if (v) atomicOr(&pm[w0 + i], v);
             }
         }
+    }
+}
+
+// ===========================================================================
+// fused path, launches 1 + 2 (grids whose bitmask fits a workgroup's LDS next to 31 other waves: G <= 104)
+//
+// k_hit_list: N x chunks workgroups of 1024 threads.  A workgroup streams its share of the env's depth + seg pixels
+// (two tiles of 4096 pixels in flight: the next tile's 16-byte requests are issued before the current tile is
+// back-projected), ORs the voxel bits into an LDS hit mask -- a pixel whose left neighbour maps to the same voxel leaves
+// the bit to it (same-address LDS atomics were 16 of the kernel's 64 us) -- then numbers the set bits with a block-wide
+// prefix sum and appends them as a RAY LIST (one int32 target voxel per ray) to the env's slice of the workspace; the
+// mask goes out with plain stores (one workgroup per env) or atomicOr of the non-zero words.
+//
+// k_ray_list: N x 16 workgroups of 256 threads; workgroup (e, s) walks rays [256 s, 256 s + 256) (+ 4096 k) of env e's
+// list, one per lane (the reference's integer Bresenham, trace_ray_lane), into an LDS path mask and ORs the non-zero
+// words out.  The per-env ray counts differ 4x around their mean (an env that faces a large surface has thousands): with
+// one workgroup -- or a fixed split -- per env the launch lasts as long as its busiest env (28 of k_raycast's 65 us were
+// the walk, 59 us in a one-launch hit + walk kernel); slices of 256 rays spread an env over as many CUs as it needs and
+// the slices of light envs retire at once.  (Measured alternatives in profiles/r02_notes.md.)
+//
+// A voxel hit from pixels of two chunks is listed by both workgroups: harmless, the path is a set.
+// ===========================================================================
+#ifndef FUSED_THREADS
+#define FUSED_THREADS 1024
+#endif
+constexpr int kFusedThreads = FUSED_THREADS;
+constexpr int kListThreads = 256;    // k_ray_list: rays per slice = lanes per workgroup
+constexpr int kListSlices = 16;     // slices per env and pass
+
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+// streaming 16-byte load (read-once camera data: keep it out of the L2's way)
+__device__ __forceinline__ float4 ld4_stream(const float *p)
+{
+    const v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+struct PixelFrame {
+    float M[12];
+    HitFrame hf;
+    float lo[3], hi[3];  // next_up(vmin), next_down(vmax): the closed interval of the kept points
+    int g, gg;
+    float sense_dist;
+};
+
+// Linear voxel index of one raw pixel, or -1 (background / outside the grid); canonical fp32 order (see k_hit_mask).
+// Two RARE branches (a depth beyond the sensing range; a quotient within round-off of an integer) instead of an early exit
+// per test.  Measured alternatives (profiles/r02_notes.md): the early-exit form of k_hit_mask (a third of the instructions
+// were exec-mask bookkeeping) and a fully straight-line form over the four pixels of a lane with one merged slow-path
+// branch (48 us against 46: it computes everything for background pixels too).
+template <bool KFAST>
+__device__ __forceinline__ int pixel_to_lin(const PixelFrame &pf, const Intrinsics &K, float fx, float fy, float draw, float sraw)
+{
+    const bool fg = sraw > 50.0f;  // nan_to_num(neginf=0) then > 50 == plain `> 50`
+    const float d = process_depth(draw, pf.sense_dist);
+    float wp[3];
+    if (KFAST) {
+        // inv_intri = [[a,0,c],[0,b,d],[0,0,1]] (checked on the host) and finite products: the zero terms of the fma chain
+        // vanish exactly, cam_z = d.
+        const float pu = __fmul_rn(d, fx), pv = __fmul_rn(d, fy);
+        const float cx = __fmaf_rn(K.k[2], d, __fmul_rn(K.k[0], pu));
+        const float cy = __fmaf_rn(K.k[5], d, __fmul_rn(K.k[4], pv));
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float acc = __fmul_rn(pf.M[i * 4 + 0], cx);
+            acc = __fmaf_rn(pf.M[i * 4 + 1], cy, acc);
+            acc = __fmaf_rn(pf.M[i * 4 + 2], d, acc);
+            wp[i] = __fadd_rn(acc, pf.M[i * 4 + 3]);  // fma(t, 1, acc) == acc + t
+        }
+    }
+    if (!KFAST || __builtin_expect(fg && !(d <= 50.0f), 0)) pixel_to_world(d, fx, fy, K, pf.M, wp);  // (+inf -> FLT_MAX etc.)
+    const HitFrame &hf = pf.hf;
+    // vmax > p > vmin on the three axes  <=>  p == clamp(p, next_up(vmin), next_down(vmax))  (a NaN compares unequal, like
+    // the reference's comparisons): three v_med3 + three compares instead of six compares and their mask arithmetic
+    const bool keep = fg && (__builtin_amdgcn_fmed3f(wp[0], pf.lo[0], pf.hi[0]) == wp[0]) &&
+                      (__builtin_amdgcn_fmed3f(wp[1], pf.lo[1], pf.hi[1]) == wp[1]) &&
+                      (__builtin_amdgcn_fmed3f(wp[2], pf.lo[2], pf.hi[2]) == wp[2]);
+    // floor((p - vmin) / v) with IEEE division semantics via the reciprocal predictor (see voxel_axis_fast); the three
+    // "quotient within 2^-21 |q| of an integer" tests fold into one comparison of the smallest margin
+    float fl[3], margin[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float x = __fsub_rn(wp[a], hf.vmin[a]);
+        const float q = __fmul_rn(x, hf.inv_vox[a]);
+        fl[a] = floorf(q);
+        const float frac = __fsub_rn(q, fl[a]);
+        const float thr = __fmul_rn(fabsf(q), 4.76837158203125e-07f);  // 2^-21
+        // frac >= thr && frac <= 1 - thr   <=>   min(frac - thr, (1 - thr) - frac) >= 0   (each difference has the sign of its comparison)
+        margin[a] = __builtin_fminf(__fsub_rn(frac, thr), __fsub_rn(__fsub_rn(1.0f, thr), frac));
+    }
+    const bool exact_needed = !(__builtin_fminf(__builtin_fminf(margin[0], margin[1]), margin[2]) >= 0.0f);
+    if (__builtin_expect(keep && exact_needed, 0)) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) fl[a] = floorf(__fdiv_rn(__fsub_rn(wp[a], hf.vmin[a]), hf.vox[a]));
+    }
+    // kept points are finite: clamp in fp32 (v_med3) then convert
+    const int ix = (int)__builtin_fminf(__builtin_fmaxf(fl[0], 0.0f), hf.gmax);
+    const int iy = (int)__builtin_fminf(__builtin_fmaxf(fl[1], 0.0f), hf.gmax);
+    const int iz = (int)__builtin_fminf(__builtin_fmaxf(fl[2], 0.0f), hf.gmax);
+    return keep ? ix * pf.gg + iy * pf.g + iz : -1;
+}
+
+template <bool KFAST>
+__global__ __launch_bounds__(kFusedThreads) void k_hit_list(
+    const float *__restrict__ depth_raw, const float *__restrict__ seg_raw, const float *__restrict__ c2w, Intrinsics K,
+    const float *__restrict__ range_gt, const float *__restrict__ voxel_size, int n, int h, int w, int g, float sense_dist,
+    int chunks, int words, uint32_t *__restrict__ hit_mask, int32_t *__restrict__ ray_count, int32_t *__restrict__ ray_list,
+    int64_t ray_cap, int32_t *__restrict__ coverage_zero)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *s_hit = smem;                 // words
+    int *s_wave = (int *)(smem + words);    // counters (64 ints reserved)
+    uint16_t *s_widx = (uint16_t *)(s_wave + 64);  // words: indices of the non-zero mask words
+    // XCD-aware block -> (env, chunk): all workgroups of env e run on XCD e % 8
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int e = (slot / chunks) * 8 + xcd;
+    const int c = slot % chunks;
+    if (e >= n) return;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+#ifdef PHASE_TIMING
+    const uint64_t pt0 = wall_clock64();
+#endif
+    for (int i = tid; i < words; i += kFusedThreads) smem[i] = 0u;
+    if (coverage_zero != nullptr && c == 0 && tid == 0) coverage_zero[e] = 0;  // (accumulated by the grid-update launch)
+
+    PixelFrame pf;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pf.M[i] = c2w[(size_t)e * 16 + i];
+    {
+        const VoxelFrame f = load_frame(range_gt + e * 6, voxel_size + e * 3);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            pf.hf.vmin[a] = f.vmin[a]; pf.hf.vmax[a] = f.vmax[a]; pf.hf.vox[a] = f.vox[a];
+            pf.hf.inv_vox[a] = __frcp_rn(f.vox[a]);
+            pf.lo[a] = nextafterf(f.vmin[a], INFINITY);
+            pf.hi[a] = nextafterf(f.vmax[a], -INFINITY);
+        }
+    }
+    pf.hf.gmax = (float)(g - 1);
+    pf.g = g; pf.gg = g * g; pf.sense_dist = sense_dist;
+    const int hw = h * w;
+    int ppc = (hw + chunks - 1) / chunks;
+    ppc = (ppc + 3) & ~3;
+    const int px0 = c * ppc, px1 = min(hw, px0 + ppc);
+    const float *dptr = depth_raw + (size_t)e * hw;
+    const float *sptr = seg_raw + (size_t)e * hw;
+    const float inv_w = __frcp_rn((float)w);
+    __syncthreads();
+
+    // ---- phase A: hit mask ------------------------------------------------------------------------------
+    if ((w & 3) == 0 && hw < (1 << 23)) {
+        // kAhead tiles of 4096 pixels in flight per workgroup (2 x 16-byte streaming requests per lane and tile); addresses
+        // are clamped, so every request is unconditional and the waits land behind a tile's arithmetic.  The stream alone runs
+        // at 6.2 TB/s (25 us), the arithmetic alone takes 44 us with the 16 waves a CU holds: this phase is instruction-issue
+        // bound (profiles/r02_notes.md).
+        constexpr int kTile = kFusedThreads * 4, kAhead = 3;
+        float4 dq[kAhead], sq[kAhead];
+        const int plast = px1 - 4;
+        const int ntiles = (px1 - px0 + kTile - 1) / kTile;
+        auto tile_px = [&](int t) { return px0 + t * kTile + tid * 4; };
+#pragma unroll
+        for (int q = 0; q < kAhead; ++q) {
+            const int pq = min(tile_px(min(q, ntiles - 1)), plast);
+            dq[q] = ld4_stream(dptr + pq);
+            sq[q] = ld4_stream(sptr + pq);
+        }
+        for (int t0 = 0; t0 < ntiles; t0 += kAhead) {
+#pragma unroll
+            for (int q = 0; q < kAhead; ++q) {
+                const int t = t0 + q;
+                const int p = t < ntiles ? tile_px(t) : px1;
+                const float4 d4 = dq[q], s4 = sq[q];
+                const int pn = min(tile_px(min(t + kAhead, ntiles - 1)), plast);
+                dq[q] = ld4_stream(dptr + pn);
+                sq[q] = ld4_stream(sptr + pn);
+                // (a tile of pure background -- all 256 pixels of the wave -- skips the arithmetic)
+                if (p < px1 && __any((s4.x > 50.0f) | (s4.y > 50.0f) | (s4.z > 50.0f) | (s4.w > 50.0f))) {
+                    const int y = floor_div_small(p, w, inv_w);  // 4 consecutive pixels share the row (w % 4 == 0)
+                    const float fy = (float)y, fx = (float)(p - y * w);
+                    const int l0 = pixel_to_lin<KFAST>(pf, K, fx, fy, d4.x, s4.x);
+                    const int l1 = pixel_to_lin<KFAST>(pf, K, fx + 1.0f, fy, d4.y, s4.y);
+                    const int l2 = pixel_to_lin<KFAST>(pf, K, fx + 2.0f, fy, d4.z, s4.z);
+                    const int l3 = pixel_to_lin<KFAST>(pf, K, fx + 3.0f, fy, d4.w, s4.w);
+                    // neighbouring pixels mostly fall into the same voxel: a pixel whose left neighbour (previous pixel of the
+                    // lane, or the last pixel of the previous lane in the 16-lane DPP row) has the same voxel leaves the bit to it
+                    const int pl = __builtin_amdgcn_update_dpp(-2, l3, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+                    if (l0 >= 0 && l0 != pl) atomicOr(&s_hit[l0 >> 5], 1u << (l0 & 31));
+                    if (l1 >= 0 && l1 != l0) atomicOr(&s_hit[l1 >> 5], 1u << (l1 & 31));
+                    if (l2 >= 0 && l2 != l1) atomicOr(&s_hit[l2 >> 5], 1u << (l2 & 31));
+                    if (l3 >= 0 && l3 != l2) atomicOr(&s_hit[l3 >> 5], 1u << (l3 & 31));
+                }
+            }
+        }
+    } else {
+        for (int p = px0 + tid; p < px1; p += kFusedThreads) {
+            const int y = p / w;
+            const int l0 = pixel_to_lin<KFAST>(pf, K, (float)(p - y * w), (float)y, dptr[p], sptr[p]);
+            if (l0 >= 0) atomicOr(&s_hit[l0 >> 5], 1u << (l0 & 31));
+        }
+    }
+
+    __syncthreads();
+#ifdef PHASE_TIMING
+    const uint64_t pt1 = wall_clock64();
+#endif
+
+    // ---- phase B: write the mask out, append its set bits to the env's ray list ------------------------------------
+    // Two levels, so that no wave runs a long serial loop alone (a lone wave issues a dependent instruction every ~8
+    // cycles; a lane expanding 8 strided words bit by bit took 15 us on an env with 4000 rays): (1) the non-zero words are
+    // compacted into an LDS index list -- wave-aggregated slot allocation, no per-word loop; (2) one lane per non-zero word
+    // (evenly spread over the workgroup) reserves list slots through a wave scan + one LDS atomic and writes its <= 32 bits.
+    const int wpl = (words + kFusedThreads - 1) / kFusedThreads;  // words per lane, strided by the workgroup
+    uint32_t *gh = hit_mask + (size_t)e * words;
+    int *s_cnt = s_wave;  // [0] non-zero words, [1] rays, [2] this workgroup's base in the env's list
+    if (tid < 4) s_cnt[tid] = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (int k = 0; k < wpl; ++k) {
+        const int wi = k * kFusedThreads + tid;
+        const uint32_t v = wi < words ? s_hit[wi] : 0u;
+        cnt += __popc(v);
+        if (wi < words) {
+            if (chunks == 1) gh[wi] = v;
+            else if (v) atomicOr(&gh[wi], v);
+        }
+        const unsigned long long nz = __ballot(v != 0u);
+        if (nz) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_cnt[0], __popcll(nz));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (v) s_widx[base + __popcll(nz & ((1ull << lane) - 1ull))] = (uint16_t)wi;
+        }
+    }
+    cnt = wave_reduce_sum(cnt);
+    if (lane == 0 && cnt) atomicAdd(&s_cnt[1], cnt);
+#ifdef PHASE_TIMING
+    const uint64_t pt2 = wall_clock64();
+#endif
+    __syncthreads();
+    const int nwords = s_cnt[0], total = s_cnt[1];
+    if (tid == 0) {
+        // this workgroup's slots in the env's list (any order: the path is a set)
+        s_cnt[2] = chunks == 1 ? 0 : atomicAdd(&ray_count[e], total);
+        if (chunks == 1) ray_count[e] = total;
+        s_cnt[3] = 0;
+    }
+    __syncthreads();
+#ifdef PHASE_TIMING
+    const uint64_t pt3 = wall_clock64();
+#endif
+    {
+        int32_t *list = ray_list + (size_t)e * ray_cap + s_cnt[2];
+        const int64_t room = ray_cap - s_cnt[2];  // (cannot overflow: one entry per pixel at most)
+        for (int j0 = 0; j0 < nwords; j0 += kFusedThreads) {
+            const int j = j0 + tid;
+            const int wi = j < nwords ? (int)s_widx[j] : 0;
+            uint32_t v = j < nwords ? s_hit[wi] : 0u;
+            const int c1 = __popc(v);
+            const int incl = wave_inclusive_scan(c1);
+            int base = 0;
+            if (lane == kWave - 1 && incl) base = atomicAdd(&s_cnt[3], incl);
+            base = __builtin_amdgcn_readlane(base, kWave - 1);
+            int o = base + incl - c1;
+            while (v) {
+                const int bit = __ffs(v) - 1;
+                v &= v - 1;
+                if (o < room) list[o] = wi * 32 + bit;
+                ++o;
+            }
+        }
+    }
+#ifdef PHASE_TIMING
+    __syncthreads();
+    if (tid == 0) {
+        int32_t *dbg = ray_list + (size_t)n * ray_cap - 8 * (size_t)gridDim.x;
+        dbg[8 * blockIdx.x + 0] = (int32_t)(pt1 - pt0);
+        dbg[8 * blockIdx.x + 1] = (int32_t)(wall_clock64() - pt1);
+        dbg[8 * blockIdx.x + 2] = s_wave[1];
+        dbg[8 * blockIdx.x + 3] = (int32_t)(pt0 & 0x7fffffff);
+        dbg[8 * blockIdx.x + 4] = (int32_t)(pt2 - pt1);
+        dbg[8 * blockIdx.x + 5] = (int32_t)(pt3 - pt2);
+        dbg[8 * blockIdx.x + 6] = (int32_t)(wall_clock64() - pt3);
+        dbg[8 * blockIdx.x + 7] = 0;
+    }
+#endif
+}
+
+// launch 2: load-balanced ray cast over the ray lists (see the header above)
+__global__ __launch_bounds__(kListThreads) void k_ray_list(
+    const int32_t *__restrict__ ray_count, const int32_t *__restrict__ ray_list, int64_t ray_cap, const float *__restrict__ poses_xyz,
+    int64_t pose_stride, const float *__restrict__ range_gt, const float *__restrict__ voxel_size, int n, int g, int words,
+    uint32_t *__restrict__ path_mask)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_path[];
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int e = (slot / kListSlices) * 8 + xcd;
+    const int sl = slot % kListSlices;
+    if (e >= n) return;
+    const int cnt = (int)min((int64_t)ray_count[e], ray_cap);
+    if (sl * kListThreads >= cnt) return;  // light env: nothing for this slice
+    const int tid = threadIdx.x;
+    for (int i = tid; i < words; i += kListThreads) s_path[i] = 0u;
+    const float *pp = poses_xyz + (size_t)e * pose_stride;
+    const int src[3] = {pose_axis_to_idx(pp[0], range_gt[e * 6 + 1], voxel_size[e * 3 + 0]),
+                        pose_axis_to_idx(pp[1], range_gt[e * 6 + 3], voxel_size[e * 3 + 1]),
+                        pose_axis_to_idx(pp[2], range_gt[e * 6 + 5], voxel_size[e * 3 + 2])};
+    const int gg = g * g;
+    const int32_t *list = ray_list + (size_t)e * ray_cap;
+    __syncthreads();
+    // Consecutive list entries are neighbouring voxels whose rays run through the same mask words step after step
+    // (64-way same-address LDS atomics): lane r walks entry (r * P) mod cnt instead, a bijection for P coprime to cnt.
+    const int64_t P = (cnt % 7919) ? 7919 : 7907;
+    for (int r = sl * kListThreads + tid; r < cnt; r += kListSlices * kListThreads)
+        trace_ray_lane<true, false>(src, list[(int)(((int64_t)r * P) % cnt)], g, gg, s_path, nullptr);
+    __syncthreads();
+    uint32_t *gp = path_mask + (size_t)e * words;
+    for (int i = tid; i < words; i += kListThreads) {
+        const uint32_t v = s_path[i];
+        if (v) atomicOr(&gp[i], v);
     }
 }
 
@@ -928,14 +1243,28 @@ static inline int mask_words_padded(int g) { return (mask_words(g) + 63) & ~63; 
 struct VoxelWorkspace {
     uint32_t *hit, *path;
     int words;
+    int32_t *ray_count;  // [n] (padded to 64 ints), directly behind the masks: one fill zeroes masks + counts
+    int32_t *ray_list;   // [n][ray_cap] target voxels, or NULL (mask-only workspace: the two-launch mask kernels run)
+    int64_t ray_cap;
 };
 
-static inline VoxelWorkspace carve(void *ws, int n, int g)
+GNBV_API size_t gnbv_voxel_workspace_bytes_hw(int n, int g, int h, int w);
+static inline size_t ray_count_ints(int n) { return ((size_t)n + 63) & ~(size_t)63; }
+// an env lists one ray per distinct voxel and chunk: never more than its pixels
+static inline int64_t ray_list_cap(int g, int h, int w) { return ((int64_t)h * w + 63) & ~(int64_t)63; }
+
+static inline VoxelWorkspace carve(void *ws, size_t ws_bytes, int n, int g, int h, int w)
 {
     VoxelWorkspace v;
     v.words = mask_words_padded(g);
     v.hit = (uint32_t *)ws;
     v.path = v.hit + (size_t)n * v.words;
+    v.ray_count = nullptr; v.ray_list = nullptr; v.ray_cap = 0;
+    if (h > 0 && w > 0 && ws_bytes >= gnbv_voxel_workspace_bytes_hw(n, g, h, w)) {
+        v.ray_count = (int32_t *)(v.path + (size_t)n * v.words);
+        v.ray_list = v.ray_count + ray_count_ints(n);
+        v.ray_cap = ray_list_cap(g, h, w);
+    }
     return v;
 }
 
@@ -943,6 +1272,12 @@ GNBV_API size_t gnbv_voxel_workspace_bytes(int n, int g)
 {
     if (n <= 0 || g <= 0) return 0;
     return (size_t)2 * n * mask_words_padded(g) * sizeof(uint32_t);
+}
+
+GNBV_API size_t gnbv_voxel_workspace_bytes_hw(int n, int g, int h, int w)
+{
+    if (n <= 0 || g <= 0 || h <= 0 || w <= 0) return 0;
+    return gnbv_voxel_workspace_bytes(n, g) + (ray_count_ints(n) + (size_t)n * (size_t)ray_list_cap(g, h, w)) * sizeof(int32_t);
 }
 
 // inv_intri is a HOST pointer to 9 floats: the matrix is a constant of the task
@@ -1055,6 +1390,66 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
         static const int forced = [] { const char *v = getenv("GENNBV_RAY_SPLITS"); return v ? atoi(v) : 0; }();
         if (forced > 0) splits = forced;  // tuning knob (tools/ab_voxel.sh)
     }
+    // inv_intri of a pinhole camera is [[a,0,c],[0,b,d],[0,0,1]]: lets the kernels drop exact-zero terms
+    const bool kfast = K.k[1] == 0.0f && K.k[3] == 0.0f && K.k[6] == 0.0f && K.k[7] == 0.0f && K.k[8] == 1.0f;
+    const int env_groups = (n + 7) / 8;
+    // hit mask + ray list, then the load-balanced ray cast over the lists (needs the h/w-sized workspace)
+    const size_t list_lds = mask_bytes + 64 * sizeof(uint32_t) + (size_t)words * sizeof(uint16_t);
+    static const bool fused_off = [] { const char *v = getenv("GENNBV_RAY_LISTS"); return v && v[0] == '0'; }();
+    if (!lds_off && !fused_off && ws.ray_list != nullptr && list_lds <= kLdsMax && words <= 65536) {
+        // workgroups per env: one per CU in total (1024 threads each; measured: a second one does not become resident beside
+        // it, 512 workgroups run as two rounds); one per env = plain stores of the hit mask, no ray listed twice
+        int fchunks = (256 + n - 1) / n;
+        fchunks = fchunks < 1 ? 1 : (fchunks > 16 ? 16 : fchunks);
+        {
+            static const int forced = [] { const char *v = getenv("GENNBV_HIT_CHUNKS"); return v ? atoi(v) : 0; }();
+            if (forced > 0) fchunks = forced;  // tuning knob (tools/ab_voxel.sh)
+        }
+        // one fill: [hit (only when OR-accumulated) | path | ray counts] are adjacent for the full env range
+        if (ws.path == ws.hit + (size_t)n * words && (void *)ws.ray_count == (void *)(ws.path + (size_t)n * words)) {
+            uint32_t *z0 = fchunks > 1 ? ws.hit : ws.path;
+            const size_t zb = (size_t)((char *)(ws.ray_count + ray_count_ints(n)) - (char *)z0);
+            if ((err = (int)hipMemsetAsync(z0, 0, zb, st))) return err;
+        } else {
+            if (fchunks > 1 && (err = (int)hipMemsetAsync(ws.hit, 0, (size_t)n * mask_bytes, st))) return err;
+            if ((err = (int)hipMemsetAsync(ws.path, 0, (size_t)n * mask_bytes, st))) return err;
+            if ((err = (int)hipMemsetAsync(ws.ray_count, 0, (size_t)n * sizeof(int32_t), st))) return err;
+        }
+        const int fgrid = env_groups * 8 * fchunks;
+#define GNBV_HITLIST(KF)                                                                                                             \
+    do {                                                                                                                             \
+        if (list_lds > 64 * 1024 &&                                                                                                  \
+            hipFuncSetAttribute((const void *)k_hit_list<KF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)list_lds) != hipSuccess) \
+            return (int)hipGetLastError();                                                                                           \
+        hipLaunchKernelGGL((k_hit_list<KF>), dim3(fgrid), dim3(kFusedThreads), list_lds, st, depth_raw, seg_raw, c2w, K, range_gt,   \
+                           voxel_size, n, h, w, g, depth_sense_dist, fchunks, words, ws.hit, ws.ray_count, ws.ray_list, ws.ray_cap,   \
+                           coverage_count);                                                                                          \
+    } while (0)
+        {
+            static const bool show = getenv("GENNBV_PRINT_OCCUPANCY") != nullptr;  // profiling aid
+            static bool shown = false;
+            if (show && !shown) {
+                shown = true;
+                int nb = -1, nr = -1;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_hit_list<true>, kFusedThreads, list_lds);
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nr, (const void *)k_ray_list, kListThreads, mask_bytes);
+                hipFuncAttributes fa;
+                (void)hipFuncGetAttributes(&fa, (const void *)k_hit_list<true>);
+                fprintf(stderr, "[gennbv] k_hit_list: %d workgroups of %d threads per CU (LDS %zu B, %d regs, static LDS %zu); k_ray_list: %d per CU\n",
+                        nb, kFusedThreads, list_lds, fa.numRegs, fa.sharedSizeBytes, nr);
+            }
+        }
+        if (kfast) GNBV_HITLIST(true);
+        else GNBV_HITLIST(false);
+#undef GNBV_HITLIST
+        if ((err = gnbv_launch_status())) return err;
+        if (mask_bytes > 64 * 1024 &&
+            hipFuncSetAttribute((const void *)k_ray_list, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mask_bytes) != hipSuccess)
+            return (int)hipGetLastError();
+        hipLaunchKernelGGL(k_ray_list, dim3(env_groups * 8 * kListSlices), dim3(kListThreads), mask_bytes, st, ws.ray_count, ws.ray_list,
+                           ws.ray_cap, poses_xyz, poses_row_stride, range_gt, voxel_size, n, g, words, ws.path);
+        return gnbv_launch_status();
+    }
     // zero the hit masks (OR-accumulated by atomics); the path masks only when they are
     // OR-accumulated too (several splits, or no LDS staging)
     const bool path_needs_zero = !lds_path || splits > 1;  // (windows write disjoint word ranges)
@@ -1067,12 +1462,9 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
     err = (int)hipMemsetAsync(coverage_count, 0, (size_t)n * sizeof(int32_t), st);
     if (err) return err;
     // launch 1: hit mask.  chunks: enough workgroups to cover the chip several times.
-    const int env_groups = (n + 7) / 8;
     int chunks = (8 * 256 + n - 1) / n;
     chunks = chunks < 1 ? 1 : (chunks > 16 ? 16 : chunks);
     const int hit_grid = env_groups * 8 * chunks * (lds_hit ? hit_windows : 1);
-    // inv_intri of a pinhole camera is [[a,0,c],[0,b,d],[0,0,1]]: lets the kernel drop exact-zero terms
-    const bool kfast = K.k[1] == 0.0f && K.k[3] == 0.0f && K.k[6] == 0.0f && K.k[7] == 0.0f && K.k[8] == 1.0f;
 #define GNBV_HIT(KF, WIN)                                                                                                            \
     do {                                                                                                                             \
         if (hit_lds > 64 * 1024 &&                                                                                                   \
@@ -1137,7 +1529,7 @@ GNBV_API int gnbv_update_occ_grid(const float *depth_raw, const float *seg_raw, 
     GNBV_CHECK_ARG(g3 < (1ll << 31) && tri_row_stride >= g3 && (int64_t)h * w < (1ll << 31));
     GNBV_CHECK_ARG(workspace_bytes >= gnbv_voxel_workspace_bytes(n, g) && ((uintptr_t)workspace & 255) == 0);
     hipStream_t st = gnbv_stream(stream);
-    VoxelWorkspace ws = carve(workspace, n, g);
+    VoxelWorkspace ws = carve(workspace, workspace_bytes, n, g, h, w);
     int err = launch_masks(depth_raw, seg_raw, c2w, inv_intri, poses_xyz, poses_row_stride, range_gt, voxel_size, n, h, w, g,
                            depth_sense_dist, coverage_count, ws, st);
     if (err) return err;
@@ -1193,6 +1585,7 @@ static int update_packed_range(const float *depth_raw, const float *seg_raw, con
     VoxelWorkspace ws = full;
     ws.hit = full.hit + (size_t)e0 * full.words;
     ws.path = full.path + (size_t)e0 * full.words;
+    if (full.ray_list) { ws.ray_count = full.ray_count + e0; ws.ray_list = full.ray_list + (size_t)e0 * full.ray_cap; }
     depth_raw += e0 * hw; seg_raw += e0 * hw; c2w += (size_t)e0 * 16; poses_xyz += (size_t)e0 * poses_row_stride;
     range_gt += (size_t)e0 * 6; voxel_size += (size_t)e0 * 3; gt_bits += (size_t)e0 * full.words;
     if (reset_mask) reset_mask += e0;
@@ -1250,7 +1643,7 @@ GNBV_API int gnbv_update_occ_grid_packed(const float *depth_raw, const float *se
     GNBV_CHECK_ARG(g3 < (1ll << 31) && tri_row_stride >= g3 && (int64_t)h * w < (1ll << 31));
     GNBV_CHECK_ARG(workspace_bytes >= gnbv_voxel_workspace_bytes(n, g) && ((uintptr_t)workspace & 255) == 0);
     hipStream_t st = gnbv_stream(stream);
-    VoxelWorkspace ws = carve(workspace, n, g);
+    VoxelWorkspace ws = carve(workspace, workspace_bytes, n, g, h, w);
     VoxelSide &side = voxel_side();
     if (!side.enabled || n < 16) {
         return update_packed_range(depth_raw, seg_raw, c2w, inv_intri, poses_xyz, poses_row_stride, range_gt, voxel_size, gt_bits,
@@ -1309,7 +1702,7 @@ GNBV_API int gnbv_update_occ_grid_coded(const float *depth_raw, const float *seg
     GNBV_CHECK_ARG(g3 < (1ll << 31) && (tri_out == nullptr || tri_row_stride >= g3) && (int64_t)h * w < (1ll << 31));
     GNBV_CHECK_ARG(workspace_bytes >= gnbv_voxel_workspace_bytes(n, g) && ((uintptr_t)workspace & 255) == 0);
     hipStream_t st = gnbv_stream(stream);
-    VoxelWorkspace ws = carve(workspace, n, g);
+    VoxelWorkspace ws = carve(workspace, workspace_bytes, n, g, h, w);
     int err = launch_masks(depth_raw, seg_raw, c2w, inv_intri, poses_xyz, poses_row_stride, range_gt, voxel_size, n, h, w, g,
                            depth_sense_dist, coverage_count, ws, st);
     if (err) return err;
@@ -1334,7 +1727,7 @@ GNBV_API int gnbv_update_occ_grid_coded(const float *depth_raw, const float *seg
 GNBV_API int gnbv_unpack_masks(const void *workspace, int n, int g, uint8_t *hit_u8, uint8_t *path_u8, void *stream)
 {
     GNBV_CHECK_ARG(workspace && n > 0 && g > 0);
-    VoxelWorkspace ws = carve(const_cast<void *>(workspace), n, g);
+    VoxelWorkspace ws = carve(const_cast<void *>(workspace), 0, n, g, 0, 0);
     const int64_t g3 = (int64_t)g * g * g;
     if (hit_u8)
         hipLaunchKernelGGL(k_unpack, dim3(grid_for(n * g3, 256)), dim3(256), 0, gnbv_stream(stream), ws.hit, g3, ws.words, n,

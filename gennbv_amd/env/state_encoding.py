@@ -53,7 +53,7 @@ class OccupancyGridUpdater:
         self.scanned_bits = torch.zeros(num_envs, words, dtype=torch.int32, device=self.device)
         self._scanned_f32 = None if self.packed else torch.zeros_like(self._prob_f32)
         self.coverage_count = torch.zeros(num_envs, dtype=torch.int32, device=self.device)
-        nbytes = self.lib.gnbv_voxel_workspace_bytes(num_envs, g)
+        nbytes = self.lib.gnbv_voxel_workspace_bytes_hw(num_envs, g, self.h, self.w)  # masks + per-env ray lists
         # torch's caching allocator returns >=512-byte aligned blocks
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         assert self.workspace.data_ptr() % 256 == 0

@@ -89,6 +89,11 @@ int gnbv_grid_tri_cls(const float *grid_prob, int64_t count, float threshold_occ
 /*   workspace: gnbv_voxel_workspace_bytes(n, g) bytes, 256-byte aligned.       */
 /* ------------------------------------------------------------------------- */
 size_t gnbv_voxel_workspace_bytes(int n, int g);
+/* The same two bitmask arrays + per-env ray lists (one int32 per distinct hit voxel and image chunk, capacity h*w per
+ * env): with a workspace of at least this size the update runs the hit-list + load-balanced ray-cast launches
+ * (csrc/voxel.hip: k_hit_list, k_ray_list); with the smaller mask-only workspace it falls back to k_hit_mask + k_raycast.
+ * Same results either way. */
+size_t gnbv_voxel_workspace_bytes_hw(int n, int g, int h, int w);
 
 int gnbv_update_occ_grid(const float *depth_raw, const float *seg_raw, const float *c2w,
                          const float *inv_intri /*[host] [3,3]*/,

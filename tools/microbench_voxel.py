@@ -18,6 +18,7 @@ ap.add_argument("--prob", default="coded", choices=["coded", "f32"], help="1-byt
 ap.add_argument("--out", default="i8", choices=["f32", "f32+i8", "i8"],
                 help="tri-class output: fp32 rows (flat observations), fp32 + int8 copy, or int8 rows only (compact observations, "
                      "coded update; the bench default)")
+ap.add_argument("--phase-times", action="store_true", help="experiment builds (-DPHASE_TIMING): per-workgroup phase times of k_hit_list")
 a = ap.parse_args()
 if a.prob != "coded":
     a.out = "f32"
@@ -51,3 +52,15 @@ ms = e0.elapsed_time(e1) / a.iters
 bvox = a.h * a.w * 8 + a.g ** 3 * 4 * 6 + 200
 print(f"update_occ_grid: {ms:.4f} ms/step  -> {a.n / ms * 1e3:.0f} env-steps/s (voxel only), "
       f"algorithmic {a.n * bvox / 1e6:.1f} MB/step -> {a.n * bvox / ms / 1e6:.1f} GB/s = {a.n * bvox / ms / 1e6 / 8000 * 100:.1f}% of 8 TB/s")
+
+if a.phase_times:
+    import numpy as np
+    nwg = a.n * max(1, int(os.environ.get("GENNBV_HIT_CHUNKS", "0")) or (256 + a.n - 1) // a.n)
+    tail = upd.workspace.view(torch.int32)[-8 * nwg:].cpu().numpy().reshape(nwg, 8)
+    pa, pb, rays, t0 = tail[:, 0] / 100.0, tail[:, 1] / 100.0, tail[:, 2], tail[:, 3] / 100.0
+    print(f"k_hit_list phases over {nwg} workgroups (us): A mean {pa.mean():.1f} max {pa.max():.1f} | B mean {pb.mean():.1f} max {pb.max():.1f} | "
+          f"rays mean {rays.mean():.0f} max {rays.max()} | start spread {t0.max() - t0.min():.1f} | end spread {(t0 + pa + pb).max() - t0.min():.1f}")
+    i = int(np.argmax(pb))
+    print("  B pieces (mask store+popc | scans | emission): mean", (tail[:, 4:7] / 100.0).mean(0).round(1), " heaviest WG:", (tail[i, 4:7] / 100.0).round(1),
+          "rays", rays[i], "its A", pa[i])
+    print("  corr(A, rays)", np.corrcoef(pa, rays)[0, 1].round(2))
