@@ -353,17 +353,28 @@ def main():
 
     env_steps = world * args.envs * args.n_steps * args.steps
     value = env_steps / elapsed
-    # roofline of the voxel update: algorithmic bytes per env-step x envs per launch
-    b_vox = args.height * args.width * 8 + args.grid ** 3 * 4 * 6 + 200
+    # roofline of the voxel update.  Two byte counts per launch (= one gnbv_update_occ_grid_coded call over the rank's envs):
+    #  * reference layout: depth + seg once, six fp32 passes over G^3 -- what a perfect implementation of the
+    #    reference's tensors would move; reported as `vs_reference_layout_floor`;
+    #  * this layout: depth + seg once, the 1-byte probability code R + W, the int8 tri-class row W,
+    #    seven bitmask passes (hit W + R, path W + R, gt R, scanned R + W) and the ray list W + R -- the bytes `frac` prices.
+    # `traffic` = HBM bytes from rocprofv3 --pmc passes of THIS build (profiles/rNN_voxel_traffic.json carries the sha256 of
+    # csrc/voxel.hip it was measured on; a different source -> null).
+    import hashlib
+    g3 = args.grid ** 3
+    b_ref = args.height * args.width * 8 + g3 * 4 * 6 + 200
+    b_lay = args.height * args.width * 8 + g3 * (3 if args.obs == "compact" else 6) + 7 * (g3 // 8) + 2 * 4 * 1200 + 200
     vox_ms = vox.total_ms() / max(vox.count(), 1)
-    achieved = args.envs * b_vox / (vox_ms * 1e-3) / 1e9
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "r01_voxel_traffic.json")
-    if os.path.exists(tf):
-        tj = json.load(open(tf))
+    achieved = args.envs * b_lay / (vox_ms * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    src_sha = hashlib.sha256(open(os.path.join(ROOT, "gennbv_amd", "csrc", "voxel.hip"), "rb").read()).hexdigest()
+    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_voxel_traffic.json")), reverse=True):
+        tj = json.load(open(os.path.join(ROOT, "profiles", name)))
         c = tj["config"]
-        if (c["envs"], c["height"], c["width"], c["grid"], c.get("obs", "flat")) == (args.envs, args.height, args.width, args.grid, args.obs):
-            traffic = tj["traffic_bytes_per_launch"]  # rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (profiles/r01_voxel_pmc.txt)
+        if tj.get("source_sha256") == src_sha and (c["envs"], c["height"], c["width"], c["grid"], c.get("obs", "flat")) == (
+                args.envs, args.height, args.width, args.grid, args.obs):
+            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/" + name
+            break
     out = {
         "metric": "env-steps/sec at 256 envs x 64^3 grid (state encoding + policy forward + GAE + PPO update)",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -380,9 +391,14 @@ def main():
                    "breakdown_ms_per_step": {"rollout": phases["rollout"].total_ms() / args.steps,
                                              "train": phases["train"].total_ms() / args.steps,
                                              "voxel_update_total": vox.total_ms() / args.steps}},
-        "roofline": {"bound": "hbm", "kernel": "gnbv_update_occ_grid_coded (k_hit_mask + k_raycast + k_grid_update_coded; 1-byte coded probability grid)",
+        "roofline": {"bound": "hbm", "kernel": "gnbv_update_occ_grid_coded (k_hit_list + k_ray_list + k_grid_update_coded + one mask fill; 1-byte coded probability grid)",
                      "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "launch_ms": vox_ms, "algorithmic_bytes_per_launch": args.envs * b_vox, "traffic": traffic},
+                     "launch_ms": vox_ms, "algorithmic_bytes_per_launch": args.envs * b_lay,
+                     "bytes_basis": "this layout's compulsory HBM bytes (depth + seg, 1-byte code R+W, int8 tri-class W, 7 bitmask passes, ray lists)",
+                     "vs_reference_layout_floor": {"reference_layout_bytes_per_launch": args.envs * b_ref,
+                                                   "floor_ms_at_peak": args.envs * b_ref / 8e12 * 1e3,
+                                                   "speedup_over_floor": (args.envs * b_ref / 8e12 * 1e3) / vox_ms},
+                     "traffic": traffic, "traffic_source": traffic_src},
     }
     if rank == 0:
         try:

@@ -65,6 +65,7 @@ SIGNATURES = {
     "gnbv_gather_minibatch": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnbv_ppo_loss": (_i, [_p, _p]),
     "gnbv_multicategorical_sample": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p, _p]),
+    "gnbv_ppo_loss_rsl": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _f, _f, _i, _p, _p, _p, _p, _p]),
     "gnbv_adam_workspace_bytes": (_sz, []),
     "gnbv_clip_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _p, _f, _p, _f, _p, _p, _sz, _p]),
     "gnbv_chamfer_workspace_bytes": (_sz, [_i, _i]),

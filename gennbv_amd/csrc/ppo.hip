@@ -197,6 +197,51 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_dlogits(GnbvPpoLoss a, con
 // serially take ~130 us -- the three launches below, 28 us together, stay.)
 
 // ---------------------------------------------------------------------------
+// rsl_rl flavour (rsl_rl/algorithms/ppo.py:160-180): one workgroup, the minibatch's scalar loss and its gradient with
+// respect to (log_prob, value, entropy) -- the distribution itself stays with the caller's modules.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kLossThreads) void k_ppo_loss_rsl(int B, const float *__restrict__ logp, const float *__restrict__ old_logp,
+                                                              const float *__restrict__ adv, const float *__restrict__ v,
+                                                              const float *__restrict__ tv, const float *__restrict__ ret, float clip,
+                                                              float vcoef, float ecoef, int clipped_v, float *__restrict__ d_logp,
+                                                              float *__restrict__ d_v, float *__restrict__ d_ent, float *__restrict__ sums)
+{
+    __shared__ float scratch[kLossThreads / 64 + 1];
+    const float invB = 1.0f / (float)B;
+    float sl = 0.f, vl = 0.f;
+    for (int i = threadIdx.x; i < B; i += kLossThreads) {
+        const float a = adv[i];
+        const float ratio = expf(logp[i] - old_logp[i]);
+        const float lo = 1.0f - clip, hi = 1.0f + clip;
+        const float rc = fminf(fmaxf(ratio, lo), hi);
+        const float s1 = -a * ratio, s2 = -a * rc;
+        sl += fmaxf(s1, s2);
+        // d max(s1, s2): the larger operand takes the gradient, ties split evenly (torch.max of two tensors)
+        const float g1 = s1 > s2 ? 1.f : (s1 < s2 ? 0.f : 0.5f), g2 = 1.f - g1;
+        const float inrange = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+        d_logp[i] = invB * (-a) * ratio * (g1 + g2 * inrange);
+        const float e1 = v[i] - ret[i];
+        if (clipped_v) {
+            const float dv = v[i] - tv[i];
+            const float vc = tv[i] + fminf(fmaxf(dv, -clip), clip);
+            const float e2 = vc - ret[i];
+            const float l1 = e1 * e1, l2 = e2 * e2;
+            vl += fmaxf(l1, l2);
+            const float h1 = l1 > l2 ? 1.f : (l1 < l2 ? 0.f : 0.5f), h2 = 1.f - h1;
+            const float vin = (dv >= -clip && dv <= clip) ? 1.f : 0.f;
+            d_v[i] = vcoef * invB * 2.0f * (h1 * e1 + h2 * e2 * vin);
+        } else {
+            vl += e1 * e1;
+            d_v[i] = vcoef * invB * 2.0f * e1;
+        }
+        d_ent[i] = -ecoef * invB;
+    }
+    sl = block_sum<kLossThreads>(sl, scratch) * invB;
+    vl = block_sum<kLossThreads>(vl, scratch) * invB;
+    if (threadIdx.x == 0 && sums) { sums[0] += vl; sums[1] += sl; }
+}
+
+// ---------------------------------------------------------------------------
 // clip_grad_norm_ + Adam over a flat buffer
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_grad_sqnorm(const float *__restrict__ g, int64_t n, double *__restrict__ partial)
@@ -363,6 +408,19 @@ GNBV_API int gnbv_ppo_loss(const GnbvPpoLoss *a, void *stream)
     hipLaunchKernelGGL(k_ppo_logp, dim3(blocks), dim3(kLossThreads), 0, st, *a, logp, ent);
     hipLaunchKernelGGL(k_ppo_scalars, dim3(1), dim3(kLossThreads), 0, st, *a, (const float *)logp, (const float *)ent, gl);
     hipLaunchKernelGGL(k_ppo_dlogits, dim3(blocks), dim3(kLossThreads), 0, st, *a, (const float *)gl);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_ppo_loss_rsl(int batch, const float *log_prob, const float *old_log_prob, const float *advantages, const float *values,
+                               const float *target_values, const float *returns, float clip_param, float value_loss_coef,
+                               float entropy_coef, int use_clipped_value_loss, float *d_log_prob, float *d_values, float *d_entropy,
+                               float *sums, void *stream)
+{
+    GNBV_CHECK_ARG(batch > 0 && log_prob && old_log_prob && advantages && values && target_values && returns);
+    GNBV_CHECK_ARG(d_log_prob && d_values && d_entropy && clip_param > 0.0f);
+    hipLaunchKernelGGL(k_ppo_loss_rsl, dim3(1), dim3(kLossThreads), 0, gnbv_stream(stream), batch, log_prob, old_log_prob, advantages,
+                       values, target_values, returns, clip_param, value_loss_coef, entropy_coef, use_clipped_value_loss, d_log_prob,
+                       d_values, d_entropy, sums);
     return gnbv_launch_status();
 }
 

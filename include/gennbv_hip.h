@@ -396,6 +396,19 @@ int gnbv_multicategorical_sample(const float *logits, int batch, int n_logits, i
  * ranks of approx_kl; *stop_flag becomes 1 (sticky) when kl_slot*grad_scale > 1.5*target_kl.
  * *step is incremented and the update applied unless *stop_flag != 0.
  * norm_out[0] = norm of the mean gradient, [1] = factor applied to `grads`. */
+/* rsl_rl flavour of the PPO minibatch loss (rsl_rl/algorithms/ppo.py:160-180): scalar part of
+ *   surrogate  = mean(max(-A r, -A clamp(r, 1 - c, 1 + c))),  r = exp(log_prob - old_log_prob)
+ *   value_loss = mean(max((v - R)^2, (tv + clamp(v - tv, -c, c) - R)^2))   (use_clipped_value_loss) or mean((R - v)^2)
+ *   loss       = surrogate + value_loss_coef * value_loss - entropy_coef * mean(entropy)
+ * for ANY action distribution: the caller evaluates log_prob / value / entropy of the minibatch with its own modules and
+ * back-propagates the three gradient vectors this call returns (ties of max() split evenly, like torch.max).
+ * All arrays [batch] fp32, device.  sums [2] (device, caller-zeroed): += value_loss, += surrogate (the reference's
+ * running `mean_value_loss` / `mean_surrogate_loss`, read once per update() instead of two .item() per minibatch). */
+int gnbv_ppo_loss_rsl(int batch, const float *log_prob, const float *old_log_prob, const float *advantages, const float *values,
+                      const float *target_values, const float *returns, float clip_param, float value_loss_coef,
+                      float entropy_coef, int use_clipped_value_loss, float *d_log_prob, float *d_values, float *d_entropy,
+                      float *sums, void *stream);
+
 size_t gnbv_adam_workspace_bytes(void);
 int gnbv_clip_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float max_grad_norm,
                         float lr, float beta1, float beta2, float eps, int64_t *step, int *stop_flag, float grad_scale,

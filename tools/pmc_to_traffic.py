@@ -5,7 +5,7 @@ gnbv_update_occ_grid launch from the FETCH_SIZE / WRITE_SIZE passes (KB units; F
     python tools/pmc_to_traffic.py profiles/r01_voxel_pmc.txt [flat|compact] > profiles/r01_voxel_traffic.json
 (second argument: the observation rows the microbenchmark wrote -- compact = int8 tri-class rows only, the bench default)
 """
-import json, re, sys
+import hashlib, json, os, re, sys
 
 fetch, write, cur, kern = {}, {}, None, None
 for line in open(sys.argv[1]):
@@ -25,7 +25,8 @@ out = {"_comment": "HBM traffic of one gnbv_update_occ_grid call of the bench co
                    "bit-packed gt/scanned; 1-byte coded probability grid when the kernel list shows k_grid_update_coded): separate "
                    "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, KB units). FETCH_SIZE is doubled per MI355X_MICROARCH.md "
                    "section HBM (gfx950 reports half the bytes of wide coalesced streaming reads); WRITE_SIZE as reported.",
+       "source_sha256": hashlib.sha256(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gennbv_amd", "csrc", "voxel.hip"), "rb").read()).hexdigest(),
        "config": {"envs": 256, "height": 240, "width": 320, "grid": 64, "obs": sys.argv[2] if len(sys.argv) > 2 else "compact"},
-       "fetch_bytes": fb, "write_bytes": wb, "traffic_bytes_per_launch": sum(fb.values()) + sum(wb.values()),
+       "fetch_bytes": fb, "write_bytes": wb, "traffic_bytes_per_launch": sum(fb.values()) + sum(wb.values()),  # (kernels only; the mask fill node is not a kernel-trace row)
        "algorithmic_bytes_per_launch": 256 * (240 * 320 * 8 + 64 ** 3 * 4 * 6 + 200)}
 print(json.dumps(out, indent=2))
