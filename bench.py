@@ -132,9 +132,11 @@ def one_iteration(algo, phases):
 
 
 def cpu_baseline(args, cfg):
-    """The oracle (CPU restatement, proven equal to the reference on the goldens) + torch-CPU
-    fp32 PPO on a bounded sample of the same workload: 16 envs, 4 env steps, full 240x320 / G
-    state encoding, policy forward, GAE and one PPO epoch (remaining epochs scaled from it).  kind = "port", single process."""
+    """The CPU port of the same path on the box's host cores, ALL of them: the oracle's state encoding (oracle/oracle.c,
+    OpenMP over the envs; proven equal to the reference on the goldens) + torch-CPU fp32 policy forward / GAE / PPO update
+    (torch's own thread pool) on a bounded sample of the workload -- 64 envs x 8 env steps at the full 240x320 / G
+    geometry, then one PPO epoch over the 512 samples in minibatches of 128 (the remaining n_epochs - 1 epochs are scaled
+    from it).  kind = "port": the reference itself cannot travel to the GPU box (it imports Isaac Gym / pycuda)."""
     import numpy as np
     import torch
     from gennbv_amd.env import synthetic as S
@@ -142,8 +144,11 @@ def cpu_baseline(args, cfg):
     from oracle import oracle as orc
     from tests import policy_util as pu
 
-    n, t_steps = 16, 4
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    n, t_steps, mb = 64, 8, 128
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    omp_threads = int(orc.lib().orc_num_threads())
     scene = S.make_scenes(n, cfg.grid_size, seed=99)
     frames = S.make_frames(scene, cfg, 2, seed=99)  # two frames, alternated
     kinv = S.inverse_intrinsics(cfg.camera_height, cfg.camera_width)
@@ -165,27 +170,31 @@ def cpu_baseline(args, cfg):
     with torch.no_grad():
         lv = pol.predict_values(torch.from_numpy(obs)).numpy().reshape(-1)
     adv, ret = orc.gae_sb3(np.stack(rew_l), np.stack(val_l), np.zeros((t_steps, n), np.uint8), lv, np.zeros(n, np.uint8))
-    # one PPO epoch over the n*t_steps samples (n_epochs passes are scaled analytically below)
+    t_rollout = time.time() - t0
+    # one PPO epoch over the n*t_steps samples in minibatches of `mb` (ppo_grid_obs.py:196-275)
     pol.set_training_mode(True)
     o = torch.from_numpy(np.concatenate(obs_l)); a = torch.from_numpy(np.concatenate(act_l)).float()
     advt = torch.from_numpy(adv.reshape(-1)); rett = torch.from_numpy(ret.reshape(-1))
     oldv = torch.from_numpy(np.concatenate(val_l)); oldlp = torch.from_numpy(np.concatenate(lp_l))
     t_train0 = time.time()
-    values, log_prob, entropy = pol.evaluate_actions(o, a)
-    values = values.flatten()
-    advn = (advt - advt.mean()) / (advt.std() + 1e-8)
-    ratio = torch.exp(log_prob - oldlp)
-    pg = -torch.min(advn * ratio, advn * torch.clamp(ratio, 0.8, 1.2)).mean()
-    vp = oldv + torch.clamp(values - oldv, -0.2, 0.2)
-    loss = 10 * pg + 0.01 * (-entropy.mean()) + 0.8 * torch.nn.functional.mse_loss(rett, vp)
-    pol.optimizer.zero_grad(); loss.backward()
-    torch.nn.utils.clip_grad_norm_(pol.parameters(), 1.0); pol.optimizer.step()
+    for k in range(0, n * t_steps, mb):
+        sl = slice(k, k + mb)
+        values, log_prob, entropy = pol.evaluate_actions(o[sl], a[sl])
+        values = values.flatten()
+        advn = (advt[sl] - advt[sl].mean()) / (advt[sl].std() + 1e-8)
+        ratio = torch.exp(log_prob - oldlp[sl])
+        pg = -torch.min(advn * ratio, advn * torch.clamp(ratio, 0.8, 1.2)).mean()
+        vp = oldv[sl] + torch.clamp(values - oldv[sl], -0.2, 0.2)
+        loss = 10 * pg + 0.01 * (-entropy.mean()) + 0.8 * torch.nn.functional.mse_loss(rett[sl], vp)
+        pol.optimizer.zero_grad(); loss.backward()
+        torch.nn.utils.clip_grad_norm_(pol.parameters(), 1.0); pol.optimizer.step()
     t_train = time.time() - t_train0
-    total = (time.time() - t0) + (args.n_epochs - 1) * t_train
-    return {"value": n * t_steps / total, "unit": "env-steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"{n} envs x {t_steps} env steps at {cfg.camera_height}x{cfg.camera_width}, {cfg.grid_size}^3: "
-                      f"oracle state encoding (1 thread) + torch-CPU fp32 policy/PPO ({args.n_epochs} epochs, "
-                      f"{torch.get_num_threads()} threads)"}
+    total = t_rollout + args.n_epochs * t_train
+    return {"value": n * t_steps / total, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n} envs x {t_steps} env steps at {cfg.camera_height}x{cfg.camera_width}, {cfg.grid_size}^3: oracle state "
+                      f"encoding (OpenMP, {omp_threads} threads) + torch-CPU fp32 policy / GAE / PPO ({torch.get_num_threads()} threads; "
+                      f"1 epoch of {n * t_steps // mb} minibatches of {mb} measured, x{args.n_epochs} epochs)",
+            "seconds": {"rollout": t_rollout, "one_epoch": t_train}}
 
 
 def ppo_loss_delta(args, device):
@@ -221,7 +230,7 @@ def ppo_loss_delta(args, device):
         hip.train()
         s_h, s_r = hip.last_train_stats, ref.last_train_stats
         names = ("policy_gradient_loss", "value_loss", "entropy_loss", "approx_kl", "clip_fraction", "loss")
-        d = np.abs(s_h - s_r[:, :s_h.shape[1]])[:, :6] / np.maximum(1.0, np.abs(s_r[:, :6]))
+        d = np.abs(s_h[:, :6] - s_r[:, :6]) / np.maximum(1.0, np.abs(s_r[:, :6]))
         out["timed_kernel_set"] = {
             "what": "G=64, batch 128, compact int8 rows, hipGraph; 20 optimizer steps on a ReplayFeedEnv rollout vs the fp64 CPU torch loop",
             "optimizer_steps": int(hip._hip["opt"].step_count.item()),

@@ -113,7 +113,7 @@ class GnbvPpoLoss(C.Structure):
                 ("logits", _p), ("values", _p), ("actions", _p), ("old_values", _p), ("old_log_prob", _p),
                 ("advantages", _p), ("returns", _p), ("d_logits", _p), ("d_values", _p), ("head_entropy", _p),
                 ("head_lse", _p), ("stats", _p), ("stats_row", _p), ("stop_flag", _p), ("scratch", _p), ("kl_out", _p),
-                ("rows", _p)]
+                ("rows", _p), ("adv_norm", _p)]
 
 
 class GennbvHipError(RuntimeError):

@@ -829,14 +829,30 @@ __global__ __launch_bounds__(256) void k_bn2_bwd_reduce(const float *__restrict_
                                                         const float *__restrict__ mean, const float *__restrict__ rstd, int P2,
                                                         float *__restrict__ partials /*[B*16][2]*/)
 {
+    // Workgroup = one (sample, channel) row of P2 values.  kU x 2 independent requests per lane are issued before any is
+    // consumed (clamped addresses): with one request in flight per lane the 2048 short workgroups ran at 1.3 TB/s (42 us
+    // for 55 MB), the loop was a chain of ~14 dependent round trips.
+    constexpr int kU = 8;
     const int bc = blockIdx.x, c = bc % kC;
     const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
+    const float *yr = y2 + (size_t)bc * P2, *gr = dz2 + (size_t)bc * P2;
     float s1 = 0.f, s2 = 0.f;
-    for (int i = threadIdx.x; i < P2; i += 256) {
-        const float y = y2[(size_t)bc * P2 + i];
-        const float g = fmaf(sc, y, sh) > 0.0f ? dz2[(size_t)bc * P2 + i] : 0.0f;
-        s1 += g;
-        s2 += g * ((y - mu) * rs);
+    for (int i0 = threadIdx.x; i0 < P2; i0 += 256 * kU) {
+        float yv[kU], gv[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int i = min(i0 + u * 256, P2 - 1);
+            yv[u] = yr[i];
+            gv[u] = gr[i];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const bool live = i0 + u * 256 < P2;
+            const float y = yv[u];
+            const float g = (live && fmaf(sc, y, sh) > 0.0f) ? gv[u] : 0.0f;
+            s1 += g;
+            s2 += g * ((y - mu) * rs);
+        }
     }
     __shared__ float r1[4], r2[4];
     s1 = wave_reduce_sum(s1);

@@ -1,10 +1,10 @@
 // ppo.hip -- the PPO minibatch update of stable_baselines3/ppo/ppo_grid_obs.py:196-275 on MI355X:
 //   * k_gather_minibatch   the five per-sample gathers of buffers.py:753-762 in one launch
-//   * k_ppo_logp / k_ppo_scalars / k_ppo_dlogits   advantage normalisation (:214-216), MultiCategorical log-prob / entropy
+//   * k_ppo_fused          advantage normalisation (:214-216), MultiCategorical log-prob / entropy
 //                          (distributions.py:321-332), clipped surrogate (:219-224), clipped value
 //                          loss (:231-241), entropy loss (:245-249), loss = 10*pg + c_e*ent + c_v*vl
 //                          (:253), approx-KL (:259-262) AND the analytic gradient of the loss with
-//                          respect to the logits and the values -- three small launches
+//                          respect to the logits and the values -- one launch
 //                          instead of ~100 tiny torch kernels forward + backward;
 //                          sets the sticky early-stop flag (:264-268) on the device.
 //   * k_grad_sqnorm / k_adam_flat   clip_grad_norm_(max_norm) + Adam(eps=1e-5) (:271-275) over ONE
@@ -70,84 +70,126 @@ __device__ __forceinline__ HeadStats head_stats(const float *lg, int n, int lane
     return {lse, -pe};
 }
 
-// phase 1, one wave per sample -> log-prob of the taken actions, entropy (sums over the heads)
-__device__ __forceinline__ void sample_logp(const GnbvPpoLoss &a, int i, int lane, float *__restrict__ logp_out, float *__restrict__ ent_out)
+// ---------------------------------------------------------------------------
+// ONE launch: a wave per sample computes the head statistics once and uses them for the log-prob, the entropy AND the
+// logit gradient (three launches recomputed them twice and paid two extra launch latencies on the update's critical path:
+// 32 us -> see profiles/r02_notes.md).  The only cross-sample quantities are the advantage mean / std -- functions of the
+// INPUTS, which every wave evaluates for itself over the <= a few hundred advantages of the minibatch -- and the logged
+// scalars, which the workgroup that finishes last adds up in a fixed order (per-sample terms in `scratch`).
+// (A single workgroup walking all samples serially was measured at ~130 us.)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kLossThreads) void k_ppo_fused(GnbvPpoLoss a, float *__restrict__ terms /*[B][8]*/, int *__restrict__ counter)
 {
-    const float *lg = a.logits + (size_t)i * a.n_logits;
-    const int64_t r = src_row(a, i);
-    float logp = 0.f, ent = 0.f;
-    int off = 0;
-    for (int h = 0; h < a.n_heads; ++h) {
-        const int n = a.head_dims[h];
-        const HeadStats hs = head_stats(lg + off, n, lane);
-        const int act = (int)a.actions[(size_t)r * a.n_heads + h];  // actions are stored as float (buffers.py:664)
-        logp += lg[off + act] - hs.lse;
-        ent += hs.ent;
-        if (a.head_entropy && lane == 0) a.head_entropy[(size_t)i * a.n_heads + h] = hs.ent;
-        if (a.head_lse && lane == 0) a.head_lse[(size_t)i * a.n_heads + h] = hs.lse;
-        off += n;
-    }
-    if (lane == 0) { logp_out[i] = logp; ent_out[i] = ent; }
-}
-
-__global__ __launch_bounds__(kLossThreads) void k_ppo_logp(GnbvPpoLoss a, float *__restrict__ logp_out, float *__restrict__ ent_out)
-{
-    const int lane = threadIdx.x & 63, i = blockIdx.x * (kLossThreads / 64) + (threadIdx.x >> 6);
-    if (i < a.batch) sample_logp(a, i, lane, logp_out, ent_out);
-}
-
-// phase 2, one workgroup -> advantage normalisation, the scalar losses, dL/dlogp, dL/dv, flags
-template <int NT>
-__device__ __forceinline__ void loss_scalars(const GnbvPpoLoss &a, const float *__restrict__ logp_in, const float *__restrict__ ent_in,
-                                             float *__restrict__ gl_out)
-{
-    __shared__ float scratch[NT / 64 + 1];
-    const int B = a.batch, tid = threadIdx.x;
+    __shared__ float scratch[kLossThreads / 64 + 1];
+    __shared__ int s_last;
+    const int B = a.batch, tid = threadIdx.x, lane = tid & 63;
+    const int i = blockIdx.x * (kLossThreads / 64) + (tid >> 6);
     const float invB = 1.0f / (float)B;
-    // ---- advantage normalisation: (A - mean) / (std_unbiased + 1e-8) ----
-    float s = 0.f;
-    for (int i = tid; i < B; i += NT) s += a.advantages[src_row(a, i)];
-    const float mean = block_sum<NT>(s, scratch) * invB;
-    float q = 0.f;
-    for (int i = tid; i < B; i += NT) {
-        const float d = a.advantages[src_row(a, i)] - mean;
-        q += d * d;
-    }
-    const float var = block_sum<NT>(q, scratch) / (float)(B > 1 ? B - 1 : 1);
-    const float inv_std = 1.0f / (sqrtf(var) + 1e-8f);
-    float pg = 0.f, vl = 0.f, en = 0.f, kl = 0.f, cf = 0.f;
-    for (int i = tid; i < B; i += NT) {
-        const float adv = a.normalize_advantage ? (a.advantages[src_row(a, i)] - mean) * inv_std : a.advantages[src_row(a, i)];
-        const float log_ratio = logp_in[i] - a.old_log_prob[src_row(a, i)];
+    if (i < B) {
+        const float *lg = a.logits + (size_t)i * a.n_logits;
+        const int64_t r = src_row(a, i);
+        // ---- head statistics, log-prob of the taken actions, entropy ----
+        float lse[kMaxHeads], hent[kMaxHeads];
+        int act[kMaxHeads];
+        float logp = 0.f, ent = 0.f;
+        {
+            int off = 0;
+#pragma unroll
+            for (int h = 0; h < kMaxHeads; ++h) {
+                if (h < a.n_heads) {
+                    const int n = a.head_dims[h];
+                    const HeadStats hs = head_stats(lg + off, n, lane);
+                    lse[h] = hs.lse; hent[h] = hs.ent;
+                    act[h] = (int)a.actions[(size_t)r * a.n_heads + h];  // actions are stored as float (buffers.py:664)
+                    logp += lg[off + act[h]] - hs.lse;
+                    ent += hs.ent;
+                    if (a.head_entropy && lane == 0) a.head_entropy[(size_t)i * a.n_heads + h] = hs.ent;
+                    if (a.head_lse && lane == 0) a.head_lse[(size_t)i * a.n_heads + h] = hs.lse;
+                    off += n;
+                }
+            }
+        }
+        // ---- advantage normalisation: (A - mean) / (std_unbiased + 1e-8), the statistics of the (global) minibatch ----
+        float mean = 0.f, inv_std = 1.f;
+        if (a.normalize_advantage) {
+            if (a.adv_norm) {
+                mean = a.adv_norm[0]; inv_std = a.adv_norm[1];
+            } else {
+                float s = 0.f;
+                for (int j = lane; j < B; j += 64) s += a.advantages[src_row(a, j)];
+                for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);  // (all lanes need the total)
+                mean = s * invB;
+                float q = 0.f;
+                for (int j = lane; j < B; j += 64) {
+                    const float d = a.advantages[src_row(a, j)] - mean;
+                    q += d * d;
+                }
+                for (int d = 32; d > 0; d >>= 1) q += __shfl_xor(q, d, 64);
+                inv_std = 1.0f / (sqrtf(q / (float)(B > 1 ? B - 1 : 1)) + 1e-8f);
+            }
+        }
+        // ---- this sample's scalar terms (every lane computes them: no broadcast needed) ----
+        const float adv = a.normalize_advantage ? (a.advantages[r] - mean) * inv_std : a.advantages[r];
+        const float log_ratio = logp - a.old_log_prob[r];
         const float ratio = expf(log_ratio);
         const float lo = 1.0f - a.clip_range, hi = 1.0f + a.clip_range;
         const float rc = fminf(fmaxf(ratio, lo), hi);
         const float s1 = adv * ratio, s2 = adv * rc;
-        pg += -fminf(s1, s2);
         // d min(s1, s2): the smaller operand takes the gradient, ties split evenly (torch.minimum)
         const float g1 = s1 < s2 ? 1.f : (s1 > s2 ? 0.f : 0.5f), g2 = 1.f - g1;
         const float inrange = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
-        gl_out[i] = -invB * a.policy_scale * adv * ratio * (g1 + g2 * inrange);
-        cf += fabsf(ratio - 1.0f) > a.clip_range ? 1.f : 0.f;
-        kl += (ratio - 1.0f) - log_ratio;
-        const float v = a.values[i], vo = a.old_values[src_row(a, i)];
+        const float gl = -invB * a.policy_scale * adv * ratio * (g1 + g2 * inrange);
+        const float v = a.values[i], vo = a.old_values[r];
         float vp = v, dvp = 1.f;
         if (a.clip_range_vf > 0.f) {
             const float dv = v - vo;
             vp = vo + fminf(fmaxf(dv, -a.clip_range_vf), a.clip_range_vf);
             dvp = (dv >= -a.clip_range_vf && dv <= a.clip_range_vf) ? 1.f : 0.f;
         }
-        const float err = vp - a.returns[src_row(a, i)];
-        vl += err * err;
-        a.d_values[i] = a.vf_coef * 2.0f * invB * err * dvp;
-        en += -ent_in[i];
+        const float err = vp - a.returns[r];
+        if (lane == 0) {
+            a.d_values[i] = a.vf_coef * 2.0f * invB * err * dvp;
+            float *t = terms + (size_t)i * 8;
+            t[0] = -fminf(s1, s2);                                  // policy-gradient term
+            t[1] = err * err;                                       // value term
+            t[2] = -ent;                                            // entropy term
+            t[3] = (ratio - 1.0f) - log_ratio;                      // approx-KL term
+            t[4] = fabsf(ratio - 1.0f) > a.clip_range ? 1.f : 0.f;  // clip fraction term
+        }
+        // ---- d logits = gl*(onehot - p) + (ent_coef/B) * p*(log p + H_head) ----
+        float *dl = a.d_logits + (size_t)i * a.n_logits;
+        int off = 0;
+#pragma unroll
+        for (int h = 0; h < kMaxHeads; ++h) {
+            if (h < a.n_heads) {
+                const int n = a.head_dims[h];
+                for (int j = lane; j < n; j += 64) {
+                    const float lp = lg[off + j] - lse[h], p = expf(lp);
+                    dl[off + j] = gl * ((j == act[h] ? 1.f : 0.f) - p) + a.ent_coef * invB * p * (lp + hent[h]);
+                }
+                off += n;
+            }
+        }
     }
-    pg = block_sum<NT>(pg, scratch) * invB;
-    vl = block_sum<NT>(vl, scratch) * invB;
-    en = block_sum<NT>(en, scratch) * invB;
-    kl = block_sum<NT>(kl, scratch) * invB;
-    cf = block_sum<NT>(cf, scratch) * invB;
+    // ---- the workgroup that finishes last adds the per-sample terms (fixed order: deterministic) ----
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(counter, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    float pg = 0.f, vl = 0.f, en = 0.f, kl = 0.f, cf = 0.f;
+    for (int j = tid; j < B; j += kLossThreads) {
+        const volatile float *t = terms + (size_t)j * 8;
+        pg += t[0]; vl += t[1]; en += t[2]; kl += t[3]; cf += t[4];
+    }
+    pg = block_sum<kLossThreads>(pg, scratch) * invB;
+    vl = block_sum<kLossThreads>(vl, scratch) * invB;
+    en = block_sum<kLossThreads>(en, scratch) * invB;
+    kl = block_sum<kLossThreads>(kl, scratch) * invB;
+    cf = block_sum<kLossThreads>(cf, scratch) * invB;
     if (tid == 0) {
+        *counter = 0;  // ready for the next call
         const float loss = pg * a.policy_scale + a.ent_coef * en + a.vf_coef * vl;
         const int stopped_before = a.stop_flag ? *a.stop_flag : 0;
         float *row = a.stats + (size_t)(*a.stats_row) * 8;
@@ -159,42 +201,6 @@ __device__ __forceinline__ void loss_scalars(const GnbvPpoLoss &a, const float *
         else if (a.stop_flag && a.target_kl > 0.f && kl > 1.5f * a.target_kl) *a.stop_flag = 1;  // sticky (:264-268)
     }
 }
-
-
-__global__ __launch_bounds__(kLossThreads) void k_ppo_scalars(GnbvPpoLoss a, const float *__restrict__ logp_in,
-                                                             const float *__restrict__ ent_in, float *__restrict__ gl_out)
-{
-    loss_scalars<kLossThreads>(a, logp_in, ent_in, gl_out);
-}
-
-// phase 3, one wave per sample -> d logits = gl*(onehot - p) + (ent_coef/B) * p*(log p + H_head)
-__device__ __forceinline__ void sample_dlogits(const GnbvPpoLoss &a, int i, int lane, float gl)
-{
-    const float invB = 1.0f / (float)a.batch;
-    const float *lg = a.logits + (size_t)i * a.n_logits;
-    float *dl = a.d_logits + (size_t)i * a.n_logits;
-    const int64_t r = src_row(a, i);
-    int off = 0;
-    for (int h = 0; h < a.n_heads; ++h) {
-        const int n = a.head_dims[h];
-        const HeadStats hs = head_stats(lg + off, n, lane);
-        const int act = (int)a.actions[(size_t)r * a.n_heads + h];
-        for (int j = lane; j < n; j += 64) {
-            const float lp = lg[off + j] - hs.lse, p = expf(lp);
-            dl[off + j] = gl * ((j == act ? 1.f : 0.f) - p) + a.ent_coef * invB * p * (lp + hs.ent);
-        }
-        off += n;
-    }
-}
-
-__global__ __launch_bounds__(kLossThreads) void k_ppo_dlogits(GnbvPpoLoss a, const float *__restrict__ gl_in)
-{
-    const int lane = threadIdx.x & 63, i = blockIdx.x * (kLossThreads / 64) + (threadIdx.x >> 6);
-    if (i < a.batch) sample_dlogits(a, i, lane, gl_in[i]);
-}
-
-// (A single-workgroup version of the three phases was measured: 1024 threads walking 128 samples x 6 heads
-// serially take ~130 us -- the three launches below, 28 us together, stay.)
 
 // ---------------------------------------------------------------------------
 // rsl_rl flavour (rsl_rl/algorithms/ppo.py:160-180): one workgroup, the minibatch's scalar loss and its gradient with
@@ -403,11 +409,8 @@ GNBV_API int gnbv_ppo_loss(const GnbvPpoLoss *a, void *stream)
     for (int h = 0; h < a->n_heads; ++h) sum += a->head_dims[h];
     GNBV_CHECK_ARG(sum == a->n_logits && a->scratch);
     hipStream_t st = gnbv_stream(stream);
-    float *logp = a->scratch, *ent = a->scratch + a->batch, *gl = a->scratch + 2 * (size_t)a->batch;
     const int blocks = (a->batch + kLossThreads / 64 - 1) / (kLossThreads / 64);
-    hipLaunchKernelGGL(k_ppo_logp, dim3(blocks), dim3(kLossThreads), 0, st, *a, logp, ent);
-    hipLaunchKernelGGL(k_ppo_scalars, dim3(1), dim3(kLossThreads), 0, st, *a, (const float *)logp, (const float *)ent, gl);
-    hipLaunchKernelGGL(k_ppo_dlogits, dim3(blocks), dim3(kLossThreads), 0, st, *a, (const float *)gl);
+    hipLaunchKernelGGL(k_ppo_fused, dim3(blocks), dim3(kLossThreads), 0, st, *a, a->scratch, (int *)(a->scratch + 8 * (size_t)a->batch));
     return gnbv_launch_status();
 }
 

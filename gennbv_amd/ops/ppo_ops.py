@@ -131,7 +131,8 @@ class PpoLossOp:
         a.d_logits, a.d_values = self.d_logits.data_ptr(), self.d_values.data_ptr()
         a.head_entropy, a.head_lse, a.kl_out, a.rows = None, None, None, None
         a.stats, a.stats_row, a.stop_flag = self.stats.data_ptr(), self.stats_row.data_ptr(), self.stop_flag.data_ptr()
-        self.scratch = z(3 * batch)
+        self.scratch = z(8 * batch + 64)  # per-sample terms + the completion counter (zero-initialised once)
+        a.adv_norm = None
         a.scratch = self.scratch.data_ptr()
         self.args = a
         self.device = device

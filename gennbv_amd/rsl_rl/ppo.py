@@ -81,8 +81,8 @@ class PPO:
         opt = self._flat
         sums = torch.zeros(2, dtype=torch.float32, device=dev)
         st = lambda: _lib.stream_ptr(dev)  # noqa: E731
-        for (obs_b, critic_obs_b, actions_b, target_values_b, adv_b, returns_b, old_lp_b, old_mu_b, old_sigma_b, _hid, _masks) in \\
-                self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs, indices=indices):
+        batches = self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs, indices=indices)
+        for (obs_b, critic_obs_b, actions_b, target_values_b, adv_b, returns_b, old_lp_b, old_mu_b, old_sigma_b, _hid, _masks) in batches:
             self.actor_critic.act(obs_b)
             lp = self.actor_critic.get_actions_log_prob(actions_b)
             value = self.actor_critic.evaluate(critic_obs_b)

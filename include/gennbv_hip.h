@@ -350,7 +350,8 @@ int gnbv_gather_minibatch(const int64_t *rows, int batch, int act_dim, const flo
                           const float *log_probs, const float *advantages, const float *returns, float *o_actions,
                           float *o_values, float *o_log_probs, float *o_adv, float *o_ret, void *stream);
 
-/* Three small launches: advantage normalisation, MultiCategorical log-prob / entropy, clipped surrogate,
+/* One launch (one wave per sample; the workgroup that finishes last adds the per-sample terms in a fixed order):
+ * advantage normalisation, MultiCategorical log-prob / entropy, clipped surrogate,
  * clipped value loss, entropy loss, loss = policy_scale*pg + ent_coef*ent + vf_coef*vl,
  * approx-KL, clip fraction, and d loss / d logits, d loss / d values.
  * stats row (8 floats) = pg, vl, ent, approx_kl, clip_fraction, loss, live, 0 is written at
@@ -372,12 +373,16 @@ typedef struct GnbvPpoLoss {
     float *stats;               /* [rows, 8] */
     int64_t *stats_row;         /* in/out [1] */
     int *stop_flag;             /* in/out [1] or NULL */
-    float *scratch;             /* [3*B] device scratch */
+    float *scratch;             /* [8*B + 64] device scratch, ZERO-initialised by the caller once (holds a completion
+                                   counter that every call leaves at zero) */
     float *kl_out;              /* NULL, or [1]: receives approx_kl INSTEAD of setting stop_flag
                                    (data-parallel: decided on the global mean, gnbv_clip_adam_step) */
     const int64_t *rows;        /* NULL, or [B]: fused minibatch gather (buffers.py:753-762) -- actions, old_values,
                                    old_log_prob, advantages, returns then point at the whole [T*N] rollout arrays
                                    and sample i reads row rows[i] */
+    const float *adv_norm;      /* NULL: the minibatch's own advantage mean / unbiased std (ppo_grid_obs.py:214-216);
+                                   or [2] = (mean, 1 / (std + 1e-8)) of the GLOBAL minibatch (data-parallel replicas:
+                                   the statistics of all ranks' rows, gennbv_amd/parallel.py) */
 } GnbvPpoLoss;
 
 int gnbv_ppo_loss(const GnbvPpoLoss *args /*[host]*/, void *stream);
@@ -390,12 +395,6 @@ int gnbv_ppo_loss(const GnbvPpoLoss *args /*[host]*/, void *stream);
 int gnbv_multicategorical_sample(const float *logits, int batch, int n_logits, int n_heads, const int *head_dims /*[host]*/,
                                  const float *uniforms, int deterministic, int64_t *actions, float *log_prob, void *stream);
 
-/* torch.nn.utils.clip_grad_norm_(max_grad_norm) + torch.optim.Adam step over ONE flat fp32
- * buffer of n parameters (max_grad_norm <= 0: no clipping). grads is the SUM over ranks,
- * grad_scale = 1/world turns it into the mean (1.0 on one GPU).  kl_slot (may be NULL): sum over
- * ranks of approx_kl; *stop_flag becomes 1 (sticky) when kl_slot*grad_scale > 1.5*target_kl.
- * *step is incremented and the update applied unless *stop_flag != 0.
- * norm_out[0] = norm of the mean gradient, [1] = factor applied to `grads`. */
 /* rsl_rl flavour of the PPO minibatch loss (rsl_rl/algorithms/ppo.py:160-180): scalar part of
  *   surrogate  = mean(max(-A r, -A clamp(r, 1 - c, 1 + c))),  r = exp(log_prob - old_log_prob)
  *   value_loss = mean(max((v - R)^2, (tv + clamp(v - tv, -c, c) - R)^2))   (use_clipped_value_loss) or mean((R - v)^2)
@@ -409,6 +408,12 @@ int gnbv_ppo_loss_rsl(int batch, const float *log_prob, const float *old_log_pro
                       float entropy_coef, int use_clipped_value_loss, float *d_log_prob, float *d_values, float *d_entropy,
                       float *sums, void *stream);
 
+/* torch.nn.utils.clip_grad_norm_(max_grad_norm) + torch.optim.Adam step over ONE flat fp32
+ * buffer of n parameters (max_grad_norm <= 0: no clipping). grads is the SUM over ranks,
+ * grad_scale = 1/world turns it into the mean (1.0 on one GPU).  kl_slot (may be NULL): sum over
+ * ranks of approx_kl; *stop_flag becomes 1 (sticky) when kl_slot*grad_scale > 1.5*target_kl.
+ * *step is incremented and the update applied unless *stop_flag != 0.
+ * norm_out[0] = norm of the mean gradient, [1] = factor applied to `grads`. */
 size_t gnbv_adam_workspace_bytes(void);
 int gnbv_clip_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float max_grad_norm,
                         float lr, float beta1, float beta2, float eps, int64_t *step, int *stop_flag, float grad_scale,

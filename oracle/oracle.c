@@ -19,6 +19,9 @@
  * (oracle/gen_golden.py -> tests/golden/<name>.npz) and the reference's CUDA-C
  * ray-cast kernel text compiled as host C++ (oracle/_ref/libref_bresenham.so).
  */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -281,8 +284,13 @@ ORC_API void orc_update_occ_grid(const float *depth /*[N,H,W] processed*/, const
                                  int32_t *coverage_count /*[N] or NULL: sum(scanned) for binary gt*/)
 {
     const int64_t g3 = (int64_t)g * g * g, hw = (int64_t)h * w;
-    uint8_t *hit = (uint8_t *)malloc(g3), *path = (uint8_t *)malloc(g3);
+    /* envs are independent (no cross-env term anywhere in update_occ_grid): one env per OpenMP thread when built with
+     * -fopenmp (bench.py's cpu_baseline uses every host core); the per-env arithmetic and its order are unchanged */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
     for (int e = 0; e < n; ++e) {
+        uint8_t *hit = (uint8_t *)malloc(g3), *path = (uint8_t *)malloc(g3);
         float *prob = prob_grid + e * g3, *scan = scanned_gt_grid + e * g3, *tri = tri_cls + e * g3;
         const float *gt = grid_gt + e * g3;
         if (reset_mask && reset_mask[e]) {
@@ -331,9 +339,9 @@ ORC_API void orc_update_occ_grid(const float *depth /*[N,H,W] processed*/, const
         if (coverage_count) coverage_count[e] = cov;
         if (hit_mask_out) memcpy(hit_mask_out + e * g3, hit, g3);
         if (path_mask_out) memcpy(path_mask_out + e * g3, path, g3);
+        free(hit);
+        free(path);
     }
-    free(hit);
-    free(path);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -401,3 +409,13 @@ ORC_API void orc_gae_rsl(const float *rewards, const float *values, const uint8_
 }
 
 ORC_API int orc_abi_version(void) { return 1; }
+
+/* threads orc_update_occ_grid uses (1 without OpenMP) */
+ORC_API int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -25,8 +25,11 @@ _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
 def build(force: bool = False) -> str:
     src = os.path.join(HERE, "oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
-                               "-fvisibility=hidden", "-o", _LIB_PATH, src, "-lm"])
+        cmd = ["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden", "-o", _LIB_PATH, src, "-lm"]
+        try:  # OpenMP over the envs of update_occ_grid (the CPU baseline of bench.py uses every host core)
+            subprocess.check_call(cmd[:2] + ["-fopenmp"] + cmd[2:], stderr=subprocess.DEVNULL)
+        except subprocess.CalledProcessError:
+            subprocess.check_call(cmd)
     return _LIB_PATH
 
 
@@ -47,6 +50,7 @@ def lib():
         L.orc_update_occ_grid.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_void_p,
                                           C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_num_threads.restype = C.c_int
         L.orc_gae_sb3.argtypes = [_f32p, _f32p, _u8p, _f32p, _u8p, C.c_int, C.c_int, C.c_double, C.c_double,
                                   _f32p, _f32p]
         L.orc_gae_rsl.argtypes = [_f32p, _f32p, _u8p, _f32p, C.c_int, C.c_int, C.c_double, C.c_double, _f32p, _f32p]
