@@ -97,7 +97,8 @@ class GnbvEncoderParams(C.Structure):
     _fields_ = [("w1", _p), ("b1", _p), ("bn1_w", _p), ("bn1_b", _p), ("bn1_rm", _p), ("bn1_rv", _p), ("bn1_nbt", _p),
                 ("w2", _p), ("b2", _p), ("bn2_w", _p), ("bn2_b", _p), ("bn2_rm", _p), ("bn2_rv", _p), ("bn2_nbt", _p),
                 ("eps", _f), ("momentum", _f), ("act_bf16", _i), ("grid_i8", _p), ("grid_i8_row_stride", _i64),
-                ("autocorr", _p), ("autocorr_row_stride", _i64)]
+                ("autocorr", _p), ("autocorr_row_stride", _i64),
+                ("world", _i), ("sync_sum", _p), ("sync_ctx", _p), ("sync_buf", _p), ("autocorr_global", _p)]
 
 
 class GnbvEncoderGrads(C.Structure):

@@ -744,6 +744,28 @@ __global__ void k_bn_finalize(double count, const float *__restrict__ gamma, con
                             mean_out, rstd_out);
 }
 
+// data-parallel: BatchNorm finalize (train mode) from batch sums that were summed over the replicas
+__global__ void k_bn_finalize_sums(const double *__restrict__ sums /*[2][16]: sum, sum of squares*/, double count, const float *__restrict__ gamma,
+                                   const float *__restrict__ beta, float eps, float momentum, float *__restrict__ running_mean,
+                                   float *__restrict__ running_var, int64_t *__restrict__ num_batches_tracked, const int *__restrict__ skip_flag,
+                                   float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out, float *__restrict__ rstd_out)
+{
+    const int c = threadIdx.x;
+    if (c < kC)
+        bn_finalize_channel(c, sums[c], sums[kC + c], count, gamma, beta, eps, momentum, 1, running_mean, running_var, num_batches_tracked,
+                            skip_flag, scale, shift, mean_out, rstd_out);
+}
+
+// data-parallel: out[32] = sum over the slices of the fused backward's BN1-backward sums (tmp[sl][512 ..  512 + 32))
+__global__ void k_gather_bn1_sums(const double *__restrict__ tmp, int slices, double *__restrict__ out)
+{
+    const int i = threadIdx.x;
+    if (i >= 2 * kC) return;
+    double a = 0.0;
+    for (int sl = 0; sl < slices; ++sl) a += tmp[(size_t)sl * (512 + 2 * kC) /*kE1F*/ + 512 + i];
+    out[i] = a;
+}
+
 // One workgroup sums the [P][32] per-workgroup partial rows in fp64 and in a fixed order (128 slices of
 // P, then the slices in order), writes the 32 sums (out_d, optional) and, when gamma != nullptr,
 // finalizes the BatchNorm layer in the same launch (train mode).
@@ -1700,7 +1722,8 @@ __global__ __launch_bounds__(1024) void k_bn1_analytic(const int *__restrict__ a
                                                       float *__restrict__ running_mean, float *__restrict__ running_var,
                                                       int64_t *__restrict__ num_batches_tracked, const int *__restrict__ skip_flag,
                                                       float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out,
-                                                      float *__restrict__ rstd_out, int *__restrict__ total_out /*[kAcRow]: saved for backward*/)
+                                                      float *__restrict__ rstd_out, int *__restrict__ total_out /*[kAcRow]: saved for backward*/,
+                                                      const int *__restrict__ ac_global /*NULL, or [kAcRow]: total over ALL replicas (statistics)*/)
 {
     __shared__ int Ri[kAcRow];
     __shared__ double q[kC][kTaps];
@@ -1708,7 +1731,12 @@ __global__ __launch_bounds__(1024) void k_bn1_analytic(const int *__restrict__ a
     if (threadIdx.x < kC * kTaps) w1s[threadIdx.x] = W1[threadIdx.x];
     gather_autocorr(ac, ac_row_stride, rows, nrows, Ri);
     if (total_out != nullptr)
-        for (int i = threadIdx.x; i < kAcRow; i += 1024) total_out[i] = Ri[i];
+        for (int i = threadIdx.x; i < kAcRow; i += 1024) total_out[i] = Ri[i];  // (this replica's rows: the backward's local sums)
+    if (ac_global != nullptr) {  // data-parallel: the batch statistics are those of the global minibatch
+        __syncthreads();
+        for (int i = threadIdx.x; i < kAcRow; i += 1024) Ri[i] = ac_global[i];
+        __syncthreads();
+    }
     if (threadIdx.x < kC * kTaps) {  // q[c][t] = W1[c][t] * sum_u W1[c][u] R[t][u]
         const int c = threadIdx.x / kTaps, t = threadIdx.x - c * kTaps;
         double a = 0.0;
@@ -1740,7 +1768,8 @@ __global__ __launch_bounds__(1024) void k_c1w_fused_finish(const double *__restr
                                                           const float *__restrict__ rstd1, const float *__restrict__ gamma1 /*NULL unless z1 mode*/,
                                                           const float *__restrict__ beta1, float *__restrict__ dW1, float *__restrict__ db1,
                                                           const double *__restrict__ S2 /*BN2 sums*/, float *g1w, float *g1b, float *g2w,
-                                                          float *g2b)
+                                                          float *g2b, const double *__restrict__ S1g /*NULL, or [2][16]: BN1-backward sums over ALL replicas*/,
+                                                          const int *__restrict__ ac_global /*NULL, or the global autocorrelation total*/)
 {
     __shared__ int Ri[kAcRow];
     __shared__ double R[kAcRow];
@@ -1762,13 +1791,19 @@ __global__ __launch_bounds__(1024) void k_c1w_fused_finish(const double *__restr
         s2 = ga != 0.0 ? (s2 - (double)beta1[co] * s1) / ga : 0.0;  // (gamma == 0: xhat is not recoverable from z1)
     }
     auto Rs = [&](int t, int u) { return R[ac_index(t, u)]; };
-    const double count = Rs(kTaps, kTaps), inv_count = 1.0 / count;
+    // Data-parallel replicas: BatchNorm-1's mean and the two backward means are those of the GLOBAL minibatch (count Mg, column
+    // sums T2g, sums S1g), while T1, R and T2 stay this replica's: the gradient all-reduce adds the replicas' dW1.
+    const double count = ac_global ? (double)ac_global[ac_index(kTaps, kTaps)] : Rs(kTaps, kTaps), inv_count = 1.0 / count;
+    const double s1m = (S1g ? S1g[co] : s1) * inv_count, s2m = (S1g ? S1g[kC + co] : s2) * inv_count;
     if (tap < kTaps) {
-        const double T2 = Rs(tap, kTaps), T2m = T2 * inv_count;
-        double cw = 0.0;  // sum_tap' W1[co][tap'] * (R[tap][tap'] - T2[tap] T2[tap'] / M)
-        for (int u = 0; u < kTaps; ++u) cw += (double)W1[co * kTaps + u] * (Rs(tap, u) - T2m * Rs(u, kTaps));
+        const double T2 = Rs(tap, kTaps);
+        double cw = 0.0;  // sum_tap' W1[co][tap'] * (R[tap][tap'] - T2[tap] T2g[tap'] / Mg)
+        for (int u = 0; u < kTaps; ++u) {
+            const double T2g = ac_global ? (double)ac_global[ac_index(u, kTaps)] : Rs(u, kTaps);
+            cw += (double)W1[co * kTaps + u] * (Rs(tap, u) - T2 * T2g * inv_count);
+        }
         const double T3 = (double)rstd1[co] * cw;
-        dW1[co * kTaps + tap] = (float)((double)scale1[co] * (T1 - (s1 * inv_count) * T2 - (s2 * inv_count) * T3));
+        dW1[co * kTaps + tap] = (float)((double)scale1[co] * (T1 - s1m * T2 - s2m * T3));
     }
     if (tap == 0) {
         db1[co] = 0.0f;
@@ -2173,6 +2208,8 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     int err;
     GNBV_CHECK_ARG(p->autocorr == nullptr || (p->autocorr_row_stride >= kAcRow && p->autocorr_row_stride % 4 == 0 && ((uintptr_t)p->autocorr & 15) == 0));
     const bool z1 = z1_path(p, grid), qm = y1_quad_major(p, grid);
+    const bool dp = training && p->world > 1 && p->sync_sum != nullptr && p->sync_buf != nullptr;  // BatchNorm over the replicas' global minibatch
+    if (dp && z1) return (int)hipErrorInvalidValue;
     if (z1) {
         // BN1 scale / shift first (training: analytic batch statistics from the input autocorrelation; eval: running
         // statistics), then conv1 with the BN + ReLU epilogue: the layer-1 buffer holds z1
@@ -2182,7 +2219,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
             hipLaunchKernelGGL(k_bn1_analytic, dim3(1), dim3(1024), 0, st, p->autocorr ? (const int *)p->autocorr : (const int *)Rac,
                                p->autocorr_row_stride, rows, p->autocorr ? batch : 0, p->w1, p->b1, p->bn1_w, p->bn1_b, p->eps, p->momentum,
                                p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC,
-                               (int *)(bn_state + kBnStateFloats));
+                               (int *)(bn_state + kBnStateFloats), (const int *)nullptr);
         } else {
             hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps, p->momentum,
                                p->bn1_rm, p->bn1_rv, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC);
@@ -2196,10 +2233,11 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     // BN1 batch statistics analytically from the stored input autocorrelation rows (k_bn1_analytic: 6 us, independent of
     // conv1) instead of partial sums in conv1 + a 12 us reduction behind it; y1 is stored as before
     const bool analytic = training && analytic_bn1(p, grid);
+    if (dp && !(analytic && fused_path(p, grid) && p->autocorr_global != nullptr)) return (int)hipErrorInvalidValue;  // (see GnbvEncoderParams.world)
     if (analytic) {
         hipLaunchKernelGGL(k_bn1_analytic, dim3(1), dim3(1024), 0, st, (const int *)p->autocorr, p->autocorr_row_stride, rows, batch, p->w1, p->b1,
                            p->bn1_w, p->bn1_b, p->eps, p->momentum, p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag, bn1, bn1 + kC, bn1 + 2 * kC,
-                           bn1 + 3 * kC, (int *)(bn_state + kBnStateFloats));
+                           bn1 + 3 * kC, (int *)(bn_state + kBnStateFloats), dp ? (const int *)p->autocorr_global : (const int *)nullptr);
         if ((err = gnbv_launch_status())) return err;
     }
     float *c1_part = (training && !analytic) ? w.bn_part : nullptr;
@@ -2277,7 +2315,16 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
                        training ? w.bn_part : nullptr);
     }
     if ((err = gnbv_launch_status())) return err;
-    if (training)
+    if (training && dp) {
+        // BatchNorm-2 over the global minibatch: this replica's (sum, sum of squares) -> sum over the replicas -> finalize
+        hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, st, w.bn_part, g2, p->sync_buf, 0.0, (const float *)nullptr, (const float *)nullptr,
+                           0.0f, 0.0f, (float *)nullptr, (float *)nullptr, (int64_t *)nullptr, (const int *)nullptr, (float *)nullptr, (float *)nullptr,
+                           (float *)nullptr, (float *)nullptr, (const float *)nullptr, (float *)nullptr);
+        if ((err = gnbv_launch_status())) return err;
+        if ((err = p->sync_sum(p->sync_ctx, 0, 2 * kC, stream))) return err;
+        hipLaunchKernelGGL(k_bn_finalize_sums, dim3(1), dim3(64), 0, st, (const double *)p->sync_buf, (double)batch * P2 * p->world, p->bn2_w, p->bn2_b,
+                           p->eps, p->momentum, p->bn2_rm, p->bn2_rv, p->bn2_nbt, skip_flag, bn2, bn2 + kC, bn2 + 2 * kC, bn2 + 3 * kC);
+    } else if (training)
         hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, st, w.bn_part, g2, (double *)nullptr, (double)batch * P2, p->bn2_w, p->bn2_b,
                            p->eps, p->momentum, p->bn2_rm, p->bn2_rv, p->bn2_nbt, skip_flag, bn2, bn2 + kC, bn2 + 2 * kC, bn2 + 3 * kC,
                            (const float *)nullptr, (float *)nullptr);
@@ -2360,8 +2407,16 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     double *S2 = w.red + 128;
     hipLaunchKernelGGL(k_bn2_bwd_finalize, dim3(1), dim3(256), 0, st, w.bn_part, batch, S2);
     if ((err = gnbv_launch_status())) return err;
-    hipLaunchKernelGGL(k_bn2_bwd_apply, dim3(batch * ((P2 + 63) / 64)), dim3(256), 0, st, d_features, y2, bn2, bn2 + kC, bn2 + 2 * kC, bn2 + 3 * kC, S2,
-                       (double)batch * P2, P2, dy2_scratch);
+    const bool dp = p->world > 1 && p->sync_sum != nullptr && p->sync_buf != nullptr;
+    if (dp && !(fused && !z1 && p->autocorr_global != nullptr && saved_total)) return (int)hipErrorInvalidValue;  // (see GnbvEncoderParams.world)
+    const double *S2m = S2;  // the sums the elementwise BN2 backward uses: this replica's, or the global minibatch's
+    if (dp) {
+        if (hipMemcpyAsync(p->sync_buf + 2 * kC, S2, 2 * kC * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return (int)hipGetLastError();
+        if ((err = p->sync_sum(p->sync_ctx, 2 * kC, 2 * kC, stream))) return err;
+        S2m = p->sync_buf + 2 * kC;
+    }
+    hipLaunchKernelGGL(k_bn2_bwd_apply, dim3(batch * ((P2 + 63) / 64)), dim3(256), 0, st, d_features, y2, bn2, bn2 + kC, bn2 + 2 * kC, bn2 + 3 * kC, S2m,
+                       (double)batch * P2 * (dp ? p->world : 1), P2, dy2_scratch);
     if ((err = gnbv_launch_status())) return err;
     // ---- conv2 weight gradient: on the side stream, beside the data gradient ----
     BwdSide &side = bwd_side();
@@ -2416,11 +2471,17 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
         if ((err = gnbv_launch_status())) return err;
         const int slf = reduce_stage1(wg1_part, gd, kE1F, tmp1, st);
         if ((err = gnbv_launch_status())) return err;
+        if (dp) {  // BatchNorm-1 backward means over the global minibatch
+            hipLaunchKernelGGL(k_gather_bn1_sums, dim3(1), dim3(64), 0, st, (const double *)tmp1, slf, p->sync_buf + 4 * kC);
+            if ((err = gnbv_launch_status())) return err;
+            if ((err = p->sync_sum(p->sync_ctx, 4 * kC, 2 * kC, stream))) return err;
+        }
         hipLaunchKernelGGL(k_c1w_fused_finish, dim3(1), dim3(1024), 0, st, (const double *)tmp1, slf,
                            saved_total ? (const int *)(bn_state + kBnStateFloats) : (p->autocorr ? (const int *)p->autocorr : (const int *)Rac),
                            p->autocorr_row_stride, rows, (!saved_total && p->autocorr) ? batch : 0,
                            p->w1, bn1, bn1 + 3 * kC, z1 ? p->bn1_w : (const float *)nullptr, p->bn1_b, g->w1, g->b1, (const double *)S2, g->bn1_w,
-                           g->bn1_b, g->bn2_w, g->bn2_b);
+                           g->bn1_b, g->bn2_w, g->bn2_b, dp ? (const double *)(p->sync_buf + 4 * kC) : (const double *)nullptr,
+                           dp ? (const int *)p->autocorr_global : (const int *)nullptr);
         if ((err = gnbv_launch_status())) return err;
         if (side.enabled && hipStreamWaitEvent(st, side.join, 0) != hipSuccess) return (int)hipGetLastError();  // join
         return gnbv_launch_status();

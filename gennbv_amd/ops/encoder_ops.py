@@ -120,7 +120,7 @@ def autocorr_supported(grid: int) -> bool:
 
 
 def _params_struct(seq, act_bf16: bool = False, grid_i8: Optional[torch.Tensor] = None,
-                   autocorr: Optional[torch.Tensor] = None) -> _lib.GnbvEncoderParams:
+                   autocorr: Optional[torch.Tensor] = None, dp=None) -> _lib.GnbvEncoderParams:
     conv1, bn1, conv2, bn2 = seq[0], seq[1], seq[3], seq[4]
     p = _lib.GnbvEncoderParams()
     p.w1, p.b1, p.bn1_w, p.bn1_b = conv1.weight.data_ptr(), conv1.bias.data_ptr(), bn1.weight.data_ptr(), bn1.bias.data_ptr()
@@ -133,12 +133,18 @@ def _params_struct(seq, act_bf16: bool = False, grid_i8: Optional[torch.Tensor] 
     p.grid_i8_row_stride = 0 if grid_i8 is None else int(grid_i8.stride(0))
     p.autocorr = None if autocorr is None else autocorr.data_ptr()
     p.autocorr_row_stride = 0 if autocorr is None else int(autocorr.stride(0))
+    # data-parallel replicas: BatchNorm over the global minibatch (GnbvEncoderParams.world; gennbv_amd/parallel.py)
+    p.world = 0 if dp is None else int(dp["world"])
+    p.sync_sum = None if dp is None else dp["cb"]
+    p.sync_ctx = None
+    p.sync_buf = None if dp is None else dp["sync_buf"].data_ptr()
+    p.autocorr_global = None if dp is None else dp["autocorr_global"].data_ptr()
     return p
 
 
 class _GridEncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, base, rows, grid_off, grid, training, skip_flag, seq, act_bf16, write_through, grid_i8, compact, autocorr, w1, b1, g1, be1, w2, b2, g2, be2):
+    def forward(ctx, base, rows, grid_off, grid, training, skip_flag, seq, act_bf16, write_through, grid_i8, compact, autocorr, dp, w1, b1, g1, be1, w2, b2, g2, be2):
         lib = _lib.load()
         _lib.require_cuda(base, w1)
         for t in (w1, b1, g1, be1, w2, b2, g2, be2):
@@ -154,7 +160,7 @@ class _GridEncoderFn(torch.autograd.Function):
         bn_state = torch.empty(2 * 4 * 16 + 768, dtype=torch.float32, device=dev)  # + the minibatch's autocorrelation total (ints)
         feats = torch.empty(batch, 16 * p2, dtype=torch.float32, device=dev)
         ws = _workspace(lib, batch, grid, dev)
-        params = _params_struct(seq, act_bf16, grid_i8, autocorr)
+        params = _params_struct(seq, act_bf16, grid_i8, autocorr, dp if training else None)
         # compact observations: `base` has no grid slice, the kernels read the int8 rows only (obs pointer NULL)
         assert not compact or grid_i8 is not None
         obs_ptr = None if compact else base.data_ptr() + 4 * grid_off
@@ -167,6 +173,7 @@ class _GridEncoderFn(torch.autograd.Function):
         ctx.write_through = write_through
         ctx.grid_i8 = grid_i8
         ctx.autocorr = autocorr
+        ctx.dp = dp if training else None
         ctx.obs_ptr = obs_ptr
         return feats
 
@@ -188,23 +195,23 @@ class _GridEncoderFn(torch.autograd.Function):
         gs = _lib.GnbvEncoderGrads()
         for name, t in zip(("w1", "b1", "bn1_w", "bn1_b", "w2", "b2", "bn2_w", "bn2_b"), grads):
             setattr(gs, name, t.data_ptr())
-        params = _params_struct(seq, act_bf16, ctx.grid_i8, ctx.autocorr)
+        params = _params_struct(seq, act_bf16, ctx.grid_i8, ctx.autocorr, ctx.dp)
         ws = _workspace(lib, batch, grid, dev)
         _lib.check(lib.gnbv_encoder_grid_backward(
             ctx.obs_ptr, _lib.ptr(rows), base.stride(0), batch, grid, C.byref(params), y1.data_ptr(),
             y2.data_ptr(), bn_state.data_ptr(), d_feats.data_ptr(), dy2.data_ptr(), dz1.data_ptr(), C.byref(gs),
             ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "gnbv_encoder_grid_backward")
         if direct:
-            return (None,) * 20
-        return (None,) * 12 + tuple(grads)
+            return (None,) * 21
+        return (None,) * 13 + tuple(grads)
 
 
 def grid_encoder(base: torch.Tensor, rows: Optional[torch.Tensor], grid_off: int, grid: int, seq, training: bool,
                  skip_flag: Optional[torch.Tensor] = None, act_bf16: bool = False, write_through: bool = False,
-                 grid_i8: Optional[torch.Tensor] = None, compact: bool = False, autocorr: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 grid_i8: Optional[torch.Tensor] = None, compact: bool = False, autocorr: Optional[torch.Tensor] = None, dp=None) -> torch.Tensor:
     """seq = the `naive_encoder_grid` nn.Sequential (conv, bn, relu, conv, bn, relu).  `compact`: `base` rows carry
     no grid slice, the grid is read from `grid_i8` only.  `autocorr`: per-row input autocorrelation (input_autocorr)."""
-    return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, bool(act_bf16), bool(write_through), grid_i8, bool(compact), autocorr, seq[0].weight, seq[0].bias,
+    return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, bool(act_bf16), bool(write_through), grid_i8, bool(compact), autocorr, dp, seq[0].weight, seq[0].bias,
                                 seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias)
 
 
@@ -317,7 +324,8 @@ def hybrid_branches(enc, observations):
     else:
         feature_action = pose_branch()
     feature_grid = grid_encoder(base, rows, s, g, enc.naive_encoder_grid, enc.training, getattr(enc, "_bn_skip_flag", None),
-                                enc.compute_dtype == torch.bfloat16, getattr(enc, "_grad_write_through", False), grid_i8, compact, autocorr)
+                                enc.compute_dtype == torch.bfloat16, getattr(enc, "_grad_write_through", False), grid_i8, compact, autocorr,
+                                getattr(enc, "_dp_sync", None))
     if getattr(enc, "_split_backward", False) and torch.is_grad_enabled():
         # data-parallel: cut the autograd graph at the conv-stack output so that the backward runs in
         # two phases (late layers first, their gradient all-reduce overlaps the conv-stack backward)

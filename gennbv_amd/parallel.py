@@ -16,9 +16,16 @@ module defines it:
     of the ranks' KLs) rides in the collective and every rank stops at the same minibatch -- no
     divergence, no deadlock;
   * clip_grad_norm_ is evaluated on the averaged gradient (after the all-reduce);
-  * per-minibatch advantage normalisation and BatchNorm batch statistics stay local to the
-    rank's shard of the minibatch (like torch DDP without SyncBatchNorm); with world = 1 this
-    is exactly the reference.
+  * the statistics that the single-GPU update takes over the MINIBATCH are taken over the GLOBAL minibatch (the union of
+    the ranks' minibatches k), so that a data-parallel update equals the single-GPU update of the global batch:
+      - advantage mean / unbiased std (ppo_grid_obs.py:214-216): a table [n_minibatches, 2] computed once per train() --
+        the advantages and the permutation are fixed for all epochs -- with two small all-reduces (`global_adv_norm`);
+      - BatchNorm-1 batch statistics: analytic from the input autocorrelation total of the global minibatch, also a
+        per-train() table (`global_autocorr`: [n_minibatches, 768] int32, one all-reduce);
+      - BatchNorm-2 batch sums (forward) and the BatchNorm-2 / BatchNorm-1 backward sums: 32 doubles each, summed over
+        the ranks inside the encoder calls through `GnbvEncoderParams.sync_sum` (three small all-reduces per optimizer
+        step, captured in the step's hipGraph like the gradient all-reduce).
+    Parameter gradients stay local sums; the gradient all-reduce adds them (see csrc/encoder.hip, k_c1w_fused_finish).
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): the 58 MB fp32 gradient of the G=64
 policy costs ~2*(7/8)*58 MB / (7*153 GB/s) = 95 us on a direct reduce-scatter + all-gather
@@ -51,12 +58,53 @@ def shard_range(total_envs: int, rank: int, world: int):
 
 
 class GradSync:
-    """Gradient (+ KL) averaging for both train paths."""
+    """Gradient (+ KL) averaging for both train paths, and the global-minibatch statistics of the fused path."""
 
     def __init__(self, world: int, group=None, always_sync: bool = False):
         self.world, self.group = int(world), group
         # exercise the collective path even with one rank (single-GPU test of the data-parallel code)
         self.active = self.world > 1 or always_sync
+        self.sync_buf = None   # fp64 [96] on the device: the three 32-double sums of GnbvEncoderParams.sync_sum
+        self._cb = None
+
+    # ---- global-minibatch statistics (fused path) ---------------------------------------
+    def encoder_sync(self, device):
+        """(callback pointer, sync_buf) for GnbvEncoderParams: sums sync_buf[offset : offset + n] over the ranks, enqueued on
+        the caller's current stream (the stream the encoder kernels run on)."""
+        import ctypes as C
+        if self.sync_buf is None:
+            self.sync_buf = torch.zeros(96, dtype=torch.float64, device=device)
+            buf, group = self.sync_buf, self.group
+
+            def cb(_ctx, offset, n, _stream):
+                try:
+                    dist.all_reduce(buf[offset:offset + n], op=dist.ReduceOp.SUM, group=group)
+                    return 0
+                except Exception as ex:  # surfaces as a failed encoder call
+                    print(f"[gennbv_amd] sync_sum failed: {ex!r}")
+                    return 1
+            self._cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p)(cb)
+        return C.cast(self._cb, C.c_void_p).value, self.sync_buf
+
+    def global_adv_norm(self, adv_rows: torch.Tensor) -> torch.Tensor:
+        """adv_rows [n_mb, B] = this rank's advantages in minibatch order -> [n_mb, 2] fp32 (mean, 1 / (std + 1e-8)) of the
+        global minibatches (unbiased std, ppo_grid_obs.py:214-216).  Two-pass in fp64."""
+        a = adv_rows.double()
+        bg = float(a.shape[1] * self.world)
+        s1 = a.sum(1)
+        dist.all_reduce(s1, op=dist.ReduceOp.SUM, group=self.group)
+        mean = s1 / bg
+        s2 = ((a - mean[:, None]) ** 2).sum(1)
+        dist.all_reduce(s2, op=dist.ReduceOp.SUM, group=self.group)
+        std = torch.sqrt(s2 / max(bg - 1.0, 1.0))
+        return torch.stack((mean, 1.0 / (std + 1e-8)), dim=1).float().contiguous()
+
+    def global_autocorr(self, ac_rows: torch.Tensor) -> torch.Tensor:
+        """ac_rows [n_mb, B, 768] int32 (this rank's autocorrelation rows in minibatch order) -> [n_mb, 768] int32 totals of
+        the global minibatches."""
+        tot = ac_rows.sum(1, dtype=torch.int64).to(torch.int32).contiguous()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
+        return tot
 
     # ---- torch-module path (per-parameter grads) --------------------------------------
     def average_grads(self, params: Iterable[torch.nn.Parameter]) -> None:

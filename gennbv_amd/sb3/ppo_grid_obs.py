@@ -248,7 +248,11 @@ class PPO_Grid_Obs:
                 values, log_prob, entropy = self.policy.evaluate_actions(rollout_data.observations, actions)
                 values = values.flatten()
                 advantages = rollout_data.advantages
-                if self.normalize_advantage:
+                if self.normalize_advantage and self._sync is not None and self._sync.active:
+                    # data-parallel: the statistics of the GLOBAL minibatch (all ranks' rows), gennbv_amd/parallel.py
+                    gm, ginv = self._sync.global_adv_norm(advantages.view(1, -1))[0]
+                    advantages = (advantages - gm) * ginv
+                elif self.normalize_advantage:
                     advantages = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
                 ratio = torch.exp(log_prob - rollout_data.old_log_prob)
                 policy_loss_1 = advantages * ratio
@@ -325,6 +329,22 @@ class PPO_Grid_Obs:
             # the GLOBAL mean after the all-reduce (gnbv_clip_adam_step), not by the loss kernel
             loss.args.kl_out = opt.kl_slot.data_ptr()
         self.policy.features_extractor._bn_skip_flag = loss.stop_flag
+        if self._sync is not None and self._sync.active and self._sync.world > 1:  # (one rank: its statistics ARE the global ones)
+            # global-minibatch statistics (gennbv_amd/parallel.py): advantage mean / std and BatchNorm-1's input
+            # autocorrelation total come from per-train() tables (one row per minibatch, copied into these two buffers
+            # before each step); BatchNorm-2 and the backward sums are summed over the ranks inside the encoder calls
+            buf = self.rollout_buffer
+            if buf.autocorr is None or buf.grid_i8 is None:
+                raise ValueError("data-parallel training runs on the fused gfx950 path: it needs the int8 grid rows with their "
+                                 "autocorrelation rows (an env with supports_grid_i8, G % 16 == 0; e.g. compact_obs=True)")
+            cb, sync_buf = self._sync.encoder_sync(self.device)
+            self._hip["adv_cur"] = torch.zeros(2, dtype=torch.float32, device=self.device)
+            self._hip["ac_cur"] = torch.zeros(768, dtype=torch.int32, device=self.device)
+            loss.args.adv_norm = self._hip["adv_cur"].data_ptr()
+            self.policy.features_extractor._dp_sync = {"world": self._sync.world, "cb": cb, "sync_buf": sync_buf,
+                                                       "autocorr_global": self._hip["ac_cur"]}
+        else:
+            self.policy.features_extractor._dp_sync = None
         from ..ops import direct_grad
         direct_grad.enable(self.policy, self.grad_write_through)
         # with write-through every gradient slice is overwritten each step: no zero-fill needed when the
@@ -461,6 +481,16 @@ class PPO_Grid_Obs:
         hyper = (float(lr), float(clip_range), None if clip_range_vf is None else float(clip_range_vf))
         if st.get("hyper") != hyper:
             st["graph"], st["hyper"] = None, hyper  # kernel arguments are baked into the graph: re-capture
+        dp = self._sync is not None and self._sync.active
+        dp_stats = dp and self._sync.world > 1
+        if dp_stats:
+            # the advantages and the permutation are fixed for the whole train() call: the global minibatches' advantage
+            # statistics and input-autocorrelation totals are computed once (three small all-reduces), not per step
+            t_, n_ = buf.buffer_size, buf.n_envs
+            adv_tab = self._sync.global_adv_norm(buf.advantages.view(t_ * n_)[rows_all].view(n_mb, batch))
+            ac_tab = self._sync.global_autocorr(buf.autocorr[:t_].view(t_ * n_, -1)[rows_all].view(n_mb, batch, -1))
+            st["adv_cur"].copy_(adv_tab[0])
+            st["ac_cur"].copy_(ac_tab[0])
         if use_graph and st["graph"] is None:
             loss.rows.copy_(rows_all[:batch])
             st["graph"] = self._capture_minibatch_graph(st)
@@ -470,7 +500,10 @@ class PPO_Grid_Obs:
         for epoch in range(self.n_epochs):
             for k in range(n_mb):
                 loss.rows.copy_(rows_all[k * batch:(k + 1) * batch])
-                if self._sync is not None and self._sync.active:
+                if dp_stats:
+                    st["adv_cur"].copy_(adv_tab[k])
+                    st["ac_cur"].copy_(ac_tab[k])
+                if dp:
                     self._dp_minibatch(st, use_graph)
                 elif use_graph:
                     st["graph"].replay()

@@ -254,6 +254,16 @@ typedef struct GnbvEncoderParams {
                                      int8 rows, same row numbering): the fused backward sums rows[b]'s rows instead of
                                      recomputing the minibatch's autocorrelation */
     int64_t autocorr_row_stride;  /* ints */
+    /* ---- data-parallel replicas: BatchNorm over the GLOBAL minibatch.  world <= 1 / sync_sum == NULL: a single
+     * replica, nothing below is read.  Otherwise the training forward / backward call sync_sum three times -- BN2 batch sums
+     * (forward), BN2-backward sums and BN1-backward sums (backward) -- each time on 32 doubles of `sync_buf`, and the
+     * statistics of BatchNorm-1 come from `autocorr_global`.  Needs the fused backward (aligned int8 rows + autocorr rows). */
+    int world;                    /* number of replicas */
+    int (*sync_sum)(void *ctx, int offset, int n, void *stream);  /* [host callback] sum sync_buf[offset, offset + n) over the
+                                     replicas in place, ordered on `stream` (e.g. an all-reduce enqueued there); returns 0 */
+    void *sync_ctx;
+    double *sync_buf;             /* device [96] */
+    const int32_t *autocorr_global; /* device [768]: sum of the autocorrelation rows of ALL replicas' minibatch rows */
 } GnbvEncoderParams;
 
 typedef struct GnbvEncoderGrads {  /* outputs, same shapes as the parameters */

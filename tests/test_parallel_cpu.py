@@ -49,7 +49,10 @@ def _local_ppo(fx, envs, batch, target_kl):
         getattr(buf, name)[: src.shape[0]].copy_(src[:, envs])
     buf.step = t
     ppo.rollout_buffer, ppo.n_envs, ppo.batch_size = buf, len(envs), batch
-    ppo.normalize_advantage, ppo.target_kl = False, target_kl
+    # advantage normalisation ON: its statistics are those of the global minibatch (GradSync.global_adv_norm); BatchNorm is
+    # frozen here because the torch modules of this CPU path have no cross-rank BatchNorm -- the fused gfx950 path has, and
+    # tests/test_parallel_gpu.py runs it with BatchNorm in train mode
+    ppo.normalize_advantage, ppo.target_kl = True, target_kl
     _freeze_bn(ppo)
     return ppo
 

@@ -1,0 +1,159 @@
+"""GPU: the data-parallel FUSED update (`PPO_Grid_Obs._dp_step_body`: phase A -> gradient all-reduce overlapped with the
+conv-stack backward -> small all-reduce -> clip + Adam) with the statistics SURVEY 8e requires to be global --
+per-minibatch advantage mean / std, BatchNorm-1 and BatchNorm-2 batch statistics IN TRAIN MODE and their backward sums, the
+approx-KL of the early stop -- against the single-process update of the global batch.
+
+Two ranks share cuda:0 here (one GPU box) and talk over gloo on CUDA tensors; the collectives therefore run eagerly
+(RCCL refuses two ranks on one device, gloo cannot be captured) -- the same `_dp_step_body` the bench replays as one
+hipGraph with RCCL collectives on a multi-GPU node."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+G, N_LOCAL, T, B_LOCAL, EPOCHS, WORLD = 16, 8, 4, 8, 2, 2
+HW = (48, 64)
+
+
+def _cfg():
+    from gennbv_amd.env.config import TaskConfig
+    return TaskConfig(camera_width=HW[1], camera_height=HW[0], grid_size=G)
+
+
+def _kwargs(cfg):
+    from gennbv_amd.network.hybrid_encoder import Hybrid_Encoder
+    return dict(net_arch=[], features_extractor_class=Hybrid_Encoder, features_extractor_kwargs=dict(
+        encoder_param={"hidden_shapes": [256, 256], "visual_dim": 256},
+        net_param={"transformer_params": [[1, 256], [1, 256]], "append_hidden_shapes": [256, 256]},
+        state_input_shape=(cfg.state_dim,), visual_input_shape=(cfg.stack, HW[0], HW[1])))
+
+
+def _algo(env, batch, target_kl):
+    from gennbv_amd.sb3.policies import ActorCriticPolicy_Train_Eval
+    from gennbv_amd.sb3.ppo_grid_obs import PPO_Grid_Obs
+    return PPO_Grid_Obs(ActorCriticPolicy_Train_Eval, env, learning_rate=1e-4, n_steps=T, batch_size=batch, n_epochs=EPOCHS, gamma=0.99,
+                        gae_lambda=0.95, clip_range=0.2, clip_range_vf=0.2, ent_coef=0.01, vf_coef=0.8, max_grad_norm=1.0, target_kl=target_kl,
+                        seed=1, device=DEV, compact_obs=True, policy_kwargs=_kwargs(_cfg()))
+
+
+class _StubEnv:
+    """The attributes PPO_Grid_Obs needs to build a policy + compact rollout buffer (no stepping)."""
+    supports_grid_i8, device, max_episode_length = True, DEV, 6
+
+    def __init__(self, n):
+        from tests import policy_util as pu
+        from gennbv_amd.spaces import Box, MultiDiscrete
+        cfg = _cfg()
+        self.num_envs = n
+        self.observation_space = Box(-np.inf, np.inf, (cfg.obs_dim,))
+        self.action_space = MultiDiscrete(pu.NVEC)
+
+    def seed(self, s):
+        pass
+
+
+FIELDS = ("observations", "grid_i8", "autocorr", "actions", "values", "log_probs", "advantages", "returns", "rewards")
+
+
+def _fill(algo, blob, envs):
+    buf = algo.rollout_buffer
+    for k in FIELDS:
+        getattr(buf, k).copy_(blob[k][:, envs].to(DEV))
+    buf.step, buf.full = T, True
+    algo.policy.load_state_dict({k: v.to(DEV) for k, v in blob["policy"].items()})
+
+
+def _local_to_global(perm, rank):
+    """local flat index i = n*T + t of rank r (n < N_LOCAL) -> the global buffer's flat index (r*N_LOCAL + n)*T + t"""
+    return (rank * N_LOCAL + perm // T) * T + perm % T
+
+
+def _worker(rank, path, port, target_kl, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from gennbv_amd import parallel
+    blob = torch.load(path, weights_only=False)
+    algo = _algo(_StubEnv(N_LOCAL), B_LOCAL, target_kl)
+    _fill(algo, blob, list(range(rank * N_LOCAL, (rank + 1) * N_LOCAL)))
+    algo.rollout_buffer.indices = blob["perm"].copy()  # the same permutation on every rank, over its own rows
+    algo.use_graph = False
+    parallel.attach(algo, WORLD)
+    algo.train()
+    assert algo.policy.features_extractor._dp_sync is not None and algo.policy.features_extractor.training
+    vec = torch.cat([p.detach().reshape(-1) for p in algo.policy.parameters()])
+    bn = torch.cat([b.detach().reshape(-1).float() for b in algo.policy.buffers()])
+    both = [torch.zeros_like(vec) for _ in range(WORLD)]
+    dist.all_gather(both, vec)
+    if rank == 0:
+        out["identical"] = bool(torch.equal(both[0], both[1]))
+        out["params"], out["bn"] = vec.cpu().numpy(), bn.cpu().numpy()
+        out["stats"] = algo.last_train_stats.copy()
+        out["steps"] = int(algo._hip["opt"].step_count.item())
+    dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("target_kl", [None, "auto"])
+def test_two_rank_fused_update_equals_the_global_batch_update(tmp_path, target_kl):
+    from gennbv_amd.env import synthetic as S
+    from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg = _cfg()
+    n = WORLD * N_LOCAL
+    scene = S.make_scenes(n, G, seed=3, device=DEV)
+    env = ReplayFeedEnv(cfg, scene, ReplayFeed.synthetic(scene, cfg, 5, seed=3), DEV, max_episode_length=6)
+    ref = _algo(env, WORLD * B_LOCAL, None)
+    ref._setup_learn(total_timesteps=10 ** 9)
+    ref.collect_rollouts(env, None, ref.rollout_buffer, n_rollout_steps=T)
+    buf = ref.rollout_buffer
+    assert buf.autocorr is not None and buf.compact_state_dim is not None
+    perm = np.random.RandomState(7).permutation(T * N_LOCAL)
+    blob = {k: getattr(buf, k).detach().cpu().clone() for k in FIELDS}
+    blob["policy"] = {k: v.detach().cpu().clone() for k, v in ref.policy.state_dict().items()}
+    blob["perm"] = perm
+    path = str(tmp_path / "rollout.pt")
+    torch.save(blob, path)
+    # the global minibatch k = rank 0's minibatch k ++ rank 1's minibatch k
+    glob = np.concatenate([np.concatenate([_local_to_global(perm[k * B_LOCAL:(k + 1) * B_LOCAL], r) for r in range(WORLD)])
+                           for k in range(T * N_LOCAL // B_LOCAL)])
+    buf.indices = glob
+
+    def run_ref(tkl):
+        ref.policy.load_state_dict({k: v.to(DEV) for k, v in blob["policy"].items()})
+        ref.target_kl, ref._hip = tkl, None
+        ref.policy.optimizer = torch.optim.Adam(ref.policy.parameters(), lr=1e-4, eps=1e-5)
+        ref.use_graph = False
+        ref.train()
+        return ref.last_train_stats.copy()
+    stats = run_ref(None)
+    if target_kl == "auto":  # a threshold the KL trace crosses in the second epoch: both sides must stop at the same minibatch
+        kl = stats[:, 3]
+        j = int(np.argmax(kl))
+        assert j >= 1
+        target_kl = float(0.5 * (kl[j] + np.max(kl[:j])) / 1.5)
+        stats = run_ref(target_kl)
+        assert len(stats) == j + 1
+    want = torch.cat([p.detach().reshape(-1) for p in ref.policy.parameters()]).cpu().numpy()
+    want_bn = torch.cat([b.detach().reshape(-1).float() for b in ref.policy.buffers()]).cpu().numpy()
+    steps = int(ref._hip["opt"].step_count.item())
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(path, _free_port(), target_kl, out), nprocs=WORLD, join=True)
+    assert out["identical"], "ranks diverged"
+    assert out["steps"] == steps and len(out["stats"]) == len(stats)  # same early-stop position
+    # the ranks log the terms of their own rows; the KL (col 3) they act on is the global mean: check it through the stop position,
+    # and the local means average to the global ones only for rank-symmetric terms -- compare the outcome instead:
+    np.testing.assert_allclose(out["bn"], want_bn, rtol=2e-5, atol=2e-6)  # BatchNorm running statistics = global-batch statistics
+    d = np.abs(out["params"] - want)
+    assert np.quantile(d, 0.999) <= 2e-6 and d.max() <= 1e-4 * 1.05 * max(steps, 1), (np.quantile(d, 0.999), d.max())
