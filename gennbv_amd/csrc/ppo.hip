@@ -172,9 +172,11 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_fused(GnbvPpoLoss a, float
         }
     }
     // ---- the workgroup that finishes last adds the per-sample terms (fixed order: deterministic) ----
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) s_last = atomicAdd(counter, 1) == (int)gridDim.x - 1;
+    __syncthreads();  // (every wave's stores have left the CU: s_waitcnt vmcnt(0) + barrier)
+    if (tid == 0) {
+        __threadfence();  // one release per workgroup, then the ticket
+        s_last = atomicAdd(counter, 1) == (int)gridDim.x - 1;
+    }
     __syncthreads();
     if (!s_last) return;
     __threadfence();
