@@ -608,8 +608,9 @@ __device__ __forceinline__ int pixel_to_lin(const PixelFrame &pf, const Intrinsi
     return keep ? ix * pf.gg + iy * pf.g + iz : -1;
 }
 
+// (amdgpu_num_sgpr: see launch_masks -- SGPR-limited occupancy)
 template <bool KFAST>
-__global__ __launch_bounds__(kFusedThreads) void k_hit_list(
+__global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80))) void k_hit_list(
     const float *__restrict__ depth_raw, const float *__restrict__ seg_raw, const float *__restrict__ c2w, Intrinsics K,
     const float *__restrict__ range_gt, const float *__restrict__ voxel_size, int n, int h, int w, int g, float sense_dist,
     int chunks, int words, uint32_t *__restrict__ hit_mask, int32_t *__restrict__ ray_count, int32_t *__restrict__ ray_list,
@@ -1397,9 +1398,10 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
     const size_t list_lds = mask_bytes + 64 * sizeof(uint32_t) + (size_t)words * sizeof(uint16_t);
     static const bool fused_off = [] { const char *v = getenv("GENNBV_RAY_LISTS"); return v && v[0] == '0'; }();
     if (!lds_off && !fused_off && ws.ray_list != nullptr && list_lds <= kLdsMax && words <= 65536) {
-        // workgroups per env: one per CU in total (1024 threads each; measured: a second one does not become resident beside
-        // it, 512 workgroups run as two rounds); one per env = plain stores of the hit mask, no ray listed twice
-        int fchunks = (256 + n - 1) / n;
+        // workgroups per env: two per CU in total (1024 threads each = 32 waves per CU).  (The kernel is capped at 80 SGPRs:
+        // with the 96 it wanted, the SIMD's 800-entry SGPR file held 7 waves and a second 16-wave workgroup never became
+        // resident beside the first -- 512 workgroups ran as two rounds, profiles/r02_notes.md.)
+        int fchunks = (512 + n - 1) / n;
         fchunks = fchunks < 1 ? 1 : (fchunks > 16 ? 16 : fchunks);
         {
             static const int forced = [] { const char *v = getenv("GENNBV_HIT_CHUNKS"); return v ? atoi(v) : 0; }();
