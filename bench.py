@@ -39,9 +39,9 @@ def parse():
     ap.add_argument("--batch-size", type=int, default=128)
     ap.add_argument("--n-epochs", type=int, default=5)
     ap.add_argument("--frames", type=int, default=8, help="frames in the synthetic feed pool")
-    ap.add_argument("--backend", default=os.environ.get("GENNBV_ENCODER_BACKEND", "hip"), choices=["hip", "torch"])
+    ap.add_argument("--backend", default="hip", choices=["hip", "torch"])
     ap.add_argument("--dtype", default="fp32", choices=["fp32"])
-    ap.add_argument("--obs", default=os.environ.get("GENNBV_BENCH_OBS", "compact"), choices=["flat", "compact"],
+    ap.add_argument("--obs", default="compact", choices=["flat", "compact"],
                     help="rollout-buffer rows: the reference's flat fp32 rows, or compact rows (grid as int8 only; same values)")
     ap.add_argument("--target-kl", default="off", help="'off' (default): the KL early stop of PPO_Grid_Obs.train (ppo_grid_obs.py:261-268) can never "
                     "trigger, so every timed iteration runs all n_epochs x minibatches (the check itself still runs on the device); "

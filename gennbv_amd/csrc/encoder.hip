@@ -2340,42 +2340,6 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     return gnbv_launch_status();
 }
 
-// EXPERIMENT (off unless GENNBV_BWD_CONCURRENT=1): side stream + fork/join events so that the conv2 weight
-// gradient (MFMA/VALU-issue bound) runs beside the conv2 data gradient (HBM bound) -- both only depend on
-// dy2.  Works under stream capture, but measured SLOWER on MI355X (train 1176 vs 1129 ms per iteration:
-// two ~10 us cross-queue joins plus L2 interference outweigh the overlap), hence not the default.
-struct BwdSide {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    bool enabled = false, init = false, own_stream = false;
-};
-static BwdSide &bwd_side()
-{
-    static BwdSide s;
-    if (!s.init) {
-        s.init = true;
-        const char *e = getenv("GENNBV_BWD_CONCURRENT");
-        if ((e && e[0] == '1') && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
-            hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess)
-            s.enabled = s.own_stream = true;
-    }
-    return s;
-}
-// The caller's own second stream for the same purpose (NULL: off again).  In a captured PPO minibatch this is the stream the
-// pose-history branch already runs on, so that the graph keeps two parallel branches instead of growing a third.
-GNBV_API int gnbv_encoder_set_backward_side_stream(void *stream)
-{
-    BwdSide &s = bwd_side();
-    if (s.own_stream) return 0;  // GENNBV_BWD_CONCURRENT=1 keeps its private stream
-    if (s.fork == nullptr && (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
-                              hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess))
-        return (int)hipGetLastError();
-    s.stream = gnbv_stream(stream);
-    s.enabled = stream != nullptr;
-    return 0;
-}
-
 GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *rows, int64_t row_stride, int batch, int grid,
                                         const GnbvEncoderParams *p, const void *y1, const float *y2, const float *bn_state,
                                         const float *d_features, float *dy2_scratch, void *dz1_scratch,
@@ -2419,12 +2383,9 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
                        (double)batch * P2 * (dp ? p->world : 1), P2, dy2_scratch);
     if ((err = gnbv_launch_status())) return err;
     // ---- conv2 weight gradient: on the side stream, beside the data gradient ----
-    BwdSide &side = bwd_side();
+    // (running this kernel on a second stream beside the data gradient was measured slower: both are bound by the CU's
+    // vector-load path, profiles/r01_notes.md)
     hipStream_t sw = st;
-    if (side.enabled) {
-        if (hipEventRecord(side.fork, st) != hipSuccess || hipStreamWaitEvent(side.stream, side.fork, 0) != hipSuccess) return (int)hipGetLastError();
-        sw = side.stream;
-    }
     int nrows2 = batch * O2 * O2;
     int wg_blocks = (nrows2 + kEncWaves - 1) / kEncWaves;
     wg_blocks = wg_blocks > 512 ? 512 : ((wg_blocks + 7) & ~7);
@@ -2434,11 +2395,8 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     } else if (z1) {
         hipLaunchKernelGGL((k_conv2_wgrad<ActF32, true>), dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
                        w.wg_part);
-    } else if (qm && !env_off("GENNBV_WGRAD_QM_LDS")) {
-        hipLaunchKernelGGL(k_conv2_wgrad_qm, dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2, w.wg_part);
     } else if (qm) {
-        hipLaunchKernelGGL((k_conv2_wgrad<ActF32, false, true>), dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
-                           w.wg_part);
+        hipLaunchKernelGGL(k_conv2_wgrad_qm, dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2, w.wg_part);
     } else {
         hipLaunchKernelGGL(k_conv2_wgrad<ActF32>, dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
                        w.wg_part);
@@ -2449,14 +2407,12 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     if ((err = gnbv_launch_status())) return err;
     // (the weight images ride in the finish launch unless it runs on the side stream)
     hipLaunchKernelGGL(k_conv2_wgrad_finish, dim3((E2 + 255) / 256), dim3(256), 0, sw, (const double *)w.tmp, sl2, g->w2, g->b2,
-                       side.enabled ? (const float *)nullptr : p->w2, w.w2img);
+                       p->w2, w.w2img);
     if ((err = gnbv_launch_status())) return err;
-    if (side.enabled && hipEventRecord(side.join, sw) != hipSuccess) return (int)hipGetLastError();
     // the conv1 weight gradient (main stream) uses its own partial / slice regions of the workspace
     float *wg1_part = w.wg_part + (size_t)512 * E2;
     double *tmp1 = w.tmp + (size_t)32 * E2;
     // ---- conv2 data gradient (+ ReLU1 mask, BN1 backward sums) ----
-    if (side.enabled) hipLaunchKernelGGL(k_prep_w2, dim3(kTaps), dim3(256), 0, st, p->w2, w.w2img, w.w2img + kTaps * 256);
     const int gd = sample_plane_group_grid(batch, (O1 + 1) / 2, kPlanesPerGroup);  // groups of plane PAIRS
     if (fused) {
         if (z1)
@@ -2483,7 +2439,6 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
                            g->bn1_b, g->bn2_w, g->bn2_b, dp ? (const double *)(p->sync_buf + 4 * kC) : (const double *)nullptr,
                            dp ? (const int *)p->autocorr_global : (const int *)nullptr);
         if ((err = gnbv_launch_status())) return err;
-        if (side.enabled && hipStreamWaitEvent(st, side.join, 0) != hipSuccess) return (int)hipGetLastError();  // join
         return gnbv_launch_status();
     }
     if (p->act_bf16) {
@@ -2546,7 +2501,6 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     hipLaunchKernelGGL(k_conv1_wgrad_finish, dim3((E1 + 255) / 256), dim3(256), 0, st, (const double *)tmp1, sl1, g->w1, g->b1,
                        (const double *)S1, (const double *)S2, g->bn1_w, g->bn1_b, g->bn2_w, g->bn2_b);
     if ((err = gnbv_launch_status())) return err;
-    if (side.enabled && hipStreamWaitEvent(st, side.join, 0) != hipSuccess) return (int)hipGetLastError();  // join
     return gnbv_launch_status();
 }
 

@@ -298,46 +298,6 @@ __global__ __launch_bounds__(kHitThreads) void k_hit_mask(
     }
 }
 
-// device-scope-atomic variant (GENNBV_MASK_LDS=0, A/B runs): straight to L2 atomics
-__global__ __launch_bounds__(kHitThreads) void k_hit_mask_global(
-    const float *__restrict__ depth_raw, const float *__restrict__ seg_raw, const float *__restrict__ c2w,
-    Intrinsics K, const float *__restrict__ range_gt, const float *__restrict__ voxel_size,
-    int n, int h, int w, int g, float sense_dist, int chunks, int words, uint32_t *__restrict__ hit_mask)
-{
-    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
-    const int e = (slot / chunks) * 8 + xcd;
-    const int c = slot % chunks;
-    if (e >= n) return;
-    float M[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) M[i] = c2w[(size_t)e * 16 + i];
-    const VoxelFrame f = load_frame(range_gt + e * 6, voxel_size + e * 3);
-    const int hw = h * w;
-    const int ppc = (hw + chunks - 1) / chunks;
-    const int px0 = c * ppc, px1 = min(hw, px0 + ppc);
-    uint32_t *gm = hit_mask + (size_t)e * words;
-    int last_word = -1;
-    uint32_t acc = 0u;
-    for (int p = px0 + threadIdx.x; p < px1; p += kHitThreads) {
-        const float sraw = seg_raw[(size_t)e * hw + p];
-        if (!(nan_to_num_neginf0(sraw) > 50.0f)) continue;
-        const int y = p / w, x = p - y * w;
-        float wp[3];
-        int ix[3];
-        pixel_to_world(process_depth(depth_raw[(size_t)e * hw + p], sense_dist), (float)x, (float)y, K, M, wp);
-        const int lin = point_to_voxel(wp, f, g, ix);
-        if (lin < 0) continue;
-        const int wd = lin >> 5;
-        if (wd != last_word) {
-            if (acc) atomicOr(&gm[last_word], acc);
-            last_word = wd;
-            acc = 0u;
-        }
-        acc |= 1u << (lin & 31);
-    }
-    if (acc) atomicOr(&gm[last_word], acc);
-}
-
 // ===========================================================================
 // fused path, launch 2: ray cast
 //
@@ -1375,10 +1335,8 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
     const int words = ws.words;
     const size_t mask_bytes = (size_t)words * sizeof(uint32_t);
     // LDS staging of the masks: a gfx950 workgroup may use all 160 KiB.  Larger masks (G > 104) are split into windows
-    // of <= 128 KiB, one workgroup per window (GENNBV_MASK_LDS=0: the old device-scope-atomic fallbacks, for A/B runs).
-    static const bool lds_off = [] { const char *v = getenv("GENNBV_MASK_LDS"); return v && v[0] == '0'; }();
+    // of <= 128 KiB, one workgroup per window.
     const size_t kLdsMax = 160 * 1024, ray_fixed = (kQueueCap + 32) * sizeof(uint32_t);
-    const bool lds_hit = !lds_off, lds_path = !lds_off;
     const int hit_windows = mask_bytes <= kLdsMax ? 1 : (int)((mask_bytes + 128 * 1024 - 1) / (128 * 1024));
     const int path_windows = mask_bytes + ray_fixed <= kLdsMax ? 1 : (int)((mask_bytes + 128 * 1024 - 1) / (128 * 1024));
     const int hit_nw = (words + hit_windows - 1) / hit_windows, path_nw = (words + path_windows - 1) / path_windows;
@@ -1387,26 +1345,17 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
     // (measured 4x the mean) is spread over several CUs (profiles/r01_notes.md)
     int splits = (1024 + n - 1) / n;
     splits = splits < 1 ? 1 : (splits > 8 ? 8 : splits);
-    {
-        static const int forced = [] { const char *v = getenv("GENNBV_RAY_SPLITS"); return v ? atoi(v) : 0; }();
-        if (forced > 0) splits = forced;  // tuning knob (tools/ab_voxel.sh)
-    }
     // inv_intri of a pinhole camera is [[a,0,c],[0,b,d],[0,0,1]]: lets the kernels drop exact-zero terms
     const bool kfast = K.k[1] == 0.0f && K.k[3] == 0.0f && K.k[6] == 0.0f && K.k[7] == 0.0f && K.k[8] == 1.0f;
     const int env_groups = (n + 7) / 8;
     // hit mask + ray list, then the load-balanced ray cast over the lists (needs the h/w-sized workspace)
     const size_t list_lds = mask_bytes + 64 * sizeof(uint32_t) + (size_t)words * sizeof(uint16_t);
-    static const bool fused_off = [] { const char *v = getenv("GENNBV_RAY_LISTS"); return v && v[0] == '0'; }();
-    if (!lds_off && !fused_off && ws.ray_list != nullptr && list_lds <= kLdsMax && words <= 65536) {
+    if (ws.ray_list != nullptr && list_lds <= kLdsMax && words <= 65536) {
         // workgroups per env: two per CU in total (1024 threads each = 32 waves per CU).  (The kernel is capped at 80 SGPRs:
         // with the 96 it wanted, the SIMD's 800-entry SGPR file held 7 waves and a second 16-wave workgroup never became
         // resident beside the first -- 512 workgroups ran as two rounds, profiles/r02_notes.md.)
         int fchunks = (512 + n - 1) / n;
         fchunks = fchunks < 1 ? 1 : (fchunks > 16 ? 16 : fchunks);
-        {
-            static const int forced = [] { const char *v = getenv("GENNBV_HIT_CHUNKS"); return v ? atoi(v) : 0; }();
-            if (forced > 0) fchunks = forced;  // tuning knob (tools/ab_voxel.sh)
-        }
         // one fill: [hit (only when OR-accumulated) | path | ray counts] are adjacent for the full env range
         if (ws.path == ws.hit + (size_t)n * words && (void *)ws.ray_count == (void *)(ws.path + (size_t)n * words)) {
             uint32_t *z0 = fchunks > 1 ? ws.hit : ws.path;
@@ -1427,20 +1376,6 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
                            voxel_size, n, h, w, g, depth_sense_dist, fchunks, words, ws.hit, ws.ray_count, ws.ray_list, ws.ray_cap,   \
                            coverage_count);                                                                                          \
     } while (0)
-        {
-            static const bool show = getenv("GENNBV_PRINT_OCCUPANCY") != nullptr;  // profiling aid
-            static bool shown = false;
-            if (show && !shown) {
-                shown = true;
-                int nb = -1, nr = -1;
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_hit_list<true>, kFusedThreads, list_lds);
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nr, (const void *)k_ray_list, kListThreads, mask_bytes);
-                hipFuncAttributes fa;
-                (void)hipFuncGetAttributes(&fa, (const void *)k_hit_list<true>);
-                fprintf(stderr, "[gennbv] k_hit_list: %d workgroups of %d threads per CU (LDS %zu B, %d regs, static LDS %zu); k_ray_list: %d per CU\n",
-                        nb, kFusedThreads, list_lds, fa.numRegs, fa.sharedSizeBytes, nr);
-            }
-        }
         if (kfast) GNBV_HITLIST(true);
         else GNBV_HITLIST(false);
 #undef GNBV_HITLIST
@@ -1454,7 +1389,7 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
     }
     // zero the hit masks (OR-accumulated by atomics); the path masks only when they are
     // OR-accumulated too (several splits, or no LDS staging)
-    const bool path_needs_zero = !lds_path || splits > 1;  // (windows write disjoint word ranges)
+    const bool path_needs_zero = splits > 1;  // (windows write disjoint word ranges)
     err = (int)hipMemsetAsync(ws.hit, 0, (size_t)n * mask_bytes, st);
     if (err) return err;
     if (path_needs_zero) {
@@ -1466,7 +1401,7 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
     // launch 1: hit mask.  chunks: enough workgroups to cover the chip several times.
     int chunks = (8 * 256 + n - 1) / n;
     chunks = chunks < 1 ? 1 : (chunks > 16 ? 16 : chunks);
-    const int hit_grid = env_groups * 8 * chunks * (lds_hit ? hit_windows : 1);
+    const int hit_grid = env_groups * 8 * chunks * hit_windows;
 #define GNBV_HIT(KF, WIN)                                                                                                            \
     do {                                                                                                                             \
         if (hit_lds > 64 * 1024 &&                                                                                                   \
@@ -1475,10 +1410,7 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
         hipLaunchKernelGGL((k_hit_mask<KF, WIN>), dim3(hit_grid), dim3(kHitThreads), hit_lds, st, depth_raw, seg_raw, c2w, K, range_gt, \
                            voxel_size, n, h, w, g, depth_sense_dist, chunks, words, ws.hit, hit_windows, hit_nw);                    \
     } while (0)
-    if (!lds_hit) {
-        hipLaunchKernelGGL(k_hit_mask_global, dim3(hit_grid), dim3(kHitThreads), 0, st, depth_raw, seg_raw, c2w, K,
-                           range_gt, voxel_size, n, h, w, g, depth_sense_dist, chunks, words, ws.hit);
-    } else if (hit_windows > 1) {
+    if (hit_windows > 1) {
         if (kfast) GNBV_HIT(true, true);
         else GNBV_HIT(false, true);
     } else {
@@ -1489,7 +1421,7 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
     err = gnbv_launch_status();
     if (err) return err;
     // launch 2: ray cast, N x splits (x windows) workgroups
-    const int ray_grid = env_groups * 8 * splits * (lds_path ? path_windows : 1);
+    const int ray_grid = env_groups * 8 * splits * path_windows;
 #define GNBV_RAY(WIN)                                                                                                                \
     do {                                                                                                                             \
         if (path_lds > 64 * 1024 &&                                                                                                  \
@@ -1498,10 +1430,7 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
         hipLaunchKernelGGL((k_raycast<true, WIN>), dim3(ray_grid), dim3(kRayThreads), path_lds, st, ws.hit, poses_xyz, poses_row_stride, \
                            range_gt, voxel_size, n, g, words, splits, ws.path, path_windows, path_nw);                               \
     } while (0)
-    if (!lds_path) {
-        hipLaunchKernelGGL((k_raycast<false, false>), dim3(ray_grid), dim3(kRayThreads), ray_fixed, st, ws.hit, poses_xyz,
-                           poses_row_stride, range_gt, voxel_size, n, g, words, splits, ws.path, 1, words);
-    } else if (path_windows > 1) {
+    if (path_windows > 1) {
         GNBV_RAY(true);
     } else {
         GNBV_RAY(false);
@@ -1610,27 +1539,6 @@ static int update_packed_range(const float *depth_raw, const float *seg_raw, con
     return gnbv_launch_status();
 }
 
-// EXPERIMENT (GENNBV_VOXEL_CHAINS=2): the batch as two independent chains on two streams, so that the
-// HBM-bound grid update of one half overlaps the ALU-bound hit-mask / ray-cast launches of the other.
-struct VoxelSide {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    bool enabled = false, init = false;
-};
-static VoxelSide &voxel_side()
-{
-    static VoxelSide s;
-    if (!s.init) {
-        s.init = true;
-        const char *e = getenv("GENNBV_VOXEL_CHAINS");
-        if ((e && e[0] == '2') && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
-            hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess)
-            s.enabled = true;
-    }
-    return s;
-}
-
 GNBV_API int gnbv_update_occ_grid_packed(const float *depth_raw, const float *seg_raw, const float *c2w, const float *inv_intri,
                                          const float *poses_xyz, int64_t poses_row_stride, const float *range_gt,
                                          const float *voxel_size, const uint32_t *gt_bits, const uint8_t *reset_mask, int n,
@@ -1646,24 +1554,8 @@ GNBV_API int gnbv_update_occ_grid_packed(const float *depth_raw, const float *se
     GNBV_CHECK_ARG(workspace_bytes >= gnbv_voxel_workspace_bytes(n, g) && ((uintptr_t)workspace & 255) == 0);
     hipStream_t st = gnbv_stream(stream);
     VoxelWorkspace ws = carve(workspace, workspace_bytes, n, g, h, w);
-    VoxelSide &side = voxel_side();
-    if (!side.enabled || n < 16) {
-        return update_packed_range(depth_raw, seg_raw, c2w, inv_intri, poses_xyz, poses_row_stride, range_gt, voxel_size, gt_bits,
-                                   reset_mask, 0, n, h, w, g, depth_sense_dist, prob_grid, scanned_bits, tri_out, tri_row_stride,
-                                   coverage_count, ws, st);
-    }
-    const int n0 = ((n / 2) + 7) & ~7;  // halves on 8-env boundaries (XCD mapping)
-    if (hipEventRecord(side.fork, st) != hipSuccess || hipStreamWaitEvent(side.stream, side.fork, 0) != hipSuccess) return (int)hipGetLastError();
-    int err = update_packed_range(depth_raw, seg_raw, c2w, inv_intri, poses_xyz, poses_row_stride, range_gt, voxel_size, gt_bits,
-                                  reset_mask, 0, n0, h, w, g, depth_sense_dist, prob_grid, scanned_bits, tri_out, tri_row_stride,
-                                  coverage_count, ws, st);
-    if (err) return err;
-    err = update_packed_range(depth_raw, seg_raw, c2w, inv_intri, poses_xyz, poses_row_stride, range_gt, voxel_size, gt_bits,
-                              reset_mask, n0, n - n0, h, w, g, depth_sense_dist, prob_grid, scanned_bits, tri_out, tri_row_stride,
-                              coverage_count, ws, side.stream);
-    if (err) return err;
-    if (hipEventRecord(side.join, side.stream) != hipSuccess || hipStreamWaitEvent(st, side.join, 0) != hipSuccess) return (int)hipGetLastError();
-    return 0;
+    return update_packed_range(depth_raw, seg_raw, c2w, inv_intri, poses_xyz, poses_row_stride, range_gt, voxel_size, gt_bits, reset_mask, 0,
+                               n, h, w, g, depth_sense_dist, prob_grid, scanned_bits, tri_out, tri_row_stride, coverage_count, ws, st);
 }
 
 // host helper: the two 256-entry tables of the coded probability grid, by the exact fp32 iteration of the reference

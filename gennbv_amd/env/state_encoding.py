@@ -61,7 +61,7 @@ class OccupancyGridUpdater:
         # Coded probability grid (1 byte per voxel, exact): only when the GT is binary (packed mode) and the caller
         # guarantees that no voxel sees more than 127 path steps between two resets (episode length <= 127).
         self.coded = bool(self.packed and max_steps_between_resets is not None and 0 < int(max_steps_between_resets) <= 127
-                          and os.environ.get("GENNBV_PROB_CODED", "1") != "0")
+                          )
         if self.coded:
             import ctypes as C
             pl, tl = (C.c_float * 256)(), (C.c_float * 256)()
@@ -80,7 +80,7 @@ class OccupancyGridUpdater:
             return self._prob_f32
         if int(self.code_overflow.item()) != 0:
             raise _lib.GennbvHipError("coded probability grid: a voxel saw more than 127 path steps between resets "
-                                      "(pass a correct max_steps_between_resets or GENNBV_PROB_CODED=0)")
+                                      "(pass a correct max_steps_between_resets, or none: the fp32 probability grid is used then)")
         n, g = self.num_envs, self.grid_size
         out = torch.empty(n, g, g, g, dtype=torch.float32, device=self.device)
         _lib.check(self.lib.gnbv_decode_prob_grid(self.prob_code.data_ptr(), out.numel(), self._prob_lut.data_ptr(), out.data_ptr(),

@@ -56,7 +56,7 @@ class PPO_Grid_Obs:
                  tensorboard_log: Optional[str] = None, create_eval_env: bool = False,
                  policy_kwargs: Optional[Dict[str, Any]] = None, verbose: int = 0, seed: Optional[int] = None,
                  device: Union[torch.device, str] = "auto", _init_setup_model: bool = True, compact_obs: Optional[bool] = None):
-        """`compact_obs` (additive; default: env GENNBV_COMPACT_OBS, off): keep the tri-class grid of every stored
+        """`compact_obs` (additive, default off): keep the tri-class grid of every stored
         observation as int8 only (sb3/buffers.py `compact`) -- same values, 3.6x less HBM for the rollout buffer."""
         assert not use_sde, "gSDE is not on the GenNBV path"
         if normalize_advantage:
@@ -89,8 +89,8 @@ class PPO_Grid_Obs:
         self.kl_poll = "minibatch"
         self.train_impl = "hip"   # fused loss / flat Adam / device-side early stop when the encoder backend is "hip"
         self.use_graph = True     # replay the minibatch step as one hipGraph
-        self.grad_write_through = os.environ.get("GENNBV_WRITE_THROUGH", "1") != "0"  # backward kernels store into the flat gradient buffer (ops/direct_grad.py)
-        self.compact_obs = (os.environ.get("GENNBV_COMPACT_OBS", "0") == "1") if compact_obs is None else bool(compact_obs)
+        self.grad_write_through = True  # backward kernels store into the flat gradient buffer (ops/direct_grad.py)
+        self.compact_obs = bool(compact_obs)
         # Time-out bootstrap (on_policy_algorithm_grid_obs.py:205-208).  "reference": what the reference computes --
         # `predict_values(new_obs)[0]` is ROW 0 of the [N, 1] values, so every timed-out env is bootstrapped with env 0's
         # value (pinned by fixture F11).  "per_env": each env's own V(new_obs), SB3's evident intent (not the reference).
@@ -357,20 +357,13 @@ class PPO_Grid_Obs:
         from ..ops import encoder_ops
         from .policies import _IdentityExtractor
         enc = self.policy.features_extractor
-        self._hip["fused_head"] = (os.environ.get("GENNBV_FUSED_HEAD", "1") != "0" and getattr(enc, "backend", "") == "hip"
+        self._hip["fused_head"] = (getattr(enc, "backend", "") == "hip"
                                    and isinstance(self.policy.mlp_extractor, _IdentityExtractor)
                                    and encoder_ops.policy_head_supported(enc, self.policy.action_net, self.policy.value_net))
         # fc_grid's weight gradient on a second stream (only the optimizer needs it; joined in _hip_minibatch_body).  Only
         # without data parallelism: there phase A ends right behind it and the all-reduce needs it at once.
         if getattr(enc, "backend", "") == "hip":
-            enc.output_layer_grid[0]._async_wgrad = (bool(self.grad_write_through) and os.environ.get("GENNBV_ASYNC_WGRAD", "1") != "0"
-                                                     and (self._sync is None or not self._sync.active))
-        # EXPERIMENT (GENNBV_BWD_SIDE=1): conv2 weight gradient on the pose branch's stream beside the conv2 data gradient
-        if getattr(enc, "backend", "") == "hip" and self.device.type == "cuda":
-            from .. import _lib
-            on = os.environ.get("GENNBV_BWD_SIDE", "0") == "1" and (self._sync is None or not self._sync.active)
-            side = encoder_ops._side_stream(self.device, 0).cuda_stream if on else None
-            _lib.load().gnbv_encoder_set_backward_side_stream(side)
+            enc.output_layer_grid[0]._async_wgrad = bool(self.grad_write_through) and (self._sync is None or not self._sync.active)
         self._hip["skip_zero"] = bool(self.grad_write_through) and all(
             id(p) in covered for p in self.policy.parameters() if p.requires_grad)
         return self._hip
@@ -629,7 +622,7 @@ class PPO_Grid_Obs:
             from .policies import _IdentityExtractor
             enc = self.policy.features_extractor
             self.policy._fused_rollout = (
-                os.environ.get("GENNBV_FUSED_ROLLOUT", "1") != "0" and self.device.type == "cuda"
+                self.device.type == "cuda"
                 and getattr(enc, "backend", "") == "hip" and isinstance(self.policy.mlp_extractor, _IdentityExtractor)
                 and hasattr(self.policy.action_dist, "sample_and_log_prob")
                 and encoder_ops.policy_head_supported(enc, self.policy.action_net, self.policy.value_net))

@@ -170,11 +170,6 @@ int gnbv_env_obs_state(float *pose_hist, const float *poses, const uint8_t *rese
 int gnbv_env_obs_rgb(const uint8_t *rgba, float *gray_prev, const uint8_t *reset_mask, int n, int h, int w, int oh, int ow,
                      float *obs_rgb, int64_t obs_row_stride, void *stream);
 
-/* EXPERIMENT (off by default): a second stream of the caller's on which gnbv_encoder_grid_backward runs the conv2 weight
- * gradient beside the conv2 data gradient (fork / join events inside the call; capture-safe).  NULL switches it off.
- * No counterpart in the reference (torch autograd serialises the two: networks.py:73-96 backward). */
-int gnbv_encoder_set_backward_side_stream(void *stream);
-
 /* compute_reward (env_train_base.py:377-398), _reward_* / check_termination /
  * reset_idx (env_train_gennbv.py:377-457,535-556), update_extra_episode_info
  * (env_train_base.py:629-639). All pointers device, arrays [N] unless noted. [host struct] */

@@ -55,7 +55,7 @@ print(f"update_occ_grid: {ms:.4f} ms/step  -> {a.n / ms * 1e3:.0f} env-steps/s (
 
 if a.phase_times:
     import numpy as np
-    nwg = a.n * max(1, int(os.environ.get("GENNBV_HIT_CHUNKS", "0")) or (512 + a.n - 1) // a.n)
+    nwg = a.n * max(1, (512 + a.n - 1) // a.n)
     tail = upd.workspace.view(torch.int32)[-8 * nwg:].cpu().numpy().reshape(nwg, 8)
     pa, pb, rays, t0 = tail[:, 0] / 100.0, tail[:, 1] / 100.0, tail[:, 2], tail[:, 3] / 100.0
     print(f"k_hit_list phases over {nwg} workgroups (us): A mean {pa.mean():.1f} max {pa.max():.1f} | B mean {pb.mean():.1f} max {pb.max():.1f} | "
