@@ -28,10 +28,17 @@ __device__ __forceinline__ float4 ld4g(const float *p) { return *reinterpret_cas
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // blockIdx.y = slab of 128 rows (8 row-tiles, 2 per wave); rows >= M are clamped for the loads and never stored.
+//
+// The W tile of a trip (64 columns x 32 k = 8 KiB) is the SAME for the four waves of the workgroup: it is fetched once
+// (two 16-byte requests per lane), staged in LDS (double-buffered, one barrier per trip) and read back as MFMA operands with
+// ds_read_b128; only the x rows of a wave come straight from global memory.  With every wave loading W itself the workgroup
+// issued 48 vector-memory instructions per 64-MFMA trip = 47 B/clk per CU of the 64 B/clk the CU's address path moves: the
+// kernel ran at 46 % of the matrix pipe's rate (profiles/r02_notes.md).
 __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linear_splitk(
     const float *__restrict__ x /*[M][K]*/, const float *__restrict__ w /*[N][K]*/, int M, int N, int K, int nchunks,
     float *__restrict__ partial /*[nchunks][M][N]*/)
 {
+    __shared__ float4 s_b[2][2][4][4][17];  // [buffer][h: 16-k step of the trip][column tile][kq][column i (+1 pad: the staging stores of 8 lanes differ in kq)]: 2 x 8.5 KiB
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int i = lane & 15, kq = lane >> 4, mbase = blockIdx.y * 128;
     // block -> (chunk, N-tile): the N-tiles of one chunk sit on the same XCD (block b runs on XCD b % 8)
@@ -42,59 +49,83 @@ __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 
     if (chunk >= nchunks) return;
     const int nstep16 = (K + 15) / 16;  // 16-k steps
     const int s0 = (int)((int64_t)chunk * nstep16 / nchunks), s1 = (int)((int64_t)(chunk + 1) * nstep16 / nchunks);
-    const float *xr[kRowTilesPerWave], *wr[4];
+    const float *xr[kRowTilesPerWave];
 #pragma unroll
     for (int rt = 0; rt < kRowTilesPerWave; ++rt) xr[rt] = x + (size_t)min(mbase + (wv * kRowTilesPerWave + rt) * 16 + i, M - 1) * K + 4 * kq;
+    // W staging: thread t fetches, for r = 0, 1, the float4 W[col = 32 r + t / 8][k = trip k0 + 4 (t % 8) .. + 3]
+    // (8 threads = 128 contiguous bytes of one column) and stores it at s_b[buf][h = (t % 8) / 4][ct = col / 16][kq = t % 4][col % 16]
+    const int t8 = threadIdx.x & 7, tcol = threadIdx.x >> 3;
+    const float *wst[2];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) wr[ct] = w + (size_t)(nt * kTileN + ct * 16 + i) * K + 4 * kq;
+    for (int r = 0; r < 2; ++r) wst[r] = w + (size_t)(nt * kTileN + 32 * r + tcol) * K + 4 * t8;
     f32x4 acc[kRowTilesPerWave][4];
 #pragma unroll
     for (int rt = 0; rt < kRowTilesPerWave; ++rt)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // one trip = two 16-k steps (12 requests per lane, 64 MFMAs).  Requests are UNCONDITIONAL (clamped
-    // addresses past the chunk end): a branch around a request group makes the compiler's s_waitcnt
-    // insertion assume the worst case at the join and wait for the prefetched group as well.
-    auto request = [&](int s, float4 (&a)[2][kRowTilesPerWave], float4 (&b)[2][4]) {
+    // Requests are UNCONDITIONAL (clamped addresses past the chunk end): a branch around a request group makes the compiler's
+    // s_waitcnt insertion assume the worst case at the join and wait for the prefetched group as well.
+    auto request_a = [&](int s, float4 (&a)[2][kRowTilesPerWave]) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int kc = min(s + h, s1 - 1) * 16;
 #pragma unroll
             for (int rt = 0; rt < kRowTilesPerWave; ++rt) a[h][rt] = ld4g(xr[rt] + min(kc, K - 4 - 4 * kq));
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) b[h][ct] = ld4g(wr[ct] + min(kc, K - 4 - 4 * kq));
         }
     };
-    auto consume = [&](int s, float4 (&a)[2][kRowTilesPerWave], const float4 (&b)[2][4]) {
+    auto request_b = [&](int s, float4 (&b)[2]) {
+        const int kc = min(s + (t8 >> 2), s1 - 1) * 16 - 16 * (t8 >> 2);  // this thread's 16-k step of the trip, clamped to the chunk
+#pragma unroll
+        for (int r = 0; r < 2; ++r) b[r] = ld4g(wst[r] + min(kc, K - 4 - 4 * t8));
+    };
+    auto stage_b = [&](int buf, const float4 (&b)[2]) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) s_b[buf][t8 >> 2][2 * r + (tcol >> 4)][t8 & 3][tcol & 15] = b[r];
+    };
+    auto consume = [&](int s, int buf, float4 (&a)[2][kRowTilesPerWave]) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const bool ok = (s + h) < s1 && (s + h) * 16 + 4 * kq + 3 < K;  // past the chunk / past K: zeros
+            float4 b[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) b[ct] = s_b[buf][h][ct][kq][i];
 #pragma unroll
             for (int rt = 0; rt < kRowTilesPerWave; ++rt) {
                 if (!ok) a[h][rt] = zero4;
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) {
-                    acc[rt][ct] = mfma4(a[h][rt].x, b[h][ct].x, acc[rt][ct]);
-                    acc[rt][ct] = mfma4(a[h][rt].y, b[h][ct].y, acc[rt][ct]);
-                    acc[rt][ct] = mfma4(a[h][rt].z, b[h][ct].z, acc[rt][ct]);
-                    acc[rt][ct] = mfma4(a[h][rt].w, b[h][ct].w, acc[rt][ct]);
+                    acc[rt][ct] = mfma4(a[h][rt].x, b[ct].x, acc[rt][ct]);
+                    acc[rt][ct] = mfma4(a[h][rt].y, b[ct].y, acc[rt][ct]);
+                    acc[rt][ct] = mfma4(a[h][rt].z, b[ct].z, acc[rt][ct]);
+                    acc[rt][ct] = mfma4(a[h][rt].w, b[ct].w, acc[rt][ct]);
                 }
             }
         }
     };
-    float4 a0[2][kRowTilesPerWave], b0[2][4], a1[2][kRowTilesPerWave], b1[2][4];
     if (s0 >= s1) return;  // (never: nchunks <= number of steps)
-    request(s0, a0, b0);
+    float4 a0[2][kRowTilesPerWave], a1[2][kRowTilesPerWave], bq[2];
+    request_a(s0, a0);
+    request_b(s0, bq);
+    stage_b(0, bq);
+    __syncthreads();
+    int buf = 0;
     for (int s = s0; s < s1; s += 4) {
-        request(s + 2, a1, b1);
+        // trip s (a0, LDS buffer `buf`) while trip s + 2's operands are in flight; then trip s + 2 while s + 4's are
+        request_a(s + 2, a1);
+        request_b(s + 2, bq);
         __builtin_amdgcn_sched_barrier(0);
-        consume(s, a0, b0);
+        consume(s, buf, a0);
         __builtin_amdgcn_sched_barrier(0);
-        request(s + 4, a0, b0);
+        stage_b(buf ^ 1, bq);
+        __syncthreads();
+        request_a(s + 4, a0);
+        request_b(s + 4, bq);
         __builtin_amdgcn_sched_barrier(0);
-        consume(s + 2, a1, b1);
+        consume(s + 2, buf ^ 1, a1);
         __builtin_amdgcn_sched_barrier(0);
+        stage_b(buf, bq);
+        __syncthreads();
     }
     // D[i = 4 kq + r][j = lane & 15]: row = tile row 4 kq + r, column = tile column i
     float *out = partial + (size_t)chunk * M * N;

@@ -363,7 +363,8 @@ class PPO_Grid_Obs:
         # fc_grid's weight gradient on a second stream (only the optimizer needs it; joined in _hip_minibatch_body).  Only
         # without data parallelism: there phase A ends right behind it and the all-reduce needs it at once.
         if getattr(enc, "backend", "") == "hip":
-            enc.output_layer_grid[0]._async_wgrad = bool(self.grad_write_through) and (self._sync is None or not self._sync.active)
+            enc.output_layer_grid[0]._async_wgrad = (bool(self.grad_write_through) and getattr(self, "async_wgrad", True)
+                                                     and (self._sync is None or not self._sync.active))
         self._hip["skip_zero"] = bool(self.grad_write_through) and all(
             id(p) in covered for p in self.policy.parameters() if p.requires_grad)
         return self._hip
