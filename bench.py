@@ -132,9 +132,9 @@ def one_iteration(algo, phases):
 
 
 def cpu_baseline(args, cfg):
-    """The CPU port of the same path on the box's host cores, ALL of them: the oracle's state encoding (oracle/oracle.c,
-    OpenMP over the envs; proven equal to the reference on the goldens) + torch-CPU fp32 policy forward / GAE / PPO update
-    (torch's own thread pool) on a bounded sample of the workload -- 64 envs x 8 env steps at the full 240x320 / G
+    """The CPU port of the same path on the box's host cores: the oracle's state encoding (oracle/oracle.c, OpenMP, one
+    thread per env; proven equal to the reference on the goldens) + torch-CPU fp32 policy forward / GAE / PPO update
+    (torch's thread pool at the count that is fastest on the host) on a bounded sample of the workload -- 64 envs x 8 env steps at the full 240x320 / G
     geometry, then one PPO epoch over the 512 samples in minibatches of 128 (the remaining n_epochs - 1 epochs are scaled
     from it).  kind = "port": the reference itself cannot travel to the GPU box (it imports Isaac Gym / pycuda)."""
     import numpy as np
@@ -145,10 +145,15 @@ def cpu_baseline(args, cfg):
     from tests import policy_util as pu
 
     n, t_steps, mb = 64, 8, 128
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    host_cores = os.cpu_count() or 1
+    # thread counts that are actually fastest on the box (measured on the 256-core host of the pool: one minibatch
+    # forward + backward takes 0.60 / 0.53 / 0.62 / 0.98 s with 16 / 32 / 64 / 128 torch threads; with all 256 the epoch took
+    # 74 s instead of ~3): torch 32 threads, the oracle one thread per env
+    torch_threads = min(host_cores, 32)
+    torch.set_num_threads(torch_threads)
+    orc.lib().orc_set_num_threads(min(host_cores, n))
     omp_threads = int(orc.lib().orc_num_threads())
+    cores = max(torch_threads, omp_threads)
     scene = S.make_scenes(n, cfg.grid_size, seed=99)
     frames = S.make_frames(scene, cfg, 2, seed=99)  # two frames, alternated
     kinv = S.inverse_intrinsics(cfg.camera_height, cfg.camera_width)
@@ -190,7 +195,7 @@ def cpu_baseline(args, cfg):
         torch.nn.utils.clip_grad_norm_(pol.parameters(), 1.0); pol.optimizer.step()
     t_train = time.time() - t_train0
     total = t_rollout + args.n_epochs * t_train
-    return {"value": n * t_steps / total, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
+    return {"value": n * t_steps / total, "unit": "env-steps/s", "cores": int(cores), "host_cores": int(host_cores), "kind": "port",
             "sample": f"{n} envs x {t_steps} env steps at {cfg.camera_height}x{cfg.camera_width}, {cfg.grid_size}^3: oracle state "
                       f"encoding (OpenMP, {omp_threads} threads) + torch-CPU fp32 policy / GAE / PPO ({torch.get_num_threads()} threads; "
                       f"1 epoch of {n * t_steps // mb} minibatches of {mb} measured, x{args.n_epochs} epochs)",

@@ -45,7 +45,7 @@ SIGNATURES = {
     "gnbv_prob_code_tables": (None, [_p, _p]),
     "gnbv_decode_prob_grid": (_i, [_p, _i64, _p, _p, _p]),
     "gnbv_update_occ_grid_coded": (_i, [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _i64, _p,
-                                        _i64, _p, _p, _p, _sz, _p]),
+                                        _i64, _p, _p, _p, _sz, _i, _p]),
     "gnbv_env_pre_step": (_i, [_p, _p, _p, _i, _p, _p, _p]),
     "gnbv_env_obs_state": (_i, [_p, _p, _p, _p, _i, _i, _p, _i64, _p]),
     "gnbv_env_obs_rgb": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i64, _p]),

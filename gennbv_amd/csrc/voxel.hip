@@ -957,7 +957,8 @@ __device__ __forceinline__ uint32_t step_code(uint32_t c, bool hit, bool path, i
 // request is coalesced.  Either tri_out (fp32 observation rows) or tri_i8 (compact rows) may be NULL, not both.
 template <int VPL>
 __global__ __launch_bounds__(kGridThreads) void k_grid_update_coded(
-    const uint32_t *__restrict__ hit_mask, const uint32_t *__restrict__ path_mask, const uint32_t *__restrict__ gt_bits,
+    uint32_t *hit_mask, uint32_t *path_mask /*(not restrict: cleared in passing when `clean`)*/, int clean, int32_t *ray_count,
+    const uint32_t *__restrict__ gt_bits,
     const uint8_t *__restrict__ reset_mask, int n, int g3, int words, int words_gt, uint8_t *__restrict__ prob_code,
     const float *__restrict__ tri_lut, uint32_t *__restrict__ scanned_bits, float *__restrict__ tri_out, int64_t tri_stride,
     int8_t *__restrict__ tri_i8, int64_t tri_i8_stride, int32_t *__restrict__ coverage, int32_t *__restrict__ overflow)
@@ -968,7 +969,10 @@ __global__ __launch_bounds__(kGridThreads) void k_grid_update_coded(
     __syncthreads();
     const int e = blockIdx.y;
     const bool reset = reset_mask != nullptr && reset_mask[e] != 0;
-    const uint32_t *hm = hit_mask + (size_t)e * words, *pm = path_mask + (size_t)e * words;
+    uint32_t *hm = hit_mask + (size_t)e * words, *pm = path_mask + (size_t)e * words;
+    // `clean`: the masks and the ray count are left ZERO for the next call (the word's owner lane clears it after every lane
+    // that shares the word -- neighbours in the same wave, same instruction -- has loaded it): saves the 16 MB fill launch
+    if (clean && ray_count != nullptr && blockIdx.x == 0 && threadIdx.x == 0) ray_count[e] = 0;
     const uint32_t *gb = gt_bits + (size_t)e * words_gt;
     uint32_t *sb = scanned_bits + (size_t)e * words_gt;
     uint8_t *code = prob_code + (size_t)e * g3;
@@ -1017,6 +1021,7 @@ __global__ __launch_bounds__(kGridThreads) void k_grid_update_coded(
                 const uint32_t sw = (reset ? 0u : sb[wd]) | (hw & gb[wd]);
                 sb[wd] = sw;
                 cov += __popc(sw);
+                if (clean) { hm[wd] = 0u; pm[wd] = 0u; }
             }
         }
     } else {
@@ -1032,6 +1037,7 @@ __global__ __launch_bounds__(kGridThreads) void k_grid_update_coded(
                 const uint32_t sw = (reset ? 0u : sb[wd]) | (hw & gb[wd]);
                 sb[wd] = sw;
                 cov += __popc(sw);
+                if (clean) { hm[wd] = 0u; pm[wd] = 0u; }
             }
         }
     }
@@ -1327,8 +1333,9 @@ GNBV_API int gnbv_grid_tri_cls(const float *grid_prob, int64_t count, float thre
 static int launch_masks(const float *depth_raw, const float *seg_raw, const float *c2w, const float *inv_intri,
                         const float *poses_xyz, int64_t poses_row_stride, const float *range_gt, const float *voxel_size, int n,
                         int h, int w, int g, float depth_sense_dist, int32_t *coverage_count, const VoxelWorkspace &ws,
-                        hipStream_t st)
+                        hipStream_t st, bool masks_are_zero = false, bool *used_lists = nullptr)
 {
+    if (used_lists) *used_lists = false;
     Intrinsics K;
     int err = fetch_intrinsics(inv_intri, st, &K);
     if (err) return err;
@@ -1356,8 +1363,11 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
         // resident beside the first -- 512 workgroups ran as two rounds, profiles/r02_notes.md.)
         int fchunks = (512 + n - 1) / n;
         fchunks = fchunks < 1 ? 1 : (fchunks > 16 ? 16 : fchunks);
+        if (used_lists) *used_lists = true;
         // one fill: [hit (only when OR-accumulated) | path | ray counts] are adjacent for the full env range
-        if (ws.path == ws.hit + (size_t)n * words && (void *)ws.ray_count == (void *)(ws.path + (size_t)n * words)) {
+        if (masks_are_zero) {
+            // (the previous call's grid-update launch left masks and counts zero: GNBV_VOXEL_WS_CLEAN)
+        } else if (ws.path == ws.hit + (size_t)n * words && (void *)ws.ray_count == (void *)(ws.path + (size_t)n * words)) {
             uint32_t *z0 = fchunks > 1 ? ws.hit : ws.path;
             const size_t zb = (size_t)((char *)(ws.ray_count + ray_count_ints(n)) - (char *)z0);
             if ((err = (int)hipMemsetAsync(z0, 0, zb, st))) return err;
@@ -1587,7 +1597,7 @@ GNBV_API int gnbv_update_occ_grid_coded(const float *depth_raw, const float *seg
                                         int h, int w, int g, float depth_sense_dist, uint8_t *prob_code, const float *tri_lut,
                                         uint32_t *scanned_bits, float *tri_out, int64_t tri_row_stride, int8_t *tri_i8,
                                         int64_t tri_i8_row_stride, int32_t *coverage_count, int32_t *overflow, void *workspace,
-                                        size_t workspace_bytes, void *stream)
+                                        size_t workspace_bytes, int workspace_flags, void *stream)
 {
     GNBV_CHECK_ARG(depth_raw && seg_raw && c2w && inv_intri && poses_xyz && range_gt && voxel_size && gt_bits);
     GNBV_CHECK_ARG(prob_code && tri_lut && scanned_bits && (tri_out || tri_i8) && coverage_count && workspace);
@@ -1597,9 +1607,12 @@ GNBV_API int gnbv_update_occ_grid_coded(const float *depth_raw, const float *seg
     GNBV_CHECK_ARG(workspace_bytes >= gnbv_voxel_workspace_bytes(n, g) && ((uintptr_t)workspace & 255) == 0);
     hipStream_t st = gnbv_stream(stream);
     VoxelWorkspace ws = carve(workspace, workspace_bytes, n, g, h, w);
+    const bool clean = (workspace_flags & GNBV_VOXEL_WS_CLEAN) != 0;
+    bool lists = false;
     int err = launch_masks(depth_raw, seg_raw, c2w, inv_intri, poses_xyz, poses_row_stride, range_gt, voxel_size, n, h, w, g,
-                           depth_sense_dist, coverage_count, ws, st);
+                           depth_sense_dist, coverage_count, ws, st, clean, &lists);
     if (err) return err;
+    const int leave_clean = (clean && lists) ? 1 : 0;  // (the two-launch mask kernels zero what they need themselves)
     GNBV_CHECK_ARG(tri_i8 == nullptr || tri_i8_row_stride >= g3);
     const bool vec4 = (g3 % 4 == 0) && (tri_out == nullptr || ((tri_row_stride % 4 == 0) && (((uintptr_t)tri_out & 15) == 0))) &&
                       (((uintptr_t)prob_code & 3) == 0) && (tri_i8 == nullptr || ((((uintptr_t)tri_i8 | (uintptr_t)tri_i8_row_stride) & 3) == 0));
@@ -1608,7 +1621,7 @@ GNBV_API int gnbv_update_occ_grid_coded(const float *depth_raw, const float *seg
     const int vpl = vec16 ? 16 : vec4 ? 4 : 1;
     const int bx = grid_update_blocks(g3 / vpl, n);
 #define GNBV_LAUNCH_CODED(V)                                                                                                          \
-    hipLaunchKernelGGL(k_grid_update_coded<V>, dim3(bx, n), dim3(kGridThreads), 0, st, ws.hit, ws.path, gt_bits, reset_mask, n, (int)g3, \
+    hipLaunchKernelGGL(k_grid_update_coded<V>, dim3(bx, n), dim3(kGridThreads), 0, st, ws.hit, ws.path, leave_clean, ws.ray_count, gt_bits, reset_mask, n, (int)g3, \
                        ws.words, ws.words, prob_code, tri_lut, scanned_bits, tri_out, tri_row_stride, tri_i8, tri_i8_row_stride,        \
                        coverage_count, overflow)
     if (vpl == 16) GNBV_LAUNCH_CODED(16);

@@ -55,7 +55,11 @@ class OccupancyGridUpdater:
         self.coverage_count = torch.zeros(num_envs, dtype=torch.int32, device=self.device)
         nbytes = self.lib.gnbv_voxel_workspace_bytes_hw(num_envs, g, self.h, self.w)  # masks + per-env ray lists
         # torch's caching allocator returns >=512-byte aligned blocks
-        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        # coded update: the grid-update launch clears the masks / ray counts it consumed, so no fill launch per step
+        # (GNBV_VOXEL_WS_CLEAN).  Switch off BEFORE the first update to keep the masks of the last step for `masks()`.
+        self.self_clean = True
+        self._ws_dirty = False
         assert self.workspace.data_ptr() % 256 == 0
         self._own_tri = None
         # Coded probability grid (1 byte per voxel, exact): only when the GT is binary (packed mode) and the caller
@@ -122,7 +126,10 @@ class OccupancyGridUpdater:
                 self.prob_code.data_ptr(), self._tri_lut.data_ptr(), self.scanned_bits.data_ptr(), _lib.ptr(tri_out),
                 int(tri_row_stride or 0), _lib.ptr(tri_i8_out), 0 if tri_i8_out is None else int(tri_i8_out.stride(0)),
                 self.coverage_count.data_ptr(), self.code_overflow.data_ptr(), self.workspace.data_ptr(),
-                self.workspace.numel(), _lib.stream_ptr(self.device)), "gnbv_update_occ_grid_coded")
+                self.workspace.numel(), 1 if (self.self_clean and not self._ws_dirty) else 0, _lib.stream_ptr(self.device)),
+                "gnbv_update_occ_grid_coded")
+            if not self.self_clean:
+                self._ws_dirty = True  # (a call without the flag leaves the masks in place: never claim "clean" again)
             return tri_out
         if self.packed:
             _lib.check(self.lib.gnbv_update_occ_grid_packed(
@@ -155,7 +162,10 @@ class OccupancyGridUpdater:
         return out
 
     def masks(self):
-        """(hit, path) bool [N,G,G,G] of the last update (parity / debugging)."""
+        """(hit, path) bool [N,G,G,G] of the last update (parity / debugging).  The self-cleaning coded update leaves no masks
+        behind: set `self_clean = False` before the update whose masks are wanted."""
+        if self.coded and self.self_clean:
+            raise _lib.GennbvHipError("masks(): the coded update cleared its masks (self_clean); set self_clean = False first")
         n, g = self.num_envs, self.grid_size
         hit = torch.empty(n, g, g, g, dtype=torch.uint8, device=self.device)
         path = torch.empty_like(hit)

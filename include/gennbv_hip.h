@@ -94,6 +94,11 @@ size_t gnbv_voxel_workspace_bytes(int n, int g);
  * (csrc/voxel.hip: k_hit_list, k_ray_list); with the smaller mask-only workspace it falls back to k_hit_mask + k_raycast.
  * Same results either way. */
 size_t gnbv_voxel_workspace_bytes_hw(int n, int g, int h, int w);
+/* gnbv_update_occ_grid_coded, workspace_flags: the caller guarantees that the two mask arrays and the ray counts of the
+ * workspace are ZERO on entry -- freshly zero-initialised, or left so by the previous call made with this flag -- and the
+ * call leaves them zero (its grid-update launch clears every word it consumes): the 16 MB fill launch per call goes away.
+ * Do not set it on a workspace that another entry point (or a call without the flag) has used since. */
+#define GNBV_VOXEL_WS_CLEAN 1
 
 int gnbv_update_occ_grid(const float *depth_raw, const float *seg_raw, const float *c2w,
                          const float *inv_intri /*[host] [3,3]*/,
@@ -139,7 +144,8 @@ int gnbv_update_occ_grid_coded(const float *depth_raw, const float *seg_raw, con
                                int8_t *tri_i8 /*NULL, or the tri-class grid as int8 rows (-1/0/1): row e at tri_i8 + e*stride;
                                                 at least one of tri_out / tri_i8 must be given*/,
                                int64_t tri_i8_row_stride /*bytes*/, int32_t *coverage_count,
-                               int32_t *overflow /*[1] device or NULL*/, void *workspace, size_t workspace_bytes, void *stream);
+                               int32_t *overflow /*[1] device or NULL*/, void *workspace, size_t workspace_bytes,
+                               int workspace_flags /* GNBV_VOXEL_WS_* */, void *stream);
 
 
 /* ------------------------------------------------------------------------- */

@@ -410,6 +410,16 @@ ORC_API void orc_gae_rsl(const float *rewards, const float *values, const uint8_
 
 ORC_API int orc_abi_version(void) { return 1; }
 
+/* number of OpenMP threads for orc_update_occ_grid (ignored without OpenMP) */
+ORC_API void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* threads orc_update_occ_grid uses (1 without OpenMP) */
 ORC_API int orc_num_threads(void)
 {

@@ -51,6 +51,7 @@ def lib():
                                           C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_gae_sb3.argtypes = [_f32p, _f32p, _u8p, _f32p, _u8p, C.c_int, C.c_int, C.c_double, C.c_double,
                                   _f32p, _f32p]
         L.orc_gae_rsl.argtypes = [_f32p, _f32p, _u8p, _f32p, C.c_int, C.c_int, C.c_double, C.c_double, _f32p, _f32p]

@@ -70,6 +70,11 @@ def _run_sequence(n, h, w, g, steps, seed, reset_at=(), pose_override=None, pack
     upd = OccupancyGridUpdater(n, g, h, w, kinv, scene.range_gt, scene.voxel_size, scene.grid_gt, DEV, packed=packed,
                                max_steps_between_resets=max_steps)
     assert upd.coded == (max_steps is not None)
+    # the coded update clears its masks in passing (self_clean): every second sequence keeps them instead and compares them
+    # with the oracle's; the self-cleaning ones are checked through the grids of the FOLLOWING steps (a left-over bit would
+    # show up there)
+    keep_masks = (seed % 2 == 0) or not upd.coded
+    upd.self_clean = not keep_masks
     prob = np.zeros((n, g, g, g), np.float32)
     scan = np.zeros_like(prob)
     rs = np.random.RandomState(seed)
@@ -94,9 +99,10 @@ def _run_sequence(n, h, w, g, steps, seed, reset_at=(), pose_override=None, pack
         else:
             tri = upd.update(f.depth_raw.to(DEV), f.seg_raw.to(DEV), c2w.to(DEV), f.poses.to(DEV).contiguous(),
                              reset_mask=None if reset is None else torch.from_numpy(reset).to(DEV))
-        hit, path = upd.masks()
-        assert np.array_equal(hit.cpu().numpy(), hit_o), f"step {s}: hit mask differs"
-        assert np.array_equal(path.cpu().numpy(), path_o), f"step {s}: path mask differs"
+        if keep_masks:
+            hit, path = upd.masks()
+            assert np.array_equal(hit.cpu().numpy(), hit_o), f"step {s}: hit mask differs"
+            assert np.array_equal(path.cpu().numpy(), path_o), f"step {s}: path mask differs"
         assert upd.prob_grid.cpu().numpy().tobytes() == prob.tobytes(), f"step {s}: prob grid differs"
         assert upd.scanned_gt_grid.cpu().numpy().tobytes() == scan.tobytes(), f"step {s}"
         assert tri.cpu().numpy().tobytes() == tri_o.tobytes(), f"step {s}"
@@ -208,6 +214,7 @@ def test_full_size_properties_config1():
     scene = S.make_scenes(n, g, seed=3, device=DEV)
     f = S.make_frames(scene, cfg, 1, seed=3, with_rgba=False)[0]
     upd = OccupancyGridUpdater(n, g, h, w, S.inverse_intrinsics(h, w), scene.range_gt, scene.voxel_size, scene.grid_gt, DEV)
+    upd.self_clean = False  # (the masks are inspected)
     c2w = S.c2w_from_view(f.view, scene.env_origins)
     tri1 = upd.update(f.depth_raw, f.seg_raw, c2w, f.poses.contiguous()).clone()
     hit, path = upd.masks()

@@ -11,6 +11,7 @@ scene=S.make_scenes(n,g,seed=1,device=dev)
 frames=S.make_frames(scene,cfg,4,seed=1,with_rgba=False)
 upd=OccupancyGridUpdater(n,g,h,w,S.inverse_intrinsics(h,w),scene.range_gt,scene.voxel_size,scene.grid_gt,dev,max_steps_between_resets=100)
 t8=torch.zeros(n,g**3,dtype=torch.int8,device=dev)
+upd.self_clean=False
 f=frames[0]
 upd.update(f.depth_raw,f.seg_raw,S.c2w_from_view(f.view,scene.env_origins),f.poses.contiguous(),tri_i8_out=t8,fp32_out=False)
 hit,path=upd.masks()

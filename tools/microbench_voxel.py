@@ -19,6 +19,7 @@ ap.add_argument("--out", default="i8", choices=["f32", "f32+i8", "i8"],
                 help="tri-class output: fp32 rows (flat observations), fp32 + int8 copy, or int8 rows only (compact observations, "
                      "coded update; the bench default)")
 ap.add_argument("--phase-times", action="store_true", help="experiment builds (-DPHASE_TIMING): per-workgroup phase times of k_hit_list")
+ap.add_argument("--no-self-clean", action="store_true", help="coded update with the per-step mask fill (A/B against the self-cleaning masks)")
 a = ap.parse_args()
 if a.prob != "coded":
     a.out = "f32"
@@ -34,9 +35,13 @@ kw = dict(tri_i8_out=t8, fp32_out=a.out != "i8") if t8 is not None else {}
 print("tri-class output:", a.out)
 c2ws = [S.c2w_from_view(f.view, scene.env_origins) for f in frames]
 poses = [f.poses.contiguous() for f in frames]
+upd.self_clean = False  # (the masks of the warm-up steps are read for the statistics line)
 for i in range(5):
     upd.update(frames[i % a.frames].depth_raw, frames[i % a.frames].seg_raw, c2ws[i % a.frames], poses[i % a.frames], **kw)
 hit, path = upd.masks()
+if not a.no_self_clean:
+    upd.self_clean, upd._ws_dirty = True, False
+    upd.workspace.zero_()  # back to the self-cleaning mode for the timed loop
 print("fg frac", float((frames[0].seg_raw > 50).float().mean()), "hit voxels/env", float(hit.flatten(1).sum(1).float().mean()),
       "path voxels/env", float(path.flatten(1).sum(1).float().mean()), "max hit/env", int(hit.flatten(1).sum(1).max()),
       "max path/env", int(path.flatten(1).sum(1).max()))
