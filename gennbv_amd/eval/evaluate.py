@@ -14,8 +14,11 @@ from .metrics import auc_update, mean_auc
 
 
 def evaluate_policy_grid_obs(model, env, n_eval_episodes: int = 10, deterministic: bool = True, return_AUC: bool = True,
-                             max_length: Optional[int] = None, accuracy_fn: Optional[Callable] = None):
-    """-> (episode_rewards, episode_lengths, mean_AUC [n_envs] or None, episode_accuracies)."""
+                             max_length: Optional[int] = None, accuracy_fn: Optional[Callable] = None,
+                             callback: Optional[Callable] = None):
+    """-> (episode_rewards, episode_lengths, mean_AUC [n_envs] or None, episode_accuracies).
+    `callback(locals, globals)` is called once per env step for every env still being counted, with the reference's
+    local names `i`, `reward`, `done`, `info` (evaluation.py:291-307; `info` is the shared infos dict of a tensor env)."""
     n_envs = env.num_envs
     max_length = int(max_length if max_length is not None else env.max_episode_length)
     targets = torch.tensor([(n_eval_episodes + i) // n_envs for i in range(n_envs)], dtype=torch.int64)
@@ -36,12 +39,17 @@ def evaluate_policy_grid_obs(model, env, n_eval_episodes: int = 10, deterministi
             actions, _, _ = policy(obs, deterministic=deterministic)  # == model.predict(obs, deterministic)
         out = env.step(actions)
         obs, rewards, dones = out[0], out[1].detach().float().cpu(), out[2].detach().cpu()
+        infos = out[3] if len(out) > 3 else {}
         accuracies = out[4] if len(out) > 4 else None
         if return_AUC and step <= max_length:
             auc = auc_update(auc, rewards, step, dones, done_flag)
         cur_r += rewards
         cur_l += 1
         live = counts < targets
+        if callback is not None:
+            for i in torch.nonzero(live).flatten().tolist():
+                info = infos if isinstance(infos, dict) else infos[i if n_envs == 1 else 0]
+                callback(dict(i=i, reward=rewards[i], done=dones[i], info=info, infos=infos, rewards=rewards, dones=dones), globals())
         done_flag += (dones.bool() & live).float()
         for i in torch.nonzero(dones.bool() & live).flatten().tolist():
             ep_r.append(float(cur_r[i]))

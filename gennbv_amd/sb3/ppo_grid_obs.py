@@ -716,6 +716,28 @@ class PPO_Grid_Obs:
         self.env.episode_length_buf = torch.randint_like(elb, high=int(self.env.max_episode_length))
         return total_timesteps
 
+    def get_env(self):
+        return self.env
+
+    def get_vec_normalize_env(self):
+        return None  # tensor envs are never wrapped in VecNormalize (base_class_grid_obs.py:511-518)
+
+    def _init_callback(self, callback, eval_env=None, eval_freq: int = 10000, n_eval_episodes: int = 5, log_path: Optional[str] = None):
+        """base_class_grid_obs.py:370-406: a list becomes a CallbackList, a function a ConvertCallback, an `eval_env`
+        adds an EvalCallback_Grid_Obs; the callback tree is bound to this model."""
+        from ..callback import BaseCallback, CallbackList, ConvertCallback, EvalCallback_Grid_Obs
+        if callback is None and eval_env is None:
+            return None
+        if isinstance(callback, list):
+            callback = CallbackList(callback)
+        if not isinstance(callback, BaseCallback):
+            callback = ConvertCallback(callback)
+        if eval_env is not None:
+            callback = CallbackList([callback, EvalCallback_Grid_Obs(eval_env, best_model_save_path=log_path, log_path=log_path,
+                                                                      eval_freq=eval_freq, n_eval_episodes=n_eval_episodes)])
+        callback.init_callback(self)
+        return callback
+
     def _update_current_progress_remaining(self, num_timesteps: int, total_timesteps: int) -> None:
         self._current_progress_remaining = 1.0 - float(num_timesteps) / float(total_timesteps)
 
@@ -725,6 +747,7 @@ class PPO_Grid_Obs:
         """on_policy_algorithm_grid_obs.py:230-298."""
         iteration = 0
         total_timesteps = self._setup_learn(total_timesteps, reset_num_timesteps)
+        callback = self._init_callback(callback, eval_env, eval_freq, n_eval_episodes, eval_log_path)
         if callback is not None:
             callback.on_training_start(locals(), globals())
         while self.num_timesteps < total_timesteps:

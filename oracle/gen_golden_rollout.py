@@ -9,6 +9,7 @@ TEST INFRASTRUCTURE ONLY.   python oracle/gen_golden_rollout.py
                (bootstrap :205-208 -- NOTE the `[0]`: every env is bootstrapped with env 0's value), the final
                predict_values (:213-217), GAE.  Stored: the feed, every observation row (packed), the sampled actions,
                the env's raw rewards / dones / time_outs, and every rollout-buffer array.
+  F14_eval_callback  f3  `EvalCallback_Grid_Obs` (stable_baselines3/common/callbacks.py:473-708) driven over a scripted env
   F12_eval     f3  `evaluate_policy_grid_obs` + `AUC_update` (stable_baselines3/common/evaluation.py:136-378) over a
                scripted 50-env 5-tuple env and a scripted model.predict: episode rewards / lengths / accuracies in
                the order the reference emits them and the mean-AUC vector.
@@ -218,14 +219,126 @@ def gen_eval(ref):
     print("F12_eval saved; episodes", len(ep_r), "steps", calls["t"])
 
 
+def evalcb_script():
+    """The scripted eval env of F14 (shared by the generator and tests/test_eval_cpu.py through the fixture's arrays)."""
+    n_envs, steps = 50, 30
+    rs = np.random.RandomState(21)
+    rewards = rs.rand(steps, n_envs).astype(np.float32)
+    first_done = rs.randint(2, steps + 1, size=n_envs)
+    dones = np.zeros((steps, n_envs), np.int64)
+    for i in range(n_envs):
+        dones[first_done[i] - 1, i] = 1
+    acc = rs.rand(steps, n_envs).astype(np.float32)
+    # one reward scale per evaluation: new bests at evaluations 0, 2, 5 (3 repeats 2's value: not strictly better)
+    scales = np.array([1.0, 0.6, 1.3, 1.3, 0.9, 2.0, 0.5], np.float32)
+    success_from = 2  # infos carries "is_success" from this evaluation on
+    return n_envs, steps, rewards, dones, acc, scales, success_from
+
+
+def gen_evalcb(ref):
+    """F14: the reference's own EvalCallback_Grid_Obs (stable_baselines3/common/callbacks.py:473-708) driven for 21
+    on_step() calls at eval_freq = 3 over a scripted 50-env eval env: what it records, dumps, saves and returns."""
+    import importlib
+    import tempfile
+    cbm = importlib.import_module("stable_baselines3.common.callbacks")
+    n_envs, steps, rewards, dones, acc, scales, success_from = evalcb_script()
+    st = {"t": 0, "k": -1}
+
+    class Env:
+        num_envs = n_envs
+
+        def env_is_wrapped(self, cls):
+            return [False]
+
+        def reset(self):
+            st["t"] = 0
+            st["k"] += 1
+            return torch.zeros(n_envs, 4), torch.zeros(n_envs), torch.zeros(n_envs), {}, {}
+
+        def step(self, actions):
+            t, k = st["t"], st["k"]
+            st["t"] += 1
+            infos = {"episode": {}}
+            if k >= success_from:
+                infos["is_success"] = float((t + k) % 3 == 0)
+            return (torch.full((n_envs, 4), float(t + 1)), torch.from_numpy(rewards[t] * scales[k]), torch.from_numpy(dones[t]), infos,
+                    {str(i): float(acc[t, i]) for i in range(n_envs)})
+
+    log = {"records": [], "dumps": [], "saves": []}
+
+    class Logger:
+        def record(self, key, value, exclude=None):
+            log["records"].append((key, float(value), "" if exclude is None else str(exclude)))
+
+        def dump(self, step=0):
+            log["dumps"].append(int(step))
+
+    class Model:
+        num_timesteps = 0
+        logger = Logger()
+
+        def get_env(self):
+            return Env()
+
+        def get_vec_normalize_env(self):
+            return None
+
+        def predict(self, observations, state=None, deterministic=True):
+            return torch.zeros(n_envs, 6, dtype=torch.long), None
+
+        def save(self, path):
+            log["saves"].append((os.path.basename(path), int(self.num_timesteps)))
+
+    class Count(cbm.BaseCallback):
+        def __init__(self, stop_at=None):
+            super().__init__()
+            self.stop_at, self.seen = stop_at, []
+
+        def _on_step(self):
+            self.seen.append(int(self.num_timesteps))
+            return not (self.stop_at is not None and len(self.seen) == self.stop_at)
+
+    ev = ref.evaluation
+    ev.is_vecenv_wrapped = lambda env, cls: False
+    cbm.sync_envs_normalization = lambda a, b: None
+    import warnings
+    with tempfile.TemporaryDirectory() as d, warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        on_best, after = Count(), Count(stop_at=5)
+        cb = cbm.EvalCallback_Grid_Obs(Env(), callback_on_new_best=on_best, callback_after_eval=after, n_eval_episodes=n_envs, eval_freq=3,
+                                       log_path=os.path.join(d, "log"), best_model_save_path=os.path.join(d, "best"), verbose=0)
+        st["k"] = -1
+        model = Model()
+        cb.init_callback(model)
+        rets = []
+        for c in range(21):
+            model.num_timesteps += n_envs
+            rets.append(bool(cb.on_step()))
+        z = np.load(os.path.join(d, "log", "evaluations.npz"))
+        npz = {k: np.asarray(z[k]) for k in z.files}
+        assert on_best.parent is cb and after.parent is cb
+    keys = sorted({r[0] for r in log["records"]})
+    out = dict(n_envs=n_envs, steps=steps, rewards=rewards, dones=dones, accuracies=acc, scales=scales, success_from=success_from,
+               eval_freq=3, n_calls=21, returns=np.array(rets), record_keys=np.array([r[0] for r in log["records"]]),
+               record_values=np.array([r[1] for r in log["records"]], np.float64), record_exclude=np.array([r[2] for r in log["records"]]),
+               dumps=np.array(log["dumps"], np.int64), save_names=np.array([s[0] for s in log["saves"]]),
+               save_timesteps=np.array([s[1] for s in log["saves"]], np.int64), on_best_seen=np.array(on_best.seen, np.int64),
+               after_seen=np.array(after.seen, np.int64), best_mean_reward=float(cb.best_mean_reward), last_mean_reward=float(cb.last_mean_reward),
+               **{"npz_" + k: v for k, v in npz.items()})
+    np.savez_compressed(os.path.join(GOLDEN, "F14_eval_callback.npz"), **out)
+    print("F14_eval_callback saved; keys", keys, "saves", log["saves"], "returns", rets, "npz", {k: v.shape for k, v in npz.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
     from build_ref import build as build_ref
     build_ref()
     ref = ref_harness.import_reference()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["rollout", "eval"]
+    which = sys.argv[1:] or ["rollout", "eval", "evalcb"]
     if "rollout" in which:
         gen_rollout(ref)
     if "eval" in which:
         gen_eval(ref)
+    if "evalcb" in which:
+        gen_evalcb(ref)
