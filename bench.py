@@ -405,7 +405,7 @@ def main():
                    "breakdown_ms_per_step": {"rollout": phases["rollout"].total_ms() / args.steps,
                                              "train": phases["train"].total_ms() / args.steps,
                                              "voxel_update_total": vox.total_ms() / args.steps}},
-        "roofline": {"bound": "hbm", "kernel": "gnbv_update_occ_grid_coded (k_hit_list + k_ray_list + k_grid_update_coded + one mask fill; 1-byte coded probability grid)",
+        "roofline": {"bound": "hbm", "kernel": "gnbv_update_occ_grid_coded (k_hit_list + k_ray_list + k_grid_update_coded, which also clears the masks it consumed; 1-byte coded probability grid)",
                      "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                      "launch_ms": vox_ms, "algorithmic_bytes_per_launch": args.envs * b_lay,
                      "bytes_basis": "this layout's compulsory HBM bytes (depth + seg, 1-byte code R+W, int8 tri-class W, 7 bitmask passes, ray lists)",
