@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libgennbv_hip.so")
 SOURCES = ["voxel.hip", "gae.hip", "envstep.hip", "encoder.hip", "linear.hip", "head.hip", "chamfer.hip", "ppo.hip"]
-HEADERS = ["common.h", os.path.join("..", "..", "include", "gennbv_hip.h")]
+HEADERS = ["common.h", "conv_split.h", os.path.join("..", "..", "include", "gennbv_hip.h")]
 ARCH = "gfx950"
 
 

@@ -693,6 +693,8 @@ __global__ __launch_bounds__(kFwdThreads) void k_conv2_fwd_lds(
 }
 
 
+#include "conv_split.h"
+
 // ---------------------------------------------------------------------------
 // BatchNorm bookkeeping.  sums [2][16] come from k_reduce_partials.
 //   train: mean / biased var from (sum, sumsq); running stats updated with the UNBIASED var
@@ -2089,13 +2091,15 @@ GNBV_API size_t gnbv_encoder_workspace_bytes(int batch, int grid)
     // weight-gradient partials (kWgradWaves x 6928 floats), fp64 reduction scratch
     const size_t bn = (size_t)(batch + 8) * o1 * kEncWaves * 2 * kC * sizeof(float);
     const size_t wg = (size_t)2048 * (kTaps * 256 + kC) * sizeof(float);
-    return bn + wg + (8192 + (size_t)64 * (kTaps * 256 + kC)) * sizeof(double) + 2 * kTaps * 256 * sizeof(float) + 4096;
+    return bn + wg + (8192 + (size_t)64 * (kTaps * 256 + kC)) * sizeof(double) + 2 * kTaps * 256 * sizeof(float) +
+           2 * 14 * 2 * 64 * 16 /*split f16 weight images*/ + 4096;
 }
 
 struct EncWs {
     float *bn_part, *wg_part;
     double *red, *tmp;
     float *w2img;  // 2 x 6912 floats
+    uint4 *w2split;  // 2 x split::kW2ImgU4 (conv_split.h)
 };
 static inline EncWs enc_carve(void *ws, int batch, int grid)
 {
@@ -2106,6 +2110,7 @@ static inline EncWs enc_carve(void *ws, int batch, int grid)
     w.red = (double *)(((uintptr_t)(w.wg_part + (size_t)2048 * (kTaps * 256 + kC)) + 255) & ~(uintptr_t)255);
     w.tmp = w.red + 8192;
     w.w2img = (float *)(w.tmp + (size_t)64 * (kTaps * 256 + kC));
+    w.w2split = (uint4 *)(w.w2img + 2 * kTaps * 256);
     return w;
 }
 
@@ -2137,6 +2142,13 @@ static inline bool conv2_fwd_lds_path(int O1, int O2)
 {
     const char *e = getenv("GENNBV_CONV2_LDS");
     return e && e[0] == '1' && O2 <= 15 && (O1 + 1) / 2 <= 16;
+}
+// conv2 kernels on the f16 matrix pipe with split (hi + lo) operands, staged through LDS (conv_split.h): fp32 y1 in the default
+// x-parity layout, 16 voxel slots per half row (G = 64)
+static inline bool conv_split_path(const GnbvEncoderParams *p, int grid)
+{
+    const int O1 = out_size(grid), O2 = out_size(O1);
+    return !env_off("GENNBV_CONV_SPLIT") && !p->act_bf16 && (O1 + 1) / 2 == 16 && O2 <= 15;
 }
 static inline bool fused_path(const GnbvEncoderParams *p, int grid)
 {
@@ -2282,10 +2294,21 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     if ((err = gnbv_launch_status())) return err;
     }
     // conv2 (BN1 + ReLU on load; + BN2 statistics).  Its LDS weight images were written by the conv1 kernel in passing.
-    const int g2 = sample_plane_group_grid(batch, O2, kPlanesPerGroup);
+    int g2 = sample_plane_group_grid(batch, O2, kPlanesPerGroup);
     if (p->act_bf16) {
         hipLaunchKernelGGL(k_conv2_fwd<ActBF16>, dim3(g2), dim3(kFwdThreads), 0, st, (const uint16_t *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
                        training ? w.bn_part : nullptr);
+    } else if (!z1 && !qm && conv_split_path(p, grid)) {
+        hipLaunchKernelGGL(k_prep_w2_split, dim3((split::kKSteps * 64 + 255) / 256), dim3(256), 0, st, p->w2, w.w2split, w.w2split + split::kW2ImgU4);
+        g2 = sample_plane_group_grid(batch, O2, split::kNP);
+        static bool attr_split = false;
+        if (!attr_split) {
+            const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_fwd_split, hipFuncAttributeMaxDynamicSharedMemorySize, split::kLdsBytes);
+            if (e != hipSuccess) return (int)e;
+            attr_split = true;
+        }
+        hipLaunchKernelGGL(k_conv2_fwd_split, dim3(g2), dim3(split::kThreads), split::kLdsBytes, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2,
+                           (const uint4 *)w.w2split, p->b2, y2, training ? w.bn_part : nullptr);
     } else if (z1) {
         hipLaunchKernelGGL((k_conv2_fwd<ActF32, true>), dim3(g2), dim3(kFwdThreads), 0, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
                        training ? w.bn_part : nullptr);

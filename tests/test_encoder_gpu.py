@@ -27,13 +27,45 @@ def _obs(b, g, seed=0):
     return o.to(DEV)
 
 
-@pytest.mark.parametrize("conv2_lds", ["0", "1"])
+def _obs_clear_of_the_relu_threshold(ref, b, g):
+    """The seeded observation batch, re-drawn (seed + 1, ...) until no BatchNorm-2 output of the fp64 reference lies within
+    1e-5 of the ReLU threshold.  Such a knife-edge element flips its mask on ANY fp32 rounding difference (two correct fp32
+    kernels land on opposite sides) and, at a batch of 4, one flip moves the conv / BN gradients by 1e-3 of their scale --
+    measured at seed 64: element (3, 5, 2, 13, 1) sits at +-6e-8."""
+    seen = {}
+    bn2 = ref.features_extractor.naive_encoder_grid[4]
+    h = bn2.register_forward_hook(lambda mod, inp, out: seen.__setitem__("min", float(out.detach().abs().min())))
+    try:
+        for seed in range(g, g + 16):
+            obs = _obs(b, g, seed=seed)
+            ref.set_training_mode(True)
+            stats = {k: v.clone() for k, v in ref.state_dict().items() if "running" in k or "num_batches" in k}
+            with torch.no_grad():
+                ref.features_extractor(obs.cpu().double())
+            ref.load_state_dict(stats, strict=False)  # (the probe must not advance the running statistics)
+            if seen["min"] >= 1e-5 or b > 16 or g > 64:  # (large batches / grids always hold such elements and dilute them)
+                return obs
+    finally:
+        h.remove()
+    raise AssertionError("no clean seed")
+
+
+@pytest.mark.parametrize("conv2_lds", ["0", "1", "split"])
 @pytest.mark.parametrize("g,b", [(20, 8), (16, 5), (33, 3), (64, 4), (128, 1), (64, 128)])  # last: the bench's minibatch
 def test_encoder_forward_backward_vs_torch_reference(g, b, conv2_lds, monkeypatch):
     """Reference = the same torch modules in fp64 on the CPU (ground truth), tolerance = fp32 round-off.
     (torch-GPU fp32 is NOT used as the reference: MIOpen's conv/BN backward is off by 0.7-4.6 % at
     G=64 against fp64, tools/check_conv_grads.py; the hand-written kernels are within 1e-6.)
-    conv2_lds = "1": the opt-in LDS-staged conv2 forward (k_conv2_fwd_lds; G <= 66, else the default kernel runs)."""
+    conv2_lds = "1": the opt-in LDS-staged conv2 forward (k_conv2_fwd_lds; G <= 66, else the default kernel runs).
+    conv2_lds = "split": the conv2 kernels on the f16 matrix pipe with split (hi + lo) operands (csrc/conv_split.h; G = 64) --
+    SAME tolerances as the fp32 kernels."""
+    if conv2_lds == "split":
+        if g != 64:
+            pytest.skip("the split kernels cover G = 64 (16 voxel slots per half row)")
+        monkeypatch.setenv("GENNBV_CONV_SPLIT", "1")
+        conv2_lds = "0"
+    else:
+        monkeypatch.setenv("GENNBV_CONV_SPLIT", "0")
     if conv2_lds == "1" and g > 66:
         pytest.skip("k_conv2_fwd_lds covers O2 <= 15 only")
     if conv2_lds == "1" and b > 64:
@@ -43,7 +75,7 @@ def test_encoder_forward_backward_vs_torch_reference(g, b, conv2_lds, monkeypatc
     ref, _, _ = pu.make_policy(g=g, device="cpu", backend="torch", det_weights=True)
     ref = ref.double()
     ref.extract_features = lambda x: ref.features_extractor(x)  # keep fp64 (no .float() cast)
-    obs = _obs(b, g, seed=g)
+    obs = _obs_clear_of_the_relu_threshold(ref, b, g)
     actions = torch.stack([torch.randint(0, n, (b,)) for n in pu.NVEC], -1).float()
     w = torch.linspace(0.5, 1.5, b)
     outs = []
@@ -219,7 +251,7 @@ def test_bf16_activation_storage_within_bf16_tolerance(g, b):
     ref, _, _ = pu.make_policy(g=g, device="cpu", backend="torch", det_weights=True)
     ref = ref.double()
     ref.extract_features = lambda x: ref.features_extractor(x)
-    obs = _obs(b, g, seed=g)
+    obs = _obs_clear_of_the_relu_threshold(ref, b, g)
     actions = torch.stack([torch.randint(0, n, (b,)) for n in pu.NVEC], -1).float()
     w = torch.linspace(0.5, 1.5, b)
     outs = []
