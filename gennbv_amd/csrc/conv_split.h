@@ -30,7 +30,10 @@ constexpr int kStageBytes = kNPl * kRing * kRowBytes;
 constexpr int kPadBytes = 64;                        // a voxel: lane m = 15 (a padding output) of tap dx = 2 reads one voxel past its row
 constexpr int kSlots = (2 * kNPl * 128 + kProdThreads - 1) / kProdThreads;  // 16-byte requests per staging thread and step (2 rows x 9 planes): 4.5 -> 5
 constexpr int kRedBytes = 2 * kNP * 1024;            // k-half partial tiles, double-buffered by step parity
+constexpr int kDyBytes = 2 * kNP * 1024;             // staged dy2 rows: [step parity][plane][hi | lo][16 voxels][16 channels] f16
+constexpr int kGradBits = 14;                        // gradients are scaled so that their largest magnitude lies in [2^13, 2^14)
 constexpr int kLdsBytes = kStageBytes + kPadBytes + kRedBytes;
+constexpr int kWgLdsBytes = kStageBytes + kPadBytes + kDyBytes;
 constexpr int kKSteps = 14, kKHalf = 7;                          // 27 taps (+ one zero tap) x 16 channels / 32
 constexpr float kZScale = 256.0f, kWScale = 1024.0f, kZMax = 65000.0f;
 constexpr int kW2ImgU4 = kKSteps * 2 * 64;           // uint4 per image: [k-step][hi | lo][lane]
@@ -72,6 +75,76 @@ __global__ void k_prep_w2_split(const float *__restrict__ W2, uint4 *__restrict_
     }
 }
 
+// The staging role shared by the split kernels: one of 512 threads (8 waves) that move the two new input rows of an iteration
+// (rows 2j+1, 2j+2 of the workgroup's <= 9 input planes, 36 KiB of fp32 y1) through registers into the LDS ring as f16 hi | lo
+// planes of z1 = 2^8 relu(bn1(y1)).  Request k of a thread: region rs = 4 k + (wave >> 1) = 2 plane + (row & 1 ^ 1), the 16-byte
+// piece `within` of that 2 KiB row.  Everything that selects a request is wave-uniform and the requests are UNCONDITIONAL
+// (clamped into the sample): a branch around a load makes the compiler wait for every load at the join.
+struct ZStager {
+    const float *ybase;
+    uint32_t rowC, planeC, st_lane;
+    int npl, O1, half;  // half = staging wave >> 1
+    bool pad_voxel;     // this thread's piece belongs to the padding voxel (x parity 1, slot 15) of its row
+    float sc[4], sh[4];
+    __device__ __forceinline__ void init(const float *y1, const float *scale1, const float *shift1, int b, int oz0, int npl_, int O1_, int ptid, int pw)
+    {
+        const int q = ptid & 3;
+        const uint32_t within = ptid & 127;                                   // 16-byte piece inside a 2 KiB row
+        st_lane = (within >> 6) * 1024 + ((within >> 2) & 15) * 32 + q * 8;   // its 8 hi bytes in the LDS row
+        pad_voxel = (within >> 6) == 1 && ((within >> 2) & 15) == 15;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            sc[s] = scale1[4 * q + s] * split::kZScale;
+            sh[s] = shift1[4 * q + s] * split::kZScale;
+        }
+        npl = npl_, O1 = O1_, half = pw >> 1;
+        rowC = 2 * 16 * kC, planeC = rowC * O1;  // floats per input row (both parities, 16 voxel slots each) / plane
+        ybase = y1 + ((size_t)b * O1 + 2 * oz0) * planeC + within * 4;
+    }
+    __device__ __forceinline__ void load(float4 (&regs)[split::kSlots], int j) const
+    {
+#pragma unroll
+        for (int k = 0; k < split::kSlots; ++k) {
+            const int rs = 4 * k + half, pi = min(rs >> 1, npl - 1), row = min(max(2 * j + 1 + (rs & 1), 0), O1 - 1);
+            regs[k] = *reinterpret_cast<const float4 *>(ybase + (uint32_t)pi * planeC + (uint32_t)row * rowC);
+        }
+    }
+    // ZERO_PAD: the padding voxel is stored as 0 instead of whatever the (never written) y1 slot holds -- needed where an
+    // operand built from it meets a zero of the other operand (0 x NaN), not where it only feeds a discarded output row
+    template <bool ZERO_PAD>
+    __device__ __forceinline__ void store(char *stage, const float4 (&regs)[split::kSlots], int j) const
+    {
+        using namespace split;
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) {
+            const int rs = 4 * k + half, pi = rs >> 1, row = 2 * j + 1 + (rs & 1);
+            if (rs >= 2 * kNPl) continue;            // (the half-empty last slot; wave-uniform, no request inside)
+            const int slot = (row + kRing) % kRing;  // (rows outside the sample land in ring slots nobody reads any more)
+            float z[4] = {__builtin_amdgcn_fmed3f(fmaf(sc[0], regs[k].x, sh[0]), 0.f, kZMax), __builtin_amdgcn_fmed3f(fmaf(sc[1], regs[k].y, sh[1]), 0.f, kZMax),
+                          __builtin_amdgcn_fmed3f(fmaf(sc[2], regs[k].z, sh[2]), 0.f, kZMax), __builtin_amdgcn_fmed3f(fmaf(sc[3], regs[k].w, sh[3]), 0.f, kZMax)};
+            h4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 a, c2;
+                split2(ZERO_PAD && pad_voxel ? 0.0f : z[e], a, c2);
+                hi[e] = a;
+                lo[e] = c2;
+            }
+            char *dst = stage + (pi * kRing + slot) * kRowBytes + st_lane;
+            *reinterpret_cast<h4 *>(dst) = hi;
+            *reinterpret_cast<h4 *>(dst + 512) = lo;
+        }
+    }
+};
+// one barrier per step.  (sched_barrier: the scheduler must not hoist the NEXT step's register-only transform, and with it the
+// wait for its requests, above this step's barrier; lgkmcnt only: the prefetched requests stay in flight)
+__device__ __forceinline__ void split_step_barrier()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // ---------------------------------------------------------------------------
 // conv2 forward.  Workgroup = 16 waves = (sample, 4 output planes), one per CU (100 KiB of LDS), walking the 15 output rows.
 //   waves 8-15 (staging): per step the two NEW input rows of the 9 input planes (36 KiB of y1) are requested two steps ahead
@@ -100,57 +173,13 @@ __global__ __launch_bounds__(split::kThreads) void k_conv2_fwd_split(
     const int np = oz1 - oz0, npl = 2 * np + 1;
     float s_sum = 0.0f, s_sq = 0.0f;
     const int nsteps = (O2 + 2) & ~1;  // O2 compute steps + the deferred epilogue of the last row, rounded up to even
-    // (sched_barrier: the scheduler must not hoist the NEXT step's register-only transform, and with it the wait for its
-    // requests, above this step's barrier)
-    auto step_barrier = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    };
+    auto step_barrier = [&]() { split_step_barrier(); };
     if (wv >= kConsWaves) {
         // ---- staging waves ----
-        const int ptid = tid - kConsWaves * kWave, pw = wv - kConsWaves;
-        const int q = ptid & 3;
-        const uint32_t within = ptid & 127;                                                  // 16-byte piece inside a 2 KiB row
-        const uint32_t st_lane = (within >> 6) * 1024 + ((within >> 2) & 15) * 32 + q * 8;   // its 8 hi bytes in the LDS row
-        float sc[4], sh[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            sc[s] = scale1[4 * q + s] * kZScale;
-            sh[s] = shift1[4 * q + s] * kZScale;
-        }
-        const uint32_t rowC = 2 * 16 * kC, planeC = rowC * O1;  // floats per input row (both parities, 16 voxel slots each) / plane
-        const float *ybase = y1 + ((size_t)b * O1 + 2 * oz0) * planeC + within * 4;
-        // request k of iteration j: region rs = 4 k + (pw >> 1) = 2 pi + rsel -> (plane pi, row 2j+1+rsel)  (wave-uniform; clamped
-        // into the sample: UNCONDITIONAL requests -- a branch around a load makes the compiler wait for every load at the join)
-        auto load_iter = [&](float4 (&regs)[kSlots], int j) {
-#pragma unroll
-            for (int k = 0; k < kSlots; ++k) {
-                const int rs = 4 * k + (pw >> 1), pi = min(rs >> 1, npl - 1), row = min(max(2 * j + 1 + (rs & 1), 0), O1 - 1);
-                regs[k] = *reinterpret_cast<const float4 *>(ybase + (uint32_t)pi * planeC + (uint32_t)row * rowC);
-            }
-        };
-        auto store_iter = [&](const float4 (&regs)[kSlots], int j) {
-#pragma unroll
-            for (int k = 0; k < kSlots; ++k) {
-                const int rs = 4 * k + (pw >> 1), pi = rs >> 1, row = 2 * j + 1 + (rs & 1);
-                if (rs >= 2 * kNPl) continue;            // (the half-empty last slot; wave-uniform, no request inside)
-                const int slot = (row + kRing) % kRing;  // (rows outside the sample: see the loop below)
-                const float z0 = __builtin_amdgcn_fmed3f(fmaf(sc[0], regs[k].x, sh[0]), 0.f, kZMax);
-                const float z1 = __builtin_amdgcn_fmed3f(fmaf(sc[1], regs[k].y, sh[1]), 0.f, kZMax);
-                const float z2 = __builtin_amdgcn_fmed3f(fmaf(sc[2], regs[k].z, sh[2]), 0.f, kZMax);
-                const float z3 = __builtin_amdgcn_fmed3f(fmaf(sc[3], regs[k].w, sh[3]), 0.f, kZMax);
-                h4 hi, lo;
-                _Float16 a, c2;
-                split2(z0, a, c2); hi[0] = a; lo[0] = c2;
-                split2(z1, a, c2); hi[1] = a; lo[1] = c2;
-                split2(z2, a, c2); hi[2] = a; lo[2] = c2;
-                split2(z3, a, c2); hi[3] = a; lo[3] = c2;
-                char *dst = stage + (pi * kRing + slot) * kRowBytes + st_lane;
-                *reinterpret_cast<h4 *>(dst) = hi;
-                *reinterpret_cast<h4 *>(dst + 512) = lo;
-            }
-        };
+        ZStager zs;
+        zs.init(y1, scale1, shift1, b, oz0, npl, O1, tid - kConsWaves * kWave, wv - kConsWaves);
+        auto load_iter = [&](float4 (&regs)[kSlots], int j) { zs.load(regs, j); };
+        auto store_iter = [&](const float4 (&regs)[kSlots], int j) { zs.store<false>(stage, regs, j); };
         float4 ra[kSlots], rb[kSlots];
         load_iter(ra, -1);
         load_iter(rb, 0);
@@ -251,4 +280,173 @@ __global__ __launch_bounds__(split::kThreads) void k_conv2_fwd_split(
         }
     }
     write_partials(partials, kWaves, wv, s_sum, s_sq);
+}
+
+
+// ---------------------------------------------------------------------------
+// conv2 weight gradient: dW2[tap][ci][co] = sum over output voxels of z1[input voxel(tap)][ci] * dy2[voxel][co]  (+ the bias
+// gradient, sum of dy2).  Same workgroup, ring and staging waves as the forward; the contraction now runs over VOXELS, and both
+// operands sit in LDS voxel-major ([voxel][16 channels]), so both reach the MFMA through the transposing LDS read
+// `ds_read_b64_tr_b16`: with lane l reading the 8 bytes at l * 8 of a 512-byte [16 voxels][16 channels] block, lane (n = l & 15,
+// g = l >> 4) receives channel n of voxels 4g .. 4g+3 -- four consecutive k of column n.  A k-block of 32 = two such blocks (the
+// rows of two output planes), i.e. two reads per operand half.
+//   MFMA: i = ci (A = z1 transposed), j = co (B = dy2), k = 32 output voxels; D -> partial[tap][ci][co] as the fp32 kernels.
+//   waves 0-7: every tap belongs to ONE wave (tap = wave + 8 i: four taps for waves 0-2, three for the rest; wave 7 also sums dy2
+//       for the bias gradient with a ones operand), so the accumulators live in registers for the whole kernel and there is no
+//       cross-wave reduction: 2 k-blocks x (4 reads + taps x (4 reads + 3 MFMA)) per step;
+//   waves 8-15: stage z1 as in the forward (the padding voxel zeroed: it meets dy2's zero padding) and the step's dy2 rows
+//       (4 planes x 15 voxels x 16 channels, scaled by 2^s and split; voxel 15 and missing planes are zeros).
+// dy2 is a gradient: its magnitude is unknown at compile time and f16's exponent range is narrow, so k_bn2_bwd_apply leaves
+// max |dy2| (atomicMax on the bit pattern) and the kernels scale by the power of two that puts it in [2^13, 2^14).
+// ---------------------------------------------------------------------------
+typedef short s4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ h8 tr_pair(const char *p0, const char *p1)
+{
+    typedef __attribute__((address_space(3))) s4v *lds_s4;
+    const s4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)p0), b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)p1);
+    typedef short s8v __attribute__((ext_vector_type(8)));
+    const s8v r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return *reinterpret_cast<const h8 *>(&r);
+}
+__device__ __forceinline__ float grad_scale(const unsigned *absmax)
+{
+    unsigned bits = absmax[(threadIdx.x & 63) * 32];  // 64 slots (k_bn2_bwd_apply); every lane ends with the maximum
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, d, 64));
+    const float amax = __uint_as_float(bits);
+    int e = 0;
+    (void)frexpf(amax, &e);  // amax = f 2^e, f in [0.5, 1)
+    return amax > 0.0f && amax < 3.0e38f ? ldexpf(1.0f, split::kGradBits - e) : 1.0f;
+}
+
+__global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_split(
+    const float *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1, const float *__restrict__ dy2 /*[B,O2^3,16]*/,
+    const unsigned *__restrict__ absmax, int B, int O1, int O2, float *__restrict__ partial /*[grid][27 * 256 + 16]*/)
+{
+    using namespace split;
+    extern __shared__ __attribute__((aligned(16))) char split_lds[];
+    char *stage = split_lds, *dyst = split_lds + split::kStageBytes + kPadBytes;
+    int b, oz0, oz1;
+    const bool live = sample_plane_group(B, O2, kNP, b, oz0, oz1);
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+    constexpr int E2 = kTaps * 256 + kC;
+    float *out = partial + (size_t)blockIdx.x * E2;
+    if (!live) {
+        for (int i = tid; i < E2; i += kThreads) out[i] = 0.0f;
+        return;
+    }
+    // (stale LDS may hold NaN patterns; the ring is read one voxel past a row and, in the first steps, next to slots not yet written)
+    for (int i = tid; i < kWgLdsBytes / 16; i += kThreads) reinterpret_cast<uint4 *>(split_lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const int np = oz1 - oz0, npl = 2 * np + 1, P2 = O2 * O2 * O2;
+    const int nsteps = (O2 + 1) & ~1;
+    const float gs = grad_scale(absmax);
+    if (wv >= kConsWaves) {
+        // ---- staging waves ----
+        const int ptid = tid - kConsWaves * kWave, pw = wv - kConsWaves;
+        ZStager zs;
+        zs.init(y1, scale1, shift1, b, oz0, npl, O1, ptid, pw);
+        // dy2: thread -> (plane, voxel, channel quad) of the step's rows; the upper four waves request a duplicate they never store
+        const int dpl = (ptid >> 6) & 3, dpiece = ptid & 63, dvox = dpiece >> 2;
+        const bool dvalid = dpl < np && dvox < O2;
+        const float *dsrc = dy2 + ((size_t)b * P2 + (size_t)(oz0 + min(dpl, np - 1)) * O2 * O2 + min(dvox, O2 - 1)) * kC + 4 * (dpiece & 3);
+        auto load_iter = [&](float4 (&regs)[kSlots], float4 &d, int j) {
+            zs.load(regs, j);
+            d = *reinterpret_cast<const float4 *>(dsrc + (size_t)min(max(j, 0), O2 - 1) * O2 * kC);
+        };
+        auto store_iter = [&](const float4 (&regs)[kSlots], const float4 &d, int j) {
+            zs.store<true>(stage, regs, j);
+            if (pw < 4) {
+                const float v[4] = {d.x, d.y, d.z, d.w};
+                h4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 a, c2;
+                    split2(dvalid ? v[e] * gs : 0.0f, a, c2);
+                    hi[e] = a;
+                    lo[e] = c2;
+                }
+                char *dst = dyst + ((j & 1) * kNP + dpl) * 1024 + dpiece * 8;
+                *reinterpret_cast<h4 *>(dst) = hi;
+                *reinterpret_cast<h4 *>(dst + 512) = lo;
+            }
+        };
+        float4 ra[kSlots], rb[kSlots], da, db;
+        load_iter(ra, da, -1);
+        load_iter(rb, db, 0);
+        store_iter(ra, da, -1);
+        load_iter(ra, da, 1);
+        store_iter(rb, db, 0);
+        load_iter(rb, db, 2);
+        split_step_barrier();
+        for (int t = 1; t <= nsteps; t += 2) {  // (branch-free around the requests: see the forward kernel)
+            store_iter(ra, da, t);
+            load_iter(ra, da, t + 2);
+            split_step_barrier();
+            store_iter(rb, db, t + 1);
+            load_iter(rb, db, t + 3);
+            split_step_barrier();
+        }
+    } else {
+        // ---- compute waves ----
+        const int n = lane & 15, g = lane >> 4, cw = wv;
+        const int ntaps = cw < 3 ? 4 : 3;
+        uint32_t tapbase[4];
+        int tapdy[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tp = min(cw + 8 * i, kTaps - 1), dz = tp / 9, dy = (tp / 3) % 3, dx = tp % 3;
+            tapbase[i] = (uint32_t)(dz * kRing * kRowBytes + (dx == 1 ? 1024 : 0) + (dx == 2 ? 32 : 0)) + lane * 8;
+            tapdy[i] = dy;
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        h8 ones;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = (_Float16)1.0f;
+        split_step_barrier();
+        for (int t = 1; t <= nsteps; ++t) {
+            const int oy = t - 1;
+            if (oy < O2) {
+                uint32_t rowoff[3];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) rowoff[dy] = (uint32_t)(((2 * oy + dy) % kRing) * kRowBytes);
+                const char *dybuf = dyst + (oy & 1) * kNP * 1024 + lane * 8;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    if (2 * kb < np) {  // (np = 3: the second block's missing plane is staged as zeros)
+                        const h8 bh = tr_pair(dybuf + (2 * kb) * 1024, dybuf + (2 * kb + 1) * 1024);
+                        const h8 bl = tr_pair(dybuf + (2 * kb) * 1024 + 512, dybuf + (2 * kb + 1) * 1024 + 512);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            if (i < ntaps) {
+                                const uint32_t off = tapbase[i] + (tapdy[i] == 0 ? rowoff[0] : tapdy[i] == 1 ? rowoff[1] : rowoff[2]);
+                                const char *a0 = stage + (2 * (2 * kb)) * kRing * kRowBytes + off, *a1 = a0 + 2 * kRing * kRowBytes;
+                                const h8 ah = tr_pair(a0, a1), al = tr_pair(a0 + 512, a1 + 512);
+                                acc[i] = mfma_h(ah, bh, acc[i]);
+                                acc[i] = mfma_h(al, bh, acc[i]);
+                                acc[i] = mfma_h(ah, bl, acc[i]);
+                            }
+                        }
+                        if (cw == 7) {
+                            acc[3] = mfma_h(ones, bh, acc[3]);
+                            acc[3] = mfma_h(ones, bl, acc[3]);
+                        }
+                    }
+                }
+            }
+            split_step_barrier();
+        }
+        const float unscale = 1.0f / (kZScale * gs);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < ntaps) {
+                const int tp = cw + 8 * i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[tp * 256 + (4 * g + r) * kC + n] = acc[i][r] * unscale;
+            }
+        }
+        if (cw == 7 && g == 0) out[kTaps * 256 + n] = acc[3][0] * (1.0f / gs);
+    }
 }

@@ -890,8 +890,9 @@ __global__ __launch_bounds__(256) void k_bn2_bwd_reduce(const float *__restrict_
 }
 
 // sums over b of the [B][16][2] partials -> S[2][16] (fp64 accumulate)
-__global__ __launch_bounds__(256) void k_bn2_bwd_finalize(const float *__restrict__ partials, int B, double *__restrict__ S)
+__global__ __launch_bounds__(256) void k_bn2_bwd_finalize(const float *__restrict__ partials, int B, double *__restrict__ S, unsigned *__restrict__ absmax)
 {
+    if (threadIdx.x < 64) absmax[threadIdx.x * 32] = 0u;
     // 32 outputs (which, c) x 8 slices of b; fixed summation order
     __shared__ double sh[8][32];
     const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
@@ -914,13 +915,13 @@ __global__ __launch_bounds__(256) void k_bn2_bwd_finalize(const float *__restric
 __global__ __launch_bounds__(256) void k_bn2_bwd_apply(const float *__restrict__ dz2, const float *__restrict__ y2, const float *__restrict__ scale,
                                                       const float *__restrict__ shift, const float *__restrict__ mean,
                                                       const float *__restrict__ rstd, const double *__restrict__ S, double count, int P2,
-                                                      float *__restrict__ dy2)
+                                                      float *__restrict__ dy2, unsigned *__restrict__ absmax /*max |dy2| as bit patterns in 64 slots of 32 uints (zeroed by k_bn2_bwd_finalize)*/)
 {
     __shared__ float tile[64][kC + 1];
     const int tiles = (P2 + 63) / 64, b = blockIdx.x / tiles, pos0 = (blockIdx.x - b * tiles) * 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int pos = min(pos0 + lane, P2 - 1);
-    float yv[4], gv[4];
+    float yv[4], gv[4], amax = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const size_t i = ((size_t)b * kC + (wv + 4 * k)) * P2 + pos;
@@ -935,8 +936,21 @@ __global__ __launch_bounds__(256) void k_bn2_bwd_apply(const float *__restrict__
         const float xhat = (y - mean[c]) * rstd[c];
         const float m1 = (float)(S[c] / count), m2 = (float)(S[kC + c] / count);
         tile[lane][c] = scale[c] * (g - m1 - xhat * m2);
+        amax = fmaxf(amax, pos0 + lane < P2 ? fabsf(tile[lane][c]) : 0.0f);
     }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) amax = fmaxf(amax, __shfl_xor(amax, d, 64));
+    __shared__ float wmax[4];
+    if (lane == 0) wmax[wv] = amax;
     __syncthreads();
+    if (threadIdx.x == 0) {
+        // one atomic per workgroup, and only when it would raise the maximum: 27 000 workgroups on one address otherwise
+        // serialise (measured: this 18 us kernel took 312 us with an unconditional atomic per wave)
+        const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        const unsigned bits = __float_as_uint(m);  // (non-negative floats order like their bit patterns; NaN never passes m == m)
+        unsigned *slot = absmax + (blockIdx.x & 63) * 32;  // 64 slots, one cache line each
+        if (m == m && bits > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, bits);
+    }
     const int p = threadIdx.x >> 2, c4 = (threadIdx.x & 3) * 4;
     if (pos0 + p < P2)
         *reinterpret_cast<float4 *>(dy2 + ((size_t)b * P2 + pos0 + p) * kC + c4) =
@@ -2392,7 +2406,8 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
                        bn2 + 3 * kC, P2, w.bn_part);
     if ((err = gnbv_launch_status())) return err;
     double *S2 = w.red + 128;
-    hipLaunchKernelGGL(k_bn2_bwd_finalize, dim3(1), dim3(256), 0, st, w.bn_part, batch, S2);
+    unsigned *dy2_absmax = (unsigned *)(w.red + 2048);  // max |dy2| (bit patterns, 64 slots x 128 bytes): the gradient scale of the split kernels
+    hipLaunchKernelGGL(k_bn2_bwd_finalize, dim3(1), dim3(256), 0, st, w.bn_part, batch, S2, dy2_absmax);
     if ((err = gnbv_launch_status())) return err;
     const bool dp = p->world > 1 && p->sync_sum != nullptr && p->sync_buf != nullptr;
     if (dp && !(fused && !z1 && p->autocorr_global != nullptr && saved_total)) return (int)hipErrorInvalidValue;  // (see GnbvEncoderParams.world)
@@ -2403,7 +2418,7 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
         S2m = p->sync_buf + 2 * kC;
     }
     hipLaunchKernelGGL(k_bn2_bwd_apply, dim3(batch * ((P2 + 63) / 64)), dim3(256), 0, st, d_features, y2, bn2, bn2 + kC, bn2 + 2 * kC, bn2 + 3 * kC, S2m,
-                       (double)batch * P2 * (dp ? p->world : 1), P2, dy2_scratch);
+                       (double)batch * P2 * (dp ? p->world : 1), P2, dy2_scratch, dy2_absmax);
     if ((err = gnbv_launch_status())) return err;
     // ---- conv2 weight gradient: on the side stream, beside the data gradient ----
     // (running this kernel on a second stream beside the data gradient was measured slower: both are bound by the CU's
@@ -2412,7 +2427,18 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     int nrows2 = batch * O2 * O2;
     int wg_blocks = (nrows2 + kEncWaves - 1) / kEncWaves;
     wg_blocks = wg_blocks > 512 ? 512 : ((wg_blocks + 7) & ~7);
-    if (p->act_bf16) {
+    const bool split_bwd = !z1 && !qm && conv_split_path(p, grid);
+    if (split_bwd) {
+        static bool attr_wg = false;
+        if (!attr_wg) {
+            const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_wgrad_split, hipFuncAttributeMaxDynamicSharedMemorySize, split::kWgLdsBytes);
+            if (e != hipSuccess) return (int)e;
+            attr_wg = true;
+        }
+        wg_blocks = sample_plane_group_grid(batch, O2, split::kNP);
+        hipLaunchKernelGGL(k_conv2_wgrad_split, dim3(wg_blocks), dim3(split::kThreads), split::kWgLdsBytes, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch,
+                           (const unsigned *)dy2_absmax, batch, O1, O2, w.wg_part);
+    } else if (p->act_bf16) {
         hipLaunchKernelGGL(k_conv2_wgrad<ActBF16>, dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const uint16_t *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
                        w.wg_part);
     } else if (z1) {

@@ -110,7 +110,7 @@ def test_encoder_forward_backward_vs_torch_reference(g, b, conv2_lds, monkeypatc
     assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-6
 
 
-@pytest.mark.parametrize("z1", ["0", "1", "qm"])  # "qm": y1 stored quad-major (GENNBV_Y1_QM=1, opt-in layout of the same path)
+@pytest.mark.parametrize("z1", ["0", "1", "qm", "fp32"])  # "qm": y1 stored quad-major (GENNBV_Y1_QM=1, opt-in layout of the same path); "fp32": GENNBV_CONV_SPLIT=0, the fp32-MFMA conv2 kernels ("0" runs the split-f16 ones at G = 64)
 @pytest.mark.parametrize("g,b", [(16, 5), (32, 3), (48, 2), (64, 4), (128, 1), (64, 128)])  # last: the bench's minibatch
 def test_fused_dgrad_conv1_wgrad_vs_fp64_reference(g, b, z1, monkeypatch):
     """With the int8 grid rows present (G % 16 == 0) the backward runs k_conv2_dgrad_c1w: conv2 data gradient and conv1
@@ -122,6 +122,9 @@ def test_fused_dgrad_conv1_wgrad_vs_fp64_reference(g, b, z1, monkeypatch):
         pytest.skip("the full-minibatch case runs on the default and quad-major kernel sets")
     monkeypatch.setenv("GENNBV_Z1", "1" if z1 == "1" else "0")
     monkeypatch.setenv("GENNBV_Y1_QM", "1" if z1 == "qm" else "0")
+    monkeypatch.setenv("GENNBV_CONV_SPLIT", "0" if z1 == "fp32" else "1")
+    if z1 == "fp32" and g != 64:
+        pytest.skip("only G = 64 has split kernels to switch off")
     from gennbv_amd.ops.encoder_ops import RowGather, input_autocorr
     hip, _, _ = pu.make_policy(g=g, device=DEV, backend="hip", det_weights=True)
     ref, _, _ = pu.make_policy(g=g, device="cpu", backend="torch", det_weights=True)
