@@ -16,6 +16,7 @@
 //   activations z1 = relu(bn1(y1))  x 2^8   (clamped to 65000 / 2^8 = 253.9 -- unreachable for normalised activations)
 //   weights                        x 2^10  (|w| < 63.4)
 #pragma once
+#include <type_traits>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -449,4 +450,330 @@ __global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_split(
         }
         if (cw == 7 && g == 0) out[kTaps * 256 + n] = acc[3][0] * (1.0f / gs);
     }
+}
+
+
+// ---------------------------------------------------------------------------
+// conv2 data gradient + conv1 weight gradient (the fused backward, see k_conv2_dgrad_c1w in encoder.hip for the algebra and
+// the outputs: T1[32 taps][16], S1, S2 per workgroup).  Workgroup = 16 waves = (sample, 4 plane pairs of the layer-1 volume),
+// one per CU, walking the 16 row pairs c.  A step = the four 2 x 2 x 32-voxel super-tiles (a, c) of the workgroup.
+//   waves 8-15 (staging): the 16 y1 rows of the NEXT step (8 planes x 2 rows, 32 KiB, each read from global memory exactly once,
+//       contiguous 16-byte requests two steps ahead) go to LDS as fp32 with an 80-byte voxel stride -- the accumulator layout
+//       reads 4 voxels of one channel per lane, and 80 bytes keep the two lane halves of a 32-lane LDS access on different
+//       banks; the next dy2 row of the 5 output planes the workgroup touches goes to a 3-row ring as scaled f16 hi | lo
+//       planes [voxel][16 channels] with a zero voxel in front and behind (ox = -1, 15) -- out-of-range planes / rows are zeros.
+//   waves 0-7 (compute): wave = (plane pair, class set).  The eight parity classes (ez, ey, ex) of a super-tile need
+//       8 + 4 + 4 + 4 + 2 + 2 + 2 + 1 taps = 14 k-steps of two taps x 16 channels; set X = classes {000, 011, 101, 110} and
+//       set Y = {001, 010, 100, 111} hold 7 k-steps each (weights in registers: 2 x 7 fragments).  Per class: the k-steps'
+//       3 split MFMAs each, then the epilogue of the fp32 kernel unchanged -- ReLU mask and xhat from the staged y1, the
+//       channel sums, and the conv1 weight-gradient contraction T1 += x^T g on fp32 MFMAs with the int8 input slab
+//       (wave-private, requested one step ahead).
+// ---------------------------------------------------------------------------
+namespace dsplit {
+constexpr int kPairs = 4;
+constexpr int kYVox = 80, kYHalf = 16 * kYVox, kYRow = 2 * kYHalf, kYBuf = 2 * 2 * kPairs * kYRow;  // 40 960 per step buffer
+constexpr int kDyHalf = 18 * 32, kDyRow = 2 * kDyHalf, kDyPlanes = kPairs + 1, kDyRing = 3;
+constexpr int kDyBytes = kDyPlanes * kDyRing * kDyRow;
+constexpr int kSlabStride = 2048;
+constexpr int kKSteps = 7;
+constexpr int kImgBytes = 2 * kKSteps * 2 * 64 * 16;  // the B-operand image (both class sets): 28 672
+constexpr int kLdsBytes = 2 * kYBuf + kDyBytes + split::kConsWaves * kSlabStride + kImgBytes;
+constexpr int kThreads = 768, kProdThreads = 256;  // 8 compute + 4 staging waves: three per SIMD -> 168 registers (the 1024-thread version spilled)
+constexpr int kYSlots = 2 * 2 * kPairs * 128 / kProdThreads;  // 16-byte requests per staging thread and step: 8
+constexpr int kDySlots = (kDyPlanes * 64 + kProdThreads - 1) / kProdThreads;  // 2
+__host__ __device__ constexpr int cls(int ty, int ci) { return ty == 0 ? (ci == 0 ? 0 : ci == 1 ? 3 : ci == 2 ? 5 : 6) : (ci == 0 ? 1 : ci == 1 ? 2 : ci == 2 ? 4 : 7); }
+__host__ __device__ constexpr int ntaps(int e) { return ((e & 4) ? 1 : 2) * ((e & 2) ? 1 : 2) * ((e & 1) ? 1 : 2); }
+__host__ __device__ constexpr int ksteps(int e) { return (ntaps(e) + 1) / 2; }
+// (closed form, NOT a recursion: the recursive version was not folded after unrolling -- a real, recursive function call per class)
+__host__ __device__ constexpr int first_kstep(int ty, int ci) { return ty == 0 ? (ci == 0 ? 0 : 3 + ci) : 2 * ci; }
+static_assert(first_kstep(0, 1) == ksteps(cls(0, 0)) && first_kstep(0, 2) == first_kstep(0, 1) + ksteps(cls(0, 1)) && first_kstep(0, 3) == first_kstep(0, 2) + ksteps(cls(0, 2)), "prefix sums, set X");
+static_assert(first_kstep(1, 1) == ksteps(cls(1, 0)) && first_kstep(1, 2) == first_kstep(1, 1) + ksteps(cls(1, 1)) && first_kstep(1, 3) == first_kstep(1, 2) + ksteps(cls(1, 2)), "prefix sums, set Y");
+// tap q of class e: which neighbour (zo, yo, xo) of dy2 it reads, and its index in the 3 x 3 x 3 kernel
+__host__ __device__ constexpr int tap_xo(int e, int q) { return q % ((e & 1) ? 1 : 2); }
+__host__ __device__ constexpr int tap_yo(int e, int q) { return (q / ((e & 1) ? 1 : 2)) % ((e & 2) ? 1 : 2); }
+__host__ __device__ constexpr int tap_zo(int e, int q) { return q / (((e & 1) ? 1 : 2) * ((e & 2) ? 1 : 2)); }
+__host__ __device__ constexpr int tap_index(int e, int q)
+{
+    return (((e & 4) ? 1 : 2 * tap_zo(e, q)) * 3 + ((e & 2) ? 1 : 2 * tap_yo(e, q))) * 3 + ((e & 1) ? 1 : 2 * tap_xo(e, q));
+}
+static_assert(first_kstep(0, 3) + ksteps(cls(0, 3)) == kKSteps && first_kstep(1, 3) + ksteps(cls(1, 3)) == kKSteps, "7 k-steps per class set");
+}  // namespace dsplit
+
+// dgrad B-operand image: [class set 2][k-step 7][hi | lo][lane = 16 g + n][j] = 2^10 W2[co = 8 (g & 1) + j][ci = n][tap(g >> 1)]
+// with the two taps of the k-step from the class walk above (a missing second tap: zeros); + the power-of-two bound of
+// sum |W2| over (co, tap) that scales the layer-1 gradient before the fp32 contraction is NOT needed (that part stays fp32).
+__global__ void k_prep_w2_dgrad_split(const float *__restrict__ W2, uint4 *__restrict__ img)
+{
+    using namespace dsplit;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * kKSteps * 64) return;
+    const int ty = i / (kKSteps * 64), s = (i >> 6) % kKSteps, lane = i & 63, n = lane & 15, g = lane >> 4;
+    int e = 0, ls = s;
+    for (int ci = 0; ci < 4; ++ci) {
+        e = cls(ty, ci);
+        if (ls < ksteps(e)) break;
+        ls -= ksteps(e);
+    }
+    const int q = 2 * ls + (g >> 1);
+    const bool has = q < ntaps(e);
+    const int tap = has ? tap_index(e, q) : 0, c0 = 8 * (g & 1);
+    h8 vh, vl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float wv = has ? W2[((size_t)(c0 + j) * kC + n) * kTaps + tap] * split::kWScale : 0.0f;
+        _Float16 hi, lo;
+        split::split2(wv, hi, lo);
+        vh[j] = hi;
+        vl[j] = lo;
+    }
+    img[((ty * kKSteps + s) * 2 + 0) * 64 + lane] = *reinterpret_cast<uint4 *>(&vh);
+    img[((ty * kKSteps + s) * 2 + 1) * 64 + lane] = *reinterpret_cast<uint4 *>(&vl);
+}
+
+template <int TY>
+__device__ __forceinline__ void dgrad_split_supertile(
+    const char *dyst, const char *ybuf, const int8_t *slab0, const int8_t *slab1, const uint4 *wimg /*this lane's column of the class set's image, in LDS*/,
+    int ai, int c, bool z1ok, bool y0ok, bool y1ok, int O1, bool tok1, float sc, float sh, float mu, float rs,
+    float unscale, float &s1, float &s2, f32x4 &T1a, f32x4 &T1b)
+{
+    using namespace dsplit;
+    const int lane = threadIdx.x & (kWave - 1), m = lane & 15, g = lane >> 4;
+    const bool second = (g >> 1) != 0;
+    uint32_t rowslot[2];  // ring slot of dy2 row c - yo
+#pragma unroll
+    for (int yo = 0; yo < 2; ++yo) rowslot[yo] = (uint32_t)((c - yo + kDyRing) % kDyRing);
+    uint32_t a_lane = (uint32_t)((m + 1) * 32 + (g & 1) * 16);
+    // (opaque to the optimiser: otherwise the 14 per-lane operand offsets and the row addresses are hoisted out of the step loop
+    // as loop invariants, and the register allocator spills them -- any scratch use at all slows these kernels several times)
+    asm volatile("" : "+v"(a_lane));
+    asm volatile("" : "+s"(ai));  // (same for the scalar plane offsets: 28 hoisted SGPRs overflowed into a spill register that itself spilled)
+    asm volatile("" : "+s"(O1));  // (and for the eight x-validity masks, two SGPRs each)
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+        const int e = cls(TY, ci), ez = (e >> 2) & 1, ey = (e >> 1) & 1, ex = e & 1;
+        // sub-tiles on out-of-grid planes / rows (the last plane pair / row pair only) are computed and masked, not skipped: a
+        // branch here would end the basic block and keep the scheduler from overlapping one class's LDS latencies with the next
+        const bool cls_ok = !((ez && !z1ok) || (ey ? !y1ok : !y0ok));
+        f32x4 acc_hh = {0.f, 0.f, 0.f, 0.f}, acc_lh = acc_hh, acc_hl = acc_hh;
+#pragma unroll
+        for (int ls = 0; ls < ksteps(e); ++ls) {
+            const int s = first_kstep(TY, ci) + ls, qa = 2 * ls, qb = min(2 * ls + 1, ntaps(e) - 1);  // (a missing second tap has zero weights)
+            auto off = [&](int q) {
+                return (uint32_t)((ai + 1 - tap_zo(e, q)) * kDyRing * kDyRow) + rowslot[tap_yo(e, q)] * kDyRow - (uint32_t)(tap_xo(e, q) * 32);
+            };
+            const uint32_t o = a_lane + (second ? off(qb) : off(qa));
+            const h8 ah = *reinterpret_cast<const h8 *>(dyst + o), al = *reinterpret_cast<const h8 *>(dyst + o + kDyHalf);
+            const uint4 uh = wimg[(s * 2 + 0) * 64], ul = wimg[(s * 2 + 1) * 64];
+            const h8 wh = *reinterpret_cast<const h8 *>(&uh), wl = *reinterpret_cast<const h8 *>(&ul);
+            acc_hh = split::mfma_h(ah, wh, acc_hh);
+            acc_lh = split::mfma_h(al, wh, acc_lh);
+            acc_hl = split::mfma_h(ah, wl, acc_hl);
+        }
+        const f32x4 acc = (acc_hh + (acc_lh + acc_hl)) * unscale;  // D[i = voxel 4g + r][j = ci = m]
+        uint32_t ylane = (uint32_t)((4 * g) * kYVox + m * 4);
+        asm volatile("" : "+v"(ylane));
+        const char *yrow = ybuf + ((2 * ai + ez) * 2 + ey) * kYRow + ex * kYHalf + ylane;
+        const int kOff = ((2 * ez) * 5 + 2 * ey) * kSlabRow + 2 * ex;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            // (the epilogue of dgrad_c1w_subtile: out-of-grid voxels are masked in the A operand and in g)
+            const bool ok = cls_ok && 2 * (4 * g + r) + ex < O1;  // x validity of voxel 4g + r (x = 2j + ex)
+            const float y = ok ? *reinterpret_cast<const float *>(yrow + r * kYVox) : 0.0f;
+            const float gv = (ok && fmaf(sc, y, sh) > 0.0f) ? acc[r] : 0.0f;
+            s1 += gv;
+            s2 = fmaf(gv, (y - mu) * rs, s2);
+            const float a0v = (float)slab0[kOff + 4 * r], a1v = (float)slab1[kOff + 4 * r];
+            T1a = mfma4(ok ? a0v : 0.0f, gv, T1a);  // A[i = tap][k = voxel]
+            T1b = mfma4(ok && tok1 ? a1v : 0.0f, gv, T1b);
+        }
+    }
+}
+
+__global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
+    const float *__restrict__ dy2, const uint4 *__restrict__ w2img /*k_prep_w2_dgrad_split*/, const unsigned *__restrict__ absmax, const float *__restrict__ y1,
+    const float *__restrict__ scale1, const float *__restrict__ shift1, const float *__restrict__ mean1, const float *__restrict__ rstd1,
+    const int8_t *__restrict__ grid_i8, const int64_t *__restrict__ rows, int64_t grid_row_stride, int B, int G, int O1, int O2,
+    float *__restrict__ partial /*[blocks][kE1F]*/)
+{
+    using namespace dsplit;
+    extern __shared__ __attribute__((aligned(16))) char split_lds[];
+    char *ybufs = split_lds, *dyst = split_lds + 2 * kYBuf, *slabs = dyst + kDyBytes;
+    uint4 *wlds = reinterpret_cast<uint4 *>(slabs + split::kConsWaves * kSlabStride);
+    const int NA = (O1 + 1) >> 1;  // 16 plane pairs / row pairs / voxels per x parity
+    int b, a0, a1;
+    const bool live = sample_plane_group(B, NA, kPairs, b, a0, a1);
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int m = lane & 15, kq = lane >> 4;
+    float s1 = 0.f, s2 = 0.f;
+    f32x4 T1a = {0.f, 0.f, 0.f, 0.f}, T1b = T1a;
+    // (stale LDS may hold NaN patterns: the zero voxels around the dy2 rows and the rows of steps not yet staged must be finite)
+    for (int i = tid; i < (kLdsBytes - kImgBytes) / 16; i += kThreads) reinterpret_cast<uint4 *>(split_lds)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < kImgBytes / 16; i += kThreads) wlds[i] = w2img[i];
+    __syncthreads();
+    const int nsteps = NA;  // 16 row pairs (even)
+    if (live && wv >= split::kConsWaves) {
+        // ---- staging waves ----
+        const int ptid = tid - split::kConsWaves * kWave;
+        const float gs = grad_scale(absmax);
+        const int P2 = O2 * O2 * O2;
+        const uint32_t rowC = 2 * 16 * kC, planeC = rowC * O1;
+        const uint32_t within = ptid & 127;
+        const float *ybase = y1 + (size_t)b * O1 * planeC + within * 4;
+        const uint32_t yst = (within >> 6) * kYHalf + ((within >> 2) & 15) * kYVox + (within & 3) * 16;
+        // dy2: request k of a thread -> piece f = 256 k + ptid = (plane a0 - 1 + (f >> 6), voxel, channel quad); pieces past the
+        // fifth plane are duplicates that are never stored
+        const int dpiece = ptid & 63, dvox = dpiece >> 2;
+        auto dy_req = [&](int k, int c) {
+            const int doz = a0 - 1 + min(4 * k + (ptid >> 6), kDyPlanes - 1);
+            return *reinterpret_cast<const float4 *>(dy2 + ((size_t)b * P2 + ((size_t)min(max(doz, 0), O2 - 1) * O2 + min(max(c, 0), O2 - 1)) * O2 + min(dvox, O2 - 1)) * kC +
+                                                     4 * (dpiece & 3));
+        };
+        auto dy_store = [&](int k, const float4 &d, int c) {
+            const int dpl = 4 * k + (ptid >> 6), doz = a0 - 1 + dpl;
+            if (dpl < kDyPlanes) {  // (wave-uniform; no request inside)
+                const float v[4] = {d.x, d.y, d.z, d.w};
+                const bool ok = doz >= 0 && doz < O2 && dvox < O2 && c >= 0 && c < O2;
+                h4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 a, c2;
+                    split::split2(ok ? v[e] * gs : 0.0f, a, c2);
+                    hi[e] = a;
+                    lo[e] = c2;
+                }
+                char *dst = dyst + (dpl * kDyRing + (c + kDyRing) % kDyRing) * kDyRow + (dvox + 1) * 32 + (dpiece & 3) * 8;
+                *reinterpret_cast<h4 *>(dst) = hi;
+                *reinterpret_cast<h4 *>(dst + kDyHalf) = lo;
+            }
+        };
+        static_assert(kDySlots == 2, "two dy2 requests per staging thread");
+        // the inputs of step c: y1 rows 2c, 2c+1 of planes 2 a0 .. 2 a0 + 7; dy2 row c
+        auto y_req = [&](int k, int c) {
+            const int rowid = 2 * k + (ptid >> 7), pl = 2 * a0 + (rowid >> 1), row = 2 * c + (rowid & 1);  // (wave-uniform)
+            return *reinterpret_cast<const float4 *>(ybase + (uint32_t)min(pl, O1 - 1) * planeC + (uint32_t)min(max(row, 0), O1 - 1) * rowC);
+        };
+        auto y_store = [&](int k, const float4 &v, int c) { *reinterpret_cast<float4 *>(ybufs + (c & 1) * kYBuf + (2 * k + (ptid >> 7)) * kYRow + yst) = v; };
+        static_assert(kYSlots == 8, "eight y1 requests per staging thread");
+        struct StepRegs { float4 y0, y1, y2, y3, y4, y5, y6, y7, d0, d1; };  // (named members: as arrays these 40 registers ended up in scratch memory)
+#define GNBV_DS_LOAD(R, C)                                                                                                      \
+    {                                                                                                                           \
+        R.y0 = y_req(0, (C)); R.y1 = y_req(1, (C)); R.y2 = y_req(2, (C)); R.y3 = y_req(3, (C));                                   \
+        R.y4 = y_req(4, (C)); R.y5 = y_req(5, (C)); R.y6 = y_req(6, (C)); R.y7 = y_req(7, (C));                                   \
+        R.d0 = dy_req(0, (C)); R.d1 = dy_req(1, (C));                                                                             \
+    }
+#define GNBV_DS_STORE(R, C)                                                                                                     \
+    {                                                                                                                           \
+        y_store(0, R.y0, (C)); y_store(1, R.y1, (C)); y_store(2, R.y2, (C)); y_store(3, R.y3, (C));                               \
+        y_store(4, R.y4, (C)); y_store(5, R.y5, (C)); y_store(6, R.y6, (C)); y_store(7, R.y7, (C));                               \
+        dy_store(0, R.d0, (C)); dy_store(1, R.d1, (C));                                                                           \
+    }
+        StepRegs ra, rb;
+        GNBV_DS_LOAD(ra, 0);
+        GNBV_DS_LOAD(rb, 1);
+        GNBV_DS_STORE(ra, 0);
+        GNBV_DS_LOAD(ra, 2);
+        split_step_barrier();
+        // step c: compute reads y1 buffer c & 1 and dy2 rows c - 1, c; staging fills buffer (c + 1) & 1 and dy2 row c + 1
+        // (branch-free around the requests: see the forward kernel).  rb holds odd steps, ra even ones.
+        for (int c = 0; c < nsteps; c += 2) {
+            GNBV_DS_STORE(rb, c + 1);
+            GNBV_DS_LOAD(rb, c + 3);
+            split_step_barrier();
+            GNBV_DS_STORE(ra, c + 2);
+            GNBV_DS_LOAD(ra, c + 4);
+            split_step_barrier();
+        }
+#undef GNBV_DS_LOAD
+#undef GNBV_DS_STORE
+    } else if (live) {
+        // ---- compute waves ----
+        const int cw = wv, ai = cw >> 1, ty = cw & 1, a = a0 + ai;
+        const float gs = grad_scale(absmax);
+        const float unscale = 1.0f / (gs * split::kWScale);
+        const uint4 *wimg = wlds + ty * kKSteps * 2 * 64 + lane;
+        const float sc = scale1[m], sh = shift1[m], mu = mean1[m], rs = rstd1[m];
+        const bool tok1 = 16 + m < kTaps;
+        const int t1 = tok1 ? 16 + m : 0;
+        int8_t *slab = reinterpret_cast<int8_t *>(slabs + cw * kSlabStride);
+        const int8_t *slab0 = slab + ((m / 9) * 5 + (m / 3) % 3) * kSlabRow + m % 3 + 16 * kq;
+        const int8_t *slab1 = slab + ((t1 / 9) * 5 + (t1 / 3) % 3) * kSlabRow + t1 % 3 + 16 * kq;
+        const int8_t *in = grid_i8 + (rows ? rows[b] : (int64_t)b) * grid_row_stride;
+        const int g3m16 = G * G * G - 16;
+        // the int8 input slab under super-tile (a, c): 5 planes x 5 rows x 80 bytes, two 16-byte requests per lane, one step ahead
+        uint4 sv0, sv1;
+        auto slab_req = [&](int c, int u) {
+            const int idx = min(lane + 64 * u, 124), row = idx / 5, seg = idx - 5 * row, zr = row / 5, yr = row - 5 * zr;
+            const int off = (min(4 * a + zr, G - 1) * G + min(4 * c + yr, G - 1)) * G + 16 * seg;
+            return *reinterpret_cast<const uint4 *>(in + min(off, g3m16));
+        };
+        auto slab_load = [&](int c) {
+            sv0 = slab_req(c, 0);
+            sv1 = slab_req(c, 1);
+        };
+        slab_load(0);
+        const bool z1ok = 2 * a + 1 < O1;
+        split_step_barrier();
+        // (one step loop per class set: with the branch inside the loop the two instantiations' scalars overflow the SGPR file)
+        auto run = [&](auto ty_c) {
+            constexpr int TY = decltype(ty_c)::value;
+            for (int c = 0; c < nsteps; ++c) {
+                reinterpret_cast<uint4 *>(slab)[lane] = sv0;
+                if (lane + 64 < 125) reinterpret_cast<uint4 *>(slab)[lane + 64] = sv1;
+                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+                __builtin_amdgcn_wave_barrier();
+                slab_load(min(c + 1, nsteps - 1));
+                __builtin_amdgcn_sched_barrier(0);
+                const bool y0ok = 2 * c < O1, y1ok = 2 * c + 1 < O1;
+                const char *ybuf = ybufs + (c & 1) * kYBuf;
+                dgrad_split_supertile<TY>(dyst, ybuf, slab0, slab1, wimg, ai, c, z1ok, y0ok, y1ok, O1, tok1, sc, sh, mu, rs, unscale, s1, s2, T1a, T1b);
+                split_step_barrier();
+            }
+        };
+        if (ty == 0)
+            run(std::integral_constant<int, 0>{});
+        else
+            run(std::integral_constant<int, 1>{});
+    }
+    // ---- workgroup-level sums: binary tree over the 8 compute waves (fixed order -> deterministic) ----
+    s1 = kgroup_sum(s1);
+    s2 = kgroup_sum(s2);
+    __syncthreads();  // every wave is done with the staged rows (reused as the reduction buffer)
+    constexpr int kSlot = 2 * kWave * 4 + 2 * kC;  // floats per wave slot
+    float *red = reinterpret_cast<float *>(split_lds);
+#pragma unroll
+    for (int half = split::kConsWaves / 2; half >= 1; half >>= 1) {
+        if (wv >= half && wv < 2 * half) {
+            float *slot = red + (wv - half) * kSlot;
+            reinterpret_cast<f32x4 *>(slot)[lane] = T1a;
+            reinterpret_cast<f32x4 *>(slot)[kWave + lane] = T1b;
+            if (lane < kC) {
+                slot[2 * kWave * 4 + lane] = s1;
+                slot[2 * kWave * 4 + kC + lane] = s2;
+            }
+        }
+        __syncthreads();
+        if (wv < half) {
+            const float *slot = red + wv * kSlot;
+            T1a += reinterpret_cast<const f32x4 *>(slot)[lane];
+            T1b += reinterpret_cast<const f32x4 *>(slot)[kWave + lane];
+            s1 += slot[2 * kWave * 4 + m];
+            s2 += slot[2 * kWave * 4 + kC + m];
+        }
+        __syncthreads();
+    }
+    float *fin = red + 16 * kSlot;
+    if (wv == 0) {  // final layout: [tap][co], S1, S2
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            fin[(4 * kq + r) * kC + m] = T1a[r];
+            fin[(16 + 4 * kq + r) * kC + m] = T1b[r];
+        }
+        if (lane < kC) {
+            fin[512 + lane] = s1;
+            fin[512 + kC + lane] = s2;
+        }
+    }
+    __syncthreads();
+    float *out = partial + (size_t)blockIdx.x * kE1F;
+    for (int o = tid; o < kE1F; o += kThreads) out[o] = fin[o];
 }

@@ -693,8 +693,6 @@ __global__ __launch_bounds__(kFwdThreads) void k_conv2_fwd_lds(
 }
 
 
-#include "conv_split.h"
-
 // ---------------------------------------------------------------------------
 // BatchNorm bookkeeping.  sums [2][16] come from k_reduce_partials.
 //   train: mean / biased var from (sum, sumsq); running stats updated with the UNBIASED var
@@ -2089,6 +2087,8 @@ __global__ void k_conv1_wgrad_finish(const double *__restrict__ tmp /*[slices][E
 // ===========================================================================
 // C-ABI
 // ===========================================================================
+#include "conv_split.h"
+
 static inline int out_size(int g) { return (g - 3) / 2 + 1; }
 
 GNBV_API size_t gnbv_encoder_y1_elems(int batch, int grid)
@@ -2313,7 +2313,9 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
         hipLaunchKernelGGL(k_conv2_fwd<ActBF16>, dim3(g2), dim3(kFwdThreads), 0, st, (const uint16_t *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
                        training ? w.bn_part : nullptr);
     } else if (!z1 && !qm && conv_split_path(p, grid)) {
-        hipLaunchKernelGGL(k_prep_w2_split, dim3((split::kKSteps * 64 + 255) / 256), dim3(256), 0, st, p->w2, w.w2split, w.w2split + split::kW2ImgU4);
+        hipLaunchKernelGGL(k_prep_w2_split, dim3((split::kKSteps * 64 + 255) / 256), dim3(256), 0, st, p->w2, w.w2split, (uint4 *)nullptr);
+        if (training)
+            hipLaunchKernelGGL(k_prep_w2_dgrad_split, dim3((2 * dsplit::kKSteps * 64 + 255) / 256), dim3(256), 0, st, p->w2, w.w2split + split::kW2ImgU4);
         g2 = sample_plane_group_grid(batch, O2, split::kNP);
         static bool attr_split = false;
         if (!attr_split) {
@@ -2464,7 +2466,17 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     // ---- conv2 data gradient (+ ReLU1 mask, BN1 backward sums) ----
     const int gd = sample_plane_group_grid(batch, (O1 + 1) / 2, kPlanesPerGroup);  // groups of plane PAIRS
     if (fused) {
-        if (z1)
+        if (split_bwd) {
+            static bool attr_dg = false;
+            if (!attr_dg) {
+                const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_dgrad_c1w_split, hipFuncAttributeMaxDynamicSharedMemorySize, dsplit::kLdsBytes);
+                if (e != hipSuccess) return (int)e;
+                attr_dg = true;
+            }
+            hipLaunchKernelGGL(k_conv2_dgrad_c1w_split, dim3(gd), dim3(dsplit::kThreads), dsplit::kLdsBytes, st, dy2_scratch, (const uint4 *)(w.w2split + split::kW2ImgU4),
+                               (const unsigned *)dy2_absmax, (const float *)y1, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->grid_i8, rows, p->grid_i8_row_stride,
+                               batch, grid, O1, O2, wg1_part);
+        } else if (z1)
             hipLaunchKernelGGL(k_conv2_dgrad_c1w<true>, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const float *)y1, bn1,
                                bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->grid_i8, rows, p->grid_i8_row_stride, batch, grid, O1, O2, wg1_part);
         else if (qm)
