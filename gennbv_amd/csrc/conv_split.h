@@ -49,31 +49,22 @@ __device__ __forceinline__ f32x4 mfma_h(h8 a, h8 b, f32x4 c) { return __builtin_
 
 // W2 [co][ci][27] -> the B-operand images of the split kernels, as two f16 planes scaled by 2^10:
 //   fwd   image [k-step s][hi|lo][lane = 16 g + n][j] = W2[co = n][ci = 8 (g & 1) + j][tap = 2 s + (g >> 1)]      (tap 27: zero)
-//   dgrad image [k-step s][hi|lo][lane = 16 g + n][j] = W2[co = 8 (g & 1) + j][ci = n][tap = 2 s + (g >> 1)]
-__global__ void k_prep_w2_split(const float *__restrict__ W2, uint4 *__restrict__ img_fwd, uint4 *__restrict__ img_dgrad)
+//   dgrad image: see prep_w2_dgrad_split_item
+// Both are written by the conv1 forward kernel in passing (prep_w2_in_passing, encoder.hip), like the fp32 images.
+__device__ __forceinline__ void prep_w2_split_item(int i, const float *__restrict__ W2, uint4 *__restrict__ img_fwd)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= split::kKSteps * 64) return;
     const int s = i >> 6, lane = i & 63, n = lane & 15, g = lane >> 4, tap = 2 * s + (g >> 1), c0 = 8 * (g & 1);
-    h8 fh, fl, dh, dl;
+    h8 fh, fl;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float wf = tap < kTaps ? W2[((size_t)n * kC + c0 + j) * kTaps + tap] * split::kWScale : 0.0f;
-        const float wd = tap < kTaps ? W2[((size_t)(c0 + j) * kC + n) * kTaps + tap] * split::kWScale : 0.0f;
         _Float16 hi, lo;
         split::split2(wf, hi, lo);
         fh[j] = hi;
         fl[j] = lo;
-        split::split2(wd, hi, lo);
-        dh[j] = hi;
-        dl[j] = lo;
     }
     img_fwd[(s * 2 + 0) * 64 + lane] = *reinterpret_cast<uint4 *>(&fh);
     img_fwd[(s * 2 + 1) * 64 + lane] = *reinterpret_cast<uint4 *>(&fl);
-    if (img_dgrad != nullptr) {
-        img_dgrad[(s * 2 + 0) * 64 + lane] = *reinterpret_cast<uint4 *>(&dh);
-        img_dgrad[(s * 2 + 1) * 64 + lane] = *reinterpret_cast<uint4 *>(&dl);
-    }
 }
 
 // The staging role shared by the split kernels: one of 512 threads (8 waves) that move the two new input rows of an iteration
@@ -502,11 +493,9 @@ static_assert(first_kstep(0, 3) + ksteps(cls(0, 3)) == kKSteps && first_kstep(1,
 // dgrad B-operand image: [class set 2][k-step 7][hi | lo][lane = 16 g + n][j] = 2^10 W2[co = 8 (g & 1) + j][ci = n][tap(g >> 1)]
 // with the two taps of the k-step from the class walk above (a missing second tap: zeros); + the power-of-two bound of
 // sum |W2| over (co, tap) that scales the layer-1 gradient before the fp32 contraction is NOT needed (that part stays fp32).
-__global__ void k_prep_w2_dgrad_split(const float *__restrict__ W2, uint4 *__restrict__ img)
+__device__ __forceinline__ void prep_w2_dgrad_split_item(int i, const float *__restrict__ W2, uint4 *__restrict__ img)
 {
     using namespace dsplit;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * kKSteps * 64) return;
     const int ty = i / (kKSteps * 64), s = (i >> 6) % kKSteps, lane = i & 63, n = lane & 15, g = lane >> 4;
     int e = 0, ls = s;
     for (int ci = 0; ci < 4; ++ci) {
@@ -528,6 +517,18 @@ __global__ void k_prep_w2_dgrad_split(const float *__restrict__ W2, uint4 *__res
     }
     img[((ty * kKSteps + s) * 2 + 0) * 64 + lane] = *reinterpret_cast<uint4 *>(&vh);
     img[((ty * kKSteps + s) * 2 + 1) * 64 + lane] = *reinterpret_cast<uint4 *>(&vl);
+}
+
+// definition of the hook the conv1 forward kernels call (declared in encoder.hip in front of them)
+__device__ void prep_w2_split_in_passing(const float *__restrict__ W2, float *__restrict__ w2img)
+{
+    uint4 *img = reinterpret_cast<uint4 *>(w2img + 2 * kTaps * 256);  // EncWs::w2split
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (split::kKSteps + 2 * dsplit::kKSteps) * 64; i += gridDim.x * blockDim.x) {
+        if (i < split::kKSteps * 64)
+            prep_w2_split_item(i, W2, img);
+        else
+            prep_w2_dgrad_split_item(i - split::kKSteps * 64, W2, img + split::kW2ImgU4);
+    }
 }
 
 template <int TY>

@@ -184,11 +184,14 @@ __global__ void k_prep_w2(const float *__restrict__ W2, float *__restrict__ img_
 
 // (the images only depend on W2: the conv1 forward kernel, which runs before every conv2 forward, writes them in
 // passing -- a few hundred extra stores in an HBM-bound launch instead of a dependent 5 us launch)
+__device__ void prep_w2_split_in_passing(const float *__restrict__ W2, float *__restrict__ w2img);  // conv_split.h: the f16 images of the split kernels
 __device__ __forceinline__ void prep_w2_in_passing(const float *__restrict__ W2, float *__restrict__ w2img)
 {
-    if (W2 != nullptr)
+    if (W2 != nullptr) {
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kTaps * 256; i += gridDim.x * blockDim.x)
             prep_w2_element(i, W2, w2img, w2img + kTaps * 256);
+        prep_w2_split_in_passing(W2, w2img);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2313,9 +2316,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
         hipLaunchKernelGGL(k_conv2_fwd<ActBF16>, dim3(g2), dim3(kFwdThreads), 0, st, (const uint16_t *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
                        training ? w.bn_part : nullptr);
     } else if (!z1 && !qm && conv_split_path(p, grid)) {
-        hipLaunchKernelGGL(k_prep_w2_split, dim3((split::kKSteps * 64 + 255) / 256), dim3(256), 0, st, p->w2, w.w2split, (uint4 *)nullptr);
-        if (training)
-            hipLaunchKernelGGL(k_prep_w2_dgrad_split, dim3((2 * dsplit::kKSteps * 64 + 255) / 256), dim3(256), 0, st, p->w2, w.w2split + split::kW2ImgU4);
+        // (its weight images, and the data-gradient kernel's, were written by the conv1 kernel in passing)
         g2 = sample_plane_group_grid(batch, O2, split::kNP);
         static bool attr_split = false;
         if (!attr_split) {
