@@ -547,156 +547,6 @@ __global__ __launch_bounds__(kFwdThreads) void k_conv2_fwd(
 }
 
 // ---------------------------------------------------------------------------
-// conv2 forward, LDS-staged (EXPERIMENT, GENNBV_CONV2_LDS=1; fp32 y1, O2 <= 15, ceil(O1/2) <= 16).  Same workgroup = (sample,
-// group of <= 4 output planes), but the workgroup walks its tiles in ROUNDS of (planes) x (RY rows) = <= 12 tiles, one per
-// wave, and the input rows a round needs -- (2 np + 1) planes x (2 RY + 1) rows x 2 parities x 1 KiB -- are read from global
-// memory ONCE, BN + ReLU'd once and kept in LDS as z1, in the MFMA operand layout [quad kq][voxel][4 channels]; the 27 taps of
-// every tile are 16-byte LDS reads (tap dx = 2: the same row, one voxel = 16 bytes further).  The requests of round c + 1 sit
-// in registers (11 x 16 bytes per lane) while round c computes.  Per round and CU: 126 KiB from L2 instead of 324.
-// MEASURED (B = 128, G = 64, per-wave timestamps): a round = 0.76 us BN + LDS store, 0.64 us barrier, 6.2 us for 108 MFMAs per
-// wave (5.3 in the last round, which has no prefetch to issue: the matrix pipe's rate), 1.2 us barrier (waves of a SIMD
-// finish 1.5 us apart) = 8.8 us against ~9 us per round of k_conv2_fwd; with the 5 us the first round waits for its
-// un-prefetched rows the launch takes 100 us against 92-95.  NOT the default: it proves the compute phase (LDS-written
-// operands, no VALU) reaches the pipe's rate, but one workgroup per CU (155 KiB of LDS) cannot hide its staging and barrier
-// phases behind another workgroup's MFMAs; the round-2 version needs half-size rounds and two workgroups per CU.
-// ---------------------------------------------------------------------------
-constexpr int kStageRegions = 63;                                 // (2 np + 1)(2 RY + 1) <= 63 for every (np, RY) chosen below
-constexpr int kStageBytes = kStageRegions * 2 * 1024 + 16;        // + 16: lane m = 15 of the last quad reads one voxel past its row
-constexpr int kW2ImgBytes = kTaps * 4 * 4 * kC * 4;               // 27 648
-constexpr int kFwdLdsBytes = kW2ImgBytes + kStageBytes;
-template <bool QM /*quad-major y1*/>
-__global__ __launch_bounds__(kFwdThreads) void k_conv2_fwd_lds(
-    const float *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1, int B, int O1, int O2,
-    const float *__restrict__ W2img, const float *__restrict__ b2, float *__restrict__ y2, float *__restrict__ partials)
-{
-    extern __shared__ __attribute__((aligned(16))) float fwd_lds[];
-    float *w2s = fwd_lds;
-    char *stage = reinterpret_cast<char *>(fwd_lds) + kW2ImgBytes;
-    fill_lds_image(w2s, W2img);
-    int b, oz0, oz1;
-    const bool live = sample_plane_group(B, O2, kPlanesPerGroup, b, oz0, oz1);
-    const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const int m = lane & 15, kq = lane >> 4;
-    if (!live) { write_partials(partials, kFwdWaves, wv, 0.f, 0.f); return; }
-    float sc[4], sh[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        sc[s] = scale1[4 * kq + s];
-        sh[s] = shift1[4 * kq + s];
-    }
-    const float bias = b2[m];
-    const int P2 = O2 * O2 * O2;
-    float s_sum = 0.0f, s_sq = 0.0f;
-    const int XH = (O1 + 1) >> 1;
-    const uint32_t XHC = (uint32_t)XH * kC, rowC = 2 * XHC, planeC = rowC * O1;
-    const int np = oz1 - oz0, NP = 2 * np + 1;
-    const int RY = min(kFwdWaves / np, (kStageRegions / NP - 1) / 2), NR = 2 * RY + 1;  // rows per round; NR = region row stride
-    const int nchunks = (O2 + RY - 1) / RY;
-    const float *ybase = y1 + (size_t)b * O1 * planeC + (size_t)(2 * oz0) * planeC + (QM ? kq * XH * 4 + min(m, XH - 1) * 4 : min(m, XH - 1) * kC + 4 * kq);
-    constexpr int kSlots = (2 * kStageRegions + kFwdWaves - 1) / kFwdWaves;  // 11 requests per lane and round
-    float4 regs[kSlots];
-    // request j of a round = (plane pi, row ri, parity): j = (pi * nr + ri) * 2 + par, nr = rows of the round (NR but for a
-    // shorter last round).  The decomposition is wave-uniform and the same for every full round: done once (11 divisions).
-    uint32_t goff[kSlots], loff[kSlots];  // global element offset (from ybase + the round's first row) / LDS byte offset; ~0u: no request
-    auto slots_for = [&](int rows_c) {
-        const int nr = 2 * rows_c + 1, nreq = NP * nr * 2;
-#pragma unroll
-        for (int k = 0; k < kSlots; ++k) {
-            const int j = wv + k * kFwdWaves, jc = min(j, nreq - 1);
-            const int par = jc & 1, pr = jc >> 1, pi = pr / nr, ri = pr - pi * nr;
-            goff[k] = (uint32_t)pi * planeC + (uint32_t)ri * rowC + par * XHC;
-            loff[k] = j < nreq ? (uint32_t)(((pi * NR + ri) * 2 + par) * 1024) : ~0u;
-        }
-    };
-    // (issued in three parts, one in front of each dz slab of the compute phase: 132 requests per CU in one burst occupy the
-    // CU's address path for ~1 us during which no wave gets to its MFMAs)
-    auto stage_load_part = [&](int c, int part) {
-        const float *src = ybase + (size_t)(2 * c * RY) * rowC;
-#pragma unroll
-        for (int k = 0; k < kSlots; ++k)
-            if (k / 4 == part) regs[k] = *reinterpret_cast<const float4 *>(src + goff[k]);  // (clamped slots: unconditional requests)
-    };
-    auto stage_load = [&](int c) {
-        stage_load_part(c, 0);
-        stage_load_part(c, 1);
-        stage_load_part(c, 2);
-    };
-    auto stage_store = [&]() {
-#pragma unroll
-        for (int k = 0; k < kSlots; ++k) {
-            if (loff[k] != ~0u) {
-                float4 z;
-                z.x = fmaxf(fmaf(sc[0], regs[k].x, sh[0]), 0.f);
-                z.y = fmaxf(fmaf(sc[1], regs[k].y, sh[1]), 0.f);
-                z.z = fmaxf(fmaf(sc[2], regs[k].z, sh[2]), 0.f);
-                z.w = fmaxf(fmaf(sc[3], regs[k].w, sh[3]), 0.f);
-                *reinterpret_cast<float4 *>(stage + loff[k] + kq * 256 + m * 16) = z;
-            }
-        }
-    };
-    slots_for(min(RY, O2));
-    stage_load(0);
-    for (int c = 0; c < nchunks; ++c) {
-        const int rows_c = min(RY, O2 - c * RY);
-        stage_store();
-        // LDS-only barriers: __syncthreads() would also wait for the round's y2 stores and the prefetch (vmcnt(0))
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const bool more = c + 1 < nchunks;
-        if (more) {
-            const int rows_n = min(RY, O2 - (c + 1) * RY);
-            if (rows_n != rows_c) slots_for(rows_n);  // (the shorter last round; wave-uniform branch)
-        }
-        const bool has_tile = wv < np * rows_c;
-        if (more && !has_tile) stage_load(c + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (has_tile) {  // this wave's tile of the round: plane pl, row r
-            const int pl = wv / rows_c, r = wv - pl * rows_c;
-            const char *tile = stage + ((2 * pl * NR + 2 * r) * 2) * 1024 + kq * 256 + m * 16;
-            f32x4 acc4[4];  // one chain per k sub-step: consecutive MFMAs are independent
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc4[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int dz = 0; dz < 3; ++dz) {
-                if (more) stage_load_part(c + 1, dz);
-                __builtin_amdgcn_sched_barrier(0);
-                float4 a[9];
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int dy = t / 3, dx = t % 3;
-                    a[t] = *reinterpret_cast<const float4 *>(tile + ((dz * NR + dy) * 2 + (dx == 1 ? 1 : 0)) * 1024 + (dx == 2 ? 16 : 0));
-                }
-                float4 wq = w2_tap(w2s, dz * 9, lane);
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const float4 wn = w2_tap(w2s, dz * 9 + (t < 8 ? t + 1 : t), lane);
-                    acc4[0] = mfma4(a[t].x, wq.x, acc4[0]);
-                    acc4[1] = mfma4(a[t].y, wq.y, acc4[1]);
-                    acc4[2] = mfma4(a[t].z, wq.z, acc4[2]);
-                    acc4[3] = mfma4(a[t].w, wq.w, acc4[3]);
-                    wq = wn;
-                }
-            }
-            const f32x4 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
-            const int oz = oz0 + pl, oy = c * RY + r;
-            float *out = y2 + ((size_t)b * kC + m) * P2 + ((size_t)oz * O2 + oy) * O2;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int oxi = 4 * kq + rr;
-                if (oxi < O2) {
-                    const float y = acc[rr] + bias;
-                    out[oxi] = y;
-                    s_sum += y;
-                    s_sq += y * y;
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    write_partials(partials, kFwdWaves, wv, s_sum, s_sq);
-}
-
-
-// ---------------------------------------------------------------------------
 // BatchNorm bookkeeping.  sums [2][16] come from k_reduce_partials.
 //   train: mean / biased var from (sum, sumsq); running stats updated with the UNBIASED var
 //          (torch.nn.BatchNorm3d, momentum 0.1) unless *skip_flag != 0
@@ -2155,11 +2005,6 @@ static inline bool env_off(const char *name)
     const char *e = getenv(name);
     return e && e[0] == '0';
 }
-static inline bool conv2_fwd_lds_path(int O1, int O2)
-{
-    const char *e = getenv("GENNBV_CONV2_LDS");
-    return e && e[0] == '1' && O2 <= 15 && (O1 + 1) / 2 <= 16;
-}
 // conv2 kernels on the f16 matrix pipe with split (hi + lo) operands, staged through LDS (conv_split.h): fp32 y1 in the default
 // x-parity layout, 16 voxel slots per half row (G = 64)
 static inline bool conv_split_path(const GnbvEncoderParams *p, int grid)
@@ -2329,26 +2174,8 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     } else if (z1) {
         hipLaunchKernelGGL((k_conv2_fwd<ActF32, true>), dim3(g2), dim3(kFwdThreads), 0, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
                        training ? w.bn_part : nullptr);
-    } else if (conv2_fwd_lds_path(O1, O2) && qm) {
-        static bool attr_set_q = false;
-        if (!attr_set_q) {
-            const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_fwd_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLdsBytes);
-            if (e != hipSuccess) return (int)e;
-            attr_set_q = true;
-        }
-        hipLaunchKernelGGL(k_conv2_fwd_lds<true>, dim3(g2), dim3(kFwdThreads), kFwdLdsBytes, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
-                           training ? w.bn_part : nullptr);
     } else if (qm) {
         hipLaunchKernelGGL((k_conv2_fwd<ActF32, false, true>), dim3(g2), dim3(kFwdThreads), 0, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
-                           training ? w.bn_part : nullptr);
-    } else if (conv2_fwd_lds_path(O1, O2)) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_fwd_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLdsBytes);
-            if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(k_conv2_fwd_lds<false>, dim3(g2), dim3(kFwdThreads), kFwdLdsBytes, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
                            training ? w.bn_part : nullptr);
     } else {
         hipLaunchKernelGGL(k_conv2_fwd<ActF32>, dim3(g2), dim3(kFwdThreads), 0, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,

@@ -50,27 +50,17 @@ def _obs_clear_of_the_relu_threshold(ref, b, g):
     raise AssertionError("no clean seed")
 
 
-@pytest.mark.parametrize("conv2_lds", ["0", "1", "split"])
+@pytest.mark.parametrize("conv2", ["fp32", "split"])
 @pytest.mark.parametrize("g,b", [(20, 8), (16, 5), (33, 3), (64, 4), (128, 1), (64, 128)])  # last: the bench's minibatch
-def test_encoder_forward_backward_vs_torch_reference(g, b, conv2_lds, monkeypatch):
+def test_encoder_forward_backward_vs_torch_reference(g, b, conv2, monkeypatch):
     """Reference = the same torch modules in fp64 on the CPU (ground truth), tolerance = fp32 round-off.
     (torch-GPU fp32 is NOT used as the reference: MIOpen's conv/BN backward is off by 0.7-4.6 % at
     G=64 against fp64, tools/check_conv_grads.py; the hand-written kernels are within 1e-6.)
-    conv2_lds = "1": the opt-in LDS-staged conv2 forward (k_conv2_fwd_lds; G <= 66, else the default kernel runs).
-    conv2_lds = "split": the conv2 kernels on the f16 matrix pipe with split (hi + lo) operands (csrc/conv_split.h; G = 64) --
-    SAME tolerances as the fp32 kernels."""
-    if conv2_lds == "split":
-        if g != 64:
-            pytest.skip("the split kernels cover G = 64 (16 voxel slots per half row)")
-        monkeypatch.setenv("GENNBV_CONV_SPLIT", "1")
-        conv2_lds = "0"
-    else:
-        monkeypatch.setenv("GENNBV_CONV_SPLIT", "0")
-    if conv2_lds == "1" and g > 66:
-        pytest.skip("k_conv2_fwd_lds covers O2 <= 15 only")
-    if conv2_lds == "1" and b > 64:
-        pytest.skip("the full-minibatch case runs on the default kernel set only")
-    monkeypatch.setenv("GENNBV_CONV2_LDS", conv2_lds)
+    conv2 = "split": the conv2 kernels on the f16 matrix pipe with split (hi + lo) operands (csrc/conv_split.h; G = 64, the
+    default there) -- SAME tolerances as the fp32-MFMA kernels, which conv2 = "fp32" (GENNBV_CONV_SPLIT=0) keeps covered."""
+    if conv2 == "split" and g != 64:
+        pytest.skip("the split kernels cover G = 64 (16 voxel slots per half row)")
+    monkeypatch.setenv("GENNBV_CONV_SPLIT", "1" if conv2 == "split" else "0")
     hip, _, _ = pu.make_policy(g=g, device=DEV, backend="hip", det_weights=True)
     ref, _, _ = pu.make_policy(g=g, device="cpu", backend="torch", det_weights=True)
     ref = ref.double()
