@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -141,6 +142,167 @@ __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 
         }
 }
 
+// ---------------------------------------------------------------------------
+// The same stage 1 on the f16 matrix pipe with SPLIT fp32 operands (see csrc/conv_split.h for the arithmetic): x = hi + lo with
+// hi = f16(x), lo = f16(x - hi), products accumulated in fp32 as hi.hi + lo.hi + hi.lo -- three `v_mfma_f32_16x16x32_f16`
+// (16 cycles each) per 32 k instead of eight `v_mfma_f32_16x16x4_f32` (32 cycles each).  The fp32 kernel above is bound by the
+// fp32 matrix pipe (3.5 GFLOP = 22 us at the peak, 40-53 us measured); this one by the 83 MB stream.
+// Same grid, chunking and staging; a trip = 32 k: lane (row i, g) loads x[row][k0 + 8 g .. + 7] (two 16-byte requests), thread t
+// loads W[col][k0 + 4 (t % 8) .. + 3] for two columns, splits them and stores them as B operands [column tile][g][column][8 halfs].
+// Exact power-of-two scalings keep the `lo` parts in f16's normal range (x 2^6 for x, |x| clamped to 1015; x 2^12 for W, |W|
+// clamped to 15.8 -- both far outside what a normalised activation / a 54 000-input linear layer holds).
+// ---------------------------------------------------------------------------
+typedef _Float16 lh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 lh4 __attribute__((ext_vector_type(4)));
+constexpr float kLinXScale = 64.0f, kLinWScale = 4096.0f, kLinMax = 65000.0f;
+__device__ __forceinline__ void lsplit(float v, float scale, _Float16 &hi, _Float16 &lo)
+{
+    const float t = __builtin_amdgcn_fmed3f(v * scale, -kLinMax, kLinMax);
+    hi = (_Float16)t;
+    lo = (_Float16)(t - (float)hi);
+}
+__device__ __forceinline__ void lsplit8(const float4 &p, const float4 &q, float scale, lh8 &hi, lh8 &lo)
+{
+    const float v[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        _Float16 a, b;
+        lsplit(v[e], scale, a, b);
+        hi[e] = a;
+        lo[e] = b;
+    }
+}
+__global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linear_splitk_split(
+    const float *__restrict__ x /*[M][K]*/, const float *__restrict__ w /*[N][K]*/, int M, int N, int K, int nchunks,
+    float *__restrict__ partial /*[nchunks][M][N]*/)
+{
+    __shared__ __attribute__((aligned(16))) char s_b[2][2][4096];  // [buffer][hi | lo][column tile 4][g 4][column 16][8 halfs]
+    const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int i = lane & 15, g = lane >> 4, mbase = blockIdx.y * 128;
+    const int ntn = N / kTileN;
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int nt = slot % ntn, chunk = (slot / ntn) * 8 + xcd;
+    if (chunk >= nchunks) return;
+    const int nstep32 = (K + 31) / 32;  // 32-k trips
+    const int s0 = (int)((int64_t)chunk * nstep32 / nchunks), s1 = (int)((int64_t)(chunk + 1) * nstep32 / nchunks);
+    if (s0 >= s1) {  // (a chunk without work still owns its partial slab)
+        float *out = partial + (size_t)chunk * M * N;
+        for (int r = threadIdx.x; r < 128 * kTileN; r += kLinThreads) {
+            const int row = mbase + r / kTileN;
+            if (row < M) out[(size_t)row * N + nt * kTileN + r % kTileN] = 0.0f;
+        }
+        return;
+    }
+    const float *xr[kRowTilesPerWave];
+#pragma unroll
+    for (int rt = 0; rt < kRowTilesPerWave; ++rt) xr[rt] = x + (size_t)min(mbase + (wv * kRowTilesPerWave + rt) * 16 + i, M - 1) * K + 8 * g;
+    const int t8 = threadIdx.x & 7, tcol = threadIdx.x >> 3;
+    const float *wst[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) wst[r] = w + (size_t)(nt * kTileN + 32 * r + tcol) * K + 4 * t8;
+    // LDS byte offsets: staging store of this thread's (column 32 r + tcol, k-quad t8); B-operand read of this lane
+    uint32_t st_off[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int col = 32 * r + tcol;
+        st_off[r] = (uint32_t)((((col >> 4) * 4 + (t8 >> 1)) * 16 + (col & 15)) * 16 + (t8 & 1) * 8);
+    }
+    const uint32_t rd_off = (uint32_t)((g * 16 + i) * 16);
+    f32x4 acc[kRowTilesPerWave][4];
+#pragma unroll
+    for (int rt = 0; rt < kRowTilesPerWave; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // requests are UNCONDITIONAL (clamped addresses): see the fp32 kernel
+    struct Trip { float4 a00, a01, a10, a11, b0, b1; };  // (named members: arrays handed to lambdas ended up in scratch memory elsewhere)
+    static_assert(kRowTilesPerWave == 2, "two row tiles per wave");
+    auto request_a = [&](int s, Trip &t) {
+        const int kc = min(min(s, s1 - 1) * 32, K - 8 - 8 * g);
+        t.a00 = ld4g(xr[0] + kc);
+        t.a01 = ld4g(xr[0] + kc + 4);
+        t.a10 = ld4g(xr[1] + kc);
+        t.a11 = ld4g(xr[1] + kc + 4);
+    };
+    auto request_b = [&](int s, Trip &t) {
+        const int kc = min(min(s, s1 - 1) * 32, K - 4 - 4 * t8);
+        t.b0 = ld4g(wst[0] + kc);
+        t.b1 = ld4g(wst[1] + kc);
+    };
+    auto stage_one = [&](int buf, bool ok, const float4 &b, uint32_t off) {
+        const float v[4] = {b.x, b.y, b.z, b.w};
+        lh4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            _Float16 p, q;
+            lsplit(ok ? v[e] : 0.0f, kLinWScale, p, q);
+            hi[e] = p;
+            lo[e] = q;
+        }
+        *reinterpret_cast<lh4 *>(&s_b[buf][0][off]) = hi;
+        *reinterpret_cast<lh4 *>(&s_b[buf][1][off]) = lo;
+    };
+    auto stage_b = [&](int buf, int s, const Trip &t) {
+        const bool ok = s < s1 && s * 32 + 4 * t8 + 3 < K;  // past the chunk / past K: zeros
+        stage_one(buf, ok, t.b0, st_off[0]);
+        stage_one(buf, ok, t.b1, st_off[1]);
+    };
+    auto consume = [&](int s, int buf, const Trip &t) {
+        const bool ok = s < s1 && s * 32 + 8 * g + 7 < K;
+        lh8 ah[kRowTilesPerWave], al[kRowTilesPerWave];
+        lsplit8(t.a00, t.a01, ok ? kLinXScale : 0.0f, ah[0], al[0]);
+        lsplit8(t.a10, t.a11, ok ? kLinXScale : 0.0f, ah[1], al[1]);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const lh8 bh = *reinterpret_cast<const lh8 *>(&s_b[buf][0][ct * 1024 + rd_off]);
+            const lh8 bl = *reinterpret_cast<const lh8 *>(&s_b[buf][1][ct * 1024 + rd_off]);
+#pragma unroll
+            for (int rt = 0; rt < kRowTilesPerWave; ++rt) {
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bh, acc[rt][ct], 0, 0, 0);
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt], bh, acc[rt][ct], 0, 0, 0);
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bl, acc[rt][ct], 0, 0, 0);
+            }
+        }
+    };
+    // Two trips per iteration.  On entry: LDS buffer 0 = W of trip s; t0.a / t1.a = x of trips s / s + 1; t1.b = W of trip s + 1.
+    // Every request is issued one trip before its data is needed (x before the other trip's MFMAs, W before the other
+    // trip's staging), all unconditional.
+    Trip t0, t1;
+    request_a(s0, t0);
+    request_b(s0, t0);
+    request_a(s0 + 1, t1);
+    request_b(s0 + 1, t1);
+    stage_b(0, s0, t0);
+    __syncthreads();
+    for (int s = s0; s < s1; s += 2) {
+        request_b(s + 2, t0);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(s, 0, t0);
+        __builtin_amdgcn_sched_barrier(0);
+        request_a(s + 2, t0);
+        stage_b(1, s + 1, t1);
+        __syncthreads();
+        request_b(s + 3, t1);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(s + 1, 1, t1);
+        __builtin_amdgcn_sched_barrier(0);
+        request_a(s + 3, t1);
+        stage_b(0, s + 2, t0);
+        __syncthreads();
+    }
+    const float unscale = 1.0f / (kLinXScale * kLinWScale);
+    float *out = partial + (size_t)chunk * M * N;
+#pragma unroll
+    for (int rt = 0; rt < kRowTilesPerWave; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = mbase + (wv * kRowTilesPerWave + rt) * 16 + 4 * g + r;
+            if (row < M) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) out[(size_t)row * N + nt * kTileN + ct * 16 + i] = acc[rt][ct][r] * unscale;
+            }
+        }
+}
+
 // out[m][n] = act(bias[n] + sum_c partial[c][m][n]); one thread per 4 consecutive columns, the chunk
 // loop is split over `kRedSplit` threads whose sub-sums are combined in a fixed order through LDS.
 constexpr int kRedSplit = 4;
@@ -202,7 +364,11 @@ GNBV_API int gnbv_linear_forward(const float *x, const float *w, const float *bi
     hipStream_t st = gnbv_stream(stream);
     const int nchunks = pick_chunks(K), ntn = N / kTileN;
     const int blocks = ((nchunks + 7) / 8) * 8 * ntn;
-    hipLaunchKernelGGL(k_linear_splitk, dim3(blocks, (M + 127) / 128), dim3(kLinThreads), 0, st, x, w, M, N, K, nchunks, (float *)workspace);
+    const char *e = getenv("GENNBV_CONV_SPLIT");  // "0": the fp32-MFMA kernels everywhere (csrc/encoder.hip conv_split_path)
+    if (!(e && e[0] == '0') && K % 8 == 0 && K >= 64)
+        hipLaunchKernelGGL(k_linear_splitk_split, dim3(blocks, (M + 127) / 128), dim3(kLinThreads), 0, st, x, w, M, N, K, nchunks, (float *)workspace);
+    else
+        hipLaunchKernelGGL(k_linear_splitk, dim3(blocks, (M + 127) / 128), dim3(kLinThreads), 0, st, x, w, M, N, K, nchunks, (float *)workspace);
     int err;
     if ((err = gnbv_launch_status())) return err;
     const int64_t total4 = (int64_t)M * N / 4;
