@@ -241,37 +241,46 @@ class _LinearReluFn(torch.autograd.Function):
     def backward(ctx, d_out):
         x, w, out = ctx.saved_tensors
         g = torch.ops.aten.threshold_backward(d_out.contiguous(), out, 0.0)
-        dx = g @ w if ctx.needs_input_grad[0] else None
         mod = ctx.mod
-        if mod is not None and mod.weight.grad is not None and mod.bias.grad is not None:
-            if getattr(mod, "_async_wgrad", False):
-                # Nothing downstream of this node needs dW / db (only the optimizer does): compute them on a second
-                # stream beside the rest of the backward; the owner of the flag joins before it reads the gradients
-                # (join_async_wgrads()).
-                cur = torch.cuda.current_stream(g.device)
-                side = _side_stream(g.device, 0)  # the pose branch's stream: a third stream makes the graph scheduler serialise branches
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    torch.mm(g.t(), x, out=mod.weight.grad)
-                    torch.sum(g, 0, out=mod.bias.grad)
-                g.record_stream(side)
-                x.record_stream(side)
-                _pending_wgrad.append(side.record_event())
-            else:
-                torch.mm(g.t(), x, out=mod.weight.grad)
-                torch.sum(g, 0, out=mod.bias.grad)
+        direct = mod is not None and mod.weight.grad is not None and mod.bias.grad is not None
+        if direct and getattr(mod, "_async_wgrad", False) and getattr(mod, "_defer_wgrad", False):
+            # Nothing downstream of this node needs dW / db (only the optimizer does): they are computed on a second stream
+            # beside the rest of the backward.  The launch itself is DEFERRED to join_async_wgrads(), i.e. until the main
+            # backward has been issued: under hipGraph replay the executor keeps a node on the queue of the first child captured
+            # after its parent, so launching the dW GEMM here moved the conv-stack backward -- the critical path -- to another
+            # queue (a ~9 us hand-over) and made dW wait for the dx GEMM it does not depend on.  It needs g only: the event.
+            # (`_defer_wgrad` is raised by the caller around its backward() only: nobody else would call the join.)
+            evt = torch.cuda.Event()
+            evt.record(torch.cuda.current_stream(g.device))
+            _deferred_wgrad.append((g, x, mod, evt))
+            dx = g @ w if ctx.needs_input_grad[0] else None
+            return dx, None, None, None
+        dx = g @ w if ctx.needs_input_grad[0] else None
+        if direct:
+            torch.mm(g.t(), x, out=mod.weight.grad)
+            torch.sum(g, 0, out=mod.bias.grad)
             return dx, None, None, None
         return dx, g.t() @ x, g.sum(0), None
 
 
-_pending_wgrad = []
+_deferred_wgrad = []
 
 
 def join_async_wgrads(device) -> None:
-    """Make the current stream wait for weight gradients that were computed on the second stream (`_async_wgrad`)."""
+    """Launch the deferred weight-gradient GEMMs (`_async_wgrad`) on the second stream and make the current stream wait for them."""
+    if not _deferred_wgrad:
+        return
     cur = torch.cuda.current_stream(device)
-    while _pending_wgrad:
-        cur.wait_event(_pending_wgrad.pop())
+    side = _side_stream(device, 0)  # the pose branch's stream: a third stream makes the graph scheduler serialise branches
+    while _deferred_wgrad:
+        g, x, mod, evt = _deferred_wgrad.pop()
+        side.wait_event(evt)
+        with torch.cuda.stream(side), torch.no_grad():
+            torch.mm(g.t(), x, out=mod.weight.grad)
+            torch.sum(g, 0, out=mod.bias.grad)
+        g.record_stream(side)
+        x.record_stream(side)
+    cur.wait_stream(side)
 
 
 def linear_relu(x: torch.Tensor, lin: torch.nn.Linear) -> torch.Tensor:
@@ -318,9 +327,7 @@ def hybrid_branches(enc, observations):
     side = _side_stream(base.device) if enc.overlap_branches else None
     if side is not None:
         cur = torch.cuda.current_stream(base.device)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            feature_action = pose_branch()
+        side.wait_stream(cur)  # the fork point; the pose kernels themselves are launched AFTER the grid branch (below)
     else:
         feature_action = pose_branch()
     feature_grid = grid_encoder(base, rows, s, g, enc.naive_encoder_grid, enc.training, getattr(enc, "_bn_skip_flag", None),
@@ -334,9 +341,41 @@ def hybrid_branches(enc, observations):
         enc._grid_feats_leaf = feature_grid
     feature_grid = linear_relu(feature_grid, enc.output_layer_grid[0])  # Linear + ReLU, split-K MFMA kernel
     if side is not None:
+        # Launch order matters under hipGraph replay: the executor keeps a node on the queue of the FIRST child captured after
+        # its parent, so with the pose branch captured first the conv chain -- the critical path -- was moved to a second queue and
+        # paid a ~10 us cross-queue hand-over at the fork and again at the join (profiles/r02_notes.md).
+        with torch.cuda.stream(side):
+            feature_action = pose_branch()
         torch.cuda.current_stream(base.device).wait_stream(side)
         feature_action.record_stream(torch.cuda.current_stream(base.device))
+        if getattr(enc, "_defer_pose_backward", False) and torch.is_grad_enabled() and feature_action.requires_grad:
+            # The same rule for the backward: autograd would run (capture) the pose branch's backward BEFORE the grid branch's
+            # (its nodes were created later).  Cut the graph at the branch output; the owner of the flag runs
+            # pose_branch_backward() after the main backward, on the second stream, from an event recorded when the head's
+            # backward produced this leaf's gradient.
+            leaf = feature_action.detach().requires_grad_(True)
+            evt = torch.cuda.Event()
+            leaf.register_hook(lambda g, e=evt, d=base.device: e.record(torch.cuda.current_stream(d)))
+            enc._pose_deferred = (feature_action, leaf, evt)
+            feature_action = leaf
     return feature_action, feature_grid
+
+
+def pose_branch_backward(enc, device) -> None:
+    """Second half of the `_defer_pose_backward` protocol (see hybrid_branches): the pose branch's backward on the second
+    stream, joined into the current stream."""
+    pending = getattr(enc, "_pose_deferred", None)
+    if pending is None:
+        return
+    enc._pose_deferred = None
+    out, leaf, evt = pending
+    if leaf.grad is None:
+        return
+    side, cur = _side_stream(device), torch.cuda.current_stream(device)
+    side.wait_event(evt)
+    with torch.cuda.stream(side):
+        torch.autograd.backward([out], [leaf.grad])
+    cur.wait_stream(side)
 
 
 class _PolicyHeadFn(torch.autograd.Function):

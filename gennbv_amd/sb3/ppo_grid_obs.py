@@ -386,6 +386,7 @@ class PPO_Grid_Obs:
                             None if buf.grid_i8 is None else buf.grid_i8[:t].view(t * n, -1), buf.compact_state_dim,
                             None if buf.autocorr is None else buf.autocorr[:t].view(t * n, -1))
             enc = pol.features_extractor
+            enc._defer_pose_backward = True  # only inside this body: it calls encoder_ops.pose_branch_backward after its backward
             if st.get("fused_head"):
                 fa, fg = encoder_ops.hybrid_branches(enc, obs)
                 logits, values, _ = encoder_ops.policy_head(enc, pol.action_net, pol.value_net, fa, fg)
@@ -393,19 +394,29 @@ class PPO_Grid_Obs:
                 features = pol.extract_features(obs)
                 logits = pol.action_net(features)
                 values = pol.value_net(features).flatten()
+            enc._defer_pose_backward = False
             loss.bind(buf)  # fused gather: the loss kernel indexes the rollout arrays through loss.rows
             d_logits, d_values = loss(logits, values)
             if not st.get("skip_zero"):
                 opt.zero_grad()
+            lin = getattr(enc, "output_layer_grid", [None])[0]
+            if lin is not None:
+                lin._defer_wgrad = True  # (only around this backward: join_async_wgrads below launches what it deferred)
             if phase == "all":
                 torch.autograd.backward([logits, values], [d_logits, d_values])
-                encoder_ops.join_async_wgrads(self.device)  # fc_grid's dW / db ran on a second stream beside the conv backward
+                if lin is not None:
+                    lin._defer_wgrad = False
+                encoder_ops.pose_branch_backward(enc, self.device)  # (deferred so that the conv chain is captured first: encoder_ops.hybrid_branches)
+                encoder_ops.join_async_wgrads(self.device)  # fc_grid's dW / db: second stream, beside the conv backward
                 if self._sync is None or not self._sync.active:
                     opt.step(self.max_grad_norm, loss.stop_flag)
                 return
             # the forward cut the graph at the conv-stack output (enc._split_backward): this backward
             # stops at that leaf and fills the gradients of every non-conv parameter
             torch.autograd.backward([logits, values], [d_logits, d_values])
+            if lin is not None:
+                lin._defer_wgrad = False
+            encoder_ops.pose_branch_backward(enc, self.device)
             encoder_ops.join_async_wgrads(self.device)
         else:  # phase "B": conv-stack backward from d loss / d (conv-stack output)
             enc = pol.features_extractor
