@@ -260,10 +260,14 @@ def test_bf16_activation_storage_within_bf16_tolerance(g, b):
     # gradients are NOT asserted in this mode: see the docstring (fp32 storage is the supported path)
 
 
+@pytest.mark.parametrize("arith", ["split", "fp32"])
 @pytest.mark.parametrize("m,n,k", [(128, 256, 54000), (256, 256, 54000), (7, 64, 1024), (130, 128, 1000), (1, 64, 4)])
-def test_splitk_linear_relu_vs_fp64(m, n, k):
+def test_splitk_linear_relu_vs_fp64(m, n, k, arith, monkeypatch):
     """fc_grid (hybrid_encoder.py:39-42): relu(x W^T + b) on the split-K MFMA kernel vs an fp64 reference;
-    tolerance = fp32 accumulation round-off over K terms.  Backward = library GEMMs on the same mask."""
+    tolerance = fp32 accumulation round-off over K terms.  Backward = library GEMMs on the same mask.
+    arith = "split": k_linear_splitk_split (f16 matrix pipe, split fp32 operands; K % 8 == 0 and K >= 64, else the fp32
+    kernel runs); "fp32": GENNBV_CONV_SPLIT=0, k_linear_splitk (fp32 MFMA).  Same tolerance."""
+    monkeypatch.setenv("GENNBV_CONV_SPLIT", "1" if arith == "split" else "0")
     from gennbv_amd.ops.encoder_ops import linear_relu
     gen = torch.Generator().manual_seed(m + n + k)
     x = (torch.rand(m, k, generator=gen) * (torch.rand(m, k, generator=gen) < 0.5)).to(DEV).requires_grad_(True)
