@@ -523,11 +523,21 @@ __device__ __forceinline__ void prep_w2_dgrad_split_item(int i, const float *__r
 __device__ void prep_w2_split_in_passing(const float *__restrict__ W2, float *__restrict__ w2img)
 {
     uint4 *img = reinterpret_cast<uint4 *>(w2img + 2 * kTaps * 256);  // EncWs::w2split
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (split::kKSteps + 2 * dsplit::kKSteps) * 64; i += gridDim.x * blockDim.x) {
+    constexpr int kImgItems = (split::kKSteps + 2 * dsplit::kKSteps) * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kImgItems + 128; i += gridDim.x * blockDim.x) {
         if (i < split::kKSteps * 64)
             prep_w2_split_item(i, W2, img);
-        else
+        else if (i < kImgItems)
             prep_w2_dgrad_split_item(i - split::kKSteps * 64, W2, img + split::kW2ImgU4);
+        else {
+            // sum |W2[co][ci][tap]| over the 16 co and the taps of parity class e: bounds |dz1| / max |dy2| for (ci, e); the data-gradient
+            // kernel takes the maximum to scale the layer-1 gradient into f16 range for its second contraction
+            const int j = i - kImgItems, ci = j & 15, e = j >> 4;
+            float a = 0.0f;
+            for (int q = 0; q < dsplit::ntaps(e); ++q)
+                for (int co = 0; co < kC; ++co) a += fabsf(W2[((size_t)co * kC + ci) * kTaps + dsplit::tap_index(e, q)]);
+            reinterpret_cast<float *>(img + 2 * split::kW2ImgU4)[j] = a;
+        }
     }
 }
 
@@ -535,11 +545,12 @@ template <int TY>
 __device__ __forceinline__ void dgrad_split_supertile(
     const char *dyst, const char *ybuf, const int8_t *slab0, const int8_t *slab1, const uint4 *wimg /*this lane's column of the class set's image, in LDS*/,
     int ai, int c, bool z1ok, bool y0ok, bool y1ok, int O1, bool tok1, float sc, float sh, float mu, float rs,
-    float unscale, float &s1, float &s2, f32x4 &T1a, f32x4 &T1b)
+    float unscale, float gscale, float &s1, float &s2, f32x4 &T1a, f32x4 &T1b)
 {
     using namespace dsplit;
     const int lane = threadIdx.x & (kWave - 1), m = lane & 15, g = lane >> 4;
     const bool second = (g >> 1) != 0;
+    h8 xs, xt, gh, gl;  // operands of the second contraction, filled class by class
     uint32_t rowslot[2];  // ring slot of dy2 row c - yo
 #pragma unroll
     for (int yo = 0; yo < 2; ++yo) rowslot[yo] = (uint32_t)((c - yo + kDyRing) % kDyRing);
@@ -570,28 +581,47 @@ __device__ __forceinline__ void dgrad_split_supertile(
             acc_lh = split::mfma_h(al, wh, acc_lh);
             acc_hl = split::mfma_h(ah, wl, acc_hl);
         }
-        const f32x4 acc = (acc_hh + (acc_lh + acc_hl)) * unscale;  // D[i = voxel 4g + r][j = ci = m]
+        const f32x4 raw = acc_hh + (acc_lh + acc_hl);  // D[i = voxel 4g + r][j = ci = m], scaled by gs 2^10
         uint32_t ylane = (uint32_t)((4 * g) * kYVox + m * 4);
         asm volatile("" : "+v"(ylane));
         const char *yrow = ybuf + ((2 * ai + ez) * 2 + ey) * kYRow + ex * kYHalf + ylane;
         const int kOff = ((2 * ez) * 5 + 2 * ey) * kSlabRow + 2 * ex;
+        float gsv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            // (the epilogue of dgrad_c1w_subtile: out-of-grid voxels are masked in the A operand and in g)
+            // (the epilogue of dgrad_c1w_subtile: out-of-grid voxels are masked in g, so they never reach the sums or T1)
             const bool ok = cls_ok && 2 * (4 * g + r) + ex < O1;  // x validity of voxel 4g + r (x = 2j + ex)
             const float y = ok ? *reinterpret_cast<const float *>(yrow + r * kYVox) : 0.0f;
-            const float gv = (ok && fmaf(sc, y, sh) > 0.0f) ? acc[r] : 0.0f;
+            const bool on = ok && fmaf(sc, y, sh) > 0.0f;
+            const float gv = on ? raw[r] * unscale : 0.0f;
             s1 += gv;
             s2 = fmaf(gv, (y - mu) * rs, s2);
-            const float a0v = (float)slab0[kOff + 4 * r], a1v = (float)slab1[kOff + 4 * r];
-            T1a = mfma4(ok ? a0v : 0.0f, gv, T1a);  // A[i = tap][k = voxel]
-            T1b = mfma4(ok && tok1 ? a1v : 0.0f, gv, T1b);
+            gsv[r] = on ? raw[r] * gscale : 0.0f;
+            xs[(ci & 1) * 4 + r] = (_Float16)(short)slab0[kOff + 4 * r];
+            xt[(ci & 1) * 4 + r] = tok1 ? (_Float16)(short)slab1[kOff + 4 * r] : (_Float16)0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            _Float16 a, b;
+            split::split2(gsv[r], a, b);
+            gh[(ci & 1) * 4 + r] = a;
+            gl[(ci & 1) * 4 + r] = b;
+        }
+        if (ci & 1) {
+            // conv1 weight gradient: T1[tap][ci] += sum over the 2 x 16 voxels of the class pair of x[voxel, tap] g[voxel][ci], on the
+            // f16 pipe as well: x in {-1, 0, 1} is exact in f16, g is split (scaled by `gscale` into f16 range); k = 32 =
+            // [class P voxels 4g .. 4g+3, class Q voxels 4g .. 4g+3] for both operands.  A[i = tap][k], B[k][j = ci].
+            T1a = split::mfma_h(xs, gh, T1a);
+            T1a = split::mfma_h(xs, gl, T1a);
+            T1b = split::mfma_h(xt, gh, T1b);
+            T1b = split::mfma_h(xt, gl, T1b);
         }
     }
 }
 
 __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
-    const float *__restrict__ dy2, const uint4 *__restrict__ w2img /*k_prep_w2_dgrad_split*/, const unsigned *__restrict__ absmax, const float *__restrict__ y1,
+    const float *__restrict__ dy2, const uint4 *__restrict__ w2img /*prep_w2_dgrad_split_item*/, const float *__restrict__ wbound /*[8 classes][16 ci]*/,
+    const unsigned *__restrict__ absmax, const float *__restrict__ y1,
     const float *__restrict__ scale1, const float *__restrict__ shift1, const float *__restrict__ mean1, const float *__restrict__ rstd1,
     const int8_t *__restrict__ grid_i8, const int64_t *__restrict__ rows, int64_t grid_row_stride, int B, int G, int O1, int O2,
     float *__restrict__ partial /*[blocks][kE1F]*/)
@@ -605,7 +635,7 @@ __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
     const bool live = sample_plane_group(B, NA, kPairs, b, a0, a1);
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(tid / kWave);
     const int m = lane & 15, kq = lane >> 4;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, t1_unscale = 0.0f;
     f32x4 T1a = {0.f, 0.f, 0.f, 0.f}, T1b = T1a;
     // (stale LDS may hold NaN patterns: the zero voxels around the dy2 rows and the rows of steps not yet staged must be finite)
     for (int i = tid; i < (kLdsBytes - kImgBytes) / 16; i += kThreads) reinterpret_cast<uint4 *>(split_lds)[i] = make_uint4(0, 0, 0, 0);
@@ -691,6 +721,14 @@ __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
         const int cw = wv, ai = cw >> 1, ty = cw & 1, a = a0 + ai;
         const float gs = grad_scale(absmax);
         const float unscale = 1.0f / (gs * split::kWScale);
+        // |raw| <= 2^14 (scaled max |dy2|) x 2^10 x max over (ci, class) of sum |W2|: scale it back under 2^14 for the f16 split
+        float wb = fmaxf(wbound[lane], wbound[64 + lane]);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) wb = fmaxf(wb, __shfl_xor(wb, d, 64));
+        int we = 0;
+        (void)frexpf(fmaxf(wb, 1.0e-30f), &we);  // wb < 2^we
+        const float gscale = ldexpf(1.0f, -(10 + we));
+        t1_unscale = ldexpf(1.0f, we) / gs;
         const uint4 *wimg = wlds + ty * kKSteps * 2 * 64 + lane;
         const float sc = scale1[m], sh = shift1[m], mu = mean1[m], rs = rstd1[m];
         const bool tok1 = 16 + m < kTaps;
@@ -726,7 +764,7 @@ __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
                 __builtin_amdgcn_sched_barrier(0);
                 const bool y0ok = 2 * c < O1, y1ok = 2 * c + 1 < O1;
                 const char *ybuf = ybufs + (c & 1) * kYBuf;
-                dgrad_split_supertile<TY>(dyst, ybuf, slab0, slab1, wimg, ai, c, z1ok, y0ok, y1ok, O1, tok1, sc, sh, mu, rs, unscale, s1, s2, T1a, T1b);
+                dgrad_split_supertile<TY>(dyst, ybuf, slab0, slab1, wimg, ai, c, z1ok, y0ok, y1ok, O1, tok1, sc, sh, mu, rs, unscale, gscale, s1, s2, T1a, T1b);
                 split_step_barrier();
             }
         };
@@ -736,6 +774,8 @@ __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
             run(std::integral_constant<int, 1>{});
     }
     // ---- workgroup-level sums: binary tree over the 8 compute waves (fixed order -> deterministic) ----
+    T1a *= t1_unscale;
+    T1b *= t1_unscale;
     s1 = kgroup_sum(s1);
     s2 = kgroup_sum(s2);
     __syncthreads();  // every wave is done with the staged rows (reused as the reduction buffer)
