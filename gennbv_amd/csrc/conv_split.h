@@ -818,3 +818,216 @@ __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
     float *out = partial + (size_t)blockIdx.x * kE1F;
     for (int o = tid; o < kE1F; o += kThreads) out[o] = fin[o];
 }
+
+
+// ---------------------------------------------------------------------------
+// Inference (BatchNorm in eval mode: rollout, evaluation): conv1 + BN1 + ReLU + conv2 in ONE kernel -- the layer-1 activations
+// never exist in global memory (2 x 488 MB per 256-env policy step otherwise: a write by conv1, a read by conv2).
+// Same workgroup, ring and compute waves as k_conv2_fwd_split; the staging waves COMPUTE the two new z1 rows of the 9 planes
+// instead of reading them: per step 36 tiles of 16 voxels x 16 channels, one `v_mfma_f32_16x16x32_f16` pair each
+// (A = W1 as f16 hi | lo x 2^10, M = channel, k = 27 taps padded to 32; B = the int8 input patch, exact in f16, N = voxel), then
+// bias + BN1 (running statistics) + ReLU, x 2^8, split, and an 8-byte store per lane into the ring -- the accumulator layout
+// (lane = voxel, 4 channels) is the ring's layout.  The int8 input rows an iteration needs (19 planes x 5 rows x 64 bytes = 6 KiB
+// instead of 36 KiB of y1) go through a double-buffered LDS slab: iteration j is requested at step j - 2 (one 16-byte request
+// per thread), stored at step j - 1 and computed at step j.
+// ---------------------------------------------------------------------------
+namespace fsplit {
+constexpr int kInPlanes = 2 * split::kNPl + 1;  // 19 input planes under the 9 z1 planes
+constexpr int kInRows = 5;                      // input rows 4j+2 .. 4j+6 under z1 rows 2j+1, 2j+2
+constexpr int kInRowBytes = 64, kInPlaneBytes = kInRows * kInRowBytes;
+constexpr int kInBuf = kInPlanes * kInPlaneBytes + 64;  // + slack: the padding voxel reads a byte past its row
+constexpr int kInPieces = kInPlanes * kInRows * 4;      // 16-byte pieces per iteration: 380 of the 512 staging threads
+constexpr int kTilesPerStep = 2 * split::kNPl * 2;      // (plane, row, x parity): 36
+constexpr float kW1Scale = 1024.0f;
+constexpr int kLdsBytes = split::kStageBytes + split::kPadBytes + split::kRedBytes + 2 * kInBuf;
+}  // namespace fsplit
+
+__global__ void k_prep_w2_split_only(const float *__restrict__ W2, float *__restrict__ w2img)
+{
+    prep_w2_split_in_passing(W2, w2img);
+}
+
+__global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_eval_split(
+    const int8_t *__restrict__ grid_i8, const int64_t *__restrict__ rows, int64_t grid_row_stride, const float *__restrict__ W1 /*[16][27]*/,
+    const float *__restrict__ b1, const float *__restrict__ scale1, const float *__restrict__ shift1, int B, int G, int O1, int O2,
+    const uint4 *__restrict__ w2img, const float *__restrict__ b2, float *__restrict__ y2)
+{
+    using namespace split;
+    using namespace fsplit;
+    extern __shared__ __attribute__((aligned(16))) char split_lds[];
+    char *stage = split_lds;
+    float *red = reinterpret_cast<float *>(split_lds + split::kStageBytes + kPadBytes);
+    char *inbuf = split_lds + split::kStageBytes + kPadBytes + kRedBytes;
+    int b, oz0, oz1;
+    const bool live = sample_plane_group(B, O2, kNP, b, oz0, oz1);
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+    if (!live) return;
+    const int np = oz1 - oz0;
+    const int nsteps = (O2 + 2) & ~1;
+    if (wv >= kConsWaves) {
+        // ---- staging waves: conv1 + BN1 + ReLU on the fly ----
+        const int ptid = tid - kConsWaves * kWave, pw = wv - kConsWaves;
+        const int n = lane & 15, g = lane >> 4;
+        // A operand: W1[ch = n][tap 8g + e] x 2^10, split
+        h8 wh, wl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int t = 8 * g + e;
+            _Float16 hi, lo;
+            split2(t < kTaps ? W1[n * kTaps + t] * kW1Scale : 0.0f, hi, lo);
+            wh[e] = hi;
+            wl[e] = lo;
+        }
+        // byte offset of tap 8g + e inside the slab, relative to the tile's (plane, row, column) origin
+        uint32_t tapoff[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int t = min(8 * g + e, kTaps - 1);
+            tapoff[e] = (uint32_t)((t / 9) * kInPlaneBytes + ((t / 3) % 3) * kInRowBytes + t % 3 + 4 * n);
+        }
+        float bb[4], sc[4], sh[4];  // channels 4g .. 4g+3 of this lane's accumulator rows
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bb[r] = b1[4 * g + r];
+            sc[r] = scale1[4 * g + r] * kZScale;
+            sh[r] = shift1[4 * g + r] * kZScale;
+        }
+        // input staging: piece f = ptid < 380 -> (plane f / 20, row (f / 4) % 5, 16-byte quarter f % 4)
+        const int f = min(ptid, kInPieces - 1), fpl = f / (kInRows * 4), frow = (f >> 2) % kInRows, fq = f & 3;
+        const int8_t *in = grid_i8 + (rows ? rows[b] : (int64_t)b) * grid_row_stride;
+        const int plane_g = min(4 * oz0 + fpl, G - 1);
+        auto in_req = [&](int j) {  // input rows 4j+2 .. 4j+6 (clamped; UNCONDITIONAL)
+            const int row_g = min(max(4 * j + 2 + frow, 0), G - 1);
+            return *reinterpret_cast<const uint4 *>(in + ((size_t)plane_g * G + row_g) * G + 16 * fq);
+        };
+        auto in_store = [&](int j, const uint4 &v) {
+            if (ptid < kInPieces) *reinterpret_cast<uint4 *>(inbuf + (j & 1) * kInBuf + fpl * kInPlaneBytes + frow * kInRowBytes + 16 * fq) = v;
+        };
+        auto compute = [&](int j) {
+            const char *ib = inbuf + (j & 1) * kInBuf;
+#pragma unroll
+            for (int k = 0; k < (kTilesPerStep + 7) / 8; ++k) {
+                const int T = pw + 8 * k;  // (wave-uniform)
+                if (T >= kTilesPerStep) continue;
+                const int pi = T >> 2, rsel = (T >> 1) & 1, par = T & 1;
+                const int8_t *origin = reinterpret_cast<const int8_t *>(ib) + (2 * pi) * kInPlaneBytes + (2 * rsel) * kInRowBytes + 2 * par;
+                h8 xb;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xb[e] = (_Float16)(short)origin[tapoff[e]];
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = mfma_h(wh, xb, acc);  // D[i = channel 4g + r][j = voxel n]
+                acc = mfma_h(wl, xb, acc);
+                h4 hi, lo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float y = acc[r] * (1.0f / kW1Scale) + bb[r];
+                    _Float16 a, c2;
+                    split2(__builtin_amdgcn_fmed3f(fmaf(sc[r], y, sh[r]), 0.f, kZMax), a, c2);
+                    hi[r] = a;
+                    lo[r] = c2;
+                }
+                const int row = 2 * j + 1 + rsel, slot = (row + kRing) % kRing;
+                char *dst = stage + (pi * kRing + slot) * kRowBytes + par * 1024 + n * 32 + g * 8;
+                *reinterpret_cast<h4 *>(dst) = hi;
+                *reinterpret_cast<h4 *>(dst + 512) = lo;
+            }
+        };
+        // prologue: three barriers (the compute waves run the same count)
+        uint4 ra = in_req(-1), rb = in_req(0);
+        in_store(-1, ra);
+        ra = in_req(1);
+        split_step_barrier();
+        compute(-1);
+        in_store(0, rb);
+        rb = in_req(2);
+        split_step_barrier();
+        compute(0);
+        in_store(1, ra);
+        ra = in_req(3);
+        split_step_barrier();
+        // step t: compute iteration t (slab t & 1), store iteration t + 1 (requested at step t - 1), request t + 3.  rb holds
+        // even iterations, ra odd ones.  Branch-free around the requests.
+        for (int t = 1; t <= nsteps; t += 2) {
+            compute(t);
+            in_store(t + 1, rb);
+            rb = in_req(t + 3);
+            split_step_barrier();
+            compute(t + 1);
+            in_store(t + 2, ra);
+            ra = in_req(t + 4);
+            split_step_barrier();
+        }
+    } else {
+        // ---- compute waves: exactly k_conv2_fwd_split's, without the BN2 partial sums ----
+        const int m = lane & 15, g = lane >> 4;
+        const int pl = wv >> 1, kh = wv & 1;
+        h8 wh[kKHalf], wl[kKHalf];
+#pragma unroll
+        for (int s = 0; s < kKHalf; ++s) {
+            const uint4 uh = w2img[((kh * kKHalf + s) * 2 + 0) * 64 + lane], ul = w2img[((kh * kKHalf + s) * 2 + 1) * 64 + lane];
+            wh[s] = *reinterpret_cast<const h8 *>(&uh);
+            wl[s] = *reinterpret_cast<const h8 *>(&ul);
+        }
+        const float bias = b2[m];
+        const int P2 = O2 * O2 * O2;
+        const uint32_t a_lane = (uint32_t)(2 * pl * kRing * kRowBytes + m * 32 + (g & 1) * 16);
+        const bool second = (g >> 1) != 0;
+        f32x4 prev = {0.f, 0.f, 0.f, 0.f};
+        float *const out_base = y2 + ((size_t)b * kC + m) * P2 + (size_t)(oz0 + pl) * O2 * O2;
+        split_step_barrier();
+        split_step_barrier();
+        split_step_barrier();
+        for (int t = 1; t <= nsteps; ++t) {
+            const int oy = t - 1;
+            if (kh == 0 && pl < np && oy >= 1 && oy - 1 < O2) {
+                const f32x4 other = *reinterpret_cast<const f32x4 *>(red + (((t - 1) & 1) * kNP + pl) * 256 + lane * 4);
+                const f32x4 acc = (prev + other) * (1.0f / (kZScale * kWScale));
+                float *out = out_base + (size_t)(oy - 1) * O2;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int oxi = 4 * g + rr;
+                    if (oxi < O2) out[oxi] = acc[rr] + bias;
+                }
+            }
+            if (pl < np && oy < O2) {
+                uint32_t rowoff[3];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) rowoff[dy] = (uint32_t)(((2 * oy + dy) % kRing) * kRowBytes);
+                auto tap_off = [&](int tp) {
+                    const int dz = tp / 9, dy = (tp / 3) % 3, dx = tp % 3;
+                    return (uint32_t)(dz * kRing * kRowBytes + (dx == 1 ? 1024 : 0) + (dx == 2 ? 32 : 0)) + rowoff[dy];
+                };
+                auto a_off = [&](int s) {
+                    const uint32_t ta = kh ? tap_off(2 * (kKHalf + s)) : tap_off(2 * s);
+                    const uint32_t tb = kh ? tap_off(min(2 * (kKHalf + s) + 1, kTaps - 1)) : tap_off(2 * s + 1);
+                    return a_lane + (second ? tb : ta);
+                };
+                f32x4 acc_hh = {0.f, 0.f, 0.f, 0.f}, acc_lh = acc_hh, acc_hl = acc_hh;
+                constexpr int kAhead = 2;
+                h8 ah[kAhead + 1], al[kAhead + 1];
+#pragma unroll
+                for (int s = 0; s < kAhead; ++s) {
+                    ah[s] = *reinterpret_cast<const h8 *>(stage + a_off(s));
+                    al[s] = *reinterpret_cast<const h8 *>(stage + a_off(s) + 512);
+                }
+#pragma unroll
+                for (int s = 0; s < kKHalf; ++s) {
+                    if (s + kAhead < kKHalf) {
+                        ah[(s + kAhead) % (kAhead + 1)] = *reinterpret_cast<const h8 *>(stage + a_off(s + kAhead));
+                        al[(s + kAhead) % (kAhead + 1)] = *reinterpret_cast<const h8 *>(stage + a_off(s + kAhead) + 512);
+                    }
+                    acc_hh = mfma_h(ah[s % (kAhead + 1)], wh[s], acc_hh);
+                    acc_lh = mfma_h(al[s % (kAhead + 1)], wh[s], acc_lh);
+                    acc_hl = mfma_h(ah[s % (kAhead + 1)], wl[s], acc_hl);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const f32x4 part = acc_hh + (acc_lh + acc_hl);
+                if (kh)
+                    *reinterpret_cast<f32x4 *>(red + ((t & 1) * kNP + pl) * 256 + lane * 4) = part;
+                else
+                    prev = part;
+            }
+            split_step_barrier();
+        }
+    }
+}

@@ -2084,7 +2084,25 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     const bool z1 = z1_path(p, grid), qm = y1_quad_major(p, grid);
     const bool dp = training && p->world > 1 && p->sync_sum != nullptr && p->sync_buf != nullptr;  // BatchNorm over the replicas' global minibatch
     if (dp && z1) return (int)hipErrorInvalidValue;
-    if (z1) {
+    // Inference with the grid as int8 rows at G = 64: conv1 + BN1 + ReLU + conv2 in one kernel, no layer-1 buffer at all
+    // (conv_split.h).  y1 is left untouched (no backward follows an eval-mode forward).
+    const bool fused_eval = !training && !z1 && !qm && conv_split_path(p, grid) && conv1_i8_staged(p, grid) && grid == 64 && !env_off("GENNBV_FUSED_EVAL");
+    if (fused_eval) {
+        hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps, p->momentum, p->bn1_rm,
+                           p->bn1_rv, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC);
+        hipLaunchKernelGGL(k_prep_w2_split_only, dim3(12), dim3(256), 0, st, p->w2, w.w2img);
+        if ((err = gnbv_launch_status())) return err;
+        static bool attr_fe = false;
+        if (!attr_fe) {
+            const hipError_t e = hipFuncSetAttribute((const void *)k_conv12_fwd_eval_split, hipFuncAttributeMaxDynamicSharedMemorySize, fsplit::kLdsBytes);
+            if (e != hipSuccess) return (int)e;
+            attr_fe = true;
+        }
+        hipLaunchKernelGGL(k_conv12_fwd_eval_split, dim3(sample_plane_group_grid(batch, O2, split::kNP)), dim3(split::kThreads), fsplit::kLdsBytes, st,
+                           p->grid_i8, rows, p->grid_i8_row_stride, p->w1, p->b1, (const float *)bn1, (const float *)(bn1 + kC), batch, grid, O1, O2,
+                           (const uint4 *)w.w2split, p->b2, y2);
+        if ((err = gnbv_launch_status())) return err;
+    } else if (z1) {
         // BN1 scale / shift first (training: analytic batch statistics from the input autocorrelation; eval: running
         // statistics), then conv1 with the BN + ReLU epilogue: the layer-1 buffer holds z1
         if (training) {
@@ -2157,7 +2175,9 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     }
     // conv2 (BN1 + ReLU on load; + BN2 statistics).  Its LDS weight images were written by the conv1 kernel in passing.
     int g2 = sample_plane_group_grid(batch, O2, kPlanesPerGroup);
-    if (p->act_bf16) {
+    if (fused_eval) {
+        // (y2 was written by k_conv12_fwd_eval_split above)
+    } else if (p->act_bf16) {
         hipLaunchKernelGGL(k_conv2_fwd<ActBF16>, dim3(g2), dim3(kFwdThreads), 0, st, (const uint16_t *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
                        training ? w.bn_part : nullptr);
     } else if (!z1 && !qm && conv_split_path(p, grid)) {

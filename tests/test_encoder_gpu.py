@@ -382,3 +382,36 @@ def test_compact_observation_rows_match_flat_rows(g, b, train, monkeypatch):
             assert torch.equal(a, c)
         else:
             assert torch.allclose(a, c, rtol=1e-4, atol=1e-6), float((a - c).abs().max())
+
+
+@pytest.mark.parametrize("b", [3, 128])
+def test_fused_eval_conv1_conv2_vs_fp64_and_the_two_kernel_path(b, monkeypatch):
+    """Inference at G = 64 with the grid as int8 rows: k_conv12_fwd_eval_split (conv1 + BN1 + ReLU + conv2 in one launch, the
+    layer-1 activations never stored; csrc/conv_split.h) against the fp64 torch modules in eval mode (running statistics) and
+    against the two-kernel path (GENNBV_FUSED_EVAL=0: k_conv1_fwd_lds + k_conv2_fwd_split)."""
+    from gennbv_amd.ops import encoder_ops
+    g = 64
+    hip, _, _ = pu.make_policy(g=g, device=DEV, backend="hip", det_weights=True)
+    seq = hip.features_extractor.naive_encoder_grid
+    gen = torch.Generator().manual_seed(7 + b)
+    with torch.no_grad():  # non-trivial running statistics
+        for bn in (seq[1], seq[4]):
+            bn.running_mean.copy_(torch.randn(16, generator=gen) * 0.2)
+            bn.running_var.copy_(torch.rand(16, generator=gen) + 0.5)
+    n = 2 * b + 1
+    grid_i8 = (torch.randint(-1, 2, (n, g ** 3), generator=gen) * (torch.rand(n, g ** 3, generator=gen) < 0.4)).to(torch.int8).to(DEV)
+    small = torch.randn(n, 600 + 8192, generator=gen).to(DEV)
+    rows = torch.randperm(n, generator=gen)[:b].to(DEV)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GENNBV_FUSED_EVAL", mode)
+        with torch.no_grad():
+            outs[mode] = encoder_ops.grid_encoder(small, rows, 600, g, seq, False, grid_i8=grid_i8, compact=True).double().cpu()
+    import copy
+    ref = copy.deepcopy(seq).double().cpu().eval()
+    with torch.no_grad():
+        want = ref(grid_i8[rows].double().cpu().view(b, 1, g, g, g)).reshape(b, -1)
+    scale = float(want.abs().max())
+    for mode in ("1", "0"):
+        assert float((outs[mode] - want).abs().max()) <= 2e-5 * scale + 1e-6, (mode, float((outs[mode] - want).abs().max()), scale)
+    assert float((outs["1"] - outs["0"]).abs().max()) <= 1e-5 * scale
