@@ -1031,3 +1031,67 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_eval_split(
         }
     }
 }
+
+
+// ---------------------------------------------------------------------------
+// conv1 forward (training, y1 stored): the staging arithmetic of k_conv12_fwd_eval_split as a kernel of its own.
+// Workgroup = (sample, output plane): the three int8 input planes under it (12 KiB, kept as int8) go to LDS once; 62 tiles of
+// 16 voxels x 16 channels (31 rows x 2 x parities), two `v_mfma_f32_16x16x32_f16` each (W1 split x 2^10, the input exact)
+// instead of seven fp32 MFMAs twice as long, + bias, and a 16-byte store per lane (4 channels of one voxel) into the
+// x-parity-split y1 layout.  The fp32 kernel spends 25 us of a 72 us launch in the matrix pipe and holds a 48 KiB fp32 slab
+// (3 workgroups per CU); this one is the 244 MB write.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_split(
+    const int8_t *__restrict__ grid_i8, const int64_t *__restrict__ rows, int64_t grid_row_stride, int B, int G, int O1, const float *__restrict__ W1,
+    const float *__restrict__ b1, float *__restrict__ y1, const float *__restrict__ W2, float *__restrict__ w2img)
+{
+    using namespace split;
+    prep_w2_in_passing(W2, w2img);
+    __shared__ __attribute__((aligned(16))) int8_t s_in[3 * 64 * 64 + 64];  // (G = 64) + slack: the padding voxel reads past its row
+    int b, oz;
+    if (!sample_plane(B, O1, b, oz)) return;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int n = lane & 15, g = lane >> 4;
+    const int8_t *in = grid_i8 + (rows ? rows[b] : (int64_t)b) * grid_row_stride + (size_t)(2 * oz) * G * G;
+    {   // 3 planes x 4 KiB = 768 16-byte pieces, three per thread, all requested before the first is stored
+        uint4 v[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) v[u] = *reinterpret_cast<const uint4 *>(in + 16 * (u * kEncThreads + tid));
+#pragma unroll
+        for (int u = 0; u < 3; ++u) reinterpret_cast<uint4 *>(s_in)[u * kEncThreads + tid] = v[u];
+        if (tid < 4) reinterpret_cast<uint4 *>(s_in)[768 + tid] = make_uint4(0, 0, 0, 0);
+    }
+    h8 wh, wl;  // A operand: W1[ch = n][tap 8g + e] x 2^10, split
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int t = 8 * g + e;
+        _Float16 hi, lo;
+        split2(t < kTaps ? W1[n * kTaps + t] * fsplit::kW1Scale : 0.0f, hi, lo);
+        wh[e] = hi;
+        wl[e] = lo;
+    }
+    uint32_t tapoff[8];  // byte offset of tap 8g + e of voxel n relative to the tile's (row, parity) origin
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int t = min(8 * g + e, kTaps - 1);
+        tapoff[e] = (uint32_t)((t / 9) * G * G + ((t / 3) % 3) * G + t % 3 + 4 * n);
+    }
+    const float4 bias = *reinterpret_cast<const float4 *>(b1 + 4 * g);
+    __syncthreads();
+    for (int T = wv; T < 2 * O1; T += kEncWaves) {  // tile = (row oy, x parity)
+        const int oy = T >> 1, par = T & 1;
+        const int8_t *origin = s_in + (2 * oy) * G + 2 * par;
+        h8 xb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xb[e] = (_Float16)(short)origin[tapoff[e]];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mfma_h(wh, xb, acc);  // D[i = channel 4g + r][j = voxel n]
+        acc = mfma_h(wl, xb, acc);
+        const int x = 2 * n + par;
+        if (x < O1) {
+            const float s = 1.0f / fsplit::kW1Scale;
+            *reinterpret_cast<float4 *>(y1 + (size_t)vox1(b, oz, oy, x, O1) * kC + 4 * g) =
+                make_float4(acc[0] * s + bias.x, acc[1] * s + bias.y, acc[2] * s + bias.z, acc[3] * s + bias.w);
+        }
+    }
+}

@@ -2145,6 +2145,9 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
         if (qm)
             hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, int8_t, false, true>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, p->grid_i8, rows,
                                p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, nozs, nozs, p->w2, w.w2img);
+        else if (conv1_i8_staged(p, grid) && c1_part == nullptr && grid == 64 && conv_split_path(p, grid) && !env_off("GENNBV_CONV1_SPLIT"))  // (no partial sums: BN1 is analytic or in eval mode)
+            hipLaunchKernelGGL(k_conv1_fwd_split, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, p->grid_i8, rows, p->grid_i8_row_stride, batch, grid,
+                               O1, p->w1, p->b1, (float *)y1, p->w2, w.w2img);
         else if (conv1_i8_staged(p, grid))  // compact int8 copy of the tri-class grid: a quarter of the input bytes
             hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, int8_t>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, p->grid_i8, rows,
                                p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, nozs, nozs, p->w2, w.w2img);
