@@ -544,13 +544,14 @@ __device__ void prep_w2_split_in_passing(const float *__restrict__ W2, float *__
 template <int TY>
 __device__ __forceinline__ void dgrad_split_supertile(
     const char *dyst, const char *ybuf, const int8_t *slab0, const int8_t *slab1, const uint4 *wimg /*this lane's column of the class set's image, in LDS*/,
-    int ai, int c, bool z1ok, bool y0ok, bool y1ok, int O1, bool tok1, float sc, float sh, float mu, float rs,
-    float unscale, float gscale, float &s1, float &s2, f32x4 &T1a, f32x4 &T1b)
+    int ai, int c, bool z1ok, bool y0ok, bool y1ok, int O1, bool tok1, float sc, float sh,
+    float gscale, float &s2, f32x4 &T1a, f32x4 &T1b)
 {
     using namespace dsplit;
     const int lane = threadIdx.x & (kWave - 1), m = lane & 15, g = lane >> 4;
     const bool second = (g >> 1) != 0;
     h8 xs, xt, gh, gl;  // operands of the second contraction, filled class by class
+    const _Float16 ones_row = m == (kTaps - 16) ? (_Float16)1.0f : (_Float16)0.0f;  // A row 27 (lane m = 11 of the second tap tile)
     uint32_t rowslot[2];  // ring slot of dy2 row c - yo
 #pragma unroll
     for (int yo = 0; yo < 2; ++yo) rowslot[yo] = (uint32_t)((c - yo + kDyRing) % kDyRing);
@@ -592,13 +593,11 @@ __device__ __forceinline__ void dgrad_split_supertile(
             // (the epilogue of dgrad_c1w_subtile: out-of-grid voxels are masked in g, so they never reach the sums or T1)
             const bool ok = cls_ok && 2 * (4 * g + r) + ex < O1;  // x validity of voxel 4g + r (x = 2j + ex)
             const float y = ok ? *reinterpret_cast<const float *>(yrow + r * kYVox) : 0.0f;
-            const bool on = ok && fmaf(sc, y, sh) > 0.0f;
-            const float gv = on ? raw[r] * unscale : 0.0f;
-            s1 += gv;
-            s2 = fmaf(gv, (y - mu) * rs, s2);
-            gsv[r] = on ? raw[r] * gscale : 0.0f;
+            gsv[r] = (ok && fmaf(sc, y, sh) > 0.0f) ? raw[r] * gscale : 0.0f;  // g, scaled into f16 range
+            s2 = fmaf(gsv[r], y, s2);                                          // sum g y: S2 = rstd (sum g y - mean S1), after the loop
             xs[(ci & 1) * 4 + r] = (_Float16)(short)slab0[kOff + 4 * r];
-            xt[(ci & 1) * 4 + r] = tok1 ? (_Float16)(short)slab1[kOff + 4 * r] : (_Float16)0.0f;
+            // second tap tile: taps 16 .. 26, and a ROW OF ONES at index 27 -- its row of T1 is sum g = S1, for free
+            xt[(ci & 1) * 4 + r] = tok1 ? (_Float16)(short)slab1[kOff + 4 * r] : ones_row;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -635,7 +634,7 @@ __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
     const bool live = sample_plane_group(B, NA, kPairs, b, a0, a1);
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(tid / kWave);
     const int m = lane & 15, kq = lane >> 4;
-    float s1 = 0.f, s2 = 0.f, t1_unscale = 0.0f;
+    float s1 = 0.f, s2 = 0.f, t1_unscale = 0.0f, g_unscale = 0.0f;
     f32x4 T1a = {0.f, 0.f, 0.f, 0.f}, T1b = T1a;
     // (stale LDS may hold NaN patterns: the zero voxels around the dy2 rows and the rows of steps not yet staged must be finite)
     for (int i = tid; i < (kLdsBytes - kImgBytes) / 16; i += kThreads) reinterpret_cast<uint4 *>(split_lds)[i] = make_uint4(0, 0, 0, 0);
@@ -720,7 +719,6 @@ __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
         // ---- compute waves ----
         const int cw = wv, ai = cw >> 1, ty = cw & 1, a = a0 + ai;
         const float gs = grad_scale(absmax);
-        const float unscale = 1.0f / (gs * split::kWScale);
         // |raw| <= 2^14 (scaled max |dy2|) x 2^10 x max over (ci, class) of sum |W2|: scale it back under 2^14 for the f16 split
         float wb = fmaxf(wbound[lane], wbound[64 + lane]);
 #pragma unroll
@@ -729,8 +727,9 @@ __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
         (void)frexpf(fmaxf(wb, 1.0e-30f), &we);  // wb < 2^we
         const float gscale = ldexpf(1.0f, -(10 + we));
         t1_unscale = ldexpf(1.0f, we) / gs;
+        g_unscale = t1_unscale;  // (g was scaled by gscale = 2^-(10 + we) on top of gs 2^10)
         const uint4 *wimg = wlds + ty * kKSteps * 2 * 64 + lane;
-        const float sc = scale1[m], sh = shift1[m], mu = mean1[m], rs = rstd1[m];
+        const float sc = scale1[m], sh = shift1[m];
         const bool tok1 = 16 + m < kTaps;
         const int t1 = tok1 ? 16 + m : 0;
         int8_t *slab = reinterpret_cast<int8_t *>(slabs + cw * kSlabStride);
@@ -764,7 +763,7 @@ __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
                 __builtin_amdgcn_sched_barrier(0);
                 const bool y0ok = 2 * c < O1, y1ok = 2 * c + 1 < O1;
                 const char *ybuf = ybufs + (c & 1) * kYBuf;
-                dgrad_split_supertile<TY>(dyst, ybuf, slab0, slab1, wimg, ai, c, z1ok, y0ok, y1ok, O1, tok1, sc, sh, mu, rs, unscale, gscale, s1, s2, T1a, T1b);
+                dgrad_split_supertile<TY>(dyst, ybuf, slab0, slab1, wimg, ai, c, z1ok, y0ok, y1ok, O1, tok1, sc, sh, gscale, s2, T1a, T1b);
                 split_step_barrier();
             }
         };
@@ -776,8 +775,13 @@ __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
     // ---- workgroup-level sums: binary tree over the 8 compute waves (fixed order -> deterministic) ----
     T1a *= t1_unscale;
     T1b *= t1_unscale;
+    // S1 = row 27 of T1 (the ones row): D[i = tap 16 + 4 kq + r][j = ci = m] -> lanes kq = 2, r = 3; S2 = rstd (sum g y - mean S1)
+    s1 = __shfl(T1b[3], 32 + m, 64);
+    s2 = kgroup_sum(s2) * g_unscale;
+    if (live && wv < split::kConsWaves) s2 = rstd1[m] * (s2 - mean1[m] * s1);
+    if (kq != 0) s1 = 0.0f;  // (kgroup_sum below adds the four k-groups: keep one copy)
     s1 = kgroup_sum(s1);
-    s2 = kgroup_sum(s2);
+    if (kq == 2) T1b[3] = 0.0f;  // (row 27 is not a tap)
     __syncthreads();  // every wave is done with the staged rows (reused as the reduction buffer)
     constexpr int kSlot = 2 * kWave * 4 + 2 * kC;  // floats per wave slot
     float *red = reinterpret_cast<float *>(split_lds);
