@@ -308,8 +308,13 @@ __device__ __forceinline__ float grad_scale(const unsigned *absmax)
     const float amax = __uint_as_float(bits);
     int e = 0;
     (void)frexpf(amax, &e);  // amax = f 2^e, f in [0.5, 1)
-    return amax > 0.0f && amax < 3.0e38f ? ldexpf(1.0f, split::kGradBits - e) : 1.0f;
+    const float sc = amax > 0.0f && amax < 3.0e38f ? ldexpf(1.0f, split::kGradBits - e) : 1.0f;
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sc)));  // (the same in every lane: keep it in a scalar register)
 }
+
+// 1 / p for p an exact power of two (the scales above): an exponent flip instead of a division, whose scale / fixup temporaries the
+// compiler kept alive across the whole kernel (and spilled)
+__device__ __forceinline__ float inv_pow2(float p) { return __int_as_float(0x7f000000 - __float_as_int(p)); }
 
 __global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_split(
     const float *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1, const float *__restrict__ dy2 /*[B,O2^3,16]*/,
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_split(
             }
             split_step_barrier();
         }
-        const float unscale = 1.0f / (kZScale * gs);
+        const float unscale = (1.0f / kZScale) * inv_pow2(gs);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i < ntaps) {
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_split(
                 for (int r = 0; r < 4; ++r) out[tp * 256 + (4 * g + r) * kC + n] = acc[i][r] * unscale;
             }
         }
-        if (cw == 7 && g == 0) out[kTaps * 256 + n] = acc[3][0] * (1.0f / gs);
+        if (cw == 7 && g == 0) out[kTaps * 256 + n] = acc[3][0] * inv_pow2(gs);
     }
 }
 
@@ -466,19 +471,25 @@ constexpr int kYVox = 80, kYHalf = 16 * kYVox, kYRow = 2 * kYHalf, kYBuf = 2 * 2
 constexpr int kDyHalf = 18 * 32, kDyRow = 2 * kDyHalf, kDyPlanes = kPairs + 1, kDyRing = 3;
 constexpr int kDyBytes = kDyPlanes * kDyRing * kDyRow;
 constexpr int kSlabStride = 2048;
-constexpr int kKSteps = 7;
-constexpr int kImgBytes = 2 * kKSteps * 2 * 64 * 16;  // the B-operand image (both class sets): 28 672
-constexpr int kLdsBytes = 2 * kYBuf + kDyBytes + split::kConsWaves * kSlabStride + kImgBytes;
-constexpr int kThreads = 768, kProdThreads = 256;  // 8 compute + 4 staging waves: three per SIMD -> 168 registers (the 1024-thread version spilled)
+constexpr int kSets = 3, kKSteps = 5;       // class sets per plane pair / k-steps per set (the image's stride)
+constexpr int kConsWaves = kPairs * kSets;  // 12 compute waves
+constexpr int kImgU4 = kSets * kKSteps * 2 * 64, kImgBytes = kImgU4 * 16;  // the B-operand image (all class sets): 30 720
+constexpr int kImgSlotU4 = 2048;            // its slot in the encoder workspace (behind the forward image)
+constexpr int kLdsBytes = 2 * kYBuf + kDyBytes + kConsWaves * kSlabStride + kImgBytes;
+constexpr int kThreads = 1024, kProdThreads = 256;  // 12 compute + 4 staging waves, four per SIMD (<= 128 registers)
 constexpr int kYSlots = 2 * 2 * kPairs * 128 / kProdThreads;  // 16-byte requests per staging thread and step: 8
 constexpr int kDySlots = (kDyPlanes * 64 + kProdThreads - 1) / kProdThreads;  // 2
-__host__ __device__ constexpr int cls(int ty, int ci) { return ty == 0 ? (ci == 0 ? 0 : ci == 1 ? 3 : ci == 2 ? 5 : 6) : (ci == 0 ? 1 : ci == 1 ? 2 : ci == 2 ? 4 : 7); }
+// set 0 = classes {000, 111} (4 + 1 k-steps), set 1 = {001, 010, 011} (2 + 2 + 1), set 2 = {100, 101, 110} (2 + 1 + 1): at most three
+// class epilogues per wave (the epilogue's instruction issue bounds the kernel)
+__host__ __device__ constexpr int ncls(int ty) { return ty == 0 ? 2 : 3; }
+__host__ __device__ constexpr int cls(int ty, int ci) { return ty == 0 ? (ci == 0 ? 0 : 7) : ty == 1 ? 1 + ci : 4 + ci; }
 __host__ __device__ constexpr int ntaps(int e) { return ((e & 4) ? 1 : 2) * ((e & 2) ? 1 : 2) * ((e & 1) ? 1 : 2); }
 __host__ __device__ constexpr int ksteps(int e) { return (ntaps(e) + 1) / 2; }
 // (closed form, NOT a recursion: the recursive version was not folded after unrolling -- a real, recursive function call per class)
-__host__ __device__ constexpr int first_kstep(int ty, int ci) { return ty == 0 ? (ci == 0 ? 0 : 3 + ci) : 2 * ci; }
-static_assert(first_kstep(0, 1) == ksteps(cls(0, 0)) && first_kstep(0, 2) == first_kstep(0, 1) + ksteps(cls(0, 1)) && first_kstep(0, 3) == first_kstep(0, 2) + ksteps(cls(0, 2)), "prefix sums, set X");
-static_assert(first_kstep(1, 1) == ksteps(cls(1, 0)) && first_kstep(1, 2) == first_kstep(1, 1) + ksteps(cls(1, 1)) && first_kstep(1, 3) == first_kstep(1, 2) + ksteps(cls(1, 2)), "prefix sums, set Y");
+__host__ __device__ constexpr int first_kstep(int ty, int ci) { return ty == 0 ? 4 * ci : ty == 1 ? 2 * ci : (ci == 0 ? 0 : 1 + ci); }
+static_assert(first_kstep(0, 1) == ksteps(cls(0, 0)) && first_kstep(0, 1) + ksteps(cls(0, 1)) <= kKSteps, "prefix sums, set 0");
+static_assert(first_kstep(1, 1) == ksteps(cls(1, 0)) && first_kstep(1, 2) == first_kstep(1, 1) + ksteps(cls(1, 1)) && first_kstep(1, 2) + ksteps(cls(1, 2)) <= kKSteps, "prefix sums, set 1");
+static_assert(first_kstep(2, 1) == ksteps(cls(2, 0)) && first_kstep(2, 2) == first_kstep(2, 1) + ksteps(cls(2, 1)) && first_kstep(2, 2) + ksteps(cls(2, 2)) <= kKSteps, "prefix sums, set 2");
 // tap q of class e: which neighbour (zo, yo, xo) of dy2 it reads, and its index in the 3 x 3 x 3 kernel
 __host__ __device__ constexpr int tap_xo(int e, int q) { return q % ((e & 1) ? 1 : 2); }
 __host__ __device__ constexpr int tap_yo(int e, int q) { return (q / ((e & 1) ? 1 : 2)) % ((e & 2) ? 1 : 2); }
@@ -487,7 +498,6 @@ __host__ __device__ constexpr int tap_index(int e, int q)
 {
     return (((e & 4) ? 1 : 2 * tap_zo(e, q)) * 3 + ((e & 2) ? 1 : 2 * tap_yo(e, q))) * 3 + ((e & 1) ? 1 : 2 * tap_xo(e, q));
 }
-static_assert(first_kstep(0, 3) + ksteps(cls(0, 3)) == kKSteps && first_kstep(1, 3) + ksteps(cls(1, 3)) == kKSteps, "7 k-steps per class set");
 }  // namespace dsplit
 
 // dgrad B-operand image: [class set 2][k-step 7][hi | lo][lane = 16 g + n][j] = 2^10 W2[co = 8 (g & 1) + j][ci = n][tap(g >> 1)]
@@ -498,13 +508,14 @@ __device__ __forceinline__ void prep_w2_dgrad_split_item(int i, const float *__r
     using namespace dsplit;
     const int ty = i / (kKSteps * 64), s = (i >> 6) % kKSteps, lane = i & 63, n = lane & 15, g = lane >> 4;
     int e = 0, ls = s;
-    for (int ci = 0; ci < 4; ++ci) {
+    bool used = false;  // (set 2 uses four of its five k-step slots)
+    for (int ci = 0; ci < ncls(ty); ++ci) {
         e = cls(ty, ci);
-        if (ls < ksteps(e)) break;
+        if (ls < ksteps(e)) { used = true; break; }
         ls -= ksteps(e);
     }
     const int q = 2 * ls + (g >> 1);
-    const bool has = q < ntaps(e);
+    const bool has = used && q < ntaps(e);
     const int tap = has ? tap_index(e, q) : 0, c0 = 8 * (g & 1);
     h8 vh, vl;
 #pragma unroll
@@ -523,7 +534,7 @@ __device__ __forceinline__ void prep_w2_dgrad_split_item(int i, const float *__r
 __device__ void prep_w2_split_in_passing(const float *__restrict__ W2, float *__restrict__ w2img)
 {
     uint4 *img = reinterpret_cast<uint4 *>(w2img + 2 * kTaps * 256);  // EncWs::w2split
-    constexpr int kImgItems = (split::kKSteps + 2 * dsplit::kKSteps) * 64;
+    constexpr int kImgItems = (split::kKSteps + dsplit::kSets * dsplit::kKSteps) * 64;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kImgItems + 128; i += gridDim.x * blockDim.x) {
         if (i < split::kKSteps * 64)
             prep_w2_split_item(i, W2, img);
@@ -536,7 +547,7 @@ __device__ void prep_w2_split_in_passing(const float *__restrict__ W2, float *__
             float a = 0.0f;
             for (int q = 0; q < dsplit::ntaps(e); ++q)
                 for (int co = 0; co < kC; ++co) a += fabsf(W2[((size_t)co * kC + ci) * kTaps + dsplit::tap_index(e, q)]);
-            reinterpret_cast<float *>(img + 2 * split::kW2ImgU4)[j] = a;
+            reinterpret_cast<float *>(img + split::kW2ImgU4 + dsplit::kImgSlotU4)[j] = a;
         }
     }
 }
@@ -562,7 +573,7 @@ __device__ __forceinline__ void dgrad_split_supertile(
     asm volatile("" : "+s"(ai));  // (same for the scalar plane offsets: 28 hoisted SGPRs overflowed into a spill register that itself spilled)
     asm volatile("" : "+s"(O1));  // (and for the eight x-validity masks, two SGPRs each)
 #pragma unroll
-    for (int ci = 0; ci < 4; ++ci) {
+    for (int ci = 0; ci < ncls(TY); ++ci) {
         const int e = cls(TY, ci), ez = (e >> 2) & 1, ey = (e >> 1) & 1, ex = e & 1;
         // sub-tiles on out-of-grid planes / rows (the last plane pair / row pair only) are computed and masked, not skipped: a
         // branch here would end the basic block and keep the scheduler from overlapping one class's LDS latencies with the next
@@ -606,7 +617,11 @@ __device__ __forceinline__ void dgrad_split_supertile(
             gh[(ci & 1) * 4 + r] = a;
             gl[(ci & 1) * 4 + r] = b;
         }
-        if (ci & 1) {
+        if (!(ci & 1) && ci == ncls(TY) - 1) {  // a set's unpaired last class: the second half of the k = 32 stays empty
+#pragma unroll
+            for (int r = 4; r < 8; ++r) xs[r] = xt[r] = gh[r] = gl[r] = (_Float16)0.0f;
+        }
+        if ((ci & 1) || ci == ncls(TY) - 1) {
             // conv1 weight gradient: T1[tap][ci] += sum over the 2 x 16 voxels of the class pair of x[voxel, tap] g[voxel][ci], on the
             // f16 pipe as well: x in {-1, 0, 1} is exact in f16, g is split (scaled by `gscale` into f16 range); k = 32 =
             // [class P voxels 4g .. 4g+3, class Q voxels 4g .. 4g+3] for both operands.  A[i = tap][k], B[k][j = ci].
@@ -628,7 +643,7 @@ __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
     using namespace dsplit;
     extern __shared__ __attribute__((aligned(16))) char split_lds[];
     char *ybufs = split_lds, *dyst = split_lds + 2 * kYBuf, *slabs = dyst + kDyBytes;
-    uint4 *wlds = reinterpret_cast<uint4 *>(slabs + split::kConsWaves * kSlabStride);
+    uint4 *wlds = reinterpret_cast<uint4 *>(slabs + kConsWaves * kSlabStride);
     const int NA = (O1 + 1) >> 1;  // 16 plane pairs / row pairs / voxels per x parity
     int b, a0, a1;
     const bool live = sample_plane_group(B, NA, kPairs, b, a0, a1);
@@ -641,9 +656,9 @@ __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
     for (int i = tid; i < kImgBytes / 16; i += kThreads) wlds[i] = w2img[i];
     __syncthreads();
     const int nsteps = NA;  // 16 row pairs (even)
-    if (live && wv >= split::kConsWaves) {
+    if (live && wv >= kConsWaves) {
         // ---- staging waves ----
-        const int ptid = tid - split::kConsWaves * kWave;
+        const int ptid = tid - kConsWaves * kWave;
         const float gs = grad_scale(absmax);
         const int P2 = O2 * O2 * O2;
         const uint32_t rowC = 2 * 16 * kC, planeC = rowC * O1;
@@ -717,7 +732,7 @@ __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
 #undef GNBV_DS_STORE
     } else if (live) {
         // ---- compute waves ----
-        const int cw = wv, ai = cw >> 1, ty = cw & 1, a = a0 + ai;
+        const int cw = wv, ai = cw / kSets, ty = cw - ai * kSets, a = a0 + ai;
         const float gs = grad_scale(absmax);
         // |raw| <= 2^14 (scaled max |dy2|) x 2^10 x max over (ci, class) of sum |W2|: scale it back under 2^14 for the f16 split
         float wb = fmaxf(wbound[lane], wbound[64 + lane]);
@@ -725,8 +740,9 @@ __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
         for (int d = 1; d < 64; d <<= 1) wb = fmaxf(wb, __shfl_xor(wb, d, 64));
         int we = 0;
         (void)frexpf(fmaxf(wb, 1.0e-30f), &we);  // wb < 2^we
+        we = __builtin_amdgcn_readfirstlane(we);
         const float gscale = ldexpf(1.0f, -(10 + we));
-        t1_unscale = ldexpf(1.0f, we) / gs;
+        t1_unscale = ldexpf(1.0f, we) * inv_pow2(gs);
         g_unscale = t1_unscale;  // (g was scaled by gscale = 2^-(10 + we) on top of gs 2^10)
         const uint4 *wimg = wlds + ty * kKSteps * 2 * 64 + lane;
         const float sc = scale1[m], sh = shift1[m];
@@ -769,16 +785,18 @@ __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
         };
         if (ty == 0)
             run(std::integral_constant<int, 0>{});
-        else
+        else if (ty == 1)
             run(std::integral_constant<int, 1>{});
+        else
+            run(std::integral_constant<int, 2>{});
     }
-    // ---- workgroup-level sums: binary tree over the 8 compute waves (fixed order -> deterministic) ----
+    // ---- workgroup-level sums: binary tree over the 16 waves (the staging waves add zeros; fixed order -> deterministic) ----
     T1a *= t1_unscale;
     T1b *= t1_unscale;
     // S1 = row 27 of T1 (the ones row): D[i = tap 16 + 4 kq + r][j = ci = m] -> lanes kq = 2, r = 3; S2 = rstd (sum g y - mean S1)
     s1 = __shfl(T1b[3], 32 + m, 64);
     s2 = kgroup_sum(s2) * g_unscale;
-    if (live && wv < split::kConsWaves) s2 = rstd1[m] * (s2 - mean1[m] * s1);
+    if (live && wv < kConsWaves) s2 = rstd1[m] * (s2 - mean1[m] * s1);
     if (kq != 0) s1 = 0.0f;  // (kgroup_sum below adds the four k-groups: keep one copy)
     s1 = kgroup_sum(s1);
     if (kq == 2) T1b[3] = 0.0f;  // (row 27 is not a tap)
@@ -786,7 +804,7 @@ __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
     constexpr int kSlot = 2 * kWave * 4 + 2 * kC;  // floats per wave slot
     float *red = reinterpret_cast<float *>(split_lds);
 #pragma unroll
-    for (int half = split::kConsWaves / 2; half >= 1; half >>= 1) {
+    for (int half = kThreads / kWave / 2; half >= 1; half >>= 1) {
         if (wv >= half && wv < 2 * half) {
             float *slot = red + (wv - half) * kSlot;
             reinterpret_cast<f32x4 *>(slot)[lane] = T1a;

@@ -1959,7 +1959,7 @@ GNBV_API size_t gnbv_encoder_workspace_bytes(int batch, int grid)
     const size_t bn = (size_t)(batch + 8) * o1 * kEncWaves * 2 * kC * sizeof(float);
     const size_t wg = (size_t)2048 * (kTaps * 256 + kC) * sizeof(float);
     return bn + wg + (8192 + (size_t)64 * (kTaps * 256 + kC)) * sizeof(double) + 2 * kTaps * 256 * sizeof(float) +
-           2 * 14 * 2 * 64 * 16 /*split f16 weight images*/ + 1024 /*their |W2| bounds*/ + 4096;
+           2 * 14 * 2 * 64 * 16 /*split f16 weight images*/ + 1024 /*their |W2| bounds*/ + 8192 + 4096;
 }
 
 struct EncWs {
@@ -2325,7 +2325,7 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
                 attr_dg = true;
             }
             hipLaunchKernelGGL(k_conv2_dgrad_c1w_split, dim3(gd), dim3(dsplit::kThreads), dsplit::kLdsBytes, st, dy2_scratch, (const uint4 *)(w.w2split + split::kW2ImgU4),
-                               (const float *)(w.w2split + 2 * split::kW2ImgU4),
+                               (const float *)(w.w2split + split::kW2ImgU4 + dsplit::kImgSlotU4),
                                (const unsigned *)dy2_absmax, (const float *)y1, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->grid_i8, rows, p->grid_i8_row_stride,
                                batch, grid, O1, O2, wg1_part);
         } else if (z1)
