@@ -1,4 +1,12 @@
-// conv2 kernels on the f16 matrix pipe with SPLIT operands (included by encoder.hip; G = 64-class shapes: ceil(O1/2) == 16, O2 <= 15).
+// The conv stack on the f16 matrix pipe with SPLIT operands (included by encoder.hip; G = 64-class shapes: ceil(O1/2) == 16,
+// O2 <= 15).  Kernels, in file order:
+//   k_conv2_fwd_split          conv2 forward (training and two-kernel inference)
+//   k_conv2_wgrad_split        conv2 weight gradient (+ bias gradient)
+//   k_conv2_dgrad_c1w_split    conv2 data gradient fused with the conv1 weight gradient and the BN1 backward sums
+//   k_conv12_fwd_eval_split    inference: conv1 + BN1 + ReLU + conv2 in one launch, no layer-1 buffer
+//   k_conv1_fwd_split          conv1 forward (training: y1 stored)
+// plus the weight-image helpers the conv1 kernels run in passing.  Reference operators: gennbv/network/hybrid_encoder.py:38-45
+// (`naive_encoder_grid`: Conv3d(1,16,3,2) - BN - ReLU - Conv3d(16,16,3,2) - BN - ReLU).
 //
 // Why: the fp32 kernels are bound by the CU's vector-load path (27 operand loads per 108 fp32 MFMAs, each re-fetching through the
 // L1 what a neighbouring tap already fetched) and, when staged through LDS, by the fp32 matrix rate itself (108 x 32 cycles per
@@ -15,6 +23,8 @@
 // out of the subnormal range for every value that matters and the accumulator is multiplied by the inverse at the end:
 //   activations z1 = relu(bn1(y1))  x 2^8   (clamped to 65000 / 2^8 = 253.9 -- unreachable for normalised activations)
 //   weights                        x 2^10  (|w| < 63.4)
+//   gradients dy2                  x the power of two that puts max |dy2| (k_bn2_bwd_apply) into [2^13, 2^14)
+//   layer-1 gradient g             x 2^-(10 + e), 2^e > max over (channel, parity class) of sum |W2|  (written with the images)
 #pragma once
 #include <type_traits>
 
