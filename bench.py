@@ -307,7 +307,7 @@ def encoder_roofline(algo, args, device, iters: int = 20):
     nbytes = 2 * x + 4 * y1 + (0 if fused else 2 * y1) + 8 * y2
     tf, gbs = flops / (ms * 1e-3) / 1e12, nbytes / (ms * 1e-3) / 1e9
     split = fused and (o1 + 1) // 2 == 16 and os.environ.get("GENNBV_CONV_SPLIT", "1") != "0"
-    return {"kernel": "conv stack of one PPO minibatch: gnbv_encoder_grid_forward + _backward (k_conv1_fwd_lds, " +
+    return {"kernel": "conv stack of one PPO minibatch: gnbv_encoder_grid_forward + _backward (" + ("k_conv1_fwd_split, " if split else "k_conv1_fwd_lds, ") +
                       ("k_conv2_fwd_split, k_conv2_wgrad_split, k_conv2_dgrad_c1w_split" if split else
                        "k_conv2_fwd, k_conv2_wgrad, k_conv2_dgrad_c1w" if fused else "k_conv2_fwd, k_conv2_wgrad, k_conv2_dgrad, k_conv1_wgrad_lds") +
                       " + BN / reduction launches)",
