@@ -59,6 +59,10 @@ SIGNATURES = {
     "gnbv_encoder_grid_backward": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnbv_linear_workspace_bytes": (_sz, [_i, _i, _i]),
     "gnbv_linear_forward": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p]),
+    "gnbv_linear_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "gnbv_linear_bwd_prep": (_i, [_p, _p, _i, _i, _p, _p, _sz, _p]),
+    "gnbv_linear_bwd_dx": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "gnbv_linear_bwd_dw": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "gnbv_policy_head_forward": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
     "gnbv_policy_head_backward": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnbv_gather_minibatch": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -338,6 +338,188 @@ __global__ __launch_bounds__(256) void k_linear_reduce(const float *__restrict__
     }
 }
 
+// ---------------------------------------------------------------------------
+// Backward of the same layer on the split-f16 path:  g = d_out * (out > 0);  dx = g W  [M][K];  dW = g^T x  [N][K];  db = sum_m g.
+// Both products are skinny GEMMs whose streamed operand (W [N][K] for dx, x [M][K] for dW) is row-major ALONG THE OUTPUT
+// dimension, i.e. the contraction index is its ROW: one kernel serves both,
+//     C[i][k] = sum_c A[i][c] B[c][k],   B row-major [C][K] streamed once, A small (g or g^T) and pre-split,
+// with B's 32 x 64 tile staged per k-step (fp32 -> f16 hi | lo -> LDS [k block of 16][c][16]) and handed to the MFMA by the
+// transposing LDS read (ds_read_b64_tr_b16, see csrc/conv_split.h), three `v_mfma_f32_16x16x32_f16` per operand pair.
+// The library GEMMs they replace run at 70 % of the fp32 matrix peak (32 us / 60 us); these are bound by the 83 / 138 MB they move.
+//   k_fc_bwd_prep: one wave per row of A: rows m of g (for dx) and rows n of g^T (for dW; also db).  A gradient has no fixed
+//                  range, so every row gets its own power-of-two scale (a row's scale factors out of its output row), then is
+//                  split and written in MFMA fragment order [row tile][k-step][hi | lo][lane][8]; k slots of lane group q:
+//                  c = 32 s + 4 q + j and 32 s + 16 + 4 q + j (j < 4) -- the order the transposing read delivers B in.
+// ---------------------------------------------------------------------------
+typedef short ls4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ lh8 ltr_pair(const char *p0, const char *p1)
+{
+    typedef __attribute__((address_space(3))) ls4 *lds_s4;
+    const ls4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)p0), b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)p1);
+    typedef short ls8 __attribute__((ext_vector_type(8)));
+    const ls8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return *reinterpret_cast<const lh8 *>(&r);
+}
+__device__ __forceinline__ float pow2_scale_for(float amax)  // the power of two that puts amax into [2^13, 2^14); 1 for 0 / inf / nan
+{
+    int e = 0;
+    (void)frexpf(amax, &e);
+    return amax > 0.0f && amax < 3.0e38f ? ldexpf(1.0f, 14 - e) : 1.0f;
+}
+// fragment element offset (in halfs, within one [hi | lo] plane pair start) of row i, contraction index c
+__device__ __forceinline__ size_t frag_pos(int row, int c, int ksteps, int hl)
+{
+    const int rt = row >> 4, i = row & 15, s = c >> 5, w = c & 31, half = w >> 4, ww = w & 15, q = ww >> 2, j = (ww & 3) + 4 * half;
+    return ((((size_t)rt * ksteps + s) * 2 + hl) * 64 + 16 * q + i) * 8 + j;
+}
+__global__ __launch_bounds__(256) void k_fc_bwd_prep(const float *__restrict__ d_out, const float *__restrict__ out, int M, int N,
+                                                     _Float16 *__restrict__ fragA_dx /*rows m, c = n*/, float *__restrict__ inv_dx /*[M]*/,
+                                                     _Float16 *__restrict__ fragA_dw /*rows n, c = m*/, float *__restrict__ inv_dw /*[N]*/,
+                                                     float *__restrict__ db /*[N] or NULL*/)
+{
+    const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool is_dx = wave < M;
+    const int row = is_dx ? wave : wave - M;
+    if (!is_dx && row >= N) return;
+    const int C = is_dx ? N : M;                  // contraction length
+    const int Cp = (C + 31) & ~31, ksteps = Cp / 32;
+    float amax = 0.0f, sum = 0.0f;
+    for (int c = lane; c < C; c += 64) {
+        const size_t idx = is_dx ? (size_t)row * N + c : (size_t)c * N + row;
+        const float gv = out[idx] > 0.0f ? d_out[idx] : 0.0f;
+        amax = fmaxf(amax, fabsf(gv));
+        sum += gv;
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        amax = fmaxf(amax, __shfl_xor(amax, d, 64));
+        sum += __shfl_xor(sum, d, 64);
+    }
+    const float sc = pow2_scale_for(amax);
+    _Float16 *frag = is_dx ? fragA_dx : fragA_dw;
+    for (int c = lane; c < Cp; c += 64) {
+        float gv = 0.0f;
+        if (c < C) {
+            const size_t idx = is_dx ? (size_t)row * N + c : (size_t)c * N + row;
+            gv = out[idx] > 0.0f ? d_out[idx] : 0.0f;
+        }
+        _Float16 hi, lo;
+        const float t = gv * sc;
+        hi = (_Float16)t;
+        lo = (_Float16)(t - (float)hi);
+        frag[frag_pos(row, c, ksteps, 0)] = hi;
+        frag[frag_pos(row, c, ksteps, 1)] = lo;
+    }
+    if (lane == 0) {
+        (is_dx ? inv_dx : inv_dw)[row] = 1.0f / sc;
+        if (!is_dx && db != nullptr) db[row] = sum;
+    }
+}
+
+// C[i][k] = inv_a[i] / bscale * sum_c Afrag[i][c] (bscale B[c][k]);  workgroup = 64 columns k, 4 waves x RT row tiles
+template <int RT>
+__global__ __launch_bounds__(256) void k_skinny_gemm_split(const uint4 *__restrict__ fragA, const float *__restrict__ inv_a, const float *__restrict__ Bm /*[C][K]*/,
+                                                           int rows /*of C*/, int Cc /*contraction length*/, int K, float bscale, float *__restrict__ Cout /*[rows][K]*/)
+{
+    __shared__ __attribute__((aligned(16))) char s_b[2][2][4096];  // [buffer][hi | lo][k block 4][c 32][16 k] f16
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x / 64);
+    const int i = lane & 15, q = lane >> 4;
+    const int k0 = blockIdx.x * 64;
+    const int ksteps = (Cc + 31) / 32;
+    // staging: thread t, piece u: c row cc = (t + 256 u) / 16, k quad kq = (t + 256 u) % 16
+    const int cc0 = threadIdx.x >> 4, kq = threadIdx.x & 15;
+    const int kcol = min(k0 + 4 * kq, K - 4);  // (clamped: a partial last slab re-reads valid columns; its stores are masked)
+    const uint32_t st_off = (uint32_t)((((kq >> 2) * 32 + cc0) * 16 + (kq & 3) * 4) * 2);
+    f32x4 acc[RT][4];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[r][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto request_b = [&](int s, float4 &b0, float4 &b1) {
+        const int c = min(32 * min(s, ksteps - 1) + cc0, Cc - 1), c2 = min(32 * min(s, ksteps - 1) + cc0 + 16, Cc - 1);
+        b0 = ld4g(Bm + (size_t)c * K + kcol);
+        b1 = ld4g(Bm + (size_t)c2 * K + kcol);
+    };
+    auto stage_b = [&](int buf, int s, const float4 &b0, const float4 &b1) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float4 &b = u ? b1 : b0;
+            const bool ok = s < ksteps && 32 * s + cc0 + 16 * u < Cc;
+            const float v[4] = {b.x, b.y, b.z, b.w};
+            lh4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 a, c;
+                lsplit(ok ? v[e] : 0.0f, bscale, a, c);
+                hi[e] = a;
+                lo[e] = c;
+            }
+            *reinterpret_cast<lh4 *>(&s_b[buf][0][st_off + u * 16 * 32]) = hi;  // (c + 16: 16 rows of 32 bytes further)
+            *reinterpret_cast<lh4 *>(&s_b[buf][1][st_off + u * 16 * 32]) = lo;
+        }
+    };
+    auto request_a = [&](int s, uint4 (&ah)[RT], uint4 (&al)[RT]) {
+        const int sc = min(s, ksteps - 1);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int rt = min(wv * RT + r, (rows + 15) / 16 - 1);
+            ah[r] = fragA[(((size_t)rt * ksteps + sc) * 2 + 0) * 64 + lane];
+            al[r] = fragA[(((size_t)rt * ksteps + sc) * 2 + 1) * 64 + lane];
+        }
+    };
+    float4 b0, b1;
+    uint4 ah[RT], al[RT];
+    request_b(0, b0, b1);
+    request_a(0, ah, al);
+    stage_b(0, 0, b0, b1);
+    request_b(1, b0, b1);
+    __syncthreads();
+    for (int s = 0; s < ksteps; ++s) {
+        const int buf = s & 1;
+        uint4 nh[RT], nl[RT];
+        request_a(s + 1, nh, nl);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const char *blk = &s_b[buf][0][ct * 1024 + lane * 8];
+            const lh8 bh = ltr_pair(blk, blk + 512), bl = ltr_pair(blk + 4096, blk + 4096 + 512);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const lh8 xh = *reinterpret_cast<const lh8 *>(&ah[r]), xl = *reinterpret_cast<const lh8 *>(&al[r]);
+                acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, bh, acc[r][ct], 0, 0, 0);
+                acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, bh, acc[r][ct], 0, 0, 0);
+                acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, bl, acc[r][ct], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        stage_b(buf ^ 1, s + 1, b0, b1);
+        request_b(s + 2, b0, b1);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            ah[r] = nh[r];
+            al[r] = nl[r];
+        }
+        __syncthreads();
+    }
+    const float ib = 1.0f / bscale;
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int rt = wv * RT + r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = rt * 16 + 4 * q + e;
+            if (row < rows) {
+                const float sc = inv_a[row] * ib;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    const int k = k0 + ct * 16 + i;
+                    if (k < K) Cout[(size_t)row * K + k] = acc[r][ct][e] * sc;
+                }
+            }
+        }
+    }
+}
+
 inline int pick_chunks(int K)
 {
     const int nstep16 = (K + 15) / 16;
@@ -374,5 +556,59 @@ GNBV_API int gnbv_linear_forward(const float *x, const float *w, const float *bi
     const int64_t total4 = (int64_t)M * N / 4;
     hipLaunchKernelGGL(k_linear_reduce, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, st, (const float *)workspace, bias, M, N, nchunks,
                        relu, out);
+    return gnbv_launch_status();
+}
+
+
+GNBV_API size_t gnbv_linear_bwd_workspace_bytes(int M, int N, int K)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const size_t mp = (size_t)((M + 15) / 16) * 16, np = (size_t)((N + 15) / 16) * 16, cn = (size_t)((N + 31) / 32) * 32, cm = (size_t)((M + 31) / 32) * 32;
+    return (mp * cn + np * cm) * 2 * sizeof(_Float16) + (mp + np) * sizeof(float) + 1024;
+}
+
+namespace {
+struct FcBwdWs {
+    _Float16 *frag_dx, *frag_dw;
+    float *inv_dx, *inv_dw;
+};
+inline FcBwdWs fc_bwd_carve(void *ws, int M, int N)
+{
+    const size_t mp = (size_t)((M + 15) / 16) * 16, np = (size_t)((N + 15) / 16) * 16, cn = (size_t)((N + 31) / 32) * 32, cm = (size_t)((M + 31) / 32) * 32;
+    FcBwdWs w;
+    w.frag_dx = (_Float16 *)ws;
+    w.frag_dw = w.frag_dx + mp * cn * 2;
+    w.inv_dx = (float *)(((uintptr_t)(w.frag_dw + np * cm * 2) + 255) & ~(uintptr_t)255);
+    w.inv_dw = w.inv_dx + mp;
+    return w;
+}
+}  // namespace
+
+GNBV_API int gnbv_linear_bwd_prep(const float *d_out, const float *out, int M, int N, float *db, void *workspace, size_t workspace_bytes, void *stream)
+{
+    GNBV_CHECK_ARG(d_out && out && workspace && M > 0 && N > 0 && M % 16 == 0 && N % 16 == 0 && M <= 256 && N <= 256);
+    GNBV_CHECK_ARG(workspace_bytes >= gnbv_linear_bwd_workspace_bytes(M, N, 4) && ((uintptr_t)workspace & 255) == 0);
+    const FcBwdWs w = fc_bwd_carve(workspace, M, N);
+    hipLaunchKernelGGL(k_fc_bwd_prep, dim3((M + N + 3) / 4), dim3(256), 0, gnbv_stream(stream), d_out, out, M, N, w.frag_dx, w.inv_dx, w.frag_dw, w.inv_dw, db);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_linear_bwd_dx(const void *workspace, const float *w, int M, int N, int K, float *dx, void *stream)
+{
+    GNBV_CHECK_ARG(workspace && w && dx && M > 0 && M % 16 == 0 && M <= 128 && N % 16 == 0 && N <= 256 && K >= 64 && K % 4 == 0);
+    GNBV_CHECK_ARG((((uintptr_t)w | (uintptr_t)dx) & 15) == 0);
+    const FcBwdWs ws = fc_bwd_carve(const_cast<void *>(workspace), M, N);
+    hipLaunchKernelGGL(k_skinny_gemm_split<2>, dim3((K + 63) / 64), dim3(256), 0, gnbv_stream(stream), (const uint4 *)ws.frag_dx, (const float *)ws.inv_dx, w, M, N, K,
+                       kLinWScale, dx);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_linear_bwd_dw(const void *workspace, const float *x, int M, int N, int K, float *dw, void *stream)
+{
+    GNBV_CHECK_ARG(workspace && x && dw && M > 0 && M % 16 == 0 && M <= 256 && N % 16 == 0 && N <= 256 && K >= 64 && K % 4 == 0);
+    GNBV_CHECK_ARG((((uintptr_t)x | (uintptr_t)dw) & 15) == 0);
+    const FcBwdWs ws = fc_bwd_carve(const_cast<void *>(workspace), M, N);
+    hipLaunchKernelGGL(k_skinny_gemm_split<4>, dim3((K + 63) / 64), dim3(256), 0, gnbv_stream(stream), (const uint4 *)ws.frag_dw, (const float *)ws.inv_dw, x, N, M, K,
+                       kLinXScale, dw);
     return gnbv_launch_status();
 }

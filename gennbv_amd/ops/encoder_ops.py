@@ -9,6 +9,7 @@ minibatch rows straight out of the rollout buffer, so the gather is fused into c
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -240,10 +241,43 @@ class _LinearReluFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out):
         x, w, out = ctx.saved_tensors
-        g = torch.ops.aten.threshold_backward(d_out.contiguous(), out, 0.0)
         mod = ctx.mod
         direct = mod is not None and mod.weight.grad is not None and mod.bias.grad is not None
-        if direct and getattr(mod, "_async_wgrad", False) and getattr(mod, "_defer_wgrad", False):
+        defer = direct and getattr(mod, "_async_wgrad", False) and getattr(mod, "_defer_wgrad", False)
+        m, k = x.shape
+        n = w.shape[0]
+        if (os.environ.get("GENNBV_CONV_SPLIT", "1") != "0" and m % 16 == 0 and m <= 128 and n % 16 == 0 and n <= 256 and k % 4 == 0 and k >= 64
+                and x.dtype == torch.float32 and x.is_contiguous() and w.is_contiguous()):
+            # hand-written split-f16 products (csrc/linear.hip): prep (mask, row scales, operand images, db), then dx here and
+            # dW either here or -- deferred, see below -- on the second stream
+            lib = _lib.load()
+            d_out = d_out.contiguous()
+            dev = x.device
+            key = ("linbwd", m, n, k, str(dev))
+            ws = _ws_cache.get(key)
+            if ws is None:
+                ws = torch.empty(lib.gnbv_linear_bwd_workspace_bytes(m, n, k), dtype=torch.uint8, device=dev)
+                _ws_cache[key] = ws
+            db = mod.bias.grad if direct else torch.empty(n, dtype=torch.float32, device=dev)
+            dw = mod.weight.grad if direct else torch.empty(n, k, dtype=torch.float32, device=dev)
+            _lib.check(lib.gnbv_linear_bwd_prep(d_out.data_ptr(), out.data_ptr(), m, n, db.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)),
+                       "gnbv_linear_bwd_prep")
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty(m, k, dtype=torch.float32, device=dev)
+                _lib.check(lib.gnbv_linear_bwd_dx(ws.data_ptr(), w.data_ptr(), m, n, k, dx.data_ptr(), _lib.stream_ptr(dev)), "gnbv_linear_bwd_dx")
+
+            def launch_dw():
+                _lib.check(lib.gnbv_linear_bwd_dw(ws.data_ptr(), x.data_ptr(), m, n, k, dw.data_ptr(), _lib.stream_ptr(dev)), "gnbv_linear_bwd_dw")
+            if defer:
+                evt = torch.cuda.Event()
+                evt.record(torch.cuda.current_stream(dev))  # (dW needs prep's images only, not the dx product)
+                _deferred_wgrad.append((launch_dw, (x, ws), evt))
+            else:
+                launch_dw()
+            return (dx, None, None, None) if direct else (dx, dw, db, None)
+        g = torch.ops.aten.threshold_backward(d_out.contiguous(), out, 0.0)
+        if defer:
             # Nothing downstream of this node needs dW / db (only the optimizer does): they are computed on a second stream
             # beside the rest of the backward.  The launch itself is DEFERRED to join_async_wgrads(), i.e. until the main
             # backward has been issued: under hipGraph replay the executor keeps a node on the queue of the first child captured
@@ -252,7 +286,11 @@ class _LinearReluFn(torch.autograd.Function):
             # (`_defer_wgrad` is raised by the caller around its backward() only: nobody else would call the join.)
             evt = torch.cuda.Event()
             evt.record(torch.cuda.current_stream(g.device))
-            _deferred_wgrad.append((g, x, mod, evt))
+
+            def launch_lib():
+                torch.mm(g.t(), x, out=mod.weight.grad)
+                torch.sum(g, 0, out=mod.bias.grad)
+            _deferred_wgrad.append((launch_lib, (g, x), evt))
             dx = g @ w if ctx.needs_input_grad[0] else None
             return dx, None, None, None
         dx = g @ w if ctx.needs_input_grad[0] else None
@@ -273,13 +311,12 @@ def join_async_wgrads(device) -> None:
     cur = torch.cuda.current_stream(device)
     side = _side_stream(device, 0)  # the pose branch's stream: a third stream makes the graph scheduler serialise branches
     while _deferred_wgrad:
-        g, x, mod, evt = _deferred_wgrad.pop()
+        launch, keep, evt = _deferred_wgrad.pop()
         side.wait_event(evt)
         with torch.cuda.stream(side), torch.no_grad():
-            torch.mm(g.t(), x, out=mod.weight.grad)
-            torch.sum(g, 0, out=mod.bias.grad)
-        g.record_stream(side)
-        x.record_stream(side)
+            launch()
+        for t in keep:
+            t.record_stream(side)
     cur.wait_stream(side)
 
 

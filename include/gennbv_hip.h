@@ -321,6 +321,18 @@ size_t gnbv_linear_workspace_bytes(int M, int N, int K);
 int gnbv_linear_forward(const float *x, const float *w, const float *bias, int M, int N, int K, int relu, float *out,
                         void *workspace, size_t workspace_bytes, void *stream);
 
+/*     Backward of the same layer (gennbv_amd/ops/encoder_ops.py::_LinearReluFn; the reference leaves it to autograd):
+ *     g = d_out * (out > 0), dx = g w [M][K], dw = g^T x [N][K], db = sum_m g [N].  gnbv_linear_bwd_prep builds g's two operand
+ *     images (row-scaled, split into f16 halves) in `workspace` and writes db (may be NULL); gnbv_linear_bwd_dx / _dw are the two
+ *     products, each streaming its [.][K] operand once -- they may run on different streams once prep is done.
+ *     M % 16 == 0, N % 16 == 0, N <= 256, K % 4 == 0, K >= 64; dx: M <= 128; dw: M <= 256.  fp32-accurate (split operands, fp32
+ *     accumulation); |w| is clamped at 15.8 and |x| at 1015 like in the forward.  workspace 256-byte aligned. */
+size_t gnbv_linear_bwd_workspace_bytes(int M, int N, int K);
+int gnbv_linear_bwd_prep(const float *d_out, const float *out, int M, int N, float *db, void *workspace, size_t workspace_bytes,
+                         void *stream);
+int gnbv_linear_bwd_dx(const void *workspace, const float *w, int M, int N, int K, float *dx, void *stream);
+int gnbv_linear_bwd_dw(const void *workspace, const float *x, int M, int N, int K, float *dw, void *stream);
+
 /* B1/B2  policy head, fused:  feat = relu([fa | fg] W_out^T + b_out)   Hybrid_Encoder.output_layer
  *                                                     (gennbv/network/hybrid_encoder.py:51-54, :89)
  *        logits = feat W_act^T + b_act, values = feat W_val^T + b_val      ActorCriticPolicy.action_net / value_net
