@@ -356,7 +356,12 @@ def hybrid_branches(enc, observations):
     def pose_branch():
         state = get_state()
         action_input = enc.positional_encoding(state.view(num_env, -1, 6)).view(num_env, -1)
-        return enc.naive_encoder_action(action_input)
+        seq = enc.naive_encoder_action  # Linear, ReLU, Linear, ReLU (hybrid_encoder.py:43-45 of the reference)
+        if len(seq) == 4 and isinstance(seq[0], torch.nn.Linear) and isinstance(seq[2], torch.nn.Linear):
+            # the same split-K / skinny-GEMM kernels as fc_grid (csrc/linear.hip): the library picked 41 + 44 us kernels for these
+            # two small products, which ran beside -- and slowed -- the conv kernels
+            return linear_relu(linear_relu(action_input, seq[0]), seq[2])
+        return seq(action_input)
 
     # The pose-history branch (a gather, a few small GEMMs and element-wise kernels) is independent of the
     # grid branch until the concat: fork it onto a second HIP stream so that it overlaps the conv kernels
