@@ -63,6 +63,7 @@ SIGNATURES = {
     "gnbv_linear_bwd_prep": (_i, [_p, _p, _i, _i, _p, _p, _sz, _p]),
     "gnbv_linear_bwd_dx": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "gnbv_linear_bwd_dw": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "gnbv_pose_encode": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
     "gnbv_policy_head_forward": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
     "gnbv_policy_head_backward": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnbv_gather_minibatch": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -612,3 +612,31 @@ GNBV_API int gnbv_linear_bwd_dw(const void *workspace, const float *x, int M, in
                        kLinXScale, dw);
     return gnbv_launch_status();
 }
+
+
+// ---------------------------------------------------------------------------
+// Pose-history input of the encoder (gennbv/network/hybrid_encoder.py:63-74,78-80): gather of the state columns + positional
+// encoding, one launch instead of five (gather, scale, sin, cos, cat):
+//   out[b][24 p + i] = sin(x[b][6 p + i / 2] * (1 + i % 2)),  out[b][24 p + 12 + i] = cos(same),   i < 12, p < n_pose
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pose_encode(const float *__restrict__ base, const int64_t *__restrict__ rows, int64_t row_stride, int batch, int n_pose,
+                                                     float *__restrict__ out)
+{
+    const int total = batch * n_pose * 12;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int i = t % 12, bp = t / 12, p = bp % n_pose, b = bp / n_pose;
+        const float x = base[(rows ? rows[b] : (int64_t)b) * row_stride + 6 * p + (i >> 1)];
+        const float v = x * ((i & 1) ? 2.0f : 1.0f);
+        float *o = out + ((size_t)b * n_pose + p) * 24 + i;
+        o[0] = sinf(v);
+        o[12] = cosf(v);
+    }
+}
+
+GNBV_API int gnbv_pose_encode(const float *base, const int64_t *rows, int64_t row_stride, int batch, int n_pose, float *out, void *stream)
+{
+    GNBV_CHECK_ARG(base && out && batch > 0 && n_pose > 0 && row_stride >= 6 * (int64_t)n_pose);
+    const int total = batch * n_pose * 12;
+    hipLaunchKernelGGL(k_pose_encode, dim3((total + 255) / 256), dim3(256), 0, gnbv_stream(stream), base, rows, row_stride, batch, n_pose, out);
+    return gnbv_launch_status();
+}

@@ -354,8 +354,15 @@ def hybrid_branches(enc, observations):
             base = base.contiguous()
 
     def pose_branch():
-        state = get_state()
-        action_input = enc.positional_encoding(state.view(num_env, -1, 6)).view(num_env, -1)
+        if s % 6 == 0 and base.dtype == torch.float32 and base.stride(1) == 1:
+            # gather + positional encoding in one launch (csrc/linear.hip k_pose_encode)
+            lib = _lib.load()
+            action_input = torch.empty(num_env, 4 * s, dtype=torch.float32, device=base.device)
+            _lib.check(lib.gnbv_pose_encode(base.data_ptr(), _lib.ptr(rows), base.stride(0), num_env, s // 6, action_input.data_ptr(),
+                                            _lib.stream_ptr(base.device)), "gnbv_pose_encode")
+        else:
+            state = get_state()
+            action_input = enc.positional_encoding(state.view(num_env, -1, 6)).view(num_env, -1)
         seq = enc.naive_encoder_action  # Linear, ReLU, Linear, ReLU (hybrid_encoder.py:43-45 of the reference)
         if len(seq) == 4 and isinstance(seq[0], torch.nn.Linear) and isinstance(seq[2], torch.nn.Linear):
             # the same split-K / skinny-GEMM kernels as fc_grid (csrc/linear.hip): the library picked 41 + 44 us kernels for these

@@ -333,6 +333,11 @@ int gnbv_linear_bwd_prep(const float *d_out, const float *out, int M, int N, flo
 int gnbv_linear_bwd_dx(const void *workspace, const float *w, int M, int N, int K, float *dx, void *stream);
 int gnbv_linear_bwd_dw(const void *workspace, const float *x, int M, int N, int K, float *dw, void *stream);
 
+/* B1  pose-history input (gennbv/network/hybrid_encoder.py:63-74 positional_encoding with 2 frequency bands, :78-80): the state
+ *     columns [0, 6 n_pose) of observation rows `rows` (NULL: rows 0 .. batch-1) of `base` (row stride in floats) ->
+ *     out [batch][24 n_pose]: per pose cat(sin(p), cos(p)) of p = (x0, 2 x0, x1, 2 x1, ..., x5, 2 x5). */
+int gnbv_pose_encode(const float *base, const int64_t *rows, int64_t row_stride, int batch, int n_pose, float *out, void *stream);
+
 /* B1/B2  policy head, fused:  feat = relu([fa | fg] W_out^T + b_out)   Hybrid_Encoder.output_layer
  *                                                     (gennbv/network/hybrid_encoder.py:51-54, :89)
  *        logits = feat W_act^T + b_act, values = feat W_val^T + b_val      ActorCriticPolicy.action_net / value_net
