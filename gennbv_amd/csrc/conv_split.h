@@ -540,12 +540,13 @@ __device__ __forceinline__ void prep_w2_dgrad_split_item(int i, const float *__r
     img[((ty * kKSteps + s) * 2 + 1) * 64 + lane] = *reinterpret_cast<uint4 *>(&vl);
 }
 
-// definition of the hook the conv1 forward kernels call (declared in encoder.hip in front of them)
-__device__ void prep_w2_split_in_passing(const float *__restrict__ W2, float *__restrict__ w2img)
+// definition of the hooks the conv1 forward kernels / k_bn1_analytic call (declared in encoder.hip in front of them): items
+// first, first + stride, ...
+__device__ void prep_w2_split_items(const float *__restrict__ W2, float *__restrict__ w2img, int first, int stride)
 {
     uint4 *img = reinterpret_cast<uint4 *>(w2img + 2 * kTaps * 256);  // EncWs::w2split
     constexpr int kImgItems = (split::kKSteps + dsplit::kSets * dsplit::kKSteps) * 64;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kImgItems + 128; i += gridDim.x * blockDim.x) {
+    for (int i = first; i < kImgItems + 128; i += stride) {
         if (i < split::kKSteps * 64)
             prep_w2_split_item(i, W2, img);
         else if (i < kImgItems)
@@ -560,6 +561,11 @@ __device__ void prep_w2_split_in_passing(const float *__restrict__ W2, float *__
             reinterpret_cast<float *>(img + split::kW2ImgU4 + dsplit::kImgSlotU4)[j] = a;
         }
     }
+}
+
+__device__ void prep_w2_split_in_passing(const float *__restrict__ W2, float *__restrict__ w2img)
+{
+    prep_w2_split_items(W2, w2img, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 template <int TY>
@@ -879,10 +885,12 @@ __global__ void k_prep_w2_split_only(const float *__restrict__ W2, float *__rest
     prep_w2_split_in_passing(W2, w2img);
 }
 
-__global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_eval_split(
+template <bool TRAIN>
+__global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
     const int8_t *__restrict__ grid_i8, const int64_t *__restrict__ rows, int64_t grid_row_stride, const float *__restrict__ W1 /*[16][27]*/,
     const float *__restrict__ b1, const float *__restrict__ scale1, const float *__restrict__ shift1, int B, int G, int O1, int O2,
-    const uint4 *__restrict__ w2img, const float *__restrict__ b2, float *__restrict__ y2)
+    const uint4 *__restrict__ w2img, const float *__restrict__ b2, float *__restrict__ y2, float *__restrict__ y1 /*TRAIN: stored for the backward*/,
+    float *__restrict__ partials /*TRAIN: BN2 partial sums, one row per workgroup*/)
 {
     using namespace split;
     using namespace fsplit;
@@ -893,12 +901,16 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_eval_split(
     int b, oz0, oz1;
     const bool live = sample_plane_group(B, O2, kNP, b, oz0, oz1);
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(tid / kWave);
-    if (!live) return;
+    if (!live) {
+        if (TRAIN) write_partials(partials, kWaves, wv, 0.f, 0.f);
+        return;
+    }
     const int np = oz1 - oz0;
     const int nsteps = (O2 + 2) & ~1;
+    float s_sum = 0.0f, s_sq = 0.0f;
     if (wv >= kConsWaves) {
         // ---- staging waves: conv1 + BN1 + ReLU on the fly ----
-        const int ptid = tid - kConsWaves * kWave, pw = wv - kConsWaves;
+        const int ptid = tid - kConsWaves * kWave, pw = (wv - kConsWaves) & 7;
         const int n = lane & 15, g = lane >> 4;
         // A operand: W1[ch = n][tap 8g + e] x 2^10, split
         h8 wh, wl;
@@ -910,12 +922,16 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_eval_split(
             wh[e] = hi;
             wl[e] = lo;
         }
-        // byte offset of tap 8g + e inside the slab, relative to the tile's (plane, row, column) origin
-        uint32_t tapoff[8];
+        // LDS byte address of tap 8g + e of voxel n of this wave's FIRST tile in input buffer 0.  Tile k of the wave is T = pw + 8k =
+        // (plane pair (pw >> 2) + 2k, row (pw >> 1) & 1, x parity pw & 1): its taps sit 4k planes further on, buffer 1 kInBuf
+        // further -- compile-time distances that go into the instructions' offset fields, so a tile costs no address arithmetic
+        const int rsel = (pw >> 1) & 1, par = pw & 1;
+        uint32_t tapaddr[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int t = min(8 * g + e, kTaps - 1);
-            tapoff[e] = (uint32_t)((t / 9) * kInPlaneBytes + ((t / 3) % 3) * kInRowBytes + t % 3 + 4 * n);
+            tapaddr[e] = (uint32_t)(split::kStageBytes + kPadBytes + kRedBytes + (t / 9 + 2 * (pw >> 2)) * kInPlaneBytes + ((t / 3) % 3 + 2 * rsel) * kInRowBytes +
+                                    t % 3 + 4 * n + 2 * par);
         }
         float bb[4], sc[4], sh[4];  // channels 4g .. 4g+3 of this lane's accumulator rows
 #pragma unroll
@@ -935,30 +951,60 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_eval_split(
         auto in_store = [&](int j, const uint4 &v) {
             if (ptid < kInPieces) *reinterpret_cast<uint4 *>(inbuf + (j & 1) * kInBuf + fpl * kInPlaneBytes + frow * kInRowBytes + 16 * fq) = v;
         };
-        auto compute = [&](int j) {
-            const char *ib = inbuf + (j & 1) * kInBuf;
-#pragma unroll
-            for (int k = 0; k < (kTilesPerStep + 7) / 8; ++k) {
-                const int T = pw + 8 * k;  // (wave-uniform)
-                if (T >= kTilesPerStep) continue;
-                const int pi = T >> 2, rsel = (T >> 1) & 1, par = T & 1;
-                const int8_t *origin = reinterpret_cast<const int8_t *>(ib) + (2 * pi) * kInPlaneBytes + (2 * rsel) * kInRowBytes + 2 * par;
+        // y1 store (TRAIN): lane part of the address -- voxel x = 2n + par of a row, channels 4g .. 4g+3.  x = 31 IS the padding slot of
+        // the odd half row (which no kernel reads as data); tiles outside the volume / of the neighbour's plane go there as well.
+        const uint32_t y1_lane = (uint32_t)((par * 16 + n) * kC + 4 * g), y1_pad = (uint32_t)((16 + 15) * kC + 4 * g);
+        auto compute = [&](int j, const int jp /* = j & 1, a literal at every call */) {
+            constexpr int kTilesPerWave = (kTilesPerStep + 7) / 8;
+            // (pw < 8 is visible to the compiler, so only the fifth tile of waves 0-3 sits under a branch; with all five under one,
+            // every y1 store below is conditional and the wait for the next input piece becomes vmcnt(1).  Repeating tile 35 in
+            // waves 4-7 instead of skipping it: +10 %, the staging waves are issue-bound.)
+            auto gather = [&](int k) {  // (the fifth tile of waves 4-7 reads past the slab: never used)
                 h8 xb;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) xb[e] = (_Float16)(short)origin[tapoff[e]];
+                for (int e = 0; e < 8; ++e)
+                    xb[e] = (_Float16)(short)*reinterpret_cast<const int8_t *>(split_lds + tapaddr[e] + (uint32_t)(jp * kInBuf + 4 * k * kInPlaneBytes));
+                return xb;
+            };
+            // software pipeline: the input bytes of tile k + 1 are requested between the MFMAs of tile k and its epilogue -- the
+            // compiler cannot move an LDS read above the previous tile's ring stores itself (same LDS array)
+            const int row = 2 * j + 1 + rsel, slot = (row + kRing) % kRing;
+            // (opaque once per step, in place: otherwise the 8 x 5 x 2 sums base + distance are hoisted out of the step loop as values
+            // of their own and spill, instead of being folded into the reads' offset fields)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(tapaddr[e]));
+            h8 xb = gather(0);
+#pragma unroll
+            for (int k = 0; k < kTilesPerWave; ++k) {
+                const int pi = (pw >> 2) + 2 * k;
+                if (k == kTilesPerWave - 1 && pi >= kNPl) continue;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 acc = mfma_h(wh, xb, acc);  // D[i = channel 4g + r][j = voxel n]
                 acc = mfma_h(wl, xb, acc);
+                if (k + 1 < kTilesPerWave) xb = gather(k + 1);
                 h4 hi, lo;
+                float yv[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float y = acc[r] * (1.0f / kW1Scale) + bb[r];
+                    yv[r] = y;
                     _Float16 a, c2;
                     split2(__builtin_amdgcn_fmed3f(fmaf(sc[r], y, sh[r]), 0.f, kZMax), a, c2);
                     hi[r] = a;
                     lo[r] = c2;
                 }
-                const int row = 2 * j + 1 + rsel, slot = (row + kRing) % kRing;
+                if (TRAIN) {
+                    // the layer-1 pre-activations go to memory as well (k_conv1_fwd_split's store): every plane by ONE workgroup -- the
+                    // plane two neighbouring groups share belongs to the upper one, except at the top of the volume.
+                    // BRANCH-FREE: a conditional store makes the compiler's wait-count merge wait for the stores just issued when
+                    // the next input piece is taken from its registers.  Row base in scalar registers, lane part precomputed.
+                    // (bitwise, not && / ||: the short-circuit form becomes control flow with the two addresses in a stack array)
+                    const int own = __builtin_amdgcn_readfirstlane((int)(row >= 0) & (int)(row < O1) & ((int)(pi < 2 * np) | ((int)(pi == 2 * np) & (int)(oz1 == O2))));
+                    const uint32_t rowbase = vox1(b, min(2 * oz0 + pi, O1 - 1), min(max(row, 0), O1 - 1), 0, O1) * kC;
+                    float *dst1 = y1 + __builtin_amdgcn_readfirstlane(rowbase);
+                    const uint32_t lane_off = y1_pad + (uint32_t)own * (y1_lane - y1_pad);
+                    *reinterpret_cast<float4 *>(dst1 + lane_off) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+                }
                 char *dst = stage + (pi * kRing + slot) * kRowBytes + par * 1024 + n * 32 + g * 8;
                 *reinterpret_cast<h4 *>(dst) = hi;
                 *reinterpret_cast<h4 *>(dst + 512) = lo;
@@ -969,28 +1015,28 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_eval_split(
         in_store(-1, ra);
         ra = in_req(1);
         split_step_barrier();
-        compute(-1);
+        compute(-1, 1);
         in_store(0, rb);
         rb = in_req(2);
         split_step_barrier();
-        compute(0);
+        compute(0, 0);
         in_store(1, ra);
         ra = in_req(3);
         split_step_barrier();
         // step t: compute iteration t (slab t & 1), store iteration t + 1 (requested at step t - 1), request t + 3.  rb holds
         // even iterations, ra odd ones.  Branch-free around the requests.
         for (int t = 1; t <= nsteps; t += 2) {
-            compute(t);
+            compute(t, 1);
             in_store(t + 1, rb);
             rb = in_req(t + 3);
             split_step_barrier();
-            compute(t + 1);
+            compute(t + 1, 0);
             in_store(t + 2, ra);
             ra = in_req(t + 4);
             split_step_barrier();
         }
     } else {
-        // ---- compute waves: exactly k_conv2_fwd_split's, without the BN2 partial sums ----
+        // ---- compute waves: exactly k_conv2_fwd_split's (the BN2 partial sums only when training) ----
         const int m = lane & 15, g = lane >> 4;
         const int pl = wv >> 1, kh = wv & 1;
         h8 wh[kKHalf], wl[kKHalf];
@@ -1018,7 +1064,14 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_eval_split(
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int oxi = 4 * g + rr;
-                    if (oxi < O2) out[oxi] = acc[rr] + bias;
+                    if (oxi < O2) {
+                        const float y = acc[rr] + bias;
+                        out[oxi] = y;
+                        if (TRAIN) {
+                            s_sum += y;
+                            s_sq += y * y;
+                        }
+                    }
                 }
             }
             if (pl < np && oy < O2) {
@@ -1062,6 +1115,7 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_eval_split(
             split_step_barrier();
         }
     }
+    if (TRAIN) write_partials(partials, kWaves, wv, s_sum, s_sq);
 }
 
 

@@ -185,6 +185,7 @@ __global__ void k_prep_w2(const float *__restrict__ W2, float *__restrict__ img_
 // (the images only depend on W2: the conv1 forward kernel, which runs before every conv2 forward, writes them in
 // passing -- a few hundred extra stores in an HBM-bound launch instead of a dependent 5 us launch)
 __device__ void prep_w2_split_in_passing(const float *__restrict__ W2, float *__restrict__ w2img);  // conv_split.h: the f16 images of the split kernels
+__device__ void prep_w2_split_items(const float *__restrict__ W2, float *__restrict__ w2img, int first, int stride);
 __device__ __forceinline__ void prep_w2_in_passing(const float *__restrict__ W2, float *__restrict__ w2img)
 {
     if (W2 != nullptr) {
@@ -1590,8 +1591,13 @@ __global__ __launch_bounds__(1024) void k_bn1_analytic(const int *__restrict__ a
                                                       int64_t *__restrict__ num_batches_tracked, const int *__restrict__ skip_flag,
                                                       float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out,
                                                       float *__restrict__ rstd_out, int *__restrict__ total_out /*[kAcRow]: saved for backward*/,
-                                                      const int *__restrict__ ac_global /*NULL, or [kAcRow]: total over ALL replicas (statistics)*/)
+                                                      const int *__restrict__ ac_global /*NULL, or [kAcRow]: total over ALL replicas (statistics)*/,
+                                                      const float *__restrict__ W2 = nullptr, float *__restrict__ w2img = nullptr)
 {
+    if (blockIdx.x > 0) {  // extra workgroups: the conv2 kernels' f16 weight images (when no conv1 kernel follows to write them in passing)
+        prep_w2_split_items(W2, w2img, (blockIdx.x - 1) * blockDim.x + threadIdx.x, (gridDim.x - 1) * blockDim.x);
+        return;
+    }
     __shared__ int Ri[kAcRow];
     __shared__ double q[kC][kTaps];
     __shared__ float w1s[kC * kTaps];  // (staged: the loops below would otherwise chain 27 global loads per thread)
@@ -2087,6 +2093,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     // Inference with the grid as int8 rows at G = 64: conv1 + BN1 + ReLU + conv2 in one kernel, no layer-1 buffer at all
     // (conv_split.h).  y1 is left untouched (no backward follows an eval-mode forward).
     const bool fused_eval = !training && !z1 && !qm && conv_split_path(p, grid) && conv1_i8_staged(p, grid) && grid == 64 && !env_off("GENNBV_FUSED_EVAL");
+    bool fused_train = false;
     if (fused_eval) {
         hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps, p->momentum, p->bn1_rm,
                            p->bn1_rv, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC);
@@ -2094,13 +2101,13 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
         if ((err = gnbv_launch_status())) return err;
         static bool attr_fe = false;
         if (!attr_fe) {
-            const hipError_t e = hipFuncSetAttribute((const void *)k_conv12_fwd_eval_split, hipFuncAttributeMaxDynamicSharedMemorySize, fsplit::kLdsBytes);
+            const hipError_t e = hipFuncSetAttribute((const void *)k_conv12_fwd_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fsplit::kLdsBytes);
             if (e != hipSuccess) return (int)e;
             attr_fe = true;
         }
-        hipLaunchKernelGGL(k_conv12_fwd_eval_split, dim3(sample_plane_group_grid(batch, O2, split::kNP)), dim3(split::kThreads), fsplit::kLdsBytes, st,
+        hipLaunchKernelGGL(k_conv12_fwd_split<false>, dim3(sample_plane_group_grid(batch, O2, split::kNP)), dim3(split::kThreads), fsplit::kLdsBytes, st,
                            p->grid_i8, rows, p->grid_i8_row_stride, p->w1, p->b1, (const float *)bn1, (const float *)(bn1 + kC), batch, grid, O1, O2,
-                           (const uint4 *)w.w2split, p->b2, y2);
+                           (const uint4 *)w.w2split, p->b2, y2, (float *)nullptr, (float *)nullptr);
         if ((err = gnbv_launch_status())) return err;
     } else if (z1) {
         // BN1 scale / shift first (training: analytic batch statistics from the input autocorrelation; eval: running
@@ -2126,15 +2133,29 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     // conv1) instead of partial sums in conv1 + a 12 us reduction behind it; y1 is stored as before
     const bool analytic = training && analytic_bn1(p, grid);
     if (dp && !(analytic && fused_path(p, grid) && p->autocorr_global != nullptr)) return (int)hipErrorInvalidValue;  // (see GnbvEncoderParams.world)
+    // Training with BN1's statistics known beforehand: conv1 + BN1 + ReLU + conv2 as ONE launch that also stores y1 for the backward
+    // (conv_split.h) -- conv2 never reads the 244 MB it would otherwise fetch right after conv1 wrote them.
+    fused_train = analytic && !qm && conv_split_path(p, grid) && grid == 64 && !env_off("GENNBV_CONV1_SPLIT") && !env_off("GENNBV_FUSED_TRAIN");
     if (analytic) {
-        hipLaunchKernelGGL(k_bn1_analytic, dim3(1), dim3(1024), 0, st, (const int *)p->autocorr, p->autocorr_row_stride, rows, batch, p->w1, p->b1,
-                           p->bn1_w, p->bn1_b, p->eps, p->momentum, p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag, bn1, bn1 + kC, bn1 + 2 * kC,
-                           bn1 + 3 * kC, (int *)(bn_state + kBnStateFloats), dp ? (const int *)p->autocorr_global : (const int *)nullptr);
+        hipLaunchKernelGGL(k_bn1_analytic, dim3(fused_train ? 3 : 1), dim3(1024), 0, st, (const int *)p->autocorr, p->autocorr_row_stride, rows, batch, p->w1,
+                           p->b1, p->bn1_w, p->bn1_b, p->eps, p->momentum, p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag, bn1, bn1 + kC, bn1 + 2 * kC,
+                           bn1 + 3 * kC, (int *)(bn_state + kBnStateFloats), dp ? (const int *)p->autocorr_global : (const int *)nullptr,
+                           p->w2, w.w2img);
         if ((err = gnbv_launch_status())) return err;
     }
     float *c1_part = (training && !analytic) ? w.bn_part : nullptr;
     // conv1 (+ BN1 statistics)
-    if (p->act_bf16) {
+    if (fused_train) {
+        static bool attr_ft = false;
+        if (!attr_ft) {
+            const hipError_t e = hipFuncSetAttribute((const void *)k_conv12_fwd_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, fsplit::kLdsBytes);
+            if (e != hipSuccess) return (int)e;
+            attr_ft = true;
+        }
+        hipLaunchKernelGGL(k_conv12_fwd_split<true>, dim3(sample_plane_group_grid(batch, O2, split::kNP)), dim3(split::kThreads), fsplit::kLdsBytes, st,
+                           p->grid_i8, rows, p->grid_i8_row_stride, p->w1, p->b1, (const float *)bn1, (const float *)(bn1 + kC), batch, grid, O1, O2,
+                           (const uint4 *)w.w2split, p->b2, y2, (float *)y1, w.bn_part);
+    } else if (p->act_bf16) {
         hipLaunchKernelGGL(k_conv1_fwd<ActBF16>, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, batch, grid, O1, p->w1,
                        p->b1, (uint16_t *)y1, c1_part, p->w2, w.w2img);
     } else {
@@ -2178,8 +2199,9 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     }
     // conv2 (BN1 + ReLU on load; + BN2 statistics).  Its LDS weight images were written by the conv1 kernel in passing.
     int g2 = sample_plane_group_grid(batch, O2, kPlanesPerGroup);
-    if (fused_eval) {
-        // (y2 was written by k_conv12_fwd_eval_split above)
+    if (fused_eval || fused_train) {
+        // (y2 was written by k_conv12_fwd_split above)
+        g2 = sample_plane_group_grid(batch, O2, split::kNP);
     } else if (p->act_bf16) {
         hipLaunchKernelGGL(k_conv2_fwd<ActBF16>, dim3(g2), dim3(kFwdThreads), 0, st, (const uint16_t *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
                        training ? w.bn_part : nullptr);

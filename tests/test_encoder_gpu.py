@@ -422,10 +422,12 @@ def test_fused_eval_conv1_conv2_vs_fp64_and_the_two_kernel_path(b, monkeypatch):
     assert float((outs["1"] - outs["0"]).abs().max()) <= 1e-5 * scale
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("b", [2, 128])
-def test_conv1_split_kernel_y1_vs_fp64(b, monkeypatch):
-    """k_conv1_fwd_split (training-mode conv1 at G = 64 on the f16 pipe: W1 split, int8 input exact) against conv3d in fp64:
-    every stored y1 element (the x-parity-split layout, padding slot excluded), and against the fp32-MFMA kernel's accuracy."""
+def test_conv1_split_kernel_y1_vs_fp64(b, fused, monkeypatch):
+    """k_conv1_fwd_split (training-mode conv1 at G = 64 on the f16 pipe: W1 split, int8 input exact; fused = "0") and the y1
+    store of k_conv12_fwd_split<true> (fused = "1") against conv3d in fp64: every stored y1 element (the x-parity-split layout,
+    padding slot excluded), and against the fp32-MFMA kernel's accuracy."""
     import torch.nn.functional as F
     from gennbv_amd.ops import encoder_ops
     g = 64
@@ -441,6 +443,7 @@ def test_conv1_split_kernel_y1_vs_fp64(b, monkeypatch):
     c1 = seq[0]
     ref = F.conv3d(grid_i8[rows].double().cpu().view(b, 1, g, g, g), c1.weight.double().cpu(), c1.bias.double().cpu(), stride=2)
     errs = {}
+    monkeypatch.setenv("GENNBV_FUSED_TRAIN", fused)
     for mode in ("1", "0"):
         monkeypatch.setenv("GENNBV_CONV1_SPLIT", mode)
         f = encoder_ops.grid_encoder(small, rows, 600, g, seq, True, grid_i8=grid_i8, compact=True, autocorr=ac)
@@ -451,3 +454,47 @@ def test_conv1_split_kernel_y1_vs_fp64(b, monkeypatch):
         errs[mode] = float((full[:, :, :, :31].permute(0, 4, 1, 2, 3).double() - ref).abs().max())
     scale = float(ref.abs().max())
     assert errs["1"] <= 2e-6 * scale and errs["1"] <= 2.0 * errs["0"] + 1e-7, (errs, scale)
+
+
+@pytest.mark.parametrize("b", [3, 128])
+def test_fused_train_forward_vs_the_two_kernel_path(b, monkeypatch):
+    """Training forward at G = 64 with BN1's statistics known beforehand (input autocorrelation): k_conv12_fwd_split<true>
+    (conv1 + BN1 + ReLU + conv2 in one launch that also stores y1 and the BN2 partial sums; csrc/conv_split.h) against
+    GENNBV_FUSED_TRAIN=0 (k_conv1_fwd_split + k_conv2_fwd_split): y1 bit-equal wherever a voxel exists, y2, the BatchNorm
+    state (scale / shift / mean / rstd of both layers), the running statistics and the features within fp32 round-off; then the
+    gradients of a random cotangent through both (same backward kernels, fed by either forward)."""
+    import copy
+    from gennbv_amd.ops import encoder_ops
+    g = 64
+    hip, _, _ = pu.make_policy(g=g, device=DEV, backend="hip", det_weights=True)
+    gen = torch.Generator().manual_seed(23 + b)
+    n = 2 * b + 1
+    grid_i8 = (torch.randint(-1, 2, (n, g ** 3), generator=gen) * (torch.rand(n, g ** 3, generator=gen) < 0.4)).to(torch.int8).to(DEV)
+    small = torch.randn(n, 600 + 8192, generator=gen).to(DEV)
+    ac = encoder_ops.input_autocorr(grid_i8, g)
+    rows = torch.randperm(n, generator=gen)[:b].to(DEV)
+    cot = torch.randn(b, 16 * 15 ** 3, generator=gen).to(DEV)
+    hip.train()
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GENNBV_FUSED_TRAIN", mode)
+        seq = copy.deepcopy(hip.features_extractor.naive_encoder_grid)
+        f = encoder_ops.grid_encoder(small, rows, 600, g, seq, True, grid_i8=grid_i8, compact=True, autocorr=ac)
+        _, _, y1, y2, bn_state, _, _ = f.grad_fn.saved_tensors
+        y1 = y1.detach().clone().view(b, 31, 31, 2, 16, 16)[:, :, :, :, :, :]
+        y1[:, :, :, 1, 15] = 0  # x = 31 does not exist (padding slot of the odd-x half row)
+        (f * cot).sum().backward()
+        res[mode] = dict(f=f.detach().clone(), y1=y1, y2=y2.detach().clone(), bn=bn_state.detach().clone()[:128],
+                         rm=[seq[1].running_mean.clone(), seq[1].running_var.clone(), seq[4].running_mean.clone(), seq[4].running_var.clone()],
+                         grads=[q.grad.clone() for q in seq.parameters()])
+    a, c = res["1"], res["0"]
+    assert torch.equal(a["y1"], c["y1"])
+    s2 = float(c["y2"].abs().max())
+    assert float((a["y2"] - c["y2"]).abs().max()) <= 2e-6 * s2, float((a["y2"] - c["y2"]).abs().max()) / s2
+    assert torch.allclose(a["bn"], c["bn"], rtol=1e-5, atol=1e-6)
+    for u, v in zip(a["rm"], c["rm"]):
+        assert torch.allclose(u, v, rtol=1e-5, atol=1e-7)
+    assert float((a["f"] - c["f"]).abs().max()) <= 1e-5 * float(c["f"].abs().max())
+    for u, v in zip(a["grads"], c["grads"]):
+        assert float((u - v).abs().max()) <= 2e-4 * float(v.abs().max()) + 1e-7, (u.shape, float((u - v).abs().max()), float(v.abs().max()))
+
