@@ -874,8 +874,12 @@ constexpr int kInPlanes = 2 * split::kNPl + 1;  // 19 input planes under the 9 z
 constexpr int kInRows = 5;                      // input rows 4j+2 .. 4j+6 under z1 rows 2j+1, 2j+2
 constexpr int kInRowBytes = 64, kInPlaneBytes = kInRows * kInRowBytes;
 constexpr int kInBuf = kInPlanes * kInPlaneBytes + 64;  // + slack: the padding voxel reads a byte past its row
-constexpr int kInPieces = kInPlanes * kInRows * 4;      // 16-byte pieces per iteration: 380 of the 512 staging threads
+constexpr int kInPieces = kInPlanes * kInRows * 4;      // 16-byte pieces per iteration: 380 of the 768 staging threads
 constexpr int kTilesPerStep = 2 * split::kNPl * 2;      // (plane, row, x parity): 36
+constexpr int kCompWaves = 4, kStageWaves = 12;          // the staging arithmetic bounds the kernel: 12 waves x 3 tiles per step; each compute
+                                                         // wave takes TWO output planes (same weights) with its half of the k-steps
+constexpr int kTilesPerWave = kTilesPerStep / kStageWaves;
+static_assert(kTilesPerWave * kStageWaves == kTilesPerStep && kStageWaves % 4 == 0 && (kCompWaves + kStageWaves) * 64 == split::kThreads, "tile split");
 constexpr float kW1Scale = 1024.0f;
 constexpr int kLdsBytes = split::kStageBytes + split::kPadBytes + split::kRedBytes + 2 * kInBuf;
 }  // namespace fsplit
@@ -908,9 +912,9 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
     const int np = oz1 - oz0;
     const int nsteps = (O2 + 2) & ~1;
     float s_sum = 0.0f, s_sq = 0.0f;
-    if (wv >= kConsWaves) {
+    if (wv >= kCompWaves) {
         // ---- staging waves: conv1 + BN1 + ReLU on the fly ----
-        const int ptid = tid - kConsWaves * kWave, pw = (wv - kConsWaves) & 7;
+        const int ptid = tid - kCompWaves * kWave, pw = min(max(wv - kCompWaves, 0), kStageWaves - 1);
         const int n = lane & 15, g = lane >> 4;
         // A operand: W1[ch = n][tap 8g + e] x 2^10, split
         h8 wh, wl;
@@ -922,8 +926,8 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
             wh[e] = hi;
             wl[e] = lo;
         }
-        // LDS byte address of tap 8g + e of voxel n of this wave's FIRST tile in input buffer 0.  Tile k of the wave is T = pw + 8k =
-        // (plane pair (pw >> 2) + 2k, row (pw >> 1) & 1, x parity pw & 1): its taps sit 4k planes further on, buffer 1 kInBuf
+        // LDS byte address of tap 8g + e of voxel n of this wave's FIRST tile in input buffer 0.  Tile k of the wave is T = pw + 12k =
+        // (plane pair (pw >> 2) + 3k, row (pw >> 1) & 1, x parity pw & 1): its taps sit 6k planes further on, buffer 1 kInBuf
         // further -- compile-time distances that go into the instructions' offset fields, so a tile costs no address arithmetic
         const int rsel = (pw >> 1) & 1, par = pw & 1;
         uint32_t tapaddr[8];
@@ -955,29 +959,24 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
         // the odd half row (which no kernel reads as data); tiles outside the volume / of the neighbour's plane go there as well.
         const uint32_t y1_lane = (uint32_t)((par * 16 + n) * kC + 4 * g), y1_pad = (uint32_t)((16 + 15) * kC + 4 * g);
         auto compute = [&](int j, const int jp /* = j & 1, a literal at every call */) {
-            constexpr int kTilesPerWave = (kTilesPerStep + 7) / 8;
-            // (pw < 8 is visible to the compiler, so only the fifth tile of waves 0-3 sits under a branch; with all five under one,
-            // every y1 store below is conditional and the wait for the next input piece becomes vmcnt(1).  Repeating tile 35 in
-            // waves 4-7 instead of skipping it: +10 %, the staging waves are issue-bound.)
-            auto gather = [&](int k) {  // (the fifth tile of waves 4-7 reads past the slab: never used)
+            auto gather = [&](int k) {
                 h8 xb;
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    xb[e] = (_Float16)(short)*reinterpret_cast<const int8_t *>(split_lds + tapaddr[e] + (uint32_t)(jp * kInBuf + 4 * k * kInPlaneBytes));
+                    xb[e] = (_Float16)(short)*reinterpret_cast<const int8_t *>(split_lds + tapaddr[e] + (uint32_t)(jp * kInBuf + 6 * k * kInPlaneBytes));
                 return xb;
             };
             // software pipeline: the input bytes of tile k + 1 are requested between the MFMAs of tile k and its epilogue -- the
             // compiler cannot move an LDS read above the previous tile's ring stores itself (same LDS array)
             const int row = 2 * j + 1 + rsel, slot = (row + kRing) % kRing;
-            // (opaque once per step, in place: otherwise the 8 x 5 x 2 sums base + distance are hoisted out of the step loop as values
+            // (opaque once per step, in place: otherwise the 8 x 3 x 2 sums base + distance are hoisted out of the step loop as values
             // of their own and spill, instead of being folded into the reads' offset fields)
 #pragma unroll
             for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(tapaddr[e]));
             h8 xb = gather(0);
 #pragma unroll
             for (int k = 0; k < kTilesPerWave; ++k) {
-                const int pi = (pw >> 2) + 2 * k;
-                if (k == kTilesPerWave - 1 && pi >= kNPl) continue;
+                const int pi = (pw >> 2) + 3 * k;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 acc = mfma_h(wh, xb, acc);  // D[i = channel 4g + r][j = voxel n]
                 acc = mfma_h(wl, xb, acc);
@@ -1036,9 +1035,10 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
             split_step_barrier();
         }
     } else {
-        // ---- compute waves: exactly k_conv2_fwd_split's (the BN2 partial sums only when training) ----
+        // ---- compute waves: k_conv2_fwd_split's arithmetic; wave = (plane pair wv >> 1, k-half wv & 1), the two planes one after the
+        // other with the same weight fragments (the BN2 partial sums only when training) ----
         const int m = lane & 15, g = lane >> 4;
-        const int pl = wv >> 1, kh = wv & 1;
+        const int pl2 = wv >> 1, kh = wv & 1;
         h8 wh[kKHalf], wl[kKHalf];
 #pragma unroll
         for (int s = 0; s < kKHalf; ++s) {
@@ -1048,19 +1048,15 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
         }
         const float bias = b2[m];
         const int P2 = O2 * O2 * O2;
-        const uint32_t a_lane = (uint32_t)(2 * pl * kRing * kRowBytes + m * 32 + (g & 1) * 16);
         const bool second = (g >> 1) != 0;
-        f32x4 prev = {0.f, 0.f, 0.f, 0.f};
-        float *const out_base = y2 + ((size_t)b * kC + m) * P2 + (size_t)(oz0 + pl) * O2 * O2;
-        split_step_barrier();
-        split_step_barrier();
-        split_step_barrier();
-        for (int t = 1; t <= nsteps; ++t) {
-            const int oy = t - 1;
+        f32x4 prev0 = {0.f, 0.f, 0.f, 0.f}, prev1 = prev0;
+        auto plane_step = [&](const int q, f32x4 &prev, int t) {
+            const int oy = t - 1, pl = 2 * pl2 + q;
+            const uint32_t a_lane = (uint32_t)(2 * pl * kRing * kRowBytes + m * 32 + (g & 1) * 16);
             if (kh == 0 && pl < np && oy >= 1 && oy - 1 < O2) {
                 const f32x4 other = *reinterpret_cast<const f32x4 *>(red + (((t - 1) & 1) * kNP + pl) * 256 + lane * 4);
                 const f32x4 acc = (prev + other) * (1.0f / (kZScale * kWScale));
-                float *out = out_base + (size_t)(oy - 1) * O2;
+                float *out = y2 + ((size_t)b * kC + m) * P2 + (size_t)(oz0 + pl) * O2 * O2 + (size_t)(oy - 1) * O2;
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int oxi = 4 * g + rr;
@@ -1112,6 +1108,13 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
                 else
                     prev = part;
             }
+        };
+        split_step_barrier();
+        split_step_barrier();
+        split_step_barrier();
+        for (int t = 1; t <= nsteps; ++t) {
+            plane_step(0, prev0, t);
+            plane_step(1, prev1, t);
             split_step_barrier();
         }
     }
