@@ -30,6 +30,7 @@
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 namespace split {
 constexpr int kThreads = 1024, kWaves = 16;          // waves 0-7 compute (output plane = wave / 2, half of the k-steps each), waves 8-15 stage
@@ -872,8 +873,8 @@ __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
 namespace fsplit {
 constexpr int kInPlanes = 2 * split::kNPl + 1;  // 19 input planes under the 9 z1 planes
 constexpr int kInRows = 5;                      // input rows 4j+2 .. 4j+6 under z1 rows 2j+1, 2j+2
-constexpr int kInRowBytes = 64, kInPlaneBytes = kInRows * kInRowBytes;
-constexpr int kInBuf = kInPlanes * kInPlaneBytes + 64;  // + slack: the padding voxel reads a byte past its row
+constexpr int kInRowBytes = 128, kInPlaneBytes = kInRows * kInRowBytes;  // the slab holds the input as f16 (converted once, by the staging store)
+constexpr int kInBuf = kInPlanes * kInPlaneBytes + 64;  // + slack: the padding voxel reads two values past its row (zeroed once: never NaN)
 constexpr int kInPieces = kInPlanes * kInRows * 4;      // 16-byte pieces per iteration: 380 of the 768 staging threads
 constexpr int kTilesPerStep = 2 * split::kNPl * 2;      // (plane, row, x parity): 36
 constexpr int kCompWaves = 4, kStageWaves = 12;          // the staging arithmetic bounds the kernel: 12 waves x 3 tiles per step; each compute
@@ -916,33 +917,44 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
         // ---- staging waves: conv1 + BN1 + ReLU on the fly ----
         const int ptid = tid - kCompWaves * kWave, pw = min(max(wv - kCompWaves, 0), kStageWaves - 1);
         const int n = lane & 15, g = lane >> 4;
-        // A operand: W1[ch = n][tap 8g + e] x 2^10, split
-        h8 wh, wl;
+        // The contraction over the 27 taps as k = 32 + 32: k-slot (g, e) of the first MFMA pair = (tap row r = 2g + (e >> 2) of the nine
+        // (dz, dy) rows, dx = e & 3), of the second pair = row 8 for g = 0 -- dx = 3 and everything else in the second pair carry ZERO
+        // weights.  A lane's four k-slots of a row are then 8 contiguous bytes of the f16 slab (x = 4n + 2 par + 0..3): two dword reads
+        // per row, three rows per lane and tile, no conversion and no packing (the byte-wise gather of the int8 slab cost 8 reads with
+        // bank conflicts + 12 VALU instructions per tile, and the LDS pipe is what these waves share with the compute waves).
+        // A operand: W1[ch = n][tap] x 2^10, split
+        h8 wh, wl, wh2, wl2;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int t = 8 * g + e;
+            const int r = 2 * g + (e >> 2), dx = e & 3;
             _Float16 hi, lo;
-            split2(t < kTaps ? W1[n * kTaps + t] * kW1Scale : 0.0f, hi, lo);
+            split2(dx < 3 ? W1[n * kTaps + 3 * r + dx] * kW1Scale : 0.0f, hi, lo);
             wh[e] = hi;
             wl[e] = lo;
+            split2(g == 0 && e < 3 ? W1[n * kTaps + 24 + e] * kW1Scale : 0.0f, hi, lo);
+            wh2[e] = hi;
+            wl2[e] = lo;
         }
-        // LDS byte address of tap 8g + e of voxel n of this wave's FIRST tile in input buffer 0.  Tile k of the wave is T = pw + 12k =
+        // LDS byte address of tap row r of voxel n of this wave's FIRST tile in input buffer 0.  Tile k of the wave is T = pw + 12k =
         // (plane pair (pw >> 2) + 3k, row (pw >> 1) & 1, x parity pw & 1): its taps sit 6k planes further on, buffer 1 kInBuf
         // further -- compile-time distances that go into the instructions' offset fields, so a tile costs no address arithmetic
         const int rsel = (pw >> 1) & 1, par = pw & 1;
-        uint32_t tapaddr[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int t = min(8 * g + e, kTaps - 1);
-            tapaddr[e] = (uint32_t)(split::kStageBytes + kPadBytes + kRedBytes + (t / 9 + 2 * (pw >> 2)) * kInPlaneBytes + ((t / 3) % 3 + 2 * rsel) * kInRowBytes +
-                                    t % 3 + 4 * n + 2 * par);
-        }
+        auto row_addr = [&](int r) {
+            return (uint32_t)(split::kStageBytes + kPadBytes + kRedBytes + (r / 3 + 2 * (pw >> 2)) * kInPlaneBytes + (r % 3 + 2 * rsel) * kInRowBytes + 2 * (4 * n + 2 * par));
+        };
+        uint32_t tapaddr[3] = {row_addr(2 * g), row_addr(2 * g + 1), row_addr(8)};
         float bb[4], sc[4], sh[4];  // channels 4g .. 4g+3 of this lane's accumulator rows
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             bb[r] = b1[4 * g + r];
             sc[r] = scale1[4 * g + r] * kZScale;
             sh[r] = shift1[4 * g + r] * kZScale;
+            if (!TRAIN) {
+                // inference never materialises y1 = acc / 2^10 + b: z = sc y + sh = (sc / 2^10) acc + (sc b + sh), one fma per value
+                // (training keeps the two roundings: the backward recomputes the ReLU mask from the STORED y1)
+                sh[r] = fmaf(sc[r], bb[r], sh[r]);
+                sc[r] *= 1.0f / kW1Scale;
+            }
         }
         // input staging: piece f = ptid < 380 -> (plane f / 20, row (f / 4) % 5, 16-byte quarter f % 4)
         const int f = min(ptid, kInPieces - 1), fpl = f / (kInRows * 4), frow = (f >> 2) % kInRows, fq = f & 3;
@@ -952,40 +964,65 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
             const int row_g = min(max(4 * j + 2 + frow, 0), G - 1);
             return *reinterpret_cast<const uint4 *>(in + ((size_t)plane_g * G + row_g) * G + 16 * fq);
         };
+        // int8 -> f16 on the way into the slab, two values per v_perm_b32 + v_pk_add_f16: the byte b ^ 0x80 under the exponent byte
+        // 0x64 is the f16 number 1024 + (b + 128), minus 1152 = b (exact: integers below 2048)
         auto in_store = [&](int j, const uint4 &v) {
-            if (ptid < kInPieces) *reinterpret_cast<uint4 *>(inbuf + (j & 1) * kInBuf + fpl * kInPlaneBytes + frow * kInRowBytes + 16 * fq) = v;
+            const uint32_t w[4] = {v.x ^ 0x80808080u, v.y ^ 0x80808080u, v.z ^ 0x80808080u, v.w ^ 0x80808080u};
+            uint32_t o[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const h2 bias = {(_Float16)1152.0f, (_Float16)1152.0f};
+                const uint32_t p0 = __builtin_amdgcn_perm(0x64646464u, w[q], 0x04010400u), p1 = __builtin_amdgcn_perm(0x64646464u, w[q], 0x04030402u);
+                const h2 f0 = *reinterpret_cast<const h2 *>(&p0) - bias, f1 = *reinterpret_cast<const h2 *>(&p1) - bias;
+                o[2 * q] = *reinterpret_cast<const uint32_t *>(&f0);
+                o[2 * q + 1] = *reinterpret_cast<const uint32_t *>(&f1);
+            }
+            if (ptid < kInPieces) {
+                uint4 *dst = reinterpret_cast<uint4 *>(inbuf + (j & 1) * kInBuf + fpl * kInPlaneBytes + frow * kInRowBytes + 32 * fq);
+                dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+                dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+            }
         };
+        if (ptid < 8) reinterpret_cast<uint4 *>(inbuf + (ptid >> 2) * kInBuf + kInPlanes * kInPlaneBytes)[ptid & 3] = make_uint4(0, 0, 0, 0);  // the slack
         // y1 store (TRAIN): lane part of the address -- voxel x = 2n + par of a row, channels 4g .. 4g+3.  x = 31 IS the padding slot of
         // the odd half row (which no kernel reads as data); tiles outside the volume / of the neighbour's plane go there as well.
         const uint32_t y1_lane = (uint32_t)((par * 16 + n) * kC + 4 * g), y1_pad = (uint32_t)((16 + 15) * kC + 4 * g);
         auto compute = [&](int j, const int jp /* = j & 1, a literal at every call */) {
-            auto gather = [&](int k) {
-                h8 xb;
+            auto gather = [&](int k, h8 &xa, h8 &xc) {
+                uint32_t d[6];
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    xb[e] = (_Float16)(short)*reinterpret_cast<const int8_t *>(split_lds + tapaddr[e] + (uint32_t)(jp * kInBuf + 6 * k * kInPlaneBytes));
-                return xb;
+                for (int r = 0; r < 3; ++r) {
+                    const uint32_t *src = reinterpret_cast<const uint32_t *>(split_lds + tapaddr[r] + (uint32_t)(jp * kInBuf + 6 * k * kInPlaneBytes));
+                    d[2 * r] = src[0];
+                    d[2 * r + 1] = src[1];
+                }
+                const uint4 ua = make_uint4(d[0], d[1], d[2], d[3]), uc = make_uint4(d[4], d[5], d[4], d[5]);
+                xa = *reinterpret_cast<const h8 *>(&ua);
+                xc = *reinterpret_cast<const h8 *>(&uc);
             };
             // software pipeline: the input bytes of tile k + 1 are requested between the MFMAs of tile k and its epilogue -- the
             // compiler cannot move an LDS read above the previous tile's ring stores itself (same LDS array)
             const int row = 2 * j + 1 + rsel, slot = (row + kRing) % kRing;
-            // (opaque once per step, in place: otherwise the 8 x 3 x 2 sums base + distance are hoisted out of the step loop as values
+            // (opaque once per step, in place: otherwise the 3 x 3 x 2 sums base + distance are hoisted out of the step loop as values
             // of their own and spill, instead of being folded into the reads' offset fields)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(tapaddr[e]));
-            h8 xb = gather(0);
+            for (int e = 0; e < 3; ++e) asm volatile("" : "+v"(tapaddr[e]));
+            h8 xb, xb2;
+            gather(0, xb, xb2);
 #pragma unroll
             for (int k = 0; k < kTilesPerWave; ++k) {
                 const int pi = (pw >> 2) + 3 * k;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 acc = mfma_h(wh, xb, acc);  // D[i = channel 4g + r][j = voxel n]
+                acc = mfma_h(wh2, xb2, acc);
                 acc = mfma_h(wl, xb, acc);
-                if (k + 1 < kTilesPerWave) xb = gather(k + 1);
+                acc = mfma_h(wl2, xb2, acc);
+                if (k + 1 < kTilesPerWave) gather(k + 1, xb, xb2);
                 h4 hi, lo;
                 float yv[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float y = acc[r] * (1.0f / kW1Scale) + bb[r];
+                    const float y = TRAIN ? acc[r] * (1.0f / kW1Scale) + bb[r] : acc[r];
                     yv[r] = y;
                     _Float16 a, c2;
                     split2(__builtin_amdgcn_fmed3f(fmaf(sc[r], y, sh[r]), 0.f, kZMax), a, c2);
@@ -998,11 +1035,10 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
                     // BRANCH-FREE: a conditional store makes the compiler's wait-count merge wait for the stores just issued when
                     // the next input piece is taken from its registers.  Row base in scalar registers, lane part precomputed.
                     // (bitwise, not && / ||: the short-circuit form becomes control flow with the two addresses in a stack array)
-                    const int own = __builtin_amdgcn_readfirstlane((int)(row >= 0) & (int)(row < O1) & ((int)(pi < 2 * np) | ((int)(pi == 2 * np) & (int)(oz1 == O2))));
+                    const bool own = (bool)((int)(row >= 0) & (int)(row < O1) & ((int)(pi < 2 * np) | ((int)(pi == 2 * np) & (int)(oz1 == O2))));
                     const uint32_t rowbase = vox1(b, min(2 * oz0 + pi, O1 - 1), min(max(row, 0), O1 - 1), 0, O1) * kC;
-                    float *dst1 = y1 + __builtin_amdgcn_readfirstlane(rowbase);
-                    const uint32_t lane_off = y1_pad + (uint32_t)own * (y1_lane - y1_pad);
-                    *reinterpret_cast<float4 *>(dst1 + lane_off) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+                    char *dst1 = reinterpret_cast<char *>(y1 + __builtin_amdgcn_readfirstlane(rowbase));
+                    *reinterpret_cast<float4 *>(dst1 + (own ? 4 * y1_lane : 4 * y1_pad)) = make_float4(yv[0], yv[1], yv[2], yv[3]);
                 }
                 char *dst = stage + (pi * kRing + slot) * kRowBytes + par * 1024 + n * 32 + g * 8;
                 *reinterpret_cast<h4 *>(dst) = hi;

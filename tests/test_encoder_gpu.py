@@ -460,7 +460,7 @@ def test_conv1_split_kernel_y1_vs_fp64(b, fused, monkeypatch):
 def test_fused_train_forward_vs_the_two_kernel_path(b, monkeypatch):
     """Training forward at G = 64 with BN1's statistics known beforehand (input autocorrelation): k_conv12_fwd_split<true>
     (conv1 + BN1 + ReLU + conv2 in one launch that also stores y1 and the BN2 partial sums; csrc/conv_split.h) against
-    GENNBV_FUSED_TRAIN=0 (k_conv1_fwd_split + k_conv2_fwd_split): y1 bit-equal wherever a voxel exists, y2, the BatchNorm
+    GENNBV_FUSED_TRAIN=0 (k_conv1_fwd_split + k_conv2_fwd_split): y1 wherever a voxel exists, y2, the BatchNorm
     state (scale / shift / mean / rstd of both layers), the running statistics and the features within fp32 round-off; then the
     gradients of a random cotangent through both (same backward kernels, fed by either forward)."""
     import copy
@@ -488,7 +488,8 @@ def test_fused_train_forward_vs_the_two_kernel_path(b, monkeypatch):
                          rm=[seq[1].running_mean.clone(), seq[1].running_var.clone(), seq[4].running_mean.clone(), seq[4].running_var.clone()],
                          grads=[q.grad.clone() for q in seq.parameters()])
     a, c = res["1"], res["0"]
-    assert torch.equal(a["y1"], c["y1"])
+    # (the fused kernel contracts the 27 taps in another order than k_conv1_fwd_split: last-bit differences)
+    assert float((a["y1"] - c["y1"]).abs().max()) <= 1e-6 * float(c["y1"].abs().max()), float((a["y1"] - c["y1"]).abs().max())
     s2 = float(c["y2"].abs().max())
     assert float((a["y2"] - c["y2"]).abs().max()) <= 2e-6 * s2, float((a["y2"] - c["y2"]).abs().max()) / s2
     assert torch.allclose(a["bn"], c["bn"], rtol=1e-5, atol=1e-6)
