@@ -252,7 +252,7 @@ def encoder_roofline(algo, args, device, iters: int = 20):
     csrc/encoder.hip) at the minibatch size, timed live with events on the launch stream, priced against BOTH roofs:
     fp32 MFMA (157 TFLOP/s dense) and HBM (8 TB/s).  Algorithmic figures per minibatch of B samples at grid G
     (DESIGN.md section 4): flops = 3 x 2 x B x (27*16*o1^3 + 432*16*o2^3) (forward + two backward contractions);
-    bytes = x (R fwd, R bwd) + y1 (W, 3 R) + y2-sized tensors (y2 W + 2 R, dy2 W + 2 R, features W, d_features R)
+    bytes = x (R fwd, R bwd) + y1 (W, 3 R; W, 2 R when conv1 + conv2 run as one forward launch) + y2-sized tensors (y2 W + 2 R, dy2 W + 2 R, features W, d_features R)
     [+ dz1 (W, R) on the unfused fallback, which the benchmarked configuration -- int8 rows, G % 16 == 0 -- never takes].
     Since round 2 the conv2 contractions run on the f16 matrix pipe with operands split into two f16 halves (fp32-accurate
     products, fp32 accumulation; csrc/conv_split.h): the stack is HBM-bound, `bound` says so, and the MFMA figure stays the
@@ -279,9 +279,10 @@ def encoder_roofline(algo, args, device, iters: int = 20):
         p_.grad = None
 
     gi8 = None if buf.grid_i8 is None else buf.grid_i8[:t].view(t * n, -1)  # what the update reads when the env provides it
+    ac = None if (gi8 is None or buf.autocorr is None) else buf.autocorr[:t].view(t * n, -1)  # (as PPO_Grid_Obs.train() passes it)
 
     def step():
-        f = encoder_ops.grid_encoder(base, rows, s_dim, g, seq, True, grid_i8=gi8, compact=buf.compact_state_dim is not None)
+        f = encoder_ops.grid_encoder(base, rows, s_dim, g, seq, True, grid_i8=gi8, compact=buf.compact_state_dim is not None, autocorr=ac)
         f.backward(torch.ones_like(f))
 
     for _ in range(3):
@@ -304,12 +305,17 @@ def encoder_roofline(algo, args, device, iters: int = 20):
     x = b * g ** 3 * (4 if gi8 is None else 1)
     y2 = b * o2 ** 3 * 16 * 4
     fused = gi8 is not None and g % 16 == 0
-    nbytes = 2 * x + 4 * y1 + (0 if fused else 2 * y1) + 8 * y2
-    tf, gbs = flops / (ms * 1e-3) / 1e12, nbytes / (ms * 1e-3) / 1e9
     split = fused and (o1 + 1) // 2 == 16 and os.environ.get("GENNBV_CONV_SPLIT", "1") != "0"
-    return {"kernel": "conv stack of one PPO minibatch: gnbv_encoder_grid_forward + _backward (" + ("k_conv1_fwd_split, " if split else "k_conv1_fwd_lds, ") +
-                      ("k_conv2_fwd_split, k_conv2_wgrad_split, k_conv2_dgrad_c1w_split" if split else
-                       "k_conv2_fwd, k_conv2_wgrad, k_conv2_dgrad_c1w" if fused else "k_conv2_fwd, k_conv2_wgrad, k_conv2_dgrad, k_conv1_wgrad_lds") +
+    # conv1 + conv2 forward as ONE launch (BN1 statistics known beforehand from the autocorrelation rows): y1 is written once and
+    # read by the two backward kernels only
+    one_fwd = split and ac is not None and g == 64 and all(os.environ.get(k, "1") != "0" for k in ("GENNBV_FUSED_TRAIN", "GENNBV_CONV1_SPLIT", "GENNBV_ANALYTIC_BN1"))
+    nbytes = 2 * x + (3 if one_fwd else 4) * y1 + (0 if fused else 2 * y1) + 8 * y2
+    tf, gbs = flops / (ms * 1e-3) / 1e12, nbytes / (ms * 1e-3) / 1e9
+    return {"kernel": "conv stack of one PPO minibatch: gnbv_encoder_grid_forward + _backward (" +
+                      ("k_conv12_fwd_split<true>, k_conv2_wgrad_split, k_conv2_dgrad_c1w_split" if one_fwd else
+                       "k_conv1_fwd_split, k_conv2_fwd_split, k_conv2_wgrad_split, k_conv2_dgrad_c1w_split" if split else
+                       "k_conv1_fwd_lds, k_conv2_fwd, k_conv2_wgrad, k_conv2_dgrad_c1w" if fused else
+                       "k_conv1_fwd_lds, k_conv2_fwd, k_conv2_wgrad, k_conv2_dgrad, k_conv1_wgrad_lds") +
                       " + BN / reduction launches)",
             "bound": "hbm" if split else "mfma",
             "ms": ms, "batch": b, "grid_input": "fp32 rows" if gi8 is None else "int8 copy", "algorithmic_flops": flops,
