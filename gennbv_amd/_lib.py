@@ -72,6 +72,7 @@ SIGNATURES = {
     "gnbv_ppo_loss_rsl": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _f, _f, _i, _p, _p, _p, _p, _p]),
     "gnbv_adam_workspace_bytes": (_sz, []),
     "gnbv_clip_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _p, _f, _p, _f, _p, _p, _sz, _p]),
+    "gnbv_clip_adam_step_rotate": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _p, _f, _p, _f, _p, _p, _sz, _p, _i, _i, _p, _p, _p]),
     "gnbv_chamfer_workspace_bytes": (_sz, [_i, _i]),
     "gnbv_chamfer_distance": (_i, [_p, _i, _p, _i, _p, _p, _sz, _p]),
     "gnbv_gae_sb3": (_i, [_p, _p, _p, _p, _p, _i, _i, _d, _d, _p, _p, _p]),

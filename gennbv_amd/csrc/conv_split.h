@@ -3,8 +3,9 @@
 //   k_conv2_fwd_split          conv2 forward (training and two-kernel inference)
 //   k_conv2_wgrad_split        conv2 weight gradient (+ bias gradient)
 //   k_conv2_dgrad_c1w_split    conv2 data gradient fused with the conv1 weight gradient and the BN1 backward sums
-//   k_conv12_fwd_eval_split    inference: conv1 + BN1 + ReLU + conv2 in one launch, no layer-1 buffer
-//   k_conv1_fwd_split          conv1 forward (training: y1 stored)
+//   k_conv12_fwd_split<TRAIN>  conv1 + BN1 + ReLU + conv2 in one launch: inference (no layer-1 buffer at all) and the training
+//                              forward with BN1's statistics known beforehand (y1 stored for the backward, never read back here)
+//   k_conv1_fwd_split          conv1 forward on its own (training without the one-launch forward: y1 stored)
 // plus the weight-image helpers the conv1 kernels run in passing.  Reference operators: gennbv/network/hybrid_encoder.py:38-45
 // (`naive_encoder_grid`: Conv3d(1,16,3,2) - BN - ReLU - Conv3d(16,16,3,2) - BN - ReLU).
 //
@@ -860,15 +861,18 @@ __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
 
 
 // ---------------------------------------------------------------------------
-// Inference (BatchNorm in eval mode: rollout, evaluation): conv1 + BN1 + ReLU + conv2 in ONE kernel -- the layer-1 activations
-// never exist in global memory (2 x 488 MB per 256-env policy step otherwise: a write by conv1, a read by conv2).
-// Same workgroup, ring and compute waves as k_conv2_fwd_split; the staging waves COMPUTE the two new z1 rows of the 9 planes
-// instead of reading them: per step 36 tiles of 16 voxels x 16 channels, one `v_mfma_f32_16x16x32_f16` pair each
-// (A = W1 as f16 hi | lo x 2^10, M = channel, k = 27 taps padded to 32; B = the int8 input patch, exact in f16, N = voxel), then
-// bias + BN1 (running statistics) + ReLU, x 2^8, split, and an 8-byte store per lane into the ring -- the accumulator layout
-// (lane = voxel, 4 channels) is the ring's layout.  The int8 input rows an iteration needs (19 planes x 5 rows x 64 bytes = 6 KiB
-// instead of 36 KiB of y1) go through a double-buffered LDS slab: iteration j is requested at step j - 2 (one 16-byte request
-// per thread), stored at step j - 1 and computed at step j.
+// conv1 + BN1 + ReLU + conv2 in ONE kernel.  TRAIN = false (BatchNorm in eval mode: rollout, evaluation): the layer-1 activations
+// never exist in global memory (2 x 488 MB per 256-env policy step otherwise: a write by conv1, a read by conv2).  TRAIN = true
+// (BN1's batch statistics known before the launch, from the input autocorrelation: k_bn1_analytic): y1 is stored for the backward
+// and the BN2 partial sums are left as by k_conv2_fwd_split, but conv2 does not read back what conv1 just wrote.
+// Ring and compute arithmetic of k_conv2_fwd_split; 4 compute waves (two output planes each) + 12 staging waves that COMPUTE the
+// two new z1 rows of the 9 planes instead of reading them: per step 36 tiles of 16 voxels x 16 channels, three per staging wave,
+// four `v_mfma_f32_16x16x32_f16` each (A = W1 as f16 hi | lo x 2^10, M = channel, k = the 27 taps laid out as 32 + 32, see the
+// staging waves; B = the input patch, exact in f16, N = voxel), then bias + BN1 + ReLU, x 2^8, split, and an 8-byte store per
+// lane into the ring -- the accumulator layout (lane = voxel, 4 channels) is the ring's layout.  The input rows an iteration needs
+// (19 planes x 5 rows x 64 voxels: 6 KiB of int8 instead of 36 KiB of y1) go through a double-buffered LDS slab, converted to f16
+// by the staging store: iteration j is requested at step j - 2 (one 16-byte request per thread), stored at step j - 1 and
+// computed at step j.  What bounds it and what was tried: profiles/r02_notes.md.
 // ---------------------------------------------------------------------------
 namespace fsplit {
 constexpr int kInPlanes = 2 * split::kNPl + 1;  // 19 input planes under the 9 z1 planes
@@ -1159,7 +1163,7 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
 
 
 // ---------------------------------------------------------------------------
-// conv1 forward (training, y1 stored): the staging arithmetic of k_conv12_fwd_eval_split as a kernel of its own.
+// conv1 forward (training, y1 stored): the (first, byte-gather) staging arithmetic of k_conv12_fwd_split as a kernel of its own.
 // Workgroup = (sample, output plane): the three int8 input planes under it (12 KiB, kept as int8) go to LDS once; 62 tiles of
 // 16 voxels x 16 channels (31 rows x 2 x parities), two `v_mfma_f32_16x16x32_f16` each (W1 split x 2^10, the input exact)
 // instead of seven fp32 MFMAs twice as long, + bias, and a 16-byte store per lane (4 channels of one voxel) into the

@@ -306,8 +306,18 @@ __global__ __launch_bounds__(256) void k_grad_norm_finalize(const double *__rest
 
 __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
                             int64_t n, const float *__restrict__ norm_coef, const int *__restrict__ stop_flag,
-                            const int64_t *__restrict__ step /*already incremented*/, float lr, float beta1, float beta2, float eps)
+                            const int64_t *__restrict__ step /*already incremented*/, float lr, float beta1, float beta2, float eps,
+                            const int64_t *__restrict__ rot_table = nullptr, int rot_rows = 0, int rot_len = 0, int64_t *__restrict__ rot_out = nullptr,
+                            int *__restrict__ rot_counter = nullptr)
 {
+    // (replayed minibatch graphs: the LAST launch of a minibatch leaves the next minibatch's row numbers in the buffer every kernel
+    // of the graph reads them from -- no copy node, no host work between two replays.  Also when the update itself is masked.)
+    if (rot_table != nullptr && blockIdx.x == 0) {
+        const int c = (*rot_counter + 1) % rot_rows;
+        for (int i = threadIdx.x; i < rot_len; i += blockDim.x) rot_out[i] = rot_table[(int64_t)c * rot_len + i];
+        __syncthreads();
+        if (threadIdx.x == 0) *rot_counter = c;
+    }
     if (stop_flag != nullptr && *stop_flag != 0) return;
     const float coef = norm_coef ? norm_coef[1] : 1.0f;
     // bias corrections in double like torch's scalar path (1 - beta**step evaluated in Python floats)
@@ -431,10 +441,11 @@ GNBV_API int gnbv_ppo_loss_rsl(int batch, const float *log_prob, const float *ol
 
 GNBV_API size_t gnbv_adam_workspace_bytes(void) { return 1024 * sizeof(double) + 64; }
 
-GNBV_API int gnbv_clip_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float max_grad_norm,
-                                 float lr, float beta1, float beta2, float eps, int64_t *step, int *stop_flag, float grad_scale,
-                                 const float *kl_slot, float target_kl, float *norm_out /*[2]: total norm, applied factor*/,
-                                 void *workspace, size_t workspace_bytes, void *stream)
+static int clip_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float max_grad_norm,
+                          float lr, float beta1, float beta2, float eps, int64_t *step, int *stop_flag, float grad_scale,
+                          const float *kl_slot, float target_kl, float *norm_out /*[2]: total norm, applied factor*/,
+                          void *workspace, size_t workspace_bytes, const int64_t *rot_table, int rot_rows, int rot_len, int64_t *rot_out,
+                          int *rot_counter, void *stream)
 {
     GNBV_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && step && norm_out && workspace && n > 0);
     GNBV_CHECK_ARG(workspace_bytes >= gnbv_adam_workspace_bytes());
@@ -448,8 +459,26 @@ GNBV_API int gnbv_clip_adam_step(float *params, const float *grads, float *exp_a
     int ab = (int)((n + 255) / 256);
     ab = ab > 4096 ? 4096 : ab;
     hipLaunchKernelGGL(k_adam_flat, dim3(ab), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, (const float *)norm_out,
-                       (const int *)stop_flag, step, lr, beta1, beta2, eps);
+                       (const int *)stop_flag, step, lr, beta1, beta2, eps, rot_table, rot_rows, rot_len, rot_out, rot_counter);
     return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_clip_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float max_grad_norm,
+                                 float lr, float beta1, float beta2, float eps, int64_t *step, int *stop_flag, float grad_scale,
+                                 const float *kl_slot, float target_kl, float *norm_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return clip_adam_step(params, grads, exp_avg, exp_avg_sq, n, max_grad_norm, lr, beta1, beta2, eps, step, stop_flag, grad_scale, kl_slot,
+                          target_kl, norm_out, workspace, workspace_bytes, nullptr, 0, 0, nullptr, nullptr, stream);
+}
+
+GNBV_API int gnbv_clip_adam_step_rotate(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float max_grad_norm,
+                                        float lr, float beta1, float beta2, float eps, int64_t *step, int *stop_flag, float grad_scale,
+                                        const float *kl_slot, float target_kl, float *norm_out, void *workspace, size_t workspace_bytes,
+                                        const int64_t *table, int table_rows, int row_len, int64_t *out, int *counter, void *stream)
+{
+    GNBV_CHECK_ARG(table && out && counter && table_rows > 0 && row_len > 0);
+    return clip_adam_step(params, grads, exp_avg, exp_avg_sq, n, max_grad_norm, lr, beta1, beta2, eps, step, stop_flag, grad_scale, kl_slot,
+                          target_kl, norm_out, workspace, workspace_bytes, table, table_rows, row_len, out, counter, stream);
 }
 
 GNBV_API int gnbv_multicategorical_sample(const float *logits, int batch, int n_logits, int n_heads, const int *head_dims,

@@ -55,15 +55,24 @@ class FlatAdam:
         self.grads.zero_()
 
     def step(self, max_grad_norm: float, stop_flag: Optional[torch.Tensor] = None, grad_scale: float = 1.0,
-             kl_slot_target: Optional[float] = None):
-        """grad_scale = 1/world and kl_slot_target = target_kl for the data-parallel tail."""
-        _lib.check(self.lib.gnbv_clip_adam_step(
-            self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.n,
-            float(max_grad_norm if max_grad_norm is not None else -1.0), float(self.lr), float(self.betas[0]),
-            float(self.betas[1]), float(self.eps), self.step_count.data_ptr(), _lib.ptr(stop_flag), float(grad_scale),
-            self.kl_slot.data_ptr() if kl_slot_target is not None else None,
-            float(kl_slot_target) if kl_slot_target is not None else -1.0, self.norm_out.data_ptr(),
-            self.ws.data_ptr(), self.ws.numel(), _lib.stream_ptr(self.params.device)), "gnbv_clip_adam_step")
+             kl_slot_target: Optional[float] = None, rotate=None):
+        """grad_scale = 1/world and kl_slot_target = target_kl for the data-parallel tail.  rotate = (table [rows, len] int64,
+        out [len] int64, counter [1] int32): the launch also leaves the next minibatch's row numbers in `out`
+        (gnbv_clip_adam_step_rotate)."""
+        args = (self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.n,
+                float(max_grad_norm if max_grad_norm is not None else -1.0), float(self.lr), float(self.betas[0]),
+                float(self.betas[1]), float(self.eps), self.step_count.data_ptr(), _lib.ptr(stop_flag), float(grad_scale),
+                self.kl_slot.data_ptr() if kl_slot_target is not None else None,
+                float(kl_slot_target) if kl_slot_target is not None else -1.0, self.norm_out.data_ptr(),
+                self.ws.data_ptr(), self.ws.numel())
+        if rotate is None:
+            _lib.check(self.lib.gnbv_clip_adam_step(*args, _lib.stream_ptr(self.params.device)), "gnbv_clip_adam_step")
+        else:
+            table, out, counter = rotate
+            assert table.dtype == torch.int64 and table.is_contiguous() and table.dim() == 2 and out.dtype == torch.int64 and out.is_contiguous()
+            assert out.numel() == table.shape[1] and counter.dtype == torch.int32
+            _lib.check(self.lib.gnbv_clip_adam_step_rotate(*args, table.data_ptr(), int(table.shape[0]), int(table.shape[1]), out.data_ptr(),
+                                                           counter.data_ptr(), _lib.stream_ptr(self.params.device)), "gnbv_clip_adam_step_rotate")
 
     def torch_state_dict(self, template: torch.optim.Adam) -> dict:
         """This optimizer's state in torch.optim.Adam.state_dict() format (checkpoints: policy.optimizer.pth);

@@ -409,7 +409,7 @@ class PPO_Grid_Obs:
                 encoder_ops.pose_branch_backward(enc, self.device)  # (deferred so that the conv chain is captured first: encoder_ops.hybrid_branches)
                 encoder_ops.join_async_wgrads(self.device)  # fc_grid's dW / db: second stream, beside the conv backward
                 if self._sync is None or not self._sync.active:
-                    opt.step(self.max_grad_norm, loss.stop_flag)
+                    opt.step(self.max_grad_norm, loss.stop_flag, rotate=st.get("rows_rot"))
                 return
             # the forward cut the graph at the conv-stack output (enc._split_backward): this backward
             # stops at that leaf and fills the gradients of every non-conv parameter
@@ -496,15 +496,34 @@ class PPO_Grid_Obs:
             ac_tab = self._sync.global_autocorr(buf.autocorr[:t_].view(t_ * n_, -1)[rows_all].view(n_mb, batch, -1))
             st["adv_cur"].copy_(adv_tab[0])
             st["ac_cur"].copy_(ac_tab[0])
+        # Replayed graph on one GPU: the row numbers of ALL minibatches of this call go to a table once, and the Adam launch that ends
+        # a minibatch leaves the next one's in `loss.rows` (gnbv_clip_adam_step_rotate) -- no copy and no host work between two
+        # replays.  (The table and the counter are baked into the graph: persistent buffers.)
+        rotating = use_graph and not dp and n_mb > 0 and os.environ.get("GENNBV_ROTATE_ROWS", "1") != "0"
+        rot = st.get("rows_rot")
+        if rotating and (rot is None or tuple(rot[0].shape) != (n_mb, batch)):
+            rot = (torch.empty(n_mb, batch, dtype=torch.int64, device=self.device), loss.rows, torch.zeros(1, dtype=torch.int32, device=self.device))
+            st["rows_rot"], st["graph"] = rot, None
+        elif not rotating and rot is not None:
+            rot = st["rows_rot"] = None
+            st["graph"] = None
+        if rotating:
+            rot[0].copy_(rows_all[:n_mb * batch].view(n_mb, batch))
+            rot[2].zero_()
         if use_graph and st["graph"] is None:
             loss.rows.copy_(rows_all[:batch])
             st["graph"] = self._capture_minibatch_graph(st)
             loss.stats_row.zero_()
             loss.stop_flag.zero_()
+            if rotating:
+                rot[2].zero_()
+        if rotating:
+            loss.rows.copy_(rows_all[:batch])
         epochs_run = 0
         for epoch in range(self.n_epochs):
             for k in range(n_mb):
-                loss.rows.copy_(rows_all[k * batch:(k + 1) * batch])
+                if not rotating:
+                    loss.rows.copy_(rows_all[k * batch:(k + 1) * batch])
                 if dp_stats:
                     st["adv_cur"].copy_(adv_tab[k])
                     st["ac_cur"].copy_(ac_tab[k])

@@ -447,6 +447,14 @@ int gnbv_clip_adam_step(float *params, const float *grads, float *exp_avg, float
                         float lr, float beta1, float beta2, float eps, int64_t *step, int *stop_flag, float grad_scale,
                         const float *kl_slot, float target_kl, float *norm_out, void *workspace, size_t workspace_bytes,
                         void *stream);
+/* Same, for a minibatch update that is replayed as a hipGraph (the reference's inner loop, ppo_grid_obs.py:199-287, walks
+ * `rollout_buffer.get(batch_size)`): the Adam launch -- the last of a minibatch -- also copies row (*counter + 1) % table_rows of
+ * `table` [table_rows][row_len] (the row numbers of every minibatch of this train() call) into `out`, the buffer all kernels
+ * of the graph read their row numbers from, and stores the new *counter: no copy and no host work between two replays. */
+int gnbv_clip_adam_step_rotate(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float max_grad_norm,
+                               float lr, float beta1, float beta2, float eps, int64_t *step, int *stop_flag, float grad_scale,
+                               const float *kl_slot, float target_kl, float *norm_out, void *workspace, size_t workspace_bytes,
+                               const int64_t *table, int table_rows, int row_len, int64_t *out, int *counter, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* 8f.3  evaluation metric: reconstruction accuracy of Env_Eval_GenNBV          */

@@ -391,7 +391,7 @@ def test_compact_observation_rows_match_flat_rows(g, b, train, monkeypatch):
 
 @pytest.mark.parametrize("b", [3, 128])
 def test_fused_eval_conv1_conv2_vs_fp64_and_the_two_kernel_path(b, monkeypatch):
-    """Inference at G = 64 with the grid as int8 rows: k_conv12_fwd_eval_split (conv1 + BN1 + ReLU + conv2 in one launch, the
+    """Inference at G = 64 with the grid as int8 rows: k_conv12_fwd_split<false> (conv1 + BN1 + ReLU + conv2 in one launch, the
     layer-1 activations never stored; csrc/conv_split.h) against the fp64 torch modules in eval mode (running statistics) and
     against the two-kernel path (GENNBV_FUSED_EVAL=0: k_conv1_fwd_lds + k_conv2_fwd_split)."""
     from gennbv_amd.ops import encoder_ops
