@@ -103,6 +103,22 @@ def test_flat_adam_matches_torch_adam_with_clipping():
     before = o2.params.clone()
     o2.step(1.0, flag)  # masked: nothing moves, step count frozen
     assert torch.equal(before, o2.params) and int(o2.step_count.item()) == 25
+    # gnbv_clip_adam_step_rotate: the same update, and the launch leaves row (counter + 1) % rows of the table in `out`
+    # (the replayed minibatch graph's row numbers) -- also when the update is masked
+    table = torch.arange(3 * 7, dtype=torch.int64, device=DEV).view(3, 7) * 11
+    out = torch.full((7,), -1, dtype=torch.int64, device=DEV)
+    counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for want in (1, 2, 0, 1):
+        o1.zero_grad(); o2.zero_grad()
+        (m1(x) ** 2).sum().backward(); (m2(x) ** 2).sum().backward()
+        torch.nn.utils.clip_grad_norm_(m1.parameters(), 1.0)
+        o1.step(); o2.step(1.0, rotate=(table, out, counter))
+        assert int(counter.item()) == want and torch.equal(out, table[want])
+    for a, b in zip(m1.parameters(), m2.parameters()):
+        torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6)
+    before = o2.params.clone()
+    o2.step(1.0, flag, rotate=(table, out, counter))
+    assert torch.equal(before, o2.params) and int(counter.item()) == 2 and torch.equal(out, table[2])
 
 
 @pytest.mark.parametrize("name", ["F9_ppo_train", "F9_ppo_train_earlystop"])
