@@ -787,7 +787,14 @@ __global__ __launch_bounds__(256) void k_bn2_bwd_finalize(const float *__restric
     const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int which = o / kC, c = o % kC;
     double acc = 0.0;
-    for (int b = sl; b < B; b += 8) acc += (double)partials[((size_t)b * kC + c) * 2 + which];
+    for (int b = sl; b < B; b += 64) {  // (eight requests in flight, clamped duplicates: same order of additions)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partials[((size_t)min(b + 8 * u, B - 1) * kC + c) * 2 + which];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (b + 8 * u < B) acc += (double)v[u];
+    }
     sh[sl][o] = acc;
     __syncthreads();
     if (sl == 0) {

@@ -315,9 +315,18 @@ __global__ __launch_bounds__(256) void k_linear_reduce(const float *__restrict__
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e4 < total4) {
         const int per = (nchunks + kRedSplit - 1) / kRedSplit, c0 = part * per, c1 = min(nchunks, c0 + per);
-        for (int c = c0; c < c1; ++c) {
-            const float4 v = ld4g(partial + ((size_t)c * M * N) + e4 * 4);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        // eight chunks requested before the first is added (clamped duplicates past the end: unconditional requests) -- as a plain
+        // loop this was one round trip per chunk, 32 in a row on the update's critical path; same order of additions
+        constexpr int kU = 8;
+        for (int c = c0; c < c1; c += kU) {
+            float4 v[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) v[u] = ld4g(partial + ((size_t)min(c + u, c1 - 1) * M * N) + e4 * 4);
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+                if (c + u < c1) {
+                    s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
+                }
         }
     }
     sub[part][q] = s;
