@@ -47,7 +47,11 @@ def parse():
                     "trigger, so every timed iteration runs all n_epochs x minibatches (the check itself still runs on the device); "
                     "'ref': the reference's 0.05, under which a random-init policy on the synthetic feed stops some iterations early")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-tuning", action="store_true", help="enable TunableOp for library GEMMs (none is left on the timed path; "
+                    "its warm-up injected ~15 k flush_icache launches)")
     ap.add_argument("--save-gemm-tuning", default=None, help="write the TunableOp selections to this file")
+    ap.add_argument("--no-flat-rows", action="store_true", help="skip the second, shorter measurement with the reference's flat fp32 rows")
+    ap.add_argument("--no-state-check", action="store_true", help="skip the oracle replay of sampled envs over the last timed rollout")
     return ap.parse_args()
 
 
@@ -195,7 +199,7 @@ def cpu_baseline(args, cfg):
         torch.nn.utils.clip_grad_norm_(pol.parameters(), 1.0); pol.optimizer.step()
     t_train = time.time() - t_train0
     total = t_rollout + args.n_epochs * t_train
-    return {"value": n * t_steps / total, "unit": "env-steps/s", "cores": int(cores), "host_cores": int(host_cores), "kind": "port",
+    return {"value": n * t_steps / total, "unit": "env-steps/s", "cores": int(cores), "host_cores": int(host_cores), "kind": "port, extrapolated",
             "sample": f"{n} envs x {t_steps} env steps at {cfg.camera_height}x{cfg.camera_width}, {cfg.grid_size}^3: oracle state "
                       f"encoding (OpenMP, {omp_threads} threads) + torch-CPU fp32 policy / GAE / PPO ({torch.get_num_threads()} threads; "
                       f"1 epoch of {n * t_steps // mb} minibatches of {mb} measured, x{args.n_epochs} epochs)",
@@ -324,6 +328,33 @@ def encoder_roofline(algo, args, device, iters: int = 20):
             "hbm": {"achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0}}
 
 
+def flat_rows_line(args, device, steps: int = 2):
+    """The same iteration with the REFERENCE's rollout-buffer layout -- flat fp32 rows [state | grid | state_rgb]
+    (stable_baselines3/common/buffers.py:655-669; `PPO_Grid_Obs(compact_obs=False)`, the API default) -- measured in the same
+    process after the headline: 1 warm-up + `steps` timed iterations.  The env still writes the int8 grid rows the conv1
+    kernels read as a side copy (GENNBV_GRID_I8); the fp32 rows are what `get()` / checkpoints / callbacks see."""
+    import copy
+    import torch
+    a2 = copy.copy(args)
+    a2.obs = "flat"
+    torch.cuda.reset_peak_memory_stats(device)
+    algo, cfg, env = build_algo(a2, device, 0, 1)
+    algo._setup_learn(total_timesteps=10 ** 12)
+    ph = {"rollout": Phase(), "train": Phase()}
+    one_iteration(algo, ph)
+    ph = {"rollout": Phase(), "train": Phase()}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_iteration(algo, ph)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"value": args.envs * args.n_steps * steps / el, "unit": "env-steps/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": 1,
+            "obs_rows": "flat fp32 rows (the reference's layout, buffers.py:655-669)",
+            "breakdown_ms_per_step": {"rollout": ph["rollout"].total_ms() / steps, "train": ph["train"].total_ms() / steps},
+            "hbm_peak_allocated_gb": torch.cuda.max_memory_allocated(device) / 1e9}
+
+
 def _flush_c_stdio():
     """RCCL writes a version banner with printf; flush it so that it cannot land after the JSON line."""
     import ctypes
@@ -354,7 +385,8 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from gennbv_amd import gemm_tuning
-    gemm_tuning.enable()  # rocBLAS / hipBLASLt algorithm selection for the Linear layers (warm-up tunes new shapes)
+    if args.gemm_tuning or args.save_gemm_tuning:
+        gemm_tuning.enable()  # rocBLAS / hipBLASLt algorithm selection (no library GEMM is left in the captured minibatch or the rollout step)
     algo, cfg, env = build_algo(args, device, rank, world)
     algo._setup_learn(total_timesteps=10 ** 12)
 
@@ -424,11 +456,27 @@ def main():
                      "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                      "launch_ms": vox_ms, "algorithmic_bytes_per_launch": args.envs * b_lay,
                      "bytes_basis": "this layout's compulsory HBM bytes (depth + seg, 1-byte code R+W, int8 tri-class W, 7 bitmask passes, ray lists)",
+                     "frac_survey_bytes": (args.envs * b_ref / (vox_ms * 1e-3) / 1e9) / 8000.0,
+                     "frac_survey_bytes_note": "SURVEY 8(d) bytes (depth + seg + six fp32 passes over G^3) / launch time / 8 TB/s; > 1 reflects the "
+                                               "re-layout (1-byte probability code, bit-packed gt / scanned, int8 tri-class rows: 4.2x fewer bytes), "
+                                               "not a kernel above the roof -- `frac` prices the bytes really moved",
                      "vs_reference_layout_floor": {"reference_layout_bytes_per_launch": args.envs * b_ref,
                                                    "floor_ms_at_peak": args.envs * b_ref / 8e12 * 1e3,
                                                    "speedup_over_floor": (args.envs * b_ref / 8e12 * 1e3) / vox_ms},
                      "traffic": traffic, "traffic_source": traffic_src},
     }
+    if rank == 0 and args.backend == "hip" and not args.no_state_check:
+        # Self-check of the TIMED tensors: sampled envs of the last timed rollout are replayed through the CPU oracle from an
+        # episode boundary inside the buffer -- same frames, same actions -- and every stored observation row, reward, done flag and
+        # the env's final probability / scanned grids are compared bit for bit (tests/state_check.py; the oracle is the checker only).
+        try:
+            from tests import state_check
+            sel = sorted({0, args.envs // 2 - 27, args.envs - 1} & set(range(args.envs)))
+            res = state_check.check_rollout(algo, sel, max_steps=40)
+            out["timed_state_check"] = res["status"]
+            out["timed_state_check_detail"] = {k: v for k, v in res.items() if k != "status"}
+        except Exception as ex:
+            out["timed_state_check"] = "error: " + repr(ex)
     if rank == 0:
         try:
             out["encoder_roofline"] = encoder_roofline(algo, args, device)
@@ -443,6 +491,16 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, cfg)
             except Exception as ex:  # the baseline must never take the bench line down
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)}
+        flat_bytes = (args.n_steps + 1) * args.envs * cfg.obs_dim * 4
+        if world == 1 and args.obs == "compact" and not args.no_flat_rows and flat_bytes < 100e9:
+            try:
+                del algo, env, vox
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+                out["config"]["flat_rows"] = flat_rows_line(args, device)
+            except Exception as ex:
+                out["config"]["flat_rows"] = {"value": None, "error": repr(ex)}
     if args.save_gemm_tuning and rank == 0:
         gemm_tuning.save(args.save_gemm_tuning)
     if dist.is_initialized():

@@ -103,7 +103,8 @@ class GnbvEncoderParams(C.Structure):
                 ("w2", _p), ("b2", _p), ("bn2_w", _p), ("bn2_b", _p), ("bn2_rm", _p), ("bn2_rv", _p), ("bn2_nbt", _p),
                 ("eps", _f), ("momentum", _f), ("act_bf16", _i), ("grid_i8", _p), ("grid_i8_row_stride", _i64),
                 ("autocorr", _p), ("autocorr_row_stride", _i64),
-                ("world", _i), ("sync_sum", _p), ("sync_ctx", _p), ("sync_buf", _p), ("autocorr_global", _p)]
+                ("world", _i), ("sync_sum", _p), ("sync_ctx", _p), ("sync_buf", _p), ("autocorr_global", _p),
+                ("force_fp32", _i), ("range_flag", _p)]
 
 
 class GnbvEncoderGrads(C.Structure):
@@ -143,7 +144,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.gnbv_abi_version() != 1:
+    if lib.gnbv_abi_version() != 2:
         raise GennbvHipError("libgennbv_hip.so ABI version mismatch")
     _lib = lib
     return lib

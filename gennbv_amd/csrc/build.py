@@ -43,17 +43,25 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Every translation unit is compiled (in parallel: they are independent) unless its object is newer than the unit, the
+    headers and this script; `force` recompiles all of them."""
     if not force and not needs_build():
         return OUT
+    from concurrent.futures import ThreadPoolExecutor
     cc = hipcc()
-    objs = []
-    for s in SOURCES:
-        o = os.path.join(HERE, os.path.splitext(s)[0] + ".o")
-        cmd = [cc] + flags() + ["-c", os.path.join(HERE, s), "-o", o]
+    hdr_t = max(os.path.getmtime(os.path.join(HERE, h)) for h in HEADERS + [os.path.basename(__file__)])
+
+    def compile_one(s):
+        src, o = os.path.join(HERE, s), os.path.join(HERE, os.path.splitext(s)[0] + ".o")
+        if not force and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(src), hdr_t):
+            return o
+        cmd = [cc] + flags() + ["-c", src, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        objs.append(o)
+        return o
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
     cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

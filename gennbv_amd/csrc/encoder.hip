@@ -587,15 +587,35 @@ __device__ __forceinline__ void bn_finalize_channel(int c, double sum, double su
     rstd_out[c] = rstd;
 }
 
+// Range guard of the split-f16 kernels (conv_split.h): z1 = relu(scale * y1 + shift) is stored as f16 x 2^8 and CLAMPED at 253.9.
+// conv1's input is a tri-class grid (|x| <= 1), so |y1[c] - b1[c]| <= sum_t |W1[c][t]| and
+//     z1[c] <= |scale| * sum_t |W1[c][t]| + |scale * b1[c] + shift|
+// -- a bound from the parameters alone, evaluated by the one thread that just wrote scale[c] / shift[c].  A channel whose bound
+// reaches the clamp sets bit 1 of *range_flag (GnbvEncoderParams.range_flag); the host mirror reads the word once per train() /
+// rollout and raises (or selects the fp32-MFMA kernels, GnbvEncoderParams.force_fp32).  Default-initialised and normally trained
+// layers sit at 5 - 40.
+__device__ __forceinline__ void l1_range_guard(int c, const float *__restrict__ W1, const float *__restrict__ b1, const float *scale,
+                                               const float *shift, int *__restrict__ range_flag)
+{
+    if (range_flag == nullptr || W1 == nullptr) return;
+    float s = 0.0f;
+    for (int t = 0; t < kTaps; ++t) s += fabsf(W1[c * kTaps + t]);
+    const float bound = fabsf(scale[c]) * s + fabsf(fmaf(scale[c], b1[c], shift[c]));
+    if (!(bound <= 253.0f)) atomicOr(range_flag, 2);
+}
+
 // eval mode: statistics = running stats (no reduction)
 __global__ void k_bn_finalize(double count, const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
                               float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ scale,
-                              float *__restrict__ shift, float *__restrict__ mean_out, float *__restrict__ rstd_out)
+                              float *__restrict__ shift, float *__restrict__ mean_out, float *__restrict__ rstd_out,
+                              const float *__restrict__ rg_W1 = nullptr, const float *__restrict__ rg_b1 = nullptr, int *__restrict__ range_flag = nullptr)
 {
     const int c = threadIdx.x;
-    if (c < kC)
+    if (c < kC) {
         bn_finalize_channel(c, 0.0, 0.0, count, gamma, beta, eps, momentum, 0, running_mean, running_var, nullptr, nullptr, scale, shift,
                             mean_out, rstd_out);
+        l1_range_guard(c, rg_W1, rg_b1, scale, shift, range_flag);  // (layer 1 only: the callers pass W1 for it)
+    }
 }
 
 // data-parallel: BatchNorm finalize (train mode) from batch sums that were summed over the replicas
@@ -628,7 +648,9 @@ __global__ __launch_bounds__(1024) void k_stats_reduce(const float *__restrict__
                                                        float momentum, float *__restrict__ running_mean, float *__restrict__ running_var,
                                                        int64_t *__restrict__ num_batches_tracked, const int *__restrict__ skip_flag,
                                                        float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out,
-                                                       float *__restrict__ rstd_out, const float *__restrict__ W2, float *__restrict__ w2img)
+                                                       float *__restrict__ rstd_out, const float *__restrict__ W2, float *__restrict__ w2img,
+                                                       const float *__restrict__ rg_W1 = nullptr, const float *__restrict__ rg_b1 = nullptr,
+                                                       int *__restrict__ range_flag = nullptr)
 {
     // (same launch, independent work) the two LDS weight images of the conv2 kernels: saves a dependent launch
     if (W2 != nullptr)
@@ -658,9 +680,11 @@ __global__ __launch_bounds__(1024) void k_stats_reduce(const float *__restrict__
         if (out_d != nullptr) out_d[threadIdx.x] = t;
     }
     __syncthreads();
-    if (gamma != nullptr && threadIdx.x < kC)
+    if (gamma != nullptr && threadIdx.x < kC) {
         bn_finalize_channel(threadIdx.x, tot[threadIdx.x], tot[kC + threadIdx.x], count, gamma, beta, eps, momentum, 1, running_mean,
                             running_var, num_batches_tracked, skip_flag, scale, shift, mean_out, rstd_out);
+        l1_range_guard(threadIdx.x, rg_W1, rg_b1, scale, shift, range_flag);
+    }
 }
 
 // out[e] = sum_p partial[p][e] in fp64 and in a fixed order (deterministic), two stages:
@@ -725,13 +749,19 @@ __global__ __launch_bounds__(256) void k_reduce_partials4(const float *__restric
 }
 
 // z2 = relu(scale2*y2 + shift2), y2 NCDHW [B,16,P2] -> flat features [B, 16*P2]
+// (range guard, bit 2 of *range_flag: these features are fc_grid's input, which the split-f16 linear kernels clamp at 1015,
+// csrc/linear.hip -- the largest value is tracked here, where every element passes through a register anyway)
 __global__ void k_bn_relu_apply(const float *__restrict__ y2, const float *__restrict__ scale, const float *__restrict__ shift,
-                                int64_t total, int P2, float *__restrict__ z2)
+                                int64_t total, int P2, float *__restrict__ z2, int *__restrict__ range_flag)
 {
+    float zmax = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)((i / P2) % kC);
-        z2[i] = fmaxf(fmaf(scale[c], y2[i], shift[c]), 0.0f);
+        const float z = fmaxf(fmaf(scale[c], y2[i], shift[c]), 0.0f);
+        z2[i] = z;
+        zmax = fmaxf(zmax, z);  // (fmaxf drops a NaN: NaNs are not this guard's business)
     }
+    if (range_flag != nullptr && __any(zmax > 1000.0f) && (threadIdx.x & (kWave - 1)) == 0) atomicOr(range_flag, 4);
 }
 
 // ---------------------------------------------------------------------------
@@ -1636,7 +1666,8 @@ __global__ __launch_bounds__(1024) void k_bn1_analytic(const int *__restrict__ a
                                                       float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out,
                                                       float *__restrict__ rstd_out, int *__restrict__ total_out /*[kAcRow]: saved for backward*/,
                                                       const int *__restrict__ ac_global /*NULL, or [kAcRow]: total over ALL replicas (statistics)*/,
-                                                      const float *__restrict__ W2 = nullptr, float *__restrict__ w2img = nullptr)
+                                                      const float *__restrict__ W2 = nullptr, float *__restrict__ w2img = nullptr,
+                                                      int *__restrict__ range_flag = nullptr)
 {
     if (blockIdx.x > 0) {  // extra workgroups: the conv2 kernels' f16 weight images (when no conv1 kernel follows to write them in passing)
         prep_w2_split_items(W2, w2img, (blockIdx.x - 1) * blockDim.x + threadIdx.x, (gridDim.x - 1) * blockDim.x);
@@ -1673,6 +1704,7 @@ __global__ __launch_bounds__(1024) void k_bn1_analytic(const int *__restrict__ a
         }
         bn_finalize_channel(c, wt + count * bb, quad + 2.0 * bb * wt + count * bb * bb, count, gamma, beta, eps, momentum, 1, running_mean,
                             running_var, num_batches_tracked, skip_flag, scale, shift, mean_out, rstd_out);
+        l1_range_guard(c, W1, b1, scale, shift, range_flag);
     }
 }
 
@@ -2063,7 +2095,7 @@ static inline bool env_off(const char *name)
 static inline bool conv_split_path(const GnbvEncoderParams *p, int grid)
 {
     const int O1 = out_size(grid), O2 = out_size(O1);
-    return !env_off("GENNBV_CONV_SPLIT") && !p->act_bf16 && (O1 + 1) / 2 == 16 && O2 <= 15;
+    return !env_off("GENNBV_CONV_SPLIT") && !p->force_fp32 && !p->act_bf16 && (O1 + 1) / 2 == 16 && O2 <= 15;
 }
 static inline bool fused_path(const GnbvEncoderParams *p, int grid)
 {
@@ -2143,7 +2175,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     bool fused_train = false;
     if (fused_eval) {
         hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps, p->momentum, p->bn1_rm,
-                           p->bn1_rv, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC);
+                           p->bn1_rv, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->w1, p->b1, p->range_flag);
         hipLaunchKernelGGL(k_prep_w2_split_only, dim3(12), dim3(256), 0, st, p->w2, w.w2img);
         if ((err = gnbv_launch_status())) return err;
         static bool attr_fe = false;
@@ -2165,10 +2197,10 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
             hipLaunchKernelGGL(k_bn1_analytic, dim3(1), dim3(1024), 0, st, p->autocorr ? (const int *)p->autocorr : (const int *)Rac,
                                p->autocorr_row_stride, rows, p->autocorr ? batch : 0, p->w1, p->b1, p->bn1_w, p->bn1_b, p->eps, p->momentum,
                                p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC,
-                               (int *)(bn_state + kBnStateFloats), (const int *)nullptr);
+                               (int *)(bn_state + kBnStateFloats), (const int *)nullptr, (const float *)nullptr, (float *)nullptr, p->range_flag);
         } else {
             hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps, p->momentum,
-                               p->bn1_rm, p->bn1_rv, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC);
+                               p->bn1_rm, p->bn1_rv, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->w1, p->b1, p->range_flag);
         }
         if ((err = gnbv_launch_status())) return err;
         hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, int8_t>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads),
@@ -2187,7 +2219,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
         hipLaunchKernelGGL(k_bn1_analytic, dim3(fused_train ? 3 : 1), dim3(1024), 0, st, (const int *)p->autocorr, p->autocorr_row_stride, rows, batch, p->w1,
                            p->b1, p->bn1_w, p->bn1_b, p->eps, p->momentum, p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag, bn1, bn1 + kC, bn1 + 2 * kC,
                            bn1 + 3 * kC, (int *)(bn_state + kBnStateFloats), dp ? (const int *)p->autocorr_global : (const int *)nullptr,
-                           p->w2, w.w2img);
+                           p->w2, w.w2img, p->range_flag);
         if ((err = gnbv_launch_status())) return err;
     }
     float *c1_part = (training && !analytic) ? w.bn_part : nullptr;
@@ -2238,10 +2270,10 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     } else if (training)
         hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, st, w.bn_part, sample_plane_grid(batch, O1), (double *)nullptr,
                            (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps, p->momentum, p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag,
-                           bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, (const float *)nullptr, (float *)nullptr);
+                           bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, (const float *)nullptr, (float *)nullptr, p->w1, p->b1, p->range_flag);
     else
         hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps, p->momentum,
-                           p->bn1_rm, p->bn1_rv, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC);
+                           p->bn1_rm, p->bn1_rv, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->w1, p->b1, p->range_flag);
     if ((err = gnbv_launch_status())) return err;
     }
     // conv2 (BN1 + ReLU on load; + BN2 statistics).  Its LDS weight images were written by the conv1 kernel in passing.
@@ -2295,7 +2327,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     const int64_t total = (int64_t)batch * kC * P2;
     int grid_x = (int)((total + 255) / 256);
     grid_x = grid_x > 4096 ? 4096 : grid_x;
-    hipLaunchKernelGGL(k_bn_relu_apply, dim3(grid_x), dim3(256), 0, st, y2, bn2, bn2 + kC, total, P2, features);
+    hipLaunchKernelGGL(k_bn_relu_apply, dim3(grid_x), dim3(256), 0, st, y2, bn2, bn2 + kC, total, P2, features, p->range_flag);
     return gnbv_launch_status();
 }
 

@@ -556,7 +556,9 @@ GNBV_API int gnbv_linear_forward(const float *x, const float *w, const float *bi
     const int nchunks = pick_chunks(K), ntn = N / kTileN;
     const int blocks = ((nchunks + 7) / 8) * 8 * ntn;
     const char *e = getenv("GENNBV_CONV_SPLIT");  // "0": the fp32-MFMA kernels everywhere (csrc/encoder.hip conv_split_path)
-    if (!(e && e[0] == '0') && K % 8 == 0 && K >= 64)
+    const bool fp32_arith = (relu & 2) != 0;  // (flag word: include/gennbv_hip.h)
+    relu &= 1;
+    if (!(e && e[0] == '0') && !fp32_arith && K % 8 == 0 && K >= 64)
         hipLaunchKernelGGL(k_linear_splitk_split, dim3(blocks, (M + 127) / 128), dim3(kLinThreads), 0, st, x, w, M, N, K, nchunks, (float *)workspace);
     else
         hipLaunchKernelGGL(k_linear_splitk, dim3(blocks, (M + 127) / 128), dim3(kLinThreads), 0, st, x, w, M, N, K, nchunks, (float *)workspace);

@@ -21,7 +21,9 @@ buffer hand its own storage to the env (no assemble + copy pass).
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 from typing import Optional
 
@@ -170,6 +172,7 @@ class ReplayFeedEnv:
         p.episode_state, p.max_episode_length_s = self.episode_state.data_ptr(), float(np.float32(self.max_episode_length_s))
         self._ep_step = 0
         self._ep_cache = (-1, None)
+        self._ep_live = collections.deque()
         self._post = p
         self.extras = {}
 
@@ -258,7 +261,20 @@ class ReplayFeedEnv:
         a = actions.to(torch.int64).contiguous()
         obs = self._observe_and_finish(a, obs_out, grid_i8_out)
         self.extras["time_outs"] = self.extras_time_outs.bool()
-        self.extras["episode"] = _LazyEpisodeInfo(self, self._ep_step)
+        info = _LazyEpisodeInfo(self, self._ep_step)
+        self.extras["episode"] = info
+        # dicts that are still referenced when their snapshot slot is about to be overwritten keep their last values (the
+        # reference hands out plain dicts that never fail); the common case -- nobody holds a dict for ~1000 env steps --
+        # costs one weakref per step and no read-back
+        live = self._ep_live
+        live.append(weakref.ref(info))
+        while live:
+            d = live[0]()
+            if d is not None and self._ep_step - d._step < self._ep_hist - 2:
+                break
+            live.popleft()
+            if d is not None:
+                d._freeze()
         return obs, self.rew_buf, self.reset_buf.bool(), self.extras
 
     # ------------------------------------------------------------------------
@@ -295,7 +311,14 @@ class _LazyEpisodeInfo(dict):
         super().__init__()
         self._env, self._step, self._seen = env, step, -1
 
+    def _freeze(self):
+        """Resolve once more and detach from the env: from here on a plain dict with the last values."""
+        self._fill()
+        self._env = None
+
     def _fill(self):
+        if self._env is None:
+            return
         if self._seen != self._env._ep_step:  # (the reference keeps mutating the dict while it is alive: refresh per env step)
             self._seen = self._env._ep_step
             super().update(self._env.episode_info(self._step))

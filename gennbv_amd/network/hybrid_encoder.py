@@ -84,6 +84,10 @@ class Hybrid_Encoder(nn.Module):
         # 2**arange(2); kept on the module's device (not in the state_dict) so that the forward is
         # capturable in a hipGraph -- the reference re-creates and uploads it on every call (:71)
         self.register_buffer("_freq_bands", 2 ** torch.arange(2).float(), persistent=False)
+        # operand ranges of the split-f16 kernels (check_operand_ranges): a device word the kernels OR activation-bound bits into
+        # (GnbvEncoderParams.range_flag) and the switch that keeps this encoder on the fp32-MFMA kernels (.force_fp32)
+        self.register_buffer("_range_flag", torch.zeros(1, dtype=torch.int32), persistent=False)
+        self.force_fp32 = False
 
     @property
     def features_dim(self) -> int:
@@ -95,6 +99,52 @@ class Hybrid_Encoder(nn.Module):
         freq_bands = self._freq_bands if freqs == 2 else (2 ** torch.arange(freqs).float()).to(positions.device)
         pts = (positions[..., None] * freq_bands).reshape(positions.shape[:-1] + (freqs * positions.shape[-1],))
         return torch.cat([torch.sin(pts), torch.cos(pts)], dim=-1)
+
+    # Limits of the split-f16 arithmetic (csrc/conv_split.h, csrc/linear.hip): operands are written as f16 hi + lo
+    # halves under fixed power-of-two scalings and CLAMPED beyond them.  The margins below leave room for one train() call's
+    # worth of Adam steps (|delta w| <= lr per step) and for batch statistics that differ from the running ones.
+    W2_LIMIT, W_FC_LIMIT, Z1_LIMIT = 62.0, 15.5, 126.0
+
+    def check_operand_ranges(self) -> dict:
+        """Make the range limits of the split-f16 kernels LOUD instead of silent.  Two parts, one host read each:
+
+        * parameter pre-check: max |W2| (limit 63.4), max |W| of fc_grid and the pose linears (15.8), and BatchNorm-1's activation
+          bound |scale| sum|W1| + |scale b1 + shift| from the RUNNING statistics (clamp at 253.9, checked at half of it).  A
+          violation switches this encoder to the fp32-MFMA kernels (`force_fp32`; exact, slower) -- nothing was computed yet;
+        * activation flags the kernels raised since the last call (BatchNorm-1 bound from the BATCH statistics, features above
+          1000): the calls in between may have clamped -> `force_fp32` is set for what follows and GennbvHipError is raised.
+
+        Called by PPO_Grid_Obs at the start and end of train() and collect_rollouts(); cheap (a few reductions, 2 reads)."""
+        from .. import _lib
+        seq = self.naive_encoder_grid
+        info = {"force_fp32": bool(self.force_fp32), "flag": 0}
+        if not seq[0].weight.is_cuda:
+            return info
+        with torch.no_grad():
+            w1, b1, bn1 = seq[0].weight.reshape(16, -1), seq[0].bias, seq[1]
+            sc = bn1.weight * torch.rsqrt(bn1.running_var + bn1.eps)
+            z1 = sc.abs() * w1.abs().sum(1) + (sc * b1 + bn1.bias - bn1.running_mean * sc).abs()
+            lin = [self.output_layer_grid[0]] + [m for m in self.naive_encoder_action if isinstance(m, nn.Linear)]
+            # the pose branch's second linear reads relu(W p + b) with |p| <= 1 (sin / cos): bounded by its rows' absolute sums
+            pose = [m for m in self.naive_encoder_action if isinstance(m, nn.Linear)]
+            xpose = (pose[0].weight.abs().sum(1) + pose[0].bias.abs()).max() if len(pose) > 1 else torch.zeros((), device=w1.device)
+            vals = torch.stack([seq[3].weight.abs().max(), torch.stack([m.weight.abs().max() for m in lin]).max(), z1.max(), xpose,
+                                self._range_flag[0].float()]).cpu()
+        w2max, wfcmax, z1max, xpmax, flag = (float(v) for v in vals)
+        info.update(w2_max=w2max, w_fc_max=wfcmax, z1_bound=z1max, pose_hidden_bound=xpmax, flag=int(flag))
+        bad = not (w2max < self.W2_LIMIT and wfcmax < self.W_FC_LIMIT and z1max < self.Z1_LIMIT and xpmax < 1000.0)  # (a NaN fails too)
+        if (bad or flag) and not self.force_fp32:
+            self.force_fp32 = True
+            for m in lin:
+                m._fp32_arith = True
+            info["force_fp32"] = True
+        if flag:
+            self._range_flag.zero_()
+            raise _lib.GennbvHipError(
+                f"split-f16 kernels: an activation left its range (flag {int(flag)}: 2 = relu(bn1(conv1)) bound above 253, 4 = a feature "
+                "above 1000); results since the last check may be clamped.  This encoder now runs on the fp32-MFMA kernels "
+                "(force_fp32): repeat the call.")
+        return info
 
     def forward(self, observations) -> torch.Tensor:
         from ..ops import encoder_ops

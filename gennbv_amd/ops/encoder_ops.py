@@ -121,7 +121,7 @@ def autocorr_supported(grid: int) -> bool:
 
 
 def _params_struct(seq, act_bf16: bool = False, grid_i8: Optional[torch.Tensor] = None,
-                   autocorr: Optional[torch.Tensor] = None, dp=None) -> _lib.GnbvEncoderParams:
+                   autocorr: Optional[torch.Tensor] = None, dp=None, guard=None) -> _lib.GnbvEncoderParams:
     conv1, bn1, conv2, bn2 = seq[0], seq[1], seq[3], seq[4]
     p = _lib.GnbvEncoderParams()
     p.w1, p.b1, p.bn1_w, p.bn1_b = conv1.weight.data_ptr(), conv1.bias.data_ptr(), bn1.weight.data_ptr(), bn1.bias.data_ptr()
@@ -140,12 +140,15 @@ def _params_struct(seq, act_bf16: bool = False, grid_i8: Optional[torch.Tensor] 
     p.sync_ctx = None
     p.sync_buf = None if dp is None else dp["sync_buf"].data_ptr()
     p.autocorr_global = None if dp is None else dp["autocorr_global"].data_ptr()
+    # operand ranges of the split-f16 kernels (network/hybrid_encoder.py: check_operand_ranges): (force_fp32, range_flag tensor)
+    p.force_fp32 = 0 if guard is None else int(bool(guard[0]))
+    p.range_flag = None if guard is None or guard[1] is None else guard[1].data_ptr()
     return p
 
 
 class _GridEncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, base, rows, grid_off, grid, training, skip_flag, seq, act_bf16, write_through, grid_i8, compact, autocorr, dp, w1, b1, g1, be1, w2, b2, g2, be2):
+    def forward(ctx, base, rows, grid_off, grid, training, skip_flag, seq, act_bf16, write_through, grid_i8, compact, autocorr, dp, guard, w1, b1, g1, be1, w2, b2, g2, be2):
         lib = _lib.load()
         _lib.require_cuda(base, w1)
         for t in (w1, b1, g1, be1, w2, b2, g2, be2):
@@ -161,7 +164,7 @@ class _GridEncoderFn(torch.autograd.Function):
         bn_state = torch.empty(2 * 4 * 16 + 768, dtype=torch.float32, device=dev)  # + the minibatch's autocorrelation total (ints)
         feats = torch.empty(batch, 16 * p2, dtype=torch.float32, device=dev)
         ws = _workspace(lib, batch, grid, dev)
-        params = _params_struct(seq, act_bf16, grid_i8, autocorr, dp if training else None)
+        params = _params_struct(seq, act_bf16, grid_i8, autocorr, dp if training else None, guard)
         # compact observations: `base` has no grid slice, the kernels read the int8 rows only (obs pointer NULL)
         assert not compact or grid_i8 is not None
         obs_ptr = None if compact else base.data_ptr() + 4 * grid_off
@@ -175,6 +178,7 @@ class _GridEncoderFn(torch.autograd.Function):
         ctx.grid_i8 = grid_i8
         ctx.autocorr = autocorr
         ctx.dp = dp if training else None
+        ctx.guard = guard
         ctx.obs_ptr = obs_ptr
         return feats
 
@@ -196,23 +200,25 @@ class _GridEncoderFn(torch.autograd.Function):
         gs = _lib.GnbvEncoderGrads()
         for name, t in zip(("w1", "b1", "bn1_w", "bn1_b", "w2", "b2", "bn2_w", "bn2_b"), grads):
             setattr(gs, name, t.data_ptr())
-        params = _params_struct(seq, act_bf16, ctx.grid_i8, ctx.autocorr, ctx.dp)
+        params = _params_struct(seq, act_bf16, ctx.grid_i8, ctx.autocorr, ctx.dp, ctx.guard)
         ws = _workspace(lib, batch, grid, dev)
         _lib.check(lib.gnbv_encoder_grid_backward(
             ctx.obs_ptr, _lib.ptr(rows), base.stride(0), batch, grid, C.byref(params), y1.data_ptr(),
             y2.data_ptr(), bn_state.data_ptr(), d_feats.data_ptr(), dy2.data_ptr(), dz1.data_ptr(), C.byref(gs),
             ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "gnbv_encoder_grid_backward")
         if direct:
-            return (None,) * 21
-        return (None,) * 13 + tuple(grads)
+            return (None,) * 22
+        return (None,) * 14 + tuple(grads)
 
 
 def grid_encoder(base: torch.Tensor, rows: Optional[torch.Tensor], grid_off: int, grid: int, seq, training: bool,
                  skip_flag: Optional[torch.Tensor] = None, act_bf16: bool = False, write_through: bool = False,
-                 grid_i8: Optional[torch.Tensor] = None, compact: bool = False, autocorr: Optional[torch.Tensor] = None, dp=None) -> torch.Tensor:
+                 grid_i8: Optional[torch.Tensor] = None, compact: bool = False, autocorr: Optional[torch.Tensor] = None, dp=None,
+                 guard=None) -> torch.Tensor:
     """seq = the `naive_encoder_grid` nn.Sequential (conv, bn, relu, conv, bn, relu).  `compact`: `base` rows carry
-    no grid slice, the grid is read from `grid_i8` only.  `autocorr`: per-row input autocorrelation (input_autocorr)."""
-    return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, bool(act_bf16), bool(write_through), grid_i8, bool(compact), autocorr, dp, seq[0].weight, seq[0].bias,
+    no grid slice, the grid is read from `grid_i8` only.  `autocorr`: per-row input autocorrelation (input_autocorr).
+    `guard` = (force_fp32, range_flag int32 [1] or None): GnbvEncoderParams.force_fp32 / .range_flag."""
+    return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, bool(act_bf16), bool(write_through), grid_i8, bool(compact), autocorr, dp, guard, seq[0].weight, seq[0].bias,
                                 seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias)
 
 
@@ -220,20 +226,23 @@ class _LinearReluFn(torch.autograd.Function):
     """relu(x @ w.T + b) on the split-K MFMA kernel (csrc/linear.hip); backward = three library GEMMs."""
 
     @staticmethod
-    def forward(ctx, x, w, b, mod=None):
+    def forward(ctx, x, w, b, mod=None, fp32_arith=False):
         ctx.mod = mod  # write-through target (ops/direct_grad.py) or None
+        ctx.fp32_arith = bool(fp32_arith)  # operand outside the split-f16 ranges: the fp32-MFMA kernel forward, library GEMMs backward
         lib = _lib.load()
         _lib.require_cuda(x, w, b)
         x = x.contiguous()
         m, k = x.shape
         n = w.shape[0]
         out = torch.empty(m, n, dtype=torch.float32, device=x.device)
-        key = ("lin", m, n, k, str(x.device))
+        # one workspace per LAYER (keyed by its weight storage), not per shape: same-shape layers of another model / policy
+        # instance, or of the pose branch on the second stream, must not share split-K partials
+        key = ("lin", m, n, k, str(x.device), w.data_ptr())
         ws = _ws_cache.get(key)
         if ws is None:
             ws = torch.empty(lib.gnbv_linear_workspace_bytes(m, n, k), dtype=torch.uint8, device=x.device)
             _ws_cache[key] = ws
-        _lib.check(lib.gnbv_linear_forward(x.data_ptr(), w.data_ptr(), b.data_ptr(), m, n, k, 1, out.data_ptr(), ws.data_ptr(),
+        _lib.check(lib.gnbv_linear_forward(x.data_ptr(), w.data_ptr(), b.data_ptr(), m, n, k, 1 | (2 if fp32_arith else 0), out.data_ptr(), ws.data_ptr(),
                                            ws.numel(), _lib.stream_ptr(x.device)), "gnbv_linear_forward")
         ctx.save_for_backward(x, w, out)
         return out
@@ -246,18 +255,23 @@ class _LinearReluFn(torch.autograd.Function):
         defer = direct and getattr(mod, "_async_wgrad", False) and getattr(mod, "_defer_wgrad", False)
         m, k = x.shape
         n = w.shape[0]
-        if (os.environ.get("GENNBV_CONV_SPLIT", "1") != "0" and m % 16 == 0 and m <= 128 and n % 16 == 0 and n <= 256 and k % 4 == 0 and k >= 64
+        if (os.environ.get("GENNBV_CONV_SPLIT", "1") != "0" and not ctx.fp32_arith and m % 16 == 0 and m <= 128 and n % 16 == 0 and n <= 256 and k % 4 == 0 and k >= 64
                 and x.dtype == torch.float32 and x.is_contiguous() and w.is_contiguous()):
             # hand-written split-f16 products (csrc/linear.hip): prep (mask, row scales, operand images, db), then dx here and
             # dW either here or -- deferred, see below -- on the second stream
             lib = _lib.load()
             d_out = d_out.contiguous()
             dev = x.device
-            key = ("linbwd", m, n, k, str(dev))
+            # per layer as well: a deferred dW launch (below) reads the operand images prep leaves here long after this
+            # function returns, so another layer of the same shape must never write the same buffer in between
+            key = ("linbwd", m, n, k, str(dev), w.data_ptr())
             ws = _ws_cache.get(key)
             if ws is None:
                 ws = torch.empty(lib.gnbv_linear_bwd_workspace_bytes(m, n, k), dtype=torch.uint8, device=dev)
                 _ws_cache[key] = ws
+            if any(ws is t for _, keep, _ in _deferred_wgrad for t in keep):
+                raise RuntimeError("linear_relu backward: this layer's previous deferred weight gradient has not been joined "
+                                   "(call join_async_wgrads() after every backward that sets _defer_wgrad)")
             db = mod.bias.grad if direct else torch.empty(n, dtype=torch.float32, device=dev)
             dw = mod.weight.grad if direct else torch.empty(n, k, dtype=torch.float32, device=dev)
             _lib.check(lib.gnbv_linear_bwd_prep(d_out.data_ptr(), out.data_ptr(), m, n, db.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)),
@@ -275,7 +289,7 @@ class _LinearReluFn(torch.autograd.Function):
                 _deferred_wgrad.append((launch_dw, (x, ws), evt))
             else:
                 launch_dw()
-            return (dx, None, None, None) if direct else (dx, dw, db, None)
+            return (dx, None, None, None, None) if direct else (dx, dw, db, None, None)
         g = torch.ops.aten.threshold_backward(d_out.contiguous(), out, 0.0)
         if defer:
             # Nothing downstream of this node needs dW / db (only the optimizer does): they are computed on a second stream
@@ -292,13 +306,13 @@ class _LinearReluFn(torch.autograd.Function):
                 torch.sum(g, 0, out=mod.bias.grad)
             _deferred_wgrad.append((launch_lib, (g, x), evt))
             dx = g @ w if ctx.needs_input_grad[0] else None
-            return dx, None, None, None
+            return dx, None, None, None, None
         dx = g @ w if ctx.needs_input_grad[0] else None
         if direct:
             torch.mm(g.t(), x, out=mod.weight.grad)
             torch.sum(g, 0, out=mod.bias.grad)
-            return dx, None, None, None
-        return dx, g.t() @ x, g.sum(0), None
+            return dx, None, None, None, None
+        return dx, g.t() @ x, g.sum(0), None, None
 
 
 _deferred_wgrad = []
@@ -325,7 +339,8 @@ def linear_relu(x: torch.Tensor, lin: torch.nn.Linear) -> torch.Tensor:
     n, k = lin.weight.shape
     if k % 4 or n % 64 or not lin.weight.is_contiguous() or x.dtype != torch.float32:
         return torch.relu(torch.nn.functional.linear(x, lin.weight, lin.bias))
-    return _LinearReluFn.apply(x, lin.weight, lin.bias, lin if getattr(lin, "_grad_write_through", False) else None)
+    return _LinearReluFn.apply(x, lin.weight, lin.bias, lin if getattr(lin, "_grad_write_through", False) else None,
+                               bool(getattr(lin, "_fp32_arith", False)))
 
 
 def hybrid_forward(enc, observations) -> torch.Tensor:
@@ -381,7 +396,7 @@ def hybrid_branches(enc, observations):
         feature_action = pose_branch()
     feature_grid = grid_encoder(base, rows, s, g, enc.naive_encoder_grid, enc.training, getattr(enc, "_bn_skip_flag", None),
                                 enc.compute_dtype == torch.bfloat16, getattr(enc, "_grad_write_through", False), grid_i8, compact, autocorr,
-                                getattr(enc, "_dp_sync", None))
+                                getattr(enc, "_dp_sync", None), (getattr(enc, "force_fp32", False), getattr(enc, "_range_flag", None)))
     if getattr(enc, "_split_backward", False) and torch.is_grad_enabled():
         # data-parallel: cut the autograd graph at the conv-stack output so that the backward runs in
         # two phases (late layers first, their gradient all-reduce overlaps the conv-stack backward)

@@ -471,6 +471,11 @@ class PPO_Grid_Obs:
             st = self._hip_setup(batch, n_mb)
         loss, opt = st["loss"], st["opt"]
         self.policy.set_training_mode(True)
+        # operand ranges of the split-f16 kernels: parameters outside them move the encoder to the fp32-MFMA kernels BEFORE anything
+        # is computed (the captured graph bakes the kernel choice in: re-capture when it flips)
+        fp32_now = self._check_ranges()
+        if st.get("force_fp32") != fp32_now:
+            st["graph"], st["force_fp32"] = None, fp32_now
         lr = self.lr_schedule(self._current_progress_remaining)
         self.logger.record("train/learning_rate", lr)
         opt.lr = lr
@@ -541,6 +546,7 @@ class PPO_Grid_Obs:
                     print(f"Early stopping at step {epoch} due to reaching max kl")
                 break
         self._n_updates += self.n_epochs
+        self._check_ranges()  # raises if a kernel of this call reached an activation bound of the split-f16 arithmetic
         rows_done = int(loss.stats_row.item())
         s = loss.stats[:rows_done].double().cpu().numpy()
         s = s[s[:, 6] > 0.5]  # minibatches the reference would have executed
@@ -561,6 +567,13 @@ class PPO_Grid_Obs:
         if clip_range_vf is not None:
             self.logger.record("train/clip_range_vf", clip_range_vf)
         self.logger.record("time/training", time.time() - training_start)
+
+    def _check_ranges(self) -> bool:
+        """Hybrid_Encoder.check_operand_ranges (split-f16 kernels' limits made loud) -> whether the encoder is on the fp32 kernels."""
+        enc = self.policy.features_extractor
+        if getattr(enc, "backend", "") != "hip" or not hasattr(enc, "check_operand_ranges"):
+            return False
+        return bool(enc.check_operand_ranges()["force_fp32"])
 
     def _capture_minibatch_graph(self, st):
         """Capture gather+forward+loss+backward+Adam of one minibatch as a hipGraph (two graphs sharing a
@@ -660,6 +673,7 @@ class PPO_Grid_Obs:
         fused_add = (self.device.type == "cuda" and getattr(self.policy, "_fused_rollout", False)
                      and os.environ.get("GENNBV_FUSED_ADD", "1") != "0")
         n_steps = 0
+        self._check_ranges()
         rollout_buffer.reset()
         first = rollout_buffer.first_obs_row()
         if self._last_obs.data_ptr() != first.data_ptr():
@@ -709,6 +723,7 @@ class PPO_Grid_Obs:
             self._last_episode_starts = dones
             self._pending = nxt
         last_values = terminal_value  # V(new_obs) of the last step (:213-215)
+        self._check_ranges()
         rollout_buffer.compute_returns_and_advantage(last_values=last_values, dones=dones)
         if callback is not None:
             callback.on_rollout_end()

@@ -13,7 +13,7 @@ Layout (stable_baselines3/common/save_util.py:289-330 of the reference): a ZIP_S
 
 Reading never needs the reference's classes: the two state dicts are plain tensors (`weights_only=True`) and from
 `data` only JSON-plain hyper-parameters are consumed.  ":serialized:" blobs go through a RESTRICTED unpickler
-(`_SafeUnpickler`: plain containers / numbers, numpy arrays and dtypes, torch dtypes, and this package's own classes)
+(`_SafeUnpickler`: plain containers / numbers, numpy arrays and dtypes, torch dtypes, and an explicit list of this package's data classes)
 -- anything else (the reference's own classes, cloudpickled lambdas, arbitrary callables) is skipped and listed in
 the returned `skipped`, so loading an untrusted archive cannot execute code from it.  `trusted=True` restores SB3's
 behaviour (full cloudpickle) for archives you wrote yourself.
@@ -77,14 +77,31 @@ _SAFE_GLOBALS = {("collections", "OrderedDict"), ("collections", "deque"),
                  ("torch", "float32"), ("torch", "float64"), ("torch", "bfloat16"), ("torch", "float16"), ("torch", "Size")}
 
 
+# classes of this package that may appear in `data` (spaces, policy / extractor classes named by `policy_kwargs`, configs).
+# An explicit (module, name) list: a module-prefix rule would let protocol-4 dotted names walk from any module of the
+# package to whatever it imports (("gennbv_amd.sb3.save_util", "os.system") resolves to os.system).
+_SAFE_PACKAGE = {("gennbv_amd.spaces", "Box"), ("gennbv_amd.spaces", "MultiDiscrete"),
+                 ("gennbv_amd.network.hybrid_encoder", "Hybrid_Encoder"),
+                 ("gennbv_amd.sb3.policies", "ActorCriticPolicy_Train_Eval"),
+                 ("gennbv_amd.sb3.distributions", "MultiCategoricalDistribution"),
+                 ("gennbv_amd.env.config", "TaskConfig"), ("gennbv_amd.env.config", "PPOConfig")}
+
+
 class _SafeUnpickler(pickle.Unpickler):
-    """Resolves only data-like globals; classes of this package are allowed by module prefix."""
+    """Resolves only data-like globals and the package's own data classes, each by exact (module, name)."""
 
     def find_class(self, module, name):
+        if "." in name:  # protocol >= 4 resolves dotted names through attributes: never needed for the allow-list
+            raise pickle.UnpicklingError(f"dotted global {module}.{name} is not allowed")
         if module == "builtins" and name in _SAFE_BUILTINS:
             return super().find_class(module, name)
-        if (module, name) in _SAFE_GLOBALS or module == "gennbv_amd" or module.startswith("gennbv_amd."):
+        if (module, name) in _SAFE_GLOBALS:
             return super().find_class(module, name)
+        if (module, name) in _SAFE_PACKAGE:
+            obj = super().find_class(module, name)
+            if not (isinstance(obj, type) and obj.__module__ == module):
+                raise pickle.UnpicklingError(f"{module}.{name} is not a class defined in {module}")
+            return obj
         raise pickle.UnpicklingError(f"global {module}.{name} is not on the allow-list")
 
 

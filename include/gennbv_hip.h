@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNBV_ABI_VERSION 1
+#define GNBV_ABI_VERSION 2
 
 int gnbv_abi_version(void);
 /* Name of the device architecture the library was compiled for ("gfx950"). [host] */
@@ -265,6 +265,16 @@ typedef struct GnbvEncoderParams {
     void *sync_ctx;
     double *sync_buf;             /* device [96] */
     const int32_t *autocorr_global; /* device [768]: sum of the autocorrelation rows of ALL replicas' minibatch rows */
+    /* ---- operand ranges of the split-f16 kernels (ABI 2).  At G = 64 the conv stack runs on the f16 matrix pipe with every
+     * fp32 operand written as hi + lo f16 halves under fixed power-of-two scalings: relu(bn1(y1)) <= 253.9, |W2| < 63,
+     * fc_grid inputs <= 1015, |W_fc| < 15.8.  Outside those ranges the split kernels would clamp, so: */
+    int force_fp32;               /* 1: never take the split-f16 kernels (the fp32-MFMA kernels have no range limits); the host
+                                     mirror sets it when a parameter pre-check finds a weight outside its range */
+    int32_t *range_flag;          /* NULL, or a device word the kernels OR bits into when an ACTIVATION bound is reached:
+                                     2 = a BatchNorm-1 channel whose parameter bound |scale| sum|W1| + |scale b1 + shift| exceeds
+                                     253 (conv1's input is tri-class, |x| <= 1); 4 = a feature (fc_grid input) above 1000.
+                                     The caller reads it once per train() / rollout; a non-zero word means the results of the
+                                     calls since the last check may be clamped: raise, or repeat with force_fp32 */
 } GnbvEncoderParams;
 
 typedef struct GnbvEncoderGrads {  /* outputs, same shapes as the parameters */
@@ -315,7 +325,9 @@ int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *rows, int64
 /* B1  Hybrid_Encoder.output_layer_grid = Linear(16*o2^3, 256) + ReLU
  *     (gennbv/network/hybrid_encoder.py:39-42, applied at :87).  out[m][n] = act(bias[n] + sum_k x[m][k] w[n][k]),
  *     x [M][K], w [N][K] (torch.nn.Linear.weight layout), K % 4 == 0, N % 64 == 0, all pointers 16-byte aligned.
- *     Deterministic split-K on fp32 MFMA (fixed summation order); relu != 0 fuses the ReLU.
+ *     Deterministic split-K (fixed summation order).  `relu` is a flag word: bit 0 fuses the ReLU; bit 1 forces the fp32-MFMA
+ *     kernel (no operand-range limits) where the default is the split-f16 kernel, which CLAMPS |x| at 1015 and |w| at 15.8
+ *     (the caller checks its ranges: GnbvEncoderParams.range_flag bit 4 for x, the weights on the host).
  *     workspace >= gnbv_linear_workspace_bytes(M, N, K). */
 size_t gnbv_linear_workspace_bytes(int M, int N, int K);
 int gnbv_linear_forward(const float *x, const float *w, const float *bias, int M, int N, int K, int relu, float *out,

@@ -141,3 +141,39 @@ def test_untrusted_archive_cannot_execute_code(tmp_path):
     data, skipped = save_util.json_to_data(text)
     assert skipped == ["policy_kwargs"] and data["plain"] == {"a": [1, 2.5, "s"]} and data["n_steps"] == 8
     assert not marker.exists()
+
+
+def _proto4_global_call(module: str, name: str, arg: str) -> bytes:
+    """Hand-built protocol-4 pickle: STACK_GLOBAL(module, name)(arg)."""
+    def s(x):
+        b = x.encode()
+        return b"\x8c" + bytes([len(b)]) + b
+    return b"\x80\x04" + s(module) + s(name) + b"\x93" + s(arg) + b"\x85R."
+
+
+@pytest.mark.parametrize("module,name", [("gennbv_amd.sb3.save_util", "os.system"), ("gennbv_amd.sb3.save_util", "_loads"),
+                                         ("gennbv_amd.sb3.save_util", "pickle.loads"), ("gennbv_amd._lib", "ctypes.CDLL"),
+                                         ("gennbv_amd.spaces", "np.load"), ("gennbv_amd.sb3.save_util", "os")])
+def test_untrusted_archive_dotted_and_package_gadgets_are_rejected(tmp_path, module, name):
+    """The allow-list is exact (module, name) pairs: a package-prefix rule let protocol-4 dotted names reach os.system
+    through any module of the package."""
+    import pickle
+    from gennbv_amd.sb3 import save_util
+    marker = tmp_path / "pwned"
+    blob = _proto4_global_call(module, name, f"touch {marker}")
+    with pytest.raises(pickle.UnpicklingError):
+        save_util._loads(blob, False)
+    assert not marker.exists()
+
+
+def test_untrusted_archive_keeps_the_package_data_classes():
+    import pickle
+    import numpy as np
+    from gennbv_amd.sb3 import save_util
+    from gennbv_amd.spaces import Box, MultiDiscrete
+    from gennbv_amd.network.hybrid_encoder import Hybrid_Encoder
+    obj = {"observation_space": Box(-np.inf, np.inf, (5,)), "action_space": MultiDiscrete([3, 4]),
+           "policy_kwargs": {"features_extractor_class": Hybrid_Encoder, "net_arch": [256]}}
+    out = save_util._loads(pickle.dumps(obj, protocol=4), False)
+    assert out["observation_space"].shape == (5,) and out["action_space"].nvec.tolist() == [3, 4]
+    assert out["policy_kwargs"]["features_extractor_class"] is Hybrid_Encoder

@@ -28,18 +28,21 @@ def _kwargs(cfg, cls):
     return dict(net_arch=[], features_extractor_class=cls, features_extractor_kwargs=dict(
         encoder_param={"hidden_shapes": [256, 256], "visual_dim": 256},
         net_param={"transformer_params": [[1, 256], [1, 256]], "append_hidden_shapes": [256, 256]},
-        state_input_shape=(cfg.state_dim,), visual_input_shape=(cfg.stack, HW[0], HW[1])))
+        state_input_shape=(cfg.state_dim,), visual_input_shape=(cfg.stack, cfg.camera_height, cfg.camera_width)))
 
 
-def _ppo_args(target_kl):
-    return dict(learning_rate=LR, n_steps=T, batch_size=BATCH, n_epochs=EPOCHS, gamma=0.99, gae_lambda=0.95, clip_range=0.2,
+def _ppo_args(target_kl, t=T, epochs=EPOCHS):
+    return dict(learning_rate=LR, n_steps=t, batch_size=BATCH, n_epochs=epochs, gamma=0.99, gae_lambda=0.95, clip_range=0.2,
                 clip_range_vf=0.2, ent_coef=0.01, vf_coef=0.8, max_grad_norm=1.0, target_kl=target_kl, seed=1)
 
 
 class _Recorded:
-    """HIP algorithm after one collect_rollouts() + everything the CPU oracle needs, recorded once per module."""
+    """HIP algorithm after one collect_rollouts() + everything the CPU oracle needs, recorded once per module.
+    (tests/test_fullsize_gpu.py builds one at BASELINE configs[1]'s full geometry through the keyword arguments.)"""
 
-    def __init__(self):
+    def __init__(self, n_envs=N_ENVS, t=T, hw=HW, epochs=EPOCHS, max_episode_length=12, frames=6, before_rollout=None):
+        N_ENVS, T, HW, EPOCHS = n_envs, t, hw, epochs  # noqa: N806  (shadow the module defaults)
+        self.n_envs, self.t, self.epochs, self.max_episode_length = n_envs, t, epochs, max_episode_length
         from gennbv_amd.env import synthetic as S
         from gennbv_amd.env.config import TaskConfig
         from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
@@ -50,15 +53,17 @@ class _Recorded:
         np.random.seed(0)
         self.cfg = cfg = TaskConfig(camera_width=HW[1], camera_height=HW[0], grid_size=G)
         scene = S.make_scenes(N_ENVS, G, seed=4, device=DEV)
-        feed = ReplayFeed.synthetic(scene, cfg, 6, seed=4)
-        env = ReplayFeedEnv(cfg, scene, feed, DEV, max_episode_length=12)  # a few resets / time-outs inside 32 steps
+        feed = ReplayFeed.synthetic(scene, cfg, frames, seed=4)
+        env = ReplayFeedEnv(cfg, scene, feed, DEV, max_episode_length=max_episode_length)  # (default: a few resets / time-outs inside 32 steps)
         self.algo = algo = PPO_Grid_Obs(ActorCriticPolicy_Train_Eval, env, device=DEV, compact_obs=True,
-                                        policy_kwargs=_kwargs(cfg, Hybrid_Encoder), **_ppo_args(None))
+                                        policy_kwargs=_kwargs(cfg, Hybrid_Encoder), **_ppo_args(None, T, EPOCHS))
         assert algo.policy.features_extractor.grid_size == G  # inferred from the observation space
         algo._setup_learn(total_timesteps=10 ** 9)
         # (default SB3 initialisation -- the state the bench times.  Do NOT sharpen the policy artificially: with
         # action_net x30 and lr 3e-4 the update is chaotic and torch-CPU fp32 itself drifts 5e-2 from torch-CPU fp64
         # within 8 steps; at these settings fp32-vs-fp64 stays <= 2e-5 while KL reaches 1e-2 and a fifth of the ratios clip.)
+        if before_rollout is not None:
+            before_rollout(algo)
         algo.collect_rollouts(env, None, algo.rollout_buffer, n_rollout_steps=T)
         torch.cuda.synchronize()
         buf = algo.rollout_buffer
@@ -74,15 +79,16 @@ class _Recorded:
         from gennbv_amd.sb3.ppo_grid_obs import PPO_Grid_Obs
         from tests.torch_reference import TorchHybridEncoder
         rec = self
+        N_ENVS, T, EPOCHS = self.n_envs, self.t, self.epochs  # noqa: N806
 
         class _Env:
-            num_envs, device, max_episode_length = N_ENVS, "cpu", 12
+            num_envs, device, max_episode_length = rec.n_envs, "cpu", rec.max_episode_length
             observation_space, action_space = rec.algo.observation_space, rec.algo.action_space
 
             def seed(self, s):
                 pass
         ppo = PPO_Grid_Obs(ActorCriticPolicy_Train_Eval, _Env(), device="cpu", policy_kwargs=_kwargs(self.cfg, TorchHybridEncoder),
-                           **_ppo_args(target_kl))
+                           **_ppo_args(target_kl, T, EPOCHS))
         assert ppo.policy.features_extractor.backend == "torch"
         ppo.policy.load_state_dict(self.state)
         ppo.policy.double()
