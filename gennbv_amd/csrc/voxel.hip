@@ -568,6 +568,113 @@ __device__ __forceinline__ int pixel_to_lin(const PixelFrame &pf, const Intrinsi
     return keep ? ix * pf.gg + iy * pf.g + iz : -1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Voxel-space PREDICTOR of a pixel's voxel (round 3).  For a pinhole camera the canonical chain of pixel_to_lin is, in real
+// arithmetic, affine in the depth:   q_a = (world_a - vmin_a) / vox_a = d * (al_a u + be_a v + ga_a) + ta_a   (u, v = pixel column /
+// row), with constants per env and axis.  Evaluated as two fma per axis it is ~6 instructions instead of ~30 for the three
+// quotients -- but it rounds differently from the canonical chain, so it only DECIDES where it provably cannot disagree:
+//
+//   |q_pred - q_canonical| <= 2^-24 (13 d S_a + 5 |M_a3| + 4 |vmin_a|) / vox_a        (both chains: one rounding per operation,
+//                                                                                      magnitudes bounded term by term; S_a =
+//                                                                                      |M_a0| Cx + |M_a1| Cy + |M_a2|, Cx = |K0| (w-1)
+//                                                                                      + |K2|, Cy = |K4| (h-1) + |K5|)
+//   thr(d) = kap d + lam  with  kap = 1.02 * 2^-24 * 16 max_a S_a / vox_a,  lam = 1.02 * 2^-24 * 8 max_a (|M_a3| + |vmin_a|) / vox_a,
+//            lam >= 8 |G - (vmax_a - vmin_a) / vox_a|   (so that "floor in [0, G)" and the reference's `vmax > p > vmin` agree)
+//
+// A pixel whose three predicted quotients all keep a distance >= thr from every integer gets floor(q_pred) = floor(q_canonical)
+// on every axis, and its in / out-of-grid decision is the reference's: it is decided here.  Everything else -- a quotient near a
+// voxel boundary (~0.1 % of the foreground pixels at 64^3), a depth the clamp / nan_to_num of post_process_camera_tensor changes, a
+// non-finite anything (NaN fails the `>=`) -- is QUEUED and evaluated with the canonical chain (pixel_to_lin) after the stream.
+// The result is bit-identical to the canonical chain by construction; tests/test_voxel_gpu.py compares both paths with the oracle.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct VoxPredict {
+    float al[3], be[3], ga[3], ta[3];
+    float kap, lam;
+};
+
+__device__ __forceinline__ float uniform_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+// (every lane computes the same ~100 fp64 operations once per workgroup; the results live in scalar registers)
+__device__ __forceinline__ VoxPredict make_predictor(const float *__restrict__ M16, const Intrinsics &K, const float *__restrict__ range6,
+                                                     const float *__restrict__ vox3, int g, int h, int w)
+{
+    VoxPredict vp;
+    const VoxelFrame f = load_frame(range6, vox3);
+    const double k0 = K.k[0], k2 = K.k[2], k4 = K.k[4], k5 = K.k[5];
+    const double cx = fabs(k0) * (double)(w - 1) + fabs(k2), cy = fabs(k4) * (double)(h - 1) + fabs(k5);
+    double kap = 0.0, lam = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double m0 = M16[a * 4 + 0], m1 = M16[a * 4 + 1], m2 = M16[a * 4 + 2], m3 = M16[a * 4 + 3];
+        const double inv = 1.0 / (double)f.vox[a], vmin = f.vmin[a];
+        vp.al[a] = uniform_f32((float)(m0 * k0 * inv));
+        vp.be[a] = uniform_f32((float)(m1 * k4 * inv));
+        vp.ga[a] = uniform_f32((float)((m0 * k2 + m1 * k5 + m2) * inv));
+        vp.ta[a] = uniform_f32((float)((m3 - vmin) * inv));
+        const double sa = fabs(m0) * cx + fabs(m1) * cy + fabs(m2);
+        kap = fmax(kap, 16.0 * sa * fabs(inv));
+        lam = fmax(lam, 8.0 * (fabs(m3) + fabs(vmin)) * fabs(inv));
+        const double qhi = ((double)f.vmax[a] - vmin) * inv;
+        lam = fmax(lam, 8.0 * fabs((double)g - qhi) * 16777216.0 / 1.02);  // (scaled back below)
+        if (!(inv > 0.0)) lam = __builtin_inf();  // a non-positive / NaN voxel size: every pixel takes the canonical chain
+    }
+    vp.kap = uniform_f32((float)(kap * (1.02 / 16777216.0)));
+    vp.lam = uniform_f32((float)(lam * (1.02 / 16777216.0)));
+    return vp;
+}
+
+// One pixel through the predictor: lin >= 0 decided "in the grid, this voxel"; -1 decided "not a hit"; `queue` set: undecided.
+__device__ __forceinline__ int pixel_predict(const VoxPredict &vp, const float (&row)[3], float u, float draw, float sraw, float sense_dist,
+                                             unsigned ug, bool &queue)
+{
+    const bool fg = sraw > 50.0f;
+    const float d = fabsf(draw);
+    const bool plain = draw >= sense_dist;  // nan_to_num and the clamp leave it alone: d = |raw| (NaN / -inf / below the range fail)
+    float m[3];
+    int ii[3];
+    bool in = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float r = __fmaf_rn(vp.al[a], u, row[a]);
+        const float q = __fmaf_rn(d, r, vp.ta[a]);
+        const float fl = floorf(q);
+        const float fr = __fsub_rn(q, fl);
+        m[a] = __builtin_fminf(fr, __fsub_rn(1.0f, fr));
+        ii[a] = (int)fl;
+        in = in && ((unsigned)ii[a] < ug);
+    }
+    const float thr = __fmaf_rn(vp.kap, d, vp.lam);
+    const bool sure = __builtin_fminf(__builtin_fminf(m[0], m[1]), m[2]) >= thr;  // (false for NaN)
+    queue = fg && !(plain && sure);
+    const int lin = (int)(__umul24(__umul24((unsigned)ii[0], ug) + (unsigned)ii[1], ug) + (unsigned)ii[2]);
+    return (fg && plain && sure && in) ? lin : -1;
+}
+
+__device__ __forceinline__ void load_pixel_frame(PixelFrame &pf, const float *__restrict__ c2w, const float *__restrict__ range_gt,
+                                                 const float *__restrict__ voxel_size, int e, int g, float sense_dist)
+{
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pf.M[i] = c2w[(size_t)e * 16 + i];
+    const VoxelFrame f = load_frame(range_gt + e * 6, voxel_size + e * 3);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        pf.hf.vmin[a] = f.vmin[a]; pf.hf.vmax[a] = f.vmax[a]; pf.hf.vox[a] = f.vox[a];
+        pf.hf.inv_vox[a] = __frcp_rn(f.vox[a]);
+        pf.lo[a] = nextafterf(f.vmin[a], INFINITY);
+        pf.hi[a] = nextafterf(f.vmax[a], -INFINITY);
+    }
+    pf.hf.gmax = (float)(g - 1);
+    pf.g = g; pf.gg = g * g; pf.sense_dist = sense_dist;
+}
+
+// undecided pixels of the predictor per workgroup (LDS queue); GNBV_NO_PREDICTOR builds (A/B, tests) run the canonical chain only
+constexpr int kQueueCapPx = 2048;
+#ifdef GNBV_NO_PREDICTOR
+constexpr bool kUsePredictor = false;
+#else
+constexpr bool kUsePredictor = true;
+#endif
+
 // (amdgpu_num_sgpr: see launch_masks -- SGPR-limited occupancy)
 template <bool KFAST>
 __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80))) void k_hit_list(
@@ -580,6 +687,8 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80)))
     uint32_t *s_hit = smem;                 // words
     int *s_wave = (int *)(smem + words);    // counters (64 ints reserved)
     uint16_t *s_widx = (uint16_t *)(s_wave + 64);  // words: indices of the non-zero mask words
+    int *s_qcnt = s_wave + 8;                      // undecided pixels of the predictor (count, then the queue behind the word list)
+    int *s_queue = (int *)(s_widx + ((words + 1) & ~1));
     // XCD-aware block -> (env, chunk): all workgroups of env e run on XCD e % 8
     const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
     const int e = (slot / chunks) * 8 + xcd;
@@ -590,23 +699,9 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80)))
     const uint64_t pt0 = wall_clock64();
 #endif
     for (int i = tid; i < words; i += kFusedThreads) smem[i] = 0u;
+    if (tid == 0) *s_qcnt = 0;
     if (coverage_zero != nullptr && c == 0 && tid == 0) coverage_zero[e] = 0;  // (accumulated by the grid-update launch)
 
-    PixelFrame pf;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) pf.M[i] = c2w[(size_t)e * 16 + i];
-    {
-        const VoxelFrame f = load_frame(range_gt + e * 6, voxel_size + e * 3);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            pf.hf.vmin[a] = f.vmin[a]; pf.hf.vmax[a] = f.vmax[a]; pf.hf.vox[a] = f.vox[a];
-            pf.hf.inv_vox[a] = __frcp_rn(f.vox[a]);
-            pf.lo[a] = nextafterf(f.vmin[a], INFINITY);
-            pf.hi[a] = nextafterf(f.vmax[a], -INFINITY);
-        }
-    }
-    pf.hf.gmax = (float)(g - 1);
-    pf.g = g; pf.gg = g * g; pf.sense_dist = sense_dist;
     const int hw = h * w;
     int ppc = (hw + chunks - 1) / chunks;
     ppc = (ppc + 3) & ~3;
@@ -617,11 +712,14 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80)))
     __syncthreads();
 
     // ---- phase A: hit mask ------------------------------------------------------------------------------
-    if ((w & 3) == 0 && hw < (1 << 23)) {
-        // kAhead tiles of 4096 pixels in flight per workgroup (2 x 16-byte streaming requests per lane and tile); addresses
-        // are clamped, so every request is unconditional and the waits land behind a tile's arithmetic.  The stream alone runs
-        // at 6.2 TB/s (25 us), the arithmetic alone takes 44 us with the 16 waves a CU holds: this phase is instruction-issue
-        // bound (profiles/r02_notes.md).
+    bool need_full_exact = false;  // (uniform) the canonical chain over every pixel of the chunk
+    if (KFAST && (w & 3) == 0 && hw < (1 << 23) && kUsePredictor) {
+        // kAhead tiles of 4096 pixels in flight per workgroup (2 x 16-byte streaming requests per lane and tile); addresses are
+        // clamped, so every request is unconditional and the waits land behind a tile's arithmetic.  Round 2 ran the canonical chain
+        // on every pixel: 36-44 us of instruction issue for a 25 us stream.  Round 3: the voxel-space predictor decides ~99.9 % of
+        // the foreground pixels in ~30 instructions, branch-free; the rest goes to an LDS queue (see VoxPredict).
+        const VoxPredict vp = make_predictor(c2w + (size_t)e * 16, K, range_gt + e * 6, voxel_size + e * 3, g, h, w);
+        const unsigned ug = (unsigned)g;
         constexpr int kTile = kFusedThreads * 4, kAhead = 3;
         float4 dq[kAhead], sq[kAhead];
         const int plast = px1 - 4;
@@ -633,6 +731,9 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80)))
             dq[q] = ld4_stream(dptr + pq);
             sq[q] = ld4_stream(sptr + pq);
         }
+        // (column, row) of the lane's first pixel, advanced by one tile per step without a division
+        const int tdy = kTile / w, tdx = kTile - tdy * w;
+        int py = floor_div_small(tile_px(0), w, inv_w), pxc = tile_px(0) - py * w;
         for (int t0 = 0; t0 < ntiles; t0 += kAhead) {
 #pragma unroll
             for (int q = 0; q < kAhead; ++q) {
@@ -644,12 +745,13 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80)))
                 sq[q] = ld4_stream(sptr + pn);
                 // (a tile of pure background -- all 256 pixels of the wave -- skips the arithmetic)
                 if (p < px1 && __any((s4.x > 50.0f) | (s4.y > 50.0f) | (s4.z > 50.0f) | (s4.w > 50.0f))) {
-                    const int y = floor_div_small(p, w, inv_w);  // 4 consecutive pixels share the row (w % 4 == 0)
-                    const float fy = (float)y, fx = (float)(p - y * w);
-                    const int l0 = pixel_to_lin<KFAST>(pf, K, fx, fy, d4.x, s4.x);
-                    const int l1 = pixel_to_lin<KFAST>(pf, K, fx + 1.0f, fy, d4.y, s4.y);
-                    const int l2 = pixel_to_lin<KFAST>(pf, K, fx + 2.0f, fy, d4.z, s4.z);
-                    const int l3 = pixel_to_lin<KFAST>(pf, K, fx + 3.0f, fy, d4.w, s4.w);
+                    const float fy = (float)py, fx = (float)pxc;  // 4 consecutive pixels share the row (w % 4 == 0)
+                    const float row[3] = {__fmaf_rn(vp.be[0], fy, vp.ga[0]), __fmaf_rn(vp.be[1], fy, vp.ga[1]), __fmaf_rn(vp.be[2], fy, vp.ga[2])};
+                    bool u0, u1, u2, u3;
+                    const int l0 = pixel_predict(vp, row, fx, d4.x, s4.x, sense_dist, ug, u0);
+                    const int l1 = pixel_predict(vp, row, fx + 1.0f, d4.y, s4.y, sense_dist, ug, u1);
+                    const int l2 = pixel_predict(vp, row, fx + 2.0f, d4.z, s4.z, sense_dist, ug, u2);
+                    const int l3 = pixel_predict(vp, row, fx + 3.0f, d4.w, s4.w, sense_dist, ug, u3);
                     // neighbouring pixels mostly fall into the same voxel: a pixel whose left neighbour (previous pixel of the
                     // lane, or the last pixel of the previous lane in the 16-lane DPP row) has the same voxel leaves the bit to it
                     const int pl = __builtin_amdgcn_update_dpp(-2, l3, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
@@ -657,10 +759,41 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80)))
                     if (l1 >= 0 && l1 != l0) atomicOr(&s_hit[l1 >> 5], 1u << (l1 & 31));
                     if (l2 >= 0 && l2 != l1) atomicOr(&s_hit[l2 >> 5], 1u << (l2 & 31));
                     if (l3 >= 0 && l3 != l2) atomicOr(&s_hit[l3 >> 5], 1u << (l3 & 31));
+                    if (__any(u0 | u1 | u2 | u3)) {  // (~20 % of the wave-tiles hold an undecided pixel, ~0.1 % of the pixels are)
+                        const int cnt = (int)u0 + (int)u1 + (int)u2 + (int)u3;
+                        if (cnt) {
+                            int slot = atomicAdd(s_qcnt, cnt);
+                            if (u0) { if (slot < kQueueCapPx) s_queue[slot] = p; ++slot; }
+                            if (u1) { if (slot < kQueueCapPx) s_queue[slot] = p + 1; ++slot; }
+                            if (u2) { if (slot < kQueueCapPx) s_queue[slot] = p + 2; ++slot; }
+                            if (u3) { if (slot < kQueueCapPx) s_queue[slot] = p + 3; }
+                        }
+                    }
                 }
+                pxc += tdx; py += tdy;
+                if (pxc >= w) { pxc -= w; ++py; }
+            }
+        }
+        __syncthreads();
+        // the undecided pixels through the canonical chain (all lanes busy; the pixels come back from L2 / HBM: ~50 per workgroup)
+        const int nq = *s_qcnt;
+        need_full_exact = nq > kQueueCapPx;  // a queue that overflowed (a surface lying ON a voxel boundary plane, say): redo the chunk
+        if (nq > 0 && !need_full_exact) {
+            PixelFrame pf;
+            load_pixel_frame(pf, c2w, range_gt, voxel_size, e, g, sense_dist);
+            for (int j = tid; j < nq; j += kFusedThreads) {
+                const int p = s_queue[j];
+                const int y = p / w;
+                const int l0 = pixel_to_lin<KFAST>(pf, K, (float)(p - y * w), (float)y, dptr[p], sptr[p]);
+                if (l0 >= 0) atomicOr(&s_hit[l0 >> 5], 1u << (l0 & 31));
             }
         }
     } else {
+        need_full_exact = true;
+    }
+    if (need_full_exact) {
+        PixelFrame pf;
+        load_pixel_frame(pf, c2w, range_gt, voxel_size, e, g, sense_dist);
         for (int p = px0 + tid; p < px1; p += kFusedThreads) {
             const int y = p / w;
             const int l0 = pixel_to_lin<KFAST>(pf, K, (float)(p - y * w), (float)y, dptr[p], sptr[p]);
@@ -1356,7 +1489,7 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
     const bool kfast = K.k[1] == 0.0f && K.k[3] == 0.0f && K.k[6] == 0.0f && K.k[7] == 0.0f && K.k[8] == 1.0f;
     const int env_groups = (n + 7) / 8;
     // hit mask + ray list, then the load-balanced ray cast over the lists (needs the h/w-sized workspace)
-    const size_t list_lds = mask_bytes + 64 * sizeof(uint32_t) + (size_t)words * sizeof(uint16_t);
+    const size_t list_lds = mask_bytes + 64 * sizeof(uint32_t) + (size_t)((words + 1) & ~1) * sizeof(uint16_t) + kQueueCapPx * sizeof(int32_t);
     if (ws.ray_list != nullptr && list_lds <= kLdsMax && words <= 65536) {
         // workgroups per env: two per CU in total (1024 threads each = 32 waves per CU).  (The kernel is capped at 80 SGPRs:
         // with the 96 it wanted, the SIMD's 800-entry SGPR file held 7 waves and a second 16-wave workgroup never became

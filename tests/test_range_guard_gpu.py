@@ -51,6 +51,12 @@ def _assert_close(got, ref, what, rel=2e-5):
 
 
 def _compare(hip, ref, obs, training=True):
+    if not training:  # inference (rollout): forward only -- the kernels' backward is the train-mode BatchNorm backward
+        for pol in (hip, ref):
+            pol.set_training_mode(False)
+        with torch.no_grad():
+            _assert_close(hip.features_extractor(_int8_batch(obs)).double().cpu(), ref.features_extractor(obs.cpu().double()), "features (eval)")
+        return
     f_r, g_r = _forward_backward(ref, obs.cpu().double(), training)
     f_h, g_h = _forward_backward(hip, _int8_batch(obs), training)
     _assert_close(f_h, f_r, "features")

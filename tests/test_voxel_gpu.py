@@ -335,3 +335,39 @@ def test_chamfer_distance_vs_float64_brute_force(n, m):
     acc = float(M.reconstruction_accuracy_cm(x.to("cuda:0"), y.to("cuda:0")))
     xr = np.unique(np.round(x.numpy().astype(np.float32) * np.float32(100.0)) / np.float32(100.0), axis=0)
     assert abs(acc - 100.0 * oracle.chamfer_distance_ref(xr, y.numpy())) <= 1e-4 * max(acc, 1e-9) + 1e-9
+
+
+def test_predictor_queue_overflow_falls_back_to_the_canonical_chain():
+    """k_hit_list decides a pixel with the voxel-space predictor only when its quotients keep clear of every voxel boundary;
+    the rest is queued for the canonical chain, and a queue that overflows (2048 per workgroup) re-runs the whole chunk.
+    A camera looking straight down at a floor that lies EXACTLY on a voxel boundary plane puts every pixel of env 0 within
+    round-off of an integer quotient; env 1 sees the same floor half a voxel higher (all pixels decided by the predictor) with a
+    band of special depths (queued, no overflow).  Both must equal the oracle bit for bit."""
+    from gennbv_amd.env.state_encoding import OccupancyGridUpdater
+    n, h, w, g = 2, 240, 320, 16
+    cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
+    scene = S.make_scenes(n, g, seed=11)
+    kinv = S.inverse_intrinsics(h, w)
+    vox_z = float(scene.voxel_size[0, 2])
+    vmin_z = float(np.float32(scene.range_gt[0, 5]) - np.float32(0.5) * np.float32(vox_z))
+    cam_z = 9.0
+    c2w = torch.zeros(n, 4, 4)
+    c2w[:, 0, 0], c2w[:, 1, 1], c2w[:, 2, 2], c2w[:, 3, 3] = 1.0, -1.0, -1.0, 1.0
+    c2w[:, 2, 3] = cam_z
+    floor_z = [vmin_z + 3.0 * vox_z, vmin_z + 3.5 * vox_z]
+    depth = torch.empty(n, h, w)
+    for e in range(n):
+        depth[e] = -(cam_z - floor_z[e])  # Isaac convention: negative metres
+    depth[1, 100:104] = torch.tensor([float("nan"), -float("inf"), -80.0, float("inf")]).view(4, 1)
+    seg = torch.full((n, h, w), 255.0)
+    poses = torch.tensor([[0.0, 0.0, cam_z, 0, 0, 0]] * n)
+    upd = OccupancyGridUpdater(n, g, h, w, kinv, scene.range_gt, scene.voxel_size, scene.grid_gt, DEV)
+    tri = upd.update(depth.to(DEV), seg.to(DEV), c2w.to(DEV), poses.to(DEV).contiguous())
+    prob = np.zeros((n, g, g, g), np.float32); scan = np.zeros_like(prob)
+    dp, sp = orc.post_process_depth(depth.numpy(), seg.numpy())
+    tri_o, cov_o = orc.update_occ_grid(dp, sp, c2w.numpy(), kinv.numpy(), poses[:, :3].numpy(), scene.range_gt.numpy(),
+                                       scene.voxel_size.numpy(), scene.grid_gt.numpy(), prob, scan)
+    assert (prob == 1.0).sum() > 50  # the floor is inside the grid
+    assert tri.cpu().numpy().tobytes() == tri_o.tobytes()
+    assert upd.prob_grid.cpu().numpy().tobytes() == prob.tobytes()
+    assert np.array_equal(upd.coverage_count.cpu().numpy(), cov_o)
