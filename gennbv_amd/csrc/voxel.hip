@@ -503,6 +503,19 @@ __device__ __forceinline__ float4 ld4_stream(const float *p)
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// The same request as an opaque instruction + an explicit wait: the compiler's wait-count insertion gives up on requests that are
+// re-issued behind a branch region inside a loop (it waits for EVERY outstanding request, `s_waitcnt vmcnt(0)`, in front of each
+// tile).  The wait names the registers it releases ("+v"), so no use can be scheduled above it.
+__device__ __forceinline__ void ld4_stream_async(v4f_t &dst, const float *p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm_keep(v4f_t &a, v4f_t &b)
+{
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+
 struct PixelFrame {
     float M[12];
     HitFrame hf;
@@ -589,7 +602,7 @@ __device__ __forceinline__ int pixel_to_lin(const PixelFrame &pf, const Intrinsi
 // ---------------------------------------------------------------------------------------------------------------------------
 struct VoxPredict {
     float al[3], be[3], ga[3], ta[3];
-    float kap, lam;
+    float kap, lim0;  // a pixel is decided when every quotient keeps |fract - 0.5| <= lim0 - kap d  (lim0 = 0.5 - lam)
 };
 
 __device__ __forceinline__ float uniform_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
@@ -619,7 +632,7 @@ __device__ __forceinline__ VoxPredict make_predictor(const float *__restrict__ M
         if (!(inv > 0.0)) lam = __builtin_inf();  // a non-positive / NaN voxel size: every pixel takes the canonical chain
     }
     vp.kap = uniform_f32((float)(kap * (1.02 / 16777216.0)));
-    vp.lam = uniform_f32((float)(lam * (1.02 / 16777216.0)));
+    vp.lim0 = uniform_f32((float)(0.5 - fmax(lam * (1.02 / 16777216.0), 1.0e-6)));
     return vp;
 }
 
@@ -630,21 +643,22 @@ __device__ __forceinline__ int pixel_predict(const VoxPredict &vp, const float (
     const bool fg = sraw > 50.0f;
     const float d = fabsf(draw);
     const bool plain = draw >= sense_dist;  // nan_to_num and the clamp leave it alone: d = |raw| (NaN / -inf / below the range fail)
-    float m[3];
+    // per axis: two fma, v_fract (q - floor q, exact), its distance from 0.5, v_cvt_flr_i32_f32 (floor + convert), one unsigned compare
+    float dev[3];
     int ii[3];
     bool in = true;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float r = __fmaf_rn(vp.al[a], u, row[a]);
         const float q = __fmaf_rn(d, r, vp.ta[a]);
-        const float fl = floorf(q);
-        const float fr = __fsub_rn(q, fl);
-        m[a] = __builtin_fminf(fr, __fsub_rn(1.0f, fr));
-        ii[a] = (int)fl;
+        dev[a] = __fsub_rn(__builtin_amdgcn_fractf(q), 0.5f);
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ii[a]) : "v"(q));
         in = in && ((unsigned)ii[a] < ug);
     }
-    const float thr = __fmaf_rn(vp.kap, d, vp.lam);
-    const bool sure = __builtin_fminf(__builtin_fminf(m[0], m[1]), m[2]) >= thr;  // (false for NaN)
+    // distance to the nearest integer = 0.5 - |fract - 0.5| >= thr   <=>   max |dev| <= 0.5 - thr   (false for NaN; the two roundings
+    // of this test are 2^-25 each against a slack of 0.2 thr: make_predictor keeps thr >= 1e-6)
+    const float lim = __fmaf_rn(-vp.kap, d, vp.lim0);
+    const bool sure = __builtin_fmaxf(__builtin_fmaxf(fabsf(dev[0]), fabsf(dev[1])), fabsf(dev[2])) <= lim;
     queue = fg && !(plain && sure);
     const int lin = (int)(__umul24(__umul24((unsigned)ii[0], ug) + (unsigned)ii[1], ug) + (unsigned)ii[2]);
     return (fg && plain && sure && in) ? lin : -1;
@@ -677,7 +691,7 @@ constexpr bool kUsePredictor = true;
 
 // (amdgpu_num_sgpr: see launch_masks -- SGPR-limited occupancy)
 template <bool KFAST>
-__global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80))) void k_hit_list(
+__global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void k_hit_list(
     const float *__restrict__ depth_raw, const float *__restrict__ seg_raw, const float *__restrict__ c2w, Intrinsics K,
     const float *__restrict__ range_gt, const float *__restrict__ voxel_size, int n, int h, int w, int g, float sense_dist,
     int chunks, int words, uint32_t *__restrict__ hit_mask, int32_t *__restrict__ ray_count, int32_t *__restrict__ ray_list,
@@ -721,44 +735,53 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80)))
         const VoxPredict vp = make_predictor(c2w + (size_t)e * 16, K, range_gt + e * 6, voxel_size + e * 3, g, h, w);
         const unsigned ug = (unsigned)g;
         constexpr int kTile = kFusedThreads * 4, kAhead = 3;
-        float4 dq[kAhead], sq[kAhead];
+        v4f_t dq[kAhead], sq[kAhead];
+        // (Dealing an env's tiles to its workgroups round-robin instead of as contiguous chunks -- the top of an image is mostly
+        // background -- was measured: both workgroups then list most of the env's voxels, k_ray_list 28 -> 33 us, phase A unchanged.)
         const int plast = px1 - 4;
         const int ntiles = (px1 - px0 + kTile - 1) / kTile;
         auto tile_px = [&](int t) { return px0 + t * kTile + tid * 4; };
 #pragma unroll
         for (int q = 0; q < kAhead; ++q) {
-            const int pq = min(tile_px(min(q, ntiles - 1)), plast);
-            dq[q] = ld4_stream(dptr + pq);
-            sq[q] = ld4_stream(sptr + pq);
+            const int pq = max(min(tile_px(max(min(q, ntiles - 1), 0)), plast), 0);
+            ld4_stream_async(dq[q], dptr + pq);
+            ld4_stream_async(sq[q], sptr + pq);
         }
         // (column, row) of the lane's first pixel, advanced by one tile per step without a division
         const int tdy = kTile / w, tdx = kTile - tdy * w;
-        int py = floor_div_small(tile_px(0), w, inv_w), pxc = tile_px(0) - py * w;
+        int py = floor_div_small(max(min(tile_px(0), plast), 0), w, inv_w), pxc = max(min(tile_px(0), plast), 0) - py * w;
         for (int t0 = 0; t0 < ntiles; t0 += kAhead) {
 #pragma unroll
             for (int q = 0; q < kAhead; ++q) {
                 const int t = t0 + q;
                 const int p = t < ntiles ? tile_px(t) : px1;
-                const float4 d4 = dq[q], s4 = sq[q];
-                const int pn = min(tile_px(min(t + kAhead, ntiles - 1)), plast);
-                dq[q] = ld4_stream(dptr + pn);
-                sq[q] = ld4_stream(sptr + pn);
+                wait_vm_keep<2 * (kAhead - 1)>(dq[q], sq[q]);  // requests complete in order: the two other slots' may stay in flight
+                const v4f_t d4 = dq[q], s4 = sq[q];
                 // (a tile of pure background -- all 256 pixels of the wave -- skips the arithmetic)
                 if (p < px1 && __any((s4.x > 50.0f) | (s4.y > 50.0f) | (s4.z > 50.0f) | (s4.w > 50.0f))) {
                     const float fy = (float)py, fx = (float)pxc;  // 4 consecutive pixels share the row (w % 4 == 0)
                     const float row[3] = {__fmaf_rn(vp.be[0], fy, vp.ga[0]), __fmaf_rn(vp.be[1], fy, vp.ga[1]), __fmaf_rn(vp.be[2], fy, vp.ga[2])};
                     bool u0, u1, u2, u3;
+#ifdef GNBV_ABL_NOARITH
+                    u0 = u1 = u2 = u3 = false;
+                    const int l0 = d4.x == 12345.0f ? 1 : -1, l1 = d4.y == 12345.0f ? 1 : -1, l2 = d4.z == 12345.0f ? 1 : -1, l3 = d4.w == 12345.0f ? 1 : -1;
+#else
                     const int l0 = pixel_predict(vp, row, fx, d4.x, s4.x, sense_dist, ug, u0);
                     const int l1 = pixel_predict(vp, row, fx + 1.0f, d4.y, s4.y, sense_dist, ug, u1);
                     const int l2 = pixel_predict(vp, row, fx + 2.0f, d4.z, s4.z, sense_dist, ug, u2);
                     const int l3 = pixel_predict(vp, row, fx + 3.0f, d4.w, s4.w, sense_dist, ug, u3);
+#endif
                     // neighbouring pixels mostly fall into the same voxel: a pixel whose left neighbour (previous pixel of the
                     // lane, or the last pixel of the previous lane in the 16-lane DPP row) has the same voxel leaves the bit to it
                     const int pl = __builtin_amdgcn_update_dpp(-2, l3, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+#ifdef GNBV_ABL_NOATOM
+                    if (((l0 ^ l1 ^ l2 ^ l3 ^ pl) & 0x7fffffff) == 0x12345678) atomicOr(&s_hit[0], 1u);
+#else
                     if (l0 >= 0 && l0 != pl) atomicOr(&s_hit[l0 >> 5], 1u << (l0 & 31));
                     if (l1 >= 0 && l1 != l0) atomicOr(&s_hit[l1 >> 5], 1u << (l1 & 31));
                     if (l2 >= 0 && l2 != l1) atomicOr(&s_hit[l2 >> 5], 1u << (l2 & 31));
                     if (l3 >= 0 && l3 != l2) atomicOr(&s_hit[l3 >> 5], 1u << (l3 & 31));
+#endif
                     if (__any(u0 | u1 | u2 | u3)) {  // (~20 % of the wave-tiles hold an undecided pixel, ~0.1 % of the pixels are)
                         const int cnt = (int)u0 + (int)u1 + (int)u2 + (int)u3;
                         if (cnt) {
@@ -772,13 +795,29 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80)))
                 }
                 pxc += tdx; py += tdy;
                 if (pxc >= w) { pxc -= w; ++py; }
+                // refill THIS slot behind its last use (the slot's registers are reused in place: issuing the request in front of
+                // the arithmetic made the compiler keep a fourth register set and rotate all of them -- behind a wait for every
+                // outstanding request -- at the end of each round); kAhead - 1 tiles per lane stay in flight during the arithmetic,
+                // 128 KiB per CU against the ~25 KiB its 10.8 B/clk x latency needs
+                const int pn = max(min(tile_px(max(min(t + kAhead, ntiles - 1), 0)), plast), 0);
+                ld4_stream_async(dq[q], dptr + pn);
+                ld4_stream_async(sq[q], sptr + pn);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the clamped duplicate requests of the last round)
         __syncthreads();
         // the undecided pixels through the canonical chain (all lanes busy; the pixels come back from L2 / HBM: ~50 per workgroup)
         const int nq = *s_qcnt;
-        need_full_exact = nq > kQueueCapPx;  // a queue that overflowed (a surface lying ON a voxel boundary plane, say): redo the chunk
-        if (nq > 0 && !need_full_exact) {
+        // a queue that overflowed (a surface lying ON a voxel boundary plane, say): the canonical chain over the whole chunk
+        if (nq > kQueueCapPx) {
+            PixelFrame pf;
+            load_pixel_frame(pf, c2w, range_gt, voxel_size, e, g, sense_dist);
+            for (int p = px0 + tid; p < px1; p += kFusedThreads) {
+                const int y = p / w;
+                const int l0 = pixel_to_lin<KFAST>(pf, K, (float)(p - y * w), (float)y, dptr[p], sptr[p]);
+                if (l0 >= 0) atomicOr(&s_hit[l0 >> 5], 1u << (l0 & 31));
+            }
+        } else if (nq > 0) {
             PixelFrame pf;
             load_pixel_frame(pf, c2w, range_gt, voxel_size, e, g, sense_dist);
             for (int j = tid; j < nq; j += kFusedThreads) {
