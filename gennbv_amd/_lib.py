@@ -63,6 +63,8 @@ SIGNATURES = {
     "gnbv_linear_bwd_prep": (_i, [_p, _p, _i, _i, _p, _p, _sz, _p]),
     "gnbv_linear_bwd_dx": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "gnbv_linear_bwd_dw": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "gnbv_linear_bwd_dw_sq_parts": (_i, [_i]),
+    "gnbv_linear_bwd_dw_sq": (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),
     "gnbv_pose_encode": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
     "gnbv_policy_head_forward": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
     "gnbv_policy_head_backward": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -73,6 +75,7 @@ SIGNATURES = {
     "gnbv_adam_workspace_bytes": (_sz, []),
     "gnbv_clip_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _p, _f, _p, _f, _p, _p, _sz, _p]),
     "gnbv_clip_adam_step_rotate": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _p, _f, _p, _f, _p, _p, _sz, _p, _i, _i, _p, _p, _p]),
+    "gnbv_clip_adam_step_ex": (_i, [_p, _p]),
     "gnbv_chamfer_workspace_bytes": (_sz, [_i, _i]),
     "gnbv_chamfer_distance": (_i, [_p, _i, _p, _i, _p, _p, _sz, _p]),
     "gnbv_gae_sb3": (_i, [_p, _p, _p, _p, _p, _i, _i, _d, _d, _p, _p, _p]),
@@ -105,6 +108,16 @@ class GnbvEncoderParams(C.Structure):
                 ("autocorr", _p), ("autocorr_row_stride", _i64),
                 ("world", _i), ("sync_sum", _p), ("sync_ctx", _p), ("sync_buf", _p), ("autocorr_global", _p),
                 ("force_fp32", _i), ("range_flag", _p)]
+
+
+class GnbvAdamStep(C.Structure):
+    """include/gennbv_hip.h: GnbvAdamStep"""
+    _fields_ = [("params", _p), ("grads", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("n", _i64),
+                ("max_grad_norm", _f), ("lr", _f), ("beta1", _f), ("beta2", _f), ("eps", _f),
+                ("step", _p), ("stop_flag", _p), ("grad_scale", _f), ("kl_slot", _p), ("target_kl", _f),
+                ("norm_out", _p), ("workspace", _p), ("workspace_bytes", _sz),
+                ("table", _p), ("table_rows", _i), ("row_len", _i), ("out", _p), ("counter", _p),
+                ("sq_lo", _i64), ("sq_hi", _i64), ("sq_partial", _p), ("sq_parts", _i)]
 
 
 class GnbvEncoderGrads(C.Structure):

@@ -1628,13 +1628,29 @@ __device__ __forceinline__ void gather_autocorr(const int *__restrict__ ac, int6
     if (nrows > 0) {
         const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
         int4 t[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-        for (int b = wv; b < nrows; b += 16) {
-            const int4 *row = reinterpret_cast<const int4 *>(ac + (rows ? rows[b] : (int64_t)b) * ac_row_stride);
+        // a wave's rows four at a time: the four row numbers, then the twelve 16-byte requests, are in flight together (one row per
+        // iteration was a chain of nrows / 16 x 2 dependent round trips: 13 us of k_bn1_analytic on the update's critical path at
+        // 128 rows; integer sums: the order of the additions does not matter)
+        for (int b0 = wv; b0 < nrows; b0 += 64) {
+            int64_t rr[4];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int4 v = row[lane + 64 * k];
-                t[k].x += v.x; t[k].y += v.y; t[k].z += v.z; t[k].w += v.w;
+            for (int u = 0; u < 4; ++u) {
+                const int b = min(b0 + 16 * u, nrows - 1);  // (clamped duplicate, masked below)
+                rr[u] = rows ? rows[b] : (int64_t)b;
             }
+            int4 v[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) v[u][k] = reinterpret_cast<const int4 *>(ac + rr[u] * ac_row_stride)[lane + 64 * k];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (b0 + 16 * u < nrows) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        t[k].x += v[u][k].x; t[k].y += v[u][k].y; t[k].z += v[u][k].z; t[k].w += v[u][k].w;
+                    }
+                }
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -1725,16 +1741,33 @@ __global__ __launch_bounds__(1024) void k_c1w_fused_finish(const double *__restr
     gather_autocorr(ac, ac_row_stride, rows, nrows, Ri);
     for (int i = threadIdx.x; i < kAcRow; i += 1024) R[i] = (double)Ri[i];
     __syncthreads();
+    // the <= 64 slices of the kE1F sums, added in slice order by one thread per sum with eight requests in flight (every thread
+    // walking its three sums slice by slice was a chain of `slices` dependent round trips: 17 us on the update's critical path)
+    __shared__ double ssum[kE1F];
+    __shared__ float w1s[kC * kTaps];
+    __shared__ double t2g[kTaps];
+    if (threadIdx.x < kC * kTaps) w1s[threadIdx.x] = W1[threadIdx.x];
+    if (threadIdx.x >= 992 && threadIdx.x < 992 + kTaps) {
+        const int u = threadIdx.x - 992;
+        t2g[u] = ac_global ? (double)ac_global[ac_index(u, kTaps)] : R[ac_index(u, kTaps)];
+    }
+    if (threadIdx.x < kE1F) {
+        double a = 0.0;
+        for (int sl0 = 0; sl0 < slices; sl0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = tmp[(size_t)min(sl0 + u, slices - 1) * kE1F + threadIdx.x];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (sl0 + u < slices) a += v[u];
+        }
+        ssum[threadIdx.x] = a;
+    }
+    __syncthreads();
     if (threadIdx.x >= 512) return;
     const int i = threadIdx.x;
     const int tap = i >> 4, co = i & 15;
-    double T1 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int sl = 0; sl < slices; ++sl) {
-        const double *t = tmp + (size_t)sl * kE1F;
-        T1 += t[i];
-        s1 += t[512 + co];
-        s2 += t[512 + kC + co];
-    }
+    double T1 = ssum[i], s1 = ssum[512 + co], s2 = ssum[512 + kC + co];
     if (gamma1 != nullptr) {  // z1 mode: s2 holds sum g*z1 over the unmasked voxels, z1 = gamma*xhat + beta there
         const double ga = (double)gamma1[co];
         s2 = ga != 0.0 ? (s2 - (double)beta1[co] * s1) / ga : 0.0;  // (gamma == 0: xhat is not recoverable from z1)
@@ -1747,10 +1780,10 @@ __global__ __launch_bounds__(1024) void k_c1w_fused_finish(const double *__restr
     if (tap < kTaps) {
         const double T2 = Rs(tap, kTaps);
         double cw = 0.0;  // sum_tap' W1[co][tap'] * (R[tap][tap'] - T2[tap] T2g[tap'] / Mg)
-        for (int u = 0; u < kTaps; ++u) {
-            const double T2g = ac_global ? (double)ac_global[ac_index(u, kTaps)] : Rs(u, kTaps);
-            cw += (double)W1[co * kTaps + u] * (Rs(tap, u) - T2 * T2g * inv_count);
-        }
+        // (W1 and the global column sums come from LDS and the loop is unrolled by three only: fully unrolled, the 27 hoisted global
+        // loads and index computations spilled 144 bytes per thread of this 1024-thread workgroup)
+#pragma unroll 3
+        for (int u = 0; u < kTaps; ++u) cw += (double)w1s[co * kTaps + u] * (Rs(tap, u) - T2 * t2g[u] * inv_count);
         const double T3 = (double)rstd1[co] * cw;
         dW1[co * kTaps + tap] = (float)((double)scale1[co] * (T1 - s1m * T2 - s2m * T3));
     }
@@ -2216,7 +2249,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     // (conv_split.h) -- conv2 never reads the 244 MB it would otherwise fetch right after conv1 wrote them.
     fused_train = analytic && !qm && conv_split_path(p, grid) && grid == 64 && !env_off("GENNBV_CONV1_SPLIT") && !env_off("GENNBV_FUSED_TRAIN");
     if (analytic) {
-        hipLaunchKernelGGL(k_bn1_analytic, dim3(fused_train ? 3 : 1), dim3(1024), 0, st, (const int *)p->autocorr, p->autocorr_row_stride, rows, batch, p->w1,
+        hipLaunchKernelGGL(k_bn1_analytic, dim3(fused_train ? 9 : 1), dim3(1024), 0, st, (const int *)p->autocorr, p->autocorr_row_stride, rows, batch, p->w1,
                            p->b1, p->bn1_w, p->bn1_b, p->eps, p->momentum, p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag, bn1, bn1 + kC, bn1 + 2 * kC,
                            bn1 + 3 * kC, (int *)(bn_state + kBnStateFloats), dp ? (const int *)p->autocorr_global : (const int *)nullptr,
                            p->w2, w.w2img, p->range_flag);

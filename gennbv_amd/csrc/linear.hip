@@ -428,7 +428,8 @@ __global__ __launch_bounds__(256) void k_fc_bwd_prep(const float *__restrict__ d
 // C[i][k] = inv_a[i] / bscale * sum_c Afrag[i][c] (bscale B[c][k]);  workgroup = 64 columns k, 4 waves x RT row tiles
 template <int RT>
 __global__ __launch_bounds__(256) void k_skinny_gemm_split(const uint4 *__restrict__ fragA, const float *__restrict__ inv_a, const float *__restrict__ Bm /*[C][K]*/,
-                                                           int rows /*of C*/, int Cc /*contraction length*/, int K, float bscale, float *__restrict__ Cout /*[rows][K]*/)
+                                                           int rows /*of C*/, int Cc /*contraction length*/, int K, float bscale, float *__restrict__ Cout /*[rows][K]*/,
+                                                           double *__restrict__ sq_partial = nullptr /*[gridDim.x]: sum of the squares this workgroup stored*/)
 {
     __shared__ __attribute__((aligned(16))) char s_b[2][2][4096];  // [buffer][hi | lo][k block 4][c 32][16 k] f16
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x / 64);
@@ -511,6 +512,7 @@ __global__ __launch_bounds__(256) void k_skinny_gemm_split(const uint4 *__restri
         __syncthreads();
     }
     const float ib = 1.0f / bscale;
+    double sq = 0.0;
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
         const int rt = wv * RT + r;
@@ -522,10 +524,26 @@ __global__ __launch_bounds__(256) void k_skinny_gemm_split(const uint4 *__restri
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) {
                     const int k = k0 + ct * 16 + i;
-                    if (k < K) Cout[(size_t)row * K + k] = acc[r][ct][e] * sc;
+                    const float v = acc[r][ct][e] * sc;
+                    if (k < K) {
+                        Cout[(size_t)row * K + k] = v;
+                        sq += (double)v * (double)v;
+                    }
                 }
             }
         }
+    }
+    // The gradient-norm clip needs sum g^2 over ALL parameters before the first one is updated; for the 13.8 M weights of fc_grid
+    // (94 % of them) that sum is taken here, while the values are in registers, instead of by a 55 MB pass of its own behind the
+    // backward (k_grad_sqnorm: 17 us on the update's critical path).  Fixed order: lanes by xor-shuffle, waves 0..3, workgroups by
+    // the consumer (gnbv_clip_adam_step_ex).
+    if (sq_partial != nullptr) {
+        __shared__ double s_sq[4];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) sq += __shfl_xor(sq, d, 64);
+        if (lane == 0) s_sq[wv] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) sq_partial[blockIdx.x] = (s_sq[0] + s_sq[1]) + (s_sq[2] + s_sq[3]);
     }
 }
 
@@ -614,14 +632,27 @@ GNBV_API int gnbv_linear_bwd_dx(const void *workspace, const float *w, int M, in
     return gnbv_launch_status();
 }
 
-GNBV_API int gnbv_linear_bwd_dw(const void *workspace, const float *x, int M, int N, int K, float *dw, void *stream)
+static int linear_bwd_dw(const void *workspace, const float *x, int M, int N, int K, float *dw, double *sq_partial, void *stream)
 {
     GNBV_CHECK_ARG(workspace && x && dw && M > 0 && M % 16 == 0 && M <= 256 && N % 16 == 0 && N <= 256 && K >= 64 && K % 4 == 0);
     GNBV_CHECK_ARG((((uintptr_t)x | (uintptr_t)dw) & 15) == 0);
     const FcBwdWs ws = fc_bwd_carve(const_cast<void *>(workspace), M, N);
     hipLaunchKernelGGL(k_skinny_gemm_split<4>, dim3((K + 63) / 64), dim3(256), 0, gnbv_stream(stream), (const uint4 *)ws.frag_dw, (const float *)ws.inv_dw, x, N, M, K,
-                       kLinXScale, dw);
+                       kLinXScale, dw, sq_partial);
     return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_linear_bwd_dw(const void *workspace, const float *x, int M, int N, int K, float *dw, void *stream)
+{
+    return linear_bwd_dw(workspace, x, M, N, K, dw, nullptr, stream);
+}
+
+GNBV_API int gnbv_linear_bwd_dw_sq_parts(int K) { return K > 0 ? (K + 63) / 64 : 0; }
+
+GNBV_API int gnbv_linear_bwd_dw_sq(const void *workspace, const float *x, int M, int N, int K, float *dw, double *sq_partial, void *stream)
+{
+    GNBV_CHECK_ARG(sq_partial && (((uintptr_t)sq_partial) & 7) == 0);
+    return linear_bwd_dw(workspace, x, M, N, K, dw, sq_partial, stream);
 }
 
 

@@ -252,17 +252,39 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_loss_rsl(int B, const floa
 // ---------------------------------------------------------------------------
 // clip_grad_norm_ + Adam over a flat buffer
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_grad_sqnorm(const float *__restrict__ g, int64_t n, double *__restrict__ partial)
+// sum g^2 over the flat gradient, WITHOUT the slice [lo, lo + gap) when gap > 0 (its producer took that sum: GnbvAdamStep.sq_*).
+// Fixed grid -> fixed summation order.  Four 16-byte requests per lane are in flight before the first is consumed (the first
+// version chained one request per iteration: 17 us for 58 MB).  Block 0 also carries the bookkeeping that used to sit in a
+// single-workgroup finalize launch between this kernel and the update: the data-parallel KL decision and the optimizer step
+// counter, both final before the Adam launch starts.
+__global__ __launch_bounds__(256) void k_grad_sqnorm(const float *__restrict__ g, int64_t n_eff, int64_t lo, int64_t gap, double *__restrict__ partial,
+                                                     float grad_scale, int64_t *step, int *stop_flag, const float *kl_slot, float target_kl)
 {
-    double acc = 0.0;
-    // 16-byte requests over the aligned body, scalar tail; fixed grid -> fixed summation order
-    const int64_t n4 = (((uintptr_t)g & 15) == 0) ? n / 4 : 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const float4 v = reinterpret_cast<const float4 *>(g)[i];
-        acc += (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && step != nullptr) {
+        // kl_slot holds the SUM of the ranks' approx-KL (it rode in front of the gradient in the all-reduce); sets the sticky
+        // stop flag before this step's update
+        if (stop_flag != nullptr && kl_slot != nullptr && target_kl > 0.f && (*kl_slot) * grad_scale > 1.5f * target_kl) *stop_flag = 1;
+        if (!(stop_flag != nullptr && *stop_flag != 0)) *step += 1;
     }
-    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const double v = (double)g[i];
+    double acc = 0.0;
+    const bool vec = (((uintptr_t)g & 15) == 0) && (lo & 3) == 0 && (gap & 3) == 0;
+    const int64_t n4 = vec ? n_eff / 4 : 0, lo4 = lo / 4, gap4 = gap / 4;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int64_t j = min(i0 + u * stride, n4 - 1);  // (clamped duplicate: unconditional request, masked below)
+            j += j >= lo4 ? gap4 : 0;
+            v[u] = reinterpret_cast<const float4 *>(g)[j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * stride < n4)
+                acc += (double)v[u].x * (double)v[u].x + (double)v[u].y * (double)v[u].y + (double)v[u].z * (double)v[u].z + (double)v[u].w * (double)v[u].w;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_eff; i += stride) {
+        const double v = (double)g[i + (i >= lo ? gap : 0)];
         acc += v * v;
     }
     __shared__ double s[256];
@@ -275,37 +297,12 @@ __global__ __launch_bounds__(256) void k_grad_sqnorm(const float *__restrict__ g
     if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
 }
 
-// clip coefficient = min(1, max_norm / (total_norm + 1e-6))  (torch.nn.utils.clip_grad_norm_)
-__global__ __launch_bounds__(256) void k_grad_norm_finalize(const double *__restrict__ partial, int nparts, float max_norm, float grad_scale, float *__restrict__ out /*[2]: norm, coef*/,
-                                                            int64_t *step, int *stop_flag, const float *kl_slot, float target_kl)
-{
-    __shared__ double sh[256];
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += 256) acc += partial[i];
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    for (int d = 128; d > 0; d >>= 1) {
-        if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
-        __syncthreads();
-    }
-    if (threadIdx.x != 0) return;
-    const double t = sh[0];
-    const float norm = (float)sqrt(t) * grad_scale;  // norm of the averaged gradient
-    float coef = max_norm > 0.f ? max_norm / (norm + 1e-6f) : 1.0f;
-    coef = coef > 1.0f ? 1.0f : coef;
-    out[0] = norm;
-    out[1] = coef * grad_scale;  // factor applied to the raw (summed) gradient
-    // (same launch) data-parallel KL decision + optimizer step counter: kl_slot holds the SUM of the ranks'
-    // approx-KL (it rode in front of the gradient in the all-reduce); sets the sticky stop flag before
-    // this step's update
-    if (step != nullptr) {
-        if (stop_flag != nullptr && kl_slot != nullptr && target_kl > 0.f && (*kl_slot) * grad_scale > 1.5f * target_kl) *stop_flag = 1;
-        if (!(stop_flag != nullptr && *stop_flag != 0)) *step += 1;
-    }
-}
-
+// clip coefficient = min(1, max_norm / (total_norm + 1e-6))  (torch.nn.utils.clip_grad_norm_), evaluated by EVERY workgroup of
+// the update from the partial sums (same order of additions everywhere: the same bits) instead of by a launch of its own.
 __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
-                            int64_t n, const float *__restrict__ norm_coef, const int *__restrict__ stop_flag,
+                            int64_t n, const double *__restrict__ partial, int nparts, const double *__restrict__ extra, int nextra,
+                            float max_norm, float grad_scale, float *__restrict__ norm_out /*[2]: norm, applied factor*/,
+                            const int *__restrict__ stop_flag,
                             const int64_t *__restrict__ step /*already incremented*/, float lr, float beta1, float beta2, float eps,
                             const int64_t *__restrict__ rot_table = nullptr, int rot_rows = 0, int rot_len = 0, int64_t *__restrict__ rot_out = nullptr,
                             int *__restrict__ rot_counter = nullptr)
@@ -319,7 +316,26 @@ __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, 
         if (threadIdx.x == 0) *rot_counter = c;
     }
     if (stop_flag != nullptr && *stop_flag != 0) return;
-    const float coef = norm_coef ? norm_coef[1] : 1.0f;
+    __shared__ double sh[256];
+    {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < nparts; i += 256) acc += partial[i];
+        for (int i = threadIdx.x; i < nextra; i += 256) acc += extra[i];
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        for (int d = 128; d > 0; d >>= 1) {
+            if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+            __syncthreads();
+        }
+    }
+    const float norm = (float)sqrt(sh[0]) * grad_scale;  // norm of the averaged gradient
+    float cf = max_norm > 0.f ? max_norm / (norm + 1e-6f) : 1.0f;
+    cf = cf > 1.0f ? 1.0f : cf;
+    const float coef = cf * grad_scale;  // factor applied to the raw (summed) gradient
+    if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out != nullptr) {
+        norm_out[0] = norm;
+        norm_out[1] = coef;
+    }
     // bias corrections in double like torch's scalar path (1 - beta**step evaluated in Python floats)
     const double t = (double)(*step);
     const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
@@ -441,34 +457,48 @@ GNBV_API int gnbv_ppo_loss_rsl(int batch, const float *log_prob, const float *ol
 
 GNBV_API size_t gnbv_adam_workspace_bytes(void) { return 1024 * sizeof(double) + 64; }
 
-static int clip_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float max_grad_norm,
-                          float lr, float beta1, float beta2, float eps, int64_t *step, int *stop_flag, float grad_scale,
-                          const float *kl_slot, float target_kl, float *norm_out /*[2]: total norm, applied factor*/,
-                          void *workspace, size_t workspace_bytes, const int64_t *rot_table, int rot_rows, int rot_len, int64_t *rot_out,
-                          int *rot_counter, void *stream)
+GNBV_API int gnbv_clip_adam_step_ex(const GnbvAdamStep *a, void *stream)
 {
-    GNBV_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && step && norm_out && workspace && n > 0);
-    GNBV_CHECK_ARG(workspace_bytes >= gnbv_adam_workspace_bytes());
+    GNBV_CHECK_ARG(a && a->params && a->grads && a->exp_avg && a->exp_avg_sq && a->step && a->norm_out && a->workspace && a->n > 0);
+    GNBV_CHECK_ARG(a->workspace_bytes >= gnbv_adam_workspace_bytes());
+    GNBV_CHECK_ARG(a->table == nullptr || (a->out && a->counter && a->table_rows > 0 && a->row_len > 0));
+    const bool sliced = a->sq_partial != nullptr && a->sq_parts > 0 && a->sq_hi > a->sq_lo;
+    GNBV_CHECK_ARG(!sliced || (a->sq_lo >= 0 && a->sq_hi <= a->n));
     hipStream_t st = gnbv_stream(stream);
-    double *partial = (double *)workspace;
-    int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
+    double *partial = (double *)a->workspace;
+    const int64_t gap = sliced ? a->sq_hi - a->sq_lo : 0, n_eff = a->n - gap;
+    int blocks = (int)((n_eff + 256 * 16 - 1) / (256 * 16));
     blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
-    hipLaunchKernelGGL(k_grad_sqnorm, dim3(blocks), dim3(256), 0, st, grads, n, partial);
-    hipLaunchKernelGGL(k_grad_norm_finalize, dim3(1), dim3(256), 0, st, partial, blocks, max_grad_norm, grad_scale, norm_out, step, stop_flag,
-                       kl_slot, target_kl);
-    int ab = (int)((n + 255) / 256);
-    ab = ab > 4096 ? 4096 : ab;
-    hipLaunchKernelGGL(k_adam_flat, dim3(ab), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, (const float *)norm_out,
-                       (const int *)stop_flag, step, lr, beta1, beta2, eps, rot_table, rot_rows, rot_len, rot_out, rot_counter);
+    hipLaunchKernelGGL(k_grad_sqnorm, dim3(blocks), dim3(256), 0, st, a->grads, n_eff, sliced ? a->sq_lo : a->n, gap, partial, a->grad_scale,
+                       a->step, a->stop_flag, a->kl_slot, a->target_kl);
+    int ab = (int)((a->n + 255) / 256);
+    ab = ab > 2048 ? 2048 : ab;  // (8 workgroups per CU, all resident at once: the clip-coefficient prologue is paid once per CU slot)
+    hipLaunchKernelGGL(k_adam_flat, dim3(ab), dim3(256), 0, st, a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->n, (const double *)partial, blocks,
+                       sliced ? a->sq_partial : (const double *)nullptr, sliced ? a->sq_parts : 0, a->max_grad_norm, a->grad_scale, a->norm_out,
+                       (const int *)a->stop_flag, (const int64_t *)a->step, a->lr, a->beta1, a->beta2, a->eps, a->table, a->table_rows, a->row_len, a->out,
+                       a->counter);
     return gnbv_launch_status();
+}
+
+static GnbvAdamStep adam_args(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float max_grad_norm, float lr, float beta1,
+                              float beta2, float eps, int64_t *step, int *stop_flag, float grad_scale, const float *kl_slot, float target_kl,
+                              float *norm_out, void *workspace, size_t workspace_bytes)
+{
+    GnbvAdamStep a = {};
+    a.params = params; a.grads = grads; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.n = n;
+    a.max_grad_norm = max_grad_norm; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+    a.step = step; a.stop_flag = stop_flag; a.grad_scale = grad_scale; a.kl_slot = kl_slot; a.target_kl = target_kl;
+    a.norm_out = norm_out; a.workspace = workspace; a.workspace_bytes = workspace_bytes;
+    return a;
 }
 
 GNBV_API int gnbv_clip_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float max_grad_norm,
                                  float lr, float beta1, float beta2, float eps, int64_t *step, int *stop_flag, float grad_scale,
                                  const float *kl_slot, float target_kl, float *norm_out, void *workspace, size_t workspace_bytes, void *stream)
 {
-    return clip_adam_step(params, grads, exp_avg, exp_avg_sq, n, max_grad_norm, lr, beta1, beta2, eps, step, stop_flag, grad_scale, kl_slot,
-                          target_kl, norm_out, workspace, workspace_bytes, nullptr, 0, 0, nullptr, nullptr, stream);
+    const GnbvAdamStep a = adam_args(params, grads, exp_avg, exp_avg_sq, n, max_grad_norm, lr, beta1, beta2, eps, step, stop_flag, grad_scale, kl_slot,
+                                     target_kl, norm_out, workspace, workspace_bytes);
+    return gnbv_clip_adam_step_ex(&a, stream);
 }
 
 GNBV_API int gnbv_clip_adam_step_rotate(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float max_grad_norm,
@@ -477,8 +507,10 @@ GNBV_API int gnbv_clip_adam_step_rotate(float *params, const float *grads, float
                                         const int64_t *table, int table_rows, int row_len, int64_t *out, int *counter, void *stream)
 {
     GNBV_CHECK_ARG(table && out && counter && table_rows > 0 && row_len > 0);
-    return clip_adam_step(params, grads, exp_avg, exp_avg_sq, n, max_grad_norm, lr, beta1, beta2, eps, step, stop_flag, grad_scale, kl_slot,
-                          target_kl, norm_out, workspace, workspace_bytes, table, table_rows, row_len, out, counter, stream);
+    GnbvAdamStep a = adam_args(params, grads, exp_avg, exp_avg_sq, n, max_grad_norm, lr, beta1, beta2, eps, step, stop_flag, grad_scale, kl_slot,
+                               target_kl, norm_out, workspace, workspace_bytes);
+    a.table = table; a.table_rows = table_rows; a.row_len = row_len; a.out = out; a.counter = counter;
+    return gnbv_clip_adam_step_ex(&a, stream);
 }
 
 GNBV_API int gnbv_multicategorical_sample(const float *logits, int batch, int n_logits, int n_heads, const int *head_dims,

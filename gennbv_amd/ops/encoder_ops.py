@@ -281,7 +281,17 @@ class _LinearReluFn(torch.autograd.Function):
                 dx = torch.empty(m, k, dtype=torch.float32, device=dev)
                 _lib.check(lib.gnbv_linear_bwd_dx(ws.data_ptr(), w.data_ptr(), m, n, k, dx.data_ptr(), _lib.stream_ptr(dev)), "gnbv_linear_bwd_dx")
 
+            # (write-through layers whose owner asked for it: sum(dW^2) leaves the GEMM as fp64 partial sums, the optimizer's norm
+            # pass then skips this gradient -- ops/ppo_ops.py FlatAdam.step(sq_slice=...))
+            sq = getattr(mod, "_dw_sq_partial", None) if direct else None
+            if mod is not None:
+                mod._dw_sq_written = sq is not None
+
             def launch_dw():
+                if sq is not None:
+                    _lib.check(lib.gnbv_linear_bwd_dw_sq(ws.data_ptr(), x.data_ptr(), m, n, k, dw.data_ptr(), sq.data_ptr(), _lib.stream_ptr(dev)),
+                               "gnbv_linear_bwd_dw_sq")
+                    return
                 _lib.check(lib.gnbv_linear_bwd_dw(ws.data_ptr(), x.data_ptr(), m, n, k, dw.data_ptr(), _lib.stream_ptr(dev)), "gnbv_linear_bwd_dw")
             if defer:
                 evt = torch.cuda.Event()
@@ -290,6 +300,8 @@ class _LinearReluFn(torch.autograd.Function):
             else:
                 launch_dw()
             return (dx, None, None, None, None) if direct else (dx, dw, db, None, None)
+        if mod is not None:
+            mod._dw_sq_written = False
         g = torch.ops.aten.threshold_backward(d_out.contiguous(), out, 0.0)
         if defer:
             # Nothing downstream of this node needs dW / db (only the optimizer does): they are computed on a second stream

@@ -55,24 +55,38 @@ class FlatAdam:
         self.grads.zero_()
 
     def step(self, max_grad_norm: float, stop_flag: Optional[torch.Tensor] = None, grad_scale: float = 1.0,
-             kl_slot_target: Optional[float] = None, rotate=None):
+             kl_slot_target: Optional[float] = None, rotate=None, sq_slice=None):
         """grad_scale = 1/world and kl_slot_target = target_kl for the data-parallel tail.  rotate = (table [rows, len] int64,
-        out [len] int64, counter [1] int32): the launch also leaves the next minibatch's row numbers in `out`
-        (gnbv_clip_adam_step_rotate)."""
-        args = (self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.n,
-                float(max_grad_norm if max_grad_norm is not None else -1.0), float(self.lr), float(self.betas[0]),
-                float(self.betas[1]), float(self.eps), self.step_count.data_ptr(), _lib.ptr(stop_flag), float(grad_scale),
-                self.kl_slot.data_ptr() if kl_slot_target is not None else None,
-                float(kl_slot_target) if kl_slot_target is not None else -1.0, self.norm_out.data_ptr(),
-                self.ws.data_ptr(), self.ws.numel())
-        if rotate is None:
-            _lib.check(self.lib.gnbv_clip_adam_step(*args, _lib.stream_ptr(self.params.device)), "gnbv_clip_adam_step")
-        else:
+        out [len] int64, counter [1] int32): the launch also leaves the next minibatch's row of `table` in `out`.
+        sq_slice = (lo, hi, partial fp64 tensor): sum(grad[lo:hi]^2) was left in `partial` by the kernel that produced that
+        gradient slice (gnbv_linear_bwd_dw_sq) -- the norm pass skips the slice.  (include/gennbv_hip.h: GnbvAdamStep)"""
+        a = _lib.GnbvAdamStep()
+        a.params, a.grads, a.exp_avg, a.exp_avg_sq, a.n = (self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+                                                           self.exp_avg_sq.data_ptr(), self.n)
+        a.max_grad_norm = float(max_grad_norm if max_grad_norm is not None else -1.0)
+        a.lr, a.beta1, a.beta2, a.eps = float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps)
+        a.step, a.stop_flag, a.grad_scale = self.step_count.data_ptr(), _lib.ptr(stop_flag), float(grad_scale)
+        a.kl_slot = self.kl_slot.data_ptr() if kl_slot_target is not None else None
+        a.target_kl = float(kl_slot_target) if kl_slot_target is not None else -1.0
+        a.norm_out, a.workspace, a.workspace_bytes = self.norm_out.data_ptr(), self.ws.data_ptr(), self.ws.numel()
+        if rotate is not None:
             table, out, counter = rotate
             assert table.dtype == torch.int64 and table.is_contiguous() and table.dim() == 2 and out.dtype == torch.int64 and out.is_contiguous()
             assert out.numel() == table.shape[1] and counter.dtype == torch.int32
-            _lib.check(self.lib.gnbv_clip_adam_step_rotate(*args, table.data_ptr(), int(table.shape[0]), int(table.shape[1]), out.data_ptr(),
-                                                           counter.data_ptr(), _lib.stream_ptr(self.params.device)), "gnbv_clip_adam_step_rotate")
+            a.table, a.table_rows, a.row_len, a.out, a.counter = (table.data_ptr(), int(table.shape[0]), int(table.shape[1]), out.data_ptr(),
+                                                                   counter.data_ptr())
+        if sq_slice is not None:
+            lo, hi, part = sq_slice
+            assert part.dtype == torch.float64 and part.is_contiguous() and 0 <= lo < hi <= self.n
+            a.sq_lo, a.sq_hi, a.sq_partial, a.sq_parts = int(lo), int(hi), part.data_ptr(), int(part.numel())
+        _lib.check(self.lib.gnbv_clip_adam_step_ex(C.byref(a), _lib.stream_ptr(self.params.device)), "gnbv_clip_adam_step_ex")
+
+    def slice_of(self, param: torch.Tensor):
+        """(lo, hi) of a parameter in the flat buffers, or None."""
+        for (off, k), p in zip(self.slices, self.module_params):
+            if p is param:
+                return off, off + k
+        return None
 
     def torch_state_dict(self, template: torch.optim.Adam) -> dict:
         """This optimizer's state in torch.optim.Adam.state_dict() format (checkpoints: policy.optimizer.pth);
@@ -119,7 +133,11 @@ class PpoLossOp:
         self.batch, self.head_dims = batch, list(head_dims)
         n_logits, nh = sum(head_dims), len(head_dims)
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=device)  # noqa: E731
-        self.rows = z(batch, dt=torch.int64)
+        # [row numbers (batch) | (mean, 1 / (std + 1e-8)) of the minibatch's advantages as two fp32 in one int64 slot]: ONE buffer, so
+        # that the row rotation of the replayed graph (FlatAdam.step(rotate=...)) delivers both
+        self.rows_ext = z(batch + 1, dt=torch.int64)
+        self.rows = self.rows_ext[:batch]
+        self.adv_slot = self.rows_ext[batch:].view(torch.float32)
         self.actions, self.old_values, self.old_log_prob = z(batch, nh), z(batch), z(batch)
         self.advantages, self.returns = z(batch), z(batch)
         self.d_logits, self.d_values = z(batch, n_logits), z(batch)

@@ -367,6 +367,18 @@ class PPO_Grid_Obs:
                                                      and (self._sync is None or not self._sync.active))
         self._hip["skip_zero"] = bool(self.grad_write_through) and all(
             id(p) in covered for p in self.policy.parameters() if p.requires_grad)
+        # fc_grid's weight gradient (94 % of all parameters) leaves its GEMM with sum(dW^2) as fp64 partial sums: the clip's norm
+        # pass skips that slice.  One GPU only: data-parallel ranks clip the all-reduced gradient, whose norm nobody has yet.
+        self._hip["sq_slice"] = None
+        if getattr(enc, "backend", "") == "hip":
+            lin = enc.output_layer_grid[0]
+            lin._dw_sq_partial, lin._dw_sq_written = None, False
+            sl = opt.slice_of(lin.weight)
+            if bool(self.grad_write_through) and (self._sync is None or not self._sync.active) and sl is not None and sl[0] % 4 == 0 and sl[1] % 4 == 0:
+                from .. import _lib
+                parts = int(_lib.load().gnbv_linear_bwd_dw_sq_parts(int(lin.weight.shape[1])))
+                lin._dw_sq_partial = torch.zeros(parts, dtype=torch.float64, device=self.device)
+                self._hip["sq_slice"] = (sl[0], sl[1], lin._dw_sq_partial)
         return self._hip
 
     def _hip_minibatch_body(self, st, phase: str = "all"):
@@ -409,7 +421,8 @@ class PPO_Grid_Obs:
                 encoder_ops.pose_branch_backward(enc, self.device)  # (deferred so that the conv chain is captured first: encoder_ops.hybrid_branches)
                 encoder_ops.join_async_wgrads(self.device)  # fc_grid's dW / db: second stream, beside the conv backward
                 if self._sync is None or not self._sync.active:
-                    opt.step(self.max_grad_norm, loss.stop_flag, rotate=st.get("rows_rot"))
+                    sq = st.get("sq_slice") if (lin is not None and getattr(lin, "_dw_sq_written", False)) else None
+                    opt.step(self.max_grad_norm, loss.stop_flag, rotate=st.get("rows_rot"), sq_slice=sq)
                 return
             # the forward cut the graph at the conv-stack output (enc._split_backward): this backward
             # stops at that leaf and fills the gradients of every non-conv parameter
@@ -506,24 +519,37 @@ class PPO_Grid_Obs:
         # replays.  (The table and the counter are baked into the graph: persistent buffers.)
         rotating = use_graph and not dp and n_mb > 0 and os.environ.get("GENNBV_ROTATE_ROWS", "1") != "0"
         rot = st.get("rows_rot")
-        if rotating and (rot is None or tuple(rot[0].shape) != (n_mb, batch)):
-            rot = (torch.empty(n_mb, batch, dtype=torch.int64, device=self.device), loss.rows, torch.zeros(1, dtype=torch.int32, device=self.device))
+        if rotating and (rot is None or tuple(rot[0].shape) != (n_mb, batch + 1)):
+            # a table row = [the minibatch's row numbers | (mean, 1 / (std + 1e-8)) of its advantages], rotated into loss.rows_ext
+            rot = (torch.empty(n_mb, batch + 1, dtype=torch.int64, device=self.device), loss.rows_ext, torch.zeros(1, dtype=torch.int32, device=self.device))
             st["rows_rot"], st["graph"] = rot, None
         elif not rotating and rot is not None:
             rot = st["rows_rot"] = None
             st["graph"] = None
+        if not dp:
+            loss.args.adv_norm = loss.adv_slot.data_ptr() if (rotating and self.normalize_advantage) else None
         if rotating:
-            rot[0].copy_(rows_all[:n_mb * batch].view(n_mb, batch))
+            rot[0][:, :batch].copy_(rows_all[:n_mb * batch].view(n_mb, batch))
+            if self.normalize_advantage:
+                # The advantages and the permutation are fixed for the whole train() call: every minibatch's statistics
+                # (ppo_grid_obs.py:214-216: mean, unbiased std) once, instead of two dependent gather passes in every wave of every
+                # loss launch
+                adv = buf.advantages.view(-1)[rows_all[:n_mb * batch]].view(n_mb, batch)
+                stats = torch.stack((adv.mean(1), 1.0 / (adv.std(1) + 1e-8)), 1).contiguous()
+                rot[0][:, batch:].view(torch.float32).copy_(stats)
             rot[2].zero_()
         if use_graph and st["graph"] is None:
-            loss.rows.copy_(rows_all[:batch])
+            if rotating:
+                loss.rows_ext.copy_(rot[0][0])
+            else:
+                loss.rows.copy_(rows_all[:batch])
             st["graph"] = self._capture_minibatch_graph(st)
             loss.stats_row.zero_()
             loss.stop_flag.zero_()
             if rotating:
                 rot[2].zero_()
         if rotating:
-            loss.rows.copy_(rows_all[:batch])
+            loss.rows_ext.copy_(rot[0][0])
         epochs_run = 0
         for epoch in range(self.n_epochs):
             for k in range(n_mb):

@@ -344,6 +344,11 @@ int gnbv_linear_bwd_prep(const float *d_out, const float *out, int M, int N, flo
                          void *stream);
 int gnbv_linear_bwd_dx(const void *workspace, const float *w, int M, int N, int K, float *dx, void *stream);
 int gnbv_linear_bwd_dw(const void *workspace, const float *x, int M, int N, int K, float *dw, void *stream);
+/*     The same product, which also leaves sum(dw^2) as gnbv_linear_bwd_dw_sq_parts(K) fp64 partial sums (one per 64 columns) in
+ *     `sq_partial`: the gradient-norm clip of the optimizer step (GnbvAdamStep.sq_partial) then needs no pass of its own over
+ *     this -- by far the largest -- gradient. */
+int gnbv_linear_bwd_dw_sq_parts(int K);
+int gnbv_linear_bwd_dw_sq(const void *workspace, const float *x, int M, int N, int K, float *dw, double *sq_partial, void *stream);
 
 /* B1  pose-history input (gennbv/network/hybrid_encoder.py:63-74 positional_encoding with 2 frequency bands, :78-80): the state
  *     columns [0, 6 n_pose) of observation rows `rows` (NULL: rows 0 .. batch-1) of `base` (row stride in floats) ->
@@ -467,6 +472,21 @@ int gnbv_clip_adam_step_rotate(float *params, const float *grads, float *exp_avg
                                float lr, float beta1, float beta2, float eps, int64_t *step, int *stop_flag, float grad_scale,
                                const float *kl_slot, float target_kl, float *norm_out, void *workspace, size_t workspace_bytes,
                                const int64_t *table, int table_rows, int row_len, int64_t *out, int *counter, void *stream);
+/* Both of the above are this call with the optional parts left out.  `table` .. `counter`: the row rotation of
+ * gnbv_clip_adam_step_rotate (table == NULL: none).  sq_lo .. sq_parts: the squared sum of the gradient slice [sq_lo, sq_hi) was
+ * already taken by its producer (gnbv_linear_bwd_dw_sq) and is read from `sq_partial` instead of from the gradient itself;
+ * sq_partial == NULL: the whole gradient is summed here.  Two launches: the squared-norm partial sums (+ step counter / KL
+ * decision), then the update, every workgroup of which evaluates the clip coefficient from the partial sums in one fixed order. */
+typedef struct GnbvAdamStep {
+    float *params; const float *grads; float *exp_avg, *exp_avg_sq; int64_t n;
+    float max_grad_norm, lr, beta1, beta2, eps;
+    int64_t *step; int *stop_flag; float grad_scale; const float *kl_slot; float target_kl;
+    float *norm_out; void *workspace; size_t workspace_bytes;
+    const int64_t *table; int table_rows, row_len; int64_t *out; int *counter;
+    int64_t sq_lo, sq_hi; const double *sq_partial; int sq_parts;
+} GnbvAdamStep;
+int gnbv_clip_adam_step_ex(const GnbvAdamStep *a /*[host]*/, void *stream);
+
 
 /* ------------------------------------------------------------------------- */
 /* 8f.3  evaluation metric: reconstruction accuracy of Env_Eval_GenNBV          */

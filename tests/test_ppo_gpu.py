@@ -119,6 +119,19 @@ def test_flat_adam_matches_torch_adam_with_clipping():
     before = o2.params.clone()
     o2.step(1.0, flag, rotate=(table, out, counter))
     assert torch.equal(before, o2.params) and int(counter.item()) == 2 and torch.equal(out, table[2])
+    # GnbvAdamStep.sq_*: the squared sum of one gradient slice comes from its producer (here: computed on the side, in two parts)
+    # and the norm pass skips the slice -- same update
+    lo, hi = o2.slice_of(m2[0].weight)
+    assert (lo, hi) == (0, 37 * 19)
+    for it in range(3):
+        o1.zero_grad(); o2.zero_grad()
+        (m1(x) ** 2).sum().backward(); (m2(x) ** 2).sum().backward()
+        torch.nn.utils.clip_grad_norm_(m1.parameters(), 1.0)
+        g = o2.grads[lo + 4:hi - 3].double() ** 2
+        part = torch.stack((g[:100].sum(), g[100:].sum()))
+        o1.step(); o2.step(1.0, sq_slice=(lo + 4, hi - 3, part))
+    for a, b in zip(m1.parameters(), m2.parameters()):
+        torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("name", ["F9_ppo_train", "F9_ppo_train_earlystop"])
