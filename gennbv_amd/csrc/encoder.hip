@@ -414,10 +414,10 @@ __device__ __forceinline__ void fill_lds_image(float *lds, const float *__restri
 }
 
 // Workgroup -> (sample b, group of PZ planes) with all groups of sample b on XCD b % 8.
-__device__ __forceinline__ bool sample_plane_group(int B, int O, int PZ, int &b, int &o0, int &o1)
+__device__ __forceinline__ bool sample_plane_group(int B, int O, int PZ, int &b, int &o0, int &o1, int block = -1)
 {
     const int ng = (O + PZ - 1) / PZ;
-    const int i = blockIdx.x, xcd = i & 7, slot = i >> 3;
+    const int i = block < 0 ? (int)blockIdx.x : block, xcd = i & 7, slot = i >> 3;  // (block: a virtual index, k_conv2_bwd_dual_split)
     const int gidx = slot % ng;
     b = (slot / ng) * 8 + xcd;
     o0 = gidx * PZ;
@@ -2415,7 +2415,32 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     int wg_blocks = (nrows2 + kEncWaves - 1) / kEncWaves;
     wg_blocks = wg_blocks > 512 ? 512 : ((wg_blocks + 7) & ~7);
     const bool split_bwd = !z1 && !qm && conv_split_path(p, grid);
-    if (split_bwd) {
+    // both backward kernels as ONE launch whose workgroup pairs share their y1 planes through the XCD's L2 (k_conv2_bwd_dual_split)
+    // OPT-IN (GENNBV_BWD_DUAL=1).  Measured (profiles/r03_notes.md): the pairs DO share -- FETCH_SIZE 581 -> 397 MB per minibatch --
+    // and the launch takes 185 us against 80 + 100 separately (206.8 against 191.4 beside fc_grid's dW GEMM in the captured
+    // minibatch): these kernels are not bound by where their bytes come from.
+    const char *dual_env = getenv("GENNBV_BWD_DUAL");
+    const bool dual_bwd = split_bwd && fused && dual_env && dual_env[0] == '1';
+    float *wg1_part_early = w.wg_part + (size_t)512 * (kTaps * 256 + kC);
+    if (dual_bwd) {
+        static bool attr_du = false;
+        if (!attr_du) {
+            const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_bwd_dual_split, hipFuncAttributeMaxDynamicSharedMemorySize, dual::kLdsBytes);
+            if (e != hipSuccess) return (int)e;
+            attr_du = true;
+        }
+        wg_blocks = sample_plane_group_grid(batch, O2, split::kNP);
+        if (wg_blocks != sample_plane_group_grid(batch, (O1 + 1) / 2, kPlanesPerGroup)) return (int)hipErrorInvalidValue;  // (same partition by construction)
+        Conv2BwdDualArgs da;
+        da.y1 = (const float *)y1; da.scale1 = bn1; da.shift1 = bn1 + kC; da.mean1 = bn1 + 2 * kC; da.rstd1 = bn1 + 3 * kC; da.dy2 = dy2_scratch;
+        da.absmax = (const unsigned *)dy2_absmax;
+        da.w2img = (const uint4 *)(w.w2split + split::kW2ImgU4);
+        da.wbound = (const float *)(w.w2split + split::kW2ImgU4 + dsplit::kImgSlotU4);
+        da.grid_i8 = p->grid_i8; da.rows = rows; da.grid_row_stride = p->grid_i8_row_stride;
+        da.B = batch; da.G = grid; da.O1 = O1; da.O2 = O2;
+        da.wg_partial = w.wg_part; da.dg_partial = wg1_part_early;
+        hipLaunchKernelGGL(k_conv2_bwd_dual_split, dim3(2 * wg_blocks), dim3(split::kThreads), dual::kLdsBytes, sw, da);
+    } else if (split_bwd) {
         static bool attr_wg = false;
         if (!attr_wg) {
             const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_wgrad_split, hipFuncAttributeMaxDynamicSharedMemorySize, split::kWgLdsBytes);
@@ -2451,7 +2476,9 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     // ---- conv2 data gradient (+ ReLU1 mask, BN1 backward sums) ----
     const int gd = sample_plane_group_grid(batch, (O1 + 1) / 2, kPlanesPerGroup);  // groups of plane PAIRS
     if (fused) {
-        if (split_bwd) {
+        if (dual_bwd) {
+            // (the data gradient ran in the dual launch above)
+        } else if (split_bwd) {
             static bool attr_dg = false;
             if (!attr_dg) {
                 const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_dgrad_c1w_split, hipFuncAttributeMaxDynamicSharedMemorySize, dsplit::kLdsBytes);

@@ -358,6 +358,11 @@ __device__ __forceinline__ void trace_ray_lane(const int (&src)[3], int lin_t, i
             } else if (LDS_PATH) {
                 // (testing the bit first -- same-address reads broadcast -- so that only the first ray through a voxel pays the
                 // atomic was slower: 32.5 against 28.6 us, the read's latency sits on the walk's critical path)
+#if defined(RAY_ABL) && RAY_ABL == 1
+                if (i >= 12)
+#elif defined(RAY_ABL) && RAY_ABL == 2
+                if (l == 0x7ffffff)
+#endif
                 atomicOr(&s_path[l >> 5], 1u << (l & 31));
             } else {
                 atomicOr(&pm[l >> 5], 1u << (l & 31));
@@ -926,6 +931,74 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80), 
 #endif
 }
 
+// One ray of trace_ray_lane as a state machine (round 3).  What the walk costs is INSTRUCTION ISSUE, not latency and not the LDS
+// atomics: a 256-ray workgroup took 7.7 us with and 7.4 us without its atomics, and two interleaved rays per lane took 12.4 us
+// (ablations in profiles/r03_notes.md) -- five waves per SIMD already fill its issue slots with these dependent integer chains.
+// So the step is kept short: branch-free, and WITHOUT the three bounds tests and the two minor coordinates when the camera voxel itself lies
+// in the grid (INB: both ends of every ray are in the grid then, hence -- the grid is convex, the coordinates monotone -- all of it).
+template <bool INB>
+struct RayWalk {
+    int pa, pb, pc, l, p1, p2, left /*voxels still to emit: da + 1 - i*/;
+    int two_db, two_dc, dl1 /*2 db - 2 da*/, dl2, sa, sb, sc, la, lb, lc;
+    __device__ __forceinline__ void init(const int (&src)[3], int lin_t, int g, int gg, bool live)
+    {
+        int tgt[3];
+        tgt[0] = lin_t / gg;
+        const int rem = lin_t - tgt[0] * gg;
+        tgt[1] = rem / g;
+        tgt[2] = rem - tgt[1] * g;
+        const int d0 = abs(tgt[0] - src[0]), d1 = abs(tgt[1] - src[1]), d2 = abs(tgt[2] - src[2]);
+        const int dm = max(max(d0, d1), d2);
+        // dominant axis tested x, y, z (utils.py:69,102,133); minors keep the reference's order
+        const bool ax = dm == d0, ay = !ax && dm == d1;
+        pa = ax ? src[0] : (ay ? src[1] : src[2]);
+        pb = ax ? src[1] : src[0];
+        pc = (ax || ay) ? src[2] : src[1];
+        const int ta = ax ? tgt[0] : (ay ? tgt[1] : tgt[2]), tb = ax ? tgt[1] : tgt[0], tc = (ax || ay) ? tgt[2] : tgt[1];
+        const int da = dm, db = ax ? d1 : d0, dc = (ax || ay) ? d2 : d1;
+        const int st_a = ax ? gg : (ay ? g : 1), st_b = ax ? g : gg, st_c = (ax || ay) ? 1 : g;
+        sa = pa < ta ? 1 : -1; sb = pb < tb ? 1 : -1; sc = pc < tc ? 1 : -1;
+        two_db = 2 * db; two_dc = 2 * dc;
+        dl1 = two_db - 2 * da; dl2 = two_dc - 2 * da;
+        p1 = two_db - da; p2 = two_dc - da;
+        l = pa * st_a + pb * st_b + pc * st_c;
+        la = sa * st_a; lb = sb * st_b; lc = sc * st_c;
+        left = live ? da + 1 : 0;
+    }
+    // emit the current voxel (if any is left and it lies in the grid), then advance:  p >= 0 ? (minor += s, p += 2 d - 2 da) : p += 2 d
+    __device__ __forceinline__ void step(unsigned ug, uint32_t *s_path)
+    {
+        bool ok = left > 0;
+        if (!INB) ok = ok && (unsigned)pa < ug && (unsigned)pb < ug && (unsigned)pc < ug;
+        atomicOr(&s_path[ok ? l >> 5 : 0], ok ? 1u << (l & 31) : 0u);  // (a step outside the grid ORs a zero into word 0: rare, and free of branches)
+        const bool ib = p1 >= 0, ic = p2 >= 0;
+        l += (ib ? lb : 0) + (ic ? lc : 0) + la;
+        p1 += ib ? dl1 : two_db;
+        p2 += ic ? dl2 : two_dc;
+        if (!INB) {
+            pb += ib ? sb : 0;
+            pc += ic ? sc : 0;
+            pa += sa;
+        }
+        --left;
+    }
+};
+
+template <bool INB>
+__device__ __forceinline__ void walk_slice(const int (&src)[3], const int32_t *__restrict__ list, int cnt, int first, int stride, int g, int gg,
+                                           uint32_t *s_path)
+{
+    // Consecutive list entries are neighbouring voxels whose rays run through the same mask words step after step
+    // (64-way same-address LDS atomics): lane r walks entry (r * P) mod cnt instead, a bijection for P coprime to cnt.
+    const int64_t P = (cnt % 7919) ? 7919 : 7907;
+    const unsigned ug = (unsigned)g;
+    for (int r = first; r < cnt; r += stride) {
+        RayWalk<INB> rw;
+        rw.init(src, list[(int)(((int64_t)r * P) % cnt)], g, gg, true);
+        for (int i = rw.left; i > 0; --i) rw.step(ug, s_path);
+    }
+}
+
 // launch 2: load-balanced ray cast over the ray lists (see the header above)
 __global__ __launch_bounds__(kListThreads) void k_ray_list(
     const int32_t *__restrict__ ray_count, const int32_t *__restrict__ ray_list, int64_t ray_cap, const float *__restrict__ poses_xyz,
@@ -933,6 +1006,10 @@ __global__ __launch_bounds__(kListThreads) void k_ray_list(
     uint32_t *__restrict__ path_mask)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_path[];
+    // block -> (env, slice), env-major.  (Measured alternatives, per-workgroup time stamps in profiles/r03_notes.md: ~1300 of the 4096
+    // workgroups are live and ~1000 fit the chip's LDS at once, so the launch runs as two rounds -- live workgroups start over 15 us;
+    // slice-major order, 384- and 512-thread workgroups and two interleaved rays per lane all lengthen the slowest workgroup by more
+    // than they save: 29-35 us against 28.)
     const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
     const int e = (slot / kListSlices) * 8 + xcd;
     const int sl = slot % kListSlices;
@@ -940,6 +1017,9 @@ __global__ __launch_bounds__(kListThreads) void k_ray_list(
     const int cnt = (int)min((int64_t)ray_count[e], ray_cap);
     if (sl * kListThreads >= cnt) return;  // light env: nothing for this slice
     const int tid = threadIdx.x;
+#ifdef PHASE_TIMING
+    const uint64_t rt0 = wall_clock64();
+#endif
     for (int i = tid; i < words; i += kListThreads) s_path[i] = 0u;
     const float *pp = poses_xyz + (size_t)e * pose_stride;
     const int src[3] = {pose_axis_to_idx(pp[0], range_gt[e * 6 + 1], voxel_size[e * 3 + 0]),
@@ -948,17 +1028,38 @@ __global__ __launch_bounds__(kListThreads) void k_ray_list(
     const int gg = g * g;
     const int32_t *list = ray_list + (size_t)e * ray_cap;
     __syncthreads();
-    // Consecutive list entries are neighbouring voxels whose rays run through the same mask words step after step
-    // (64-way same-address LDS atomics): lane r walks entry (r * P) mod cnt instead, a bijection for P coprime to cnt.
-    const int64_t P = (cnt % 7919) ? 7919 : 7907;
-    for (int r = sl * kListThreads + tid; r < cnt; r += kListSlices * kListThreads)
-        trace_ray_lane<true, false>(src, list[(int)(((int64_t)r * P) % cnt)], g, gg, s_path, nullptr);
+    const bool src_in = (unsigned)src[0] < (unsigned)g && (unsigned)src[1] < (unsigned)g && (unsigned)src[2] < (unsigned)g;  // (per env: uniform)
+    if (src_in)
+        walk_slice<true>(src, list, cnt, sl * kListThreads + tid, kListSlices * kListThreads, g, gg, s_path);
+    else
+        walk_slice<false>(src, list, cnt, sl * kListThreads + tid, kListSlices * kListThreads, g, gg, s_path);
+#ifdef PHASE_TIMING
+    const uint64_t rt1w = wall_clock64();  // this wave's walk
+#endif
     __syncthreads();
+#ifdef PHASE_TIMING
+    const uint64_t rt1 = wall_clock64();
+#endif
     uint32_t *gp = path_mask + (size_t)e * words;
+#if defined(RAY_ABL) && RAY_ABL == 3
+    if (words < 0)
+#endif
     for (int i = tid; i < words; i += kListThreads) {
         const uint32_t v = s_path[i];
         if (v) atomicOr(&gp[i], v);
     }
+#ifdef PHASE_TIMING
+    __syncthreads();
+    if (tid == 0) {
+        int32_t *dbg = const_cast<int32_t *>(ray_list) + (size_t)n * ray_cap - 8 * 512 - 8 * (size_t)(blockIdx.x + 1);
+        dbg[0] = (int32_t)(rt0 & 0x7fffffff);
+        dbg[1] = (int32_t)(rt1w - rt0);
+        dbg[2] = (int32_t)(rt1 - rt0);
+        dbg[3] = (int32_t)(wall_clock64() - rt0);
+        dbg[4] = cnt;
+        dbg[5] = 1;
+    }
+#endif
 }
 
 // ===========================================================================
@@ -1562,10 +1663,11 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
         else GNBV_HITLIST(false);
 #undef GNBV_HITLIST
         if ((err = gnbv_launch_status())) return err;
-        if (mask_bytes > 64 * 1024 &&
-            hipFuncSetAttribute((const void *)k_ray_list, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mask_bytes) != hipSuccess)
+        const size_t ray_lds = mask_bytes;
+        if (ray_lds > 64 * 1024 &&
+            hipFuncSetAttribute((const void *)k_ray_list, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ray_lds) != hipSuccess)
             return (int)hipGetLastError();
-        hipLaunchKernelGGL(k_ray_list, dim3(env_groups * 8 * kListSlices), dim3(kListThreads), mask_bytes, st, ws.ray_count, ws.ray_list,
+        hipLaunchKernelGGL(k_ray_list, dim3(env_groups * 8 * kListSlices), dim3(kListThreads), ray_lds, st, ws.ray_count, ws.ray_list,
                            ws.ray_cap, poses_xyz, poses_row_stride, range_gt, voxel_size, n, g, words, ws.path);
         return gnbv_launch_status();
     }

@@ -60,6 +60,11 @@ print(f"update_occ_grid: {ms:.4f} ms/step  -> {a.n / ms * 1e3:.0f} env-steps/s (
 
 if a.phase_times:
     import numpy as np
+    nrb = ((a.n + 7) // 8) * 8 * 16
+    # one more step on a zeroed stamp area, so that every stamp belongs to the SAME launch
+    upd.workspace.view(torch.int32)[-(8 * 512 + 8 * nrb):].zero_()
+    upd.update(frames[0].depth_raw, frames[0].seg_raw, c2ws[0], poses[0], **kw)
+    torch.cuda.synchronize()
     nwg = a.n * max(1, (512 + a.n - 1) // a.n)
     tail = upd.workspace.view(torch.int32)[-8 * nwg:].cpu().numpy().reshape(nwg, 8)
     pa, pb, rays, t0 = tail[:, 0] / 100.0, tail[:, 1] / 100.0, tail[:, 2], tail[:, 3] / 100.0
@@ -69,3 +74,10 @@ if a.phase_times:
     print("  B pieces (mask store+popc | scans | emission): mean", (tail[:, 4:7] / 100.0).mean(0).round(1), " heaviest WG:", (tail[i, 4:7] / 100.0).round(1),
           "rays", rays[i], "its A", pa[i])
     print("  corr(A, rays)", np.corrcoef(pa, rays)[0, 1].round(2))
+
+    rt = upd.workspace.view(torch.int32)[-(8 * 512 + 8 * nrb):-8 * 512].cpu().numpy().reshape(nrb, 8)[::-1]
+    live = rt[rt[:, 5] == 1]
+    t0 = live[:, 0] / 100.0
+    print(f"k_ray_list phases over {len(live)} live workgroups of {nrb} (us): wave-0 walk mean {live[:, 1].mean() / 100:.1f} max {live[:, 1].max() / 100:.1f} | "
+          f"walk (all waves) mean {live[:, 2].mean() / 100:.1f} max {live[:, 2].max() / 100:.1f} | total mean {live[:, 3].mean() / 100:.1f} max {live[:, 3].max() / 100:.1f} | "
+          f"start spread {t0.max() - t0.min():.1f} | end spread {(t0 + live[:, 3] / 100.0).max() - t0.min():.1f}")
