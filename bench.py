@@ -449,6 +449,8 @@ def main():
                    "minibatches_last_iteration": int(len(algo.last_train_stats)) if getattr(algo, "last_train_stats", None) is not None else None,
                    "hbm_peak_allocated_gb": torch.cuda.max_memory_allocated(device) / 1e9,
                    "parallelism": f"env-sharded dp{world}", "dp_graph_mode": getattr(algo, "dp_graph_mode", None),
+                   "dp_update": (None if world == 1 else "fc_grid.weight reduce-scattered, updated by its owner rank, all-gathered; the rest all-reduced"
+                                 if getattr((algo._hip or {}).get("opt"), "shard", None) is not None else "whole gradient all-reduced, replicated update"),
                    "breakdown_ms_per_step": {"rollout": phases["rollout"].total_ms() / args.steps,
                                              "train": phases["train"].total_ms() / args.steps,
                                              "voxel_update_total": vox.total_ms() / args.steps}},

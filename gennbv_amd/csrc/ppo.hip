@@ -302,6 +302,8 @@ __global__ __launch_bounds__(256) void k_grad_sqnorm(const float *__restrict__ g
 __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
                             int64_t n, const double *__restrict__ partial, int nparts, const double *__restrict__ extra, int nextra,
                             float max_norm, float grad_scale, float *__restrict__ norm_out /*[2]: norm, applied factor*/,
+                            const float *__restrict__ coef_in /*NULL, or a [2] an earlier launch of this step wrote: use its factor*/,
+                            int64_t skip_lo, int64_t skip_hi /*elements [skip_lo, skip_hi) are left alone (another rank's shard)*/,
                             const int *__restrict__ stop_flag,
                             const int64_t *__restrict__ step /*already incremented*/, float lr, float beta1, float beta2, float eps,
                             const int64_t *__restrict__ rot_table = nullptr, int rot_rows = 0, int rot_len = 0, int64_t *__restrict__ rot_out = nullptr,
@@ -317,7 +319,10 @@ __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, 
     }
     if (stop_flag != nullptr && *stop_flag != 0) return;
     __shared__ double sh[256];
-    {
+    float coef;
+    if (coef_in != nullptr) {
+        coef = coef_in[1];
+    } else {
         double acc = 0.0;
         for (int i = threadIdx.x; i < nparts; i += 256) acc += partial[i];
         for (int i = threadIdx.x; i < nextra; i += 256) acc += extra[i];
@@ -327,14 +332,14 @@ __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, 
             if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
             __syncthreads();
         }
-    }
-    const float norm = (float)sqrt(sh[0]) * grad_scale;  // norm of the averaged gradient
-    float cf = max_norm > 0.f ? max_norm / (norm + 1e-6f) : 1.0f;
-    cf = cf > 1.0f ? 1.0f : cf;
-    const float coef = cf * grad_scale;  // factor applied to the raw (summed) gradient
-    if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out != nullptr) {
-        norm_out[0] = norm;
-        norm_out[1] = coef;
+        const float norm = (float)sqrt(sh[0]) * grad_scale;  // norm of the averaged gradient
+        float cf = max_norm > 0.f ? max_norm / (norm + 1e-6f) : 1.0f;
+        cf = cf > 1.0f ? 1.0f : cf;
+        coef = cf * grad_scale;  // factor applied to the raw (summed) gradient
+        if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out != nullptr) {
+            norm_out[0] = norm;
+            norm_out[1] = coef;
+        }
     }
     // bias corrections in double like torch's scalar path (1 - beta**step evaluated in Python floats)
     const double t = (double)(*step);
@@ -342,6 +347,7 @@ __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, 
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i >= skip_lo && i < skip_hi) continue;
         const float gi = g[i] * coef;
         const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);  // exp_avg.lerp_(grad, 1 - beta1)
         const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;  // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
@@ -475,8 +481,21 @@ GNBV_API int gnbv_clip_adam_step_ex(const GnbvAdamStep *a, void *stream)
     ab = ab > 2048 ? 2048 : ab;  // (8 workgroups per CU, all resident at once: the clip-coefficient prologue is paid once per CU slot)
     hipLaunchKernelGGL(k_adam_flat, dim3(ab), dim3(256), 0, st, a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->n, (const double *)partial, blocks,
                        sliced ? a->sq_partial : (const double *)nullptr, sliced ? a->sq_parts : 0, a->max_grad_norm, a->grad_scale, a->norm_out,
-                       (const int *)a->stop_flag, (const int64_t *)a->step, a->lr, a->beta1, a->beta2, a->eps, a->table, a->table_rows, a->row_len, a->out,
+                       (const float *)nullptr, a->upd_skip_lo, a->upd_skip_hi, (const int *)a->stop_flag, (const int64_t *)a->step, a->lr, a->beta1, a->beta2, a->eps, a->table, a->table_rows, a->row_len, a->out,
                        a->counter);
+    return gnbv_launch_status();
+}
+
+// The Adam update of a parameter SHARD (data-parallel replicas that own 1 / world of a large slice: gennbv_amd/parallel.py) with the
+// clip factor the step's main launch left in norm_out[1]; same step counter / stop flag.
+GNBV_API int gnbv_adam_shard_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const float *norm_out,
+                                  float lr, float beta1, float beta2, float eps, const int64_t *step, const int *stop_flag, void *stream)
+{
+    GNBV_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && norm_out && step && n > 0);
+    int ab = (int)((n + 255) / 256);
+    ab = ab > 2048 ? 2048 : ab;
+    hipLaunchKernelGGL(k_adam_flat, dim3(ab), dim3(256), 0, gnbv_stream(stream), params, grads, exp_avg, exp_avg_sq, n, (const double *)nullptr, 0,
+                       (const double *)nullptr, 0, 0.0f, 1.0f, (float *)nullptr, norm_out, (int64_t)0, (int64_t)0, stop_flag, step, lr, beta1, beta2, eps);
     return gnbv_launch_status();
 }
 

@@ -55,11 +55,12 @@ class FlatAdam:
         self.grads.zero_()
 
     def step(self, max_grad_norm: float, stop_flag: Optional[torch.Tensor] = None, grad_scale: float = 1.0,
-             kl_slot_target: Optional[float] = None, rotate=None, sq_slice=None):
+             kl_slot_target: Optional[float] = None, rotate=None, sq_slice=None, skip_update: bool = False):
         """grad_scale = 1/world and kl_slot_target = target_kl for the data-parallel tail.  rotate = (table [rows, len] int64,
         out [len] int64, counter [1] int32): the launch also leaves the next minibatch's row of `table` in `out`.
         sq_slice = (lo, hi, partial fp64 tensor): sum(grad[lo:hi]^2) was left in `partial` by the kernel that produced that
-        gradient slice (gnbv_linear_bwd_dw_sq) -- the norm pass skips the slice.  (include/gennbv_hip.h: GnbvAdamStep)"""
+        gradient slice (gnbv_linear_bwd_dw_sq) -- the norm pass skips the slice; `skip_update`: nor is the slice updated here (its
+        update is sharded over the data-parallel ranks: shard_step).  (include/gennbv_hip.h: GnbvAdamStep)"""
         a = _lib.GnbvAdamStep()
         a.params, a.grads, a.exp_avg, a.exp_avg_sq, a.n = (self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
                                                            self.exp_avg_sq.data_ptr(), self.n)
@@ -79,7 +80,46 @@ class FlatAdam:
             lo, hi, part = sq_slice
             assert part.dtype == torch.float64 and part.is_contiguous() and 0 <= lo < hi <= self.n
             a.sq_lo, a.sq_hi, a.sq_partial, a.sq_parts = int(lo), int(hi), part.data_ptr(), int(part.numel())
+            if skip_update:
+                a.upd_skip_lo, a.upd_skip_hi = int(lo), int(hi)
         _lib.check(self.lib.gnbv_clip_adam_step_ex(C.byref(a), _lib.stream_ptr(self.params.device)), "gnbv_clip_adam_step_ex")
+
+    # ---- data-parallel replicas: the update of one large slice sharded over the ranks (gennbv_amd/parallel.py) ----
+    def enable_shard(self, lo: int, hi: int, rank: int, world: int) -> bool:
+        """Rank `rank` of `world` owns parameters [lo + rank * sh, lo + (rank + 1) * sh), sh = (hi - lo) / world, of the slice
+        [lo, hi): it receives that shard of the summed gradient (reduce-scatter), keeps Adam moments for it only, updates it and
+        all-gathers the slice.  False (nothing changes) when the slice does not divide evenly."""
+        if (hi - lo) % world or world < 1:
+            return False
+        sh = (hi - lo) // world
+        dev = self.params.device
+        self.shard = {"lo": lo, "hi": hi, "sh": sh, "rank": rank, "world": world,
+                      "grad": torch.zeros(sh, dtype=torch.float32, device=dev),
+                      "sq": torch.zeros(1, dtype=torch.float64, device=dev)}
+        return True
+
+    def gather_shard_state(self, group=None) -> None:
+        """Adam moments of the sharded slice from their owners into every rank's flat buffers (checkpoints: torch_state_dict)."""
+        s = getattr(self, "shard", None)
+        if s is None or s["world"] <= 1:
+            return
+        import torch.distributed as dist
+        _, m, v = self.shard_views()
+        dist.all_gather_into_tensor(self.exp_avg[s["lo"]:s["hi"]], m, group=group)
+        dist.all_gather_into_tensor(self.exp_avg_sq[s["lo"]:s["hi"]], v, group=group)
+
+    def shard_views(self):
+        s = self.shard
+        a = s["lo"] + s["rank"] * s["sh"]
+        return self.params[a:a + s["sh"]], self.exp_avg[a:a + s["sh"]], self.exp_avg_sq[a:a + s["sh"]]
+
+    def shard_step(self, stop_flag: Optional[torch.Tensor] = None):
+        """Adam on this rank's shard from `shard["grad"]` with the clip factor the main step() of this optimizer step computed."""
+        p, m, v = self.shard_views()
+        _lib.check(self.lib.gnbv_adam_shard_step(p.data_ptr(), self.shard["grad"].data_ptr(), m.data_ptr(), v.data_ptr(), int(self.shard["sh"]),
+                                                 self.norm_out.data_ptr(), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                                 self.step_count.data_ptr(), _lib.ptr(stop_flag), _lib.stream_ptr(self.params.device)),
+                   "gnbv_adam_shard_step")
 
     def slice_of(self, param: torch.Tensor):
         """(lo, hi) of a parameter in the flat buffers, or None."""

@@ -484,8 +484,15 @@ typedef struct GnbvAdamStep {
     float *norm_out; void *workspace; size_t workspace_bytes;
     const int64_t *table; int table_rows, row_len; int64_t *out; int *counter;
     int64_t sq_lo, sq_hi; const double *sq_partial; int sq_parts;
+    int64_t upd_skip_lo, upd_skip_hi;   /* parameters [upd_skip_lo, upd_skip_hi) are NOT updated by this call (their gradient still
+                                           counts for the norm through sq_partial): a slice whose update is sharded over the
+                                           data-parallel replicas, gnbv_adam_shard_step */
 } GnbvAdamStep;
 int gnbv_clip_adam_step_ex(const GnbvAdamStep *a /*[host]*/, void *stream);
+/* Adam on a shard of n parameters with the clip factor norm_out[1] that gnbv_clip_adam_step_ex of the SAME optimizer step left
+ * behind (same step counter and stop flag, neither is modified). */
+int gnbv_adam_shard_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const float *norm_out,
+                         float lr, float beta1, float beta2, float eps, const int64_t *step, const int *stop_flag, void *stream);
 
 
 /* ------------------------------------------------------------------------- */

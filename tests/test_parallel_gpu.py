@@ -73,7 +73,7 @@ def _local_to_global(perm, rank):
     return (rank * N_LOCAL + perm // T) * T + perm % T
 
 
-def _worker(rank, path, port, target_kl, out):
+def _worker(rank, path, port, target_kl, out, shard=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     from gennbv_amd import parallel
@@ -82,9 +82,21 @@ def _worker(rank, path, port, target_kl, out):
     _fill(algo, blob, list(range(rank * N_LOCAL, (rank + 1) * N_LOCAL)))
     algo.rollout_buffer.indices = blob["perm"].copy()  # the same permutation on every rank, over its own rows
     algo.use_graph = False
+    algo.shard_update = shard
     parallel.attach(algo, WORLD)
     algo.train()
     assert algo.policy.features_extractor._dp_sync is not None and algo.policy.features_extractor.training
+    opt = algo._hip["opt"]
+    assert (getattr(opt, "shard", None) is not None) == shard
+    if shard:
+        # fc_grid.weight: reduce-scattered, updated by its owner, all-gathered; the Adam moments of the OTHER rank's half stay zero
+        # here and are complete after gather_shard_state (what get_parameters() / save() call)
+        sh = opt.shard
+        assert sh["hi"] - sh["lo"] == algo.policy.features_extractor.output_layer_grid[0].weight.numel() and sh["sh"] * WORLD == sh["hi"] - sh["lo"]
+        other = slice(sh["lo"] + (1 - rank) * sh["sh"], sh["lo"] + (2 - rank) * sh["sh"])
+        assert float(opt.exp_avg_sq[other].abs().max()) == 0.0 and float(opt.exp_avg_sq[sh["lo"]:sh["hi"]].abs().max()) > 0.0
+        sd = algo.get_parameters()["policy.optimizer"]
+        assert float(opt.exp_avg_sq[other].abs().max()) > 0.0 and len(sd["state"]) > 0
     vec = torch.cat([p.detach().reshape(-1) for p in algo.policy.parameters()])
     bn = torch.cat([b.detach().reshape(-1).float() for b in algo.policy.buffers()])
     both = [torch.zeros_like(vec) for _ in range(WORLD)]
@@ -104,8 +116,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("target_kl", [None, "auto"])
-def test_two_rank_fused_update_equals_the_global_batch_update(tmp_path, target_kl):
+@pytest.mark.parametrize("target_kl,shard", [(None, True), ("auto", True), (None, False)])
+def test_two_rank_fused_update_equals_the_global_batch_update(tmp_path, target_kl, shard):
     from gennbv_amd.env import synthetic as S
     from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
     torch.manual_seed(0)
@@ -149,7 +161,7 @@ def test_two_rank_fused_update_equals_the_global_batch_update(tmp_path, target_k
     want_bn = torch.cat([b.detach().reshape(-1).float() for b in ref.policy.buffers()]).cpu().numpy()
     steps = int(ref._hip["opt"].step_count.item())
     out = mp.Manager().dict()
-    mp.spawn(_worker, args=(path, _free_port(), target_kl, out), nprocs=WORLD, join=True)
+    mp.spawn(_worker, args=(path, _free_port(), target_kl, out, shard), nprocs=WORLD, join=True)
     assert out["identical"], "ranks diverged"
     assert out["steps"] == steps and len(out["stats"]) == len(stats)  # same early-stop position
     # the ranks log the terms of their own rows; the KL (col 3) they act on is the global mean: check it through the stop position,

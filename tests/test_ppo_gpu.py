@@ -134,11 +134,14 @@ def test_flat_adam_matches_torch_adam_with_clipping():
         torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("name", ["F9_ppo_train", "F9_ppo_train_earlystop"])
-def test_data_parallel_code_path_on_one_gpu(name):
+@pytest.mark.parametrize("name,shard", [("F9_ppo_train", False), ("F9_ppo_train_earlystop", False), ("F9_ppo_train", True), ("F9_ppo_train_earlystop", True)])
+def test_data_parallel_code_path_on_one_gpu(name, shard, monkeypatch):
     """The multi-GPU branch (graph body -> RCCL all-reduce of the flat gradient + KL slot -> clip/Adam
-    tail with the global KL decision) with a one-rank NCCL communicator must reproduce the goldens."""
+    tail with the global KL decision) with a one-rank NCCL communicator must reproduce the goldens.
+    shard: the sharded update of fc_grid.weight (reduce-scatter -> owner's Adam -> all-gather, GENNBV_FORCE_SHARD=1 makes the one
+    rank its only owner) -- the RCCL reduce_scatter / all_gather calls captured in the minibatch hipGraph."""
     import os
+    monkeypatch.setenv("GENNBV_FORCE_SHARD", "1" if shard else "0")
     import torch.distributed as dist
     from gennbv_amd import parallel
     if not dist.is_initialized():
@@ -149,6 +152,9 @@ def test_data_parallel_code_path_on_one_gpu(name):
     ppo = _ppo_from_fixture(fx, device=DEV, backend="hip")
     parallel.attach(ppo, 1, always_sync=True)
     _check(ppo, fx)
+    assert (getattr(ppo._hip["opt"], "shard", None) is not None) == shard
+    if shard:
+        assert ppo.dp_graph_mode == "one hipGraph incl. RCCL collectives", ppo.dp_graph_mode
 
 
 @pytest.mark.parametrize("dims", [(81, 81, 51, 1, 13, 13), (7, 5, 3, 1, 4, 2), (200, 1, 65)])  # the reference's action lattice first (81-way heads > one wave)
