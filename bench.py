@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--target-kl", default="off", help="'off' (default): the KL early stop of PPO_Grid_Obs.train (ppo_grid_obs.py:261-268) can never "
                     "trigger, so every timed iteration runs all n_epochs x minibatches (the check itself still runs on the device); "
                     "'ref': the reference's 0.05, under which a random-init policy on the synthetic feed stops some iterations early")
+    ap.add_argument("--semantic", action="store_true", help="BASELINE configs[2]: the opt-in semantic branch over the two gray frames "
+                    "(Hybrid_Encoder(semantic_branch=True): build-defined, the released reference never reads them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-tuning", action="store_true", help="enable TunableOp for library GEMMs (none is left on the timed path; "
                     "its warm-up injected ~15 k flush_icache launches)")
@@ -82,7 +84,8 @@ def build_algo(args, device, rank, world):
                                net_param={"transformer_params": [[1, 256], [1, 256]], "append_hidden_shapes": [256, 256]},
                                state_input_shape=(cfg.state_dim,),
                                visual_input_shape=(cfg.stack, cfg.camera_height, cfg.camera_width),
-                               compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)))
+                               compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32,
+                               **({"semantic_branch": True} if args.semantic and args.backend == "hip" else {}))))
     if world > 1 or os.environ.get("GENNBV_FORCE_DP") == "1":
         from gennbv_amd import parallel
         # GENNBV_FORCE_DP=1: run the data-parallel code path with a one-rank communicator (overhead check)
@@ -445,6 +448,7 @@ def main():
                                f"{args.grid}^3 grid, n_steps={args.n_steps}, batch_size={args.batch_size}, "
                                f"n_epochs={args.n_epochs}, one step = one PPO iteration",
                    "global_envs": world * args.envs, "encoder_backend": args.backend, "obs_rows": args.obs,
+                   "semantic_branch": bool(args.semantic),
                    "kl_early_stop": "reference (0.05)" if args.target_kl == "ref" else "never triggers (full work every iteration)",
                    "minibatches_last_iteration": int(len(algo.last_train_stats)) if getattr(algo, "last_train_stats", None) is not None else None,
                    "hbm_peak_allocated_gb": torch.cuda.max_memory_allocated(device) / 1e9,

@@ -54,7 +54,7 @@ class Hybrid_Encoder(nn.Module):
     backend = "hip"  # the only implementation of the product class (tests/torch_reference.py subclasses it as "torch")
 
     def __init__(self, observation_space, encoder_param=None, net_param=None, visual_input_shape=None,
-                 state_input_shape=None, grid_size: Optional[int] = None, compute_dtype=torch.float32):
+                 state_input_shape=None, grid_size: Optional[int] = None, compute_dtype=torch.float32, semantic_branch: bool = False):
         assert encoder_param is not None, "Need parameters !"
         assert net_param is not None, "Need parameters !"
         assert isinstance(visual_input_shape, (List, Tuple, list, tuple)), "Use tuple or list"
@@ -80,7 +80,18 @@ class Hybrid_Encoder(nn.Module):
         self.output_layer_grid = nn.Sequential(nn.Linear(self.grid_feat, 256), nn.ReLU(inplace=True))
         self.naive_encoder_action = nn.Sequential(nn.Linear(pose_feat, 256), nn.ReLU(inplace=True),
                                                   nn.Linear(256, 256), nn.ReLU(inplace=True))
-        self.output_layer = nn.Sequential(nn.Linear(512, 256), nn.ReLU(inplace=True))
+        # Semantic branch (BASELINE configs[2]) -- OPT-IN and BUILD-DEFINED: the released reference renders the two
+        # 64 x 64 gray frames into obs["state_rgb"] (env_train_base.py:517-520, env_train_gennbv.py:359-366) and its encoder never reads
+        # them (hybrid_encoder.py:76-98), so there is nothing to be equal to ("parity unpinned"); default off, and then the module
+        # tree / state_dict is the reference's.  On: the frames (x 1/255) are cut into 8 x 8 patches, every patch of both frames goes
+        # through Linear(128, 64) + ReLU (a strided Conv2d(2, 64, k8, s8) written as a GEMM), the 64 patch embeddings through
+        # Linear(4096, 256) + ReLU, and the 256 features join the pose and grid features in front of output_layer (768 inputs) --
+        # all on the split-K linear kernels of fc_grid (csrc/linear.hip).
+        self.semantic_branch = bool(semantic_branch)
+        if self.semantic_branch:
+            self.naive_encoder_rgb = nn.Sequential(nn.Linear(2 * 8 * 8, 64), nn.ReLU(inplace=True))
+            self.output_layer_rgb = nn.Sequential(nn.Linear(64 * 64, 256), nn.ReLU(inplace=True))
+        self.output_layer = nn.Sequential(nn.Linear(768 if self.semantic_branch else 512, 256), nn.ReLU(inplace=True))
         # 2**arange(2); kept on the module's device (not in the state_dict) so that the forward is
         # capturable in a hipGraph -- the reference re-creates and uploads it on every call (:71)
         self.register_buffer("_freq_bands", 2 ** torch.arange(2).float(), persistent=False)
@@ -125,9 +136,13 @@ class Hybrid_Encoder(nn.Module):
             sc = bn1.weight * torch.rsqrt(bn1.running_var + bn1.eps)
             z1 = sc.abs() * w1.abs().sum(1) + (sc * b1 + bn1.bias - bn1.running_mean * sc).abs()
             lin = [self.output_layer_grid[0]] + [m for m in self.naive_encoder_action if isinstance(m, nn.Linear)]
+            if self.semantic_branch:
+                lin += [self.naive_encoder_rgb[0], self.output_layer_rgb[0]]
             # the pose branch's second linear reads relu(W p + b) with |p| <= 1 (sin / cos): bounded by its rows' absolute sums
             pose = [m for m in self.naive_encoder_action if isinstance(m, nn.Linear)]
             xpose = (pose[0].weight.abs().sum(1) + pose[0].bias.abs()).max() if len(pose) > 1 else torch.zeros((), device=w1.device)
+            if self.semantic_branch:  # (same bound for the patch embeddings: inputs in 0 .. 1)
+                xpose = torch.maximum(xpose, (self.naive_encoder_rgb[0].weight.abs().sum(1) + self.naive_encoder_rgb[0].bias.abs()).max())
             vals = torch.stack([seq[3].weight.abs().max(), torch.stack([m.weight.abs().max() for m in lin]).max(), z1.max(), xpose,
                                 self._range_flag[0].float()]).cpu()
         w2max, wfcmax, z1max, xpmax, flag = (float(v) for v in vals)
@@ -145,6 +160,13 @@ class Hybrid_Encoder(nn.Module):
                 "above 1000); results since the last check may be clamped.  This encoder now runs on the fp32-MFMA kernels "
                 "(force_fp32): repeat the call.")
         return info
+
+    @staticmethod
+    def rgb_patches(rgb: torch.Tensor) -> torch.Tensor:
+        """[B, 2 * 64 * 64] gray frames (values 0 .. 255) -> [B * 64, 128]: patch (py, px) of both frames, scaled to 0 .. 1."""
+        b = rgb.shape[0]
+        x = rgb.reshape(b, 2, 8, 8, 8, 8).permute(0, 2, 4, 1, 3, 5)  # (b, c, py, iy, px, ix) -> (b, py, px, c, iy, ix)
+        return (x * (1.0 / 255.0)).reshape(b * 64, 128)
 
     def forward(self, observations) -> torch.Tensor:
         from ..ops import encoder_ops

@@ -357,8 +357,22 @@ def linear_relu(x: torch.Tensor, lin: torch.nn.Linear) -> torch.Tensor:
 
 def hybrid_forward(enc, observations) -> torch.Tensor:
     """Hybrid_Encoder.forward with the grid branch on the gfx950 kernels."""
-    feature_action, feature_grid = hybrid_branches(enc, observations)
+    feature_action, feature_grid = hybrid_branches(enc, observations)  # (feature_grid = [grid | semantic] with the opt-in branch)
     return enc.output_layer(torch.cat((feature_action, feature_grid), dim=-1))
+
+
+def semantic_features(enc, observations) -> torch.Tensor:
+    """The opt-in semantic branch (network/hybrid_encoder.py): two 64 x 64 gray frames -> [B, 256] on the linear kernels."""
+    s, g = enc.state_input_shape[0], enc.grid_size
+    if isinstance(observations, (RowGather, DenseObs)):
+        off = s if observations.compact_state_dim is not None else s + g ** 3
+        rgb = observations.base[:, off:off + 8192]
+        if observations.rows is not None:
+            rgb = rgb[observations.rows]
+    else:
+        rgb = observations[:, s + g ** 3:s + g ** 3 + 8192]
+    emb = linear_relu(enc.rgb_patches(rgb.float()).contiguous(), enc.naive_encoder_rgb[0])
+    return linear_relu(emb.reshape(rgb.shape[0], -1), enc.output_layer_rgb[0])
 
 
 def hybrid_branches(enc, observations):
@@ -406,6 +420,7 @@ def hybrid_branches(enc, observations):
         side.wait_stream(cur)  # the fork point; the pose kernels themselves are launched AFTER the grid branch (below)
     else:
         feature_action = pose_branch()
+        feature_sem = semantic_features(enc, observations) if getattr(enc, "semantic_branch", False) else None
     feature_grid = grid_encoder(base, rows, s, g, enc.naive_encoder_grid, enc.training, getattr(enc, "_bn_skip_flag", None),
                                 enc.compute_dtype == torch.bfloat16, getattr(enc, "_grad_write_through", False), grid_i8, compact, autocorr,
                                 getattr(enc, "_dp_sync", None), (getattr(enc, "force_fp32", False), getattr(enc, "_range_flag", None)))
@@ -422,8 +437,11 @@ def hybrid_branches(enc, observations):
         # paid a ~10 us cross-queue hand-over at the fork and again at the join (profiles/r02_notes.md).
         with torch.cuda.stream(side):
             feature_action = pose_branch()
+            feature_sem = semantic_features(enc, observations) if getattr(enc, "semantic_branch", False) else None
         torch.cuda.current_stream(base.device).wait_stream(side)
         feature_action.record_stream(torch.cuda.current_stream(base.device))
+        if feature_sem is not None:
+            feature_sem.record_stream(torch.cuda.current_stream(base.device))
         if getattr(enc, "_defer_pose_backward", False) and torch.is_grad_enabled() and feature_action.requires_grad:
             # The same rule for the backward: autograd would run (capture) the pose branch's backward BEFORE the grid branch's
             # (its nodes were created later).  Cut the graph at the branch output; the owner of the flag runs
@@ -434,6 +452,8 @@ def hybrid_branches(enc, observations):
             leaf.register_hook(lambda g, e=evt, d=base.device: e.record(torch.cuda.current_stream(d)))
             enc._pose_deferred = (feature_action, leaf, evt)
             feature_action = leaf
+    if feature_sem is not None:  # output_layer's columns: [pose | grid | semantic]
+        feature_grid = torch.cat((feature_grid, feature_sem), dim=-1)
     return feature_action, feature_grid
 
 

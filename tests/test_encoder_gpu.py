@@ -512,3 +512,48 @@ def test_fused_train_forward_vs_the_two_kernel_path(b, monkeypatch):
         for u, v in zip(a["grads"], c["grads"]):
             assert float((u - v).abs().max()) <= 2e-4 * float(v.abs().max()) + 2e-6 * top, (u.shape, float((u - v).abs().max()), float(v.abs().max()), top)
 
+
+
+@pytest.mark.parametrize("g,b", [(16, 8), (64, 4)])
+def test_semantic_branch_forward_backward_vs_fp64(g, b):
+    """SURVEY 8f.4 / BASELINE configs[2] (opt-in, build-defined: the released reference never reads obs["state_rgb"]): the two
+    64 x 64 gray frames -> 8 x 8 patch embeddings -> 256 features in front of output_layer (768 inputs), on the split-K linear
+    kernels and the fused policy head with K2 = 512.  Reference = the same modules in fp64 on the CPU; flat rows and gathered
+    compact rows; the default (branch off) keeps the reference's state_dict."""
+    from gennbv_amd.ops.encoder_ops import RowGather, input_autocorr
+    hip, _, _ = pu.make_policy(g=g, device=DEV, backend="hip", det_weights=False, semantic_branch=True)
+    ref, _, _ = pu.make_policy(g=g, device="cpu", backend="torch", det_weights=False, semantic_branch=True)
+    plain, _, _ = pu.make_policy(g=g, device="cpu", backend="torch", det_weights=False)
+    extra = set(ref.state_dict()) - set(plain.state_dict())
+    assert extra == {f"features_extractor.{k}" for k in ("naive_encoder_rgb.0.weight", "naive_encoder_rgb.0.bias", "output_layer_rgb.0.weight", "output_layer_rgb.0.bias")}
+    hip.load_state_dict({k: v.to(DEV) for k, v in ref.state_dict().items()})
+    ref = ref.double()
+    ref.extract_features = lambda x: ref.features_extractor(x)
+    obs = _obs_clear_of_the_relu_threshold(ref, b, g)  # (the grid branch does not see the gray frames: the probe stays valid)
+    gen = torch.Generator().manual_seed(g)
+    obs[:, 600 + g ** 3:] = (torch.rand(b, 8192, generator=gen) * 255.0).round().to(DEV)  # gray values as the env writes them
+    rows = torch.randperm(b, generator=gen).to(DEV)
+    actions = torch.stack([torch.randint(0, n, (b,), generator=gen) for n in pu.NVEC], -1).float()
+    w = torch.linspace(0.5, 1.5, b)
+    grid_i8 = obs[:, 600:600 + g ** 3].to(torch.int8).contiguous()
+    small = torch.cat((obs[:, :600], obs[:, 600 + g ** 3:]), 1).contiguous()
+    inputs = {"flat": obs[rows], "compact": RowGather(small, rows, grid_i8, 600, input_autocorr(grid_i8, g) if g % 16 == 0 else None)}
+    res = {}
+    for name, (pol, x, dev, dt) in {"ref": (ref, obs[rows].cpu().double(), "cpu", torch.float64), "flat": (hip, inputs["flat"], DEV, torch.float32),
+                                     "compact": (hip, inputs["compact"], DEV, torch.float32)}.items():
+        pol.set_training_mode(True)
+        pol.zero_grad()
+        values, log_prob, entropy = pol.evaluate_actions(x, actions.to(dev))
+        ww = w.to(dev, dt)
+        ((values.flatten() * ww).sum() + (log_prob * ww.flip(0)).sum() + 0.3 * (entropy * ww).sum()).backward()
+        res[name] = ([t.detach().double().cpu() for t in (values, log_prob, entropy)],
+                     {k: p.grad.detach().double().cpu().clone() for k, p in pol.named_parameters() if p.grad is not None})
+    for name in ("flat", "compact"):
+        for x, y in zip(res["ref"][0], res[name][0]):
+            assert float((x - y).abs().max()) <= 2e-5 * float(x.abs().max()) + 1e-6, name
+        for k, r in res["ref"][1].items():
+            scale = float(r.abs().max())
+            if scale > 1e-9 and ("rgb" in k or "output_layer." in k or "action_net" in k or "value_net" in k):
+                err = float((r - res[name][1][k]).abs().max())
+                assert err <= 2e-5 * scale, (name, k, err, scale)
+    assert float(res["ref"][1]["features_extractor.naive_encoder_rgb.0.weight"].abs().max()) > 0

@@ -24,6 +24,10 @@ class TorchHybridEncoder(Hybrid_Encoder):
         feature_action = self.naive_encoder_action(action_input)
         feature_grid = self.naive_encoder_grid(grid_input).reshape(num_env, -1)
         feature_grid = self.output_layer_grid(feature_grid)
+        if self.semantic_branch:  # (opt-in, build-defined: network/hybrid_encoder.py)
+            rgb = observations[:, s + g ** 3:s + g ** 3 + 8192]
+            emb = self.naive_encoder_rgb(self.rgb_patches(rgb)).reshape(num_env, -1)
+            return self.output_layer(torch.cat((feature_action, feature_grid, self.output_layer_rgb(emb)), dim=-1))
         return self.output_layer(torch.cat((feature_action, feature_grid), dim=-1))
 
 
