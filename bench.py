@@ -40,7 +40,9 @@ def parse():
     ap.add_argument("--n-epochs", type=int, default=5)
     ap.add_argument("--frames", type=int, default=8, help="frames in the synthetic feed pool")
     ap.add_argument("--backend", default="hip", choices=["hip", "torch"])
-    ap.add_argument("--dtype", default="fp32", choices=["fp32"])
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 (default, the headline): fp32-accurate arithmetic; bf16: the opt-in reduced-precision mode -- layer-1 activations "
+                         "stored as bf16, arithmetic in fp32 (flat rows only; PPO loss delta 1e-3-class, tests/test_ppo_gpu.py)")
     ap.add_argument("--obs", default="compact", choices=["flat", "compact"],
                     help="rollout-buffer rows: the reference's flat fp32 rows, or compact rows (grid as int8 only; same values)")
     ap.add_argument("--target-kl", default="off", help="'off' (default): the KL early stop of PPO_Grid_Obs.train (ppo_grid_obs.py:261-268) can never "
@@ -59,6 +61,8 @@ def parse():
 
 def build_algo(args, device, rank, world):
     import torch
+    if args.dtype == "bf16":
+        args.obs = "flat"  # (the bf16-storage kernels read the fp32 grid slice of flat rows)
     from gennbv_amd.env import synthetic as S
     from gennbv_amd.env.config import TaskConfig, PPOConfig
     from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
@@ -443,7 +447,7 @@ def main():
         "metric": "env-steps/sec at 256 envs x 64^3 grid (state encoding + policy forward + GAE + PPO update)",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.dtype == "fp32" else "f32 arithmetic, bf16 layer-1 activation storage (opt-in reduced-precision mode)", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: {args.envs} envs/GPU x {args.height}x{args.width} depth x "
                                f"{args.grid}^3 grid, n_steps={args.n_steps}, batch_size={args.batch_size}, "
                                f"n_epochs={args.n_epochs}, one step = one PPO iteration",

@@ -61,7 +61,7 @@ def test_policy_forward_eval_and_train_mode_vs_reference():
             np.testing.assert_allclose(v.numpy(), fx["bn_after/" + k], rtol=1e-6, atol=1e-6)
 
 
-def _ppo_from_fixture(fx, device="cpu", backend="torch"):
+def _ppo_from_fixture(fx, device="cpu", backend="torch", **enc_kw):
     from gennbv_amd.sb3.ppo_grid_obs import PPO_Grid_Obs
     from gennbv_amd.sb3.policies import ActorCriticPolicy_Train_Eval
     from tests.torch_reference import encoder_class
@@ -84,7 +84,7 @@ def _ppo_from_fixture(fx, device="cpu", backend="torch"):
                                               net_param={"transformer_params": [[1, 256], [1, 256]],
                                                          "append_hidden_shapes": [256, 256]},
                                               state_input_shape=(600,), visual_input_shape=(100, 400, 400),
-                                              grid_size=20)))
+                                              grid_size=20, **enc_kw)))
     shapes = {k: tuple(v.shape) for k, v in ppo.policy.state_dict().items()}
     ppo.policy.load_state_dict({k: torch.from_numpy(v).to(device) for k, v in gu.det_state_dict(shapes).items()})
     buf = ppo.rollout_buffer

@@ -344,3 +344,23 @@ def test_fused_rollout_add_equals_bootstrap_plus_add(first):
     for name in ("actions", "rewards", "episode_starts", "values", "log_probs"):
         assert torch.equal(getattr(bufs[0], name), getattr(bufs[1], name)), name
     assert bufs[1].step == t and bufs[1].full
+
+
+def test_reduced_precision_mode_bf16_activation_storage_loss_delta():
+    """BASELINE configs[1] names "PPO bf16", configs[4] "fp16 ... 3D conv".  The build's answer ("Precision"):
+    the default is fp32-ACCURATE arithmetic on the f16 matrix pipe (split operands), because reduced-precision storage moves the
+    PPO losses beyond north_star's 1e-4; the opt-in reduced-precision mode is `compute_dtype=torch.bfloat16` -- the layer-1
+    activations (y1 and its gradient, 2 x 244 MB per minibatch at G = 64) stored as bf16, all arithmetic in fp32 -- and THIS is its
+    stated tolerance against the reference's own train() (fixture F9: 12 optimizer steps at G = 20): every logged loss within 5e-3
+    (measured on MI355X: see the assertion message of a deliberately failing bound in profiles/r03_notes.md; the fp32 default
+    reproduces the same fixture to 2e-6)."""
+    fx = gu.load("F9_ppo_train")
+    ppo = _ppo_from_fixture(fx, device=DEV, backend="hip", compute_dtype=torch.bfloat16)
+    assert ppo.policy.features_extractor.compute_dtype == torch.bfloat16
+    ppo.train()
+    log = ppo.logger.name_to_value
+    keys = ("train/policy_gradient_loss", "train/value_loss", "train/entropy_loss", "train/loss", "train/approx_kl")
+    deltas = {k: abs(float(log[k]) - float(fx["log/" + k])) for k in keys}
+    print("bf16-storage mode, |delta| vs the reference's train():", deltas)
+    assert max(deltas.values()) <= 5e-3, deltas
+    assert max(deltas.values()) > 1e-7  # (the mode is on: fp32 storage lands at ~1e-6 and below)
