@@ -329,6 +329,9 @@ def encoder_roofline(algo, args, device, iters: int = 20):
                        "k_conv1_fwd_lds, k_conv2_fwd, k_conv2_wgrad, k_conv2_dgrad, k_conv1_wgrad_lds") +
                       " + BN / reduction launches)",
             "bound": "hbm" if split else "mfma",
+            "note": ("the split kernels stream at 3-4.5 TB/s each but are NOT byte-bound: letting the two backward kernels share y1 through L2 "
+                     "(GENNBV_BWD_DUAL=1) removed 184 MB of HBM reads per minibatch and no time (profiles/r03_notes.md); both roofs are context")
+                    if split else None,
             "ms": ms, "batch": b, "grid_input": "fp32 rows" if gi8 is None else "int8 copy", "algorithmic_flops": flops,
             "algorithmic_bytes": nbytes,
             "mfma": {"achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "dtype": "f32"},
