@@ -108,7 +108,7 @@ class GnbvEncoderParams(C.Structure):
                 ("eps", _f), ("momentum", _f), ("act_bf16", _i), ("grid_i8", _p), ("grid_i8_row_stride", _i64),
                 ("autocorr", _p), ("autocorr_row_stride", _i64),
                 ("world", _i), ("sync_sum", _p), ("sync_ctx", _p), ("sync_buf", _p), ("autocorr_global", _p),
-                ("force_fp32", _i), ("range_flag", _p)]
+                ("autocorr_total", _p), ("force_fp32", _i), ("range_flag", _p)]
 
 
 class GnbvAdamStep(C.Structure):

@@ -2249,7 +2249,10 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     // (conv_split.h) -- conv2 never reads the 244 MB it would otherwise fetch right after conv1 wrote them.
     fused_train = analytic && !qm && conv_split_path(p, grid) && grid == 64 && !env_off("GENNBV_CONV1_SPLIT") && !env_off("GENNBV_FUSED_TRAIN");
     if (analytic) {
-        hipLaunchKernelGGL(k_bn1_analytic, dim3(fused_train ? 9 : 1), dim3(1024), 0, st, (const int *)p->autocorr, p->autocorr_row_stride, rows, batch, p->w1,
+        // (the caller may hand over the minibatch's autocorrelation total: no gather then -- GnbvEncoderParams.autocorr_total)
+        const bool have_total = p->autocorr_total != nullptr && !dp;
+        hipLaunchKernelGGL(k_bn1_analytic, dim3(fused_train ? 9 : 1), dim3(1024), 0, st, have_total ? (const int *)p->autocorr_total : (const int *)p->autocorr,
+                           p->autocorr_row_stride, rows, have_total ? 0 : batch, p->w1,
                            p->b1, p->bn1_w, p->bn1_b, p->eps, p->momentum, p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag, bn1, bn1 + kC, bn1 + 2 * kC,
                            bn1 + 3 * kC, (int *)(bn_state + kBnStateFloats), dp ? (const int *)p->autocorr_global : (const int *)nullptr,
                            p->w2, w.w2img, p->range_flag);

@@ -143,6 +143,8 @@ def _params_struct(seq, act_bf16: bool = False, grid_i8: Optional[torch.Tensor] 
     # operand ranges of the split-f16 kernels (network/hybrid_encoder.py: check_operand_ranges): (force_fp32, range_flag tensor)
     p.force_fp32 = 0 if guard is None else int(bool(guard[0]))
     p.range_flag = None if guard is None or guard[1] is None else guard[1].data_ptr()
+    # (guard[2], optional: int32 [768] device tensor with the minibatch's autocorrelation total -- GnbvEncoderParams.autocorr_total)
+    p.autocorr_total = None if guard is None or len(guard) < 3 or guard[2] is None else guard[2].data_ptr()
     return p
 
 
@@ -217,7 +219,8 @@ def grid_encoder(base: torch.Tensor, rows: Optional[torch.Tensor], grid_off: int
                  guard=None) -> torch.Tensor:
     """seq = the `naive_encoder_grid` nn.Sequential (conv, bn, relu, conv, bn, relu).  `compact`: `base` rows carry
     no grid slice, the grid is read from `grid_i8` only.  `autocorr`: per-row input autocorrelation (input_autocorr).
-    `guard` = (force_fp32, range_flag int32 [1] or None): GnbvEncoderParams.force_fp32 / .range_flag."""
+    `guard` = (force_fp32, range_flag int32 [1] or None[, autocorr_total int32 [768] or None]): GnbvEncoderParams.force_fp32 /
+    .range_flag / .autocorr_total."""
     return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, bool(act_bf16), bool(write_through), grid_i8, bool(compact), autocorr, dp, guard, seq[0].weight, seq[0].bias,
                                 seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias)
 
@@ -423,7 +426,9 @@ def hybrid_branches(enc, observations):
         feature_sem = semantic_features(enc, observations) if getattr(enc, "semantic_branch", False) else None
     feature_grid = grid_encoder(base, rows, s, g, enc.naive_encoder_grid, enc.training, getattr(enc, "_bn_skip_flag", None),
                                 enc.compute_dtype == torch.bfloat16, getattr(enc, "_grad_write_through", False), grid_i8, compact, autocorr,
-                                getattr(enc, "_dp_sync", None), (getattr(enc, "force_fp32", False), getattr(enc, "_range_flag", None)))
+                                getattr(enc, "_dp_sync", None),
+                                (getattr(enc, "force_fp32", False), getattr(enc, "_range_flag", None),
+                                 getattr(enc, "_autocorr_total", None) if (enc.training and autocorr is not None) else None))
     if getattr(enc, "_split_backward", False) and torch.is_grad_enabled():
         # data-parallel: cut the autograd graph at the conv-stack output so that the backward runs in
         # two phases (late layers first, their gradient all-reduce overlaps the conv-stack backward)

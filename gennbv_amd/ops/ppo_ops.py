@@ -175,9 +175,11 @@ class PpoLossOp:
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=device)  # noqa: E731
         # [row numbers (batch) | (mean, 1 / (std + 1e-8)) of the minibatch's advantages as two fp32 in one int64 slot]: ONE buffer, so
         # that the row rotation of the replayed graph (FlatAdam.step(rotate=...)) delivers both
-        self.rows_ext = z(batch + 1, dt=torch.int64)
+        # ... | the sum of the minibatch's input-autocorrelation rows, 768 int32 (GnbvEncoderParams.autocorr_total)]
+        self.rows_ext = z(batch + 1 + 384, dt=torch.int64)
         self.rows = self.rows_ext[:batch]
-        self.adv_slot = self.rows_ext[batch:].view(torch.float32)
+        self.adv_slot = self.rows_ext[batch:batch + 1].view(torch.float32)
+        self.ac_slot = self.rows_ext[batch + 1:].view(torch.int32)
         self.actions, self.old_values, self.old_log_prob = z(batch, nh), z(batch), z(batch)
         self.advantages, self.returns = z(batch), z(batch)
         self.d_logits, self.d_values = z(batch, n_logits), z(batch)

@@ -555,15 +555,20 @@ class PPO_Grid_Obs:
         # replays.  (The table and the counter are baked into the graph: persistent buffers.)
         rotating = use_graph and not dp and n_mb > 0 and os.environ.get("GENNBV_ROTATE_ROWS", "1") != "0"
         rot = st.get("rows_rot")
-        if rotating and (rot is None or tuple(rot[0].shape) != (n_mb, batch + 1)):
-            # a table row = [the minibatch's row numbers | (mean, 1 / (std + 1e-8)) of its advantages], rotated into loss.rows_ext
-            rot = (torch.empty(n_mb, batch + 1, dtype=torch.int64, device=self.device), loss.rows_ext, torch.zeros(1, dtype=torch.int32, device=self.device))
+        if rotating and (rot is None or tuple(rot[0].shape) != (n_mb, batch + 1 + 384)):
+            # a table row = [the minibatch's row numbers | (mean, 1 / (std + 1e-8)) of its advantages | the sum of its input-autocorrelation
+            # rows], rotated into loss.rows_ext
+            rot = (torch.zeros(n_mb, batch + 1 + 384, dtype=torch.int64, device=self.device), loss.rows_ext, torch.zeros(1, dtype=torch.int32, device=self.device))
             st["rows_rot"], st["graph"] = rot, None
         elif not rotating and rot is not None:
             rot = st["rows_rot"] = None
             st["graph"] = None
         if not dp:
             loss.args.adv_norm = loss.adv_slot.data_ptr() if (rotating and self.normalize_advantage) else None
+        if not rotating:
+            self.policy.features_extractor._autocorr_total = None
+            if st.get("ac_total_on"):
+                st["graph"], st["ac_total_on"] = None, False
         if rotating:
             rot[0][:, :batch].copy_(rows_all[:n_mb * batch].view(n_mb, batch))
             if self.normalize_advantage:
@@ -572,7 +577,18 @@ class PPO_Grid_Obs:
                 # loss launch
                 adv = buf.advantages.view(-1)[rows_all[:n_mb * batch]].view(n_mb, batch)
                 stats = torch.stack((adv.mean(1), 1.0 / (adv.std(1) + 1e-8)), 1).contiguous()
-                rot[0][:, batch:].view(torch.float32).copy_(stats)
+                rot[0][:, batch:batch + 1].view(torch.float32).copy_(stats)
+            # BatchNorm-1's batch statistics come from the SUM of the minibatch's autocorrelation rows: one table per train() call
+            # instead of a gather of 128 scattered rows in front of every forward (k_bn1_analytic)
+            enc_ = self.policy.features_extractor
+            use_tot = buf.autocorr is not None and not dp
+            if use_tot:
+                ac_rows = buf.autocorr[:buf.buffer_size].view(buf.buffer_size * buf.n_envs, -1)
+                tot = ac_rows[rows_all[:n_mb * batch]].view(n_mb, batch, -1).sum(1, dtype=torch.int64)
+                rot[0][:, batch + 1:].view(torch.int32).copy_(tot.to(torch.int32))
+            if st.get("ac_total_on") != use_tot:
+                st["graph"], st["ac_total_on"] = None, use_tot  # (the pointer is a kernel argument baked into the graph)
+            enc_._autocorr_total = loss.ac_slot if use_tot else None  # (only for the duration of this call: cleared below)
             rot[2].zero_()
         if use_graph and st["graph"] is None:
             if rotating:
@@ -608,6 +624,7 @@ class PPO_Grid_Obs:
                     print(f"Early stopping at step {epoch} due to reaching max kl")
                 break
         self._n_updates += self.n_epochs
+        self.policy.features_extractor._autocorr_total = None  # (the slot holds the LAST minibatch's total: never for another caller)
         self._check_ranges()  # raises if a kernel of this call reached an activation bound of the split-f16 arithmetic
         rows_done = int(loss.stats_row.item())
         s = loss.stats[:rows_done].double().cpu().numpy()

@@ -268,6 +268,10 @@ typedef struct GnbvEncoderParams {
     /* ---- operand ranges of the split-f16 kernels (ABI 2).  At G = 64 the conv stack runs on the f16 matrix pipe with every
      * fp32 operand written as hi + lo f16 halves under fixed power-of-two scalings: relu(bn1(y1)) <= 253.9, |W2| < 63,
      * fc_grid inputs <= 1015, |W_fc| < 15.8.  Outside those ranges the split kernels would clamp, so: */
+    const int32_t *autocorr_total;/* NULL, or device [768]: the SUM of the minibatch's autocorrelation rows, computed by the caller (the
+                                     permutation is fixed for a whole train() call: one table for all its minibatches) -- the training
+                                     forward then skips its gather of `autocorr` rows (128 scattered 3 KiB rows, ~6 us of dependent
+                                     round trips on the update's critical path); `autocorr` must still be set (it selects the path) */
     int force_fp32;               /* 1: never take the split-f16 kernels (the fp32-MFMA kernels have no range limits); the host
                                      mirror sets it when a parameter pre-check finds a weight outside its range */
     int32_t *range_flag;          /* NULL, or a device word the kernels OR bits into when an ACTIVATION bound is reached:

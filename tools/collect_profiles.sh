@@ -8,8 +8,8 @@ cd $GRAFT_REPO_ROOT
 python bench.py --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_n1.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_k
-rocprofv3 --kernel-trace --stats -d /tmp/prof_k -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --n-steps 16 --no-cpu-baseline > /tmp/prof_k.log 2>&1
-echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 --n-steps 16 --no-cpu-baseline" > $OUT/bench_kernel_trace.txt
+rocprofv3 --kernel-trace --stats -d /tmp/prof_k -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --n-steps 16 --no-cpu-baseline --no-flat-rows --no-state-check > /tmp/prof_k.log 2>&1
+echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 --n-steps 16 --no-cpu-baseline --no-flat-rows --no-state-check" > $OUT/bench_kernel_trace.txt
 python $GRAFT_REPO_ROOT/tools/rocprof_summary.py /tmp/prof_k >> $OUT/bench_kernel_trace.txt
 # one PPO minibatch / one rollout step as timelines (same trace)
 python $GRAFT_REPO_ROOT/tools/rocprof_timeline.py /tmp/prof_k 600 k_ppo_fused > $OUT/minibatch_timeline.txt
