@@ -70,6 +70,7 @@ SIGNATURES = {
     "gnbv_policy_head_backward": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnbv_gather_minibatch": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnbv_ppo_loss": (_i, [_p, _p]),
+    "gnbv_ppo_loss_finish": (_i, [_p, _p]),
     "gnbv_multicategorical_sample": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p, _p]),
     "gnbv_ppo_loss_rsl": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _f, _f, _i, _p, _p, _p, _p, _p]),
     "gnbv_adam_workspace_bytes": (_sz, []),
@@ -118,7 +119,7 @@ class GnbvAdamStep(C.Structure):
                 ("step", _p), ("stop_flag", _p), ("grad_scale", _f), ("kl_slot", _p), ("target_kl", _f),
                 ("norm_out", _p), ("workspace", _p), ("workspace_bytes", _sz),
                 ("table", _p), ("table_rows", _i), ("row_len", _i), ("out", _p), ("counter", _p),
-                ("sq_lo", _i64), ("sq_hi", _i64), ("sq_partial", _p), ("sq_parts", _i), ("upd_skip_lo", _i64), ("upd_skip_hi", _i64)]
+                ("sq_lo", _i64), ("sq_hi", _i64), ("sq_partial", _p), ("sq_parts", _i), ("loss_finish", _p), ("upd_skip_lo", _i64), ("upd_skip_hi", _i64)]
 
 
 class GnbvEncoderGrads(C.Structure):
@@ -134,7 +135,7 @@ class GnbvPpoLoss(C.Structure):
                 ("logits", _p), ("values", _p), ("actions", _p), ("old_values", _p), ("old_log_prob", _p),
                 ("advantages", _p), ("returns", _p), ("d_logits", _p), ("d_values", _p), ("head_entropy", _p),
                 ("head_lse", _p), ("stats", _p), ("stats_row", _p), ("stop_flag", _p), ("scratch", _p), ("kl_out", _p),
-                ("rows", _p), ("adv_norm", _p)]
+                ("rows", _p), ("adv_norm", _p), ("defer_stats", _i)]
 
 
 class GennbvHipError(RuntimeError):

@@ -70,6 +70,37 @@ __device__ __forceinline__ HeadStats head_stats(const float *lg, int n, int lane
     return {lse, -pe};
 }
 
+// The minibatch's logged scalars from the per-sample terms k_ppo_fused left in `terms` ([B][8]), added in a fixed order by ONE
+// workgroup of kLossThreads threads; writes the statistics row, takes the KL early-stop decision (ppo_grid_obs.py:261-268) and --
+// `step` != NULL: the caller is the optimizer's norm launch -- counts the optimizer step unless the update is masked.
+__device__ void ppo_stats_finish(const GnbvPpoLoss &a, const float *__restrict__ terms, float *scratch /*LDS, kLossThreads / 64 + 1*/, int64_t *step)
+{
+    const int B = a.batch, tid = threadIdx.x;
+    const float invB = 1.0f / (float)B;
+    float pg = 0.f, vl = 0.f, en = 0.f, kl = 0.f, cf = 0.f;
+    for (int j = tid; j < B; j += kLossThreads) {
+        const volatile float *t = terms + (size_t)j * 8;
+        pg += t[0]; vl += t[1]; en += t[2]; kl += t[3]; cf += t[4];
+    }
+    pg = block_sum<kLossThreads>(pg, scratch) * invB;
+    vl = block_sum<kLossThreads>(vl, scratch) * invB;
+    en = block_sum<kLossThreads>(en, scratch) * invB;
+    kl = block_sum<kLossThreads>(kl, scratch) * invB;
+    cf = block_sum<kLossThreads>(cf, scratch) * invB;
+    if (tid == 0) {
+        const float loss = pg * a.policy_scale + a.ent_coef * en + a.vf_coef * vl;
+        const int stopped_before = a.stop_flag ? *a.stop_flag : 0;
+        float *row = a.stats + (size_t)(*a.stats_row) * 8;
+        row[0] = pg; row[1] = vl; row[2] = en; row[3] = kl; row[4] = cf; row[5] = loss;
+        row[6] = stopped_before ? 0.f : 1.f;  // live row (the reference never ran this minibatch otherwise)
+        row[7] = 0.f;
+        *a.stats_row += 1;
+        if (a.kl_out) *a.kl_out = kl;  // data-parallel: the decision is taken on the global mean after the all-reduce
+        else if (a.stop_flag && a.target_kl > 0.f && kl > 1.5f * a.target_kl) *a.stop_flag = 1;  // sticky (:264-268)
+        if (step != nullptr && !(a.stop_flag != nullptr && *a.stop_flag != 0)) *step += 1;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // ONE launch: a wave per sample computes the head statistics once and uses them for the log-prob, the entropy AND the
 // logit gradient (three launches recomputed them twice and paid two extra launch latencies on the update's critical path:
@@ -171,6 +202,7 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_fused(GnbvPpoLoss a, float
             }
         }
     }
+    if (a.defer_stats) return;  // (the caller adds the terms up later: ppo_stats_finish inside the optimizer's norm launch)
     // ---- the workgroup that finishes last adds the per-sample terms (fixed order: deterministic) ----
     __syncthreads();  // (every wave's stores have left the CU: s_waitcnt vmcnt(0) + barrier)
     if (tid == 0) {
@@ -180,28 +212,8 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_fused(GnbvPpoLoss a, float
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    float pg = 0.f, vl = 0.f, en = 0.f, kl = 0.f, cf = 0.f;
-    for (int j = tid; j < B; j += kLossThreads) {
-        const volatile float *t = terms + (size_t)j * 8;
-        pg += t[0]; vl += t[1]; en += t[2]; kl += t[3]; cf += t[4];
-    }
-    pg = block_sum<kLossThreads>(pg, scratch) * invB;
-    vl = block_sum<kLossThreads>(vl, scratch) * invB;
-    en = block_sum<kLossThreads>(en, scratch) * invB;
-    kl = block_sum<kLossThreads>(kl, scratch) * invB;
-    cf = block_sum<kLossThreads>(cf, scratch) * invB;
-    if (tid == 0) {
-        *counter = 0;  // ready for the next call
-        const float loss = pg * a.policy_scale + a.ent_coef * en + a.vf_coef * vl;
-        const int stopped_before = a.stop_flag ? *a.stop_flag : 0;
-        float *row = a.stats + (size_t)(*a.stats_row) * 8;
-        row[0] = pg; row[1] = vl; row[2] = en; row[3] = kl; row[4] = cf; row[5] = loss;
-        row[6] = stopped_before ? 0.f : 1.f;  // live row (the reference never ran this minibatch otherwise)
-        row[7] = 0.f;
-        *a.stats_row += 1;
-        if (a.kl_out) *a.kl_out = kl;  // data-parallel: the decision is taken on the global mean after the all-reduce
-        else if (a.stop_flag && a.target_kl > 0.f && kl > 1.5f * a.target_kl) *a.stop_flag = 1;  // sticky (:264-268)
-    }
+    if (tid == 0) *counter = 0;  // ready for the next call
+    ppo_stats_finish(a, terms, scratch, nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -258,9 +270,34 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_loss_rsl(int B, const floa
 // single-workgroup finalize launch between this kernel and the update: the data-parallel KL decision and the optimizer step
 // counter, both final before the Adam launch starts.
 __global__ __launch_bounds__(256) void k_grad_sqnorm(const float *__restrict__ g, int64_t n_eff, int64_t lo, int64_t gap, double *__restrict__ partial,
-                                                     float grad_scale, int64_t *step, int *stop_flag, const float *kl_slot, float target_kl)
+                                                     float grad_scale, int64_t *step, int *stop_flag, const float *kl_slot, float target_kl,
+                                                     int nblocks /*norm blocks; then, if launched: one block that folds `extra`, one that finishes the loss*/,
+                                                     const double *__restrict__ extra, int nextra, int fin_block, GnbvPpoLoss fin)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && step != nullptr) {
+    static_assert(kLossThreads == 256, "the finish block is one loss workgroup");
+    if (extra != nullptr && (int)blockIdx.x == nblocks) {
+        // the producer's partial sums of the skipped slice (gnbv_linear_bwd_dw_sq: 844 of them) folded into ONE more partial here,
+        // so that the update's workgroups re-add ~200 numbers each instead of ~1040 (that prologue cost the Adam launch 5-10 us)
+        __shared__ double se[256];
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < nextra; i += 256) acc += extra[i];
+        se[threadIdx.x] = acc;
+        __syncthreads();
+        for (int d = 128; d > 0; d >>= 1) {
+            if (threadIdx.x < d) se[threadIdx.x] += se[threadIdx.x + d];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partial[nblocks] = se[0];
+        return;
+    }
+    if ((int)blockIdx.x == fin_block) {
+        // (same launch, independent work) the loss kernel left its per-sample terms behind (GnbvPpoLoss.defer_stats): the logged
+        // scalars, the KL stop decision and -- in the SAME thread, after that decision -- the optimizer step counter
+        __shared__ float fscratch[kLossThreads / 64 + 1];
+        ppo_stats_finish(fin, fin.scratch, fscratch, step);
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && step != nullptr && fin_block < 0) {
         // kl_slot holds the SUM of the ranks' approx-KL (it rode in front of the gradient in the all-reduce); sets the sticky
         // stop flag before this step's update
         if (stop_flag != nullptr && kl_slot != nullptr && target_kl > 0.f && (*kl_slot) * grad_scale > 1.5f * target_kl) *stop_flag = 1;
@@ -269,7 +306,7 @@ __global__ __launch_bounds__(256) void k_grad_sqnorm(const float *__restrict__ g
     double acc = 0.0;
     const bool vec = (((uintptr_t)g & 15) == 0) && (lo & 3) == 0 && (gap & 3) == 0;
     const int64_t n4 = vec ? n_eff / 4 : 0, lo4 = lo / 4, gap4 = gap / 4;
-    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t stride = (int64_t)nblocks * 256;
     for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride) {
         float4 v[4];
 #pragma unroll
@@ -448,6 +485,19 @@ GNBV_API int gnbv_ppo_loss(const GnbvPpoLoss *a, void *stream)
     return gnbv_launch_status();
 }
 
+__global__ __launch_bounds__(kLossThreads) void k_ppo_stats_finish(GnbvPpoLoss a)
+{
+    __shared__ float fscratch[kLossThreads / 64 + 1];
+    ppo_stats_finish(a, a.scratch, fscratch, nullptr);
+}
+
+GNBV_API int gnbv_ppo_loss_finish(const GnbvPpoLoss *a, void *stream)
+{
+    GNBV_CHECK_ARG(a && a->defer_stats && a->batch > 1 && a->scratch && a->stats && a->stats_row);
+    hipLaunchKernelGGL(k_ppo_stats_finish, dim3(1), dim3(kLossThreads), 0, gnbv_stream(stream), *a);
+    return gnbv_launch_status();
+}
+
 GNBV_API int gnbv_ppo_loss_rsl(int batch, const float *log_prob, const float *old_log_prob, const float *advantages, const float *values,
                                const float *target_values, const float *returns, float clip_param, float value_loss_coef,
                                float entropy_coef, int use_clipped_value_loss, float *d_log_prob, float *d_values, float *d_entropy,
@@ -461,7 +511,7 @@ GNBV_API int gnbv_ppo_loss_rsl(int batch, const float *log_prob, const float *ol
     return gnbv_launch_status();
 }
 
-GNBV_API size_t gnbv_adam_workspace_bytes(void) { return 1024 * sizeof(double) + 64; }
+GNBV_API size_t gnbv_adam_workspace_bytes(void) { return 1026 * sizeof(double) + 64; }
 
 GNBV_API int gnbv_clip_adam_step_ex(const GnbvAdamStep *a, void *stream)
 {
@@ -475,12 +525,23 @@ GNBV_API int gnbv_clip_adam_step_ex(const GnbvAdamStep *a, void *stream)
     const int64_t gap = sliced ? a->sq_hi - a->sq_lo : 0, n_eff = a->n - gap;
     int blocks = (int)((n_eff + 256 * 16 - 1) / (256 * 16));
     blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
-    hipLaunchKernelGGL(k_grad_sqnorm, dim3(blocks), dim3(256), 0, st, a->grads, n_eff, sliced ? a->sq_lo : a->n, gap, partial, a->grad_scale,
-                       a->step, a->stop_flag, a->kl_slot, a->target_kl);
+    GnbvPpoLoss fin = {};
+    const bool finish = a->loss_finish != nullptr;
+    if (finish) {
+        fin = *a->loss_finish;
+        GNBV_CHECK_ARG(fin.defer_stats && fin.scratch && fin.stats && fin.stats_row && fin.kl_out == nullptr && fin.stop_flag == a->stop_flag);
+    }
+    const int fold = sliced ? 1 : 0, fin_block = finish ? blocks + fold : -1;
+    hipLaunchKernelGGL(k_grad_sqnorm, dim3(blocks + fold + (finish ? 1 : 0)), dim3(256), 0, st, a->grads, n_eff, sliced ? a->sq_lo : a->n, gap, partial,
+                       a->grad_scale, a->step, a->stop_flag, a->kl_slot, a->target_kl, blocks, sliced ? a->sq_partial : (const double *)nullptr,
+                       sliced ? a->sq_parts : 0, fin_block, fin);
     int ab = (int)((a->n + 255) / 256);
-    ab = ab > 2048 ? 2048 : ab;  // (8 workgroups per CU, all resident at once: the clip-coefficient prologue is paid once per CU slot)
-    hipLaunchKernelGGL(k_adam_flat, dim3(ab), dim3(256), 0, st, a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->n, (const double *)partial, blocks,
-                       sliced ? a->sq_partial : (const double *)nullptr, sliced ? a->sq_parts : 0, a->max_grad_norm, a->grad_scale, a->norm_out,
+#ifndef GNBV_ADAM_BLOCKS
+#define GNBV_ADAM_BLOCKS 8192  // (same-call A/B of the whole bench: 2048 workgroups +5 us per minibatch, 4096 +1-2 us)
+#endif
+    ab = ab > GNBV_ADAM_BLOCKS ? GNBV_ADAM_BLOCKS : ab;
+    hipLaunchKernelGGL(k_adam_flat, dim3(ab), dim3(256), 0, st, a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->n, (const double *)partial, blocks + fold,
+                       (const double *)nullptr, 0, a->max_grad_norm, a->grad_scale, a->norm_out,
                        (const float *)nullptr, a->upd_skip_lo, a->upd_skip_hi, (const int *)a->stop_flag, (const int64_t *)a->step, a->lr, a->beta1, a->beta2, a->eps, a->table, a->table_rows, a->row_len, a->out,
                        a->counter);
     return gnbv_launch_status();

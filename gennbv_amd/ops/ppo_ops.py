@@ -55,7 +55,7 @@ class FlatAdam:
         self.grads.zero_()
 
     def step(self, max_grad_norm: float, stop_flag: Optional[torch.Tensor] = None, grad_scale: float = 1.0,
-             kl_slot_target: Optional[float] = None, rotate=None, sq_slice=None, skip_update: bool = False):
+             kl_slot_target: Optional[float] = None, rotate=None, sq_slice=None, skip_update: bool = False, loss_finish=None):
         """grad_scale = 1/world and kl_slot_target = target_kl for the data-parallel tail.  rotate = (table [rows, len] int64,
         out [len] int64, counter [1] int32): the launch also leaves the next minibatch's row of `table` in `out`.
         sq_slice = (lo, hi, partial fp64 tensor): sum(grad[lo:hi]^2) was left in `partial` by the kernel that produced that
@@ -82,6 +82,8 @@ class FlatAdam:
             a.sq_lo, a.sq_hi, a.sq_partial, a.sq_parts = int(lo), int(hi), part.data_ptr(), int(part.numel())
             if skip_update:
                 a.upd_skip_lo, a.upd_skip_hi = int(lo), int(hi)
+        if loss_finish is not None:  # a GnbvPpoLoss with defer_stats = 1 (PpoLossOp.args): its statistics are finished inside the norm launch
+            a.loss_finish = C.addressof(loss_finish)
         _lib.check(self.lib.gnbv_clip_adam_step_ex(C.byref(a), _lib.stream_ptr(self.params.device)), "gnbv_clip_adam_step_ex")
 
     # ---- data-parallel replicas: the update of one large slice sharded over the ranks (gennbv_amd/parallel.py) ----
@@ -202,6 +204,7 @@ class PpoLossOp:
         a.stats, a.stats_row, a.stop_flag = self.stats.data_ptr(), self.stats_row.data_ptr(), self.stop_flag.data_ptr()
         self.scratch = z(8 * batch + 64)  # per-sample terms + the completion counter (zero-initialised once)
         a.adv_norm = None
+        a.defer_stats = 0
         a.scratch = self.scratch.data_ptr()
         self.args = a
         self.device = device

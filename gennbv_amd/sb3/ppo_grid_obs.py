@@ -330,6 +330,9 @@ class PPO_Grid_Obs:
             # the rank's approx-KL rides in the slot behind the flat gradient; the flag is set from
             # the GLOBAL mean after the all-reduce (gnbv_clip_adam_step), not by the loss kernel
             loss.args.kl_out = opt.kl_slot.data_ptr()
+        # one GPU: the loss launch leaves its per-sample terms behind and the optimizer's norm launch adds them up in passing (no release
+        # fence + ticket per loss workgroup on the critical path); data-parallel: the KL must exist before the gradient exchange
+        loss.args.defer_stats = 0 if (self._sync is not None and self._sync.active) else 1
         self.policy.features_extractor._bn_skip_flag = loss.stop_flag
         # (GENNBV_FORCE_SHARD=1: also with a one-rank communicator -- the captured reduce-scatter / all-gather code path on one GPU)
         if (self._sync is not None and self._sync.active and (self._sync.world > 1 or os.environ.get("GENNBV_FORCE_SHARD") == "1")
@@ -432,7 +435,8 @@ class PPO_Grid_Obs:
                 encoder_ops.join_async_wgrads(self.device)  # fc_grid's dW / db: second stream, beside the conv backward
                 if self._sync is None or not self._sync.active:
                     sq = st.get("sq_slice") if (lin is not None and getattr(lin, "_dw_sq_written", False)) else None
-                    opt.step(self.max_grad_norm, loss.stop_flag, rotate=st.get("rows_rot"), sq_slice=sq)
+                    opt.step(self.max_grad_norm, loss.stop_flag, rotate=st.get("rows_rot"), sq_slice=sq,
+                             loss_finish=loss.args if loss.args.defer_stats else None)
                 return
             # the forward cut the graph at the conv-stack output (enc._split_backward): this backward
             # stops at that leaf and fills the gradients of every non-conv parameter

@@ -432,9 +432,15 @@ typedef struct GnbvPpoLoss {
     const float *adv_norm;      /* NULL: the minibatch's own advantage mean / unbiased std (ppo_grid_obs.py:214-216);
                                    or [2] = (mean, 1 / (std + 1e-8)) of the GLOBAL minibatch (data-parallel replicas:
                                    the statistics of all ranks' rows, gennbv_amd/parallel.py) */
+    int defer_stats;            /* 0: gnbv_ppo_loss also writes the statistics row and takes the KL stop decision (its last workgroup:
+                                   a release fence + a ticket per workgroup on the update's critical path).  1: it only leaves the
+                                   per-sample terms in `scratch`; the caller finishes them with gnbv_ppo_loss_finish, or -- no launch
+                                   of its own -- inside gnbv_clip_adam_step_ex (GnbvAdamStep.loss_finish), before the update reads
+                                   the stop flag.  Not with kl_out (the data-parallel KL must exist before the gradient exchange). */
 } GnbvPpoLoss;
 
 int gnbv_ppo_loss(const GnbvPpoLoss *args /*[host]*/, void *stream);
+int gnbv_ppo_loss_finish(const GnbvPpoLoss *args /*[host]; defer_stats == 1*/, void *stream);
 
 /* C5  rollout side of MultiCategoricalDistribution (stable_baselines3/common/distributions.py:299-352 via
  *     ActorCriticPolicy.forward, policies.py:1024-1030): actions[b][h] ~ Categorical(softmax(logits_h[b])) by
@@ -488,6 +494,9 @@ typedef struct GnbvAdamStep {
     float *norm_out; void *workspace; size_t workspace_bytes;
     const int64_t *table; int table_rows, row_len; int64_t *out; int *counter;
     int64_t sq_lo, sq_hi; const double *sq_partial; int sq_parts;
+    const GnbvPpoLoss *loss_finish;     /* NULL, or [host] the loss arguments of this minibatch with defer_stats = 1: an extra workgroup
+                                           of the norm launch adds up its per-sample terms (statistics row, KL stop decision, then the
+                                           step counter) -- same stop_flag as this call's */
     int64_t upd_skip_lo, upd_skip_hi;   /* parameters [upd_skip_lo, upd_skip_hi) are NOT updated by this call (their gradient still
                                            counts for the norm through sq_partial): a slice whose update is sharded over the
                                            data-parallel replicas, gnbv_adam_shard_step */

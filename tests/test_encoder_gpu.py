@@ -521,6 +521,7 @@ def test_semantic_branch_forward_backward_vs_fp64(g, b):
     kernels and the fused policy head with K2 = 512.  Reference = the same modules in fp64 on the CPU; flat rows and gathered
     compact rows; the default (branch off) keeps the reference's state_dict."""
     from gennbv_amd.ops.encoder_ops import RowGather, input_autocorr
+    torch.manual_seed(1000 + g)  # (random initialisation: seeded, so that the ReLU-threshold probe below sees the same weights every run)
     hip, _, _ = pu.make_policy(g=g, device=DEV, backend="hip", det_weights=False, semantic_branch=True)
     ref, _, _ = pu.make_policy(g=g, device="cpu", backend="torch", det_weights=False, semantic_branch=True)
     plain, _, _ = pu.make_policy(g=g, device="cpu", backend="torch", det_weights=False)
