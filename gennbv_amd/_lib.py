@@ -65,6 +65,10 @@ SIGNATURES = {
     "gnbv_linear_bwd_dw": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "gnbv_linear_bwd_dw_sq_parts": (_i, [_i]),
     "gnbv_linear_bwd_dw_sq": (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),
+    "gnbv_linear_fold_ok": (_i, [_i, _i, _i, _i]),
+    "gnbv_linear_forward_fold": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p]),
+    "gnbv_linear_bwd_dw_fold": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
+    "gnbv_linear_forward_fold_adam": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p, _p]),
     "gnbv_pose_encode": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
     "gnbv_policy_head_forward": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
     "gnbv_policy_head_backward": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -78,6 +82,7 @@ SIGNATURES = {
     "gnbv_clip_adam_step_rotate": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _p, _f, _p, _f, _p, _p, _sz, _p, _i, _i, _p, _p, _p]),
     "gnbv_clip_adam_step_ex": (_i, [_p, _p]),
     "gnbv_adam_shard_step": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _p, _p, _p]),
+    "gnbv_adam_slice_pending": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _p, _p, _p]),
     "gnbv_chamfer_workspace_bytes": (_sz, [_i, _i]),
     "gnbv_chamfer_distance": (_i, [_p, _i, _p, _i, _p, _p, _sz, _p]),
     "gnbv_gae_sb3": (_i, [_p, _p, _p, _p, _p, _i, _i, _d, _d, _p, _p, _p]),
@@ -119,7 +124,13 @@ class GnbvAdamStep(C.Structure):
                 ("step", _p), ("stop_flag", _p), ("grad_scale", _f), ("kl_slot", _p), ("target_kl", _f),
                 ("norm_out", _p), ("workspace", _p), ("workspace_bytes", _sz),
                 ("table", _p), ("table_rows", _i), ("row_len", _i), ("out", _p), ("counter", _p),
-                ("sq_lo", _i64), ("sq_hi", _i64), ("sq_partial", _p), ("sq_parts", _i), ("loss_finish", _p), ("upd_skip_lo", _i64), ("upd_skip_hi", _i64)]
+                ("sq_lo", _i64), ("sq_hi", _i64), ("sq_partial", _p), ("sq_parts", _i), ("loss_finish", _p), ("upd_skip_lo", _i64), ("upd_skip_hi", _i64), ("pending", _p)]
+
+
+class GnbvOwedAdam(C.Structure):
+    """include/gennbv_hip.h: GnbvOwedAdam"""
+    _fields_ = [("grads", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("norm_out", _p), ("step", _p), ("pending", _p),
+                ("lr", _f), ("beta1", _f), ("beta2", _f), ("eps", _f)]
 
 
 class GnbvEncoderGrads(C.Structure):
@@ -159,7 +170,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.gnbv_abi_version() != 2:
+    if lib.gnbv_abi_version() != 3:
         raise GennbvHipError("libgennbv_hip.so ABI version mismatch")
     _lib = lib
     return lib

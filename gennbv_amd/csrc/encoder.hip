@@ -2186,7 +2186,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
                                        void *workspace, size_t workspace_bytes, void *stream)
 {
     // obs_grid == NULL: compact observations, the grid exists only as the int8 rows p->grid_i8 (fp32 activations only)
-    GNBV_CHECK_ARG(p && (obs_grid || (p->grid_i8 && !p->act_bf16)) && y1 && y2 && bn_state && features && workspace && batch > 0 && grid >= 7);
+    GNBV_CHECK_ARG(p && (obs_grid || (p->grid_i8 && !p->act_bf16)) && y1 && y2 && bn_state && workspace && batch > 0 && grid >= 7);
     GNBV_CHECK_ARG(p->grid_i8 == nullptr || p->grid_i8_row_stride >= (int64_t)grid * grid * grid);
     GNBV_CHECK_ARG(workspace_bytes >= gnbv_encoder_workspace_bytes(batch, grid) && ((uintptr_t)workspace & 255) == 0);
     GNBV_CHECK_ARG(p->w1 && p->b1 && p->bn1_w && p->bn1_b && p->bn1_rm && p->bn1_rv && p->w2 && p->b2 && p->bn2_w && p->bn2_b &&
@@ -2363,6 +2363,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     const int64_t total = (int64_t)batch * kC * P2;
     int grid_x = (int)((total + 255) / 256);
     grid_x = grid_x > 4096 ? 4096 : grid_x;
+    if (features == nullptr) return gnbv_launch_status();  // (the consumer folds BN2 + ReLU into its operand load: gnbv_linear_forward_fold)
     hipLaunchKernelGGL(k_bn_relu_apply, dim3(grid_x), dim3(256), 0, st, y2, bn2, bn2 + kC, total, P2, features, p->range_flag);
     return gnbv_launch_status();
 }

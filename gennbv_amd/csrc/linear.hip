@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "../../include/gennbv_hip.h"
 
 namespace {
 
@@ -172,9 +173,22 @@ __device__ __forceinline__ void lsplit8(const float4 &p, const float4 &q, float 
         lo[e] = b;
     }
 }
+// FOLD (round 3): x is a BatchNorm pre-activation [M][C][P] and the operand is relu(scale[c] x + shift[c]), c = column / P -- the
+// BN2 + ReLU pass in front of fc_grid (k_bn_relu_apply: a 27 MB write, a 27 MB read and a launch on the update's critical path)
+// folded into this kernel's operand load.  P >= 512 (the caller checks): a chunk of <= 512 columns then meets at most one channel
+// boundary, and a 32-column trip that does not contain it takes the scalar path (one fma + one max per element).  The largest
+// operand is tracked for the range guard (bit 4 of *range_flag when it passes 1000: the split clamps x at 1015).
+//
+// ADAM (round 3, with FOLD): the layer's weight still has the PREVIOUS optimizer step's update coming (GnbvOwedAdam: the clip + Adam
+// launch skipped this slice and raised *pending).  Every weight element is staged by exactly one thread of one workgroup of this
+// launch (M <= 128: one row block), so that thread applies the update -- same expressions as k_adam_flat (csrc/ppo.hip), bit-identical
+// -- writes p / m / v back and stages the NEW weight: the update's 7 x 4 bytes per parameter ride this kernel's weight stream instead
+// of a 65 us launch of their own in front of it (this kernel alone: 30 us; together ~70).
+template <bool FOLD, bool ADAM = false>
 __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linear_splitk_split(
-    const float *__restrict__ x /*[M][K]*/, const float *__restrict__ w /*[N][K]*/, int M, int N, int K, int nchunks,
-    float *__restrict__ partial /*[nchunks][M][N]*/)
+    const float *__restrict__ x /*[M][K]*/, const float *w /*[N][K]*/, int M, int N, int K, int nchunks,
+    float *__restrict__ partial /*[nchunks][M][N]*/, const float *__restrict__ xs_scale = nullptr, const float *__restrict__ xs_shift = nullptr,
+    int xs_P = 0, int *__restrict__ range_flag = nullptr, GnbvOwedAdam oa = GnbvOwedAdam{})
 {
     __shared__ __attribute__((aligned(16))) char s_b[2][2][4096];  // [buffer][hi | lo][column tile 4][g 4][column 16][8 halfs]
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -214,8 +228,26 @@ __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // requests are UNCONDITIONAL (clamped addresses): see the fp32 kernel
-    struct Trip { float4 a00, a01, a10, a11, b0, b1; };  // (named members: arrays handed to lambdas ended up in scratch memory elsewhere)
+    struct Trip { float4 a00, a01, a10, a11, b0, b1, g0, g1, m0, m1, v0, v1; };  // (named members: arrays handed to lambdas ended up in scratch memory elsewhere; g / m / v: ADAM only)
     static_assert(kRowTilesPerWave == 2, "two row tiles per wave");
+    // ADAM: is the update owed (uniform), its scalars (k_adam_flat's prologue)
+    bool upd = false;
+    float ad_coef = 0.f, ad_step = 0.f, ad_bc2s = 1.f;
+    const float *gst[2] = {nullptr, nullptr};
+    float *mst[2] = {nullptr, nullptr}, *vst[2] = {nullptr, nullptr};
+    if (ADAM) {
+        upd = *oa.pending != 0;
+        ad_coef = oa.norm_out[1];
+        const double t = (double)(*oa.step);
+        const double bc1 = 1.0 - pow((double)oa.beta1, t), bc2 = 1.0 - pow((double)oa.beta2, t);
+        ad_step = (float)((double)oa.lr / bc1);
+        ad_bc2s = (float)sqrt(bc2);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const size_t off = (size_t)(nt * kTileN + 32 * r + tcol) * K + 4 * t8;
+            gst[r] = oa.grads + off; mst[r] = oa.exp_avg + off; vst[r] = oa.exp_avg_sq + off;
+        }
+    }
     auto request_a = [&](int s, Trip &t) {
         const int kc = min(min(s, s1 - 1) * 32, K - 8 - 8 * g);
         t.a00 = ld4g(xr[0] + kc);
@@ -227,6 +259,25 @@ __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 
         const int kc = min(min(s, s1 - 1) * 32, K - 4 - 4 * t8);
         t.b0 = ld4g(wst[0] + kc);
         t.b1 = ld4g(wst[1] + kc);
+        if (ADAM && upd) {
+            t.g0 = ld4g(gst[0] + kc); t.g1 = ld4g(gst[1] + kc);
+            t.m0 = ld4g(mst[0] + kc); t.m1 = ld4g(mst[1] + kc);
+            t.v0 = ld4g(vst[0] + kc); t.v1 = ld4g(vst[1] + kc);
+        }
+    };
+    auto adam4 = [&](float4 &pw, const float4 &gw, float4 &mw, float4 &vw) {  // k_adam_flat's element update, four times
+        float *pp = &pw.x, *mm = &mw.x, *vv = &vw.x;
+        const float *gg = &gw.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gi = gg[e] * ad_coef;
+            const float mi = mm[e] + (gi - mm[e]) * (1.0f - oa.beta1);
+            const float vi = vv[e] * oa.beta2 + (1.0f - oa.beta2) * gi * gi;
+            mm[e] = mi;
+            vv[e] = vi;
+            const float denom = sqrtf(vi) / ad_bc2s + oa.eps;
+            pp[e] = pp[e] - ad_step * (mi / denom);
+        }
     };
     auto stage_one = [&](int buf, bool ok, const float4 &b, uint32_t off) {
         const float v[4] = {b.x, b.y, b.z, b.w};
@@ -241,13 +292,63 @@ __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 
         *reinterpret_cast<lh4 *>(&s_b[buf][0][off]) = hi;
         *reinterpret_cast<lh4 *>(&s_b[buf][1][off]) = lo;
     };
-    auto stage_b = [&](int buf, int s, const Trip &t) {
+    auto stage_b = [&](int buf, int s, Trip &t) {
         const bool ok = s < s1 && s * 32 + 4 * t8 + 3 < K;  // past the chunk / past K: zeros
+        if (ADAM && upd && ok) {  // (ok: this thread is the element's one owner; its request was not clamped)
+            const int kc = s * 32;
+            adam4(t.b0, t.g0, t.m0, t.v0);
+            adam4(t.b1, t.g1, t.m1, t.v1);
+            *reinterpret_cast<float4 *>(const_cast<float *>(wst[0]) + kc) = t.b0;
+            *reinterpret_cast<float4 *>(const_cast<float *>(wst[1]) + kc) = t.b1;
+            *reinterpret_cast<float4 *>(mst[0] + kc) = t.m0;
+            *reinterpret_cast<float4 *>(mst[1] + kc) = t.m1;
+            *reinterpret_cast<float4 *>(vst[0] + kc) = t.v0;
+            *reinterpret_cast<float4 *>(vst[1] + kc) = t.v1;
+        }
         stage_one(buf, ok, t.b0, st_off[0]);
         stage_one(buf, ok, t.b1, st_off[1]);
     };
-    auto consume = [&](int s, int buf, const Trip &t) {
+    // FOLD: the channel of the chunk's first column, the first column of the next channel, both channels' (scale, shift)
+    float f_sc[2] = {0.f, 0.f}, f_sh[2] = {0.f, 0.f}, zmax = 0.0f;
+    int f_kb = 0x7fffffff;
+    if (FOLD) {
+        const int c_lo = (s0 * 32) / xs_P, nch = (K + xs_P - 1) / xs_P;
+        f_kb = (c_lo + 1) * xs_P;
+        f_sc[0] = xs_scale[c_lo]; f_sh[0] = xs_shift[c_lo];
+        f_sc[1] = xs_scale[min(c_lo + 1, nch - 1)]; f_sh[1] = xs_shift[min(c_lo + 1, nch - 1)];
+    }
+    auto fold8 = [&](float4 &p, float4 &q, int k0) {  // the eight operands of columns k0 .. k0 + 7
+        float v[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool hi = k0 + e >= f_kb;
+            v[e] = fmaxf(fmaf(hi ? f_sc[1] : f_sc[0], v[e], hi ? f_sh[1] : f_sh[0]), 0.0f);
+        }
+        zmax = fmaxf(zmax, fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7]))));
+        p = make_float4(v[0], v[1], v[2], v[3]);
+        q = make_float4(v[4], v[5], v[6], v[7]);
+    };
+    auto consume = [&](int s, int buf, Trip &t) {
         const bool ok = s < s1 && s * 32 + 8 * g + 7 < K;
+        if (FOLD) {
+            const int k0 = min(min(s, s1 - 1) * 32, K - 8 - 8 * g) + 8 * g;  // (the columns request_a fetched for this lane)
+            if (s * 32 + 32 <= f_kb || s * 32 >= f_kb) {  // (wave-uniform: the trip lies inside one channel)
+                const int u = s * 32 >= f_kb ? 1 : 0;
+                const float sc = f_sc[u], sh = f_sh[u];
+                float *vv[4] = {&t.a00.x, &t.a01.x, &t.a10.x, &t.a11.x};
+#pragma unroll
+                for (int h = 0; h < 4; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float z = fmaxf(fmaf(sc, vv[h][e], sh), 0.0f);
+                        vv[h][e] = z;
+                        zmax = fmaxf(zmax, z);
+                    }
+            } else {
+                fold8(t.a00, t.a01, k0);
+                fold8(t.a10, t.a11, k0);
+            }
+        }
         lh8 ah[kRowTilesPerWave], al[kRowTilesPerWave];
         lsplit8(t.a00, t.a01, ok ? kLinXScale : 0.0f, ah[0], al[0]);
         lsplit8(t.a10, t.a11, ok ? kLinXScale : 0.0f, ah[1], al[1]);
@@ -289,6 +390,7 @@ __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 
         stage_b(0, s + 2, t0);
         __syncthreads();
     }
+    if (FOLD && range_flag != nullptr && __any(zmax > 1000.0f) && lane == 0) atomicOr(range_flag, 4);
     const float unscale = 1.0f / (kLinXScale * kLinWScale);
     float *out = partial + (size_t)chunk * M * N;
 #pragma unroll
@@ -426,10 +528,13 @@ __global__ __launch_bounds__(256) void k_fc_bwd_prep(const float *__restrict__ d
 }
 
 // C[i][k] = inv_a[i] / bscale * sum_c Afrag[i][c] (bscale B[c][k]);  workgroup = 64 columns k, 4 waves x RT row tiles
-template <int RT>
-__global__ __launch_bounds__(256) void k_skinny_gemm_split(const uint4 *__restrict__ fragA, const float *__restrict__ inv_a, const float *__restrict__ Bm /*[C][K]*/,
+// FOLD: B[c][k] is a BatchNorm pre-activation and the operand is relu(scale[k / P] B + shift[k / P]) (see k_linear_splitk_split);
+// a thread stages the same four columns in every step, so its four (scale, shift) pairs are loop constants.
+template <int RT, bool FOLD = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_skinny_gemm_split(const uint4 *__restrict__ fragA, const float *__restrict__ inv_a, const float *__restrict__ Bm /*[C][K]*/,
                                                            int rows /*of C*/, int Cc /*contraction length*/, int K, float bscale, float *__restrict__ Cout /*[rows][K]*/,
-                                                           double *__restrict__ sq_partial = nullptr /*[gridDim.x]: sum of the squares this workgroup stored*/)
+                                                           double *__restrict__ sq_partial = nullptr /*[gridDim.x]: sum of the squares this workgroup stored*/,
+                                                           const float *__restrict__ xs_scale = nullptr, const float *__restrict__ xs_shift = nullptr, int xs_P = 0)
 {
     __shared__ __attribute__((aligned(16))) char s_b[2][2][4096];  // [buffer][hi | lo][k block 4][c 32][16 k] f16
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x / 64);
@@ -440,6 +545,15 @@ __global__ __launch_bounds__(256) void k_skinny_gemm_split(const uint4 *__restri
     const int cc0 = threadIdx.x >> 4, kq = threadIdx.x & 15;
     const int kcol = min(k0 + 4 * kq, K - 4);  // (clamped: a partial last slab re-reads valid columns; its stores are masked)
     const uint32_t st_off = (uint32_t)((((kq >> 2) * 32 + cc0) * 16 + (kq & 3) * 4) * 2);
+    float f_sc[4] = {1.f, 1.f, 1.f, 1.f}, f_sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (FOLD) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (kcol + e) / xs_P;
+            f_sc[e] = xs_scale[c];
+            f_sh[e] = xs_shift[c];
+        }
+    }
     f32x4 acc[RT][4];
 #pragma unroll
     for (int r = 0; r < RT; ++r)
@@ -455,7 +569,11 @@ __global__ __launch_bounds__(256) void k_skinny_gemm_split(const uint4 *__restri
         for (int u = 0; u < 2; ++u) {
             const float4 &b = u ? b1 : b0;
             const bool ok = s < ksteps && 32 * s + cc0 + 16 * u < Cc;
-            const float v[4] = {b.x, b.y, b.z, b.w};
+            float v[4] = {b.x, b.y, b.z, b.w};
+            if (FOLD) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(f_sc[e], v[e], f_sh[e]), 0.0f);
+            }
             lh4 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -563,6 +681,65 @@ GNBV_API size_t gnbv_linear_workspace_bytes(int M, int N, int K)
     return (size_t)pick_chunks(K) * M * N * sizeof(float) + 256;
 }
 
+namespace {
+inline bool split_kernels_on()
+{
+    const char *e = getenv("GENNBV_CONV_SPLIT");  // "0": the fp32-MFMA kernels everywhere (csrc/encoder.hip conv_split_path)
+    return !(e && e[0] == '0');
+}
+}  // namespace
+
+GNBV_API int gnbv_linear_fold_ok(int M, int N, int K, int P)
+{
+    if (M <= 0 || N <= 0 || K < 64 || K % 8 != 0 || P < 512 || K % P != 0 || !split_kernels_on()) return 0;
+    const int nchunks = pick_chunks(K), nstep32 = (K + 31) / 32;
+    return ((nstep32 + nchunks - 1) / nchunks + 1) * 32 <= P ? 1 : 0;  // (a chunk meets at most one channel boundary)
+}
+
+GNBV_API int gnbv_linear_forward_fold(const float *y, const float *scale, const float *shift, int P, int *range_flag, const float *w, const float *bias,
+                                      int M, int N, int K, int relu, float *out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    GNBV_CHECK_ARG(y && scale && shift && w && bias && out && workspace);
+    GNBV_CHECK_ARG(N > 0 && N % kTileN == 0 && gnbv_linear_fold_ok(M, N, K, P) && !(relu & 2));
+    GNBV_CHECK_ARG((((uintptr_t)y | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)out | (uintptr_t)workspace) & 15) == 0);
+    GNBV_CHECK_ARG(workspace_bytes >= gnbv_linear_workspace_bytes(M, N, K));
+    hipStream_t st = gnbv_stream(stream);
+    const int nchunks = pick_chunks(K), ntn = N / kTileN;
+    const int blocks = ((nchunks + 7) / 8) * 8 * ntn;
+    hipLaunchKernelGGL(k_linear_splitk_split<true>, dim3(blocks, (M + 127) / 128), dim3(kLinThreads), 0, st, y, w, M, N, K, nchunks, (float *)workspace, scale,
+                       shift, P, range_flag);
+    int err;
+    if ((err = gnbv_launch_status())) return err;
+    const int64_t total4 = (int64_t)M * N / 4;
+    hipLaunchKernelGGL(k_linear_reduce, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, st, (const float *)workspace, bias, M, N, nchunks,
+                       relu & 1, out);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_linear_forward_fold_adam(const float *y, const float *scale, const float *shift, int P, int *range_flag, float *w, const float *bias,
+                                           int M, int N, int K, int relu, float *out, void *workspace, size_t workspace_bytes, const GnbvOwedAdam *adam,
+                                           void *stream)
+{
+    GNBV_CHECK_ARG(y && scale && shift && w && bias && out && workspace && adam);
+    GNBV_CHECK_ARG(adam->grads && adam->exp_avg && adam->exp_avg_sq && adam->norm_out && adam->step && adam->pending);
+    GNBV_CHECK_ARG(M <= 128 /*one row block: every weight element has ONE owner thread*/ && N > 0 && N % kTileN == 0 && gnbv_linear_fold_ok(M, N, K, P) &&
+                   !(relu & 2));
+    GNBV_CHECK_ARG((((uintptr_t)y | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)out | (uintptr_t)workspace | (uintptr_t)adam->grads | (uintptr_t)adam->exp_avg |
+                     (uintptr_t)adam->exp_avg_sq) & 15) == 0);
+    GNBV_CHECK_ARG(workspace_bytes >= gnbv_linear_workspace_bytes(M, N, K));
+    hipStream_t st = gnbv_stream(stream);
+    const int nchunks = pick_chunks(K), ntn = N / kTileN;
+    const int blocks = ((nchunks + 7) / 8) * 8 * ntn;
+    hipLaunchKernelGGL((k_linear_splitk_split<true, true>), dim3(blocks, 1), dim3(kLinThreads), 0, st, y, (const float *)w, M, N, K, nchunks, (float *)workspace,
+                       scale, shift, P, range_flag, *adam);
+    int err;
+    if ((err = gnbv_launch_status())) return err;
+    const int64_t total4 = (int64_t)M * N / 4;
+    hipLaunchKernelGGL(k_linear_reduce, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, st, (const float *)workspace, bias, M, N, nchunks,
+                       relu & 1, out);
+    return gnbv_launch_status();
+}
+
 GNBV_API int gnbv_linear_forward(const float *x, const float *w, const float *bias, int M, int N, int K, int relu, float *out,
                                  void *workspace, size_t workspace_bytes, void *stream)
 {
@@ -573,11 +750,10 @@ GNBV_API int gnbv_linear_forward(const float *x, const float *w, const float *bi
     hipStream_t st = gnbv_stream(stream);
     const int nchunks = pick_chunks(K), ntn = N / kTileN;
     const int blocks = ((nchunks + 7) / 8) * 8 * ntn;
-    const char *e = getenv("GENNBV_CONV_SPLIT");  // "0": the fp32-MFMA kernels everywhere (csrc/encoder.hip conv_split_path)
     const bool fp32_arith = (relu & 2) != 0;  // (flag word: include/gennbv_hip.h)
     relu &= 1;
-    if (!(e && e[0] == '0') && !fp32_arith && K % 8 == 0 && K >= 64)
-        hipLaunchKernelGGL(k_linear_splitk_split, dim3(blocks, (M + 127) / 128), dim3(kLinThreads), 0, st, x, w, M, N, K, nchunks, (float *)workspace);
+    if (split_kernels_on() && !fp32_arith && K % 8 == 0 && K >= 64)
+        hipLaunchKernelGGL(k_linear_splitk_split<false>, dim3(blocks, (M + 127) / 128), dim3(kLinThreads), 0, st, x, w, M, N, K, nchunks, (float *)workspace);
     else
         hipLaunchKernelGGL(k_linear_splitk, dim3(blocks, (M + 127) / 128), dim3(kLinThreads), 0, st, x, w, M, N, K, nchunks, (float *)workspace);
     int err;
@@ -632,14 +808,28 @@ GNBV_API int gnbv_linear_bwd_dx(const void *workspace, const float *w, int M, in
     return gnbv_launch_status();
 }
 
-static int linear_bwd_dw(const void *workspace, const float *x, int M, int N, int K, float *dw, double *sq_partial, void *stream)
+static int linear_bwd_dw(const void *workspace, const float *x, int M, int N, int K, float *dw, double *sq_partial, void *stream,
+                         const float *scale = nullptr, const float *shift = nullptr, int P = 0)
 {
     GNBV_CHECK_ARG(workspace && x && dw && M > 0 && M % 16 == 0 && M <= 256 && N % 16 == 0 && N <= 256 && K >= 64 && K % 4 == 0);
     GNBV_CHECK_ARG((((uintptr_t)x | (uintptr_t)dw) & 15) == 0);
     const FcBwdWs ws = fc_bwd_carve(const_cast<void *>(workspace), M, N);
-    hipLaunchKernelGGL(k_skinny_gemm_split<4>, dim3((K + 63) / 64), dim3(256), 0, gnbv_stream(stream), (const uint4 *)ws.frag_dw, (const float *)ws.inv_dw, x, N, M, K,
-                       kLinXScale, dw, sq_partial);
+    if (scale != nullptr) {
+        GNBV_CHECK_ARG(shift != nullptr && P > 0 && K % P == 0);
+        hipLaunchKernelGGL((k_skinny_gemm_split<4, true>), dim3((K + 63) / 64), dim3(256), 0, gnbv_stream(stream), (const uint4 *)ws.frag_dw,
+                           (const float *)ws.inv_dw, x, N, M, K, kLinXScale, dw, sq_partial, scale, shift, P);
+    } else {
+        hipLaunchKernelGGL(k_skinny_gemm_split<4>, dim3((K + 63) / 64), dim3(256), 0, gnbv_stream(stream), (const uint4 *)ws.frag_dw, (const float *)ws.inv_dw, x, N, M, K,
+                           kLinXScale, dw, sq_partial);
+    }
     return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_linear_bwd_dw_fold(const void *workspace, const float *y, const float *scale, const float *shift, int P, int M, int N, int K, float *dw,
+                                     double *sq_partial /*NULL: none*/, void *stream)
+{
+    GNBV_CHECK_ARG(scale && shift);
+    return linear_bwd_dw(workspace, y, M, N, K, dw, sq_partial, stream, scale, shift, P);
 }
 
 GNBV_API int gnbv_linear_bwd_dw(const void *workspace, const float *x, int M, int N, int K, float *dw, void *stream)

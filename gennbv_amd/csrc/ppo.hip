@@ -344,7 +344,9 @@ __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, 
                             const int *__restrict__ stop_flag,
                             const int64_t *__restrict__ step /*already incremented*/, float lr, float beta1, float beta2, float eps,
                             const int64_t *__restrict__ rot_table = nullptr, int rot_rows = 0, int rot_len = 0, int64_t *__restrict__ rot_out = nullptr,
-                            int *__restrict__ rot_counter = nullptr)
+                            int *__restrict__ rot_counter = nullptr,
+                            int *__restrict__ pending_out = nullptr /*<- 1 when this step's update is applied (the skipped slice is then owed), else 0*/,
+                            const int *__restrict__ pending_in = nullptr /*the owed slice: run only when *pending_in != 0*/)
 {
     // (replayed minibatch graphs: the LAST launch of a minibatch leaves the next minibatch's row numbers in the buffer every kernel
     // of the graph reads them from -- no copy node, no host work between two replays.  Also when the update itself is masked.)
@@ -354,7 +356,9 @@ __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, 
         __syncthreads();
         if (threadIdx.x == 0) *rot_counter = c;
     }
-    if (stop_flag != nullptr && *stop_flag != 0) return;
+    const bool stopped = stop_flag != nullptr && *stop_flag != 0;
+    if (pending_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *pending_out = stopped ? 0 : 1;
+    if (stopped || (pending_in != nullptr && *pending_in == 0)) return;
     __shared__ double sh[256];
     float coef;
     if (coef_in != nullptr) {
@@ -383,8 +387,9 @@ __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, 
     const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        if (i >= skip_lo && i < skip_hi) continue;
+    const int64_t gap = skip_hi > skip_lo ? skip_hi - skip_lo : 0;  // (the grid covers the n - gap live elements only)
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n - gap; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = j < skip_lo ? j : j + gap;
         const float gi = g[i] * coef;
         const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);  // exp_avg.lerp_(grad, 1 - beta1)
         const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;  // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
@@ -520,6 +525,7 @@ GNBV_API int gnbv_clip_adam_step_ex(const GnbvAdamStep *a, void *stream)
     GNBV_CHECK_ARG(a->table == nullptr || (a->out && a->counter && a->table_rows > 0 && a->row_len > 0));
     const bool sliced = a->sq_partial != nullptr && a->sq_parts > 0 && a->sq_hi > a->sq_lo;
     GNBV_CHECK_ARG(!sliced || (a->sq_lo >= 0 && a->sq_hi <= a->n));
+    GNBV_CHECK_ARG(a->upd_skip_hi <= a->upd_skip_lo || (a->upd_skip_lo >= 0 && a->upd_skip_hi <= a->n));
     hipStream_t st = gnbv_stream(stream);
     double *partial = (double *)a->workspace;
     const int64_t gap = sliced ? a->sq_hi - a->sq_lo : 0, n_eff = a->n - gap;
@@ -535,7 +541,8 @@ GNBV_API int gnbv_clip_adam_step_ex(const GnbvAdamStep *a, void *stream)
     hipLaunchKernelGGL(k_grad_sqnorm, dim3(blocks + fold + (finish ? 1 : 0)), dim3(256), 0, st, a->grads, n_eff, sliced ? a->sq_lo : a->n, gap, partial,
                        a->grad_scale, a->step, a->stop_flag, a->kl_slot, a->target_kl, blocks, sliced ? a->sq_partial : (const double *)nullptr,
                        sliced ? a->sq_parts : 0, fin_block, fin);
-    int ab = (int)((a->n + 255) / 256);
+    int ab = (int)((a->n - (a->upd_skip_hi > a->upd_skip_lo ? a->upd_skip_hi - a->upd_skip_lo : 0) + 255) / 256);
+    ab = ab < 1 ? 1 : ab;
 #ifndef GNBV_ADAM_BLOCKS
 #define GNBV_ADAM_BLOCKS 8192  // (same-call A/B of the whole bench: 2048 workgroups +5 us per minibatch, 4096 +1-2 us)
 #endif
@@ -543,7 +550,23 @@ GNBV_API int gnbv_clip_adam_step_ex(const GnbvAdamStep *a, void *stream)
     hipLaunchKernelGGL(k_adam_flat, dim3(ab), dim3(256), 0, st, a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->n, (const double *)partial, blocks + fold,
                        (const double *)nullptr, 0, a->max_grad_norm, a->grad_scale, a->norm_out,
                        (const float *)nullptr, a->upd_skip_lo, a->upd_skip_hi, (const int *)a->stop_flag, (const int64_t *)a->step, a->lr, a->beta1, a->beta2, a->eps, a->table, a->table_rows, a->row_len, a->out,
-                       a->counter);
+                       a->counter, a->upd_skip_hi > a->upd_skip_lo ? a->pending : (int *)nullptr);
+    return gnbv_launch_status();
+}
+
+// The update of the slice a step's main launch skipped (GnbvAdamStep.upd_skip_lo / hi with .pending), launched LATER -- at the head
+// of the next minibatch, on a second stream beside the conv stack's forward, which does not read that slice: the update is 392 MB
+// of HBM traffic (~65 us) that otherwise sits alone on the critical path.  Runs iff *pending != 0; same clip factor (norm_out[1])
+// and step counter as the launch that owed it (nothing between the two launches writes either).
+GNBV_API int gnbv_adam_slice_pending(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const float *norm_out,
+                                     float lr, float beta1, float beta2, float eps, const int64_t *step, const int *pending, void *stream)
+{
+    GNBV_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && norm_out && step && pending && n > 0);
+    int ab = (int)((n + 255) / 256);
+    ab = ab > GNBV_ADAM_BLOCKS ? GNBV_ADAM_BLOCKS : ab;
+    hipLaunchKernelGGL(k_adam_flat, dim3(ab), dim3(256), 0, gnbv_stream(stream), params, grads, exp_avg, exp_avg_sq, n, (const double *)nullptr, 0,
+                       (const double *)nullptr, 0, 0.0f, 1.0f, (float *)nullptr, norm_out, (int64_t)0, (int64_t)0, (const int *)nullptr, step, lr, beta1, beta2,
+                       eps, (const int64_t *)nullptr, 0, 0, (int64_t *)nullptr, (int *)nullptr, (int *)nullptr, pending);
     return gnbv_launch_status();
 }
 

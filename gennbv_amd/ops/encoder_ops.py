@@ -150,7 +150,7 @@ def _params_struct(seq, act_bf16: bool = False, grid_i8: Optional[torch.Tensor] 
 
 class _GridEncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, base, rows, grid_off, grid, training, skip_flag, seq, act_bf16, write_through, grid_i8, compact, autocorr, dp, guard, w1, b1, g1, be1, w2, b2, g2, be2):
+    def forward(ctx, base, rows, grid_off, grid, training, skip_flag, seq, act_bf16, write_through, grid_i8, compact, autocorr, dp, guard, fold, w1, b1, g1, be1, w2, b2, g2, be2):
         lib = _lib.load()
         _lib.require_cuda(base, w1)
         for t in (w1, b1, g1, be1, w2, b2, g2, be2):
@@ -164,7 +164,9 @@ class _GridEncoderFn(torch.autograd.Function):
         y1 = torch.empty(lib.gnbv_encoder_y1_elems(batch, grid), dtype=act_dt, device=dev)
         y2 = torch.empty(batch * 16 * p2, dtype=torch.float32, device=dev)
         bn_state = torch.empty(2 * 4 * 16 + 768, dtype=torch.float32, device=dev)  # + the minibatch's autocorrelation total (ints)
-        feats = torch.empty(batch, 16 * p2, dtype=torch.float32, device=dev)
+        # fold: BatchNorm-2 + ReLU are left to the consumer's operand load (linear_relu(..., fold=...)): no feature tensor; the
+        # outputs are the raw conv output y2 viewed as [B, 16 P2] and bn_state (its floats 64..96 = BN2's scale | shift)
+        feats = None if fold else torch.empty(batch, 16 * p2, dtype=torch.float32, device=dev)
         ws = _workspace(lib, batch, grid, dev)
         params = _params_struct(seq, act_bf16, grid_i8, autocorr, dp if training else None, guard)
         # compact observations: `base` has no grid slice, the kernels read the int8 rows only (obs pointer NULL)
@@ -172,7 +174,7 @@ class _GridEncoderFn(torch.autograd.Function):
         obs_ptr = None if compact else base.data_ptr() + 4 * grid_off
         _lib.check(lib.gnbv_encoder_grid_forward(
             obs_ptr, _lib.ptr(rows), base.stride(0), batch, grid, C.byref(params), int(training), _lib.ptr(skip_flag),
-            y1.data_ptr(), y2.data_ptr(), bn_state.data_ptr(), feats.data_ptr(), ws.data_ptr(), ws.numel(),
+            y1.data_ptr(), y2.data_ptr(), bn_state.data_ptr(), _lib.ptr(feats), ws.data_ptr(), ws.numel(),
             _lib.stream_ptr(dev)), "gnbv_encoder_grid_forward")
         ctx.save_for_backward(base, rows, y1, y2, bn_state, w1, w2)
         ctx.meta = (grid_off, grid, batch, seq, act_bf16)
@@ -182,10 +184,15 @@ class _GridEncoderFn(torch.autograd.Function):
         ctx.dp = dp if training else None
         ctx.guard = guard
         ctx.obs_ptr = obs_ptr
+        if fold:
+            # (the "gradient of this output" that comes back is d loss / d relu(bn2(y2)): the consumer's input gradient)
+            ctx.mark_non_differentiable(bn_state)
+            ctx.set_materialize_grads(False)  # (or autograd fills a zero "gradient" of bn_state: a launch on the critical path)
+            return y2.view(batch, 16 * p2), bn_state
         return feats
 
     @staticmethod
-    def backward(ctx, d_feats):
+    def backward(ctx, d_feats, _d_bn_state=None):
         lib = _lib.load()
         base, rows, y1, y2, bn_state, w1, w2 = ctx.saved_tensors
         grid_off, grid, batch, seq, act_bf16 = ctx.meta
@@ -209,19 +216,20 @@ class _GridEncoderFn(torch.autograd.Function):
             y2.data_ptr(), bn_state.data_ptr(), d_feats.data_ptr(), dy2.data_ptr(), dz1.data_ptr(), C.byref(gs),
             ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "gnbv_encoder_grid_backward")
         if direct:
-            return (None,) * 22
-        return (None,) * 14 + tuple(grads)
+            return (None,) * 23
+        return (None,) * 15 + tuple(grads)
 
 
 def grid_encoder(base: torch.Tensor, rows: Optional[torch.Tensor], grid_off: int, grid: int, seq, training: bool,
                  skip_flag: Optional[torch.Tensor] = None, act_bf16: bool = False, write_through: bool = False,
                  grid_i8: Optional[torch.Tensor] = None, compact: bool = False, autocorr: Optional[torch.Tensor] = None, dp=None,
-                 guard=None) -> torch.Tensor:
+                 guard=None, fold: bool = False):
     """seq = the `naive_encoder_grid` nn.Sequential (conv, bn, relu, conv, bn, relu).  `compact`: `base` rows carry
     no grid slice, the grid is read from `grid_i8` only.  `autocorr`: per-row input autocorrelation (input_autocorr).
     `guard` = (force_fp32, range_flag int32 [1] or None[, autocorr_total int32 [768] or None]): GnbvEncoderParams.force_fp32 /
-    .range_flag / .autocorr_total."""
-    return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, bool(act_bf16), bool(write_through), grid_i8, bool(compact), autocorr, dp, guard, seq[0].weight, seq[0].bias,
+    .range_flag / .autocorr_total.  `fold`: returns (y2 [B, 16 P2] -- the second conv's raw output --, bn_state) for
+    linear_relu(y2, lin, fold=(bn_state, P2, range_flag)) instead of the features (include/gennbv_hip.h gnbv_linear_forward_fold)."""
+    return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, bool(act_bf16), bool(write_through), grid_i8, bool(compact), autocorr, dp, guard, bool(fold), seq[0].weight, seq[0].bias,
                                 seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias)
 
 
@@ -229,8 +237,12 @@ class _LinearReluFn(torch.autograd.Function):
     """relu(x @ w.T + b) on the split-K MFMA kernel (csrc/linear.hip); backward = three library GEMMs."""
 
     @staticmethod
-    def forward(ctx, x, w, b, mod=None, fp32_arith=False):
+    def forward(ctx, x, w, b, mod=None, fp32_arith=False, bn_state=None, fold_p=0, range_flag=None, owed_adam=None):
         ctx.mod = mod  # write-through target (ops/direct_grad.py) or None
+        # bn_state given: x is a BatchNorm pre-activation [M][C][fold_p] and the layer's input is relu(scale[c] x + shift[c]),
+        # formed in the kernels' operand loads (scale | shift = floats 64..96 of bn_state); the input gradient returned by
+        # backward is the gradient of THAT input (the producer, _GridEncoderFn, runs BatchNorm's backward from it)
+        ctx.fold_p = int(fold_p) if bn_state is not None else 0
         ctx.fp32_arith = bool(fp32_arith)  # operand outside the split-f16 ranges: the fp32-MFMA kernel forward, library GEMMs backward
         lib = _lib.load()
         _lib.require_cuda(x, w, b)
@@ -245,6 +257,18 @@ class _LinearReluFn(torch.autograd.Function):
         if ws is None:
             ws = torch.empty(lib.gnbv_linear_workspace_bytes(m, n, k), dtype=torch.uint8, device=x.device)
             _ws_cache[key] = ws
+        if ctx.fold_p:
+            assert not fp32_arith
+            sc = bn_state.data_ptr() + 4 * 64
+            if owed_adam is not None:
+                _lib.check(lib.gnbv_linear_forward_fold_adam(x.data_ptr(), sc, sc + 4 * 16, ctx.fold_p, _lib.ptr(range_flag), w.data_ptr(), b.data_ptr(), m, n, k,
+                                                             1, out.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(owed_adam), _lib.stream_ptr(x.device)),
+                           "gnbv_linear_forward_fold_adam")
+            else:
+                _lib.check(lib.gnbv_linear_forward_fold(x.data_ptr(), sc, sc + 4 * 16, ctx.fold_p, _lib.ptr(range_flag), w.data_ptr(), b.data_ptr(), m, n, k, 1,
+                                                        out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(x.device)), "gnbv_linear_forward_fold")
+            ctx.save_for_backward(x, w, out, bn_state)
+            return out
         _lib.check(lib.gnbv_linear_forward(x.data_ptr(), w.data_ptr(), b.data_ptr(), m, n, k, 1 | (2 if fp32_arith else 0), out.data_ptr(), ws.data_ptr(),
                                            ws.numel(), _lib.stream_ptr(x.device)), "gnbv_linear_forward")
         ctx.save_for_backward(x, w, out)
@@ -252,7 +276,8 @@ class _LinearReluFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out):
-        x, w, out = ctx.saved_tensors
+        x, w, out = ctx.saved_tensors[:3]
+        bn_state = ctx.saved_tensors[3] if ctx.fold_p else None
         mod = ctx.mod
         direct = mod is not None and mod.weight.grad is not None and mod.bias.grad is not None
         defer = direct and getattr(mod, "_async_wgrad", False) and getattr(mod, "_defer_wgrad", False)
@@ -291,6 +316,11 @@ class _LinearReluFn(torch.autograd.Function):
                 mod._dw_sq_written = sq is not None
 
             def launch_dw():
+                if bn_state is not None:
+                    sc = bn_state.data_ptr() + 4 * 64
+                    _lib.check(lib.gnbv_linear_bwd_dw_fold(ws.data_ptr(), x.data_ptr(), sc, sc + 4 * 16, ctx.fold_p, m, n, k, dw.data_ptr(), _lib.ptr(sq),
+                                                           _lib.stream_ptr(dev)), "gnbv_linear_bwd_dw_fold")
+                    return
                 if sq is not None:
                     _lib.check(lib.gnbv_linear_bwd_dw_sq(ws.data_ptr(), x.data_ptr(), m, n, k, dw.data_ptr(), sq.data_ptr(), _lib.stream_ptr(dev)),
                                "gnbv_linear_bwd_dw_sq")
@@ -299,12 +329,15 @@ class _LinearReluFn(torch.autograd.Function):
             if defer:
                 evt = torch.cuda.Event()
                 evt.record(torch.cuda.current_stream(dev))  # (dW needs prep's images only, not the dx product)
-                _deferred_wgrad.append((launch_dw, (x, ws), evt))
+                _deferred_wgrad.append((launch_dw, (x, ws) if bn_state is None else (x, ws, bn_state), evt))
             else:
                 launch_dw()
-            return (dx, None, None, None, None) if direct else (dx, dw, db, None, None)
+            return (dx, None, None) + (None,) * 6 if direct else (dx, dw, db) + (None,) * 6
         if mod is not None:
             mod._dw_sq_written = False
+        if bn_state is not None:  # (shapes outside the hand-written backward: the activations once, in torch)
+            c = k // ctx.fold_p
+            x = torch.relu(x.view(m, c, ctx.fold_p) * bn_state[64:64 + c].view(1, c, 1) + bn_state[64 + 16:64 + 16 + c].view(1, c, 1)).view(m, k)
         g = torch.ops.aten.threshold_backward(d_out.contiguous(), out, 0.0)
         if defer:
             # Nothing downstream of this node needs dW / db (only the optimizer does): they are computed on a second stream
@@ -321,13 +354,13 @@ class _LinearReluFn(torch.autograd.Function):
                 torch.sum(g, 0, out=mod.bias.grad)
             _deferred_wgrad.append((launch_lib, (g, x), evt))
             dx = g @ w if ctx.needs_input_grad[0] else None
-            return dx, None, None, None, None
+            return (dx, None, None) + (None,) * 6
         dx = g @ w if ctx.needs_input_grad[0] else None
         if direct:
             torch.mm(g.t(), x, out=mod.weight.grad)
             torch.sum(g, 0, out=mod.bias.grad)
-            return dx, None, None, None, None
-        return dx, g.t() @ x, g.sum(0), None, None
+            return (dx, None, None) + (None,) * 6
+        return (dx, g.t() @ x, g.sum(0)) + (None,) * 6
 
 
 _deferred_wgrad = []
@@ -349,13 +382,28 @@ def join_async_wgrads(device) -> None:
     cur.wait_stream(side)
 
 
-def linear_relu(x: torch.Tensor, lin: torch.nn.Linear) -> torch.Tensor:
-    """Linear + ReLU of the K-dominated fc layer (hybrid_encoder.py:39-42 of the reference)."""
+def linear_relu(x: torch.Tensor, lin: torch.nn.Linear, fold=None, owed_adam=None) -> torch.Tensor:
+    """Linear + ReLU of the K-dominated fc layer (hybrid_encoder.py:39-42 of the reference).  fold = (bn_state, P, range_flag) from
+    grid_encoder(..., fold=True) after linear_fold_ok(...): x is the conv stack's raw output, BatchNorm-2 + ReLU happen in the operand load."""
     n, k = lin.weight.shape
+    if fold is not None:  # (owed_adam: a _lib.GnbvOwedAdam -- the weight's pending optimizer update, applied by the forward kernel)
+        return _LinearReluFn.apply(x, lin.weight, lin.bias, lin if getattr(lin, "_grad_write_through", False) else None, False, fold[0], fold[1], fold[2],
+                                   owed_adam)
+    assert owed_adam is None
     if k % 4 or n % 64 or not lin.weight.is_contiguous() or x.dtype != torch.float32:
         return torch.relu(torch.nn.functional.linear(x, lin.weight, lin.bias))
     return _LinearReluFn.apply(x, lin.weight, lin.bias, lin if getattr(lin, "_grad_write_through", False) else None,
                                bool(getattr(lin, "_fp32_arith", False)))
+
+
+def linear_fold_ok(lin: torch.nn.Linear, m: int, p: int, force_fp32: bool) -> bool:
+    """Can fc layer `lin` take its input as (pre-BatchNorm activations, scale, shift) -- linear_relu(..., fold=...)?"""
+    n, k = lin.weight.shape
+    if force_fp32 or getattr(lin, "_fp32_arith", False) or os.environ.get("GENNBV_FC_FOLD", "1") == "0":
+        return False
+    if n % 64 or not lin.weight.is_contiguous() or lin.weight.dtype != torch.float32:
+        return False
+    return bool(_lib.load().gnbv_linear_fold_ok(int(m), int(n), int(k), int(p)))
 
 
 def hybrid_forward(enc, observations) -> torch.Tensor:
@@ -424,18 +472,30 @@ def hybrid_branches(enc, observations):
     else:
         feature_action = pose_branch()
         feature_sem = semantic_features(enc, observations) if getattr(enc, "semantic_branch", False) else None
+    p2 = conv_out(conv_out(g)) ** 3
+    fold = linear_fold_ok(enc.output_layer_grid[0], num_env, p2, getattr(enc, "force_fp32", False))
     feature_grid = grid_encoder(base, rows, s, g, enc.naive_encoder_grid, enc.training, getattr(enc, "_bn_skip_flag", None),
                                 enc.compute_dtype == torch.bfloat16, getattr(enc, "_grad_write_through", False), grid_i8, compact, autocorr,
                                 getattr(enc, "_dp_sync", None),
                                 (getattr(enc, "force_fp32", False), getattr(enc, "_range_flag", None),
-                                 getattr(enc, "_autocorr_total", None) if (enc.training and autocorr is not None) else None))
+                                 getattr(enc, "_autocorr_total", None) if (enc.training and autocorr is not None) else None), fold)
+    fold_args = None
+    if fold:  # (y2, bn_state): BatchNorm-2 + ReLU are formed inside fc_grid's kernels
+        feature_grid, bn_state = feature_grid
+        fold_args = (bn_state, p2, getattr(enc, "_range_flag", None))
     if getattr(enc, "_split_backward", False) and torch.is_grad_enabled():
         # data-parallel: cut the autograd graph at the conv-stack output so that the backward runs in
         # two phases (late layers first, their gradient all-reduce overlaps the conv-stack backward)
         enc._grid_feats_out = feature_grid
         feature_grid = feature_grid.detach().requires_grad_(True)
         enc._grid_feats_leaf = feature_grid
-    feature_grid = linear_relu(feature_grid, enc.output_layer_grid[0])  # Linear + ReLU, split-K MFMA kernel
+    # fc_grid.weight's optimizer update of the PREVIOUS minibatch, owed to this forward (sb3/ppo_grid_obs.py: FlatAdam.step(owe_slice)):
+    # applied by the kernel that streams the weight (gnbv_linear_forward_fold_adam)
+    owed = getattr(enc, "_fc_owed_adam", None)
+    if owed is not None:
+        enc._fc_owed_adam = None
+        assert fold_args is not None, "the caller checks linear_fold_ok before it leaves an update to this forward"
+    feature_grid = linear_relu(feature_grid, enc.output_layer_grid[0], fold_args, owed)  # Linear + ReLU, split-K MFMA kernel
     if side is not None:
         # Launch order matters under hipGraph replay: the executor keeps a node on the queue of the FIRST child captured after
         # its parent, so with the pose branch captured first the conv chain -- the critical path -- was moved to a second queue and

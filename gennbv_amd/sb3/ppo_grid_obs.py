@@ -392,6 +392,11 @@ class PPO_Grid_Obs:
                 parts = int(_lib.load().gnbv_linear_bwd_dw_sq_parts(int(lin.weight.shape[1])))
                 lin._dw_sq_partial = torch.zeros(parts, dtype=torch.float64, device=self.device)
                 self._hip["sq_slice"] = (sl[0], sl[1], lin._dw_sq_partial)
+            # GENNBV_ADAM_FUSE=1 (opt-in; measured SLOWER, profiles/r03_notes.md): its Adam update (392 MB of HBM traffic, ~68 us) is
+            # OWED to the next minibatch's fc_grid forward, the kernel that next streams that weight (FlatAdam.step(owe_slice=...) ->
+            # gnbv_linear_forward_fold_adam; settled by a launch of its own at the end of train()).  One GPU only as well.
+            if (self._sync is None or not self._sync.active) and sl is not None and sl[0] % 4 == 0 and os.environ.get("GENNBV_ADAM_FUSE", "0") == "1":
+                self._hip["owe_fc"] = (sl[0], sl[1])
         return self._hip
 
     def _hip_minibatch_body(self, st, phase: str = "all"):
@@ -411,6 +416,15 @@ class PPO_Grid_Obs:
                             None if buf.grid_i8 is None else buf.grid_i8[:t].view(t * n, -1), buf.compact_state_dim,
                             None if buf.autocorr is None else buf.autocorr[:t].view(t * n, -1))
             enc = pol.features_extractor
+            if phase == "all" and st.get("owe_fc") is not None:
+                # the previous minibatch's update of fc_grid.weight rides this minibatch's fc_grid forward (encoder_ops.hybrid_branches
+                # -> gnbv_linear_forward_fold_adam); shapes that kernel does not take: as a launch of its own, here
+                lin_ = enc.output_layer_grid[0]
+                p2_ = encoder_ops.conv_out(encoder_ops.conv_out(enc.grid_size)) ** 3
+                if int(loss.batch) <= 128 and encoder_ops.linear_fold_ok(lin_, int(loss.batch), p2_, getattr(enc, "force_fp32", False)):
+                    enc._fc_owed_adam = opt.owed_adam(st["owe_fc"])
+                else:
+                    opt.slice_step_pending(st["owe_fc"])
             enc._defer_pose_backward = True  # only inside this body: it calls encoder_ops.pose_branch_backward after its backward
             if st.get("fused_head"):
                 fa, fg = encoder_ops.hybrid_branches(enc, obs)
@@ -436,7 +450,7 @@ class PPO_Grid_Obs:
                 if self._sync is None or not self._sync.active:
                     sq = st.get("sq_slice") if (lin is not None and getattr(lin, "_dw_sq_written", False)) else None
                     opt.step(self.max_grad_norm, loss.stop_flag, rotate=st.get("rows_rot"), sq_slice=sq,
-                             loss_finish=loss.args if loss.args.defer_stats else None)
+                             loss_finish=loss.args if loss.args.defer_stats else None, owe_slice=st.get("owe_fc"))
                 return
             # the forward cut the graph at the conv-stack output (enc._split_backward): this backward
             # stops at that leaf and fills the gradients of every non-conv parameter
@@ -607,26 +621,29 @@ class PPO_Grid_Obs:
         if rotating:
             loss.rows_ext.copy_(rot[0][0])
         epochs_run = 0
-        for epoch in range(self.n_epochs):
-            for k in range(n_mb):
-                if not rotating:
-                    loss.rows.copy_(rows_all[k * batch:(k + 1) * batch])
-                if dp_stats:
-                    st["adv_cur"].copy_(adv_tab[k])
-                    st["ac_cur"].copy_(ac_tab[k])
-                if dp:
-                    self._dp_minibatch(st, use_graph)
-                elif use_graph:
-                    st["graph"].replay()
-                else:
-                    self._hip_minibatch_body(st)
-            epochs_run += 1
-            # the ONLY read-back inside train(): early-stop flag, once per epoch (the reference
-            # reads approx_kl on the host after every minibatch, :261-268)
-            if self.target_kl is not None and int(loss.stop_flag.item()) != 0:
-                if self.verbose >= 1:
-                    print(f"Early stopping at step {epoch} due to reaching max kl")
-                break
+        try:
+            for epoch in range(self.n_epochs):
+                for k in range(n_mb):
+                    if not rotating:
+                        loss.rows.copy_(rows_all[k * batch:(k + 1) * batch])
+                    if dp_stats:
+                        st["adv_cur"].copy_(adv_tab[k])
+                        st["ac_cur"].copy_(ac_tab[k])
+                    if dp:
+                        self._dp_minibatch(st, use_graph)
+                    elif use_graph:
+                        st["graph"].replay()
+                    else:
+                        self._hip_minibatch_body(st)
+                epochs_run += 1
+                # the ONLY read-back inside train(): early-stop flag, once per epoch (the reference
+                # reads approx_kl on the host after every minibatch, :261-268)
+                if self.target_kl is not None and int(loss.stop_flag.item()) != 0:
+                    if self.verbose >= 1:
+                        print(f"Early stopping at step {epoch} due to reaching max kl")
+                    break
+        finally:
+            opt.settle_owed_slice()  # (the last minibatch's update of fc_grid.weight, owed to a next minibatch that does not come)
         self._n_updates += self.n_epochs
         self.policy.features_extractor._autocorr_total = None  # (the slot holds the LAST minibatch's total: never for another caller)
         self._check_ranges()  # raises if a kernel of this call reached an activation bound of the split-f16 arithmetic

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNBV_ABI_VERSION 2
+#define GNBV_ABI_VERSION 3
 
 int gnbv_abi_version(void);
 /* Name of the device architecture the library was compiled for ("gfx950"). [host] */
@@ -310,7 +310,8 @@ size_t gnbv_encoder_y1_elems(int batch, int grid);
  * bn_state: 128 floats [2][4][16] (scale, shift, mean, rstd per layer) + 768 ints (the minibatch total of the input
  * autocorrelation, written when the forward derived BatchNorm-1's statistics from it and read back by the backward):
  * 896 four-byte words.
- * features [B, 16*O2^3] is the reference's `naive_encoder_grid(x).reshape(num_env, -1)`. */
+ * features [B, 16*O2^3] is the reference's `naive_encoder_grid(x).reshape(num_env, -1)`; NULL: not written (the BatchNorm-2 + ReLU pass is
+ * left to gnbv_linear_forward_fold / gnbv_linear_bwd_dw_fold, which form the activations from y2 and bn_state in registers). */
 int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *rows, int64_t row_stride, int batch, int grid,
                               const GnbvEncoderParams *params /*[host]*/, int training, const int *skip_flag, void *y1,
                               float *y2, float *bn_state, float *features, void *workspace, size_t workspace_bytes,
@@ -353,6 +354,40 @@ int gnbv_linear_bwd_dw(const void *workspace, const float *x, int M, int N, int 
  *     this -- by far the largest -- gradient. */
 int gnbv_linear_bwd_dw_sq_parts(int K);
 int gnbv_linear_bwd_dw_sq(const void *workspace, const float *x, int M, int N, int K, float *dw, double *sq_partial, void *stream);
+
+/* B1  fc_grid with BatchNorm-2 + ReLU folded into its operand load (round 3; replaces Hybrid_Encoder.naive_encoder_grid[4:6] +
+ *     output_layer_grid, gennbv/network/hybrid_encoder.py:40-49, as ONE product): x[m][k] = relu(scale[k / P] y[m][k] +
+ *     shift[k / P]) is formed in registers from the conv stack's raw output y [M][K] (K = channels x P), the 4 K M bytes of
+ *     normalised activations are never written or re-read.  Same arithmetic as gnbv_encoder_forward's k_bn_relu_apply followed by
+ *     gnbv_linear_forward / gnbv_linear_bwd_dw_sq (one fma + one max in fp32, then the same split-f16 product): bit-identical
+ *     results.  scale / shift: GnbvEncoderParams.bn_state + 4 x 16 and + 5 x 16 floats (layer 2) of the forward call that wrote
+ *     y (features == NULL in gnbv_encoder_grid_forward skips that call's own BN2 + ReLU pass).  *range_flag (may be NULL): bit 4 when an
+ *     operand passes 1000 (the f16 split clamps at 1015).  gnbv_linear_fold_ok: 1 when (M, N, K, P) can take this path
+ *     (P >= 512, K % P == 0, split kernels on); otherwise materialise the activations (features != NULL) as before.
+ *     d/dy of the product = the existing gnbv_linear_bwd_dx (d/dx) followed by gnbv_encoder_backward (whose BN2 backward takes
+ *     d/dx and y, never x). */
+int gnbv_linear_fold_ok(int M, int N, int K, int P);
+int gnbv_linear_forward_fold(const float *y, const float *scale, const float *shift, int P, int *range_flag, const float *w, const float *bias,
+                             int M, int N, int K, int relu, float *out, void *workspace, size_t workspace_bytes, void *stream);
+int gnbv_linear_bwd_dw_fold(const void *workspace, const float *y, const float *scale, const float *shift, int P, int M, int N, int K, float *dw,
+                            double *sq_partial /*NULL: none*/, void *stream);
+
+/* ... and with the layer's OWED optimizer update applied on the way (round 3): the previous step's gnbv_clip_adam_step_ex skipped this
+ * weight (GnbvAdamStep.upd_skip_lo / hi = its slice of the flat buffers, .pending) and the forward that next reads the weight applies
+ * clip + Adam to every element as it streams it -- each element is staged by exactly one thread of the launch (M <= 128) --, writes
+ * weight / exp_avg / exp_avg_sq back and multiplies with the NEW weight.  Same expressions as the optimizer launch: bit-identical
+ * parameters and moments; the update's 28 bytes per parameter ride the product's weight stream instead of a launch of their own
+ * (~65 us at 13.8 M parameters) in front of it.  Nothing happens to the weight when *pending == 0 (first minibatch of a train() call,
+ * update masked by the KL stop).  The pointers are the SLICE's (flat buffer + slice offset); norm_out / step / pending as left by the
+ * owing gnbv_clip_adam_step_ex.  After the last minibatch: gnbv_adam_slice_pending. */
+typedef struct GnbvOwedAdam {
+    const float *grads; float *exp_avg, *exp_avg_sq;
+    const float *norm_out; const int64_t *step; const int *pending;
+    float lr, beta1, beta2, eps;
+} GnbvOwedAdam;
+int gnbv_linear_forward_fold_adam(const float *y, const float *scale, const float *shift, int P, int *range_flag, float *w, const float *bias,
+                                  int M, int N, int K, int relu, float *out, void *workspace, size_t workspace_bytes,
+                                  const GnbvOwedAdam *adam /*[host]*/, void *stream);
 
 /* B1  pose-history input (gennbv/network/hybrid_encoder.py:63-74 positional_encoding with 2 frequency bands, :78-80): the state
  *     columns [0, 6 n_pose) of observation rows `rows` (NULL: rows 0 .. batch-1) of `base` (row stride in floats) ->
@@ -499,9 +534,17 @@ typedef struct GnbvAdamStep {
                                            step counter) -- same stop_flag as this call's */
     int64_t upd_skip_lo, upd_skip_hi;   /* parameters [upd_skip_lo, upd_skip_hi) are NOT updated by this call (their gradient still
                                            counts for the norm through sq_partial): a slice whose update is sharded over the
-                                           data-parallel replicas, gnbv_adam_shard_step */
+                                           data-parallel replicas, gnbv_adam_shard_step -- or owed to a later launch, `pending` */
+    int *pending;                       /* NULL, or [device] <- 1 when this call applied its update (the skipped slice is then owed to
+                                           gnbv_adam_slice_pending), 0 when the update was masked by stop_flag */
 } GnbvAdamStep;
 int gnbv_clip_adam_step_ex(const GnbvAdamStep *a /*[host]*/, void *stream);
+/* The update of a slice the step's main call skipped (upd_skip_lo / hi + pending), as a launch of its own: after the LAST minibatch of
+ * a train() call (inside the call the next minibatch's fc_grid forward applies it on the way: gnbv_linear_forward_fold_adam).  Runs
+ * iff *pending != 0, with the clip factor norm_out[1] and the step counter the owing call left; the caller clears *pending
+ * afterwards.  Bit-identical to the update gnbv_clip_adam_step_ex would have applied. */
+int gnbv_adam_slice_pending(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const float *norm_out,
+                            float lr, float beta1, float beta2, float eps, const int64_t *step, const int *pending, void *stream);
 /* Adam on a shard of n parameters with the clip factor norm_out[1] that gnbv_clip_adam_step_ex of the SAME optimizer step left
  * behind (same step counter and stop flag, neither is modified). */
 int gnbv_adam_shard_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const float *norm_out,

@@ -558,3 +558,93 @@ def test_semantic_branch_forward_backward_vs_fp64(g, b):
                 err = float((r - res[name][1][k]).abs().max())
                 assert err <= 2e-5 * scale, (name, k, err, scale)
     assert float(res["ref"][1]["features_extractor.naive_encoder_rgb.0.weight"].abs().max()) > 0
+
+
+@pytest.mark.parametrize("g,b,train", [(64, 4, True), (64, 128, True), (64, 37, False), (128, 1, True)])
+def test_bn2_relu_folded_into_fc_grid_is_bit_identical(g, b, train, monkeypatch):
+    """Round 3: fc_grid's kernels form relu(bn2(y2)) in their operand loads (gnbv_linear_forward_fold / gnbv_linear_bwd_dw_fold)
+    instead of reading a materialised feature tensor (GENNBV_FC_FOLD=0: k_bn_relu_apply + the plain entry points).  Same fp32
+    fma + max, same split-f16 product: every output and every gradient must be IDENTICAL, bit for bit.  (One exception: batches the
+    hand-written backward does not take -- M % 16 != 0 -- form the activations in torch for the library GEMM, a multiply and an add
+    instead of one fma: fc_grid's weight gradient then agrees to an ulp of its operands.)"""
+    from gennbv_amd.ops import encoder_ops as eo
+    outs = []
+    for fold in ("1", "0"):
+        monkeypatch.setenv("GENNBV_FC_FOLD", fold)
+        hip, _, _ = pu.make_policy(g=g, device=DEV, backend="hip", det_weights=True)
+        enc = hip.features_extractor
+        assert eo.linear_fold_ok(enc.output_layer_grid[0], b, eo.conv_out(eo.conv_out(g)) ** 3, False) == (fold == "1")
+        obs = _obs(b, g, seed=5)
+        hip.set_training_mode(train)
+        if train:
+            hip.zero_grad()
+            f = enc(obs)
+            (f * torch.linspace(0.5, 1.5, f.shape[1], device=DEV)).sum().backward()
+            names = ["features"] + [n for n, _ in enc.named_parameters()] + [k for k in enc.state_dict() if "running" in k]
+            outs.append([f.detach().clone()] + [p.grad.detach().clone() for p in enc.parameters()]
+                        + [v.clone() for k, v in enc.state_dict().items() if "running" in k])
+        else:
+            names = ["features"]
+            with torch.no_grad():
+                outs.append([enc(obs).clone()])
+        assert int(enc._range_flag.item()) == 0
+    assert len(outs[0]) == len(outs[1]) == len(names)
+    for n, a, r in zip(names, *outs):
+        if n == "output_layer_grid.0.weight" and b % 16:
+            assert float((a - r).abs().max()) <= 2e-7 * float(r.abs().max()), n
+        else:
+            assert torch.equal(a, r), n
+
+
+@pytest.mark.parametrize("m,pending", [(128, 1), (128, 0), (48, 1)])
+def test_fc_grid_forward_applies_the_owed_adam_update_bit_identically(m, pending):
+    """gnbv_linear_forward_fold_adam == gnbv_adam_slice_pending followed by gnbv_linear_forward_fold: the same parameters, moments and
+    outputs, bit for bit (each weight element is updated by the one thread that stages it); *pending == 0: nothing moves."""
+    import ctypes as C
+    from gennbv_amd import _lib
+    lib = _lib.load()
+    n, ch, p = 256, 16, 3375
+    k = ch * p
+    gen = torch.Generator(device=DEV).manual_seed(7 + m)
+    rnd = lambda *s: torch.randn(*s, generator=gen, device=DEV)  # noqa: E731
+    y = rnd(m, k)
+    bn_state = torch.zeros(896, device=DEV)
+    bn_state[64:80] = torch.rand(16, generator=gen, device=DEV) + 0.5
+    bn_state[80:96] = rnd(16) * 0.3
+    w0, bias = rnd(n, k) * 0.01, rnd(n) * 0.1
+    g0, m0, v0 = rnd(n, k) * 1e-3, rnd(n, k) * 1e-4, torch.rand(n, k, generator=gen, device=DEV) * 1e-6
+    norm_out = torch.tensor([3.0, 0.1666], device=DEV)
+    step = torch.tensor([5], dtype=torch.int64, device=DEV)
+    pend = torch.tensor([pending], dtype=torch.int32, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ws = torch.empty(lib.gnbv_linear_workspace_bytes(m, n, k), dtype=torch.uint8, device=DEV)
+    sc = bn_state.data_ptr() + 4 * 64
+    hyper = (3e-4, 0.9, 0.999, 1e-5)
+    res = []
+    for fused in (False, True):
+        w, mm, vv = w0.clone(), m0.clone(), v0.clone()
+        out = torch.empty(m, n, device=DEV)
+        if fused:
+            a = _lib.GnbvOwedAdam()
+            a.grads, a.exp_avg, a.exp_avg_sq = g0.data_ptr(), mm.data_ptr(), vv.data_ptr()
+            a.norm_out, a.step, a.pending = norm_out.data_ptr(), step.data_ptr(), pend.data_ptr()
+            a.lr, a.beta1, a.beta2, a.eps = hyper
+            _lib.check(lib.gnbv_linear_forward_fold_adam(y.data_ptr(), sc, sc + 64, p, flag.data_ptr(), w.data_ptr(), bias.data_ptr(), m, n, k, 1, out.data_ptr(),
+                                                         ws.data_ptr(), ws.numel(), C.byref(a), None), "fold_adam")
+        else:
+            _lib.check(lib.gnbv_adam_slice_pending(w.data_ptr(), g0.data_ptr(), mm.data_ptr(), vv.data_ptr(), n * k, norm_out.data_ptr(), *hyper,
+                                                   step.data_ptr(), pend.data_ptr(), None), "slice_pending")
+            _lib.check(lib.gnbv_linear_forward_fold(y.data_ptr(), sc, sc + 64, p, flag.data_ptr(), w.data_ptr(), bias.data_ptr(), m, n, k, 1, out.data_ptr(),
+                                                    ws.data_ptr(), ws.numel(), None), "fold")
+        torch.cuda.synchronize()
+        res.append((w, mm, vv, out))
+    for name, a_, b_ in zip(("weight", "exp_avg", "exp_avg_sq", "out"), *res):
+        assert torch.equal(a_, b_), name
+    assert torch.equal(res[0][0], w0) == (pending == 0)
+    # and the update itself is torch.optim.Adam's (clip factor applied to the gradient first)
+    if pending:
+        gi = g0.double() * float(norm_out[1])
+        m_ref = m0.double() + (gi - m0.double()) * (1 - 0.9)
+        v_ref = v0.double() * 0.999 + (1 - 0.999) * gi * gi
+        p_ref = w0.double() - (3e-4 / (1 - 0.9 ** 5)) * m_ref / (v_ref.sqrt() / (1 - 0.999 ** 5) ** 0.5 + 1e-5)
+        assert float((res[1][0].double() - p_ref).abs().max()) < 1e-7

@@ -132,6 +132,32 @@ def test_flat_adam_matches_torch_adam_with_clipping():
         o1.step(); o2.step(1.0, sq_slice=(lo + 4, hi - 3, part))
     for a, b in zip(m1.parameters(), m2.parameters()):
         torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6)
+    # GnbvAdamStep.pending / gnbv_adam_slice_pending: the update of one slice owed to a LATER launch (the trainer puts it beside the next
+    # minibatch's conv forward) -- step(owe_slice) + slice_step_pending() == step(), bit for bit, incl. the masked step in between
+    m3 = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.Linear(19, 5)).to(DEV)
+    m3.load_state_dict({k: v.clone() for k, v in m2.state_dict().items()})
+    o3 = FlatAdam(m3, lr=3e-3, eps=1e-5)
+    for t_src, t_dst in ((o2.exp_avg, o3.exp_avg), (o2.exp_avg_sq, o3.exp_avg_sq), (o2.step_count, o3.step_count)):
+        t_dst.copy_(t_src)
+    assert torch.equal(o2.params, o3.params)
+    stop2, stop3 = torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+    for it in range(4):
+        o3.slice_step_pending()       # (what the previous step owes; a no-op the first time and after the masked step)
+        o2.zero_grad(); o3.zero_grad()
+        (m2(x) ** 2).sum().backward(); (m3(x) ** 2).sum().backward()
+        stop2.fill_(int(it == 2)); stop3.fill_(int(it == 2))  # step 2 is masked: nothing is owed after it
+        w3 = m3[0].weight.detach().clone()
+        o2.step(1.0, stop2)
+        o3.step(1.0, stop3, owe_slice=(lo, hi))
+        assert torch.equal(m3[0].weight, w3)  # the owing launch leaves the slice alone ...
+        assert int(o3.pending.item()) == int(it != 2)
+        assert torch.equal(o2.params[hi:], o3.params[hi:])  # ... and updates everything else
+    o3.settle_owed_slice()
+    assert int(o3.pending.item()) == 0
+    for t2, t3 in ((o2.params, o3.params), (o2.exp_avg, o3.exp_avg), (o2.exp_avg_sq, o3.exp_avg_sq), (o2.step_count, o3.step_count)):
+        assert torch.equal(t2, t3)
+    o3.slice_step_pending()  # nothing owed: nothing moves
+    assert torch.equal(o2.params, o3.params)
 
 
 @pytest.mark.parametrize("name,shard", [("F9_ppo_train", False), ("F9_ppo_train_earlystop", False), ("F9_ppo_train", True), ("F9_ppo_train_earlystop", True)])

@@ -134,7 +134,7 @@ def test_bn1_gamma_x300_precheck_and_device_flag():
 
 
 def test_features_above_the_fc_input_clamp_raise():
-    """BatchNorm-2 gamma x 3000: fc_grid's inputs exceed 1000 -> bit 4 of the flag (k_bn_relu_apply) -> GennbvHipError; the
+    """BatchNorm-2 gamma x 3000: fc_grid's inputs exceed 1000 -> bit 4 of the flag (fc_grid's operand load, or k_bn_relu_apply when the fold is off) -> GennbvHipError; the
     repeat (fp32 linear kernel, no clamp) is exact."""
     from gennbv_amd._lib import GennbvHipError
 
