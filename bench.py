@@ -459,13 +459,16 @@ def main():
                    "kl_early_stop": "reference (0.05)" if args.target_kl == "ref" else "never triggers (full work every iteration)",
                    "minibatches_last_iteration": int(len(algo.last_train_stats)) if getattr(algo, "last_train_stats", None) is not None else None,
                    "hbm_peak_allocated_gb": torch.cuda.max_memory_allocated(device) / 1e9,
+                   "fc_grid_adam": {None: "inside the optimizer launch", "side": "owed to the next minibatch: second stream, beside its conv forward",
+                                    "fuse": "owed to the next minibatch's fc_grid forward kernel"}[(algo._hip or {}).get("owe_mode")],
                    "parallelism": f"env-sharded dp{world}", "dp_graph_mode": getattr(algo, "dp_graph_mode", None),
                    "dp_update": (None if world == 1 else "fc_grid.weight reduce-scattered, updated by its owner rank, all-gathered; the rest all-reduced"
                                  if getattr((algo._hip or {}).get("opt"), "shard", None) is not None else "whole gradient all-reduced, replicated update"),
                    "breakdown_ms_per_step": {"rollout": phases["rollout"].total_ms() / args.steps,
                                              "train": phases["train"].total_ms() / args.steps,
                                              "voxel_update_total": vox.total_ms() / args.steps}},
-        "roofline": {"bound": "hbm", "kernel": "gnbv_update_occ_grid_coded (k_hit_list + k_ray_list + k_grid_update_coded, which also clears the masks it consumed; 1-byte coded probability grid)",
+        "roofline": {"bound": "hbm", "kernel": ("gnbv_update_occ_grid_coded (" + ("k_hit_list + k_ray_list" if args.grid <= 104 else "k_hit_atomic + k_ray_slab") +
+                                                " + k_grid_update_coded, which also clears the masks it consumed; 1-byte coded probability grid)"),
                      "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                      "launch_ms": vox_ms, "algorithmic_bytes_per_launch": args.envs * b_lay,
                      "bytes_basis": "this layout's compulsory HBM bytes (depth + seg, 1-byte code R+W, int8 tri-class W, 7 bitmask passes, ray lists)",

@@ -552,7 +552,10 @@ __device__ __forceinline__ void prep_w2_dgrad_split_item(int i, const float *__r
 
 // definition of the hooks the conv1 forward kernels / k_bn1_analytic call (declared in encoder.hip in front of them): items
 // first, first + stride, ...
-__device__ void prep_w2_split_items(const float *__restrict__ W2, float *__restrict__ w2img, int first, int stride)
+// WIDE: the caller is a launch of its own on a critical path (k_bn1_analytic's extra workgroups, k_prep_w2_split_only), not a conv kernel
+// that writes the images in passing (whose register budget the wide form of the bound sums would break)
+template <bool WIDE>
+__device__ __forceinline__ void prep_w2_split_items(const float *__restrict__ W2, float *__restrict__ w2img, int first, int stride)
 {
     uint4 *img = reinterpret_cast<uint4 *>(w2img + 2 * kTaps * 256);  // EncWs::w2split
     constexpr int kImgItems = (split::kKSteps + dsplit::kSets * dsplit::kKSteps) * 64;
@@ -565,9 +568,32 @@ __device__ void prep_w2_split_items(const float *__restrict__ W2, float *__restr
             // sum |W2[co][ci][tap]| over the 16 co and the taps of parity class e: bounds |dz1| / max |dy2| for (ci, e); the data-gradient
             // kernel takes the maximum to scale the layer-1 gradient into f16 range for its second contraction
             const int j = i - kImgItems, ci = j & 15, e = j >> 4;
+            const int nt = dsplit::ntaps(e);
             float a = 0.0f;
-            for (int q = 0; q < dsplit::ntaps(e); ++q)
-                for (int co = 0; co < kC; ++co) a += fabsf(W2[((size_t)co * kC + ci) * kTaps + dsplit::tap_index(e, q)]);
+            if (WIDE) {
+                // four taps = 64 loads requested before the first addition (same order of additions as the plain double loop, whose
+                // load -> add chains were up to 128 dependent round trips on the critical path of the forward's first launch)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (4 * h < nt) {
+                        float v[4][kC];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int tq = dsplit::tap_index(e, 4 * h + q < nt ? 4 * h + q : nt - 1);
+#pragma unroll
+                            for (int co = 0; co < kC; ++co) v[q][co] = W2[((size_t)co * kC + ci) * kTaps + tq];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int co = 0; co < kC; ++co)
+                                if (4 * h + q < nt) a += fabsf(v[q][co]);
+                    }
+                }
+            } else {
+                for (int q = 0; q < nt; ++q)
+                    for (int co = 0; co < kC; ++co) a += fabsf(W2[((size_t)co * kC + ci) * kTaps + dsplit::tap_index(e, q)]);
+            }
             reinterpret_cast<float *>(img + split::kW2ImgU4 + dsplit::kImgSlotU4)[j] = a;
         }
     }
@@ -575,7 +601,7 @@ __device__ void prep_w2_split_items(const float *__restrict__ W2, float *__restr
 
 __device__ void prep_w2_split_in_passing(const float *__restrict__ W2, float *__restrict__ w2img)
 {
-    prep_w2_split_items(W2, w2img, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+    prep_w2_split_items<false>(W2, w2img, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 template <int TY>
@@ -948,7 +974,7 @@ constexpr int kLdsBytes = split::kStageBytes + split::kPadBytes + split::kRedByt
 
 __global__ void k_prep_w2_split_only(const float *__restrict__ W2, float *__restrict__ w2img)
 {
-    prep_w2_split_in_passing(W2, w2img);
+    prep_w2_split_items<true>(W2, w2img, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 template <bool TRAIN>

@@ -185,7 +185,8 @@ __global__ void k_prep_w2(const float *__restrict__ W2, float *__restrict__ img_
 // (the images only depend on W2: the conv1 forward kernel, which runs before every conv2 forward, writes them in
 // passing -- a few hundred extra stores in an HBM-bound launch instead of a dependent 5 us launch)
 __device__ void prep_w2_split_in_passing(const float *__restrict__ W2, float *__restrict__ w2img);  // conv_split.h: the f16 images of the split kernels
-__device__ void prep_w2_split_items(const float *__restrict__ W2, float *__restrict__ w2img, int first, int stride);
+template <bool WIDE>
+__device__ __forceinline__ void prep_w2_split_items(const float *__restrict__ W2, float *__restrict__ w2img, int first, int stride);
 __device__ __forceinline__ void prep_w2_in_passing(const float *__restrict__ W2, float *__restrict__ w2img)
 {
     if (W2 != nullptr) {
@@ -714,13 +715,13 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const T *__restrict__ p
 // Same sums in the same order (wave w of a slice adds rows p0 + w, p0 + w + 4, ... in fp64, then ((s0 + s1) + s2) + s3), four
 // columns per lane with 16-byte loads, eight rows requested before the first is added: the scalar form above ran the 14 MB of
 // the conv2 weight-gradient partials at 0.85 TB/s (a chain of dependent 4-byte loads per lane) on the update's critical path.
-__global__ __launch_bounds__(256) void k_reduce_partials4(const float *__restrict__ partial, int P, int E /* % 4 == 0 */, int per_slice,
-                                                          double *__restrict__ out_d)
+__device__ __forceinline__ void reduce_partials4_body(const float *__restrict__ partial, int P, int E /* % 4 == 0 */, int per_slice,
+                                                      double *__restrict__ out_d, int bx, int by)
 {
     __shared__ double s[4][64][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int e = (blockIdx.x * 64 + lane) * 4;
-    const int p0 = blockIdx.y * per_slice, p1 = min(P, p0 + per_slice);
+    const int e = (bx * 64 + lane) * 4;
+    const int p0 = by * per_slice, p1 = min(P, p0 + per_slice);
     const int ec = min(e, E - 4);
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     constexpr int kU = 8;
@@ -744,8 +745,28 @@ __global__ __launch_bounds__(256) void k_reduce_partials4(const float *__restric
     __syncthreads();
     if (e < E) {  // wave w finishes column e + w
         const double t = ((s[0][lane][wv] + s[1][lane][wv]) + s[2][lane][wv]) + s[3][lane][wv];
-        out_d[(size_t)blockIdx.y * E + e + wv] = t;
+        out_d[(size_t)by * E + e + wv] = t;
     }
+}
+
+__global__ __launch_bounds__(256) void k_reduce_partials4(const float *__restrict__ partial, int P, int E /* % 4 == 0 */, int per_slice,
+                                                          double *__restrict__ out_d)
+{
+    reduce_partials4_body(partial, P, E, per_slice, out_d, blockIdx.x, blockIdx.y);
+}
+
+// Two such reductions as ONE launch (the conv2 and the conv1 weight-gradient partials behind the data-gradient kernel: only the
+// optimizer reads either, so the first no longer sits between the two conv kernels).  Blocks [0, nbx_a) x [0, slices_a) are job a.
+struct ReduceJob {
+    const float *partial; int P, E, per_slice, slices, nbx; double *out;
+};
+__global__ __launch_bounds__(256) void k_reduce_partials4_x2(ReduceJob a, ReduceJob b)
+{
+    const bool first = (int)blockIdx.x < a.nbx;  // (workgroup-uniform)
+    const int bx = first ? blockIdx.x : blockIdx.x - a.nbx;
+    if ((int)blockIdx.y >= (first ? a.slices : b.slices)) return;
+    reduce_partials4_body(first ? a.partial : b.partial, first ? a.P : b.P, first ? a.E : b.E, first ? a.per_slice : b.per_slice, first ? a.out : b.out, bx,
+                          blockIdx.y);
 }
 
 // z2 = relu(scale2*y2 + shift2), y2 NCDHW [B,16,P2] -> flat features [B, 16*P2]
@@ -1175,10 +1196,10 @@ __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(2, 
 
 // partial-sum layout [tap][ci][co] (+16) -> torch layout dW2 [co][ci][27], db2 [16]
 // (+ the conv2 weight images for the data-gradient kernel that follows: saves a dependent launch)
-__global__ void k_conv2_wgrad_finish(const double *__restrict__ tmp /*[slices][E]*/, int slices, float *__restrict__ dW2,
-                                     float *__restrict__ db2, const float *__restrict__ W2, float *__restrict__ w2img)
+__device__ __forceinline__ void conv2_wgrad_finish_body(const double *__restrict__ tmp /*[slices][E]*/, int slices, float *__restrict__ dW2,
+                                                        float *__restrict__ db2, const float *__restrict__ W2, float *__restrict__ w2img, int i)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, E = kTaps * 256 + kC;
+    const int E = kTaps * 256 + kC;
     if (W2 != nullptr && i < kTaps * 256) prep_w2_element(i, W2, w2img, w2img + kTaps * 256);
     if (i >= E) return;
     double t = 0.0;
@@ -1190,6 +1211,11 @@ __global__ void k_conv2_wgrad_finish(const double *__restrict__ tmp /*[slices][E
     } else {
         db2[i - kTaps * 256] = (float)t;
     }
+}
+__global__ void k_conv2_wgrad_finish(const double *__restrict__ tmp /*[slices][E]*/, int slices, float *__restrict__ dW2,
+                                     float *__restrict__ db2, const float *__restrict__ W2, float *__restrict__ w2img)
+{
+    conv2_wgrad_finish_body(tmp, slices, dW2, db2, W2, w2img, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // The transposed conv as 8 sub-convolutions.  A "super-tile" (a, c, j0) is the 2 x 2 x 32 block of
@@ -1686,7 +1712,7 @@ __global__ __launch_bounds__(1024) void k_bn1_analytic(const int *__restrict__ a
                                                       int *__restrict__ range_flag = nullptr)
 {
     if (blockIdx.x > 0) {  // extra workgroups: the conv2 kernels' f16 weight images (when no conv1 kernel follows to write them in passing)
-        prep_w2_split_items(W2, w2img, (blockIdx.x - 1) * blockDim.x + threadIdx.x, (gridDim.x - 1) * blockDim.x);
+        prep_w2_split_items<true>(W2, w2img, (blockIdx.x - 1) * blockDim.x + threadIdx.x, (gridDim.x - 1) * blockDim.x);
         return;
     }
     __shared__ int Ri[kAcRow];
@@ -1727,7 +1753,7 @@ __global__ __launch_bounds__(1024) void k_bn1_analytic(const int *__restrict__ a
 // dW1, db1 and the BN affine gradients from the fused kernel's sums and the input autocorrelation (fp64).
 // One workgroup of 1024 threads.  ac: per-sample autocorrelation rows (gather_autocorr) or, with nrows == 0, the
 // minibatch total.
-__global__ __launch_bounds__(1024) void k_c1w_fused_finish(const double *__restrict__ tmp /*[slices][kE1F]*/, int slices, const int *__restrict__ ac,
+__device__ __forceinline__ void c1w_fused_finish_body(const double *__restrict__ tmp /*[slices][kE1F]*/, int slices, const int *__restrict__ ac,
                                                           int64_t ac_row_stride, const int64_t *__restrict__ rows, int nrows,
                                                           const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ scale1,
                                                           const float *__restrict__ rstd1, const float *__restrict__ gamma1 /*NULL unless z1 mode*/,
@@ -1794,6 +1820,37 @@ __global__ __launch_bounds__(1024) void k_c1w_fused_finish(const double *__restr
         g2b[co] = (float)S2[co];
         g2w[co] = (float)S2[kC + co];
     }
+}
+
+__global__ __launch_bounds__(1024) void k_c1w_fused_finish(const double *__restrict__ tmp /*[slices][kE1F]*/, int slices, const int *__restrict__ ac,
+                                                          int64_t ac_row_stride, const int64_t *__restrict__ rows, int nrows,
+                                                          const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ scale1,
+                                                          const float *__restrict__ rstd1, const float *__restrict__ gamma1 /*NULL unless z1 mode*/,
+                                                          const float *__restrict__ beta1, float *__restrict__ dW1, float *__restrict__ db1,
+                                                          const double *__restrict__ S2 /*BN2 sums*/, float *g1w, float *g1b, float *g2w,
+                                                          float *g2b, const double *__restrict__ S1g /*NULL, or [2][16]: BN1-backward sums over ALL replicas*/,
+                                                          const int *__restrict__ ac_global /*NULL, or the global autocorrelation total*/)
+{
+    c1w_fused_finish_body(tmp, slices, ac, ac_row_stride, rows, nrows, W1, scale1, rstd1, gamma1, beta1, dW1, db1, S2, g1w, g1b, g2w, g2b, S1g, ac_global);
+}
+
+// The same finish as workgroup 0 of a launch whose other workgroups finish the conv2 weight gradient (k_conv2_wgrad_finish's sums,
+// 1024 elements each): one launch behind the data-gradient kernel instead of one on either side of it.
+__global__ __launch_bounds__(1024) void k_wgrad_finish_both(const double *__restrict__ tmp2 /*[slices2][27 * 256 + 16]*/, int slices2, float *__restrict__ dW2,
+                                                           float *__restrict__ db2, const double *__restrict__ tmp /*[slices][kE1F]*/, int slices, const int *__restrict__ ac,
+                                                          int64_t ac_row_stride, const int64_t *__restrict__ rows, int nrows,
+                                                          const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ scale1,
+                                                          const float *__restrict__ rstd1, const float *__restrict__ gamma1 /*NULL unless z1 mode*/,
+                                                          const float *__restrict__ beta1, float *__restrict__ dW1, float *__restrict__ db1,
+                                                          const double *__restrict__ S2 /*BN2 sums*/, float *g1w, float *g1b, float *g2w,
+                                                          float *g2b, const double *__restrict__ S1g /*NULL, or [2][16]: BN1-backward sums over ALL replicas*/,
+                                                          const int *__restrict__ ac_global /*NULL, or the global autocorrelation total*/)
+{
+    if (blockIdx.x > 0) {
+        conv2_wgrad_finish_body(tmp2, slices2, dW2, db2, (const float *)nullptr, (float *)nullptr, (blockIdx.x - 1) * 1024 + threadIdx.x);
+        return;
+    }
+    c1w_fused_finish_body(tmp, slices, ac, ac_row_stride, rows, nrows, W1, scale1, rstd1, gamma1, beta1, dW1, db1, S2, g1w, g1b, g2w, g2b, S1g, ac_global);
 }
 
 // ---------------------------------------------------------------------------
@@ -2100,10 +2157,14 @@ constexpr int kReduceSlices = 64;
 
 // stage 1 of the deterministic fp64 reduction: partial [P][E] -> tmp [slices][E]; the consumer (a
 // *_finish kernel) adds the <= 64 slices in order.  Returns the number of slices.
+static inline int reduce_slices(int P)
+{
+    const int slices = P / 32;  // ~32 partial rows per workgroup
+    return slices < 1 ? 1 : (slices > kReduceSlices ? kReduceSlices : slices);
+}
 static inline int reduce_stage1(const float *partial, int P, int E, double *tmp, hipStream_t st)
 {
-    int slices = P / 32;  // ~32 partial rows per workgroup
-    slices = slices < 1 ? 1 : (slices > kReduceSlices ? kReduceSlices : slices);
+    const int slices = reduce_slices(P);
     const int per = (P + slices - 1) / slices;
     if (E % 4 == 0 && (((uintptr_t)partial) & 15) == 0)
         hipLaunchKernelGGL(k_reduce_partials4, dim3((E / 4 + 63) / 64, slices), dim3(256), 0, st, partial, P, E, per, tmp);
@@ -2112,6 +2173,13 @@ static inline int reduce_stage1(const float *partial, int P, int E, double *tmp,
                            (float *)nullptr);
     return slices;
 }
+static inline ReduceJob reduce_job(const float *partial, int P, int E, double *tmp)
+{
+    ReduceJob j;
+    j.partial = partial; j.P = P; j.E = E; j.slices = reduce_slices(P); j.per_slice = (P + j.slices - 1) / j.slices; j.nbx = (E / 4 + 63) / 64; j.out = tmp;
+    return j;
+}
+static inline bool reduce_job_ok(const ReduceJob &j) { return j.E % 4 == 0 && (((uintptr_t)j.partial) & 15) == 0; }
 
 // Kernel-path predicates shared by forward and backward (they must agree on what the layer-1 buffer holds).
 //   fused_path: conv2 data gradient fused with the conv1 weight gradient (needs the grid as aligned int8 rows)
@@ -2468,15 +2536,25 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     }
     if ((err = gnbv_launch_status())) return err;
     const int E2 = kTaps * 256 + kC;
-    const int sl2 = reduce_stage1(w.wg_part, wg_blocks, E2, w.tmp, sw);  // <= 16 slices: tmp[0, 16 E2)
-    if ((err = gnbv_launch_status())) return err;
-    // (the weight images ride in the finish launch unless it runs on the side stream)
-    hipLaunchKernelGGL(k_conv2_wgrad_finish, dim3((E2 + 255) / 256), dim3(256), 0, sw, (const double *)w.tmp, sl2, g->w2, g->b2,
-                       p->w2, w.w2img);
-    if ((err = gnbv_launch_status())) return err;
     // the conv1 weight gradient (main stream) uses its own partial / slice regions of the workspace
     float *wg1_part = w.wg_part + (size_t)512 * E2;
     double *tmp1 = w.tmp + (size_t)32 * E2;
+    // Only the optimizer reads dW2: on the split path (whose data-gradient kernel takes its weight images from the forward's
+    // k_bn1_analytic, not from this finish) the reduction and the finish wait behind the data gradient and share their launches with
+    // the conv1 weight gradient's (k_reduce_partials4_x2, k_wgrad_finish_both): two launches less between the two conv kernels.
+    // (GENNBV_LATE_WGRAD_FINISH=0: the four-launch order, A/B runs.)
+    const ReduceJob job2 = reduce_job(w.wg_part, wg_blocks, E2, w.tmp);
+    static const bool late_env = !(getenv("GENNBV_LATE_WGRAD_FINISH") && getenv("GENNBV_LATE_WGRAD_FINISH")[0] == '0');
+    const bool late_finish = late_env && split_bwd && fused && !dual_bwd && !dp && reduce_job_ok(job2) && job2.slices <= 32 &&
+                             wg_blocks <= 512;  // (its partials must stay clear of the conv1 partials at 512 E2 and its slices of tmp1 at 32 E2)
+    if (!late_finish) {
+        const int sl2 = reduce_stage1(w.wg_part, wg_blocks, E2, w.tmp, sw);  // <= 16 slices: tmp[0, 16 E2)
+        if ((err = gnbv_launch_status())) return err;
+        // (the weight images ride in the finish launch unless it runs on the side stream)
+        hipLaunchKernelGGL(k_conv2_wgrad_finish, dim3((E2 + 255) / 256), dim3(256), 0, sw, (const double *)w.tmp, sl2, g->w2, g->b2,
+                           p->w2, w.w2img);
+        if ((err = gnbv_launch_status())) return err;
+    }
     // ---- conv2 data gradient (+ ReLU1 mask, BN1 backward sums) ----
     const int gd = sample_plane_group_grid(batch, (O1 + 1) / 2, kPlanesPerGroup);  // groups of plane PAIRS
     if (fused) {
@@ -2503,6 +2581,23 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
             hipLaunchKernelGGL(k_conv2_dgrad_c1w<false>, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const float *)y1, bn1,
                                bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->grid_i8, rows, p->grid_i8_row_stride, batch, grid, O1, O2, wg1_part);
         if ((err = gnbv_launch_status())) return err;
+        const ReduceJob job1 = reduce_job(wg1_part, gd, kE1F, tmp1);
+        if (late_finish && reduce_job_ok(job1)) {
+            hipLaunchKernelGGL(k_reduce_partials4_x2, dim3(job2.nbx + job1.nbx, job2.slices > job1.slices ? job2.slices : job1.slices), dim3(256), 0, st, job2, job1);
+            if ((err = gnbv_launch_status())) return err;
+            hipLaunchKernelGGL(k_wgrad_finish_both, dim3(1 + (E2 + 1023) / 1024), dim3(1024), 0, st, (const double *)w.tmp, job2.slices, g->w2, g->b2,
+                               (const double *)tmp1, job1.slices,
+                               saved_total ? (const int *)(bn_state + kBnStateFloats) : (p->autocorr ? (const int *)p->autocorr : (const int *)Rac),
+                               p->autocorr_row_stride, rows, (!saved_total && p->autocorr) ? batch : 0,
+                               p->w1, bn1, bn1 + 3 * kC, z1 ? p->bn1_w : (const float *)nullptr, p->bn1_b, g->w1, g->b1, (const double *)S2, g->bn1_w,
+                               g->bn1_b, g->bn2_w, g->bn2_b, (const double *)nullptr, (const int *)nullptr);
+            return gnbv_launch_status();
+        }
+        if (late_finish) {  // (kE1F partials not 16-byte aligned: never with this workspace layout)
+            const int sl2 = reduce_stage1(w.wg_part, wg_blocks, E2, w.tmp, st);
+            hipLaunchKernelGGL(k_conv2_wgrad_finish, dim3((E2 + 255) / 256), dim3(256), 0, st, (const double *)w.tmp, sl2, g->w2, g->b2, p->w2, w.w2img);
+            if ((err = gnbv_launch_status())) return err;
+        }
         const int slf = reduce_stage1(wg1_part, gd, kE1F, tmp1, st);
         if ((err = gnbv_launch_status())) return err;
         if (dp) {  // BatchNorm-1 backward means over the global minibatch

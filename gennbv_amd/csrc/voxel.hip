@@ -1063,6 +1063,253 @@ __global__ __launch_bounds__(kListThreads) void k_ray_list(
 }
 
 // ===========================================================================
+// large grids (G > 104: a 128^3 bitmask is 256 KiB, no workgroup can hold it next to its lists), launches 1 + 2 (round 3)
+//
+// k_hit_atomic: the phase A of k_hit_list -- same stream, same predictor, same queue of undecided pixels -- WITHOUT a mask in LDS: a
+// pixel's voxel bit is ORed into the env's hit mask in global memory (all workgroups of an env run on one XCD: its L2 serves them),
+// and the atomic's RETURN value says whether this pixel was the first to set it -- exactly then the voxel is appended to the env's
+// ray list (wave-aggregated slot allocation).  Set semantics are exact (one list entry per distinct voxel, as the reference's
+// torch.unique gives, utils.py:230-270); the four atomics of a lane's pixel group are issued before the first result is used.
+// (The windowed round-1 k_hit_mask ran the canonical chain over every pixel once per 128 KiB window: 0.79 ms at 512 x 128^3.)
+//
+// k_ray_slab: workgroup (e, slab, slice) owns the x-planes [X0, X1) of env e's path mask (<= 32 KiB of LDS at 128^3: 16 planes) and
+// walks, of every ray of its slice, ONLY the steps whose voxel lies in that slab.  The reference's integer Bresenham (utils.py:48-167)
+// has a closed form -- point j of a ray is a_j = a_0 + s_a j on the dominant axis and b_j = b_0 + s_b floor((2 d_b j + d_a) / (2 d_a))
+// on a minor axis, error term p_j = 2 d_b (j + 1) - d_a - 2 d_a nb_j (induction on p_j in [2 d_b - 2 d_a, 2 d_b)) -- so the first and
+// last step inside a slab and the walker's state there follow from four small integer divisions; the steps in between are the
+// sequential walk (RayWalk::step), bit for bit.  No step is walked twice (the windowed k_raycast walked every ray once per window),
+// and the mask of a workgroup is as small as at 64^3.
+// ===========================================================================
+__device__ __forceinline__ int udiv_small(int n, int d)  // floor(n / d), 0 <= n < 2^22, d > 0: reciprocal estimate + two-sided correction
+{
+    int q = (int)(__fmul_rn((float)n, __builtin_amdgcn_rcpf((float)d)));
+    int r = n - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) ++q;
+    return q;
+}
+
+template <bool KFAST>
+__global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_hit_atomic(
+    const float *__restrict__ depth_raw, const float *__restrict__ seg_raw, const float *__restrict__ c2w, Intrinsics K,
+    const float *__restrict__ range_gt, const float *__restrict__ voxel_size, int n, int h, int w, int g, float sense_dist,
+    int chunks, int words, uint32_t *__restrict__ hit_mask, int32_t *__restrict__ ray_count, int32_t *__restrict__ ray_list,
+    int64_t ray_cap, int32_t *__restrict__ coverage_zero)
+{
+    __shared__ int s_qcnt;
+    __shared__ int s_queue[kQueueCapPx];
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int e = (slot / chunks) * 8 + xcd;
+    const int c = slot % chunks;
+    if (e >= n) return;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    if (tid == 0) s_qcnt = 0;
+    if (coverage_zero != nullptr && c == 0 && tid == 0) coverage_zero[e] = 0;
+    const int hw = h * w;
+    int ppc = (hw + chunks - 1) / chunks;
+    ppc = (ppc + 3) & ~3;
+    const int px0 = c * ppc, px1 = min(hw, px0 + ppc);
+    const float *dptr = depth_raw + (size_t)e * hw;
+    const float *sptr = seg_raw + (size_t)e * hw;
+    const float inv_w = __frcp_rn((float)w);
+    uint32_t *gh = hit_mask + (size_t)e * words;
+    int32_t *list = ray_list + (size_t)e * ray_cap;
+    int32_t *cnt_e = ray_count + e;
+    // OR the bits of up to four voxels (l < 0: none) into the env's mask; the voxels this call set first go to the ray list.
+    // Called by converged code paths and by loop tails alike: ballots see the active lanes only, the leader is one of them.
+    auto mark4 = [&](int l0, int l1, int l2, int l3) {
+        const int ls[4] = {l0, l1, l2, l3};
+        uint32_t old[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) old[k] = ls[k] >= 0 ? atomicOr(&gh[ls[k] >> 5], 1u << (ls[k] & 31)) : 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool first = ls[k] >= 0 && !((old[k] >> (ls[k] & 31)) & 1u);
+            const unsigned long long m = __ballot(first);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(cnt_e, __popcll(m));
+                base = __builtin_amdgcn_readlane(base, leader);
+                const int o = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (first && o < ray_cap) list[o] = ls[k];
+            }
+        }
+    };
+    __syncthreads();
+    bool need_full_exact = false;
+    if (KFAST && (w & 3) == 0 && hw < (1 << 23) && kUsePredictor) {
+        const VoxPredict vp = make_predictor(c2w + (size_t)e * 16, K, range_gt + e * 6, voxel_size + e * 3, g, h, w);
+        const unsigned ug = (unsigned)g;
+        constexpr int kTile = kFusedThreads * 4, kAhead = 3;
+        v4f_t dq[kAhead], sq[kAhead];
+        const int plast = px1 - 4;
+        const int ntiles = (px1 - px0 + kTile - 1) / kTile;
+        auto tile_px = [&](int t) { return px0 + t * kTile + tid * 4; };
+#pragma unroll
+        for (int q = 0; q < kAhead; ++q) {
+            const int pq = max(min(tile_px(max(min(q, ntiles - 1), 0)), plast), 0);
+            ld4_stream_async(dq[q], dptr + pq);
+            ld4_stream_async(sq[q], sptr + pq);
+        }
+        const int tdy = kTile / w, tdx = kTile - tdy * w;
+        int py = floor_div_small(max(min(tile_px(0), plast), 0), w, inv_w), pxc = max(min(tile_px(0), plast), 0) - py * w;
+        for (int t0 = 0; t0 < ntiles; t0 += kAhead) {
+#pragma unroll
+            for (int q = 0; q < kAhead; ++q) {
+                const int t = t0 + q;
+                const int p = t < ntiles ? tile_px(t) : px1;
+                wait_vm_keep<2 * (kAhead - 1)>(dq[q], sq[q]);
+                const v4f_t d4 = dq[q], s4 = sq[q];
+                if (p < px1 && __any((s4.x > 50.0f) | (s4.y > 50.0f) | (s4.z > 50.0f) | (s4.w > 50.0f))) {
+                    const float fy = (float)py, fx = (float)pxc;
+                    const float row[3] = {__fmaf_rn(vp.be[0], fy, vp.ga[0]), __fmaf_rn(vp.be[1], fy, vp.ga[1]), __fmaf_rn(vp.be[2], fy, vp.ga[2])};
+                    bool u0, u1, u2, u3;
+                    const int l0 = pixel_predict(vp, row, fx, d4.x, s4.x, sense_dist, ug, u0);
+                    const int l1 = pixel_predict(vp, row, fx + 1.0f, d4.y, s4.y, sense_dist, ug, u1);
+                    const int l2 = pixel_predict(vp, row, fx + 2.0f, d4.z, s4.z, sense_dist, ug, u2);
+                    const int l3 = pixel_predict(vp, row, fx + 3.0f, d4.w, s4.w, sense_dist, ug, u3);
+                    const int pl = __builtin_amdgcn_update_dpp(-2, l3, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+                    mark4(l0 != pl ? l0 : -1, l1 != l0 ? l1 : -1, l2 != l1 ? l2 : -1, l3 != l2 ? l3 : -1);
+                    if (__any(u0 | u1 | u2 | u3)) {
+                        const int cnt = (int)u0 + (int)u1 + (int)u2 + (int)u3;
+                        if (cnt) {
+                            int qs = atomicAdd(&s_qcnt, cnt);
+                            if (u0) { if (qs < kQueueCapPx) s_queue[qs] = p; ++qs; }
+                            if (u1) { if (qs < kQueueCapPx) s_queue[qs] = p + 1; ++qs; }
+                            if (u2) { if (qs < kQueueCapPx) s_queue[qs] = p + 2; ++qs; }
+                            if (u3) { if (qs < kQueueCapPx) s_queue[qs] = p + 3; }
+                        }
+                    }
+                }
+                pxc += tdx; py += tdy;
+                if (pxc >= w) { pxc -= w; ++py; }
+                // refill THIS slot behind its last use (see k_hit_list)
+                const int pn = max(min(tile_px(max(min(t + kAhead, ntiles - 1), 0)), plast), 0);
+                ld4_stream_async(dq[q], dptr + pn);
+                ld4_stream_async(sq[q], sptr + pn);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int nq = s_qcnt;
+        if (nq > kQueueCapPx) {
+            need_full_exact = true;  // (re-marking a voxel the stream already set is harmless: the atomic reports "not first")
+        } else if (nq > 0) {
+            PixelFrame pf;
+            load_pixel_frame(pf, c2w, range_gt, voxel_size, e, g, sense_dist);
+            for (int j = tid; j < nq; j += kFusedThreads) {
+                const int p = s_queue[j];
+                const int y = p / w;
+                mark4(pixel_to_lin<KFAST>(pf, K, (float)(p - y * w), (float)y, dptr[p], sptr[p]), -1, -1, -1);
+            }
+        }
+    } else {
+        need_full_exact = true;
+    }
+    if (need_full_exact) {
+        PixelFrame pf;
+        load_pixel_frame(pf, c2w, range_gt, voxel_size, e, g, sense_dist);
+        for (int p = px0 + tid; p < px1; p += kFusedThreads) {
+            const int y = p / w;
+            mark4(pixel_to_lin<KFAST>(pf, K, (float)(p - y * w), (float)y, dptr[p], sptr[p]), -1, -1, -1);
+        }
+    }
+}
+
+// One ray restricted to the x-planes [X0, X1): RayWalk's state at the first point inside, `left` = points inside (see the header).
+template <bool INB>
+__device__ __forceinline__ void init_ray_slab(RayWalk<INB> &rw, const int (&src)[3], int lin_t, int g, int gg, int X0, int X1)
+{
+    int tgt[3];
+    tgt[0] = lin_t / gg;
+    const int rem = lin_t - tgt[0] * gg;
+    tgt[1] = rem / g;
+    tgt[2] = rem - tgt[1] * g;
+    rw.left = 0;
+    if (max(src[0], tgt[0]) < X0 || min(src[0], tgt[0]) >= X1) return;  // the ray's x-range misses the slab
+    const int d0 = abs(tgt[0] - src[0]), d1 = abs(tgt[1] - src[1]), d2 = abs(tgt[2] - src[2]);
+    const int dm = max(max(d0, d1), d2);
+    const bool ax = dm == d0, ay = !ax && dm == d1;  // dominant axis tested x, y, z (utils.py:69,102,133)
+    const int pa0 = ax ? src[0] : (ay ? src[1] : src[2]), pb0 = ax ? src[1] : src[0], pc0 = (ax || ay) ? src[2] : src[1];
+    const int ta = ax ? tgt[0] : (ay ? tgt[1] : tgt[2]), tb = ax ? tgt[1] : tgt[0], tc = (ax || ay) ? tgt[2] : tgt[1];
+    const int da = dm, db = ax ? d1 : d0, dc = (ax || ay) ? d2 : d1;
+    const int st_a = ax ? gg : (ay ? g : 1), st_b = ax ? g : gg, st_c = (ax || ay) ? 1 : g;
+    rw.sa = pa0 < ta ? 1 : -1; rw.sb = pb0 < tb ? 1 : -1; rw.sc = pc0 < tc ? 1 : -1;
+    // x advances by k in [klo, khi] x-steps while it is inside the slab (x is the dominant axis, or the FIRST minor axis)
+    const int sx = src[0] < tgt[0] ? 1 : -1;
+    const int klo = max(sx > 0 ? X0 - src[0] : src[0] - (X1 - 1), 0), khi = min(sx > 0 ? (X1 - 1) - src[0] : src[0] - X0, d0);
+    int jlo = 0, jhi = da;
+    if (ax) {
+        jlo = klo; jhi = khi;
+    } else if (d0 > 0) {
+        // nx(j) = floor((2 dx j + da) / (2 da)); the first j with nx(j) >= k (k >= 1) is ceil((2 da k - da) / (2 dx))
+        if (klo >= 1) jlo = udiv_small(2 * da * klo - da + 2 * d0 - 1, 2 * d0);
+        jhi = min(da, udiv_small(2 * da * (khi + 1) - da + 2 * d0 - 1, 2 * d0) - 1);
+    }
+    if (jlo > jhi) return;
+    const int nb = da > 0 ? udiv_small(2 * db * jlo + da, 2 * da) : 0, nc = da > 0 ? udiv_small(2 * dc * jlo + da, 2 * da) : 0;
+    rw.pa = pa0 + rw.sa * jlo; rw.pb = pb0 + rw.sb * nb; rw.pc = pc0 + rw.sc * nc;
+    rw.two_db = 2 * db; rw.two_dc = 2 * dc;
+    rw.dl1 = rw.two_db - 2 * da; rw.dl2 = rw.two_dc - 2 * da;
+    rw.p1 = rw.two_db * (jlo + 1) - da - 2 * da * nb; rw.p2 = rw.two_dc * (jlo + 1) - da - 2 * da * nc;
+    rw.l = rw.pa * st_a + rw.pb * st_b + rw.pc * st_c - X0 * gg;  // bit index inside the slab's mask
+    rw.la = rw.sa * st_a; rw.lb = rw.sb * st_b; rw.lc = rw.sc * st_c;
+    rw.left = jhi - jlo + 1;
+}
+
+template <bool INB>
+__device__ __forceinline__ void walk_slab(const int (&src)[3], const int32_t *__restrict__ list, int cnt, int first, int stride, int g, int gg,
+                                          int X0, int X1, uint32_t *s_path)
+{
+    const int64_t P = (cnt % 7919) ? 7919 : 7907;  // (as walk_slice: neighbouring list entries are neighbouring voxels)
+    const unsigned ug = (unsigned)g;
+    for (int r = first; r < cnt; r += stride) {
+        RayWalk<INB> rw;
+        init_ray_slab<INB>(rw, src, list[(int)(((int64_t)r * P) % cnt)], g, gg, X0, X1);
+        for (int i = rw.left; i > 0; --i) rw.step(ug, s_path);
+    }
+}
+
+__global__ __launch_bounds__(kListThreads) void k_ray_slab(
+    const int32_t *__restrict__ ray_count, const int32_t *__restrict__ ray_list, int64_t ray_cap, const float *__restrict__ poses_xyz,
+    int64_t pose_stride, const float *__restrict__ range_gt, const float *__restrict__ voxel_size, int n, int g, int words, int slabs,
+    int slab_planes, uint32_t *__restrict__ path_mask)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_path[];
+    // block -> (env, slab, slice); all workgroups of env e run on XCD e % 8
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int per_env = slabs * kListSlices;
+    const int e = (slot / per_env) * 8 + xcd;
+    const int rem = slot % per_env, slab = rem / kListSlices, sl = rem % kListSlices;
+    if (e >= n) return;
+    const int cnt = (int)min((int64_t)ray_count[e], ray_cap);
+    if (sl * kListThreads >= cnt) return;
+    const int tid = threadIdx.x, gg = g * g;
+    const int X0 = slab * slab_planes, X1 = min(g, X0 + slab_planes);
+    const int w0 = (int)(((int64_t)X0 * gg) >> 5);  // (X0 * gg % 32 == 0: the host picks slab_planes that way)
+    const int nw = min(words, (int)(((int64_t)X1 * gg + 31) >> 5)) - w0;
+    for (int i = tid; i < nw; i += kListThreads) s_path[i] = 0u;
+    const float *pp = poses_xyz + (size_t)e * pose_stride;
+    const int src[3] = {pose_axis_to_idx(pp[0], range_gt[e * 6 + 1], voxel_size[e * 3 + 0]),
+                        pose_axis_to_idx(pp[1], range_gt[e * 6 + 3], voxel_size[e * 3 + 1]),
+                        pose_axis_to_idx(pp[2], range_gt[e * 6 + 5], voxel_size[e * 3 + 2])};
+    const int32_t *list = ray_list + (size_t)e * ray_cap;
+    __syncthreads();
+    const bool src_in = (unsigned)src[0] < (unsigned)g && (unsigned)src[1] < (unsigned)g && (unsigned)src[2] < (unsigned)g;
+    if (src_in)
+        walk_slab<true>(src, list, cnt, sl * kListThreads + tid, kListSlices * kListThreads, g, gg, X0, X1, s_path);
+    else
+        walk_slab<false>(src, list, cnt, sl * kListThreads + tid, kListSlices * kListThreads, g, gg, X0, X1, s_path);
+    __syncthreads();
+    uint32_t *gp = path_mask + (size_t)e * words + w0;
+    for (int i = tid; i < nw; i += kListThreads) {
+        const uint32_t v = s_path[i];
+        if (v) atomicOr(&gp[i], v);
+    }
+}
+
+// ===========================================================================
 // fused path, launch 3: streaming grid update (A6 tail + A7 + coverage count)
 // ===========================================================================
 constexpr int kGridThreads = 256;
@@ -1602,6 +1849,14 @@ GNBV_API int gnbv_grid_tri_cls(const float *grid_prob, int64_t count, float thre
 }
 
 
+// GENNBV_VOXEL_LARGE: 1 = the large-grid kernels (k_hit_atomic + k_ray_slab) at every grid size, 0 = never (the round-1 kernels above
+// G = 104), unset = by size.  Read per call (tests switch it between calls).
+static int voxel_large_mode()
+{
+    const char *v = getenv("GENNBV_VOXEL_LARGE");
+    return (v && (v[0] == '0' || v[0] == '1')) ? v[0] - '0' : -1;
+}
+
 // launches 1 + 2 (and the memsets): hit mask and path mask of every env into the workspace
 static int launch_masks(const float *depth_raw, const float *seg_raw, const float *c2w, const float *inv_intri,
                         const float *poses_xyz, int64_t poses_row_stride, const float *range_gt, const float *voxel_size, int n,
@@ -1630,7 +1885,7 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
     const int env_groups = (n + 7) / 8;
     // hit mask + ray list, then the load-balanced ray cast over the lists (needs the h/w-sized workspace)
     const size_t list_lds = mask_bytes + 64 * sizeof(uint32_t) + (size_t)((words + 1) & ~1) * sizeof(uint16_t) + kQueueCapPx * sizeof(int32_t);
-    if (ws.ray_list != nullptr && list_lds <= kLdsMax && words <= 65536) {
+    if (ws.ray_list != nullptr && list_lds <= kLdsMax && words <= 65536 && voxel_large_mode() != 1) {
         // workgroups per env: two per CU in total (1024 threads each = 32 waves per CU).  (The kernel is capped at 80 SGPRs:
         // with the 96 it wanted, the SIMD's 800-entry SGPR file held 7 waves and a second 16-wave workgroup never became
         // resident beside the first -- 512 workgroups ran as two rounds, profiles/r02_notes.md.)
@@ -1670,6 +1925,52 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
         hipLaunchKernelGGL(k_ray_list, dim3(env_groups * 8 * kListSlices), dim3(kListThreads), ray_lds, st, ws.ray_count, ws.ray_list,
                            ws.ray_cap, poses_xyz, poses_row_stride, range_gt, voxel_size, n, g, words, ws.path);
         return gnbv_launch_status();
+    }
+    // large grids (the mask does not fit a workgroup's LDS next to its lists: G > 104) with the list workspace: k_hit_atomic +
+    // k_ray_slab.  (GENNBV_VOXEL_LARGE=1 takes this path at every grid size: tests.)
+    // (GENNBV_VOXEL_LARGE=0: the round-1 kernels below; GENNBV_VOXEL_SLAB_PLANES=k: planes per slab, rounded up to the alignment -- tests.)
+    if (ws.ray_list != nullptr && voxel_large_mode() != 0) {
+        // slabs of whole x-planes whose first bit is word-aligned, <= 32 KiB of mask each where the grid allows it
+        const int64_t gg = (int64_t)g * g;
+        int align = 32;
+        while (align > 1 && (gg * (align / 2)) % 32 == 0) align /= 2;
+        int64_t per = (8192 * 32) / (gg * align);
+        int slab_planes = (int)(align * (per < 1 ? 1 : per));
+        if (const char *sp = getenv("GENNBV_VOXEL_SLAB_PLANES")) {
+            const int k = atoi(sp);
+            if (k > 0) slab_planes = ((k + align - 1) / align) * align;
+        }
+        slab_planes = slab_planes > g ? ((g + align - 1) / align) * align : slab_planes;
+        const int slabs = (g + slab_planes - 1) / slab_planes;
+        const size_t slab_lds = (size_t)((slab_planes * gg + 31) / 32) * sizeof(uint32_t);
+        if (slab_lds <= kLdsMax) {
+            if (used_lists) *used_lists = true;
+            if (masks_are_zero) {
+            } else if (ws.path == ws.hit + (size_t)n * words && (void *)ws.ray_count == (void *)(ws.path + (size_t)n * words)) {
+                const size_t zb = (size_t)((char *)(ws.ray_count + ray_count_ints(n)) - (char *)ws.hit);
+                if ((err = (int)hipMemsetAsync(ws.hit, 0, zb, st))) return err;
+            } else {
+                if ((err = (int)hipMemsetAsync(ws.hit, 0, (size_t)n * mask_bytes, st))) return err;
+                if ((err = (int)hipMemsetAsync(ws.path, 0, (size_t)n * mask_bytes, st))) return err;
+                if ((err = (int)hipMemsetAsync(ws.ray_count, 0, (size_t)n * sizeof(int32_t), st))) return err;
+            }
+            int fchunks = (512 + n - 1) / n;  // two 1024-thread workgroups per CU in total
+            fchunks = fchunks < 1 ? 1 : (fchunks > 16 ? 16 : fchunks);
+            const int fgrid = env_groups * 8 * fchunks;
+            if (kfast)
+                hipLaunchKernelGGL((k_hit_atomic<true>), dim3(fgrid), dim3(kFusedThreads), 0, st, depth_raw, seg_raw, c2w, K, range_gt, voxel_size, n, h, w, g,
+                                   depth_sense_dist, fchunks, words, ws.hit, ws.ray_count, ws.ray_list, ws.ray_cap, coverage_count);
+            else
+                hipLaunchKernelGGL((k_hit_atomic<false>), dim3(fgrid), dim3(kFusedThreads), 0, st, depth_raw, seg_raw, c2w, K, range_gt, voxel_size, n, h, w, g,
+                                   depth_sense_dist, fchunks, words, ws.hit, ws.ray_count, ws.ray_list, ws.ray_cap, coverage_count);
+            if ((err = gnbv_launch_status())) return err;
+            if (slab_lds > 64 * 1024 &&
+                hipFuncSetAttribute((const void *)k_ray_slab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slab_lds) != hipSuccess)
+                return (int)hipGetLastError();
+            hipLaunchKernelGGL(k_ray_slab, dim3(env_groups * 8 * slabs * kListSlices), dim3(kListThreads), slab_lds, st, ws.ray_count, ws.ray_list, ws.ray_cap,
+                               poses_xyz, poses_row_stride, range_gt, voxel_size, n, g, words, slabs, slab_planes, ws.path);
+            return gnbv_launch_status();
+        }
     }
     // zero the hit masks (OR-accumulated by atomics); the path masks only when they are
     // OR-accumulated too (several splits, or no LDS staging)

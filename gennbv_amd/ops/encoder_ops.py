@@ -491,6 +491,19 @@ def hybrid_branches(enc, observations):
         enc._grid_feats_leaf = feature_grid
     # fc_grid.weight's optimizer update of the PREVIOUS minibatch, owed to this forward (sb3/ppo_grid_obs.py: FlatAdam.step(owe_slice)):
     # applied by the kernel that streams the weight (gnbv_linear_forward_fold_adam)
+    owed_side = getattr(enc, "_fc_owed_side", None)
+    if owed_side is not None:
+        # ... or applied by a launch of its own on the second stream, forked at this forward's first kernel: a pure HBM stream (28 bytes
+        # per parameter) beside the issue-bound conv kernels; this forward's fc_grid product is the first reader of the new weight
+        enc._fc_owed_side = None
+        if side is not None:
+            with torch.cuda.stream(side):
+                owed_side()
+                evt_owed = torch.cuda.Event()
+                evt_owed.record(side)
+            torch.cuda.current_stream(base.device).wait_event(evt_owed)
+        else:
+            owed_side()
     owed = getattr(enc, "_fc_owed_adam", None)
     if owed is not None:
         enc._fc_owed_adam = None

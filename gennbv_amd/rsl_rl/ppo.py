@@ -15,6 +15,32 @@ from .. import _lib
 from .storage import RolloutStorage
 
 
+class _FlatAdamView:
+    """`alg.optimizer` as the reference's runner uses it (rsl_rl/runners/on_policy_runner.py: `optimizer.state_dict()` /
+    `load_state_dict()` in save / load, `param_groups[...]["lr"]`): a torch.optim.Adam whose state lives in the flat HIP optimizer
+    once the first update() created it.  Before that it IS the torch optimizer's state."""
+
+    def __init__(self, owner, torch_adam):
+        self._owner, self._adam = owner, torch_adam
+
+    def __getattr__(self, name):  # param_groups, defaults, ...
+        return getattr(self._adam, name)
+
+    def state_dict(self):
+        flat = self._owner._flat
+        return flat.torch_state_dict(self._adam) if flat is not None else self._adam.state_dict()
+
+    def load_state_dict(self, sd):
+        self._adam.load_state_dict(sd)
+        flat = self._owner._flat
+        if flat is not None:
+            flat.load_torch_state_dict(self._adam.state_dict())
+            for g in self._adam.param_groups:
+                flat.lr = float(g["lr"])
+        for g in self._adam.param_groups:
+            self._owner.learning_rate = float(g["lr"])
+
+
 class PPO:
     def __init__(self, actor_critic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
                  value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True,
@@ -24,8 +50,9 @@ class PPO:
         self.actor_critic = actor_critic
         self.actor_critic.to(self.device)
         self.storage = None
-        self.optimizer = torch.optim.Adam(self.actor_critic.parameters(), lr=learning_rate)
-        self._flat = None  # ops.ppo_ops.FlatAdam, created at the first update() on a GPU
+        self._flat = None
+        self.optimizer = _FlatAdamView(self, torch.optim.Adam(self.actor_critic.parameters(), lr=learning_rate))
+        # (self._flat: ops.ppo_ops.FlatAdam, created at the first update() on a GPU; `optimizer` reads / writes its state from then on)
         self.transition = RolloutStorage.Transition()
         self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
         self.value_loss_coef, self.entropy_coef = value_loss_coef, entropy_coef
@@ -77,7 +104,7 @@ class PPO:
             from ..ops.ppo_ops import FlatAdam
             eps, betas = self.optimizer.defaults["eps"], self.optimizer.defaults["betas"]
             self._flat = FlatAdam(self.actor_critic, lr=self.learning_rate, betas=betas, eps=eps)
-            self._flat.load_torch_adam_state(self.optimizer)
+            self._flat.load_torch_adam_state(self.optimizer._adam)
         opt = self._flat
         sums = torch.zeros(2, dtype=torch.float32, device=dev)
         st = lambda: _lib.stream_ptr(dev)  # noqa: E731

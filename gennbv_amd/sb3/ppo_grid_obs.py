@@ -395,8 +395,14 @@ class PPO_Grid_Obs:
             # GENNBV_ADAM_FUSE=1 (opt-in; measured SLOWER, profiles/r03_notes.md): its Adam update (392 MB of HBM traffic, ~68 us) is
             # OWED to the next minibatch's fc_grid forward, the kernel that next streams that weight (FlatAdam.step(owe_slice=...) ->
             # gnbv_linear_forward_fold_adam; settled by a launch of its own at the end of train()).  One GPU only as well.
-            if (self._sync is None or not self._sync.active) and sl is not None and sl[0] % 4 == 0 and os.environ.get("GENNBV_ADAM_FUSE", "0") == "1":
-                self._hip["owe_fc"] = (sl[0], sl[1])
+            # GENNBV_ADAM_SIDE=1 (opt-in as well): the same owed update as a launch of its own on the SECOND stream at the head of the next
+            # minibatch, beside k_bn1_analytic + k_conv12_fwd_split (issue-bound, ~3.4 TB/s) instead of in front of them: the update
+            # is a pure HBM stream and the only thing that needs the new weight is fc_grid's forward behind the conv stack.
+            if (self._sync is None or not self._sync.active) and sl is not None and sl[0] % 4 == 0:
+                if os.environ.get("GENNBV_ADAM_FUSE", "0") == "1":
+                    self._hip["owe_fc"], self._hip["owe_mode"] = (sl[0], sl[1]), "fuse"
+                elif os.environ.get("GENNBV_ADAM_SIDE", "0") == "1" and getattr(enc, "overlap_branches", False):
+                    self._hip["owe_fc"], self._hip["owe_mode"] = (sl[0], sl[1]), "side"
         return self._hip
 
     def _hip_minibatch_body(self, st, phase: str = "all"):
@@ -421,7 +427,9 @@ class PPO_Grid_Obs:
                 # -> gnbv_linear_forward_fold_adam); shapes that kernel does not take: as a launch of its own, here
                 lin_ = enc.output_layer_grid[0]
                 p2_ = encoder_ops.conv_out(encoder_ops.conv_out(enc.grid_size)) ** 3
-                if int(loss.batch) <= 128 and encoder_ops.linear_fold_ok(lin_, int(loss.batch), p2_, getattr(enc, "force_fp32", False)):
+                if st.get("owe_mode") == "side":  # second stream, joined in front of fc_grid's forward (encoder_ops.hybrid_branches)
+                    enc._fc_owed_side = lambda o=st["owe_fc"]: opt.slice_step_pending(o)
+                elif int(loss.batch) <= 128 and encoder_ops.linear_fold_ok(lin_, int(loss.batch), p2_, getattr(enc, "force_fp32", False)):
                     enc._fc_owed_adam = opt.owed_adam(st["owe_fc"])
                 else:
                     opt.slice_step_pending(st["owe_fc"])
@@ -445,8 +453,14 @@ class PPO_Grid_Obs:
                 torch.autograd.backward([logits, values], [d_logits, d_values])
                 if lin is not None:
                     lin._defer_wgrad = False
-                encoder_ops.pose_branch_backward(enc, self.device)  # (deferred so that the conv chain is captured first: encoder_ops.hybrid_branches)
-                encoder_ops.join_async_wgrads(self.device)  # fc_grid's dW / db: second stream, beside the conv backward
+                if os.environ.get("GENNBV_DW_FIRST", "0") == "1":
+                    # fc_grid's dW GEMM in FRONT of the pose branch's backward on the second stream: it then starts behind fc_bwd_prep and
+                    # runs beside the dx GEMM / the BatchNorm-2 backward instead of beside k_conv2_wgrad_split
+                    encoder_ops.join_async_wgrads(self.device)
+                    encoder_ops.pose_branch_backward(enc, self.device)
+                else:
+                    encoder_ops.pose_branch_backward(enc, self.device)  # (deferred so that the conv chain is captured first: encoder_ops.hybrid_branches)
+                    encoder_ops.join_async_wgrads(self.device)  # fc_grid's dW / db: second stream, beside the conv backward
                 if self._sync is None or not self._sync.active:
                     sq = st.get("sq_slice") if (lin is not None and getattr(lin, "_dw_sq_written", False)) else None
                     opt.step(self.max_grad_norm, loss.stop_flag, rotate=st.get("rows_rot"), sq_slice=sq,

@@ -78,6 +78,26 @@ def test_rsl_rl_ppo_matches_the_vendored_reference():
     for k, v in ac.state_dict().items():
         np.testing.assert_allclose(v.cpu().numpy(), fx["final/" + k], rtol=1e-4, atol=2e-5, err_msg=k)
     assert st.step == 0  # storage.clear()
+    # `alg.optimizer` (what the reference's runner saves / loads, on_policy_runner.py) carries the flat optimizer's state ...
+    sd = ppo.optimizer.state_dict()
+    n_up = int(cfg["num_learning_epochs"]) * int(cfg["num_mini_batches"])
+    ps = list(ac.parameters())
+    assert len(sd["state"]) == len(ps) and all(int(e["step"]) == n_up for e in sd["state"].values())
+    assert all(float(e["exp_avg_sq"].abs().sum()) > 0 for e in sd["state"].values())
+    assert abs(sd["param_groups"][0]["lr"] - ppo.learning_rate) < 1e-12
+    # ... and a second algorithm object that loads it into a fresh torch Adam owns the same moments after its first update() builds
+    # the flat optimizer (load -> FlatAdam.load_torch_adam_state), as does one that loads it after that
+    ac2 = _ActorCritic(d_obs, d_act, [])
+    ac2.load_state_dict(ac.state_dict())
+    ppo2 = PPO(ac2, device=DEV, **cfg)
+    ppo2.optimizer.load_state_dict(sd)
+    sd2 = ppo2.optimizer.state_dict()
+    for i in sd["state"]:
+        assert torch.equal(sd2["state"][i]["exp_avg"].cpu(), sd["state"][i]["exp_avg"].cpu())
+    ppo.optimizer.load_state_dict(sd2)  # (the flat optimizer exists: written through)
+    sd3 = ppo.optimizer.state_dict()
+    for i in sd["state"]:
+        assert torch.equal(sd3["state"][i]["exp_avg_sq"].cpu(), sd["state"][i]["exp_avg_sq"].cpu()) and int(sd3["state"][i]["step"]) == n_up
 
 
 def test_rsl_loss_kernel_gradients_vs_torch_autograd():

@@ -175,6 +175,37 @@ def test_f32_path_and_non_binary_ground_truth():
     assert upd.packed
 
 
+@pytest.mark.parametrize("n,h,w,g,steps,planes", [(4, 120, 160, 16, 6, "3"), (3, 100, 100, 20, 5, "2"), (5, 120, 160, 64, 4, "8"), (2, 30, 37, 33, 4, "32"),
+                                                  (9, 48, 64, 128, 2, ""), (2, 60, 80, 128, 3, "48")])
+def test_large_grid_kernels_bit_exact_vs_oracle(n, h, w, g, steps, planes, monkeypatch):
+    """k_hit_atomic (hit bits by returning global atomics, the first setter lists the voxel) + k_ray_slab (every ray walked slab by
+    slab of x-planes from the closed form of the reference's Bresenham): the path grids above G = 104 take by default, forced here
+    at every size (GENNBV_VOXEL_LARGE=1) with slab heights that do not divide the grid (GENNBV_VOXEL_SLAB_PLANES; rounded up to the
+    word alignment: G = 20 -> 2, G = 33 -> 32 planes); masks, coded grids, tri-class rows and coverage against the oracle over a
+    sequence with resets."""
+    monkeypatch.setenv("GENNBV_VOXEL_LARGE", "1")
+    if planes:
+        monkeypatch.setenv("GENNBV_VOXEL_SLAB_PLANES", planes)
+    _run_sequence(n, h, w, g, steps, seed=40 + g, reset_at=(2,), max_steps=100)
+    _run_sequence(n, h, w, g, min(steps, 3), seed=41 + g, reset_at=(1,), max_steps=100, int8_only=(g ** 3 % 4 == 0))
+
+
+def test_large_grid_kernels_sources_outside_the_grid_and_round1_kernels(monkeypatch):
+    """Ray sources outside the grid through the slab walk (bounds-tested steps), and the round-1 window kernels at 128^3
+    (GENNBV_VOXEL_LARGE=0), which stay the path of a workspace without ray lists."""
+    far = [torch.tensor([[100.0, -60.0, 40.0, 0, 0, 0], [-8.9, 8.9, -3.0, 0, 0, 0], [0.0, 0.0, 300.0, 0, 0, 0],
+                         [2000.0, 900.0, 5000.0, 0, 0, 0]]),
+           torch.tensor([[-700.0, 0.3, 0.2, 0, 0, 0], [8.0, 8.0, 10.0, 0, 0, 0], [-8.0, -8.0, 0.0, 0, 0, 0],
+                         [0.1, 0.1, 0.1, 0, 0, 0]])]
+    monkeypatch.setenv("GENNBV_VOXEL_LARGE", "1")
+    for g, planes in ((16, "5"), (64, "16")):
+        monkeypatch.setenv("GENNBV_VOXEL_SLAB_PLANES", planes)
+        _run_sequence(4, 60, 80, g, 2, seed=5, pose_override=far)
+    monkeypatch.delenv("GENNBV_VOXEL_SLAB_PLANES")
+    monkeypatch.setenv("GENNBV_VOXEL_LARGE", "0")
+    _run_sequence(2, 60, 80, 128, 2, seed=139, reset_at=(1,))
+
+
 def test_ray_source_far_outside_grid():
     """Ray sources the lattice never produces: far outside the grid (closed form with large
     deltas, and the sequential fallback beyond kMaxClosedFormDelta), below / beside the grid."""
@@ -337,13 +368,16 @@ def test_chamfer_distance_vs_float64_brute_force(n, m):
     assert abs(acc - 100.0 * oracle.chamfer_distance_ref(xr, y.numpy())) <= 1e-4 * max(acc, 1e-9) + 1e-9
 
 
-def test_predictor_queue_overflow_falls_back_to_the_canonical_chain():
+@pytest.mark.parametrize("large", ["", "1"])
+def test_predictor_queue_overflow_falls_back_to_the_canonical_chain(large, monkeypatch):
     """k_hit_list decides a pixel with the voxel-space predictor only when its quotients keep clear of every voxel boundary;
     the rest is queued for the canonical chain, and a queue that overflows (2048 per workgroup) re-runs the whole chunk.
     A camera looking straight down at a floor that lies EXACTLY on a voxel boundary plane puts every pixel of env 0 within
     round-off of an integer quotient; env 1 sees the same floor half a voxel higher (all pixels decided by the predictor) with a
     band of special depths (queued, no overflow).  Both must equal the oracle bit for bit."""
     from gennbv_amd.env.state_encoding import OccupancyGridUpdater
+    if large:  # the same stream / queue / fallback inside k_hit_atomic
+        monkeypatch.setenv("GENNBV_VOXEL_LARGE", large)
     n, h, w, g = 2, 240, 320, 16
     cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
     scene = S.make_scenes(n, g, seed=11)
