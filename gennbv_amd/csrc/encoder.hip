@@ -2542,9 +2542,12 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     // Only the optimizer reads dW2: on the split path (whose data-gradient kernel takes its weight images from the forward's
     // k_bn1_analytic, not from this finish) the reduction and the finish wait behind the data gradient and share their launches with
     // the conv1 weight gradient's (k_reduce_partials4_x2, k_wgrad_finish_both): two launches less between the two conv kernels.
-    // (GENNBV_LATE_WGRAD_FINISH=0: the four-launch order, A/B runs.)
+    // OPT-IN (GENNBV_LATE_WGRAD_FINISH=1).  Measured (profiles/r03_notes.md): 34 -> 32 launches per minibatch and no time -- the 17 us
+    // that leave the gap between the two conv kernels come back as a longer data-gradient kernel, which then runs beside more of
+    // fc_grid's dW GEMM on the second stream (100 -> 110 us).
     const ReduceJob job2 = reduce_job(w.wg_part, wg_blocks, E2, w.tmp);
-    static const bool late_env = !(getenv("GENNBV_LATE_WGRAD_FINISH") && getenv("GENNBV_LATE_WGRAD_FINISH")[0] == '0');
+    const char *late_s = getenv("GENNBV_LATE_WGRAD_FINISH");
+    const bool late_env = late_s && late_s[0] == '1';
     const bool late_finish = late_env && split_bwd && fused && !dual_bwd && !dp && reduce_job_ok(job2) && job2.slices <= 32 &&
                              wg_blocks <= 512;  // (its partials must stay clear of the conv1 partials at 512 E2 and its slices of tmp1 at 32 E2)
     if (!late_finish) {

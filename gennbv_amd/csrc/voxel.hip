@@ -1096,14 +1096,15 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(8
     int chunks, int words, uint32_t *__restrict__ hit_mask, int32_t *__restrict__ ray_count, int32_t *__restrict__ ray_list,
     int64_t ray_cap, int32_t *__restrict__ coverage_zero)
 {
-    __shared__ int s_qcnt;
+    __shared__ int s_qcnt, s_cnt;
     __shared__ int s_queue[kQueueCapPx];
     const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
     const int e = (slot / chunks) * 8 + xcd;
     const int c = slot % chunks;
     if (e >= n) return;
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
-    if (tid == 0) s_qcnt = 0;
+    const bool own_env = chunks == 1;  // this workgroup lists the whole env: its ray count lives in LDS until the end
+    if (tid == 0) { s_qcnt = 0; s_cnt = 0; }
     if (coverage_zero != nullptr && c == 0 && tid == 0) coverage_zero[e] = 0;
     const int hw = h * w;
     int ppc = (hw + chunks - 1) / chunks;
@@ -1122,17 +1123,29 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(8
         uint32_t old[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) old[k] = ls[k] >= 0 ? atomicOr(&gh[ls[k] >> 5], 1u << (ls[k] & 31)) : 0xffffffffu;
+        // ONE slot reservation per wave and call: the four ballots first, then the leader's add (an env owned by one workgroup counts in
+        // LDS; the workgroups of a shared env add to its global counter -- the same address for all of them, so every add saved counts)
+        bool first[4];
+        unsigned long long m[4];
+        int total = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const bool first = ls[k] >= 0 && !((old[k] >> (ls[k] & 31)) & 1u);
-            const unsigned long long m = __ballot(first);
-            if (m) {
-                const int leader = __ffsll((long long)m) - 1;
-                int base = 0;
-                if (lane == leader) base = atomicAdd(cnt_e, __popcll(m));
-                base = __builtin_amdgcn_readlane(base, leader);
-                const int o = base + __popcll(m & ((1ull << lane) - 1ull));
-                if (first && o < ray_cap) list[o] = ls[k];
+            first[k] = ls[k] >= 0 && !((old[k] >> (ls[k] & 31)) & 1u);
+            m[k] = __ballot(first[k]);
+            total += __popcll(m[k]);
+        }
+        if (total) {
+            const unsigned long long act = __ballot(true);
+            const int leader = __ffsll((long long)act) - 1;
+            int base = 0;
+            if (lane == leader) base = own_env ? atomicAdd(&s_cnt, total) : atomicAdd(cnt_e, total);
+            base = __builtin_amdgcn_readlane(base, leader);
+            const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int o = base + __popcll(m[k] & below);
+                if (first[k] && o < ray_cap) list[o] = ls[k];
+                base += __popcll(m[k]);
             }
         }
     };
@@ -1141,7 +1154,7 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(8
     if (KFAST && (w & 3) == 0 && hw < (1 << 23) && kUsePredictor) {
         const VoxPredict vp = make_predictor(c2w + (size_t)e * 16, K, range_gt + e * 6, voxel_size + e * 3, g, h, w);
         const unsigned ug = (unsigned)g;
-        constexpr int kTile = kFusedThreads * 4, kAhead = 3;
+        constexpr int kTile = kFusedThreads * 4, kAhead = 2;  // (two tiles in flight: the atomics, not the stream, pace this kernel; 64 VGPRs)
         v4f_t dq[kAhead], sq[kAhead];
         const int plast = px1 - 4;
         const int ntiles = (px1 - px0 + kTile - 1) / kTile;
@@ -1215,19 +1228,61 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(8
             mark4(pixel_to_lin<KFAST>(pf, K, (float)(p - y * w), (float)y, dptr[p], sptr[p]), -1, -1, -1);
         }
     }
+    if (own_env) {
+        __syncthreads();
+        if (tid == 0) *cnt_e = s_cnt;
+    }
 }
 
 // One ray restricted to the x-planes [X0, X1): RayWalk's state at the first point inside, `left` = points inside (see the header).
+__device__ __forceinline__ int udiv_rcp(int n, int d, float rcp_d)  // the same with the reciprocal estimate of d at hand
+{
+    int q = (int)(__fmul_rn((float)n, rcp_d));
+    int r = n - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) ++q;
+    return q;
+}
+// per-workgroup constants of the slab walk: reciprocals of g^2 and g (grids below 2^22 voxels: the target's coordinates by two
+// multiplications instead of two integer divisions) and of the ray count (the lanes' permutation of the list in 32-bit arithmetic)
+struct SlabConsts {
+    float rgg, rg;
+    bool small_grid, perm32;
+    uint32_t cnt_magic, P;
+};
+__device__ __forceinline__ SlabConsts slab_consts(int g, int gg, int cnt)
+{
+    SlabConsts k;
+    k.rgg = __builtin_amdgcn_rcpf((float)gg);
+    k.rg = __builtin_amdgcn_rcpf((float)g);
+    k.small_grid = (int64_t)gg * g < (1 << 22);
+    k.P = (cnt % 7919) ? 7919u : 7907u;  // (as walk_slice: neighbouring list entries are neighbouring voxels)
+    k.perm32 = (uint64_t)cnt * k.P < (1ull << 32);
+    k.cnt_magic = cnt > 0 ? 0xffffffffu / (uint32_t)cnt : 0u;
+    return k;
+}
+// (r * P) mod cnt
+__device__ __forceinline__ int perm_index(int r, int cnt, const SlabConsts &k)
+{
+    if (k.perm32) {
+        const uint32_t x = (uint32_t)r * k.P;
+        uint32_t rem = x - __umulhi(x, k.cnt_magic) * (uint32_t)cnt;  // the estimate is the quotient or one below it
+        if (rem >= (uint32_t)cnt) rem -= (uint32_t)cnt;
+        return (int)rem;
+    }
+    return (int)(((int64_t)r * (int64_t)k.P) % cnt);
+}
+
 template <bool INB>
-__device__ __forceinline__ void init_ray_slab(RayWalk<INB> &rw, const int (&src)[3], int lin_t, int g, int gg, int X0, int X1)
+__device__ __forceinline__ void init_ray_slab(RayWalk<INB> &rw, const int (&src)[3], int lin_t, int g, int gg, int X0, int X1, const SlabConsts &k)
 {
     int tgt[3];
-    tgt[0] = lin_t / gg;
-    const int rem = lin_t - tgt[0] * gg;
-    tgt[1] = rem / g;
-    tgt[2] = rem - tgt[1] * g;
+    tgt[0] = k.small_grid ? udiv_rcp(lin_t, gg, k.rgg) : lin_t / gg;
     rw.left = 0;
     if (max(src[0], tgt[0]) < X0 || min(src[0], tgt[0]) >= X1) return;  // the ray's x-range misses the slab
+    const int rem = lin_t - tgt[0] * gg;
+    tgt[1] = k.small_grid ? udiv_rcp(rem, g, k.rg) : rem / g;
+    tgt[2] = rem - tgt[1] * g;
     const int d0 = abs(tgt[0] - src[0]), d1 = abs(tgt[1] - src[1]), d2 = abs(tgt[2] - src[2]);
     const int dm = max(max(d0, d1), d2);
     const bool ax = dm == d0, ay = !ax && dm == d1;  // dominant axis tested x, y, z (utils.py:69,102,133)
@@ -1262,11 +1317,11 @@ template <bool INB>
 __device__ __forceinline__ void walk_slab(const int (&src)[3], const int32_t *__restrict__ list, int cnt, int first, int stride, int g, int gg,
                                           int X0, int X1, uint32_t *s_path)
 {
-    const int64_t P = (cnt % 7919) ? 7919 : 7907;  // (as walk_slice: neighbouring list entries are neighbouring voxels)
+    const SlabConsts k = slab_consts(g, gg, cnt);
     const unsigned ug = (unsigned)g;
     for (int r = first; r < cnt; r += stride) {
         RayWalk<INB> rw;
-        init_ray_slab<INB>(rw, src, list[(int)(((int64_t)r * P) % cnt)], g, gg, X0, X1);
+        init_ray_slab<INB>(rw, src, list[perm_index(r, cnt, k)], g, gg, X0, X1, k);
         for (int i = rw.left; i > 0; --i) rw.step(ug, s_path);
     }
 }
@@ -1274,14 +1329,15 @@ __device__ __forceinline__ void walk_slab(const int (&src)[3], const int32_t *__
 __global__ __launch_bounds__(kListThreads) void k_ray_slab(
     const int32_t *__restrict__ ray_count, const int32_t *__restrict__ ray_list, int64_t ray_cap, const float *__restrict__ poses_xyz,
     int64_t pose_stride, const float *__restrict__ range_gt, const float *__restrict__ voxel_size, int n, int g, int words, int slabs,
-    int slab_planes, uint32_t *__restrict__ path_mask)
+    int slab_planes, int slices, uint32_t *__restrict__ path_mask)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_path[];
-    // block -> (env, slab, slice); all workgroups of env e run on XCD e % 8
+    // block -> (env, slab, slice); all workgroups of env e run on XCD e % 8.  (`slices` per slab: a workgroup pays ~2 us for clearing
+    // and flushing its mask whatever it walks -- 16 slices x 8 slabs x 512 envs were 65 536 workgroups, a quarter of the launch.)
     const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
-    const int per_env = slabs * kListSlices;
+    const int per_env = slabs * slices;
     const int e = (slot / per_env) * 8 + xcd;
-    const int rem = slot % per_env, slab = rem / kListSlices, sl = rem % kListSlices;
+    const int rem = slot % per_env, slab = rem / slices, sl = rem % slices;
     if (e >= n) return;
     const int cnt = (int)min((int64_t)ray_count[e], ray_cap);
     if (sl * kListThreads >= cnt) return;
@@ -1298,9 +1354,9 @@ __global__ __launch_bounds__(kListThreads) void k_ray_slab(
     __syncthreads();
     const bool src_in = (unsigned)src[0] < (unsigned)g && (unsigned)src[1] < (unsigned)g && (unsigned)src[2] < (unsigned)g;
     if (src_in)
-        walk_slab<true>(src, list, cnt, sl * kListThreads + tid, kListSlices * kListThreads, g, gg, X0, X1, s_path);
+        walk_slab<true>(src, list, cnt, sl * kListThreads + tid, slices * kListThreads, g, gg, X0, X1, s_path);
     else
-        walk_slab<false>(src, list, cnt, sl * kListThreads + tid, kListSlices * kListThreads, g, gg, X0, X1, s_path);
+        walk_slab<false>(src, list, cnt, sl * kListThreads + tid, slices * kListThreads, g, gg, X0, X1, s_path);
     __syncthreads();
     uint32_t *gp = path_mask + (size_t)e * words + w0;
     for (int i = tid; i < nw; i += kListThreads) {
@@ -1967,8 +2023,14 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
             if (slab_lds > 64 * 1024 &&
                 hipFuncSetAttribute((const void *)k_ray_slab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slab_lds) != hipSuccess)
                 return (int)hipGetLastError();
-            hipLaunchKernelGGL(k_ray_slab, dim3(env_groups * 8 * slabs * kListSlices), dim3(kListThreads), slab_lds, st, ws.ray_count, ws.ray_list, ws.ray_cap,
-                               poses_xyz, poses_row_stride, range_gt, voxel_size, n, g, words, slabs, slab_planes, ws.path);
+            int slab_slices = 32 / slabs;  // ~32 workgroups per env, at least two per slab
+            slab_slices = slab_slices < 2 ? 2 : (slab_slices > kListSlices ? kListSlices : slab_slices);
+            if (const char *ss = getenv("GENNBV_VOXEL_SLAB_SLICES")) {
+                const int k = atoi(ss);
+                if (k >= 1 && k <= kListSlices) slab_slices = k;
+            }
+            hipLaunchKernelGGL(k_ray_slab, dim3(env_groups * 8 * slabs * slab_slices), dim3(kListThreads), slab_lds, st, ws.ray_count, ws.ray_list, ws.ray_cap,
+                               poses_xyz, poses_row_stride, range_gt, voxel_size, n, g, words, slabs, slab_planes, slab_slices, ws.path);
             return gnbv_launch_status();
         }
     }

@@ -91,7 +91,8 @@ int gnbv_grid_tri_cls(const float *grid_prob, int64_t count, float threshold_occ
 size_t gnbv_voxel_workspace_bytes(int n, int g);
 /* The same two bitmask arrays + per-env ray lists (one int32 per distinct hit voxel and image chunk, capacity h*w per
  * env): with a workspace of at least this size the update runs the hit-list + load-balanced ray-cast launches
- * (csrc/voxel.hip: k_hit_list, k_ray_list); with the smaller mask-only workspace it falls back to k_hit_mask + k_raycast.
+ * (csrc/voxel.hip: k_hit_list, k_ray_list; grids whose bitmask fits no workgroup's LDS -- G > 104 -- k_hit_atomic, k_ray_slab); with
+ * the smaller mask-only workspace it falls back to k_hit_mask + k_raycast.
  * Same results either way. */
 size_t gnbv_voxel_workspace_bytes_hw(int n, int g, int h, int w);
 /* gnbv_update_occ_grid_coded, workspace_flags: the caller guarantees that the two mask arrays and the ray counts of the

@@ -100,7 +100,7 @@ def test_encoder_forward_backward_vs_torch_reference(g, b, conv2, monkeypatch):
     assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-6
 
 
-@pytest.mark.parametrize("z1", ["0", "1", "qm", "fp32", "dual"])  # "dual": GENNBV_BWD_DUAL=1, the two split backward kernels as ONE launch (opt-in; "0" runs them separately); "qm": y1 stored quad-major (GENNBV_Y1_QM=1, opt-in layout of the same path); "fp32": GENNBV_CONV_SPLIT=0, the fp32-MFMA conv2 kernels ("0" runs the split-f16 ones at G = 64)
+@pytest.mark.parametrize("z1", ["0", "1", "qm", "fp32", "dual", "late"])  # "late": GENNBV_LATE_WGRAD_FINISH=1, both weight-gradient reductions / finishes as two launches behind the data gradient (opt-in); "dual": GENNBV_BWD_DUAL=1, the two split backward kernels as ONE launch (opt-in; "0" runs them separately); "qm": y1 stored quad-major (GENNBV_Y1_QM=1, opt-in layout of the same path); "fp32": GENNBV_CONV_SPLIT=0, the fp32-MFMA conv2 kernels ("0" runs the split-f16 ones at G = 64)
 @pytest.mark.parametrize("g,b", [(16, 5), (32, 3), (48, 2), (64, 4), (128, 1), (64, 128)])  # last: the bench's minibatch
 def test_fused_dgrad_conv1_wgrad_vs_fp64_reference(g, b, z1, monkeypatch):
     """With the int8 grid rows present (G % 16 == 0) the backward runs k_conv2_dgrad_c1w: conv2 data gradient and conv1
@@ -114,8 +114,9 @@ def test_fused_dgrad_conv1_wgrad_vs_fp64_reference(g, b, z1, monkeypatch):
     monkeypatch.setenv("GENNBV_Y1_QM", "1" if z1 == "qm" else "0")
     monkeypatch.setenv("GENNBV_CONV_SPLIT", "0" if z1 == "fp32" else "1")
     monkeypatch.setenv("GENNBV_BWD_DUAL", "1" if z1 == "dual" else "0")
-    if z1 == "dual" and g != 64:
-        pytest.skip("only G = 64 has the split kernels the dual launch combines")
+    monkeypatch.setenv("GENNBV_LATE_WGRAD_FINISH", "1" if z1 == "late" else "0")
+    if z1 in ("dual", "late") and g != 64:
+        pytest.skip("only G = 64 has the split kernels the dual launch combines / the late finish follows")
     # The comparison "analytic vs measured BN1 statistics" below needs bit-identical y1 in both runs: the split conv1 kernel only
     # runs where no partial sums are asked for (the analytic run), the fp32 one in the measured run, and two of the 61 M layer-1
     # pre-activations of the (64, 128) case sit within 2e-8 of the ReLU threshold -- a flipped mask moves the bias gradient, a sum
