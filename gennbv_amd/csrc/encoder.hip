@@ -838,12 +838,13 @@ __global__ __launch_bounds__(256) void k_bn2_bwd_finalize(const float *__restric
     const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int which = o / kC, c = o % kC;
     double acc = 0.0;
-    for (int b = sl; b < B; b += 64) {  // (eight requests in flight, clamped duplicates: same order of additions)
-        float v[8];
+    for (int b = sl; b < B; b += 128) {  // (sixteen requests in flight -- ONE round trip at B = 128: this single workgroup runs beside
+                                         // fc_grid's dW GEMM, whose stream triples the latency of each --, clamped duplicates: same order of additions)
+        float v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = partials[((size_t)min(b + 8 * u, B - 1) * kC + c) * 2 + which];
+        for (int u = 0; u < 16; ++u) v[u] = partials[((size_t)min(b + 8 * u, B - 1) * kC + c) * 2 + which];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 16; ++u)
             if (b + 8 * u < B) acc += (double)v[u];
     }
     sh[sl][o] = acc;
@@ -2542,9 +2543,10 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     // Only the optimizer reads dW2: on the split path (whose data-gradient kernel takes its weight images from the forward's
     // k_bn1_analytic, not from this finish) the reduction and the finish wait behind the data gradient and share their launches with
     // the conv1 weight gradient's (k_reduce_partials4_x2, k_wgrad_finish_both): two launches less between the two conv kernels.
-    // OPT-IN (GENNBV_LATE_WGRAD_FINISH=1).  Measured (profiles/r03_notes.md): 34 -> 32 launches per minibatch and no time -- the 17 us
-    // that leave the gap between the two conv kernels come back as a longer data-gradient kernel, which then runs beside more of
-    // fc_grid's dW GEMM on the second stream (100 -> 110 us).
+    // OPT-IN (GENNBV_LATE_WGRAD_FINISH=1).  Measured (profiles/r03_notes.md): by itself 34 -> 32 launches per minibatch and no time --
+    // the 17 us that leave the gap between the two conv kernels come back as a longer data-gradient kernel beside more of fc_grid's dW
+    // GEMM --; with that GEMM in FRONT of the pose branch's backward on the second stream (GENNBV_DW_FIRST=1, sb3/ppo_grid_obs.py) the
+    // replayed graph is bimodal from process to process: 561-566 us per minibatch or 581-589, against a steady 570-576.
     const ReduceJob job2 = reduce_job(w.wg_part, wg_blocks, E2, w.tmp);
     const char *late_s = getenv("GENNBV_LATE_WGRAD_FINISH");
     const bool late_env = late_s && late_s[0] == '1';

@@ -2025,10 +2025,6 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
                 return (int)hipGetLastError();
             int slab_slices = 32 / slabs;  // ~32 workgroups per env, at least two per slab
             slab_slices = slab_slices < 2 ? 2 : (slab_slices > kListSlices ? kListSlices : slab_slices);
-            if (const char *ss = getenv("GENNBV_VOXEL_SLAB_SLICES")) {
-                const int k = atoi(ss);
-                if (k >= 1 && k <= kListSlices) slab_slices = k;
-            }
             hipLaunchKernelGGL(k_ray_slab, dim3(env_groups * 8 * slabs * slab_slices), dim3(kListThreads), slab_lds, st, ws.ray_count, ws.ray_list, ws.ray_cap,
                                poses_xyz, poses_row_stride, range_gt, voxel_size, n, g, words, slabs, slab_planes, slab_slices, ws.path);
             return gnbv_launch_status();

@@ -453,10 +453,16 @@ class PPO_Grid_Obs:
                 torch.autograd.backward([logits, values], [d_logits, d_values])
                 if lin is not None:
                     lin._defer_wgrad = False
-                # (fc_grid's dW GEMM in FRONT of the pose branch's backward on the second stream -- beside the dx GEMM / the BatchNorm-2 backward
-                # instead of beside k_conv2_wgrad_split -- was measured: 575 -> 577 us per minibatch, profiles/r03_notes.md)
-                encoder_ops.pose_branch_backward(enc, self.device)  # (deferred so that the conv chain is captured first: encoder_ops.hybrid_branches)
-                encoder_ops.join_async_wgrads(self.device)  # fc_grid's dW / db: second stream, beside the conv backward
+                if os.environ.get("GENNBV_DW_FIRST", "0") == "1":
+                    # OPT-IN: fc_grid's dW GEMM in FRONT of the pose branch's backward on the second stream: it starts behind k_fc_bwd_prep and
+                    # runs beside the dx GEMM / the BatchNorm-2 backward instead of beside the two conv kernels.  Measured (profiles/r03_notes.md):
+                    # nothing by itself; with the late weight-gradient finish (csrc/encoder.hip) 561-566 us per minibatch in some processes,
+                    # 581-589 in others, against a steady 570-576.
+                    encoder_ops.join_async_wgrads(self.device)
+                    encoder_ops.pose_branch_backward(enc, self.device)
+                else:
+                    encoder_ops.pose_branch_backward(enc, self.device)  # (deferred so that the conv chain is captured first: encoder_ops.hybrid_branches)
+                    encoder_ops.join_async_wgrads(self.device)  # fc_grid's dW / db: second stream, beside the conv backward
                 if self._sync is None or not self._sync.active:
                     sq = st.get("sq_slice") if (lin is not None and getattr(lin, "_dw_sq_written", False)) else None
                     opt.step(self.max_grad_norm, loss.stop_flag, rotate=st.get("rows_rot"), sq_slice=sq,
