@@ -1204,8 +1204,14 @@ __device__ __forceinline__ void conv2_wgrad_finish_body(const double *__restrict
     if (W2 != nullptr && i < kTaps * 256) prep_w2_element(i, W2, w2img, w2img + kTaps * 256);
     if (i >= E) return;
     double t = 0.0;
-#pragma unroll 8
-    for (int sl = 0; sl < slices; ++sl) t += tmp[(size_t)sl * E + i];
+    for (int sl0 = 0; sl0 < slices; sl0 += 16) {  // (sixteen requests in flight: the usual 16 slices are one round trip; same order of additions)
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = tmp[(size_t)min(sl0 + u, slices - 1) * E + i];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (sl0 + u < slices) t += v[u];
+    }
     if (i < kTaps * 256) {
         const int tap = i >> 8, ci = (i >> 4) & 15, co = i & 15;
         dW2[((size_t)co * kC + ci) * kTaps + tap] = (float)t;
@@ -1780,12 +1786,12 @@ __device__ __forceinline__ void c1w_fused_finish_body(const double *__restrict__
     }
     if (threadIdx.x < kE1F) {
         double a = 0.0;
-        for (int sl0 = 0; sl0 < slices; sl0 += 8) {
-            double v[8];
+        for (int sl0 = 0; sl0 < slices; sl0 += 16) {
+            double v[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = tmp[(size_t)min(sl0 + u, slices - 1) * kE1F + threadIdx.x];
+            for (int u = 0; u < 16; ++u) v[u] = tmp[(size_t)min(sl0 + u, slices - 1) * kE1F + threadIdx.x];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 16; ++u)
                 if (sl0 + u < slices) a += v[u];
         }
         ssum[threadIdx.x] = a;

@@ -27,21 +27,26 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 // ---- "NT" contraction: both operands k-contiguous, 16-byte requests along k ------------------------
 // arow / brow point at (row i, k = 0) / (col j, k = 0) of this lane (already offset by 4 kq); K % 16 == 0.
 // A may switch to a second segment (the concat of two inputs) at k = K1.
+// U = 16-k groups whose requests are issued together: the contraction is a chain of dependent L2 round trips (~1 us each) with a
+// handful of MFMAs in between, and these launches are a few dozen single-wave-per-SIMD workgroups -- registers are free.  U = 16
+// (256 k per round trip, 128 VGPRs of operands) makes output_layer's K = 512 two round trips instead of eight (round 3; the
+// order of the accumulation, k ascending, is unchanged: bit-identical results).
+template <int U>
 __device__ __forceinline__ f32x4 contract_nt(const float *arow, const float *arow2, int K1, const float *brow, int K, bool a_ok, bool b_ok)
 {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k0 = 0; k0 < K; k0 += 64) {
-        float4 a[4], b[4];
+    for (int k0 = 0; k0 < K; k0 += 16 * U) {
+        float4 a[U], b[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int k = min(k0 + 16 * u, K - 16);
             a[u] = ld4(k < K1 ? arow + k : arow2 + (k - K1));
             b[u] = ld4(brow + k);
         }
-        __builtin_amdgcn_sched_barrier(0);  // all 8 requests of the 64-k step before its first MFMA
+        __builtin_amdgcn_sched_barrier(0);  // all 2 U requests of the step before its first MFMA
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const bool live = k0 + 16 * u < K;
             const float4 av = (a_ok && live) ? a[u] : z, bv = b_ok ? b[u] : z;
             acc = mfma4(av.x, bv.x, acc);
@@ -52,6 +57,8 @@ __device__ __forceinline__ f32x4 contract_nt(const float *arow, const float *aro
     }
     return acc;
 }
+constexpr int kHeadU = 16;  // 16-k groups per round trip in the forward contractions
+constexpr int kHeadUB = 4;  // 32-k (or 32-row) groups per round trip in the backward contractions (4-byte requests: 16 per group)
 
 // ===========================================================================================
 // forward 1: feat[M][F] = relu([fa | fg] W_out^T + b_out)
@@ -65,8 +72,8 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_fwd_feat(const float *__r
     const int tiles_j = F / 16, tile = blockIdx.x * 4 + wv, ti = tile / tiles_j, tj = tile % tiles_j;
     if (ti * 16 >= M) return;
     const int i = min(ti * 16 + x, M - 1), j = tj * 16 + x;
-    const f32x4 acc = contract_nt(fa + (size_t)i * K1 + 4 * kq, fg + (size_t)i * K2 + 4 * kq, K1, W_out + (size_t)j * (K1 + K2) + 4 * kq,
-                                  K1 + K2, true, true);
+    const f32x4 acc = contract_nt<kHeadU>(fa + (size_t)i * K1 + 4 * kq, fg + (size_t)i * K2 + 4 * kq, K1, W_out + (size_t)j * (K1 + K2) + 4 * kq,
+                                          K1 + K2, true, true);
     const float bias = b_out[j];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_fwd_out(const float *__re
     if (ti * 16 >= M) return;
     const int i = min(ti * 16 + x, M - 1), j = tj * 16 + x;
     const float *brow = j < A ? W_act + (size_t)j * F : W_val;  // column A = the value head
-    const f32x4 acc = contract_nt(feat + (size_t)i * F + 4 * kq, feat, F, brow + 4 * kq, F, true, j <= A);
+    const f32x4 acc = contract_nt<kHeadU>(feat + (size_t)i * F + 4 * kq, feat, F, brow + 4 * kq, F, true, j <= A);
     const float bias = j < A ? b_act[j] : (j == A ? b_val[0] : 0.0f);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -116,20 +123,21 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_bwd_dh(const float *__res
     if (ti * 16 >= M) return;
     const int i = min(ti * 16 + x, M - 1), j = tj * 16 + x, K = A + 1;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += 32) {
-        float a[2][4], b[2][4];
+    const float dv = d_values[i], wv_j = W_val[j];
+    for (int k0 = 0; k0 < K; k0 += 32 * kHeadUB) {  // (kHeadUB x 16 requests per round trip: A + 1 = 241 -> two instead of eight)
+        float a[2 * kHeadUB][4], b[2 * kHeadUB][4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2 * kHeadUB; ++u)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int k = k0 + 16 * u + 4 * kq + s, kc = min(k, A - 1);
                 const float av = d_logits[(size_t)i * A + kc], bv = W_act[(size_t)kc * F + j];
-                a[u][s] = k < A ? av : (k == A ? d_values[i] : 0.0f);
-                b[u][s] = k < A ? bv : (k == A ? W_val[j] : 0.0f);
+                a[u][s] = k < A ? av : (k == A ? dv : 0.0f);
+                b[u][s] = k < A ? bv : (k == A ? wv_j : 0.0f);
             }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2 * kHeadUB; ++u)
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc = mfma4(a[u][s], b[u][s], acc);
     }
@@ -162,11 +170,11 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_bwd_rest(const float *__r
         const int tiles_j = KC / 16, ti = tile / tiles_j, tj = tile % tiles_j;
         const int i = min(ti * 16 + x, M - 1), j = tj * 16 + x;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int k0 = 0; k0 < F; k0 += 32) {
-            float4 a[2];
-            float b[2][4];
+        for (int k0 = 0; k0 < F; k0 += 32 * kHeadUB) {
+            float4 a[2 * kHeadUB];
+            float b[2 * kHeadUB][4];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < 2 * kHeadUB; ++u) {
                 const int k = min(k0 + 16 * u, F - 16) + 4 * kq;
                 a[u] = ld4(dH + (size_t)i * F + k);
 #pragma unroll
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_bwd_rest(const float *__r
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < 2 * kHeadUB; ++u) {
                 if (k0 + 16 * u >= F) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 acc = mfma4(a[u].x, b[u][0], acc);
                 acc = mfma4(a[u].y, b[u][1], acc);
@@ -202,10 +210,10 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_bwd_rest(const float *__r
     const int i = ti * 16 + x, j = tj * 16 + x;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float asum = 0.0f;
-    for (int m0 = 0; m0 < M; m0 += 32) {
-        float a[2][4], b[2][4];
+    for (int m0 = 0; m0 < M; m0 += 32 * kHeadUB) {
+        float a[2 * kHeadUB][4], b[2 * kHeadUB][4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2 * kHeadUB; ++u)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int m = m0 + 16 * u + 4 * kq + s, mc = min(m, M - 1);
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_bwd_rest(const float *__r
             }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2 * kHeadUB; ++u)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 acc = mfma4(a[u][s], b[u][s], acc);
@@ -259,6 +267,8 @@ GNBV_API int gnbv_policy_head_forward(const float *fa, const float *fg, int M, i
     GNBV_CHECK_ARG((((uintptr_t)fa | (uintptr_t)fg | (uintptr_t)W_out | (uintptr_t)W_act | (uintptr_t)W_val | (uintptr_t)feat) & 15) == 0);
     hipStream_t st = gnbv_stream(stream);
     const int mt = (M + 15) / 16;
+    // (Both as ONE launch -- a workgroup per 16 rows, the features handed over in LDS -- was measured in round 3: 578-582 -> 601-606 us per
+    // minibatch.  Eight workgroups pull all of W_out, 512 KiB each, through eight CUs' load paths; 32 workgroups share it out.)
     hipLaunchKernelGGL(k_head_fwd_feat, dim3((mt * (F / 16) + 3) / 4), dim3(kHeadThreads), 0, st, fa, fg, M, K1, K2, W_out, b_out, F, feat);
     int err;
     if ((err = gnbv_launch_status())) return err;

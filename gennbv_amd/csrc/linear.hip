@@ -417,9 +417,9 @@ __global__ __launch_bounds__(256) void k_linear_reduce(const float *__restrict__
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e4 < total4) {
         const int per = (nchunks + kRedSplit - 1) / kRedSplit, c0 = part * per, c1 = min(nchunks, c0 + per);
-        // eight chunks requested before the first is added (clamped duplicates past the end: unconditional requests) -- as a plain
+        // kU chunks requested before the first is added (clamped duplicates past the end: unconditional requests) -- as a plain
         // loop this was one round trip per chunk, 32 in a row on the update's critical path; same order of additions
-        constexpr int kU = 8;
+        constexpr int kU = 16;  // (round 3: sixteen -- fc_grid's 128 chunks over four parts are two round trips instead of four)
         for (int c = c0; c < c1; c += kU) {
             float4 v[kU];
 #pragma unroll

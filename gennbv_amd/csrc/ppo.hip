@@ -70,6 +70,28 @@ __device__ __forceinline__ HeadStats head_stats(const float *lg, int n, int lane
     return {lse, -pe};
 }
 
+// The same statistics from the head's logits in registers (x0 = logit lane, x1 = logit lane + 64; n <= 128): the same per-lane order of
+// operations and the same shuffles as head_stats -- bit-identical --, without its three passes of loads per head (each pass of each of
+// the six heads was a round trip of its own on the update's critical path: k_ppo_fused 16 us).
+__device__ __forceinline__ HeadStats head_stats_regs(float x0, float x1, int n, int lane)
+{
+    const bool h0 = lane < n, h1 = lane + 64 < n;
+    float mx = -INFINITY;
+    if (h0) mx = fmaxf(mx, x0);
+    if (h1) mx = fmaxf(mx, x1);
+    for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    float se = 0.f;
+    if (h0) se += expf(x0 - mx);
+    if (h1) se += expf(x1 - mx);
+    for (int d = 32; d > 0; d >>= 1) se += __shfl_xor(se, d, 64);
+    const float lse = mx + logf(se);
+    float pe = 0.f;
+    if (h0) { const float lp = x0 - lse; pe += expf(lp) * lp; }
+    if (h1) { const float lp = x1 - lse; pe += expf(lp) * lp; }
+    for (int d = 32; d > 0; d >>= 1) pe += __shfl_xor(pe, d, 64);
+    return {lse, -pe};
+}
+
 // The minibatch's logged scalars from the per-sample terms k_ppo_fused left in `terms` ([B][8]), added in a fixed order by ONE
 // workgroup of kLossThreads threads; writes the statistics row, takes the KL early-stop decision (ppo_grid_obs.py:261-268) and --
 // `step` != NULL: the caller is the optimizer's norm launch -- counts the optimizer step unless the update is masked.
@@ -123,16 +145,41 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_fused(GnbvPpoLoss a, float
         float lse[kMaxHeads], hent[kMaxHeads];
         int act[kMaxHeads];
         float logp = 0.f, ent = 0.f;
+        // every operand first -- the sample's logits (two per lane and head: heads of <= 128 categories), its actions and the logits of
+        // the taken actions' heads are then in flight together instead of head after head
+        float x0[kMaxHeads], x1[kMaxHeads], xa[kMaxHeads];
+        bool regs = true;  // (uniform)
         {
             int off = 0;
 #pragma unroll
             for (int h = 0; h < kMaxHeads; ++h) {
                 if (h < a.n_heads) {
                     const int n = a.head_dims[h];
-                    const HeadStats hs = head_stats(lg + off, n, lane);
-                    lse[h] = hs.lse; hent[h] = hs.ent;
+                    regs = regs && n <= 128;
+                    x0[h] = lg[off + min(lane, n - 1)];
+                    x1[h] = lg[off + min(lane + 64, n - 1)];
                     act[h] = (int)a.actions[(size_t)r * a.n_heads + h];  // actions are stored as float (buffers.py:664)
-                    logp += lg[off + act[h]] - hs.lse;
+                    off += n;
+                }
+            }
+            off = 0;
+#pragma unroll
+            for (int h = 0; h < kMaxHeads; ++h) {
+                if (h < a.n_heads) {
+                    xa[h] = lg[off + act[h]];
+                    off += a.head_dims[h];
+                }
+            }
+        }
+        {
+            int off = 0;
+#pragma unroll
+            for (int h = 0; h < kMaxHeads; ++h) {
+                if (h < a.n_heads) {
+                    const int n = a.head_dims[h];
+                    const HeadStats hs = regs ? head_stats_regs(x0[h], x1[h], n, lane) : head_stats(lg + off, n, lane);
+                    lse[h] = hs.lse; hent[h] = hs.ent;
+                    logp += xa[h] - hs.lse;
                     ent += hs.ent;
                     if (a.head_entropy && lane == 0) a.head_entropy[(size_t)i * a.n_heads + h] = hs.ent;
                     if (a.head_lse && lane == 0) a.head_lse[(size_t)i * a.n_heads + h] = hs.lse;
@@ -195,7 +242,8 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_fused(GnbvPpoLoss a, float
             if (h < a.n_heads) {
                 const int n = a.head_dims[h];
                 for (int j = lane; j < n; j += 64) {
-                    const float lp = lg[off + j] - lse[h], p = expf(lp);
+                    const float xv = regs ? (j == lane ? x0[h] : x1[h]) : lg[off + j];
+                    const float lp = xv - lse[h], p = expf(lp);
                     dl[off + j] = gl * ((j == act[h] ? 1.f : 0.f) - p) + a.ent_coef * invB * p * (lp + hent[h]);
                 }
                 off += n;
