@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_fwd_feat(const float *__r
 {
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int x = lane & 15, kq = lane >> 4;
-    const int tiles_j = F / 16, tile = blockIdx.x * 4 + wv, ti = tile / tiles_j, tj = tile % tiles_j;
+    const int tiles_j = F / 16, tile = blockIdx.x * (int)(blockDim.x / kWave) + wv, ti = tile / tiles_j, tj = tile % tiles_j;
     if (ti * 16 >= M) return;
     const int i = min(ti * 16 + x, M - 1), j = tj * 16 + x;
     const f32x4 acc = contract_nt<kHeadU>(fa + (size_t)i * K1 + 4 * kq, fg + (size_t)i * K2 + 4 * kq, K1, W_out + (size_t)j * (K1 + K2) + 4 * kq,
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_fwd_out(const float *__re
 {
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int x = lane & 15, kq = lane >> 4;
-    const int tiles_j = (A + 1 + 15) / 16, tile = blockIdx.x * 4 + wv, ti = tile / tiles_j, tj = tile % tiles_j;
+    const int tiles_j = (A + 1 + 15) / 16, tile = blockIdx.x * (int)(blockDim.x / kWave) + wv, ti = tile / tiles_j, tj = tile % tiles_j;
     if (ti * 16 >= M) return;
     const int i = min(ti * 16 + x, M - 1), j = tj * 16 + x;
     const float *brow = j < A ? W_act + (size_t)j * F : W_val;  // column A = the value head
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_bwd_dh(const float *__res
 {
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int x = lane & 15, kq = lane >> 4;
-    const int tiles_j = F / 16, tile = blockIdx.x * 4 + wv, ti = tile / tiles_j, tj = tile % tiles_j;
+    const int tiles_j = F / 16, tile = blockIdx.x * (int)(blockDim.x / kWave) + wv, ti = tile / tiles_j, tj = tile % tiles_j;
     if (ti * 16 >= M) return;
     const int i = min(ti * 16 + x, M - 1), j = tj * 16 + x, K = A + 1;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_bwd_rest(const float *__r
 {
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int x = lane & 15, kq = lane >> 4, KC = K1 + K2;
-    int tile = blockIdx.x * 4 + wv;
+    int tile = blockIdx.x * (int)(blockDim.x / kWave) + wv;
     if (tile < n0) {
         // ---- kind 0: rows = minibatch rows, columns = concat inputs ----
         const int tiles_j = KC / 16, ti = tile / tiles_j, tj = tile % tiles_j;
@@ -269,10 +269,12 @@ GNBV_API int gnbv_policy_head_forward(const float *fa, const float *fg, int M, i
     const int mt = (M + 15) / 16;
     // (Both as ONE launch -- a workgroup per 16 rows, the features handed over in LDS -- was measured in round 3: 578-582 -> 601-606 us per
     // minibatch.  Eight workgroups pull all of W_out, 512 KiB each, through eight CUs' load paths; 32 workgroups share it out.)
-    hipLaunchKernelGGL(k_head_fwd_feat, dim3((mt * (F / 16) + 3) / 4), dim3(kHeadThreads), 0, st, fa, fg, M, K1, K2, W_out, b_out, F, feat);
+    // ONE wave (tile) per workgroup in the three launches with at most a few hundred tiles: a tile pulls its 64 KiB of operands through
+    // its CU's load path (~23 GB/s per CU), so 128 tiles on 128 CUs instead of four each on 32
+    hipLaunchKernelGGL(k_head_fwd_feat, dim3(mt * (F / 16)), dim3(kWave), 0, st, fa, fg, M, K1, K2, W_out, b_out, F, feat);
     int err;
     if ((err = gnbv_launch_status())) return err;
-    hipLaunchKernelGGL(k_head_fwd_out, dim3((mt * ((A + 1 + 15) / 16) + 3) / 4), dim3(kHeadThreads), 0, st, (const float *)feat, M, F, W_act, b_act,
+    hipLaunchKernelGGL(k_head_fwd_out, dim3(mt * ((A + 1 + 15) / 16)), dim3(kWave), 0, st, (const float *)feat, M, F, W_act, b_act,
                        A, W_val, b_val, logits, values);
     return gnbv_launch_status();
 }
@@ -288,7 +290,7 @@ GNBV_API int gnbv_policy_head_backward(const float *fa, const float *fg, int M, 
     GNBV_CHECK_ARG((((uintptr_t)dH_scratch) & 15) == 0);
     hipStream_t st = gnbv_stream(stream);
     const int mt = (M + 15) / 16, KC = K1 + K2;
-    hipLaunchKernelGGL(k_head_bwd_dh, dim3((mt * (F / 16) + 3) / 4), dim3(kHeadThreads), 0, st, d_logits, d_values, M, A, W_act, W_val, F, feat,
+    hipLaunchKernelGGL(k_head_bwd_dh, dim3(mt * (F / 16)), dim3(kWave), 0, st, d_logits, d_values, M, A, W_act, W_val, F, feat,
                        dH_scratch);
     int err;
     if ((err = gnbv_launch_status())) return err;

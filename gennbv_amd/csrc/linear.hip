@@ -408,12 +408,16 @@ __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 
 // out[m][n] = act(bias[n] + sum_c partial[c][m][n]); one thread per 4 consecutive columns, the chunk
 // loop is split over `kRedSplit` threads whose sub-sums are combined in a fixed order through LDS.
 constexpr int kRedSplit = 4;
-__global__ __launch_bounds__(256) void k_linear_reduce(const float *__restrict__ partial, const float *__restrict__ bias, int M, int N,
+constexpr int kRedQ = 16;
+__global__ __launch_bounds__(kRedSplit * kRedQ) void k_linear_reduce(const float *__restrict__ partial, const float *__restrict__ bias, int M, int N,
                                                        int nchunks, int relu, float *__restrict__ out)
 {
-    __shared__ float4 sub[kRedSplit][64];
-    const int q = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int64_t e4 = (int64_t)blockIdx.x * 64 + q, total4 = (int64_t)M * N / 4;
+    // kRedQ float4 elements x kRedSplit parts per workgroup (round 3: 16 x 4 = one wave; with 64 x 4 a workgroup pulled 128 chunks x 1 KiB
+    // through its CU's load path, ~23 GB/s per CU: the 6 us of this launch at fc_grid's shape; 512 one-wave workgroups share it out.
+    // Same sums in the same order.)
+    __shared__ float4 sub[kRedSplit][kRedQ];
+    const int q = threadIdx.x % kRedQ, part = threadIdx.x / kRedQ;
+    const int64_t e4 = (int64_t)blockIdx.x * kRedQ + q, total4 = (int64_t)M * N / 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e4 < total4) {
         const int per = (nchunks + kRedSplit - 1) / kRedSplit, c0 = part * per, c1 = min(nchunks, c0 + per);
@@ -711,7 +715,7 @@ GNBV_API int gnbv_linear_forward_fold(const float *y, const float *scale, const 
     int err;
     if ((err = gnbv_launch_status())) return err;
     const int64_t total4 = (int64_t)M * N / 4;
-    hipLaunchKernelGGL(k_linear_reduce, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, st, (const float *)workspace, bias, M, N, nchunks,
+    hipLaunchKernelGGL(k_linear_reduce, dim3((unsigned)((total4 + kRedQ - 1) / kRedQ)), dim3(kRedSplit * kRedQ), 0, st, (const float *)workspace, bias, M, N, nchunks,
                        relu & 1, out);
     return gnbv_launch_status();
 }
@@ -735,7 +739,7 @@ GNBV_API int gnbv_linear_forward_fold_adam(const float *y, const float *scale, c
     int err;
     if ((err = gnbv_launch_status())) return err;
     const int64_t total4 = (int64_t)M * N / 4;
-    hipLaunchKernelGGL(k_linear_reduce, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, st, (const float *)workspace, bias, M, N, nchunks,
+    hipLaunchKernelGGL(k_linear_reduce, dim3((unsigned)((total4 + kRedQ - 1) / kRedQ)), dim3(kRedSplit * kRedQ), 0, st, (const float *)workspace, bias, M, N, nchunks,
                        relu & 1, out);
     return gnbv_launch_status();
 }
@@ -759,7 +763,7 @@ GNBV_API int gnbv_linear_forward(const float *x, const float *w, const float *bi
     int err;
     if ((err = gnbv_launch_status())) return err;
     const int64_t total4 = (int64_t)M * N / 4;
-    hipLaunchKernelGGL(k_linear_reduce, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, st, (const float *)workspace, bias, M, N, nchunks,
+    hipLaunchKernelGGL(k_linear_reduce, dim3((unsigned)((total4 + kRedQ - 1) / kRedQ)), dim3(kRedSplit * kRedQ), 0, st, (const float *)workspace, bias, M, N, nchunks,
                        relu, out);
     return gnbv_launch_status();
 }
