@@ -302,9 +302,13 @@ def test_bad_arguments_return_error_codes():
     assert lib.gnbv_gae_sb3(None, None, None, None, None, 1, 1, 0.99, 0.95, None, None, None) == 1
 
 
-def test_non_pinhole_intrinsics_take_the_generic_path():
-    """inv_intri with non-zero skew terms disables the exact-zero shortcut (k_hit_mask<false>)."""
+@pytest.mark.parametrize("large", ["", "1"])
+def test_non_pinhole_intrinsics_take_the_generic_path(large, monkeypatch):
+    """inv_intri with non-zero skew terms disables the exact-zero shortcut (k_hit_list<false> / k_hit_mask<false>; large = "1":
+    k_hit_atomic<false>, the canonical chain over every pixel through the atomics)."""
     from gennbv_amd.env.state_encoding import OccupancyGridUpdater
+    if large:
+        monkeypatch.setenv("GENNBV_VOXEL_LARGE", large)
     n, h, w, g = 3, 60, 80, 16
     cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
     scene = S.make_scenes(n, g, seed=21)
@@ -322,9 +326,12 @@ def test_non_pinhole_intrinsics_take_the_generic_path():
     assert upd.prob_grid.cpu().numpy().tobytes() == prob.tobytes()
 
 
-def test_special_depth_values_in_fused_path():
-    """NaN / +-inf / < -50 raw depths and NaN seg inside the fused kernel (A1 fused)."""
+@pytest.mark.parametrize("large", ["", "1"])
+def test_special_depth_values_in_fused_path(large, monkeypatch):
+    """NaN / +-inf / < -50 raw depths and NaN seg inside the fused kernel (A1 fused; large = "1": inside k_hit_atomic)."""
     from gennbv_amd.env.state_encoding import OccupancyGridUpdater
+    if large:
+        monkeypatch.setenv("GENNBV_VOXEL_LARGE", large)
     n, h, w, g = 2, 48, 64, 16
     cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
     scene = S.make_scenes(n, g, seed=4)
