@@ -1,6 +1,6 @@
 """bench.py -- env-steps/sec of the GenNBV state-encoding + PPO hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W      (N > 1 without a launcher environment: starts its N ranks itself, self_launch())
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch of synthetic input = one PPO
@@ -374,12 +374,60 @@ def _flush_c_stdio():
         pass
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks ourselves -- the command the contract
+    names (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`) with a
+    free port -- and hand its exit code back.  The ranks' stdout is inherited, so rank 0's JSON line is this process's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL across processes needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without a launcher environment: starting the ranks with: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, world: int, rank: int) -> None:
+    """GENNBV_BENCH_DRY=1 (tests/test_bench_launch_cpu.py): the launch / rendezvous / max-over-ranks / one-JSON-line skeleton of main() over
+    gloo, without a GPU and without the hot path -- what `--gpus N` needs in order to START wherever N devices exist."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "max_rank_seconds": elapsed}), flush=True)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("GENNBV_BENCH_DRY") == "1":
+        return dry_run(args, world, int(os.environ.get("RANK", "0")))
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if torch.cuda.device_count() < max(1, world):
+        raise SystemExit(f"bench.py: {world} rank(s) need {world} GPU(s), this node shows {torch.cuda.device_count()}")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 or os.environ.get("GENNBV_FORCE_DP") == "1":
