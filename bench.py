@@ -40,9 +40,6 @@ def parse():
     ap.add_argument("--n-epochs", type=int, default=5)
     ap.add_argument("--frames", type=int, default=8, help="frames in the synthetic feed pool")
     ap.add_argument("--backend", default="hip", choices=["hip", "torch"])
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
-                    help="fp32 (default, the headline): fp32-accurate arithmetic; bf16: the opt-in reduced-precision mode -- layer-1 activations "
-                         "stored as bf16, arithmetic in fp32 (flat rows only; PPO loss delta 1e-3-class, tests/test_ppo_gpu.py)")
     ap.add_argument("--obs", default="compact", choices=["flat", "compact"],
                     help="rollout-buffer rows: the reference's flat fp32 rows, or compact rows (grid as int8 only; same values)")
     ap.add_argument("--target-kl", default="off", help="'off' (default): the KL early stop of PPO_Grid_Obs.train (ppo_grid_obs.py:261-268) can never "
@@ -61,8 +58,6 @@ def parse():
 
 def build_algo(args, device, rank, world):
     import torch
-    if args.dtype == "bf16":
-        args.obs = "flat"  # (the bf16-storage kernels read the fp32 grid slice of flat rows)
     from gennbv_amd.env import synthetic as S
     from gennbv_amd.env.config import TaskConfig, PPOConfig
     from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
@@ -88,7 +83,6 @@ def build_algo(args, device, rank, world):
                                net_param={"transformer_params": [[1, 256], [1, 256]], "append_hidden_shapes": [256, 256]},
                                state_input_shape=(cfg.state_dim,),
                                visual_input_shape=(cfg.stack, cfg.camera_height, cfg.camera_width),
-                               compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32,
                                **({"semantic_branch": True} if args.semantic and args.backend == "hip" else {}))))
     if world > 1 or os.environ.get("GENNBV_FORCE_DP") == "1":
         from gennbv_amd import parallel
@@ -342,7 +336,7 @@ def flat_rows_line(args, device, steps: int = 2):
     """The same iteration with the REFERENCE's rollout-buffer layout -- flat fp32 rows [state | grid | state_rgb]
     (stable_baselines3/common/buffers.py:655-669; `PPO_Grid_Obs(compact_obs=False)`, the API default) -- measured in the same
     process after the headline: 1 warm-up + `steps` timed iterations.  The env still writes the int8 grid rows the conv1
-    kernels read as a side copy (GENNBV_GRID_I8); the fp32 rows are what `get()` / checkpoints / callbacks see."""
+    kernels read as a side copy (`PPO_Grid_Obs.grid_i8_rows`); the fp32 rows are what `get()` / checkpoints / callbacks see."""
     import copy
     import torch
     a2 = copy.copy(args)
@@ -498,7 +492,7 @@ def main():
         "metric": "env-steps/sec at 256 envs x 64^3 grid (state encoding + policy forward + GAE + PPO update)",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.dtype == "fp32" else "f32 arithmetic, bf16 layer-1 activation storage (opt-in reduced-precision mode)", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: {args.envs} envs/GPU x {args.height}x{args.width} depth x "
                                f"{args.grid}^3 grid, n_steps={args.n_steps}, batch_size={args.batch_size}, "
                                f"n_epochs={args.n_epochs}, one step = one PPO iteration",
@@ -507,8 +501,6 @@ def main():
                    "kl_early_stop": "reference (0.05)" if args.target_kl == "ref" else "never triggers (full work every iteration)",
                    "minibatches_last_iteration": int(len(algo.last_train_stats)) if getattr(algo, "last_train_stats", None) is not None else None,
                    "hbm_peak_allocated_gb": torch.cuda.max_memory_allocated(device) / 1e9,
-                   "fc_grid_adam": {None: "inside the optimizer launch", "side": "owed to the next minibatch: second stream, beside its conv forward",
-                                    "fuse": "owed to the next minibatch's fc_grid forward kernel"}[(algo._hip or {}).get("owe_mode")],
                    "parallelism": f"env-sharded dp{world}", "dp_graph_mode": getattr(algo, "dp_graph_mode", None),
                    "dp_update": (None if world == 1 else "fc_grid.weight reduce-scattered, updated by its owner rank, all-gathered; the rest all-reduced"
                                  if getattr((algo._hip or {}).get("opt"), "shard", None) is not None else "whole gradient all-reduced, replicated update"),

@@ -68,7 +68,6 @@ SIGNATURES = {
     "gnbv_linear_fold_ok": (_i, [_i, _i, _i, _i]),
     "gnbv_linear_forward_fold": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "gnbv_linear_bwd_dw_fold": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
-    "gnbv_linear_forward_fold_adam": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p, _p]),
     "gnbv_pose_encode": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
     "gnbv_policy_head_forward": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
     "gnbv_policy_head_backward": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -82,7 +81,6 @@ SIGNATURES = {
     "gnbv_clip_adam_step_rotate": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _p, _f, _p, _f, _p, _p, _sz, _p, _i, _i, _p, _p, _p]),
     "gnbv_clip_adam_step_ex": (_i, [_p, _p]),
     "gnbv_adam_shard_step": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _p, _p, _p]),
-    "gnbv_adam_slice_pending": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _p, _p, _p]),
     "gnbv_chamfer_workspace_bytes": (_sz, [_i, _i]),
     "gnbv_chamfer_distance": (_i, [_p, _i, _p, _i, _p, _p, _sz, _p]),
     "gnbv_gae_sb3": (_i, [_p, _p, _p, _p, _p, _i, _i, _d, _d, _p, _p, _p]),
@@ -111,7 +109,7 @@ class GnbvEncoderParams(C.Structure):
     """include/gennbv_hip.h: GnbvEncoderParams"""
     _fields_ = [("w1", _p), ("b1", _p), ("bn1_w", _p), ("bn1_b", _p), ("bn1_rm", _p), ("bn1_rv", _p), ("bn1_nbt", _p),
                 ("w2", _p), ("b2", _p), ("bn2_w", _p), ("bn2_b", _p), ("bn2_rm", _p), ("bn2_rv", _p), ("bn2_nbt", _p),
-                ("eps", _f), ("momentum", _f), ("act_bf16", _i), ("grid_i8", _p), ("grid_i8_row_stride", _i64),
+                ("eps", _f), ("momentum", _f), ("grid_i8", _p), ("grid_i8_row_stride", _i64),
                 ("autocorr", _p), ("autocorr_row_stride", _i64),
                 ("world", _i), ("sync_sum", _p), ("sync_ctx", _p), ("sync_buf", _p), ("autocorr_global", _p),
                 ("autocorr_total", _p), ("force_fp32", _i), ("range_flag", _p)]
@@ -124,13 +122,7 @@ class GnbvAdamStep(C.Structure):
                 ("step", _p), ("stop_flag", _p), ("grad_scale", _f), ("kl_slot", _p), ("target_kl", _f),
                 ("norm_out", _p), ("workspace", _p), ("workspace_bytes", _sz),
                 ("table", _p), ("table_rows", _i), ("row_len", _i), ("out", _p), ("counter", _p),
-                ("sq_lo", _i64), ("sq_hi", _i64), ("sq_partial", _p), ("sq_parts", _i), ("loss_finish", _p), ("upd_skip_lo", _i64), ("upd_skip_hi", _i64), ("pending", _p)]
-
-
-class GnbvOwedAdam(C.Structure):
-    """include/gennbv_hip.h: GnbvOwedAdam"""
-    _fields_ = [("grads", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("norm_out", _p), ("step", _p), ("pending", _p),
-                ("lr", _f), ("beta1", _f), ("beta2", _f), ("eps", _f)]
+                ("sq_lo", _i64), ("sq_hi", _i64), ("sq_partial", _p), ("sq_parts", _i), ("loss_finish", _p), ("upd_skip_lo", _i64), ("upd_skip_hi", _i64)]
 
 
 class GnbvEncoderGrads(C.Structure):
@@ -170,7 +162,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.gnbv_abi_version() != 3:
+    if lib.gnbv_abi_version() != 4:
         raise GennbvHipError("libgennbv_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -328,7 +328,6 @@ __device__ __forceinline__ float grad_scale(const unsigned *absmax)
 // compiler kept alive across the whole kernel (and spilled)
 __device__ __forceinline__ float inv_pow2(float p) { return __int_as_float(0x7f000000 - __float_as_int(p)); }
 
-// (the body, with the workgroup's index as a parameter: k_conv2_bwd_dual_split runs it on every second group of eight workgroups)
 __device__ __forceinline__ void conv2_wgrad_split_body(
     const float *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1, const float *__restrict__ dy2 /*[B,O2^3,16]*/,
     const unsigned *__restrict__ absmax, int B, int O1, int O2, float *__restrict__ partial /*[grid][27 * 256 + 16]*/, const int vblock)
@@ -902,44 +901,6 @@ __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_split(
 {
     conv2_dgrad_c1w_split_body(dy2, w2img, wbound, absmax, y1, scale1, shift1, mean1, rstd1, grid_i8, rows, grid_row_stride, B, G, O1, O2, partial,
                                (int)blockIdx.x);
-}
-
-// ---------------------------------------------------------------------------
-// Both backward kernels in ONE launch (round 3).  They partition the layer-1 volume identically -- workgroup v of either covers
-// (sample b, planes 8 j .. 8 j + 8) with b = (v / 32) * 8 + v % 8, j = (v / 8) % 4 -- and each streams that 0.5 MB of y1 from global
-// memory once: launched one after the other, y1 (244 MB at B = 128) crossed the memory system twice, ~150 us apart.  Here block i
-// runs item v = (i / 16) * 8 + i % 8 in role (i / 8) % 2: blocks i and i + 8 -- same XCD, dispatched in the same round -- are the
-// weight-gradient and the data-gradient workgroup of the SAME planes, walk them in the same row order at about the same pace, and
-// the second request for a row is served by the XCD's L2 (4 MiB against ~16 MB/ms ... the pair's 1 MB window).  Nothing depends on
-// that placement (the roles share no state; block -> XCD is an observed mapping used for speed only).  One workgroup per CU either
-// way (100 / 151 KiB of LDS); registers: the larger of the two bodies.
-// ---------------------------------------------------------------------------
-struct Conv2BwdDualArgs {
-    // role 0: conv2_wgrad_split_body          role 1: conv2_dgrad_c1w_split_body
-    const float *y1, *scale1, *shift1, *mean1, *rstd1, *dy2;
-    const unsigned *absmax;
-    const uint4 *w2img;
-    const float *wbound;
-    const int8_t *grid_i8;
-    const int64_t *rows;
-    int64_t grid_row_stride;
-    int B, G, O1, O2;
-    float *wg_partial, *dg_partial;
-};
-
-namespace dual {
-constexpr int kLdsBytes = dsplit::kLdsBytes > split::kWgLdsBytes ? dsplit::kLdsBytes : split::kWgLdsBytes;
-static_assert(dsplit::kThreads == split::kThreads, "one workgroup shape for both roles");
-}  // namespace dual
-
-__global__ __launch_bounds__(split::kThreads) void k_conv2_bwd_dual_split(const Conv2BwdDualArgs a)
-{
-    const int i = blockIdx.x, v = (i >> 4) * 8 + (i & 7);
-    if ((i >> 3) & 1)
-        conv2_dgrad_c1w_split_body(a.dy2, a.w2img, a.wbound, a.absmax, a.y1, a.scale1, a.shift1, a.mean1, a.rstd1, a.grid_i8, a.rows, a.grid_row_stride,
-                                   a.B, a.G, a.O1, a.O2, a.dg_partial, v);
-    else
-        conv2_wgrad_split_body(a.y1, a.scale1, a.shift1, a.dy2, a.absmax, a.B, a.O1, a.O2, a.wg_partial, v);
 }
 
 

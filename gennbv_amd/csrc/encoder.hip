@@ -45,47 +45,15 @@ __device__ __forceinline__ uint32_t vox1(int b, int z, int y, int x, int O1)
     const uint32_t XH = (uint32_t)(O1 + 1) >> 1;
     return ((((uint32_t)b * O1 + z) * O1 + y) * 2 + (x & 1)) * XH + ((uint32_t)x >> 1);
 }
-// QUAD-MAJOR variant of the same buffer (fp32, fused-backward path): inside a (row, x-parity) block of XH voxels the four channel
-// quads are separate runs, [quad][voxel][4 channels]: element offset of channel 4*quad of voxel (b, z, y, x).  The 16-byte operand
-// load of MFMA lane (m = voxel, kq = quad) is then 16 bytes from its neighbour m + 1 -- a wave-wide dwordx4 load whose lane quads
-// read one contiguous 64-byte segment goes through the CU's load path at twice the rate of one whose lanes are 64 bytes apart
-// (tools/ubench/vmem_quad_rate.hip: 15.9 vs 29.6 cycles), and that path is what bounds the conv2 kernels.
-__device__ __forceinline__ uint32_t y1q(int b, int z, int y, int x, int O1, int quad)
-{
-    const uint32_t XH = (uint32_t)(O1 + 1) >> 1;
-    return ((((((uint32_t)b * O1 + z) * O1 + y) * 2 + (x & 1)) * 4 + quad) * XH + ((uint32_t)x >> 1)) * 4;
-}
 static inline size_t y1_elems(int batch, int O1) { return (size_t)batch * O1 * O1 * 2 * ((O1 + 1) / 2) * kC; }
 
-// Storage type of the layer-1 activations (y1, dz1'): fp32, or bf16 (math stays fp32; halves the
-// dominant HBM traffic of the conv stack -- opt-in, BASELINE config 2's "bf16").
+// Storage type of the layer-1 activations (y1, dz1'): fp32.  (The kernels keep the storage policy as a template parameter; the bf16
+// storage mode of rounds 1-3 was removed in round 4: slower than fp32 on the split kernels and 1e-3-class loss deltas)
 struct ActF32 {
     typedef float T;
     static __device__ __forceinline__ float4 ld4(const T *p) { return *reinterpret_cast<const float4 *>(p); }
     static __device__ __forceinline__ void st4(T *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
     static __device__ __forceinline__ float ld1(const T *p) { return *p; }
-};
-struct ActBF16 {
-    typedef uint16_t T;
-    static __device__ __forceinline__ float up(uint32_t h) { return __uint_as_float(h << 16); }
-    static __device__ __forceinline__ uint32_t down(float x)  // round to nearest even
-    {
-        const uint32_t u = __float_as_uint(x);
-        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-    }
-    static __device__ __forceinline__ float4 ld4(const T *p)
-    {
-        const uint2 u = *reinterpret_cast<const uint2 *>(p);
-        return make_float4(up(u.x & 0xffffu), up(u.x >> 16), up(u.y & 0xffffu), up(u.y >> 16));
-    }
-    static __device__ __forceinline__ void st4(T *p, float4 v)
-    {
-        uint2 u;
-        u.x = down(v.x) | (down(v.y) << 16);
-        u.y = down(v.z) | (down(v.w) << 16);
-        *reinterpret_cast<uint2 *>(p) = u;
-    }
-    static __device__ __forceinline__ float ld1(const T *p) { return up((uint32_t)*p); }
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -290,12 +258,11 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd(
 // fetched with a quarter of the bytes and widened while it is written to LDS).
 // LDS8 (int8 input only): the slab stays int8 in LDS (a quarter of the bytes: G = 128 fits, 48 KiB) and is widened
 // when the MFMA operand is read; no faster than the fp32 slab where that fits (measured at G = 64), so only used beyond.
-template <typename A, typename IN, bool LDS8 = false, bool QM = false /*quad-major y1*/>
+template <typename A, typename IN, bool LDS8 = false>
 __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
     const IN *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, int B, int G, int O1,
     const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ b1, typename A::T *__restrict__ y1,
-    float *__restrict__ partials, const float *__restrict__ zscale /*NULL: store y1 (pre-BN); else z1 = relu(zscale*y1 + zshift)*/,
-    const float *__restrict__ zshift, const float *__restrict__ W2 = nullptr, float *__restrict__ w2img = nullptr)
+    float *__restrict__ partials, const float *__restrict__ W2 = nullptr, float *__restrict__ w2img = nullptr)
 {
     prep_w2_in_passing(W2, w2img);
     extern __shared__ __attribute__((aligned(16))) float s_in[];  // [3][NR][G]
@@ -368,9 +335,6 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
 #pragma unroll
         for (int s = 0; s < 7; ++s) asm volatile("v_mov_b32 %0, %0" : "+v"(wf[s]));
         const float4 bias = *reinterpret_cast<const float4 *>(b1 + 4 * kq);
-        const bool z1 = zscale != nullptr;  // BN1 scale / shift known up front (analytic batch statistics, or eval mode)
-        const float4 zs = z1 ? *reinterpret_cast<const float4 *>(zscale + 4 * kq) : make_float4(1.f, 1.f, 1.f, 1.f);
-        const float4 zh = z1 ? *reinterpret_cast<const float4 *>(zshift + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int oy = wv; oy < O1; oy += kEncWaves) {
             for (int ox0 = 0; ox0 < O1; ox0 += 16) {
                 const int ox = min(ox0 + m, O1 - 1);
@@ -390,16 +354,13 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
                 const int oxm = ox0 + m;
                 if (oxm < O1) {
                     float4 y = make_float4(acc[0] + bias.x, acc[1] + bias.y, acc[2] + bias.z, acc[3] + bias.w);
-                    if (z1) {
-                        y = make_float4(fmaxf(fmaf(zs.x, y.x, zh.x), 0.f), fmaxf(fmaf(zs.y, y.y, zh.y), 0.f),
-                                        fmaxf(fmaf(zs.z, y.z, zh.z), 0.f), fmaxf(fmaf(zs.w, y.w, zh.w), 0.f));
-                    } else if (partials != nullptr) {
+                    if (partials != nullptr) {
                         s_sum[0] += y.x; s_sq[0] += y.x * y.x;
                         s_sum[1] += y.y; s_sq[1] += y.y * y.y;
                         s_sum[2] += y.z; s_sq[2] += y.z * y.z;
                         s_sum[3] += y.w; s_sq[3] += y.w * y.w;
                     }
-                    A::st4(y1 + (QM ? y1q(b, oz, oy, oxm, O1, kq) : vox1(b, oz, oy, oxm, O1) * kC + 4 * kq), y);
+                    A::st4(y1 + vox1(b, oz, oy, oxm, O1) * kC + 4 * kq, y);
                 }
             }
         }
@@ -418,7 +379,7 @@ __device__ __forceinline__ void fill_lds_image(float *lds, const float *__restri
 __device__ __forceinline__ bool sample_plane_group(int B, int O, int PZ, int &b, int &o0, int &o1, int block = -1)
 {
     const int ng = (O + PZ - 1) / PZ;
-    const int i = block < 0 ? (int)blockIdx.x : block, xcd = i & 7, slot = i >> 3;  // (block: a virtual index, k_conv2_bwd_dual_split)
+    const int i = block < 0 ? (int)blockIdx.x : block, xcd = i & 7, slot = i >> 3;
     const int gidx = slot % ng;
     b = (slot / ng) * 8 + xcd;
     o0 = gidx * PZ;
@@ -435,7 +396,7 @@ constexpr int kBigWaves = kBigThreads / kWave;
 // ---------------------------------------------------------------------------
 // Workgroup = 12 waves (three per SIMD, <= 168 VGPRs each): room for the third slab buffer; 4 planes x 15 rows = 60 tiles = 5 per wave.
 constexpr int kFwdThreads = 768, kFwdWaves = kFwdThreads / kWave;
-template <typename A, bool Z1 = false /*the layer-1 buffer holds z1 = relu(bn1(y1)) already*/, bool QM = false /*quad-major y1*/>
+template <typename A>
 __global__ __launch_bounds__(kFwdThreads) void k_conv2_fwd(
     const typename A::T *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1, int B, int O1, int O2,
     const float *__restrict__ W2img /*k_prep_w2 fwd image*/, const float *__restrict__ b2, float *__restrict__ y2,
@@ -467,12 +428,12 @@ __global__ __launch_bounds__(kFwdThreads) void k_conv2_fwd(
     auto request = [&](int wk, int dz, float4 (&v)[9]) {
         const int oz = oz0 + wk / (O2 * ntile_x), rr = wk % (O2 * ntile_x), oy = rr / ntile_x;
         const int ox = min((rr % ntile_x) * 16 + m, O2 - 1);
-        const uint32_t base = QM ? y1q(b, 2 * oz + dz, 2 * oy, 2 * ox, O1, kq) : vox1(b, 2 * oz + dz, 2 * oy, 2 * ox, O1) * kC + 4 * kq;  // even-parity voxel ox
+        const uint32_t base = vox1(b, 2 * oz + dz, 2 * oy, 2 * ox, O1) * kC + 4 * kq;  // even-parity voxel ox
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int dy = t / 3, dx = t % 3;
             // dx = 0, 2: even plane, voxels ox, ox + 1; dx = 1: odd plane, voxel ox
-            v[t] = A::ld4(y1 + base + (dy * rowC + (dx == 1 ? XHC : 0) + (dx == 2 ? (QM ? 4 : kC) : 0)));
+            v[t] = A::ld4(y1 + base + (dy * rowC + (dx == 1 ? XHC : 0) + (dx == 2 ? kC : 0)));
         }
     };
     auto consume = [&](int dz, float4 (&v)[9], f32x4 &acc) {
@@ -480,14 +441,12 @@ __global__ __launch_bounds__(kFwdThreads) void k_conv2_fwd(
         // preceded by its own v_fma, v_max, s_nop (46 cycles per MFMA in tools/ubench/mfma_valu_groups.hip against 37-38
         // when the vector work is grouped in front of >= 8 MFMAs: what costs is the MFMA -> VALU -> MFMA turn-around, not
         // the vector instructions themselves).
-        if (!Z1) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                v[t].x = fmaxf(fmaf(sc[0], v[t].x, sh[0]), 0.f);
-                v[t].y = fmaxf(fmaf(sc[1], v[t].y, sh[1]), 0.f);
-                v[t].z = fmaxf(fmaf(sc[2], v[t].z, sh[2]), 0.f);
-                v[t].w = fmaxf(fmaf(sc[3], v[t].w, sh[3]), 0.f);
-            }
+        for (int t = 0; t < 9; ++t) {
+            v[t].x = fmaxf(fmaf(sc[0], v[t].x, sh[0]), 0.f);
+            v[t].y = fmaxf(fmaf(sc[1], v[t].y, sh[1]), 0.f);
+            v[t].z = fmaxf(fmaf(sc[2], v[t].z, sh[2]), 0.f);
+            v[t].w = fmaxf(fmaf(sc[3], v[t].w, sh[3]), 0.f);
         }
         // weights: one 16-byte LDS read per tap, issued ONE TAP AHEAD of its MFMAs and pinned there (left alone the
         // compiler puts every LDS read right in front of its use: ds_read, s_waitcnt lgkmcnt(0), 2 MFMAs -- the LDS
@@ -755,20 +714,6 @@ __global__ __launch_bounds__(256) void k_reduce_partials4(const float *__restric
     reduce_partials4_body(partial, P, E, per_slice, out_d, blockIdx.x, blockIdx.y);
 }
 
-// Two such reductions as ONE launch (the conv2 and the conv1 weight-gradient partials behind the data-gradient kernel: only the
-// optimizer reads either, so the first no longer sits between the two conv kernels).  Blocks [0, nbx_a) x [0, slices_a) are job a.
-struct ReduceJob {
-    const float *partial; int P, E, per_slice, slices, nbx; double *out;
-};
-__global__ __launch_bounds__(256) void k_reduce_partials4_x2(ReduceJob a, ReduceJob b)
-{
-    const bool first = (int)blockIdx.x < a.nbx;  // (workgroup-uniform)
-    const int bx = first ? blockIdx.x : blockIdx.x - a.nbx;
-    if ((int)blockIdx.y >= (first ? a.slices : b.slices)) return;
-    reduce_partials4_body(first ? a.partial : b.partial, first ? a.P : b.P, first ? a.E : b.E, first ? a.per_slice : b.per_slice, first ? a.out : b.out, bx,
-                          blockIdx.y);
-}
-
 // z2 = relu(scale2*y2 + shift2), y2 NCDHW [B,16,P2] -> flat features [B, 16*P2]
 // (range guard, bit 2 of *range_flag: these features are fc_grid's input, which the split-f16 linear kernels clamp at 1015,
 // csrc/linear.hip -- the largest value is tracked here, where every element passes through a register anyway)
@@ -971,7 +916,7 @@ __device__ __forceinline__ void wgrad_reduce_store(f32x4 (&acc)[kTaps], float bs
     for (int o = threadIdx.x; o < kTaps * 256 + kC; o += kEncThreads) out[o] = red[1][o];
 }
 
-template <typename A, bool Z1 = false, bool QM = false /*quad-major y1*/>
+template <typename A>
 __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv2_wgrad(
     const typename A::T *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1,
     const float *__restrict__ dy2 /*[B,O2,O2,O2,16]*/, int B, int O1, int O2, float *__restrict__ partial)
@@ -1031,11 +976,11 @@ __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(2, 
         const int xc = min(4 * rq.xg + kq, O2 - 1);
         bv = dy2[rq.dbase + xc * kC + n];
         // voxel 2xc of the even plane / voxel xc of the odd plane
-        const uint32_t off = rq.ybase + (QM ? (uint32_t)(n >> 2) * (XHC / 4) + xc * 4 + (n & 3) : (uint32_t)xc * kC + n), off1 = off + XHC;
+        const uint32_t off = rq.ybase + (uint32_t)xc * kC + n, off1 = off + XHC;
 #pragma unroll
         for (int tap = 0; tap < kTaps; ++tap) {
             const int dx = tap % 3;
-            av[tap] = A::ld1(tapp[tap / 3] + (dx == 1 ? off1 : off) + (dx == 2 ? (QM ? 4 : kC) : 0));
+            av[tap] = A::ld1(tapp[tap / 3] + (dx == 1 ? off1 : off) + (dx == 2 ? kC : 0));
         }
         if (++requested < nitems) advance(rq);  // (past the last item the same one is requested again: unconditional requests)
     };
@@ -1049,7 +994,7 @@ __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(2, 
         // kernel is bound by its 28 four-byte requests per 27 MFMAs, profiles/r01_notes.md)
 #pragma unroll
         for (int tap = 0; tap < kTaps; ++tap) {
-            const float a = Z1 ? av[tap] : fmaxf(fmaf(sc, av[tap], sh), 0.0f);
+            const float a = fmaxf(fmaf(sc, av[tap], sh), 0.0f);
             acc[tap] = mfma4(a, bb, acc[tap]);
         }
     };
@@ -1070,130 +1015,6 @@ __global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(2, 
     (void)wave_global;
 }
 
-// ---------------------------------------------------------------------------
-// conv2 weight gradient for QUAD-MAJOR y1 (fp32).  Same work split, accumulators and epilogue as k_conv2_wgrad; what changes is
-// how the z1 operands reach the MFMAs.  k_conv2_wgrad's lanes are (channel n, position kq) and fetch 27 dwords each per item --
-// 28 wave-wide requests per 27 MFMAs, which is what bounds it (the CU's load path: profiles/r01_notes.md).  Here the 81 distinct
-// (row of 9, voxel of 5 even + 4 odd) x 16-channel pieces under an item are fetched as 16-byte [voxel][quad] vectors -- lane =
-// (quad a, piece i16 + 16 j): 6 requests whose neighbouring lanes read neighbouring voxels of one quad run = contiguous bytes --
-// BN + ReLU'd once, written to a per-wave LDS slab [piece][16 channels (+4 pad)] and read back in MFMA layout (lane (n, kq):
-// one ds_read_b32 per tap at an immediate offset).  Per item: 6 + 1 global requests, 6 LDS writes, 27 LDS reads, 27 MFMAs, and
-// no VALU between the MFMAs.
-// ---------------------------------------------------------------------------
-constexpr int kWgPieces = 81, kWgPieceStride = 20, kWgWaveLds = kWgPieces * kWgPieceStride;
-__global__ __launch_bounds__(kEncThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv2_wgrad_qm(
-    const float *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1,
-    const float *__restrict__ dy2 /*[B,O2,O2,O2,16]*/, int B, int O1, int O2, float *__restrict__ partial)
-{
-    __shared__ __attribute__((aligned(16))) float smem[2 * (kTaps * 256 + kC)];  // the reduction buffers; the operand slabs alias their front
-    static_assert(kEncWaves * kWgWaveLds <= 2 * (kTaps * 256 + kC), "slabs must fit");
-    const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const int n = lane & 15, kq = lane >> 4;  // MFMA roles: channel n, position kq
-    const int a = lane >> 4, i16 = lane & 15;  // staging roles: channel quad a, pieces i16 + 16 j
-    float sc4[4], sh4[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        sc4[s] = scale1[4 * a + s];
-        sh4[s] = shift1[4 * a + s];
-    }
-    f32x4 acc[kTaps];
-#pragma unroll
-    for (int t = 0; t < kTaps; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.0f;
-    const int nrows = B * O2 * O2;
-    int row0, row1;
-    wave_row_range(nrows, row0, row1);
-    const int ng = (O2 + 3) / 4, nitems = (row1 - row0) * ng;
-    const int XH = (O1 + 1) >> 1;
-    const uint32_t XHC = (uint32_t)XH * kC, rowC = 2 * XHC, planeC = rowC * O1;
-    // this lane's six pieces: p = i16 + 16 j -> (row = (dz, dy), w): w < 5 even-parity voxel e0 + w, else odd-parity voxel e0 + w - 5
-    constexpr int kSlots = (kWgPieces + 15) / 16;
-    uint32_t poff[kSlots];
-    int pw[kSlots];
-#pragma unroll
-    for (int j = 0; j < kSlots; ++j) {
-        const int pc = min(i16 + 16 * j, kWgPieces - 1), row = pc / 9, w = pc - 9 * row;
-        poff[j] = (uint32_t)(row / 3) * planeC + (uint32_t)(row % 3) * rowC + (w >= 5 ? XHC : 0) + (uint32_t)a * XH * 4;
-        pw[j] = w >= 5 ? w - 5 : w;
-    }
-    float *slab = smem + wv * kWgWaveLds;
-    struct Cursor {
-        int xg, oy, oz, b;
-        uint32_t ybase, dbase;
-    };
-    auto cursor_at = [&](int row) {
-        Cursor c;
-        c.b = row / (O2 * O2);
-        const int rem = row - c.b * O2 * O2;
-        c.oz = rem / O2;
-        c.oy = rem - c.oz * O2;
-        c.xg = 0;
-        c.ybase = vox1(c.b, 2 * c.oz, 2 * c.oy, 0, O1) * kC;  // (x = 0, parity 0: the same offset in both layouts)
-        c.dbase = (uint32_t)row * O2 * kC;
-        return c;
-    };
-    auto advance = [&](Cursor &c) {
-        if (++c.xg < ng) return;
-        c.xg = 0;
-        c.dbase += O2 * kC;
-        if (++c.oy == O2) {
-            c.oy = 0;
-            if (++c.oz == O2) { c.oz = 0; ++c.b; }
-        }
-        c.ybase = vox1(c.b, 2 * c.oz, 2 * c.oy, 0, O1) * kC;
-    };
-    Cursor rq = cursor_at(row0);
-    int requested = 0, cxg = 0;
-    auto request = [&](float &bv, float4 (&pc)[kSlots]) {
-        const int xc = min(4 * rq.xg + kq, O2 - 1);
-        bv = dy2[rq.dbase + xc * kC + n];
-        const int e0 = 4 * rq.xg;
-#pragma unroll
-        for (int j = 0; j < kSlots; ++j)
-            pc[j] = *reinterpret_cast<const float4 *>(y1 + rq.ybase + poff[j] + (uint32_t)min(e0 + pw[j], XH - 1) * 4);
-        if (++requested < nitems) advance(rq);
-    };
-    auto consume = [&](int it, float bv, const float4 (&pc)[kSlots]) {
-        const bool ok = 4 * cxg + kq < O2 && it < nitems;
-        if (++cxg == ng) cxg = 0;
-        const float bb = ok ? bv : 0.0f;
-        bsum += bb;
-#pragma unroll
-        for (int j = 0; j < kSlots; ++j) {
-            if (i16 + 16 * j < kWgPieces) {
-                float4 z;
-                z.x = fmaxf(fmaf(sc4[0], pc[j].x, sh4[0]), 0.f);
-                z.y = fmaxf(fmaf(sc4[1], pc[j].y, sh4[1]), 0.f);
-                z.z = fmaxf(fmaf(sc4[2], pc[j].z, sh4[2]), 0.f);
-                z.w = fmaxf(fmaf(sc4[3], pc[j].w, sh4[3]), 0.f);
-                *reinterpret_cast<float4 *>(slab + (i16 + 16 * j) * kWgPieceStride + 4 * a) = z;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const float *rd = slab + kq * kWgPieceStride + n;
-#pragma unroll
-        for (int tap = 0; tap < kTaps; ++tap) {
-            const int row = tap / 3, dx = tap % 3, w0 = dx == 1 ? 5 : (dx == 2 ? 1 : 0);
-            acc[tap] = mfma4(rd[(row * 9 + w0) * kWgPieceStride], bb, acc[tap]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    float b0, b1;
-    float4 p0[kSlots], p1[kSlots];
-    if (nitems > 0) request(b0, p0);
-    for (int it = 0; it < nitems; it += 2) {
-        request(b1, p1);
-        __builtin_amdgcn_sched_barrier(0);
-        consume(it, b0, p0);
-        __builtin_amdgcn_sched_barrier(0);
-        request(b0, p0);
-        __builtin_amdgcn_sched_barrier(0);
-        consume(it + 1, b1, p1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();  // every wave is done with its slab before the reduction buffers are written over them
-    wgrad_reduce_store(acc, bsum, reinterpret_cast<float (*)[kTaps * 256 + kC]>(smem), partial, lane, wv, n, kq);
-}
 
 // partial-sum layout [tap][ci][co] (+16) -> torch layout dW2 [co][ci][27], db2 [16]
 // (+ the conv2 weight images for the data-gradient kernel that follows: saves a dependent launch)
@@ -1364,7 +1185,7 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad(
 constexpr int kSlabRow = 80, kSlabBytes = 25 * kSlabRow;  // 5 planes x 5 rows x (65 -> 80) bytes
 constexpr int kE1F = 512 + 2 * kC;                        // T1 [32 taps][16], S1, S2 [16]
 
-template <bool Z1, int EZ, int EY, int EX>
+template <int EZ, int EY, int EX>
 __device__ __forceinline__ void dgrad_c1w_subtile(
     const float4 (&L)[8], const float (&Y)[4], const float *w2d, const int8_t *slab0, const int8_t *slab1, const bool (&ok0)[4],
     const bool (&ok1)[4], float sc, float sh, float mu, float rs, float &s1, float &s2, f32x4 (&T1)[2])
@@ -1391,18 +1212,15 @@ __device__ __forceinline__ void dgrad_c1w_subtile(
         // Out-of-grid voxels (x only: out-of-grid planes / rows skip the sub-tile) are masked in the A operand, so
         // their g never reaches T1; g is masked as well for the channel sums.
         const float y = ok0[r] ? Y[r] : 0.0f;  // (out-of-grid slots of y1 are never written: may hold Inf / NaN)
-        // Z1: the buffer holds z1 = relu(bn1(y1)); the ReLU mask is z1 > 0 and s2 accumulates sum g*z1 (the finish kernel
-        // turns it into sum g*xhat = (sum g*z1 - beta*S1) / gamma)
-        const float g = (ok0[r] && (Z1 ? y : fmaf(sc, y, sh)) > 0.0f) ? acc[r] : 0.0f;
+        const float g = (ok0[r] && fmaf(sc, y, sh) > 0.0f) ? acc[r] : 0.0f;
         s1 += g;
-        s2 = fmaf(g, Z1 ? y : (y - mu) * rs, s2);
+        s2 = fmaf(g, (y - mu) * rs, s2);
         const float a0v = (float)slab0[kOff + 4 * r], a1v = (float)slab1[kOff + 4 * r];  // unconditional reads, then selects
         T1[0] = mfma4(ok0[r] ? a0v : 0.0f, g, T1[0]);  // A[i = tap][k = voxel]
         T1[1] = mfma4(ok1[r] ? a1v : 0.0f, g, T1[1]);
     }
 }
 
-template <bool Z1, bool QM = false /*quad-major y1*/>
 __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad_c1w(
     const float *__restrict__ dy2, const float *__restrict__ W2 /*dgrad image*/, const float *__restrict__ y1, const float *__restrict__ scale1,
     const float *__restrict__ shift1, const float *__restrict__ mean1, const float *__restrict__ rstd1, const int8_t *__restrict__ grid_i8,
@@ -1472,9 +1290,9 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad_c1w(
                 const int ez = e >> 2, ey = (e >> 1) & 1, ex = e & 1;
                 const int iz = min(2 * a + ez, O1 - 1), iy = min(2 * c + ey, O1 - 1);
                 const uint32_t blk = ((((uint32_t)b * O1 + iz) * O1 + iy) * 2 + ex) * NA * kC;  // the (row, parity) block
-                const float *p = y1 + blk + (QM ? (uint32_t)(m >> 2) * NA * 4 + jb * 4 + (m & 3) : (uint32_t)jb * kC + m);
+                const float *p = y1 + blk + (uint32_t)jb * kC + m;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[r] = p[r * (QM ? 4 : kC)];
+                for (int r = 0; r < 4; ++r) dst[r] = p[r * kC];
             };
             request_y(0, Y[0]);
             request_y(1, Y[1]);
@@ -1491,22 +1309,22 @@ __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad_c1w(
             __builtin_amdgcn_wave_barrier();
             // sub-tiles on out-of-grid planes / rows are skipped (wave-uniform)
             const bool z0 = 2 * a < O1, z1 = 2 * a + 1 < O1, y0 = 2 * c < O1, y1ok = 2 * c + 1 < O1;
-            if (z0 && y0) dgrad_c1w_subtile<Z1, 0, 0, 0>(L, Y[0], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, T1);
-            if (z0 && y0) dgrad_c1w_subtile<Z1, 0, 0, 1>(L, Y[1], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, T1);
+            if (z0 && y0) dgrad_c1w_subtile<0, 0, 0>(L, Y[0], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, T1);
+            if (z0 && y0) dgrad_c1w_subtile<0, 0, 1>(L, Y[1], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, T1);
             __builtin_amdgcn_sched_barrier(0);
             request_y(4, Y[4]);
             request_y(5, Y[5]);
             __builtin_amdgcn_sched_barrier(0);
-            if (z0 && y1ok) dgrad_c1w_subtile<Z1, 0, 1, 0>(L, Y[2], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, T1);
-            if (z0 && y1ok) dgrad_c1w_subtile<Z1, 0, 1, 1>(L, Y[3], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, T1);
+            if (z0 && y1ok) dgrad_c1w_subtile<0, 1, 0>(L, Y[2], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, T1);
+            if (z0 && y1ok) dgrad_c1w_subtile<0, 1, 1>(L, Y[3], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, T1);
             __builtin_amdgcn_sched_barrier(0);
             request_y(6, Y[6]);
             request_y(7, Y[7]);
             __builtin_amdgcn_sched_barrier(0);
-            if (z1 && y0) dgrad_c1w_subtile<Z1, 1, 0, 0>(L, Y[4], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, T1);
-            if (z1 && y0) dgrad_c1w_subtile<Z1, 1, 0, 1>(L, Y[5], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, T1);
-            if (z1 && y1ok) dgrad_c1w_subtile<Z1, 1, 1, 0>(L, Y[6], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, T1);
-            if (z1 && y1ok) dgrad_c1w_subtile<Z1, 1, 1, 1>(L, Y[7], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, T1);
+            if (z1 && y0) dgrad_c1w_subtile<1, 0, 0>(L, Y[4], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, T1);
+            if (z1 && y0) dgrad_c1w_subtile<1, 0, 1>(L, Y[5], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, T1);
+            if (z1 && y1ok) dgrad_c1w_subtile<1, 1, 0>(L, Y[6], w2d, slab0, slab1, ok0[0], ok1[0], sc, sh, mu, rs, s1, s2, T1);
+            if (z1 && y1ok) dgrad_c1w_subtile<1, 1, 1>(L, Y[7], w2d, slab0, slab1, ok0[1], ok1[1], sc, sh, mu, rs, s1, s2, T1);
             __builtin_amdgcn_wave_barrier();  // the next super-tile overwrites the slab
         }
     }
@@ -1763,7 +1581,7 @@ __global__ __launch_bounds__(1024) void k_bn1_analytic(const int *__restrict__ a
 __device__ __forceinline__ void c1w_fused_finish_body(const double *__restrict__ tmp /*[slices][kE1F]*/, int slices, const int *__restrict__ ac,
                                                           int64_t ac_row_stride, const int64_t *__restrict__ rows, int nrows,
                                                           const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ scale1,
-                                                          const float *__restrict__ rstd1, const float *__restrict__ gamma1 /*NULL unless z1 mode*/,
+                                                          const float *__restrict__ rstd1,
                                                           const float *__restrict__ beta1, float *__restrict__ dW1, float *__restrict__ db1,
                                                           const double *__restrict__ S2 /*BN2 sums*/, float *g1w, float *g1b, float *g2w,
                                                           float *g2b, const double *__restrict__ S1g /*NULL, or [2][16]: BN1-backward sums over ALL replicas*/,
@@ -1801,10 +1619,6 @@ __device__ __forceinline__ void c1w_fused_finish_body(const double *__restrict__
     const int i = threadIdx.x;
     const int tap = i >> 4, co = i & 15;
     double T1 = ssum[i], s1 = ssum[512 + co], s2 = ssum[512 + kC + co];
-    if (gamma1 != nullptr) {  // z1 mode: s2 holds sum g*z1 over the unmasked voxels, z1 = gamma*xhat + beta there
-        const double ga = (double)gamma1[co];
-        s2 = ga != 0.0 ? (s2 - (double)beta1[co] * s1) / ga : 0.0;  // (gamma == 0: xhat is not recoverable from z1)
-    }
     auto Rs = [&](int t, int u) { return R[ac_index(t, u)]; };
     // Data-parallel replicas: BatchNorm-1's mean and the two backward means are those of the GLOBAL minibatch (count Mg, column
     // sums T2g, sums S1g), while T1, R and T2 stay this replica's: the gradient all-reduce adds the replicas' dW1.
@@ -1832,32 +1646,13 @@ __device__ __forceinline__ void c1w_fused_finish_body(const double *__restrict__
 __global__ __launch_bounds__(1024) void k_c1w_fused_finish(const double *__restrict__ tmp /*[slices][kE1F]*/, int slices, const int *__restrict__ ac,
                                                           int64_t ac_row_stride, const int64_t *__restrict__ rows, int nrows,
                                                           const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ scale1,
-                                                          const float *__restrict__ rstd1, const float *__restrict__ gamma1 /*NULL unless z1 mode*/,
+                                                          const float *__restrict__ rstd1,
                                                           const float *__restrict__ beta1, float *__restrict__ dW1, float *__restrict__ db1,
                                                           const double *__restrict__ S2 /*BN2 sums*/, float *g1w, float *g1b, float *g2w,
                                                           float *g2b, const double *__restrict__ S1g /*NULL, or [2][16]: BN1-backward sums over ALL replicas*/,
                                                           const int *__restrict__ ac_global /*NULL, or the global autocorrelation total*/)
 {
-    c1w_fused_finish_body(tmp, slices, ac, ac_row_stride, rows, nrows, W1, scale1, rstd1, gamma1, beta1, dW1, db1, S2, g1w, g1b, g2w, g2b, S1g, ac_global);
-}
-
-// The same finish as workgroup 0 of a launch whose other workgroups finish the conv2 weight gradient (k_conv2_wgrad_finish's sums,
-// 1024 elements each): one launch behind the data-gradient kernel instead of one on either side of it.
-__global__ __launch_bounds__(1024) void k_wgrad_finish_both(const double *__restrict__ tmp2 /*[slices2][27 * 256 + 16]*/, int slices2, float *__restrict__ dW2,
-                                                           float *__restrict__ db2, const double *__restrict__ tmp /*[slices][kE1F]*/, int slices, const int *__restrict__ ac,
-                                                          int64_t ac_row_stride, const int64_t *__restrict__ rows, int nrows,
-                                                          const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ scale1,
-                                                          const float *__restrict__ rstd1, const float *__restrict__ gamma1 /*NULL unless z1 mode*/,
-                                                          const float *__restrict__ beta1, float *__restrict__ dW1, float *__restrict__ db1,
-                                                          const double *__restrict__ S2 /*BN2 sums*/, float *g1w, float *g1b, float *g2w,
-                                                          float *g2b, const double *__restrict__ S1g /*NULL, or [2][16]: BN1-backward sums over ALL replicas*/,
-                                                          const int *__restrict__ ac_global /*NULL, or the global autocorrelation total*/)
-{
-    if (blockIdx.x > 0) {
-        conv2_wgrad_finish_body(tmp2, slices2, dW2, db2, (const float *)nullptr, (float *)nullptr, (blockIdx.x - 1) * 1024 + threadIdx.x);
-        return;
-    }
-    c1w_fused_finish_body(tmp, slices, ac, ac_row_stride, rows, nrows, W1, scale1, rstd1, gamma1, beta1, dW1, db1, S2, g1w, g1b, g2w, g2b, S1g, ac_global);
+    c1w_fused_finish_body(tmp, slices, ac, ac_row_stride, rows, nrows, W1, scale1, rstd1, beta1, dW1, db1, S2, g1w, g1b, g2w, g2b, S1g, ac_global);
 }
 
 // ---------------------------------------------------------------------------
@@ -2180,19 +1975,8 @@ static inline int reduce_stage1(const float *partial, int P, int E, double *tmp,
                            (float *)nullptr);
     return slices;
 }
-static inline ReduceJob reduce_job(const float *partial, int P, int E, double *tmp)
-{
-    ReduceJob j;
-    j.partial = partial; j.P = P; j.E = E; j.slices = reduce_slices(P); j.per_slice = (P + j.slices - 1) / j.slices; j.nbx = (E / 4 + 63) / 64; j.out = tmp;
-    return j;
-}
-static inline bool reduce_job_ok(const ReduceJob &j) { return j.E % 4 == 0 && (((uintptr_t)j.partial) & 15) == 0; }
-
 // Kernel-path predicates shared by forward and backward (they must agree on what the layer-1 buffer holds).
 //   fused_path: conv2 data gradient fused with the conv1 weight gradient (needs the grid as aligned int8 rows)
-//   z1_path   : additionally, BatchNorm-1's scale / shift are known before conv1 runs (analytic batch statistics from
-//               the input autocorrelation, or eval mode), conv1 applies BN + ReLU in its epilogue and the buffer holds
-//               z1 = relu(bn1(y1)) instead of y1
 static inline bool env_off(const char *name)
 {
     const char *e = getenv(name);
@@ -2203,11 +1987,11 @@ static inline bool env_off(const char *name)
 static inline bool conv_split_path(const GnbvEncoderParams *p, int grid)
 {
     const int O1 = out_size(grid), O2 = out_size(O1);
-    return !env_off("GENNBV_CONV_SPLIT") && !p->force_fp32 && !p->act_bf16 && (O1 + 1) / 2 == 16 && O2 <= 15;
+    return !env_off("GENNBV_CONV_SPLIT") && !p->force_fp32 && (O1 + 1) / 2 == 16 && O2 <= 15;
 }
 static inline bool fused_path(const GnbvEncoderParams *p, int grid)
 {
-    return !env_off("GENNBV_FUSED_BWD") && !p->act_bf16 && p->grid_i8 != nullptr && grid % 16 == 0 && 3 * grid * grid <= 64 * 1024 &&
+    return !env_off("GENNBV_FUSED_BWD") && p->grid_i8 != nullptr && grid % 16 == 0 && 3 * grid * grid <= 64 * 1024 &&
            p->grid_i8_row_stride % 16 == 0 && (((uintptr_t)p->grid_i8 & 15) == 0);
 }
 static inline bool conv1_i8_staged(const GnbvEncoderParams *p, int grid)
@@ -2216,33 +2000,14 @@ static inline bool conv1_i8_staged(const GnbvEncoderParams *p, int grid)
     return p->grid_i8 != nullptr && grid % 16 == 0 && p->grid_i8_row_stride % 16 == 0 && (((uintptr_t)p->grid_i8 & 15) == 0) &&
            (size_t)3 * (2 * O1 + 1) * grid * sizeof(float) <= 64 * 1024 && 2 * O1 + 1 <= grid;
 }
-// z1_path is OPT-IN (GENNBV_Z1=1): correct (tests) but measured slower on MI355X -- train 1144-1149 vs 1119-1122 ms per
-// iteration, same box: without the fma+max in front of their MFMAs conv2 forward / weight gradient do not get faster
-// (95 / 105 us: they wait on operand latency, not on the issue slot), so the saving is conv1's statistics only.
-// y1 / z1 stored quad-major (see y1q): the fp32 fused-backward path at the sizes the fp32-slab conv1 kernel takes; every kernel
-// that touches y1 on that path (conv1_fwd_lds, conv2_fwd(_lds), conv2_wgrad, conv2_dgrad_c1w) has the layout as a template flag.
-static inline bool y1_quad_major(const GnbvEncoderParams *p, int grid)
-{
-    // OPT-IN (GENNBV_Y1_QM=1).  Same-box A/B at B = 128, G = 64: k_conv2_fwd 98.3 -> 92.8 us, k_conv1_fwd_lds 73.8 -> 69.0 (contiguous
-    // 16-byte stores), k_conv2_dgrad_c1w unchanged, but k_conv2_wgrad 98.8 -> 118.7: its lanes are (channel, position) and now read
-    // 16 scattered 16-byte pieces per load instead of 256 contiguous bytes.  Becomes the default once the weight gradient loads
-    // [voxel][quad] vectors and transposes them through LDS (7 dwordx4 requests per item instead of 28 dword requests).
-    const char *z = getenv("GENNBV_Z1"), *q = getenv("GENNBV_Y1_QM");
-    return q && q[0] == '1' && fused_path(p, grid) && conv1_i8_staged(p, grid) && !(z && z[0] == '1');
-}
-static inline bool z1_path(const GnbvEncoderParams *p, int grid)
-{
-    const char *e = getenv("GENNBV_Z1");
-    return e && e[0] == '1' && fused_path(p, grid) && conv1_i8_staged(p, grid);
-}
 
 // bn_state = [2][4][16] floats (scale, shift, mean, rstd per layer) + kAcRow ints: the minibatch total of the input
-// autocorrelation, written by the forward whenever it computed BN1's statistics from it (analytic_bn1 / z1_path) and read
+// autocorrelation, written by the forward whenever it computed BN1's statistics from it (analytic_bn1) and read
 // back by the backward instead of gathering the rows again
 constexpr int kBnStateFloats = 2 * 4 * kC;
 static inline bool analytic_bn1(const GnbvEncoderParams *p, int grid)
 {
-    return p->autocorr != nullptr && !p->act_bf16 && conv1_i8_staged(p, grid) && 3 * grid * grid <= 64 * 1024 && !env_off("GENNBV_ANALYTIC_BN1");
+    return p->autocorr != nullptr && conv1_i8_staged(p, grid) && 3 * grid * grid <= 64 * 1024 && !env_off("GENNBV_ANALYTIC_BN1");
 }
 
 // minibatch total of the input autocorrelation into `Rac` (when the caller has no per-row results)
@@ -2261,7 +2026,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
                                        void *workspace, size_t workspace_bytes, void *stream)
 {
     // obs_grid == NULL: compact observations, the grid exists only as the int8 rows p->grid_i8 (fp32 activations only)
-    GNBV_CHECK_ARG(p && (obs_grid || (p->grid_i8 && !p->act_bf16)) && y1 && y2 && bn_state && workspace && batch > 0 && grid >= 7);
+    GNBV_CHECK_ARG(p && (obs_grid || (p->grid_i8)) && y1 && y2 && bn_state && workspace && batch > 0 && grid >= 7);
     GNBV_CHECK_ARG(p->grid_i8 == nullptr || p->grid_i8_row_stride >= (int64_t)grid * grid * grid);
     GNBV_CHECK_ARG(workspace_bytes >= gnbv_encoder_workspace_bytes(batch, grid) && ((uintptr_t)workspace & 255) == 0);
     GNBV_CHECK_ARG(p->w1 && p->b1 && p->bn1_w && p->bn1_b && p->bn1_rm && p->bn1_rv && p->w2 && p->b2 && p->bn2_w && p->bn2_b &&
@@ -2274,12 +2039,10 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     float *bn1 = bn_state, *bn2 = bn_state + 4 * kC;
     int err;
     GNBV_CHECK_ARG(p->autocorr == nullptr || (p->autocorr_row_stride >= kAcRow && p->autocorr_row_stride % 4 == 0 && ((uintptr_t)p->autocorr & 15) == 0));
-    const bool z1 = z1_path(p, grid), qm = y1_quad_major(p, grid);
     const bool dp = training && p->world > 1 && p->sync_sum != nullptr && p->sync_buf != nullptr;  // BatchNorm over the replicas' global minibatch
-    if (dp && z1) return (int)hipErrorInvalidValue;
     // Inference with the grid as int8 rows at G = 64: conv1 + BN1 + ReLU + conv2 in one kernel, no layer-1 buffer at all
     // (conv_split.h).  y1 is left untouched (no backward follows an eval-mode forward).
-    const bool fused_eval = !training && !z1 && !qm && conv_split_path(p, grid) && conv1_i8_staged(p, grid) && grid == 64 && !env_off("GENNBV_FUSED_EVAL");
+    const bool fused_eval = !training && conv_split_path(p, grid) && conv1_i8_staged(p, grid) && grid == 64 && !env_off("GENNBV_FUSED_EVAL");
     bool fused_train = false;
     if (fused_eval) {
         hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps, p->momentum, p->bn1_rm,
@@ -2296,25 +2059,6 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
                            p->grid_i8, rows, p->grid_i8_row_stride, p->w1, p->b1, (const float *)bn1, (const float *)(bn1 + kC), batch, grid, O1, O2,
                            (const uint4 *)w.w2split, p->b2, y2, (float *)nullptr, (float *)nullptr);
         if ((err = gnbv_launch_status())) return err;
-    } else if (z1) {
-        // BN1 scale / shift first (training: analytic batch statistics from the input autocorrelation; eval: running
-        // statistics), then conv1 with the BN + ReLU epilogue: the layer-1 buffer holds z1
-        if (training) {
-            int *Rac = (int *)(w.red + 1024);
-            if (p->autocorr == nullptr && (err = launch_autocorr_total(p, rows, batch, grid, Rac, st))) return err;
-            hipLaunchKernelGGL(k_bn1_analytic, dim3(1), dim3(1024), 0, st, p->autocorr ? (const int *)p->autocorr : (const int *)Rac,
-                               p->autocorr_row_stride, rows, p->autocorr ? batch : 0, p->w1, p->b1, p->bn1_w, p->bn1_b, p->eps, p->momentum,
-                               p->bn1_rm, p->bn1_rv, p->bn1_nbt, skip_flag, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC,
-                               (int *)(bn_state + kBnStateFloats), (const int *)nullptr, (const float *)nullptr, (float *)nullptr, p->range_flag);
-        } else {
-            hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps, p->momentum,
-                               p->bn1_rm, p->bn1_rv, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->w1, p->b1, p->range_flag);
-        }
-        if ((err = gnbv_launch_status())) return err;
-        hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, int8_t>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads),
-                           (size_t)3 * (2 * O1 + 1) * grid * sizeof(float), st, p->grid_i8, rows, p->grid_i8_row_stride, batch, grid, O1, p->w1,
-                           p->b1, (float *)y1, (float *)nullptr, (const float *)bn1, (const float *)(bn1 + kC), p->w2, w.w2img);
-        if ((err = gnbv_launch_status())) return err;
     } else {
     // BN1 batch statistics analytically from the stored input autocorrelation rows (k_bn1_analytic: 6 us, independent of
     // conv1) instead of partial sums in conv1 + a 12 us reduction behind it; y1 is stored as before
@@ -2322,7 +2066,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     if (dp && !(analytic && fused_path(p, grid) && p->autocorr_global != nullptr)) return (int)hipErrorInvalidValue;  // (see GnbvEncoderParams.world)
     // Training with BN1's statistics known beforehand: conv1 + BN1 + ReLU + conv2 as ONE launch that also stores y1 for the backward
     // (conv_split.h) -- conv2 never reads the 244 MB it would otherwise fetch right after conv1 wrote them.
-    fused_train = analytic && !qm && conv_split_path(p, grid) && grid == 64 && !env_off("GENNBV_CONV1_SPLIT") && !env_off("GENNBV_FUSED_TRAIN");
+    fused_train = analytic && conv_split_path(p, grid) && grid == 64 && !env_off("GENNBV_CONV1_SPLIT") && !env_off("GENNBV_FUSED_TRAIN");
     if (analytic) {
         // (the caller may hand over the minibatch's autocorrelation total: no gather then -- GnbvEncoderParams.autocorr_total)
         const bool have_total = p->autocorr_total != nullptr && !dp;
@@ -2345,30 +2089,23 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
         hipLaunchKernelGGL(k_conv12_fwd_split<true>, dim3(sample_plane_group_grid(batch, O2, split::kNP)), dim3(split::kThreads), fsplit::kLdsBytes, st,
                            p->grid_i8, rows, p->grid_i8_row_stride, p->w1, p->b1, (const float *)bn1, (const float *)(bn1 + kC), batch, grid, O1, O2,
                            (const uint4 *)w.w2split, p->b2, y2, (float *)y1, w.bn_part);
-    } else if (p->act_bf16) {
-        hipLaunchKernelGGL(k_conv1_fwd<ActBF16>, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, batch, grid, O1, p->w1,
-                       p->b1, (uint16_t *)y1, c1_part, p->w2, w.w2img);
     } else {
         const size_t c1_lds = (size_t)3 * (2 * O1 + 1) * grid * sizeof(float);
         const bool c1_staged = obs_grid != nullptr && (grid % 4 == 0) && (row_stride % 4 == 0) && (((uintptr_t)obs_grid & 15) == 0) && c1_lds <= 64 * 1024 &&
                                2 * O1 + 1 <= grid;
-        const float *nozs = nullptr;
-        if (qm)
-            hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, int8_t, false, true>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, p->grid_i8, rows,
-                               p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, nozs, nozs, p->w2, w.w2img);
-        else if (conv1_i8_staged(p, grid) && c1_part == nullptr && grid == 64 && conv_split_path(p, grid) && !env_off("GENNBV_CONV1_SPLIT"))  // (no partial sums: BN1 is analytic or in eval mode)
+        if (conv1_i8_staged(p, grid) && c1_part == nullptr && grid == 64 && conv_split_path(p, grid) && !env_off("GENNBV_CONV1_SPLIT"))  // (no partial sums: BN1 is analytic or in eval mode)
             hipLaunchKernelGGL(k_conv1_fwd_split, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, p->grid_i8, rows, p->grid_i8_row_stride, batch, grid,
                                O1, p->w1, p->b1, (float *)y1, p->w2, w.w2img);
         else if (conv1_i8_staged(p, grid))  // compact int8 copy of the tri-class grid: a quarter of the input bytes
             hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, int8_t>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, p->grid_i8, rows,
-                               p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, nozs, nozs, p->w2, w.w2img);
+                               p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, p->w2, w.w2img);
         else if (c1_staged)
             hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, float>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, obs_grid, rows,
-                               row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, nozs, nozs, p->w2, w.w2img);
+                               row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, p->w2, w.w2img);
         else if (p->grid_i8 != nullptr && grid % 16 == 0 && p->grid_i8_row_stride % 16 == 0 && (((uintptr_t)p->grid_i8 & 15) == 0) &&
                  c1_lds / 4 <= 64 * 1024 && 2 * O1 + 1 <= grid)  // int8 rows, fp32 slab too large (G = 128): int8 slab
             hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, int8_t, true>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds / 4, st, p->grid_i8,
-                               rows, p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, nozs, nozs, p->w2, w.w2img);
+                               rows, p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, p->w2, w.w2img);
         else if (obs_grid == nullptr)  // compact rows at a size the staged kernels do not take
             hipLaunchKernelGGL((k_conv1_fwd<ActF32, int8_t>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, p->grid_i8, rows,
                                p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, p->w2, w.w2img);
@@ -2392,10 +2129,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     if (fused_eval || fused_train) {
         // (y2 was written by k_conv12_fwd_split above)
         g2 = sample_plane_group_grid(batch, O2, split::kNP);
-    } else if (p->act_bf16) {
-        hipLaunchKernelGGL(k_conv2_fwd<ActBF16>, dim3(g2), dim3(kFwdThreads), 0, st, (const uint16_t *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
-                       training ? w.bn_part : nullptr);
-    } else if (!z1 && !qm && conv_split_path(p, grid)) {
+    } else if (conv_split_path(p, grid)) {
         // (its weight images, and the data-gradient kernel's, were written by the conv1 kernel in passing)
         g2 = sample_plane_group_grid(batch, O2, split::kNP);
         static bool attr_split = false;
@@ -2406,12 +2140,6 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
         }
         hipLaunchKernelGGL(k_conv2_fwd_split, dim3(g2), dim3(split::kThreads), split::kLdsBytes, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2,
                            (const uint4 *)w.w2split, p->b2, y2, training ? w.bn_part : nullptr);
-    } else if (z1) {
-        hipLaunchKernelGGL((k_conv2_fwd<ActF32, true>), dim3(g2), dim3(kFwdThreads), 0, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
-                       training ? w.bn_part : nullptr);
-    } else if (qm) {
-        hipLaunchKernelGGL((k_conv2_fwd<ActF32, false, true>), dim3(g2), dim3(kFwdThreads), 0, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
-                           training ? w.bn_part : nullptr);
     } else {
         hipLaunchKernelGGL(k_conv2_fwd<ActF32>, dim3(g2), dim3(kFwdThreads), 0, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
                        training ? w.bn_part : nullptr);
@@ -2448,7 +2176,7 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
                                         const float *d_features, float *dy2_scratch, void *dz1_scratch,
                                         const GnbvEncoderGrads *g, void *workspace, size_t workspace_bytes, void *stream)
 {
-    GNBV_CHECK_ARG(p && (obs_grid || (p->grid_i8 && !p->act_bf16)) && y1 && y2 && bn_state && d_features && dy2_scratch && dz1_scratch && g && workspace);
+    GNBV_CHECK_ARG(p && (obs_grid || (p->grid_i8)) && y1 && y2 && bn_state && d_features && dy2_scratch && dz1_scratch && g && workspace);
     GNBV_CHECK_ARG(p->grid_i8 == nullptr || p->grid_i8_row_stride >= (int64_t)grid * grid * grid);
     GNBV_CHECK_ARG(batch > 0 && grid >= 7 && workspace_bytes >= gnbv_encoder_workspace_bytes(batch, grid));
     GNBV_CHECK_ARG(g->w1 && g->b1 && g->bn1_w && g->bn1_b && g->w2 && g->b2 && g->bn2_w && g->bn2_b);
@@ -2459,13 +2187,13 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     int err;
     // conv2 data gradient fused with the conv1 weight gradient (dz1' never stored) when the grid exists as aligned
     // int8 rows; the input autocorrelation it needs runs on a second stream beside the kernels below
-    const bool fused = fused_path(p, grid), z1 = z1_path(p, grid), qm = y1_quad_major(p, grid);  // (GENNBV_FUSED_BWD=0: A/B runs, bit-equality tests; GENNBV_Z1=1: opt-in)
+    const bool fused = fused_path(p, grid);  // (GENNBV_FUSED_BWD=0: A/B runs, bit-equality tests)
     GNBV_CHECK_ARG(p->autocorr == nullptr || (p->autocorr_row_stride >= kAcRow && p->autocorr_row_stride % 4 == 0 && ((uintptr_t)p->autocorr & 15) == 0));
     // the input autocorrelation: per-sample rows computed when the observation was produced (p->autocorr), or
     // the minibatch total computed here
     int *Rac = (int *)(w.red + 1024);  // [kAcRow]
     // (a training forward that computed BN1's statistics from the autocorrelation left the minibatch total in bn_state)
-    const bool saved_total = fused && (z1 || analytic_bn1(p, grid));
+    const bool saved_total = fused && analytic_bn1(p, grid);
     if (fused && !saved_total && p->autocorr == nullptr && (err = launch_autocorr_total(p, rows, batch, grid, Rac, st))) return err;
     // ---- BN2 + ReLU backward ----
     hipLaunchKernelGGL(k_bn2_bwd_reduce, dim3(batch * kC), dim3(256), 0, st, d_features, y2, bn2, bn2 + kC, bn2 + 2 * kC,
@@ -2476,7 +2204,7 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     hipLaunchKernelGGL(k_bn2_bwd_finalize, dim3(1), dim3(256), 0, st, w.bn_part, batch, S2, dy2_absmax);
     if ((err = gnbv_launch_status())) return err;
     const bool dp = p->world > 1 && p->sync_sum != nullptr && p->sync_buf != nullptr;
-    if (dp && !(fused && !z1 && p->autocorr_global != nullptr && saved_total)) return (int)hipErrorInvalidValue;  // (see GnbvEncoderParams.world)
+    if (dp && !(fused && p->autocorr_global != nullptr && saved_total)) return (int)hipErrorInvalidValue;  // (see GnbvEncoderParams.world)
     const double *S2m = S2;  // the sums the elementwise BN2 backward uses: this replica's, or the global minibatch's
     if (dp) {
         if (hipMemcpyAsync(p->sync_buf + 2 * kC, S2, 2 * kC * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return (int)hipGetLastError();
@@ -2493,33 +2221,8 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     int nrows2 = batch * O2 * O2;
     int wg_blocks = (nrows2 + kEncWaves - 1) / kEncWaves;
     wg_blocks = wg_blocks > 512 ? 512 : ((wg_blocks + 7) & ~7);
-    const bool split_bwd = !z1 && !qm && conv_split_path(p, grid);
-    // both backward kernels as ONE launch whose workgroup pairs share their y1 planes through the XCD's L2 (k_conv2_bwd_dual_split)
-    // OPT-IN (GENNBV_BWD_DUAL=1).  Measured (profiles/r03_notes.md): the pairs DO share -- FETCH_SIZE 581 -> 397 MB per minibatch --
-    // and the launch takes 185 us against 80 + 100 separately (206.8 against 191.4 beside fc_grid's dW GEMM in the captured
-    // minibatch): these kernels are not bound by where their bytes come from.
-    const char *dual_env = getenv("GENNBV_BWD_DUAL");
-    const bool dual_bwd = split_bwd && fused && dual_env && dual_env[0] == '1';
-    float *wg1_part_early = w.wg_part + (size_t)512 * (kTaps * 256 + kC);
-    if (dual_bwd) {
-        static bool attr_du = false;
-        if (!attr_du) {
-            const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_bwd_dual_split, hipFuncAttributeMaxDynamicSharedMemorySize, dual::kLdsBytes);
-            if (e != hipSuccess) return (int)e;
-            attr_du = true;
-        }
-        wg_blocks = sample_plane_group_grid(batch, O2, split::kNP);
-        if (wg_blocks != sample_plane_group_grid(batch, (O1 + 1) / 2, kPlanesPerGroup)) return (int)hipErrorInvalidValue;  // (same partition by construction)
-        Conv2BwdDualArgs da;
-        da.y1 = (const float *)y1; da.scale1 = bn1; da.shift1 = bn1 + kC; da.mean1 = bn1 + 2 * kC; da.rstd1 = bn1 + 3 * kC; da.dy2 = dy2_scratch;
-        da.absmax = (const unsigned *)dy2_absmax;
-        da.w2img = (const uint4 *)(w.w2split + split::kW2ImgU4);
-        da.wbound = (const float *)(w.w2split + split::kW2ImgU4 + dsplit::kImgSlotU4);
-        da.grid_i8 = p->grid_i8; da.rows = rows; da.grid_row_stride = p->grid_i8_row_stride;
-        da.B = batch; da.G = grid; da.O1 = O1; da.O2 = O2;
-        da.wg_partial = w.wg_part; da.dg_partial = wg1_part_early;
-        hipLaunchKernelGGL(k_conv2_bwd_dual_split, dim3(2 * wg_blocks), dim3(split::kThreads), dual::kLdsBytes, sw, da);
-    } else if (split_bwd) {
+    const bool split_bwd = conv_split_path(p, grid);
+    if (split_bwd) {
         static bool attr_wg = false;
         if (!attr_wg) {
             const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_wgrad_split, hipFuncAttributeMaxDynamicSharedMemorySize, split::kWgLdsBytes);
@@ -2529,14 +2232,6 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
         wg_blocks = sample_plane_group_grid(batch, O2, split::kNP);
         hipLaunchKernelGGL(k_conv2_wgrad_split, dim3(wg_blocks), dim3(split::kThreads), split::kWgLdsBytes, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch,
                            (const unsigned *)dy2_absmax, batch, O1, O2, w.wg_part);
-    } else if (p->act_bf16) {
-        hipLaunchKernelGGL(k_conv2_wgrad<ActBF16>, dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const uint16_t *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
-                       w.wg_part);
-    } else if (z1) {
-        hipLaunchKernelGGL((k_conv2_wgrad<ActF32, true>), dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
-                       w.wg_part);
-    } else if (qm) {
-        hipLaunchKernelGGL(k_conv2_wgrad_qm, dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2, w.wg_part);
     } else {
         hipLaunchKernelGGL(k_conv2_wgrad<ActF32>, dim3(wg_blocks), dim3(kEncThreads), 0, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch, batch, O1, O2,
                        w.wg_part);
@@ -2546,22 +2241,10 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     // the conv1 weight gradient (main stream) uses its own partial / slice regions of the workspace
     float *wg1_part = w.wg_part + (size_t)512 * E2;
     double *tmp1 = w.tmp + (size_t)32 * E2;
-    // Only the optimizer reads dW2: on the split path (whose data-gradient kernel takes its weight images from the forward's
-    // k_bn1_analytic, not from this finish) the reduction and the finish wait behind the data gradient and share their launches with
-    // the conv1 weight gradient's (k_reduce_partials4_x2, k_wgrad_finish_both): two launches less between the two conv kernels.
-    // OPT-IN (GENNBV_LATE_WGRAD_FINISH=1).  Measured (profiles/r03_notes.md): by itself 34 -> 32 launches per minibatch and no time --
-    // the 17 us that leave the gap between the two conv kernels come back as a longer data-gradient kernel beside more of fc_grid's dW
-    // GEMM --; with that GEMM in FRONT of the pose branch's backward on the second stream (GENNBV_DW_FIRST=1, sb3/ppo_grid_obs.py) the
-    // replayed graph is bimodal from process to process: 561-566 us per minibatch or 581-589, against a steady 570-576.
-    const ReduceJob job2 = reduce_job(w.wg_part, wg_blocks, E2, w.tmp);
-    const char *late_s = getenv("GENNBV_LATE_WGRAD_FINISH");
-    const bool late_env = late_s && late_s[0] == '1';
-    const bool late_finish = late_env && split_bwd && fused && !dual_bwd && !dp && reduce_job_ok(job2) && job2.slices <= 32 &&
-                             wg_blocks <= 512;  // (its partials must stay clear of the conv1 partials at 512 E2 and its slices of tmp1 at 32 E2)
-    if (!late_finish) {
+    {
         const int sl2 = reduce_stage1(w.wg_part, wg_blocks, E2, w.tmp, sw);  // <= 16 slices: tmp[0, 16 E2)
         if ((err = gnbv_launch_status())) return err;
-        // (the weight images ride in the finish launch unless it runs on the side stream)
+        // (the weight images ride in the finish launch)
         hipLaunchKernelGGL(k_conv2_wgrad_finish, dim3((E2 + 255) / 256), dim3(256), 0, sw, (const double *)w.tmp, sl2, g->w2, g->b2,
                            p->w2, w.w2img);
         if ((err = gnbv_launch_status())) return err;
@@ -2569,9 +2252,7 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     // ---- conv2 data gradient (+ ReLU1 mask, BN1 backward sums) ----
     const int gd = sample_plane_group_grid(batch, (O1 + 1) / 2, kPlanesPerGroup);  // groups of plane PAIRS
     if (fused) {
-        if (dual_bwd) {
-            // (the data gradient ran in the dual launch above)
-        } else if (split_bwd) {
+        if (split_bwd) {
             static bool attr_dg = false;
             if (!attr_dg) {
                 const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_dgrad_c1w_split, hipFuncAttributeMaxDynamicSharedMemorySize, dsplit::kLdsBytes);
@@ -2582,33 +2263,10 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
                                (const float *)(w.w2split + split::kW2ImgU4 + dsplit::kImgSlotU4),
                                (const unsigned *)dy2_absmax, (const float *)y1, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->grid_i8, rows, p->grid_i8_row_stride,
                                batch, grid, O1, O2, wg1_part);
-        } else if (z1)
-            hipLaunchKernelGGL(k_conv2_dgrad_c1w<true>, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const float *)y1, bn1,
-                               bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->grid_i8, rows, p->grid_i8_row_stride, batch, grid, O1, O2, wg1_part);
-        else if (qm)
-            hipLaunchKernelGGL((k_conv2_dgrad_c1w<false, true>), dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const float *)y1, bn1,
-                               bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->grid_i8, rows, p->grid_i8_row_stride, batch, grid, O1, O2, wg1_part);
-        else
-            hipLaunchKernelGGL(k_conv2_dgrad_c1w<false>, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const float *)y1, bn1,
+        } else
+            hipLaunchKernelGGL(k_conv2_dgrad_c1w, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const float *)y1, bn1,
                                bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->grid_i8, rows, p->grid_i8_row_stride, batch, grid, O1, O2, wg1_part);
         if ((err = gnbv_launch_status())) return err;
-        const ReduceJob job1 = reduce_job(wg1_part, gd, kE1F, tmp1);
-        if (late_finish && reduce_job_ok(job1)) {
-            hipLaunchKernelGGL(k_reduce_partials4_x2, dim3(job2.nbx + job1.nbx, job2.slices > job1.slices ? job2.slices : job1.slices), dim3(256), 0, st, job2, job1);
-            if ((err = gnbv_launch_status())) return err;
-            hipLaunchKernelGGL(k_wgrad_finish_both, dim3(1 + (E2 + 1023) / 1024), dim3(1024), 0, st, (const double *)w.tmp, job2.slices, g->w2, g->b2,
-                               (const double *)tmp1, job1.slices,
-                               saved_total ? (const int *)(bn_state + kBnStateFloats) : (p->autocorr ? (const int *)p->autocorr : (const int *)Rac),
-                               p->autocorr_row_stride, rows, (!saved_total && p->autocorr) ? batch : 0,
-                               p->w1, bn1, bn1 + 3 * kC, z1 ? p->bn1_w : (const float *)nullptr, p->bn1_b, g->w1, g->b1, (const double *)S2, g->bn1_w,
-                               g->bn1_b, g->bn2_w, g->bn2_b, (const double *)nullptr, (const int *)nullptr);
-            return gnbv_launch_status();
-        }
-        if (late_finish) {  // (kE1F partials not 16-byte aligned: never with this workspace layout)
-            const int sl2 = reduce_stage1(w.wg_part, wg_blocks, E2, w.tmp, st);
-            hipLaunchKernelGGL(k_conv2_wgrad_finish, dim3((E2 + 255) / 256), dim3(256), 0, st, (const double *)w.tmp, sl2, g->w2, g->b2, p->w2, w.w2img);
-            if ((err = gnbv_launch_status())) return err;
-        }
         const int slf = reduce_stage1(wg1_part, gd, kE1F, tmp1, st);
         if ((err = gnbv_launch_status())) return err;
         if (dp) {  // BatchNorm-1 backward means over the global minibatch
@@ -2619,16 +2277,13 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
         hipLaunchKernelGGL(k_c1w_fused_finish, dim3(1), dim3(1024), 0, st, (const double *)tmp1, slf,
                            saved_total ? (const int *)(bn_state + kBnStateFloats) : (p->autocorr ? (const int *)p->autocorr : (const int *)Rac),
                            p->autocorr_row_stride, rows, (!saved_total && p->autocorr) ? batch : 0,
-                           p->w1, bn1, bn1 + 3 * kC, z1 ? p->bn1_w : (const float *)nullptr, p->bn1_b, g->w1, g->b1, (const double *)S2, g->bn1_w,
+                           p->w1, bn1, bn1 + 3 * kC, p->bn1_b, g->w1, g->b1, (const double *)S2, g->bn1_w,
                            g->bn1_b, g->bn2_w, g->bn2_b, dp ? (const double *)(p->sync_buf + 4 * kC) : (const double *)nullptr,
                            dp ? (const int *)p->autocorr_global : (const int *)nullptr);
         if ((err = gnbv_launch_status())) return err;
         return gnbv_launch_status();
     }
-    if (p->act_bf16) {
-        hipLaunchKernelGGL(k_conv2_dgrad<ActBF16>, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const uint16_t *)y1, bn1, bn1 + kC, bn1 + 2 * kC,
-                       bn1 + 3 * kC, batch, O1, O2, (uint16_t *)dz1_scratch, w.bn_part);
-    } else {
+    {
         hipLaunchKernelGGL(k_conv2_dgrad<ActF32>, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const float *)y1, bn1, bn1 + kC, bn1 + 2 * kC,
                        bn1 + 3 * kC, batch, O1, O2, (float *)dz1_scratch, w.bn_part);
     }
@@ -2646,10 +2301,7 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     const int c1w_nr = (2 * ((O1 + 1) / 2) * kC + 255) / 256, c1w_ni = (9 * grid + 255) / 256;  // 16-byte requests per lane and row
     const bool c1w_staged = obs_grid != nullptr && (grid % 4 == 0) && (row_stride % 4 == 0) && (((uintptr_t)obs_grid & 15) == 0) && c1w_lds <= 64 * 1024 &&
                             c1w_nr <= 4 && c1w_ni <= 5;
-    if (p->act_bf16) {
-        hipLaunchKernelGGL(k_conv1_wgrad<ActBF16>, dim3(wg1_blocks), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride, (const uint16_t *)dz1_scratch, (const uint16_t *)y1, bn1,
-                       bn1 + 2 * kC, bn1 + 3 * kC, S1, (double)batch * O1 * O1 * O1, batch, grid, O1, wg1_part);
-    } else if (p->grid_i8 != nullptr && grid % 16 == 0 && 9 * grid <= 1024 && p->grid_i8_row_stride % 16 == 0 &&
+    if (p->grid_i8 != nullptr && grid % 16 == 0 && 9 * grid <= 1024 && p->grid_i8_row_stride % 16 == 0 &&
                (((uintptr_t)p->grid_i8 & 15) == 0) && c1w_lds <= 64 * 1024 && c1w_nr <= 4) {
 #define GNBV_C1W8(NR)                                                                                                             \
     hipLaunchKernelGGL((k_conv1_wgrad_lds<ActF32, NR, 1, int8_t>), dim3(wg1_blocks), dim3(kEncThreads), c1w_lds, st, p->grid_i8,  \

@@ -178,17 +178,11 @@ __device__ __forceinline__ void lsplit8(const float4 &p, const float4 &q, float 
 // folded into this kernel's operand load.  P >= 512 (the caller checks): a chunk of <= 512 columns then meets at most one channel
 // boundary, and a 32-column trip that does not contain it takes the scalar path (one fma + one max per element).  The largest
 // operand is tracked for the range guard (bit 4 of *range_flag when it passes 1000: the split clamps x at 1015).
-//
-// ADAM (round 3, with FOLD): the layer's weight still has the PREVIOUS optimizer step's update coming (GnbvOwedAdam: the clip + Adam
-// launch skipped this slice and raised *pending).  Every weight element is staged by exactly one thread of one workgroup of this
-// launch (M <= 128: one row block), so that thread applies the update -- same expressions as k_adam_flat (csrc/ppo.hip), bit-identical
-// -- writes p / m / v back and stages the NEW weight: the update's 7 x 4 bytes per parameter ride this kernel's weight stream instead
-// of a 65 us launch of their own in front of it (this kernel alone: 30 us; together ~70).
-template <bool FOLD, bool ADAM = false>
+template <bool FOLD>
 __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linear_splitk_split(
     const float *__restrict__ x /*[M][K]*/, const float *w /*[N][K]*/, int M, int N, int K, int nchunks,
     float *__restrict__ partial /*[nchunks][M][N]*/, const float *__restrict__ xs_scale = nullptr, const float *__restrict__ xs_shift = nullptr,
-    int xs_P = 0, int *__restrict__ range_flag = nullptr, GnbvOwedAdam oa = GnbvOwedAdam{})
+    int xs_P = 0, int *__restrict__ range_flag = nullptr)
 {
     __shared__ __attribute__((aligned(16))) char s_b[2][2][4096];  // [buffer][hi | lo][column tile 4][g 4][column 16][8 halfs]
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -228,26 +222,8 @@ __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // requests are UNCONDITIONAL (clamped addresses): see the fp32 kernel
-    struct Trip { float4 a00, a01, a10, a11, b0, b1, g0, g1, m0, m1, v0, v1; };  // (named members: arrays handed to lambdas ended up in scratch memory elsewhere; g / m / v: ADAM only)
+    struct Trip { float4 a00, a01, a10, a11, b0, b1; };  // (named members: arrays handed to lambdas ended up in scratch memory elsewhere)
     static_assert(kRowTilesPerWave == 2, "two row tiles per wave");
-    // ADAM: is the update owed (uniform), its scalars (k_adam_flat's prologue)
-    bool upd = false;
-    float ad_coef = 0.f, ad_step = 0.f, ad_bc2s = 1.f;
-    const float *gst[2] = {nullptr, nullptr};
-    float *mst[2] = {nullptr, nullptr}, *vst[2] = {nullptr, nullptr};
-    if (ADAM) {
-        upd = *oa.pending != 0;
-        ad_coef = oa.norm_out[1];
-        const double t = (double)(*oa.step);
-        const double bc1 = 1.0 - pow((double)oa.beta1, t), bc2 = 1.0 - pow((double)oa.beta2, t);
-        ad_step = (float)((double)oa.lr / bc1);
-        ad_bc2s = (float)sqrt(bc2);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const size_t off = (size_t)(nt * kTileN + 32 * r + tcol) * K + 4 * t8;
-            gst[r] = oa.grads + off; mst[r] = oa.exp_avg + off; vst[r] = oa.exp_avg_sq + off;
-        }
-    }
     auto request_a = [&](int s, Trip &t) {
         const int kc = min(min(s, s1 - 1) * 32, K - 8 - 8 * g);
         t.a00 = ld4g(xr[0] + kc);
@@ -259,25 +235,6 @@ __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 
         const int kc = min(min(s, s1 - 1) * 32, K - 4 - 4 * t8);
         t.b0 = ld4g(wst[0] + kc);
         t.b1 = ld4g(wst[1] + kc);
-        if (ADAM && upd) {
-            t.g0 = ld4g(gst[0] + kc); t.g1 = ld4g(gst[1] + kc);
-            t.m0 = ld4g(mst[0] + kc); t.m1 = ld4g(mst[1] + kc);
-            t.v0 = ld4g(vst[0] + kc); t.v1 = ld4g(vst[1] + kc);
-        }
-    };
-    auto adam4 = [&](float4 &pw, const float4 &gw, float4 &mw, float4 &vw) {  // k_adam_flat's element update, four times
-        float *pp = &pw.x, *mm = &mw.x, *vv = &vw.x;
-        const float *gg = &gw.x;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float gi = gg[e] * ad_coef;
-            const float mi = mm[e] + (gi - mm[e]) * (1.0f - oa.beta1);
-            const float vi = vv[e] * oa.beta2 + (1.0f - oa.beta2) * gi * gi;
-            mm[e] = mi;
-            vv[e] = vi;
-            const float denom = sqrtf(vi) / ad_bc2s + oa.eps;
-            pp[e] = pp[e] - ad_step * (mi / denom);
-        }
     };
     auto stage_one = [&](int buf, bool ok, const float4 &b, uint32_t off) {
         const float v[4] = {b.x, b.y, b.z, b.w};
@@ -294,17 +251,6 @@ __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 
     };
     auto stage_b = [&](int buf, int s, Trip &t) {
         const bool ok = s < s1 && s * 32 + 4 * t8 + 3 < K;  // past the chunk / past K: zeros
-        if (ADAM && upd && ok) {  // (ok: this thread is the element's one owner; its request was not clamped)
-            const int kc = s * 32;
-            adam4(t.b0, t.g0, t.m0, t.v0);
-            adam4(t.b1, t.g1, t.m1, t.v1);
-            *reinterpret_cast<float4 *>(const_cast<float *>(wst[0]) + kc) = t.b0;
-            *reinterpret_cast<float4 *>(const_cast<float *>(wst[1]) + kc) = t.b1;
-            *reinterpret_cast<float4 *>(mst[0] + kc) = t.m0;
-            *reinterpret_cast<float4 *>(mst[1] + kc) = t.m1;
-            *reinterpret_cast<float4 *>(vst[0] + kc) = t.v0;
-            *reinterpret_cast<float4 *>(vst[1] + kc) = t.v1;
-        }
         stage_one(buf, ok, t.b0, st_off[0]);
         stage_one(buf, ok, t.b1, st_off[1]);
     };
@@ -712,30 +658,6 @@ GNBV_API int gnbv_linear_forward_fold(const float *y, const float *scale, const 
     const int blocks = ((nchunks + 7) / 8) * 8 * ntn;
     hipLaunchKernelGGL(k_linear_splitk_split<true>, dim3(blocks, (M + 127) / 128), dim3(kLinThreads), 0, st, y, w, M, N, K, nchunks, (float *)workspace, scale,
                        shift, P, range_flag);
-    int err;
-    if ((err = gnbv_launch_status())) return err;
-    const int64_t total4 = (int64_t)M * N / 4;
-    hipLaunchKernelGGL(k_linear_reduce, dim3((unsigned)((total4 + kRedQ - 1) / kRedQ)), dim3(kRedSplit * kRedQ), 0, st, (const float *)workspace, bias, M, N, nchunks,
-                       relu & 1, out);
-    return gnbv_launch_status();
-}
-
-GNBV_API int gnbv_linear_forward_fold_adam(const float *y, const float *scale, const float *shift, int P, int *range_flag, float *w, const float *bias,
-                                           int M, int N, int K, int relu, float *out, void *workspace, size_t workspace_bytes, const GnbvOwedAdam *adam,
-                                           void *stream)
-{
-    GNBV_CHECK_ARG(y && scale && shift && w && bias && out && workspace && adam);
-    GNBV_CHECK_ARG(adam->grads && adam->exp_avg && adam->exp_avg_sq && adam->norm_out && adam->step && adam->pending);
-    GNBV_CHECK_ARG(M <= 128 /*one row block: every weight element has ONE owner thread*/ && N > 0 && N % kTileN == 0 && gnbv_linear_fold_ok(M, N, K, P) &&
-                   !(relu & 2));
-    GNBV_CHECK_ARG((((uintptr_t)y | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)out | (uintptr_t)workspace | (uintptr_t)adam->grads | (uintptr_t)adam->exp_avg |
-                     (uintptr_t)adam->exp_avg_sq) & 15) == 0);
-    GNBV_CHECK_ARG(workspace_bytes >= gnbv_linear_workspace_bytes(M, N, K));
-    hipStream_t st = gnbv_stream(stream);
-    const int nchunks = pick_chunks(K), ntn = N / kTileN;
-    const int blocks = ((nchunks + 7) / 8) * 8 * ntn;
-    hipLaunchKernelGGL((k_linear_splitk_split<true, true>), dim3(blocks, 1), dim3(kLinThreads), 0, st, y, (const float *)w, M, N, K, nchunks, (float *)workspace,
-                       scale, shift, P, range_flag, *adam);
     int err;
     if ((err = gnbv_launch_status())) return err;
     const int64_t total4 = (int64_t)M * N / 4;

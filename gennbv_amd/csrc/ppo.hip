@@ -392,9 +392,7 @@ __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, 
                             const int *__restrict__ stop_flag,
                             const int64_t *__restrict__ step /*already incremented*/, float lr, float beta1, float beta2, float eps,
                             const int64_t *__restrict__ rot_table = nullptr, int rot_rows = 0, int rot_len = 0, int64_t *__restrict__ rot_out = nullptr,
-                            int *__restrict__ rot_counter = nullptr,
-                            int *__restrict__ pending_out = nullptr /*<- 1 when this step's update is applied (the skipped slice is then owed), else 0*/,
-                            const int *__restrict__ pending_in = nullptr /*the owed slice: run only when *pending_in != 0*/)
+                            int *__restrict__ rot_counter = nullptr)
 {
     // (replayed minibatch graphs: the LAST launch of a minibatch leaves the next minibatch's row numbers in the buffer every kernel
     // of the graph reads them from -- no copy node, no host work between two replays.  Also when the update itself is masked.)
@@ -405,8 +403,7 @@ __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, 
         if (threadIdx.x == 0) *rot_counter = c;
     }
     const bool stopped = stop_flag != nullptr && *stop_flag != 0;
-    if (pending_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *pending_out = stopped ? 0 : 1;
-    if (stopped || (pending_in != nullptr && *pending_in == 0)) return;
+    if (stopped) return;
     __shared__ double sh[256];
     float coef;
     if (coef_in != nullptr) {
@@ -598,23 +595,7 @@ GNBV_API int gnbv_clip_adam_step_ex(const GnbvAdamStep *a, void *stream)
     hipLaunchKernelGGL(k_adam_flat, dim3(ab), dim3(256), 0, st, a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->n, (const double *)partial, blocks + fold,
                        (const double *)nullptr, 0, a->max_grad_norm, a->grad_scale, a->norm_out,
                        (const float *)nullptr, a->upd_skip_lo, a->upd_skip_hi, (const int *)a->stop_flag, (const int64_t *)a->step, a->lr, a->beta1, a->beta2, a->eps, a->table, a->table_rows, a->row_len, a->out,
-                       a->counter, a->upd_skip_hi > a->upd_skip_lo ? a->pending : (int *)nullptr);
-    return gnbv_launch_status();
-}
-
-// The update of the slice a step's main launch skipped (GnbvAdamStep.upd_skip_lo / hi with .pending), launched LATER -- at the head
-// of the next minibatch, on a second stream beside the conv stack's forward, which does not read that slice: the update is 392 MB
-// of HBM traffic (~65 us) that otherwise sits alone on the critical path.  Runs iff *pending != 0; same clip factor (norm_out[1])
-// and step counter as the launch that owed it (nothing between the two launches writes either).
-GNBV_API int gnbv_adam_slice_pending(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const float *norm_out,
-                                     float lr, float beta1, float beta2, float eps, const int64_t *step, const int *pending, void *stream)
-{
-    GNBV_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && norm_out && step && pending && n > 0);
-    int ab = (int)((n + 255) / 256);
-    ab = ab > GNBV_ADAM_BLOCKS ? GNBV_ADAM_BLOCKS : ab;
-    hipLaunchKernelGGL(k_adam_flat, dim3(ab), dim3(256), 0, gnbv_stream(stream), params, grads, exp_avg, exp_avg_sq, n, (const double *)nullptr, 0,
-                       (const double *)nullptr, 0, 0.0f, 1.0f, (float *)nullptr, norm_out, (int64_t)0, (int64_t)0, (const int *)nullptr, step, lr, beta1, beta2,
-                       eps, (const int64_t *)nullptr, 0, 0, (int64_t *)nullptr, (int *)nullptr, (int *)nullptr, pending);
+                       a->counter);
     return gnbv_launch_status();
 }
 

@@ -68,7 +68,11 @@ class Hybrid_Encoder(nn.Module):
         self._features_dim = copy.deepcopy(net_param)["append_hidden_shapes"][-1]
         self._observation_space = observation_space
         self.grid_size = int(grid_size) if grid_size is not None else infer_grid_size(observation_space, state_input_shape[0])
-        self.compute_dtype = compute_dtype
+        if compute_dtype not in (None, torch.float32):
+            # (the bf16 activation-storage mode of rounds 1-3 is gone: slower than the fp32-accurate split-f16 kernels and 1e-3-class loss
+            # deltas -- DESIGN.md section 5, "Precision")
+            raise ValueError("Hybrid_Encoder computes in fp32 (fp32-accurate products on the f16 matrix pipe); compute_dtype must be torch.float32")
+        self.compute_dtype = torch.float32
         self.overlap_branches = True  # pose branch on a second stream
         o1, o2 = conv_out(self.grid_size)
         self.grid_feat = 16 * o2 ** 3  # 1024 at G=20

@@ -120,7 +120,7 @@ def autocorr_supported(grid: int) -> bool:
     return grid >= 16 and grid % 16 == 0 and 3 * grid * grid <= 64 * 1024
 
 
-def _params_struct(seq, act_bf16: bool = False, grid_i8: Optional[torch.Tensor] = None,
+def _params_struct(seq, grid_i8: Optional[torch.Tensor] = None,
                    autocorr: Optional[torch.Tensor] = None, dp=None, guard=None) -> _lib.GnbvEncoderParams:
     conv1, bn1, conv2, bn2 = seq[0], seq[1], seq[3], seq[4]
     p = _lib.GnbvEncoderParams()
@@ -129,7 +129,6 @@ def _params_struct(seq, act_bf16: bool = False, grid_i8: Optional[torch.Tensor] 
     p.w2, p.b2, p.bn2_w, p.bn2_b = conv2.weight.data_ptr(), conv2.bias.data_ptr(), bn2.weight.data_ptr(), bn2.bias.data_ptr()
     p.bn2_rm, p.bn2_rv, p.bn2_nbt = bn2.running_mean.data_ptr(), bn2.running_var.data_ptr(), bn2.num_batches_tracked.data_ptr()
     p.eps, p.momentum = float(bn1.eps), float(bn1.momentum)
-    p.act_bf16 = int(bool(act_bf16))
     p.grid_i8 = None if grid_i8 is None else grid_i8.data_ptr()
     p.grid_i8_row_stride = 0 if grid_i8 is None else int(grid_i8.stride(0))
     p.autocorr = None if autocorr is None else autocorr.data_ptr()
@@ -150,7 +149,7 @@ def _params_struct(seq, act_bf16: bool = False, grid_i8: Optional[torch.Tensor] 
 
 class _GridEncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, base, rows, grid_off, grid, training, skip_flag, seq, act_bf16, write_through, grid_i8, compact, autocorr, dp, guard, fold, w1, b1, g1, be1, w2, b2, g2, be2):
+    def forward(ctx, base, rows, grid_off, grid, training, skip_flag, seq, write_through, grid_i8, compact, autocorr, dp, guard, fold, w1, b1, g1, be1, w2, b2, g2, be2):
         lib = _lib.load()
         _lib.require_cuda(base, w1)
         for t in (w1, b1, g1, be1, w2, b2, g2, be2):
@@ -160,15 +159,14 @@ class _GridEncoderFn(torch.autograd.Function):
         o1 = conv_out(grid)
         o2 = conv_out(o1)
         p2 = o2 ** 3
-        act_dt = torch.bfloat16 if act_bf16 else torch.float32
-        y1 = torch.empty(lib.gnbv_encoder_y1_elems(batch, grid), dtype=act_dt, device=dev)
+        y1 = torch.empty(lib.gnbv_encoder_y1_elems(batch, grid), dtype=torch.float32, device=dev)
         y2 = torch.empty(batch * 16 * p2, dtype=torch.float32, device=dev)
         bn_state = torch.empty(2 * 4 * 16 + 768, dtype=torch.float32, device=dev)  # + the minibatch's autocorrelation total (ints)
         # fold: BatchNorm-2 + ReLU are left to the consumer's operand load (linear_relu(..., fold=...)): no feature tensor; the
         # outputs are the raw conv output y2 viewed as [B, 16 P2] and bn_state (its floats 64..96 = BN2's scale | shift)
         feats = None if fold else torch.empty(batch, 16 * p2, dtype=torch.float32, device=dev)
         ws = _workspace(lib, batch, grid, dev)
-        params = _params_struct(seq, act_bf16, grid_i8, autocorr, dp if training else None, guard)
+        params = _params_struct(seq, grid_i8, autocorr, dp if training else None, guard)
         # compact observations: `base` has no grid slice, the kernels read the int8 rows only (obs pointer NULL)
         assert not compact or grid_i8 is not None
         obs_ptr = None if compact else base.data_ptr() + 4 * grid_off
@@ -177,7 +175,7 @@ class _GridEncoderFn(torch.autograd.Function):
             y1.data_ptr(), y2.data_ptr(), bn_state.data_ptr(), _lib.ptr(feats), ws.data_ptr(), ws.numel(),
             _lib.stream_ptr(dev)), "gnbv_encoder_grid_forward")
         ctx.save_for_backward(base, rows, y1, y2, bn_state, w1, w2)
-        ctx.meta = (grid_off, grid, batch, seq, act_bf16)
+        ctx.meta = (grid_off, grid, batch, seq)
         ctx.write_through = write_through
         ctx.grid_i8 = grid_i8
         ctx.autocorr = autocorr
@@ -195,13 +193,13 @@ class _GridEncoderFn(torch.autograd.Function):
     def backward(ctx, d_feats, _d_bn_state=None):
         lib = _lib.load()
         base, rows, y1, y2, bn_state, w1, w2 = ctx.saved_tensors
-        grid_off, grid, batch, seq, act_bf16 = ctx.meta
+        grid_off, grid, batch, seq = ctx.meta
         dev = base.device
         o1 = conv_out(grid)
         o2 = conv_out(o1)
         d_feats = d_feats.contiguous().float()
         dy2 = torch.empty(batch * o2 ** 3 * 16, dtype=torch.float32, device=dev)
-        dz1 = torch.empty(lib.gnbv_encoder_y1_elems(batch, grid), dtype=torch.bfloat16 if act_bf16 else torch.float32, device=dev)
+        dz1 = torch.empty(lib.gnbv_encoder_y1_elems(batch, grid), dtype=torch.float32, device=dev)
         ps = (seq[0].weight, seq[0].bias, seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias)
         # write-through (ops/direct_grad.py): the kernels store into the parameters' .grad slices
         direct = bool(ctx.write_through) and all(t.grad is not None and t.grad.is_contiguous() for t in ps)
@@ -209,19 +207,19 @@ class _GridEncoderFn(torch.autograd.Function):
         gs = _lib.GnbvEncoderGrads()
         for name, t in zip(("w1", "b1", "bn1_w", "bn1_b", "w2", "b2", "bn2_w", "bn2_b"), grads):
             setattr(gs, name, t.data_ptr())
-        params = _params_struct(seq, act_bf16, ctx.grid_i8, ctx.autocorr, ctx.dp, ctx.guard)
+        params = _params_struct(seq, ctx.grid_i8, ctx.autocorr, ctx.dp, ctx.guard)
         ws = _workspace(lib, batch, grid, dev)
         _lib.check(lib.gnbv_encoder_grid_backward(
             ctx.obs_ptr, _lib.ptr(rows), base.stride(0), batch, grid, C.byref(params), y1.data_ptr(),
             y2.data_ptr(), bn_state.data_ptr(), d_feats.data_ptr(), dy2.data_ptr(), dz1.data_ptr(), C.byref(gs),
             ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "gnbv_encoder_grid_backward")
         if direct:
-            return (None,) * 23
-        return (None,) * 15 + tuple(grads)
+            return (None,) * 22
+        return (None,) * 14 + tuple(grads)
 
 
 def grid_encoder(base: torch.Tensor, rows: Optional[torch.Tensor], grid_off: int, grid: int, seq, training: bool,
-                 skip_flag: Optional[torch.Tensor] = None, act_bf16: bool = False, write_through: bool = False,
+                 skip_flag: Optional[torch.Tensor] = None, write_through: bool = False,
                  grid_i8: Optional[torch.Tensor] = None, compact: bool = False, autocorr: Optional[torch.Tensor] = None, dp=None,
                  guard=None, fold: bool = False):
     """seq = the `naive_encoder_grid` nn.Sequential (conv, bn, relu, conv, bn, relu).  `compact`: `base` rows carry
@@ -229,7 +227,7 @@ def grid_encoder(base: torch.Tensor, rows: Optional[torch.Tensor], grid_off: int
     `guard` = (force_fp32, range_flag int32 [1] or None[, autocorr_total int32 [768] or None]): GnbvEncoderParams.force_fp32 /
     .range_flag / .autocorr_total.  `fold`: returns (y2 [B, 16 P2] -- the second conv's raw output --, bn_state) for
     linear_relu(y2, lin, fold=(bn_state, P2, range_flag)) instead of the features (include/gennbv_hip.h gnbv_linear_forward_fold)."""
-    return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, bool(act_bf16), bool(write_through), grid_i8, bool(compact), autocorr, dp, guard, bool(fold), seq[0].weight, seq[0].bias,
+    return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, bool(write_through), grid_i8, bool(compact), autocorr, dp, guard, bool(fold), seq[0].weight, seq[0].bias,
                                 seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias)
 
 
@@ -237,7 +235,7 @@ class _LinearReluFn(torch.autograd.Function):
     """relu(x @ w.T + b) on the split-K MFMA kernel (csrc/linear.hip); backward = three library GEMMs."""
 
     @staticmethod
-    def forward(ctx, x, w, b, mod=None, fp32_arith=False, bn_state=None, fold_p=0, range_flag=None, owed_adam=None):
+    def forward(ctx, x, w, b, mod=None, fp32_arith=False, bn_state=None, fold_p=0, range_flag=None):
         ctx.mod = mod  # write-through target (ops/direct_grad.py) or None
         # bn_state given: x is a BatchNorm pre-activation [M][C][fold_p] and the layer's input is relu(scale[c] x + shift[c]),
         # formed in the kernels' operand loads (scale | shift = floats 64..96 of bn_state); the input gradient returned by
@@ -260,13 +258,8 @@ class _LinearReluFn(torch.autograd.Function):
         if ctx.fold_p:
             assert not fp32_arith
             sc = bn_state.data_ptr() + 4 * 64
-            if owed_adam is not None:
-                _lib.check(lib.gnbv_linear_forward_fold_adam(x.data_ptr(), sc, sc + 4 * 16, ctx.fold_p, _lib.ptr(range_flag), w.data_ptr(), b.data_ptr(), m, n, k,
-                                                             1, out.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(owed_adam), _lib.stream_ptr(x.device)),
-                           "gnbv_linear_forward_fold_adam")
-            else:
-                _lib.check(lib.gnbv_linear_forward_fold(x.data_ptr(), sc, sc + 4 * 16, ctx.fold_p, _lib.ptr(range_flag), w.data_ptr(), b.data_ptr(), m, n, k, 1,
-                                                        out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(x.device)), "gnbv_linear_forward_fold")
+            _lib.check(lib.gnbv_linear_forward_fold(x.data_ptr(), sc, sc + 4 * 16, ctx.fold_p, _lib.ptr(range_flag), w.data_ptr(), b.data_ptr(), m, n, k, 1,
+                                                    out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(x.device)), "gnbv_linear_forward_fold")
             ctx.save_for_backward(x, w, out, bn_state)
             return out
         _lib.check(lib.gnbv_linear_forward(x.data_ptr(), w.data_ptr(), b.data_ptr(), m, n, k, 1 | (2 if fp32_arith else 0), out.data_ptr(), ws.data_ptr(),
@@ -382,14 +375,12 @@ def join_async_wgrads(device) -> None:
     cur.wait_stream(side)
 
 
-def linear_relu(x: torch.Tensor, lin: torch.nn.Linear, fold=None, owed_adam=None) -> torch.Tensor:
+def linear_relu(x: torch.Tensor, lin: torch.nn.Linear, fold=None) -> torch.Tensor:
     """Linear + ReLU of the K-dominated fc layer (hybrid_encoder.py:39-42 of the reference).  fold = (bn_state, P, range_flag) from
     grid_encoder(..., fold=True) after linear_fold_ok(...): x is the conv stack's raw output, BatchNorm-2 + ReLU happen in the operand load."""
     n, k = lin.weight.shape
-    if fold is not None:  # (owed_adam: a _lib.GnbvOwedAdam -- the weight's pending optimizer update, applied by the forward kernel)
-        return _LinearReluFn.apply(x, lin.weight, lin.bias, lin if getattr(lin, "_grad_write_through", False) else None, False, fold[0], fold[1], fold[2],
-                                   owed_adam)
-    assert owed_adam is None
+    if fold is not None:
+        return _LinearReluFn.apply(x, lin.weight, lin.bias, lin if getattr(lin, "_grad_write_through", False) else None, False, fold[0], fold[1], fold[2])
     if k % 4 or n % 64 or not lin.weight.is_contiguous() or x.dtype != torch.float32:
         return torch.relu(torch.nn.functional.linear(x, lin.weight, lin.bias))
     return _LinearReluFn.apply(x, lin.weight, lin.bias, lin if getattr(lin, "_grad_write_through", False) else None,
@@ -399,7 +390,7 @@ def linear_relu(x: torch.Tensor, lin: torch.nn.Linear, fold=None, owed_adam=None
 def linear_fold_ok(lin: torch.nn.Linear, m: int, p: int, force_fp32: bool) -> bool:
     """Can fc layer `lin` take its input as (pre-BatchNorm activations, scale, shift) -- linear_relu(..., fold=...)?"""
     n, k = lin.weight.shape
-    if force_fp32 or getattr(lin, "_fp32_arith", False) or os.environ.get("GENNBV_FC_FOLD", "1") == "0":
+    if force_fp32 or getattr(lin, "_fp32_arith", False) or getattr(lin, "_no_fold", False):  # (_no_fold: tests, the materialised-feature path)
         return False
     if n % 64 or not lin.weight.is_contiguous() or lin.weight.dtype != torch.float32:
         return False
@@ -475,7 +466,7 @@ def hybrid_branches(enc, observations):
     p2 = conv_out(conv_out(g)) ** 3
     fold = linear_fold_ok(enc.output_layer_grid[0], num_env, p2, getattr(enc, "force_fp32", False))
     feature_grid = grid_encoder(base, rows, s, g, enc.naive_encoder_grid, enc.training, getattr(enc, "_bn_skip_flag", None),
-                                enc.compute_dtype == torch.bfloat16, getattr(enc, "_grad_write_through", False), grid_i8, compact, autocorr,
+                                getattr(enc, "_grad_write_through", False), grid_i8, compact, autocorr,
                                 getattr(enc, "_dp_sync", None),
                                 (getattr(enc, "force_fp32", False), getattr(enc, "_range_flag", None),
                                  getattr(enc, "_autocorr_total", None) if (enc.training and autocorr is not None) else None), fold)
@@ -489,26 +480,7 @@ def hybrid_branches(enc, observations):
         enc._grid_feats_out = feature_grid
         feature_grid = feature_grid.detach().requires_grad_(True)
         enc._grid_feats_leaf = feature_grid
-    # fc_grid.weight's optimizer update of the PREVIOUS minibatch, owed to this forward (sb3/ppo_grid_obs.py: FlatAdam.step(owe_slice)):
-    # applied by the kernel that streams the weight (gnbv_linear_forward_fold_adam)
-    owed_side = getattr(enc, "_fc_owed_side", None)
-    if owed_side is not None:
-        # ... or applied by a launch of its own on the second stream, forked at this forward's first kernel: a pure HBM stream (28 bytes
-        # per parameter) beside the issue-bound conv kernels; this forward's fc_grid product is the first reader of the new weight
-        enc._fc_owed_side = None
-        if side is not None:
-            with torch.cuda.stream(side):
-                owed_side()
-                evt_owed = torch.cuda.Event()
-                evt_owed.record(side)
-            torch.cuda.current_stream(base.device).wait_event(evt_owed)
-        else:
-            owed_side()
-    owed = getattr(enc, "_fc_owed_adam", None)
-    if owed is not None:
-        enc._fc_owed_adam = None
-        assert fold_args is not None, "the caller checks linear_fold_ok before it leaves an update to this forward"
-    feature_grid = linear_relu(feature_grid, enc.output_layer_grid[0], fold_args, owed)  # Linear + ReLU, split-K MFMA kernel
+    feature_grid = linear_relu(feature_grid, enc.output_layer_grid[0], fold_args)  # Linear + ReLU, split-K MFMA kernel
     if side is not None:
         # Launch order matters under hipGraph replay: the executor keeps a node on the queue of the FIRST child captured after
         # its parent, so with the pose branch captured first the conv chain -- the critical path -- was moved to a second queue and

@@ -39,8 +39,6 @@ class FlatAdam:
         self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
         self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
         self.ws = torch.empty(self.lib.gnbv_adam_workspace_bytes(), dtype=torch.uint8, device=dev)
-        self.pending = torch.zeros(1, dtype=torch.int32, device=dev)  # 1: the slice `owed` still has the last step's update coming
-        self.owed = None
         self.lr, self.betas, self.eps = lr, betas, eps
         off = 0
         self.slices = []
@@ -57,14 +55,12 @@ class FlatAdam:
         self.grads.zero_()
 
     def step(self, max_grad_norm: float, stop_flag: Optional[torch.Tensor] = None, grad_scale: float = 1.0,
-             kl_slot_target: Optional[float] = None, rotate=None, sq_slice=None, skip_update: bool = False, loss_finish=None,
-             owe_slice=None):
+             kl_slot_target: Optional[float] = None, rotate=None, sq_slice=None, skip_update: bool = False, loss_finish=None):
         """grad_scale = 1/world and kl_slot_target = target_kl for the data-parallel tail.  rotate = (table [rows, len] int64,
         out [len] int64, counter [1] int32): the launch also leaves the next minibatch's row of `table` in `out`.
         sq_slice = (lo, hi, partial fp64 tensor): sum(grad[lo:hi]^2) was left in `partial` by the kernel that produced that
         gradient slice (gnbv_linear_bwd_dw_sq) -- the norm pass skips the slice; `skip_update`: nor is the slice updated here (its
-        update is sharded over the data-parallel ranks: shard_step).  `owe_slice` = (lo, hi): that slice's update is left to a
-        later slice_step_pending() -- this launch records in self.pending whether it is owed.  (include/gennbv_hip.h: GnbvAdamStep)"""
+        update is sharded over the data-parallel ranks: shard_step).  (include/gennbv_hip.h: GnbvAdamStep)"""
         a = _lib.GnbvAdamStep()
         a.params, a.grads, a.exp_avg, a.exp_avg_sq, a.n = (self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
                                                            self.exp_avg_sq.data_ptr(), self.n)
@@ -86,42 +82,9 @@ class FlatAdam:
             a.sq_lo, a.sq_hi, a.sq_partial, a.sq_parts = int(lo), int(hi), part.data_ptr(), int(part.numel())
             if skip_update:
                 a.upd_skip_lo, a.upd_skip_hi = int(lo), int(hi)
-        if owe_slice is not None:
-            assert not skip_update and 0 <= owe_slice[0] < owe_slice[1] <= self.n
-            self.owed = (int(owe_slice[0]), int(owe_slice[1]))
-            a.upd_skip_lo, a.upd_skip_hi = self.owed
-            a.pending = self.pending.data_ptr()
         if loss_finish is not None:  # a GnbvPpoLoss with defer_stats = 1 (PpoLossOp.args): its statistics are finished inside the norm launch
             a.loss_finish = C.addressof(loss_finish)
         _lib.check(self.lib.gnbv_clip_adam_step_ex(C.byref(a), _lib.stream_ptr(self.params.device)), "gnbv_clip_adam_step_ex")
-
-    # ---- the update of one large slice owed to the kernel that next reads that weight (sb3/ppo_grid_obs.py) ----
-    def slice_step_pending(self, owed=None) -> None:
-        """Adam on the slice the last step(owe_slice=...) skipped, iff that step applied its update (self.pending, on the device)."""
-        if owed is not None:
-            self.owed = (int(owed[0]), int(owed[1]))
-        if self.owed is None:
-            return
-        lo, hi = self.owed
-        _lib.check(self.lib.gnbv_adam_slice_pending(self.params[lo:hi].data_ptr(), self.grads[lo:hi].data_ptr(), self.exp_avg[lo:hi].data_ptr(),
-                                                    self.exp_avg_sq[lo:hi].data_ptr(), hi - lo, self.norm_out.data_ptr(), float(self.lr), float(self.betas[0]),
-                                                    float(self.betas[1]), float(self.eps), self.step_count.data_ptr(), self.pending.data_ptr(),
-                                                    _lib.stream_ptr(self.params.device)), "gnbv_adam_slice_pending")
-
-    def owed_adam(self, owed) -> "_lib.GnbvOwedAdam":
-        """The owed slice's update as arguments for the kernel that next streams that weight (gnbv_linear_forward_fold_adam)."""
-        lo, hi = self.owed = (int(owed[0]), int(owed[1]))
-        a = _lib.GnbvOwedAdam()
-        a.grads, a.exp_avg, a.exp_avg_sq = self.grads[lo:hi].data_ptr(), self.exp_avg[lo:hi].data_ptr(), self.exp_avg_sq[lo:hi].data_ptr()
-        a.norm_out, a.step, a.pending = self.norm_out.data_ptr(), self.step_count.data_ptr(), self.pending.data_ptr()
-        a.lr, a.beta1, a.beta2, a.eps = float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps)
-        return a
-
-    def settle_owed_slice(self) -> None:
-        """After the last step(owe_slice=True) of a sequence: apply what is owed, then nothing is."""
-        if self.owed is not None:
-            self.slice_step_pending()
-            self.pending.zero_()
 
     # ---- data-parallel replicas: the update of one large slice sharded over the ranks (gennbv_amd/parallel.py) ----
     def enable_shard(self, lo: int, hi: int, rank: int, world: int) -> bool:

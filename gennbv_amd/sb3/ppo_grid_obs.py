@@ -90,6 +90,9 @@ class PPO_Grid_Obs:
         self.train_impl = "hip"   # fused loss / flat Adam / device-side early stop when the encoder backend is "hip"
         self.use_graph = True     # replay the minibatch step as one hipGraph
         self.grad_write_through = True  # backward kernels store into the flat gradient buffer (ops/direct_grad.py)
+        self.rotate_rows = True   # replayed graph on one GPU: the Adam launch leaves the next minibatch's row numbers behind (no host copy)
+        self.grid_i8_rows = True  # int8 side copy of the grid rows next to flat fp32 rows (what the conv1 kernels of the update read)
+        self.fused_add = True     # time-out bootstrap + the five buffer copies of rollout_buffer.add as one launch (gnbv_rollout_add)
         self.compact_obs = bool(compact_obs)
         # Time-out bootstrap (on_policy_algorithm_grid_obs.py:205-208).  "reference": what the reference computes --
         # `predict_values(new_obs)[0]` is ROW 0 of the [N, 1] values, so every timed-out env is bootstrapped with env 0's
@@ -392,17 +395,6 @@ class PPO_Grid_Obs:
                 parts = int(_lib.load().gnbv_linear_bwd_dw_sq_parts(int(lin.weight.shape[1])))
                 lin._dw_sq_partial = torch.zeros(parts, dtype=torch.float64, device=self.device)
                 self._hip["sq_slice"] = (sl[0], sl[1], lin._dw_sq_partial)
-            # GENNBV_ADAM_FUSE=1 (opt-in; measured SLOWER, profiles/r03_notes.md): its Adam update (392 MB of HBM traffic, ~68 us) is
-            # OWED to the next minibatch's fc_grid forward, the kernel that next streams that weight (FlatAdam.step(owe_slice=...) ->
-            # gnbv_linear_forward_fold_adam; settled by a launch of its own at the end of train()).  One GPU only as well.
-            # GENNBV_ADAM_SIDE=1 (opt-in as well): the same owed update as a launch of its own on the SECOND stream at the head of the next
-            # minibatch, beside k_bn1_analytic + k_conv12_fwd_split (issue-bound, ~3.4 TB/s) instead of in front of them: the update
-            # is a pure HBM stream and the only thing that needs the new weight is fc_grid's forward behind the conv stack.
-            if (self._sync is None or not self._sync.active) and sl is not None and sl[0] % 4 == 0:
-                if os.environ.get("GENNBV_ADAM_FUSE", "0") == "1":
-                    self._hip["owe_fc"], self._hip["owe_mode"] = (sl[0], sl[1]), "fuse"
-                elif os.environ.get("GENNBV_ADAM_SIDE", "0") == "1" and getattr(enc, "overlap_branches", False):
-                    self._hip["owe_fc"], self._hip["owe_mode"] = (sl[0], sl[1]), "side"
         return self._hip
 
     def _hip_minibatch_body(self, st, phase: str = "all"):
@@ -422,17 +414,6 @@ class PPO_Grid_Obs:
                             None if buf.grid_i8 is None else buf.grid_i8[:t].view(t * n, -1), buf.compact_state_dim,
                             None if buf.autocorr is None else buf.autocorr[:t].view(t * n, -1))
             enc = pol.features_extractor
-            if phase == "all" and st.get("owe_fc") is not None:
-                # the previous minibatch's update of fc_grid.weight rides this minibatch's fc_grid forward (encoder_ops.hybrid_branches
-                # -> gnbv_linear_forward_fold_adam); shapes that kernel does not take: as a launch of its own, here
-                lin_ = enc.output_layer_grid[0]
-                p2_ = encoder_ops.conv_out(encoder_ops.conv_out(enc.grid_size)) ** 3
-                if st.get("owe_mode") == "side":  # second stream, joined in front of fc_grid's forward (encoder_ops.hybrid_branches)
-                    enc._fc_owed_side = lambda o=st["owe_fc"]: opt.slice_step_pending(o)
-                elif int(loss.batch) <= 128 and encoder_ops.linear_fold_ok(lin_, int(loss.batch), p2_, getattr(enc, "force_fp32", False)):
-                    enc._fc_owed_adam = opt.owed_adam(st["owe_fc"])
-                else:
-                    opt.slice_step_pending(st["owe_fc"])
             enc._defer_pose_backward = True  # only inside this body: it calls encoder_ops.pose_branch_backward after its backward
             if st.get("fused_head"):
                 fa, fg = encoder_ops.hybrid_branches(enc, obs)
@@ -453,20 +434,12 @@ class PPO_Grid_Obs:
                 torch.autograd.backward([logits, values], [d_logits, d_values])
                 if lin is not None:
                     lin._defer_wgrad = False
-                if os.environ.get("GENNBV_DW_FIRST", "0") == "1":
-                    # OPT-IN: fc_grid's dW GEMM in FRONT of the pose branch's backward on the second stream: it starts behind k_fc_bwd_prep and
-                    # runs beside the dx GEMM / the BatchNorm-2 backward instead of beside the two conv kernels.  Measured (profiles/r03_notes.md):
-                    # nothing by itself; with the late weight-gradient finish (csrc/encoder.hip) 561-566 us per minibatch in some processes,
-                    # 581-589 in others, against a steady 570-576.
-                    encoder_ops.join_async_wgrads(self.device)
-                    encoder_ops.pose_branch_backward(enc, self.device)
-                else:
-                    encoder_ops.pose_branch_backward(enc, self.device)  # (deferred so that the conv chain is captured first: encoder_ops.hybrid_branches)
-                    encoder_ops.join_async_wgrads(self.device)  # fc_grid's dW / db: second stream, beside the conv backward
+                encoder_ops.pose_branch_backward(enc, self.device)  # (deferred so that the conv chain is captured first: encoder_ops.hybrid_branches)
+                encoder_ops.join_async_wgrads(self.device)  # fc_grid's dW / db: second stream, beside the conv backward
                 if self._sync is None or not self._sync.active:
                     sq = st.get("sq_slice") if (lin is not None and getattr(lin, "_dw_sq_written", False)) else None
                     opt.step(self.max_grad_norm, loss.stop_flag, rotate=st.get("rows_rot"), sq_slice=sq,
-                             loss_finish=loss.args if loss.args.defer_stats else None, owe_slice=st.get("owe_fc"))
+                             loss_finish=loss.args if loss.args.defer_stats else None)
                 return
             # the forward cut the graph at the conv-stack output (enc._split_backward): this backward
             # stops at that leaf and fills the gradients of every non-conv parameter
@@ -587,7 +560,7 @@ class PPO_Grid_Obs:
         # Replayed graph on one GPU: the row numbers of ALL minibatches of this call go to a table once, and the Adam launch that ends
         # a minibatch leaves the next one's in `loss.rows` (gnbv_clip_adam_step_rotate) -- no copy and no host work between two
         # replays.  (The table and the counter are baked into the graph: persistent buffers.)
-        rotating = use_graph and not dp and n_mb > 0 and os.environ.get("GENNBV_ROTATE_ROWS", "1") != "0"
+        rotating = use_graph and not dp and n_mb > 0 and self.rotate_rows
         rot = st.get("rows_rot")
         if rotating and (rot is None or tuple(rot[0].shape) != (n_mb, batch + 1 + 384)):
             # a table row = [the minibatch's row numbers | (mean, 1 / (std + 1e-8)) of its advantages | the sum of its input-autocorrelation
@@ -659,9 +632,9 @@ class PPO_Grid_Obs:
                         print(f"Early stopping at step {epoch} due to reaching max kl")
                     break
         finally:
-            opt.settle_owed_slice()  # (the last minibatch's update of fc_grid.weight, owed to a next minibatch that does not come)
+            # (also when the loop raises: the slot holds the LAST minibatch's total -- never for another caller's training-mode forward)
+            self.policy.features_extractor._autocorr_total = None
         self._n_updates += self.n_epochs
-        self.policy.features_extractor._autocorr_total = None  # (the slot holds the LAST minibatch's total: never for another caller)
         self._check_ranges()  # raises if a kernel of this call reached an activation bound of the split-f16 arithmetic
         rows_done = int(loss.stats_row.item())
         s = loss.stats[:rows_done].double().cpu().numpy()
@@ -765,7 +738,7 @@ class PPO_Grid_Obs:
         conv1 kernels of the update): on when the env offers it, the encoder runs on the gfx950 kernels and G % 16 == 0."""
         enc = self.policy.features_extractor
         g = getattr(enc, "grid_size", 0)
-        if (os.environ.get("GENNBV_GRID_I8", "1") != "0" and getattr(self.env, "supports_grid_i8", False)
+        if (self.grid_i8_rows and getattr(self.env, "supports_grid_i8", False)
                 and getattr(enc, "backend", "") == "hip" and g % 16 == 0 and self.rollout_buffer.grid_i8 is None):
             self.rollout_buffer.enable_grid_i8(g ** 3)
 
@@ -791,7 +764,7 @@ class PPO_Grid_Obs:
                 and hasattr(self.policy.action_dist, "sample_and_log_prob")
                 and encoder_ops.policy_head_supported(enc, self.policy.action_net, self.policy.value_net))
         fused_add = (self.device.type == "cuda" and getattr(self.policy, "_fused_rollout", False)
-                     and os.environ.get("GENNBV_FUSED_ADD", "1") != "0")
+                     and self.fused_add)
         n_steps = 0
         self._check_ranges()
         rollout_buffer.reset()

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNBV_ABI_VERSION 3
+#define GNBV_ABI_VERSION 4
 
 int gnbv_abi_version(void);
 /* Name of the device architecture the library was compiled for ("gfx950"). [host] */
@@ -244,7 +244,6 @@ typedef struct GnbvEncoderParams {
     float *bn2_rm, *bn2_rv;
     int64_t *bn2_nbt;
     float eps, momentum;          /* 1e-5, 0.1 (torch.nn.BatchNorm3d defaults) */
-    int act_bf16;                 /* 0: y1 / dz1 scratch are fp32; 1: bf16 storage (math stays fp32) */
     const int8_t *grid_i8;        /* NULL, or an int8 copy of the grid slices (values -1/0/1, as written by
                                      gnbv_update_occ_grid_coded): sample b reads grid_i8 + (rows ? rows[b] : b) *
                                      grid_i8_row_stride bytes instead of obs_grid (a quarter of the input traffic);
@@ -298,7 +297,7 @@ int gnbv_input_autocorr(const int8_t *grid_i8, int64_t grid_i8_row_stride, int n
                         void *stream);
 
 size_t gnbv_encoder_workspace_bytes(int batch, int grid);
-/* number of ELEMENTS (fp32 or bf16, GnbvEncoderParams.act_bf16) of the layer-1 activation buffers (y1, dz1_scratch) */
+/* number of fp32 ELEMENTS of the layer-1 activation buffers (y1, dz1_scratch) */
 size_t gnbv_encoder_y1_elems(int batch, int grid);
 
 /* obs_grid: pointer to the grid slice of row 0 of an observation matrix (NULL with params->grid_i8 set: compact
@@ -373,22 +372,6 @@ int gnbv_linear_forward_fold(const float *y, const float *scale, const float *sh
 int gnbv_linear_bwd_dw_fold(const void *workspace, const float *y, const float *scale, const float *shift, int P, int M, int N, int K, float *dw,
                             double *sq_partial /*NULL: none*/, void *stream);
 
-/* ... and with the layer's OWED optimizer update applied on the way (round 3): the previous step's gnbv_clip_adam_step_ex skipped this
- * weight (GnbvAdamStep.upd_skip_lo / hi = its slice of the flat buffers, .pending) and the forward that next reads the weight applies
- * clip + Adam to every element as it streams it -- each element is staged by exactly one thread of the launch (M <= 128) --, writes
- * weight / exp_avg / exp_avg_sq back and multiplies with the NEW weight.  Same expressions as the optimizer launch: bit-identical
- * parameters and moments; the update's 28 bytes per parameter ride the product's weight stream instead of a launch of their own
- * (~65 us at 13.8 M parameters) in front of it.  Nothing happens to the weight when *pending == 0 (first minibatch of a train() call,
- * update masked by the KL stop).  The pointers are the SLICE's (flat buffer + slice offset); norm_out / step / pending as left by the
- * owing gnbv_clip_adam_step_ex.  After the last minibatch: gnbv_adam_slice_pending. */
-typedef struct GnbvOwedAdam {
-    const float *grads; float *exp_avg, *exp_avg_sq;
-    const float *norm_out; const int64_t *step; const int *pending;
-    float lr, beta1, beta2, eps;
-} GnbvOwedAdam;
-int gnbv_linear_forward_fold_adam(const float *y, const float *scale, const float *shift, int P, int *range_flag, float *w, const float *bias,
-                                  int M, int N, int K, int relu, float *out, void *workspace, size_t workspace_bytes,
-                                  const GnbvOwedAdam *adam /*[host]*/, void *stream);
 
 /* B1  pose-history input (gennbv/network/hybrid_encoder.py:63-74 positional_encoding with 2 frequency bands, :78-80): the state
  *     columns [0, 6 n_pose) of observation rows `rows` (NULL: rows 0 .. batch-1) of `base` (row stride in floats) ->
@@ -535,17 +518,9 @@ typedef struct GnbvAdamStep {
                                            step counter) -- same stop_flag as this call's */
     int64_t upd_skip_lo, upd_skip_hi;   /* parameters [upd_skip_lo, upd_skip_hi) are NOT updated by this call (their gradient still
                                            counts for the norm through sq_partial): a slice whose update is sharded over the
-                                           data-parallel replicas, gnbv_adam_shard_step -- or owed to a later launch, `pending` */
-    int *pending;                       /* NULL, or [device] <- 1 when this call applied its update (the skipped slice is then owed to
-                                           gnbv_adam_slice_pending), 0 when the update was masked by stop_flag */
+                                           data-parallel replicas, gnbv_adam_shard_step */
 } GnbvAdamStep;
 int gnbv_clip_adam_step_ex(const GnbvAdamStep *a /*[host]*/, void *stream);
-/* The update of a slice the step's main call skipped (upd_skip_lo / hi + pending), as a launch of its own: after the LAST minibatch of
- * a train() call (inside the call the next minibatch's fc_grid forward applies it on the way: gnbv_linear_forward_fold_adam).  Runs
- * iff *pending != 0, with the clip factor norm_out[1] and the step counter the owing call left; the caller clears *pending
- * afterwards.  Bit-identical to the update gnbv_clip_adam_step_ex would have applied. */
-int gnbv_adam_slice_pending(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const float *norm_out,
-                            float lr, float beta1, float beta2, float eps, const int64_t *step, const int *pending, void *stream);
 /* Adam on a shard of n parameters with the clip factor norm_out[1] that gnbv_clip_adam_step_ex of the SAME optimizer step left
  * behind (same step counter and stop flag, neither is modified). */
 int gnbv_adam_shard_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const float *norm_out,

@@ -100,23 +100,13 @@ def test_encoder_forward_backward_vs_torch_reference(g, b, conv2, monkeypatch):
     assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-6
 
 
-@pytest.mark.parametrize("z1", ["0", "1", "qm", "fp32", "dual", "late"])  # "late": GENNBV_LATE_WGRAD_FINISH=1, both weight-gradient reductions / finishes as two launches behind the data gradient (opt-in); "dual": GENNBV_BWD_DUAL=1, the two split backward kernels as ONE launch (opt-in; "0" runs them separately); "qm": y1 stored quad-major (GENNBV_Y1_QM=1, opt-in layout of the same path); "fp32": GENNBV_CONV_SPLIT=0, the fp32-MFMA conv2 kernels ("0" runs the split-f16 ones at G = 64)
+@pytest.mark.parametrize("z1", ["0", "fp32"])  # "fp32": GENNBV_CONV_SPLIT=0, the fp32-MFMA conv2 kernels ("0" runs the split-f16 ones at G = 64)
 @pytest.mark.parametrize("g,b", [(16, 5), (32, 3), (48, 2), (64, 4), (128, 1), (64, 128)])  # last: the bench's minibatch
 def test_fused_dgrad_conv1_wgrad_vs_fp64_reference(g, b, z1, monkeypatch):
     """With the int8 grid rows present (G % 16 == 0) the backward runs k_conv2_dgrad_c1w: conv2 data gradient and conv1
     weight gradient in one launch, BN1 backward applied to fp64 sums afterwards (dz1' is never stored).  All conv / BN
-    gradients against the fp64 torch reference, tolerance = fp32 round-off; rows are gathered (RowGather).
-    z1 = "1" (opt-in GENNBV_Z1): BN1 batch statistics analytically from the input autocorrelation, conv1 stores
-    relu(bn1(y1)) (G <= 64; G = 128 keeps the y1 layout)."""
-    if b > 64 and z1 == "1":
-        pytest.skip("the full-minibatch case runs on the default and quad-major kernel sets")
-    monkeypatch.setenv("GENNBV_Z1", "1" if z1 == "1" else "0")
-    monkeypatch.setenv("GENNBV_Y1_QM", "1" if z1 == "qm" else "0")
+    gradients against the fp64 torch reference, tolerance = fp32 round-off; rows are gathered (RowGather)."""
     monkeypatch.setenv("GENNBV_CONV_SPLIT", "0" if z1 == "fp32" else "1")
-    monkeypatch.setenv("GENNBV_BWD_DUAL", "1" if z1 == "dual" else "0")
-    monkeypatch.setenv("GENNBV_LATE_WGRAD_FINISH", "1" if z1 == "late" else "0")
-    if z1 in ("dual", "late") and g != 64:
-        pytest.skip("only G = 64 has the split kernels the dual launch combines / the late finish follows")
     # The comparison "analytic vs measured BN1 statistics" below needs bit-identical y1 in both runs: the split conv1 kernel only
     # runs where no partial sums are asked for (the analytic run), the fp32 one in the measured run, and two of the 61 M layer-1
     # pre-activations of the (64, 128) case sit within 2e-8 of the ReLU threshold -- a flipped mask moves the bias gradient, a sum
@@ -241,32 +231,11 @@ def test_row_gather_equals_materialised_batch():
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("g,b", [(20, 8), (64, 4)])
-def test_bf16_activation_storage_within_bf16_tolerance(g, b):
-    """compute_dtype=bfloat16 (EXPERIMENTAL, opt-in) stores the layer-1 activations (y1, dz1) in bf16,
-    math stays fp32: forward within 2e-3 of the fp64 reference.  Gradient accuracy in this mode is poor on small
-    batches (BatchNorm backward subtracts batch means from bf16-rounded values, ReLU masks flip near
-    zero) while the speed-up is only ~10 % of the conv time -- the kernels are instruction-bound,
-    not bandwidth-bound (profiles/r01_notes.md) -- so fp32 storage is the default and the only
-    mode bench.py measures."""
-    hip, _, _ = pu.make_policy(g=g, device=DEV, backend="hip", det_weights=True, compute_dtype=torch.bfloat16)
-    ref, _, _ = pu.make_policy(g=g, device="cpu", backend="torch", det_weights=True)
-    ref = ref.double()
-    ref.extract_features = lambda x: ref.features_extractor(x)
-    obs = _obs_clear_of_the_relu_threshold(ref, b, g)
-    actions = torch.stack([torch.randint(0, n, (b,)) for n in pu.NVEC], -1).float()
-    w = torch.linspace(0.5, 1.5, b)
-    outs = []
-    for pol, dev, dt in ((ref, "cpu", torch.float64), (hip, DEV, torch.float32)):
-        pol.set_training_mode(True)
-        pol.zero_grad()
-        values, log_prob, entropy = pol.evaluate_actions(obs.to(dev, dt), actions.to(dev))
-        ww = w.to(dev, dt)
-        ((values.flatten() * ww).sum() + (log_prob * ww.flip(0)).sum() + 0.3 * (entropy * ww).sum()).backward()
-        outs.append([t.detach().double().cpu() for t in (values, log_prob, entropy)])
-    for x, y in zip(*outs):
-        assert float((x - y).abs().max()) <= 2e-3 * float(x.abs().max()) + 1e-4
-    # gradients are NOT asserted in this mode: see the docstring (fp32 storage is the supported path)
+def test_reduced_precision_storage_is_refused():
+    """The bf16 activation-storage mode of rounds 1-3 was removed (slower than the fp32-accurate split-f16 kernels, 1e-3-class loss
+    deltas: DESIGN.md section 5): asking for it fails loudly instead of silently computing in another precision."""
+    with pytest.raises(ValueError, match="fp32"):
+        pu.make_policy(g=20, device=DEV, backend="hip", det_weights=True, compute_dtype=torch.bfloat16)
 
 
 @pytest.mark.parametrize("arith", ["split", "fp32"])
@@ -564,16 +533,16 @@ def test_semantic_branch_forward_backward_vs_fp64(g, b):
 @pytest.mark.parametrize("g,b,train", [(64, 4, True), (64, 128, True), (64, 37, False), (128, 1, True)])
 def test_bn2_relu_folded_into_fc_grid_is_bit_identical(g, b, train, monkeypatch):
     """Round 3: fc_grid's kernels form relu(bn2(y2)) in their operand loads (gnbv_linear_forward_fold / gnbv_linear_bwd_dw_fold)
-    instead of reading a materialised feature tensor (GENNBV_FC_FOLD=0: k_bn_relu_apply + the plain entry points).  Same fp32
+    instead of reading a materialised feature tensor (`lin._no_fold`: k_bn_relu_apply + the plain entry points).  Same fp32
     fma + max, same split-f16 product: every output and every gradient must be IDENTICAL, bit for bit.  (One exception: batches the
     hand-written backward does not take -- M % 16 != 0 -- form the activations in torch for the library GEMM, a multiply and an add
     instead of one fma: fc_grid's weight gradient then agrees to an ulp of its operands.)"""
     from gennbv_amd.ops import encoder_ops as eo
     outs = []
     for fold in ("1", "0"):
-        monkeypatch.setenv("GENNBV_FC_FOLD", fold)
         hip, _, _ = pu.make_policy(g=g, device=DEV, backend="hip", det_weights=True)
         enc = hip.features_extractor
+        enc.output_layer_grid[0]._no_fold = fold == "0"
         assert eo.linear_fold_ok(enc.output_layer_grid[0], b, eo.conv_out(eo.conv_out(g)) ** 3, False) == (fold == "1")
         obs = _obs(b, g, seed=5)
         hip.set_training_mode(train)
@@ -595,57 +564,3 @@ def test_bn2_relu_folded_into_fc_grid_is_bit_identical(g, b, train, monkeypatch)
             assert float((a - r).abs().max()) <= 2e-7 * float(r.abs().max()), n
         else:
             assert torch.equal(a, r), n
-
-
-@pytest.mark.parametrize("m,pending", [(128, 1), (128, 0), (48, 1)])
-def test_fc_grid_forward_applies_the_owed_adam_update_bit_identically(m, pending):
-    """gnbv_linear_forward_fold_adam == gnbv_adam_slice_pending followed by gnbv_linear_forward_fold: the same parameters, moments and
-    outputs, bit for bit (each weight element is updated by the one thread that stages it); *pending == 0: nothing moves."""
-    import ctypes as C
-    from gennbv_amd import _lib
-    lib = _lib.load()
-    n, ch, p = 256, 16, 3375
-    k = ch * p
-    gen = torch.Generator(device=DEV).manual_seed(7 + m)
-    rnd = lambda *s: torch.randn(*s, generator=gen, device=DEV)  # noqa: E731
-    y = rnd(m, k)
-    bn_state = torch.zeros(896, device=DEV)
-    bn_state[64:80] = torch.rand(16, generator=gen, device=DEV) + 0.5
-    bn_state[80:96] = rnd(16) * 0.3
-    w0, bias = rnd(n, k) * 0.01, rnd(n) * 0.1
-    g0, m0, v0 = rnd(n, k) * 1e-3, rnd(n, k) * 1e-4, torch.rand(n, k, generator=gen, device=DEV) * 1e-6
-    norm_out = torch.tensor([3.0, 0.1666], device=DEV)
-    step = torch.tensor([5], dtype=torch.int64, device=DEV)
-    pend = torch.tensor([pending], dtype=torch.int32, device=DEV)
-    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
-    ws = torch.empty(lib.gnbv_linear_workspace_bytes(m, n, k), dtype=torch.uint8, device=DEV)
-    sc = bn_state.data_ptr() + 4 * 64
-    hyper = (3e-4, 0.9, 0.999, 1e-5)
-    res = []
-    for fused in (False, True):
-        w, mm, vv = w0.clone(), m0.clone(), v0.clone()
-        out = torch.empty(m, n, device=DEV)
-        if fused:
-            a = _lib.GnbvOwedAdam()
-            a.grads, a.exp_avg, a.exp_avg_sq = g0.data_ptr(), mm.data_ptr(), vv.data_ptr()
-            a.norm_out, a.step, a.pending = norm_out.data_ptr(), step.data_ptr(), pend.data_ptr()
-            a.lr, a.beta1, a.beta2, a.eps = hyper
-            _lib.check(lib.gnbv_linear_forward_fold_adam(y.data_ptr(), sc, sc + 64, p, flag.data_ptr(), w.data_ptr(), bias.data_ptr(), m, n, k, 1, out.data_ptr(),
-                                                         ws.data_ptr(), ws.numel(), C.byref(a), None), "fold_adam")
-        else:
-            _lib.check(lib.gnbv_adam_slice_pending(w.data_ptr(), g0.data_ptr(), mm.data_ptr(), vv.data_ptr(), n * k, norm_out.data_ptr(), *hyper,
-                                                   step.data_ptr(), pend.data_ptr(), None), "slice_pending")
-            _lib.check(lib.gnbv_linear_forward_fold(y.data_ptr(), sc, sc + 64, p, flag.data_ptr(), w.data_ptr(), bias.data_ptr(), m, n, k, 1, out.data_ptr(),
-                                                    ws.data_ptr(), ws.numel(), None), "fold")
-        torch.cuda.synchronize()
-        res.append((w, mm, vv, out))
-    for name, a_, b_ in zip(("weight", "exp_avg", "exp_avg_sq", "out"), *res):
-        assert torch.equal(a_, b_), name
-    assert torch.equal(res[0][0], w0) == (pending == 0)
-    # and the update itself is torch.optim.Adam's (clip factor applied to the gradient first)
-    if pending:
-        gi = g0.double() * float(norm_out[1])
-        m_ref = m0.double() + (gi - m0.double()) * (1 - 0.9)
-        v_ref = v0.double() * 0.999 + (1 - 0.999) * gi * gi
-        p_ref = w0.double() - (3e-4 / (1 - 0.9 ** 5)) * m_ref / (v_ref.sqrt() / (1 - 0.999 ** 5) ** 0.5 + 1e-5)
-        assert float((res[1][0].double() - p_ref).abs().max()) < 1e-7

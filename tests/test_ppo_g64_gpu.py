@@ -157,34 +157,18 @@ def _compare(hip, ref, n_steps_expected):
     return worst
 
 
-def _adam_mode(monkeypatch, adam):
-    """Where fc_grid.weight's Adam update runs: "own" (default) = inside the optimizer launch of its own minibatch; "side"
-    (GENNBV_ADAM_SIDE=1) = owed to the next minibatch, a launch of its own on the second stream beside that minibatch's conv forward;
-    "fuse" (GENNBV_ADAM_FUSE=1) = owed to the next minibatch's fc_grid forward kernel (gnbv_linear_forward_fold_adam).  Owed updates
-    are settled after the last minibatch.  (Both opt-ins were measured slower than the default: profiles/r03_notes.md.)"""
-    monkeypatch.setenv("GENNBV_DW_FIRST", "1" if adam == "fuse" else "0")  # (the opt-in order of the second stream's backward, with the late
-    monkeypatch.setenv("GENNBV_LATE_WGRAD_FINISH", "1" if adam == "fuse" else "0")  # weight-gradient finish, rides one variant)
-    monkeypatch.setenv("GENNBV_ADAM_FUSE", "1" if adam == "fuse" else "0")
-    monkeypatch.setenv("GENNBV_ADAM_SIDE", "1" if adam == "side" else "0")
-
-
-@pytest.mark.parametrize("graph,adam", [(True, "side"), (False, "side"), (True, "own"), (False, "own"), (True, "fuse"), (False, "fuse")])
-def test_train_g64_b128_matches_fp64_oracle(rec, oracle_full, graph, adam, monkeypatch):
-    _adam_mode(monkeypatch, adam)
+@pytest.mark.parametrize("graph", [True, False])
+def test_train_g64_b128_matches_fp64_oracle(rec, oracle_full, graph):
     n_mb = N_ENVS * T // BATCH
     hip = _fresh_hip(rec, None, graph)
     hip.train()
-    assert (hip._hip.get("owe_fc") is not None) == (adam != "own") and int(hip._hip["opt"].pending.item()) == 0
-    assert hip._hip.get("owe_mode") == (None if adam == "own" else adam)
     assert hip.rollout_buffer.compact_state_dim is not None and hip.rollout_buffer.autocorr is not None  # the bench's row layout
     _compare(hip, oracle_full, EPOCHS * n_mb)
 
 
-@pytest.mark.parametrize("adam", ["side", "own"])  # ("fuse": test_train_g64_b128_matches_fp64_oracle and test_encoder_gpu.py cover its kernel)
-def test_train_g64_b128_early_stop_position(rec, oracle_full, adam, monkeypatch):
+def test_train_g64_b128_early_stop_position(rec, oracle_full):
     """target_kl chosen between two consecutive running maxima of the oracle's KL trace: both sides must stop at the
     same minibatch (ppo_grid_obs.py:261-268: the step that trips the test is evaluated but not applied)."""
-    _adam_mode(monkeypatch, adam)
     kl = oracle_full.last_train_stats[:, 3]
     j = next((i for i in range(6, len(kl)) if kl[i] > 1.25 * kl[:i].max() + 1e-6), None)
     if j is None:

@@ -34,11 +34,11 @@ def _force_actions(algo, fx):
 
 @pytest.mark.parametrize("fused_add", ["1", "0"])
 def test_hip_rollout_reproduces_reference_collect_rollouts(fused_add, monkeypatch):
-    monkeypatch.setenv("GENNBV_FUSED_ADD", fused_add)
     fx = gu.load("F11_rollout")
     env, cfg = make_env_from_fixture(fx)
     t, n = int(fx["T"]), int(fx["n"])
     algo = ru.make_algo(env, DEV, "hip", t)
+    algo.fused_add = fused_add == "1"
     algo._setup_learn(total_timesteps=10 ** 9)  # env.reset() into buffer row 0 (frame 0), episode starts = 1
     reset_rows = ru.unpack_rows(fx["reset_state"], fx["reset_grid"], fx["reset_rgb"])
     assert np.array_equal(algo._last_obs.cpu().numpy(), reset_rows)

@@ -12,10 +12,9 @@ ap.add_argument("--backend", default="torch")
 ap.add_argument("--autocast", action="store_true")
 ap.add_argument("--channels-last", action="store_true")
 ap.add_argument("--fwd-only", action="store_true")
-ap.add_argument("--bf16-act", action="store_true")
 a = ap.parse_args()
 dev = "cuda:0"
-pol, _, _ = pu.make_policy(g=a.g, device=dev, backend=a.backend, det_weights=False, **({"compute_dtype": torch.bfloat16} if a.bf16_act else {}))
+pol, _, _ = pu.make_policy(g=a.g, device=dev, backend=a.backend, det_weights=False)
 if a.channels_last:
     pol = pol.to(memory_format=torch.channels_last_3d)
 d = pu.obs_dim(a.g)
