@@ -58,6 +58,9 @@ def parse():
 
 def build_algo(args, device, rank, world):
     import torch
+    if args.grid % 16 != 0 and args.obs == "compact":
+        # (the int8 grid rows / compact observations need G % 16 == 0; the reference's own default grid, 20^3, runs on flat fp32 rows)
+        args.obs = "flat"
     from gennbv_amd.env import synthetic as S
     from gennbv_amd.env.config import TaskConfig, PPOConfig
     from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
@@ -252,7 +255,7 @@ def ppo_loss_delta(args, device):
     return out
 
 
-def encoder_roofline(algo, args, device, iters: int = 20):
+def encoder_roofline(algo, args, device, iters: int = 200, warm_ms: float = 150.0):
     """Second roofline object: the conv stack of the PPO update (conv1/conv2 forward + backward through the C-ABI,
     csrc/encoder.hip) at the minibatch size, timed live with events on the launch stream, priced against BOTH roofs:
     fp32 MFMA (157 TFLOP/s dense) and HBM (8 TB/s).  Algorithmic figures per minibatch of B samples at grid G
@@ -261,7 +264,13 @@ def encoder_roofline(algo, args, device, iters: int = 20):
     [+ dz1 (W, R) on the unfused fallback, which the benchmarked configuration -- int8 rows, G % 16 == 0 -- never takes].
     Since round 2 the conv2 contractions run on the f16 matrix pipe with operands split into two f16 halves (fp32-accurate
     products, fp32 accumulation; csrc/conv_split.h): the stack is HBM-bound, `bound` says so, and the MFMA figure stays the
-    ALGORITHMIC fp32 flop rate against the fp32 peak (what an fp32 implementation would need)."""
+    ALGORITHMIC fp32 flop rate against the fp32 peak (what an fp32 implementation would need).
+
+    Measurement protocol (round 4; BENCH_r03 carried 4.57 ms here against 0.386 in the builder's own run of the same command): this
+    runs right after `timed_state_check`, i.e. after SECONDS of CPU-side oracle replay with the GPU idle, and 3 + 20 iterations of a
+    0.4 ms step (9 ms in all) ended before the device had left its idle power state.  Now: >= `warm_ms` of GPU-busy warm-up, `iters`
+    iterations timed ONE BY ONE with events, `ms` = the median, the spread reported, and `unstable: true` when max / min of the middle
+    80 % exceeds 1.5 (the figure must not be quoted then)."""
     import torch
     from gennbv_amd.ops import encoder_ops
     enc = algo.policy.features_extractor
@@ -290,16 +299,7 @@ def encoder_roofline(algo, args, device, iters: int = 20):
         f = encoder_ops.grid_encoder(base, rows, s_dim, g, seq, True, grid_i8=gi8, compact=buf.compact_state_dim is not None, autocorr=ac)
         f.backward(torch.ones_like(f))
 
-    for _ in range(3):
-        step()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        step()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    ms, spread = _timed_median(step, iters, warm_ms)
     for m, (rm, rv, nb) in zip((seq[1], seq[4]), stats):  # leave the policy exactly as it was
         m.running_mean.copy_(rm); m.running_var.copy_(rv); m.num_batches_tracked.copy_(nb)
     for p_, g_ in zip(seq.parameters(), grads):
@@ -324,12 +324,68 @@ def encoder_roofline(algo, args, device, iters: int = 20):
                       " + BN / reduction launches)",
             "bound": "hbm" if split else "mfma",
             "note": ("the split kernels stream at 3-4.5 TB/s each but are NOT byte-bound: letting the two backward kernels share y1 through L2 "
-                     "(GENNBV_BWD_DUAL=1) removed 184 MB of HBM reads per minibatch and no time (profiles/r03_notes.md); both roofs are context")
+                     "removed 184 MB of HBM reads per minibatch and no time (round-3 experiment, profiles/r03_notes.md); both roofs are context")
                     if split else None,
-            "ms": ms, "batch": b, "grid_input": "fp32 rows" if gi8 is None else "int8 copy", "algorithmic_flops": flops,
+            "ms": ms, "ms_spread": spread, "unstable": spread["unstable"], "batch": b, "grid_input": "fp32 rows" if gi8 is None else "int8 copy", "algorithmic_flops": flops,
             "algorithmic_bytes": nbytes,
             "mfma": {"achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "dtype": "f32"},
             "hbm": {"achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0}}
+
+
+def _timed_median(step, iters: int, warm_ms: float):
+    """`step()` timed one call at a time with events on the current stream after >= warm_ms of the same work; (median ms, spread)."""
+    import torch
+    t0 = time.perf_counter()
+    n_warm = 0
+    while True:
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
+        n_warm += 8
+        if (time.perf_counter() - t0) * 1e3 >= warm_ms and n_warm >= 16:
+            break
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    ev[0].record()
+    for i in range(iters):
+        step()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    d = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(iters))
+    lo, hi = d[iters // 10], d[iters - 1 - iters // 10]
+    med = d[iters // 2]
+    return med, {"iters": iters, "warmup_iters": n_warm, "min": d[0], "p10": lo, "median": med, "p90": hi, "max": d[-1], "mean": sum(d) / iters,
+                 "unstable": bool(hi > 1.5 * lo)}
+
+
+def train_roofline(algo, args, train_ms_per_step: float):
+    """Third roofline object: ONE WHOLE PPO MINIBATCH (the unit the step is made of: 1280 of them per iteration at configs[1]) priced on
+    its compulsory HBM bytes: the conv stack's streams (x R fwd + R bwd, y1 W + 2 R, eight y2-sized tensors),
+    fc_grid's weight three times (W read by the forward and by the dx product, dW written), and the optimizer's 28 bytes per parameter
+    (p R+W, g R, m R+W, v R+W).  achieved = those bytes / (train phase of a timed iteration / minibatches in it) -- measured on the timed
+    region itself, hipGraph replay, both streams, every small kernel included; peak = 8 TB/s."""
+    enc = algo.policy.features_extractor
+    if getattr(enc, "backend", "") != "hip":
+        return None
+    b, g = args.batch_size, args.grid
+    o1 = (g - 3) // 2 + 1
+    o2 = (o1 - 3) // 2 + 1
+    n_mb = args.n_epochs * (args.n_steps * args.envs // b)
+    if getattr(algo, "last_train_stats", None) is not None:
+        n_mb = int(len(algo.last_train_stats))  # (what the last timed iteration ran: all of them unless --target-kl ref stopped it)
+    compact = algo.rollout_buffer.grid_i8 is not None
+    x = b * g ** 3 * (1 if compact else 4)
+    y1, y2 = b * o1 ** 3 * 16 * 4, b * o2 ** 3 * 16 * 4
+    conv = 2 * x + 3 * y1 + 8 * y2
+    n_par = sum(p.numel() for p in algo.policy.parameters() if p.requires_grad)
+    fc = 3 * 4 * enc.output_layer_grid[0].weight.numel()
+    adam = 28 * n_par
+    total = conv + fc + adam
+    ms = train_ms_per_step / max(n_mb, 1)
+    gbs = total / (ms * 1e-3) / 1e9
+    return {"kernel": "one PPO minibatch of the timed train() phase (captured hipGraph: forward, loss, backward, clip + Adam; both streams)",
+            "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "ms_per_minibatch": ms, "minibatches_per_step": n_mb,
+            "algorithmic_bytes": total, "bytes": {"conv_stack": conv, "fc_grid_weight_x3": fc, "adam_28B_per_param": adam}, "parameters": n_par,
+            "note": "y1 counted W + 2 R (one-launch training forward); bytes are compulsory traffic, not PMC traffic"}
 
 
 def flat_rows_line(args, device, steps: int = 2):
@@ -357,6 +413,14 @@ def flat_rows_line(args, device, steps: int = 2):
             "obs_rows": "flat fp32 rows (the reference's layout, buffers.py:655-669)",
             "breakdown_ms_per_step": {"rollout": ph["rollout"].total_ms() / steps, "train": ph["train"].total_ms() / steps},
             "hbm_peak_allocated_gb": torch.cuda.max_memory_allocated(device) / 1e9}
+
+
+def _workload_name(args) -> str:
+    key = (args.envs, args.height, args.width, args.grid, bool(args.semantic))
+    return {(256, 240, 320, 64, False): "BASELINE configs[1]", (256, 240, 320, 64, True): "BASELINE configs[2]",
+            (512, 240, 320, 128, False): "BASELINE configs[4]'s per-GPU shard",
+            (256, 400, 400, 20, False): "the reference's own default workload (train_gennbv.py:19-93, config_gennbv_train.py:24-25: 400x400 depth, 20^3 grid, pose history 100)",
+            }.get(key, "custom workload")
 
 
 def _flush_c_stdio():
@@ -493,7 +557,7 @@ def main():
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: {args.envs} envs/GPU x {args.height}x{args.width} depth x "
+        "config": {"workload": f"{_workload_name(args)}: {args.envs} envs/GPU x {args.height}x{args.width} depth x "
                                f"{args.grid}^3 grid, n_steps={args.n_steps}, batch_size={args.batch_size}, "
                                f"n_epochs={args.n_epochs}, one step = one PPO iteration",
                    "global_envs": world * args.envs, "encoder_backend": args.backend, "obs_rows": args.obs,
@@ -534,6 +598,10 @@ def main():
         except Exception as ex:
             out["timed_state_check"] = "error: " + repr(ex)
     if rank == 0:
+        try:
+            out["train_roofline"] = train_roofline(algo, args, phases["train"].total_ms() / args.steps)
+        except Exception as ex:
+            out["train_roofline"] = {"error": repr(ex)}
         try:
             out["encoder_roofline"] = encoder_roofline(algo, args, device)
         except Exception as ex:

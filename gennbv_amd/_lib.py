@@ -146,26 +146,42 @@ class GennbvHipError(RuntimeError):
 
 
 _lib = None
+_loaded = {}
 
 
-def load():
-    """dlopen the HIP library and bind every C-ABI symbol.  Raises if it is absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _open(path: str):
+    if path in _loaded:
+        return _loaded[path]
+    if not os.path.exists(path):
         raise GennbvHipError(
-            f"{LIB_PATH} is missing: build it with `python -m gennbv_amd.csrc.build` "
+            f"{path} is missing: build it with `python -m gennbv_amd.csrc.build` "
             "(or __graft_entry__.build()).  gennbv_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
     if lib.gnbv_abi_version() != 4:
         raise GennbvHipError("libgennbv_hip.so ABI version mismatch")
-    _lib = lib
+    _loaded[path] = lib
     return lib
+
+
+def load():
+    """dlopen the HIP library and bind every C-ABI symbol.  Raises if it is absent."""
+    global _lib
+    if _lib is None:
+        _lib = _open(LIB_PATH)
+    return _lib
+
+
+def activate(path=None):
+    """A/B tooling only (tools/ab_interleaved.py): make `path` (default: the in-tree library) the library load() returns from now on.
+    Two builds can live in one process -- kernels are bound when a call / a hipGraph capture is made, so objects built and graphs
+    captured while a library was active keep running its kernels."""
+    global _lib
+    _lib = _open(os.path.abspath(path) if path else LIB_PATH)
+    return _lib
 
 
 def check(err: int, what: str):

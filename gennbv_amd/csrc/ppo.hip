@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_grad_sqnorm(const float *__restrict__ g
         if (!(stop_flag != nullptr && *stop_flag != 0)) *step += 1;
     }
     double acc = 0.0;
-    const bool vec = (((uintptr_t)g & 15) == 0) && (lo & 3) == 0 && (gap & 3) == 0;
+    const bool vec = (((uintptr_t)g & 15) == 0) && (gap == 0 || ((lo & 3) == 0 && (gap & 3) == 0));  // (no gap: `lo` = n marks nothing and need not be aligned)
     const int64_t n4 = vec ? n_eff / 4 : 0, lo4 = lo / 4, gap4 = gap / 4;
     const int64_t stride = (int64_t)nblocks * 256;
     for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride) {

@@ -120,14 +120,17 @@ class Hybrid_Encoder(nn.Module):
     # worth of Adam steps (|delta w| <= lr per step) and for batch statistics that differ from the running ones.
     W2_LIMIT, W_FC_LIMIT, Z1_LIMIT = 62.0, 15.5, 126.0
 
-    def check_operand_ranges(self) -> dict:
+    def check_operand_ranges(self, raise_on_flag: bool = True) -> dict:
         """Make the range limits of the split-f16 kernels LOUD instead of silent.  Two parts, one host read each:
 
         * parameter pre-check: max |W2| (limit 63.4), max |W| of fc_grid and the pose linears (15.8), and BatchNorm-1's activation
           bound |scale| sum|W1| + |scale b1 + shift| from the RUNNING statistics (clamp at 253.9, checked at half of it).  A
           violation switches this encoder to the fp32-MFMA kernels (`force_fp32`; exact, slower) -- nothing was computed yet;
-        * activation flags the kernels raised since the last call (BatchNorm-1 bound from the BATCH statistics, features above
-          1000): the calls in between may have clamped -> `force_fp32` is set for what follows and GennbvHipError is raised.
+        * activation flags the kernels raised since the last call (bit 2: BatchNorm-1's worst-case bound from the BATCH statistics -- a
+          CONSERVATIVE bound: a minibatch of near-constant grids has a tiny variance, hence a large scale, with nothing near the clamp;
+          bit 4: a feature above 1000, from the real values): the calls in between MAY have clamped -> `force_fp32` is set for what
+          follows and, with `raise_on_flag`, GennbvHipError is raised.  `raise_on_flag=False` returns the flag in `info["flag"]` for a
+          caller that can repeat the work on the fp32 kernels (PPO_Grid_Obs.train() snapshots its state and replays the call).
 
         Called by PPO_Grid_Obs at the start and end of train() and collect_rollouts(); cheap (a few reductions, 2 reads)."""
         from .. import _lib
@@ -159,6 +162,7 @@ class Hybrid_Encoder(nn.Module):
             info["force_fp32"] = True
         if flag:
             self._range_flag.zero_()
+        if flag and raise_on_flag:
             raise _lib.GennbvHipError(
                 f"split-f16 kernels: an activation left its range (flag {int(flag)}: 2 = relu(bn1(conv1)) bound above 253, 4 = a feature "
                 "above 1000); results since the last check may be clamped.  This encoder now runs on the fp32-MFMA kernels "

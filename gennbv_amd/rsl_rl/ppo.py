@@ -24,6 +24,8 @@ class _FlatAdamView:
         self._owner, self._adam = owner, torch_adam
 
     def __getattr__(self, name):  # param_groups, defaults, ...
+        if name in ("_adam", "_owner") or (name.startswith("__") and name.endswith("__")):
+            raise AttributeError(name)  # (copy.deepcopy / pickle probe the instance before __init__ ran: no recursion through _adam)
         return getattr(self._adam, name)
 
     def state_dict(self):
@@ -37,8 +39,9 @@ class _FlatAdamView:
             flat.load_torch_state_dict(self._adam.state_dict())
             for g in self._adam.param_groups:
                 flat.lr = float(g["lr"])
-        for g in self._adam.param_groups:
-            self._owner.learning_rate = float(g["lr"])
+        if self._owner.schedule != "adaptive":  # (the reference's adaptive schedule restarts from the CONFIGURED rate after a load:
+            for g in self._adam.param_groups:   # rsl_rl/algorithms/ppo.py:148-159 writes `self.learning_rate` into the groups, never reads them)
+                self._owner.learning_rate = float(g["lr"])
 
 
 class PPO:

@@ -157,8 +157,8 @@ class PPO_Grid_Obs:
         """{"policy": state_dict, "policy.optimizer": torch.optim.Adam-format state dict}."""
         opt_sd = self.policy.optimizer.state_dict()
         if self._hip and self._hip.get("opt") is not None:
-            if self._sync is not None and self._sync.active:  # (collective: every rank calls get_parameters / save together)
-                self._hip["opt"].gather_shard_state(self._sync.group)
+            # (NOT a collective: with the sharded fc_grid update every rank's moments are made complete at the end of each train() call
+            # -- `_train_hip_once` -- so a save on one rank only, or on rank-local conditions inside callbacks, cannot hang the others)
             opt_sd = self._hip["opt"].torch_state_dict(self.policy.optimizer)  # the flat HIP Adam owns the moments
         return {"policy": self.policy.state_dict(), "policy.optimizer": opt_sd}
 
@@ -514,8 +514,66 @@ class PPO_Grid_Obs:
         self._hip_minibatch_tail(st)
 
     def _train_hip(self) -> None:
-        """train() on the gfx950 kernels: same arithmetic as the reference loop
-        (ppo_grid_obs.py:196-275), zero host synchronisation inside an epoch."""
+        """train() on the gfx950 kernels (`_train_hip_once`), made safe against the operand ranges of the split-f16 arithmetic: the
+        parameter pre-check moves the encoder to the fp32-MFMA kernels BEFORE anything is computed; the activation flags the kernels
+        raise are only known AFTER the call, when every Adam step and BatchNorm update has been applied -- so the update state
+        (flat parameters, Adam moments, step counter, module buffers, `_n_updates`: ~0.18 GB, one device copy per call) is snapshotted
+        first, and a flagged call is REPEATED on the fp32-MFMA kernels from that snapshot instead of aborting learn() mid-run with
+        possibly clamped results applied.  Data-parallel: the flag is the maximum over the ranks, so every rank repeats together."""
+        enc = self.policy.features_extractor
+        guarded = getattr(enc, "backend", "") == "hip" and hasattr(enc, "check_operand_ranges") and self.device.type == "cuda"
+        snap = self._snapshot_update_state() if guarded and not getattr(enc, "force_fp32", False) else None
+        self._train_hip_once()
+        if not guarded:
+            return
+        flag = int(enc.check_operand_ranges(raise_on_flag=False)["flag"])
+        if self._sync is not None and self._sync.active and self._sync.world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([flag], dtype=torch.int32, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._sync.group)
+            flag = int(t.item())
+        if not flag:
+            return
+        if snap is None:  # already on the fp32 kernels: only a feature above 1000 can get here, and nothing clamps there
+            return
+        import warnings
+        warnings.warn(f"[gennbv_amd] train(): an activation left the split-f16 operand range (flag {flag}); the call is repeated on the "
+                      "fp32-MFMA kernels from the state it started with (exact, slower); the encoder stays on them")
+        enc.force_fp32 = True
+        enc.check_operand_ranges(raise_on_flag=False)  # (marks the linears `_fp32_arith`, clears the flag)
+        self._restore_update_state(snap)
+        self.range_replays = getattr(self, "range_replays", 0) + 1
+        self._train_hip_once()
+        enc.check_operand_ranges(raise_on_flag=False)
+
+    def _snapshot_update_state(self):
+        opt = self._hip["opt"] if self._hip else None
+        st = {"n_updates": self._n_updates, "buffers": [b.detach().clone() for b in self.policy.buffers()]}
+        if opt is not None:
+            st["flat"] = [t.clone() for t in (opt.params, opt.exp_avg, opt.exp_avg_sq, opt.step_count)]
+        else:  # first call: the flat optimizer does not exist yet (it is built from the torch Adam's state, which this call does not touch)
+            st["params"] = [p.detach().clone() for p in self.policy.parameters()]
+        return st
+
+    def _restore_update_state(self, st) -> None:
+        opt = self._hip["opt"]
+        with torch.no_grad():
+            for b, v in zip(self.policy.buffers(), st["buffers"]):
+                b.copy_(v)
+            if "flat" in st:
+                for t, v in zip((opt.params, opt.exp_avg, opt.exp_avg_sq, opt.step_count), st["flat"]):
+                    t.copy_(v)
+            else:
+                for p, v in zip(self.policy.parameters(), st["params"]):
+                    p.copy_(v)  # (parameters are views of opt.params by now: this restores the flat buffer)
+                opt.exp_avg.zero_(); opt.exp_avg_sq.zero_(); opt.step_count.zero_()
+                opt.load_torch_adam_state(self.policy.optimizer)
+        self._n_updates = st["n_updates"]
+        self._hip["graph"] = None  # the kernel choice is baked into the captured graph
+
+    def _train_hip_once(self) -> None:
+        """One pass of train(): same arithmetic as the reference loop (ppo_grid_obs.py:196-275), zero host synchronisation inside an
+        epoch."""
         training_start = time.time()
         buf = self.rollout_buffer
         total = buf.buffer_size * buf.n_envs
@@ -635,7 +693,10 @@ class PPO_Grid_Obs:
             # (also when the loop raises: the slot holds the LAST minibatch's total -- never for another caller's training-mode forward)
             self.policy.features_extractor._autocorr_total = None
         self._n_updates += self.n_epochs
-        self._check_ranges()  # raises if a kernel of this call reached an activation bound of the split-f16 arithmetic
+        if dp and getattr(opt, "shard", None) is not None and self._sync.world > 1:
+            # sharded fc_grid update: the owners' Adam moments into every rank's flat buffers HERE, at a point every rank passes together
+            # (two all-gathers of 55 MB per train() call), so that get_parameters() / save() never need a collective
+            opt.gather_shard_state(self._sync.group)
         rows_done = int(loss.stats_row.item())
         s = loss.stats[:rows_done].double().cpu().numpy()
         s = s[s[:, 6] > 0.5]  # minibatches the reference would have executed
@@ -695,8 +756,10 @@ class PPO_Grid_Obs:
             return ga
         except Exception as ex:  # collectives not capturable on this stack: capture the compute only
             if getattr(st["opt"], "shard", None) is not None:
-                # (the warm-up and the failed capture ran with the update masked: nothing has been sharded yet -- fall back to the
-                # all-reduced, replicated update, whose collectives sit between the two graphs)
+                # fall back to the all-reduced, replicated update, whose collectives sit between the two graphs.  Safe also when an
+                # EARLIER train() call ran sharded steps (a re-capture after lr / clip_range changed): captures only happen at the start
+                # of a train() call, the warm-up and the failed capture ran with the update masked, and every train() call ends by
+                # gathering the owners' moments into every rank's buffers (`_train_hip_once`) -- all ranks hold the complete Adam state
                 st["opt"].shard = None
             self.dp_graph_mode = f"two compute graphs + eager collectives ({type(ex).__name__})"
             if self.verbose >= 1:

@@ -3,9 +3,11 @@ conv-stack backward -> small all-reduce -> clip + Adam) with the statistics SURV
 per-minibatch advantage mean / std, BatchNorm-1 and BatchNorm-2 batch statistics IN TRAIN MODE and their backward sums, the
 approx-KL of the early stop -- against the single-process update of the global batch.
 
-Two ranks share cuda:0 here (one GPU box) and talk over gloo on CUDA tensors; the collectives therefore run eagerly
-(RCCL refuses two ranks on one device, gloo cannot be captured) -- the same `_dp_step_body` the bench replays as one
-hipGraph with RCCL collectives on a multi-GPU node."""
+The ranks (2, 4 and 8: the target world size of BASELINE configs[3]) share cuda:0 here (one GPU box) and talk over gloo on CUDA
+tensors; the collectives therefore run eagerly (RCCL refuses two ranks on one device, gloo cannot be captured) -- the same
+`_dp_step_body` the bench replays as one hipGraph with RCCL collectives on a multi-GPU node.  With `use_graph=True` the capture of
+the gloo collectives is REFUSED, which is exactly the fallback the algorithm must survive: two compute graphs + eager collectives
+and the replicated update (`test_capture_refused_fallback...`)."""
 import os
 
 import numpy as np
@@ -16,7 +18,7 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-G, N_LOCAL, T, B_LOCAL, EPOCHS, WORLD = 16, 8, 4, 8, 2, 2
+G, N_LOCAL, T, B_LOCAL, EPOCHS = 16, 8, 4, 8, 2
 HW = (48, 64)
 
 
@@ -73,7 +75,7 @@ def _local_to_global(perm, rank):
     return (rank * N_LOCAL + perm // T) * T + perm % T
 
 
-def _worker(rank, path, port, target_kl, out, shard=True):
+def _worker(rank, WORLD, path, port, target_kl, out, shard=True, graph=False):  # noqa: N803
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     from gennbv_amd import parallel
@@ -81,28 +83,39 @@ def _worker(rank, path, port, target_kl, out, shard=True):
     algo = _algo(_StubEnv(N_LOCAL), B_LOCAL, target_kl)
     _fill(algo, blob, list(range(rank * N_LOCAL, (rank + 1) * N_LOCAL)))
     algo.rollout_buffer.indices = blob["perm"].copy()  # the same permutation on every rank, over its own rows
-    algo.use_graph = False
+    algo.use_graph = graph
     algo.shard_update = shard
     parallel.attach(algo, WORLD)
     algo.train()
     assert algo.policy.features_extractor._dp_sync is not None and algo.policy.features_extractor.training
     opt = algo._hip["opt"]
-    assert (getattr(opt, "shard", None) is not None) == shard
-    if shard:
-        # fc_grid.weight: reduce-scattered, updated by its owner, all-gathered; the Adam moments of the OTHER rank's half stay zero
-        # here and are complete after gather_shard_state (what get_parameters() / save() call)
+    if graph:  # gloo collectives cannot be captured: the fallback must have been taken, on every rank alike
+        assert str(getattr(algo, "dp_graph_mode", "")).startswith("two compute graphs"), getattr(algo, "dp_graph_mode", None)
+        assert getattr(opt, "shard", None) is None and isinstance(algo._hip["graph"], tuple)
+    else:
+        assert (getattr(opt, "shard", None) is not None) == shard
+    if shard and not graph:
+        # fc_grid.weight: reduce-scattered, updated by its owner, all-gathered.  The Adam moments exist on their OWNER during the steps
+        # and are gathered into every rank's flat buffers at the end of train() (a point all ranks pass together), so that
+        # get_parameters() / save() are NOT collective: rank 0 alone calls it below, which would hang if it were
         sh = opt.shard
         assert sh["hi"] - sh["lo"] == algo.policy.features_extractor.output_layer_grid[0].weight.numel() and sh["sh"] * WORLD == sh["hi"] - sh["lo"]
-        other = slice(sh["lo"] + (1 - rank) * sh["sh"], sh["lo"] + (2 - rank) * sh["sh"])
-        assert float(opt.exp_avg_sq[other].abs().max()) == 0.0 and float(opt.exp_avg_sq[sh["lo"]:sh["hi"]].abs().max()) > 0.0
-        sd = algo.get_parameters()["policy.optimizer"]
-        assert float(opt.exp_avg_sq[other].abs().max()) > 0.0 and len(sd["state"]) > 0
+        assert sh["rank"] == rank and sh["world"] == WORLD
+        for r in range(WORLD):  # every rank's shard of the moments is present (non-zero) everywhere after train()
+            assert float(opt.exp_avg_sq[sh["lo"] + r * sh["sh"]:sh["lo"] + (r + 1) * sh["sh"]].abs().max()) > 0.0, (rank, r)
+        if rank == 0:
+            sd = algo.get_parameters()["policy.optimizer"]
+            assert len(sd["state"]) > 0
+        mom = torch.cat((opt.exp_avg, opt.exp_avg_sq))
+        allm = [torch.zeros_like(mom) for _ in range(WORLD)]
+        dist.all_gather(allm, mom)
+        assert all(torch.equal(allm[0], m) for m in allm[1:]), "Adam moments differ between the ranks after train()"
     vec = torch.cat([p.detach().reshape(-1) for p in algo.policy.parameters()])
     bn = torch.cat([b.detach().reshape(-1).float() for b in algo.policy.buffers()])
     both = [torch.zeros_like(vec) for _ in range(WORLD)]
     dist.all_gather(both, vec)
     if rank == 0:
-        out["identical"] = bool(torch.equal(both[0], both[1]))
+        out["identical"] = all(bool(torch.equal(both[0], b)) for b in both[1:])
         out["params"], out["bn"] = vec.cpu().numpy(), bn.cpu().numpy()
         out["stats"] = algo.last_train_stats.copy()
         out["steps"] = int(algo._hip["opt"].step_count.item())
@@ -116,8 +129,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("target_kl,shard", [(None, True), ("auto", True), (None, False)])
-def test_two_rank_fused_update_equals_the_global_batch_update(tmp_path, target_kl, shard):
+@pytest.mark.parametrize("world,target_kl,shard,graph", [(2, None, True, False), (2, "auto", True, False), (2, None, False, False),
+                                                         (4, "auto", True, False), (8, None, True, False), (8, "auto", True, False),
+                                                         (2, "auto", True, True)])
+def test_multi_rank_fused_update_equals_the_global_batch_update(tmp_path, world, target_kl, shard, graph):
+    """world 4 / 8: the fc_grid.weight shard boundaries (110 592 weights over 4 / 8 owners), gather_shard_state and the stop position at
+    the target world size.  graph=True: the capture of the (gloo) collectives is refused -> two compute graphs + eager collectives
+    + replicated update, with 2 ranks."""
+    WORLD = world  # noqa: N806
     from gennbv_amd.env import synthetic as S
     from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
     torch.manual_seed(0)
@@ -161,7 +180,7 @@ def test_two_rank_fused_update_equals_the_global_batch_update(tmp_path, target_k
     want_bn = torch.cat([b.detach().reshape(-1).float() for b in ref.policy.buffers()]).cpu().numpy()
     steps = int(ref._hip["opt"].step_count.item())
     out = mp.Manager().dict()
-    mp.spawn(_worker, args=(path, _free_port(), target_kl, out, shard), nprocs=WORLD, join=True)
+    mp.spawn(_worker, args=(WORLD, path, _free_port(), target_kl, out, shard, graph), nprocs=WORLD, join=True)
     assert out["identical"], "ranks diverged"
     assert out["steps"] == steps and len(out["stats"]) == len(stats)  # same early-stop position
     # the ranks log the terms of their own rows; the KL (col 3) they act on is the global mean: check it through the stop position,

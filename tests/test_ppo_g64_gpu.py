@@ -24,15 +24,16 @@ G, N_ENVS, T, BATCH, EPOCHS, LR = 64, 16, 32, 128, 5, 1e-4  # lr, clip ranges, c
 HW = (60, 80)
 
 
-def _kwargs(cfg, cls):
+def _kwargs(cfg, cls, semantic=False):
     return dict(net_arch=[], features_extractor_class=cls, features_extractor_kwargs=dict(
         encoder_param={"hidden_shapes": [256, 256], "visual_dim": 256},
         net_param={"transformer_params": [[1, 256], [1, 256]], "append_hidden_shapes": [256, 256]},
-        state_input_shape=(cfg.state_dim,), visual_input_shape=(cfg.stack, cfg.camera_height, cfg.camera_width)))
+        state_input_shape=(cfg.state_dim,), visual_input_shape=(cfg.stack, cfg.camera_height, cfg.camera_width),
+        **({"semantic_branch": True} if semantic else {})))
 
 
-def _ppo_args(target_kl, t=T, epochs=EPOCHS):
-    return dict(learning_rate=LR, n_steps=t, batch_size=BATCH, n_epochs=epochs, gamma=0.99, gae_lambda=0.95, clip_range=0.2,
+def _ppo_args(target_kl, t=T, epochs=EPOCHS, batch=None):
+    return dict(learning_rate=LR, n_steps=t, batch_size=BATCH if batch is None else batch, n_epochs=epochs, gamma=0.99, gae_lambda=0.95, clip_range=0.2,
                 clip_range_vf=0.2, ent_coef=0.01, vf_coef=0.8, max_grad_norm=1.0, target_kl=target_kl, seed=1)
 
 
@@ -40,9 +41,11 @@ class _Recorded:
     """HIP algorithm after one collect_rollouts() + everything the CPU oracle needs, recorded once per module.
     (tests/test_fullsize_gpu.py builds one at BASELINE configs[1]'s full geometry through the keyword arguments.)"""
 
-    def __init__(self, n_envs=N_ENVS, t=T, hw=HW, epochs=EPOCHS, max_episode_length=12, frames=6, before_rollout=None):
-        N_ENVS, T, HW, EPOCHS = n_envs, t, hw, epochs  # noqa: N806  (shadow the module defaults)
+    def __init__(self, n_envs=N_ENVS, t=T, hw=HW, epochs=EPOCHS, max_episode_length=12, frames=6, before_rollout=None, g=G, batch=BATCH,
+                 semantic=False):
+        N_ENVS, T, HW, EPOCHS, G = n_envs, t, hw, epochs, g  # noqa: N806  (shadow the module defaults)
         self.n_envs, self.t, self.epochs, self.max_episode_length = n_envs, t, epochs, max_episode_length
+        self.g, self.batch, self.semantic = g, batch, semantic
         from gennbv_amd.env import synthetic as S
         from gennbv_amd.env.config import TaskConfig
         from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
@@ -53,10 +56,10 @@ class _Recorded:
         np.random.seed(0)
         self.cfg = cfg = TaskConfig(camera_width=HW[1], camera_height=HW[0], grid_size=G)
         scene = S.make_scenes(N_ENVS, G, seed=4, device=DEV)
-        feed = ReplayFeed.synthetic(scene, cfg, frames, seed=4)
+        feed = ReplayFeed.synthetic(scene, cfg, frames, seed=4, **({"with_rgba": True} if semantic else {}))
         env = ReplayFeedEnv(cfg, scene, feed, DEV, max_episode_length=max_episode_length)  # (default: a few resets / time-outs inside 32 steps)
         self.algo = algo = PPO_Grid_Obs(ActorCriticPolicy_Train_Eval, env, device=DEV, compact_obs=True,
-                                        policy_kwargs=_kwargs(cfg, Hybrid_Encoder), **_ppo_args(None, T, EPOCHS))
+                                        policy_kwargs=_kwargs(cfg, Hybrid_Encoder, semantic), **_ppo_args(None, T, EPOCHS, batch))
         assert algo.policy.features_extractor.grid_size == G  # inferred from the observation space
         algo._setup_learn(total_timesteps=10 ** 9)
         # (default SB3 initialisation -- the state the bench times.  Do NOT sharpen the policy artificially: with
@@ -87,8 +90,8 @@ class _Recorded:
 
             def seed(self, s):
                 pass
-        ppo = PPO_Grid_Obs(ActorCriticPolicy_Train_Eval, _Env(), device="cpu", policy_kwargs=_kwargs(self.cfg, TorchHybridEncoder),
-                           **_ppo_args(target_kl, T, EPOCHS))
+        ppo = PPO_Grid_Obs(ActorCriticPolicy_Train_Eval, _Env(), device="cpu", policy_kwargs=_kwargs(self.cfg, TorchHybridEncoder, self.semantic),
+                           **_ppo_args(target_kl, T, EPOCHS, self.batch))
         assert ppo.policy.features_extractor.backend == "torch"
         ppo.policy.load_state_dict(self.state)
         ppo.policy.double()
@@ -180,3 +183,45 @@ def test_train_g64_b128_early_stop_position(rec, oracle_full):
     hip = _fresh_hip(rec, target, True)
     hip.train()
     _compare(hip, ref, j)
+
+
+def test_train_semantic_branch_g64_b128_hipgraph_matches_fp64_oracle():
+    """BASELINE configs[2] at the train() level: `Hybrid_Encoder(semantic_branch=True)` -- the two gray frames ->
+    8x8 patch embeddings -> Linear 4096->256 -> concatenated in front of `output_layer` (768 inputs) -- through the captured minibatch
+    graph with the rgb linears and the K2 = 512 head (what `bench.py --semantic` times), against the fp64 CPU loop of the same class
+    with the same torch modules.  Same tolerances as the default kernel set (1e-4 per logged scalar over 20 optimizer steps)."""
+    rec = _Recorded(semantic=True)
+    enc = rec.algo.policy.features_extractor
+    assert enc.semantic_branch and enc.output_layer[0].in_features == 768
+    rgb = rec.flat_obs[..., rec.cfg.state_dim + G ** 3:]
+    assert float(rgb.abs().max()) > 1.0 and float(rgb.std()) > 1.0  # the gray frames carry an image, not zeros
+    ref = rec.oracle(None)
+    hip = _fresh_hip(rec, None, True)
+    hip.train()
+    assert hip._hip["graph"] is not None and hip._hip.get("fused_head")
+    _compare(hip, ref, EPOCHS * (N_ENVS * T // BATCH))
+    # the branch is live: its parameters moved
+    moved = {k: float((hip.policy.state_dict()[k].cpu() - v).abs().max()) for k, v in rec.state.items() if "_rgb" in k and "weight" in k}
+    assert moved and min(moved.values()) > 0.0, moved
+
+
+def test_train_g128_eight_samples_matches_fp64_oracle():
+    """BASELINE configs[4]'s grid (128^3; fp32-MFMA conv kernels, int8 slab conv1, k_hit_atomic + k_ray_slab in the rollout that
+    records the buffer) through train(): 4 envs x 4 steps = 16 samples, minibatches of 8, 2 epochs = 4 optimizer steps under the
+    hipGraph, against the fp64 CPU loop (the G = 128 optimizer path had no check)."""
+    rec = _Recorded(n_envs=4, t=4, hw=(60, 80), epochs=2, g=128, batch=8, frames=4)
+    assert rec.algo.policy.features_extractor.grid_size == 128
+    ref = rec.oracle(None)
+    hip = _fresh_hip(rec, None, True)
+    hip.train()
+    s_h, s_r = hip.last_train_stats, ref.last_train_stats
+    assert len(s_h) == len(s_r) == 4 and int(hip._hip["opt"].step_count.item()) == 4
+    d = np.abs(s_h[:, :6] - s_r[:, :6]) / np.maximum(1.0, np.abs(s_r[:, :6]))
+    assert float(d.max()) <= 1e-4, d
+    sd_h, sd_r = hip.policy.state_dict(), ref.policy.state_dict()
+    for k, v in sd_r.items():
+        if "running" in k:
+            assert float((sd_h[k].double().cpu() - v).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), k
+    diffs = torch.cat([(p.detach().double().cpu() - q.detach()).abs().reshape(-1)
+                       for (_, p), (_, q) in zip(hip.policy.named_parameters(), ref.policy.named_parameters())])
+    assert float(torch.quantile(diffs[::61].float(), 0.999)) <= 2e-4 and float(diffs.max()) <= LR * 4 * 1.05

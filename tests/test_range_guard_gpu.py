@@ -169,3 +169,33 @@ def test_train_call_checks_ranges_and_recaptures():
     assert len(s_h) == len(s_r) == 2
     d = np.abs(s_h[:, :6] - s_r[:, :6]) / np.maximum(1.0, np.abs(s_r[:, :6]))
     assert float(d.max()) <= 1e-4, d
+
+
+def test_train_call_flagged_by_an_activation_is_replayed_on_the_fp32_kernels():
+    """a range flag is only known AFTER train() applied every Adam step and BatchNorm update, so raising there aborts
+    learn() with possibly clamped results applied.  Now train() snapshots its update state and REPEATS a flagged call on the fp32-MFMA
+    kernels: BatchNorm-2 gamma x 400 puts fc_grid's inputs above 1000 (bit 4; no parameter is out of range, so the pre-check passes),
+    the call must warn, finish, and equal the fp64 loop run ONCE from the same initial state."""
+    from tests import test_ppo_g64_gpu as t64
+    rec = t64._Recorded(n_envs=16, t=16, epochs=1)
+    with torch.no_grad():
+        rec.state["features_extractor.naive_encoder_grid.4.weight"].mul_(400.0)
+    ref = rec.oracle(None)
+    hip = t64._fresh_hip(rec, None, True)
+    hip.policy.features_extractor.force_fp32 = False
+    with pytest.warns(UserWarning, match="repeated on the"):
+        hip.train()
+    enc = hip.policy.features_extractor
+    assert enc.force_fp32 and hip.range_replays == 1 and int(enc._range_flag.item()) == 0
+    s_h, s_r = hip.last_train_stats, ref.last_train_stats
+    assert len(s_h) == len(s_r) == 2 and int(hip._hip["opt"].step_count.item()) == 2 and hip._n_updates == ref._n_updates
+    d = np.abs(s_h[:, :6] - s_r[:, :6]) / np.maximum(1.0, np.abs(s_r[:, :6]))
+    assert float(d.max()) <= 1e-4, d
+    sd_h = hip.policy.state_dict()
+    for k, v in ref.policy.state_dict().items():
+        if "running" in k:
+            assert float((sd_h[k].double().cpu() - v).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), k
+        if "num_batches" in k:
+            assert int(sd_h[k]) == int(v), k  # the flagged pass's BatchNorm updates were rolled back
+    hip.train()  # and the next call runs without a replay
+    assert hip.range_replays == 1

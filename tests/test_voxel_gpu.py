@@ -1,4 +1,6 @@
 """GPU: HIP state-encoding kernels (through the C-ABI) vs the CPU oracle and the goldens."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -277,6 +279,44 @@ def test_full_size_properties_config1():
                                        scene.range_gt[sel].cpu().numpy(), scene.voxel_size[sel].cpu().numpy(), scene.grid_gt[sel].cpu().numpy(), pr, sc)
     assert prob1[sel].cpu().numpy().tobytes() == pr.tobytes()
     assert tri1[sel].cpu().numpy().tobytes() == tri_o.tobytes()
+
+
+@pytest.mark.parametrize("large", ["0", "1"])  # "1": k_hit_atomic (the kernel of grids above 104^3) forced at 64^3
+def test_hit_mask_of_all_256_full_size_envs_equals_the_per_pixel_oracle_voxels(large, monkeypatch):
+    """Every voxel a foreground pixel lands in -- per pixel, by the oracle's canonical chain (A1 post-processing, A2 back-projection,
+    A3 index; gennbv/utils.py:230-270, env_train_gennbv.py:277-299) -- must be in the hit mask, and nothing else: ALL 256 envs of
+    BASELINE configs[1]'s geometry, not a sample of three.  (Round 3's tools/debug_hit_mask.py as a test: it is the check that caught a
+    k_hit_list variant losing 6 single-pixel voxels in 256 envs -- voxels one pixel wide are exactly what a sampled check misses.)"""
+    from gennbv_amd.env.state_encoding import OccupancyGridUpdater
+    monkeypatch.setenv("GENNBV_VOXEL_LARGE", large)
+    n, h, w, g = 256, 240, 320, 64
+    cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
+    scene = S.make_scenes(n, g, seed=1, device=DEV)
+    kinv = S.inverse_intrinsics(h, w)
+    upd = OccupancyGridUpdater(n, g, h, w, kinv, scene.range_gt, scene.voxel_size, scene.grid_gt, DEV)
+    upd.self_clean = False
+    orc.lib().orc_set_num_threads(min(64, os.cpu_count() or 1))
+    total_single = 0
+    for seed in (1, 2):  # two poses per env
+        f = S.make_frames(scene, cfg, 1, seed=seed, with_rgba=False)[0]
+        c2w = S.c2w_from_view(f.view, scene.env_origins)
+        upd.update(f.depth_raw, f.seg_raw, c2w, f.poses.contiguous(), reset_mask=torch.ones(n, dtype=torch.uint8, device=DEV))
+        hit, _ = upd.masks()
+        hit = hit.cpu().numpy().reshape(n, -1)
+        dp, sp = orc.post_process_depth(f.depth_raw.cpu().numpy(), f.seg_raw.cpu().numpy())
+        world, fg = orc.back_projection(dp, sp, c2w.cpu().numpy(), kinv.numpy())
+        idx = orc.points_to_idx(world, fg, scene.range_gt.cpu().numpy(), scene.voxel_size.cpu().numpy(), g).reshape(n, h * w, 3)
+        keep = idx[..., 0] >= 0  # (background / out-of-range pixels: -1)
+        lin = (idx[..., 0].astype(np.int64) * g + idx[..., 1]) * g + idx[..., 2]
+        for e in range(n):
+            cnt = np.bincount(lin[e][keep[e]], minlength=g ** 3)
+            ref = cnt > 0
+            total_single += int((cnt == 1).sum())
+            if not np.array_equal(ref, hit[e]):
+                miss, extra = np.nonzero(ref & ~hit[e])[0], np.nonzero(~ref & hit[e])[0]
+                raise AssertionError(f"env {e} (frame seed {seed}): {len(miss)} voxels missing {miss[:6]}, {len(extra)} extra {extra[:6]}; "
+                                     f"pixels of the first missing voxel: {np.nonzero(keep[e] & (lin[e] == (miss[0] if len(miss) else -1)))[0][:8]}")
+    assert total_single > 1000  # the case the sampled checks cannot see is present: voxels hit by exactly one pixel
 
 
 def test_tri_written_into_strided_observation_rows():

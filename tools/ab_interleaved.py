@@ -1,0 +1,187 @@
+"""Interleaved A/B of kernel variants inside ONE process on ONE box.
+
+Round 3's A/Bs ran whole bench processes one after the other: +-3 % box-to-box, and a replayed graph that lands in one of two
+states per PROCESS (561-566 vs 581-589 us) -- 10 us effects did not resolve.  Here every variant is built and captured once, in the
+same process, and the variants are then timed alternately in short chunks, many rounds, so that clock / thermal drift is common to
+all of them:
+
+    python tools/ab_interleaved.py --what train  --variant base --variant "nofuse:GENNBV_FUSED_TRAIN=0" --variant "old:LIB=/path/libold.so"
+    python tools/ab_interleaved.py --what voxel  --variant base --variant "old:LIB=gennbv_amd/libgennbv_hip_old.so"
+    python tools/ab_interleaved.py --what rollout ...
+
+A variant is `name[:K=V,K=V,...]`; `LIB=path` selects another build of libgennbv_hip.so (gennbv_amd._lib.activate), everything else
+is an environment variable that is set while the variant is BUILT and CAPTURED (the library reads its switches at call / capture
+time; a replayed hipGraph has them baked in).  `train`: the captured PPO minibatch graph of bench.py's algorithm object (learning
+rate 1e-12: thousands of replays must not walk the parameters away).  `voxel`: gnbv_update_occ_grid_coded as the env calls it
+(eager launches).  `rollout`: one env step + policy forward of collect_rollouts (eager; or its graph when the build has one).
+
+Output per variant: median and MAD of the per-call time over all chunks, and -- against the FIRST variant -- the median of the
+per-round paired differences with its MAD: the number to quote."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def parse_variant(v: str):
+    name, _, rest = v.partition(":")
+    env, lib = {}, None
+    for kv in filter(None, rest.split(",")):
+        k, _, val = kv.partition("=")
+        if k == "LIB":
+            lib = val
+        else:
+            env[k] = val
+    return name, env, lib
+
+
+class _Env:
+    def __init__(self, env):
+        self.env, self.old = env, {}
+
+    def __enter__(self):
+        for k, v in self.env.items():
+            self.old[k] = os.environ.get(k)
+            os.environ[k] = v
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def build_train(a, dev):
+    import torch
+    import bench
+    ns = argparse.Namespace(gpus=1, steps=1, warmup=0, envs=a.envs, grid=a.grid, height=a.height, width=a.width, n_steps=a.n_steps, batch_size=a.batch_size,
+                            n_epochs=1, frames=2, backend="hip", obs="compact", target_kl="off", semantic=a.semantic, no_cpu_baseline=True,
+                            gemm_tuning=False, save_gemm_tuning=None, no_flat_rows=True, no_state_check=True)
+    algo, cfg, env = bench.build_algo(ns, dev, 0, 1)
+    algo.learning_rate = 1e-12
+    algo.lr_schedule = lambda _: 1e-12
+    algo._setup_learn(total_timesteps=10 ** 12)
+    algo.collect_rollouts(algo.env, None, algo.rollout_buffer, n_rollout_steps=algo.n_steps)
+    algo.train()
+    g = algo._hip["graph"]
+    assert g is not None and not isinstance(g, tuple)
+    torch.cuda.synchronize()
+    return (lambda: g.replay()), algo
+
+
+def build_voxel(a, dev):
+    import torch
+    from gennbv_amd.env import synthetic as S
+    from gennbv_amd.env.config import TaskConfig
+    from gennbv_amd.env.state_encoding import OccupancyGridUpdater
+    cfg = TaskConfig(camera_width=a.width, camera_height=a.height, grid_size=a.grid)
+    scene = S.make_scenes(a.envs, a.grid, seed=1, device=dev)
+    frames = S.make_frames(scene, cfg, 4, seed=1, with_rgba=False)
+    upd = OccupancyGridUpdater(a.envs, a.grid, a.height, a.width, S.inverse_intrinsics(a.height, a.width), scene.range_gt, scene.voxel_size, scene.grid_gt,
+                               dev, max_steps_between_resets=100)
+    t8 = torch.zeros(a.envs, a.grid ** 3, dtype=torch.int8, device=dev)
+    c2ws = [S.c2w_from_view(f.view, scene.env_origins) for f in frames]
+    poses = [f.poses.contiguous() for f in frames]
+    all_reset = torch.ones(a.envs, dtype=torch.uint8, device=dev)
+    state = {"i": 0}
+
+    def step():
+        i = state["i"] = state["i"] + 1
+        k = i % 4
+        upd.update(frames[k].depth_raw, frames[k].seg_raw, c2ws[k], poses[k], reset_mask=all_reset if i % 64 == 63 else None, tri_i8_out=t8, fp32_out=False)
+    for _ in range(8):
+        step()
+    torch.cuda.synchronize()
+    return step, (upd, frames, t8)
+
+
+def build_rollout(a, dev):
+    import torch
+    import bench
+    ns = argparse.Namespace(gpus=1, steps=1, warmup=0, envs=a.envs, grid=a.grid, height=a.height, width=a.width, n_steps=a.n_steps, batch_size=a.batch_size,
+                            n_epochs=1, frames=4, backend="hip", obs="compact", target_kl="off", semantic=a.semantic, no_cpu_baseline=True,
+                            gemm_tuning=False, save_gemm_tuning=None, no_flat_rows=True, no_state_check=True)
+    algo, cfg, env = bench.build_algo(ns, dev, 0, 1)
+    algo._setup_learn(total_timesteps=10 ** 12)
+
+    def step():  # one whole rollout of n_steps env steps (per-call time is divided by n_steps below)
+        algo.collect_rollouts(algo.env, None, algo.rollout_buffer, n_rollout_steps=algo.n_steps)
+    step()
+    torch.cuda.synchronize()
+    return step, algo
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--what", default="train", choices=["train", "voxel", "rollout"])
+    ap.add_argument("--variant", action="append", required=True)
+    ap.add_argument("--rounds", type=int, default=20)
+    ap.add_argument("--chunk", type=int, default=None, help="calls per timed chunk (default: 50 train / 50 voxel / 1 rollout)")
+    ap.add_argument("--envs", type=int, default=256)
+    ap.add_argument("--grid", type=int, default=64)
+    ap.add_argument("--height", type=int, default=240)
+    ap.add_argument("--width", type=int, default=320)
+    ap.add_argument("--n-steps", type=int, default=8)
+    ap.add_argument("--batch-size", type=int, default=128)
+    ap.add_argument("--semantic", action="store_true")
+    ap.add_argument("--json", default=None)
+    a = ap.parse_args()
+    import torch
+    from gennbv_amd import _lib
+    dev = "cuda:0"
+    torch.cuda.set_device(dev)
+    build = {"train": build_train, "voxel": build_voxel, "rollout": build_rollout}[a.what]
+    chunk = a.chunk or {"train": 50, "voxel": 50, "rollout": 1}[a.what]
+    per_call_div = a.n_steps if a.what == "rollout" else 1
+    variants = []
+    for v in a.variant:
+        name, env, lib = parse_variant(v)
+        with _Env(env):
+            _lib.activate(lib)
+            fn, keep = build(a, dev)
+        variants.append({"name": name, "env": env, "lib": lib, "fn": fn, "keep": keep, "t": []})
+    _lib.activate(None)
+    # GPU-busy warm-up (leave the idle power state: 0.3 s of the first variant), then the alternating rounds
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.3:
+        for _ in range(chunk):
+            variants[0]["fn"]()
+        torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for r in range(a.rounds):
+        order = variants[r % len(variants):] + variants[:r % len(variants)]  # rotate who goes first
+        for v in order:
+            v["fn"]()  # one untimed call: the variant's code / data back in the caches
+            ev0.record()
+            for _ in range(chunk):
+                v["fn"]()
+            ev1.record()
+            torch.cuda.synchronize()
+            v["t"].append(ev0.elapsed_time(ev1) * 1e3 / chunk / per_call_div)  # us per call
+    unit = {"train": "us / minibatch", "voxel": "us / update", "rollout": "us / env step"}[a.what]
+    base = variants[0]
+    out = {"what": a.what, "unit": unit, "rounds": a.rounds, "chunk": chunk, "device": torch.cuda.get_device_name(0), "variants": []}
+    for v in variants:
+        med = statistics.median(v["t"])
+        mad = statistics.median(abs(x - med) for x in v["t"])
+        diffs = [x - y for x, y in zip(v["t"], base["t"])]
+        dmed = statistics.median(diffs)
+        dmad = statistics.median(abs(x - dmed) for x in diffs)
+        out["variants"].append({"name": v["name"], "env": v["env"], "lib": v["lib"], "median": med, "mad": mad, "min": min(v["t"]), "max": max(v["t"]),
+                                "paired_delta_vs_first": dmed, "paired_delta_mad": dmad})
+        print(f"{v['name']:20s} {med:9.2f} +- {mad:5.2f} {unit}   [min {min(v['t']):.2f}, max {max(v['t']):.2f}]   vs {base['name']}: {dmed:+7.2f} +- {dmad:4.2f}")
+    if a.json:
+        with open(a.json, "w") as f:
+            json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,20 @@
+#!/bin/bash
+# run on the GPU box: stages of round 4's measurement calls.  tools/run_r4.sh <stage> ...
+cd $GRAFT_REPO_ROOT
+O=$GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $O
+for st in "$@"; do
+case $st in
+  tests)   timeout 1500 python -m pytest tests -m gpu -q --maxfail=12 --durations=12 -p no:cacheprovider > $O/r4_tests.log 2>&1; tail -40 $O/r4_tests.log ;;
+  bench)   timeout 900 python bench.py --steps 5 --warmup 2 2>$O/r4_bench.err | tail -1 > $O/r4_bench_n1.json; cut -c1-600 $O/r4_bench_n1.json ;;
+  benchdrv) timeout 1200 python bench.py --steps 20 --warmup 5 2>$O/r4_benchdrv.err | tail -1 > $O/r4_bench_driver_cfg_n1.json; cut -c1-400 $O/r4_bench_driver_cfg_n1.json ;;
+  idle)    timeout 300 python tools/idle_ramp.py > $O/r4_idle_ramp.txt 2>&1; cat $O/r4_idle_ramp.txt ;;
+  dp1)     GENNBV_FORCE_DP=1 GENNBV_FORCE_SHARD=1 timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-flat-rows 2>$O/r4_dp1.err | tail -1 > $O/r4_bench_dp1_n1.json; cut -c1-500 $O/r4_bench_dp1_n1.json ;;
+  refdef)  timeout 1200 python bench.py --steps 3 --warmup 1 --height 400 --width 400 --grid 20 --no-flat-rows 2>$O/r4_refdef.err | tail -1 > $O/r4_bench_refdefault_n1.json; cut -c1-600 $O/r4_bench_refdefault_n1.json ;;
+  abtrain) timeout 600 python tools/ab_interleaved.py --what train --variant base --variant "base2" --variant "twokernel:GENNBV_FUSED_TRAIN=0" --rounds 12 --json $O/r4_ab_train.json 2>&1 | tail -5 ;;
+  abvoxel) timeout 600 python tools/ab_interleaved.py --what voxel --variant base --variant base2 --rounds 20 --json $O/r4_ab_voxel.json 2>&1 | tail -4 ;;
+  prof)    bash tools/collect_profiles.sh r04 2>&1 | tail -5 ;;
+  mb)      bash tools/prof_minibatch.sh r4_mb 2>&1 | tail -3 ;;
+  *) echo "unknown stage $st" ;;
+esac
+done
