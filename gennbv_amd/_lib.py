@@ -80,6 +80,8 @@ SIGNATURES = {
     "gnbv_clip_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _p, _f, _p, _f, _p, _p, _sz, _p]),
     "gnbv_clip_adam_step_rotate": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _p, _f, _p, _f, _p, _p, _sz, _p, _i, _i, _p, _p, _p]),
     "gnbv_clip_adam_step_ex": (_i, [_p, _p]),
+    "gnbv_sq_partials_count": (_i, []),
+    "gnbv_sq_partials": (_i, [_p, _i64, _p, _p]),
     "gnbv_adam_shard_step": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _p, _p, _p]),
     "gnbv_chamfer_workspace_bytes": (_sz, [_i, _i]),
     "gnbv_chamfer_distance": (_i, [_p, _i, _p, _i, _p, _p, _sz, _p]),

@@ -612,6 +612,43 @@ GNBV_API int gnbv_adam_shard_step(float *params, const float *grads, float *exp_
     return gnbv_launch_status();
 }
 
+// sum(g^2) of a gradient shard as kSqParts fp64 partial sums in one fixed order (the sharded data-parallel update: every rank squares the
+// shard of the REDUCED gradient it received; the partial sums ride an all-reduce and enter the clip factor through GnbvAdamStep.sq_partial)
+constexpr int kSqParts = 256;
+__global__ __launch_bounds__(256) void k_sq_partials(const float *__restrict__ g, int64_t n, double *__restrict__ partial)
+{
+    __shared__ double sh[256];
+    double acc = 0.0;
+    const bool vec = (((uintptr_t)g & 15) == 0);
+    const int64_t n4 = vec ? n / 4 : 0, stride = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const float4 *>(g)[min(i0 + u * stride, n4 - 1)];  // (clamped: unconditional requests)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * stride < n4)
+                acc += (double)v[u].x * (double)v[u].x + (double)v[u].y * (double)v[u].y + (double)v[u].z * (double)v[u].z + (double)v[u].w * (double)v[u].w;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) acc += (double)g[i] * (double)g[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+GNBV_API int gnbv_sq_partials_count(void) { return kSqParts; }
+
+GNBV_API int gnbv_sq_partials(const float *grads, int64_t n, double *partial, void *stream)
+{
+    GNBV_CHECK_ARG(grads && partial && n > 0);
+    hipLaunchKernelGGL(k_sq_partials, dim3(kSqParts), dim3(256), 0, gnbv_stream(stream), grads, n, partial);
+    return gnbv_launch_status();
+}
+
 static GnbvAdamStep adam_args(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float max_grad_norm, float lr, float beta1,
                               float beta2, float eps, int64_t *step, int *stop_flag, float grad_scale, const float *kl_slot, float target_kl,
                               float *norm_out, void *workspace, size_t workspace_bytes)

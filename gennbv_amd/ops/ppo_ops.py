@@ -97,7 +97,7 @@ class FlatAdam:
         dev = self.params.device
         self.shard = {"lo": lo, "hi": hi, "sh": sh, "rank": rank, "world": world,
                       "grad": torch.zeros(sh, dtype=torch.float32, device=dev),
-                      "sq": torch.zeros(1, dtype=torch.float64, device=dev)}
+                      "sq": torch.zeros(int(self.lib.gnbv_sq_partials_count()), dtype=torch.float64, device=dev)}
         return True
 
     def gather_shard_state(self, group=None) -> None:
@@ -109,6 +109,12 @@ class FlatAdam:
         _, m, v = self.shard_views()
         dist.all_gather_into_tensor(self.exp_avg[s["lo"]:s["hi"]], m, group=group)
         dist.all_gather_into_tensor(self.exp_avg_sq[s["lo"]:s["hi"]], v, group=group)
+
+    def shard_sq(self) -> torch.Tensor:
+        """sum(shard gradient^2) as fixed-order fp64 partial sums in shard["sq"] (one launch; summed over the ranks by the caller)."""
+        s = self.shard
+        _lib.check(self.lib.gnbv_sq_partials(s["grad"].data_ptr(), int(s["sh"]), s["sq"].data_ptr(), _lib.stream_ptr(self.params.device)), "gnbv_sq_partials")
+        return s["sq"]
 
     def shard_views(self):
         s = self.shard

@@ -487,7 +487,7 @@ class PPO_Grid_Obs:
         self._hip_minibatch_body(st, "B")
         dist.all_reduce(opt.grads_with_slot[:opt.SLOT + n_conv], op=dist.ReduceOp.SUM, group=self._sync.group)
         w_rs.wait()
-        torch.sum(sh["grad"].double() ** 2, dim=0, keepdim=True, out=sh["sq"])
+        opt.shard_sq()  # (one launch: 256 fp64 partial sums of the shard's squares; three torch kernels and 2 x 110 MB of fp64 temporaries before)
         dist.all_reduce(sh["sq"], op=dist.ReduceOp.SUM, group=self._sync.group)
         w_ar.wait()
         opt.step(self.max_grad_norm, loss.stop_flag, grad_scale=1.0 / self._sync.world, kl_slot_target=loss.args.target_kl,
@@ -764,14 +764,36 @@ class PPO_Grid_Obs:
             self.dp_graph_mode = f"two compute graphs + eager collectives ({type(ex).__name__})"
             if self.verbose >= 1:
                 print(f"[gennbv_amd] RCCL capture failed ({ex!r}); using two compute graphs + eager collectives")
-            torch.cuda.synchronize(self.device)
+            self._abandon_capture()
+        # (a fresh capture stream: the one the refused capture ran on may still be in the `invalidated` capture state)
+        cap = torch.cuda.Stream(self.device)
         ga = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+        with torch.cuda.graph(ga, stream=cap, capture_error_mode="thread_local"):
             self._hip_minibatch_body(st, "A")
         gb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
+        with torch.cuda.graph(gb, pool=ga.pool(), stream=cap, capture_error_mode="thread_local"):
             self._hip_minibatch_body(st, "B")
         return (ga, gb)
+
+    def _abandon_capture(self) -> None:
+        """After a capture that was refused half-way (a collective that cannot be captured invalidates the capture): end it on the
+        capture stream torch keeps for `torch.cuda.graph` -- the failed `capture_end` raised before it cleared the stream's status,
+        and a stream left `invalidated` refuses every later capture ("Cannot register the state during capturing stage") -- and make
+        torch pick a new default capture stream."""
+        import ctypes
+        cap = getattr(torch.cuda.graph, "default_capture_stream", None)
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            for s_ in ([cap] if cap is not None else []) + [torch.cuda.current_stream(self.device)]:
+                g = ctypes.c_void_p()
+                hip.hipStreamEndCapture(ctypes.c_void_p(s_.cuda_stream), ctypes.byref(g))  # (an error code here is the expected outcome)
+                if g.value:
+                    hip.hipGraphDestroy(g)
+            hip.hipGetLastError()
+        except OSError:
+            pass
+        torch.cuda.graph.default_capture_stream = None
+        torch.cuda.synchronize(self.device)
 
     # ------------------------------------------------------------------------------
     def _env_step(self, actions, obs_out):

@@ -521,6 +521,11 @@ typedef struct GnbvAdamStep {
                                            data-parallel replicas, gnbv_adam_shard_step */
 } GnbvAdamStep;
 int gnbv_clip_adam_step_ex(const GnbvAdamStep *a /*[host]*/, void *stream);
+/* sum(grads[0 .. n)^2) as gnbv_sq_partials_count() fp64 partial sums in one fixed order -> partial [device].  The sharded data-parallel
+ * update: a rank squares the shard of the reduced gradient it owns, the partial sums are summed over the ranks (an all-reduce of
+ * 2 KB) and enter the clip factor of gnbv_clip_adam_step_ex through GnbvAdamStep.sq_partial / sq_parts. */
+int gnbv_sq_partials_count(void);
+int gnbv_sq_partials(const float *grads, int64_t n, double *partial /*[gnbv_sq_partials_count()]*/, void *stream);
 /* Adam on a shard of n parameters with the clip factor norm_out[1] that gnbv_clip_adam_step_ex of the SAME optimizer step left
  * behind (same step counter and stop flag, neither is modified). */
 int gnbv_adam_shard_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const float *norm_out,

@@ -130,7 +130,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,target_kl,shard,graph", [(2, None, True, False), (2, "auto", True, False), (2, None, False, False),
-                                                         (4, "auto", True, False), (8, None, True, False), (8, "auto", True, False),
+                                                         (4, "auto", True, False), (8, "auto", True, False),
                                                          (2, "auto", True, True)])
 def test_multi_rank_fused_update_equals_the_global_batch_update(tmp_path, world, target_kl, shard, graph):
     """world 4 / 8: the fc_grid.weight shard boundaries (110 592 weights over 4 / 8 owners), gather_shard_state and the stop position at

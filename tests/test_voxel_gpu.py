@@ -60,12 +60,15 @@ def test_postprocess_backprojection_voxelidx_vs_golden():
 
 
 def _run_sequence(n, h, w, g, steps, seed, reset_at=(), pose_override=None, packed=None, gt_scale=None, max_steps=None,
-                  int8_only=False):
+                  int8_only=False, blank_envs=()):
     """HIP updater vs oracle on the same seeded synthetic frames; returns per-step mismatch info."""
     from gennbv_amd.env.state_encoding import OccupancyGridUpdater
     cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
     scene = S.make_scenes(n, g, seed=seed)
     frames = S.make_frames(scene, cfg, min(steps, 4), seed=seed, with_rgba=False)
+    for k, e in enumerate(blank_envs):  # envs that see only background in some frames: empty ray lists (no walk task does any work)
+        for f in frames[k % 2::2]:
+            f.seg_raw[e] = 0.0
     kinv = S.inverse_intrinsics(h, w)
     if gt_scale is not None:
         scene.grid_gt = scene.grid_gt * gt_scale
@@ -120,11 +123,13 @@ def test_fused_update_bit_exact_vs_oracle(n, h, w, g, steps):
     _run_sequence(n, h, w, g, steps, seed=11 + g, reset_at=(2,))
 
 
+@pytest.mark.parametrize("fused_walk", ["1", "0"])  # "0": k_ray_list + k_grid_update_coded as two launches (GENNBV_VOXEL_FUSED_WALK=0)
 @pytest.mark.parametrize("n,h,w,g,steps", [(4, 120, 160, 16, 14), (3, 100, 100, 20, 6), (5, 120, 160, 64, 5), (2, 30, 37, 33, 4)])
-def test_coded_probability_grid_bit_exact_vs_oracle(n, h, w, g, steps):
+def test_coded_probability_grid_bit_exact_vs_oracle(n, h, w, g, steps, fused_walk, monkeypatch):
     """1-byte coded prob grid (code = base << 7 | #path steps): decoded grid, tri-class grid, scanned set and coverage
     equal the oracle bit for bit over a sequence with resets (repeated -0.05 steps reach the fp32 values the reference
     reaches: -0.05, -0.1, -0.15000001, ...)."""
+    monkeypatch.setenv("GENNBV_VOXEL_FUSED_WALK", fused_walk)
     _run_sequence(n, h, w, g, steps, seed=23 + g, reset_at=(2, 5), max_steps=100)
 
 
@@ -134,6 +139,24 @@ def test_coded_update_int8_only_rows_bit_exact_vs_oracle(n, h, w, g, steps):
     """Compact observation rows (no fp32 tri-class output): G^3 % 16 == 0 takes the 16-voxels-per-lane kernel,
     G = 18 the 4-per-lane one, G = 33 the scalar one."""
     _run_sequence(n, h, w, g, steps, seed=31 + g, reset_at=(2, 5), max_steps=100, int8_only=True)
+
+
+@pytest.mark.parametrize("seed", [40, 41])  # even: masks kept and compared (memset per call); odd: self-cleaning workspace
+def test_walk_update_scheduler_uneven_load(seed):
+    """k_walk_update (ray walk + grid update as one persistent launch; tasks claimed from per-XCD counters, update tasks wait for
+    their env's walk tasks): 67 envs (XCD queues of 9 and 8 envs), envs whose ray list is EMPTY in some frames, envs with one slice
+    and envs with sixteen, resets, six consecutive calls on one workspace (the scheduler words must come back to zero every time) --
+    hit / path masks, probability codes, scanned sets, coverage and int8 rows against the oracle at every step."""
+    upd = _run_sequence(67, 60, 80, 64, 6, seed=seed, reset_at=(2, 4), max_steps=100, int8_only=True, blank_envs=(0, 3, 8, 17, 66))
+    torch.cuda.synchronize()
+    n_pad = 128
+    words = upd.workspace.view(torch.int32)
+    # (layout: masks, then ray counts [n padded to 64], then the scheduler words)
+    from gennbv_amd import _lib
+    lib = _lib.load()
+    mask_ints = lib.gnbv_voxel_workspace_bytes(67, 64) // 4
+    sched = words[mask_ints + n_pad: mask_ints + 3 * n_pad + 2 * 8 * 16 + 64]
+    assert int(sched.abs().sum()) == 0, "scheduler words not left zero"
 
 
 def test_coded_probability_grid_tables_and_saturation():

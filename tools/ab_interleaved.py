@@ -144,9 +144,12 @@ def main():
     variants = []
     for v in a.variant:
         name, env, lib = parse_variant(v)
+        print(f"[ab] building variant {name} env={env} lib={lib}", file=sys.stderr, flush=True)
         with _Env(env):
             _lib.activate(lib)
             fn, keep = build(a, dev)
+        torch.cuda.synchronize()
+        print(f"[ab] variant {name} built and captured", file=sys.stderr, flush=True)
         variants.append({"name": name, "env": env, "lib": lib, "fn": fn, "keep": keep, "t": []})
     _lib.activate(None)
     # GPU-busy warm-up (leave the idle power state: 0.3 s of the first variant), then the alternating rounds
@@ -157,6 +160,8 @@ def main():
         torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for r in range(a.rounds):
+        if r < 2:
+            print(f"[ab] round {r}", file=sys.stderr, flush=True)
         order = variants[r % len(variants):] + variants[:r % len(variants)]  # rotate who goes first
         for v in order:
             v["fn"]()  # one untimed call: the variant's code / data back in the caches

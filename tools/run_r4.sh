@@ -15,6 +15,14 @@ case $st in
   abvoxel) timeout 600 python tools/ab_interleaved.py --what voxel --variant base --variant base2 --rounds 20 --json $O/r4_ab_voxel.json 2>&1 | tail -4 ;;
   prof)    bash tools/collect_profiles.sh r04 2>&1 | tail -5 ;;
   mb)      bash tools/prof_minibatch.sh r4_mb 2>&1 | tail -3 ;;
+  voxtests) timeout 900 python -m pytest tests/test_voxel_gpu.py tests/test_envstep_gpu.py tests/test_rollout_gpu.py -m gpu -q -x -p no:cacheprovider > $O/r4_voxtests.log 2>&1; tail -15 $O/r4_voxtests.log ;;
+  fulltests) timeout 600 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -5 ;;
+  partests) timeout 900 python -m pytest tests/test_parallel_gpu.py tests/test_ppo_gpu.py -m gpu -q -p no:cacheprovider --durations=5 > $O/r4_partests.log 2>&1; tail -30 $O/r4_partests.log ;;
+  abvox2)  timeout 600 python tools/ab_interleaved.py --what voxel --variant "two:GENNBV_VOXEL_FUSED_WALK=0" --variant "fused" --variant "two2:GENNBV_VOXEL_FUSED_WALK=0" --rounds 20 --json $O/r4_ab_voxel.json 2>&1 | tail -6 ;;
+  abtrain1) timeout 600 python tools/ab_interleaved.py --what train --variant base --variant base2 --rounds 12 --json $O/r4_ab_train1.json 2>&1 | tail -12 ;;
+  abtrain2) timeout 600 python tools/ab_interleaved.py --what train --variant base --variant "twokernel:GENNBV_FUSED_TRAIN=0" --rounds 12 --json $O/r4_ab_train2.json 2>&1 | tail -12 ;;
+  voxprof) python tools/microbench_voxel.py 2>&1 | tail -2; cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_v; rocprofv3 --kernel-trace --stats -d /tmp/prof_v -- python $GRAFT_REPO_ROOT/tools/microbench_voxel.py > /dev/null 2>&1; python $GRAFT_REPO_ROOT/tools/rocprof_summary.py /tmp/prof_v | grep -E "^kernel|k_|rocclr" | cut -c1-190 | tee $O/r4_voxel_kernel_trace.txt; cd $GRAFT_REPO_ROOT ;;
+  dp1prof) GENNBV_FORCE_DP=1 GENNBV_FORCE_SHARD=1 bash tools/prof_minibatch.sh r4_dp1_mb 2>&1 | tail -3 ;;
   *) echo "unknown stage $st" ;;
 esac
 done
