@@ -489,12 +489,17 @@ constexpr int kPairs = 4;
 constexpr int kYVox = 80, kYHalf = 16 * kYVox, kYRow = 2 * kYHalf, kYBuf = 2 * 2 * kPairs * kYRow;  // 40 960 per step buffer
 constexpr int kDyHalf = 18 * 32, kDyRow = 2 * kDyHalf, kDyPlanes = kPairs + 1, kDyRing = 3;
 constexpr int kDyBytes = kDyPlanes * kDyRing * kDyRow;
-constexpr int kSlabStride = 2048;
+// the int8 input under the workgroup's four plane pairs: 17 planes x 5 rows x 80 bytes per step, staged ONCE by the staging waves (round 4:
+// each of the 12 compute waves used to fetch the 5 x 5 x 80-byte slab of its plane pair itself -- three waves per plane pair, the same
+// 2 KB each: 24 KB of the 64 KB per step that went through the CU's vector-memory path, which is what bounds this kernel at its
+// 10.8 B / clk; 6.8 KB now)
+constexpr int kSlabPlanes = 4 * kPairs + 1, kSlabBuf = kSlabPlanes * 5 * 80;  // 6800 bytes per step parity
+constexpr int kSlabPieces = kSlabPlanes * 5 * 4;  // 340 sixteen-byte pieces: x = 0 .. 63 of every row (byte 64 of a row is only read for voxels past the grid, which are masked)
 constexpr int kSets = 3, kKSteps = 5;       // class sets per plane pair / k-steps per set (the image's stride)
 constexpr int kConsWaves = kPairs * kSets;  // 12 compute waves
 constexpr int kImgU4 = kSets * kKSteps * 2 * 64, kImgBytes = kImgU4 * 16;  // the B-operand image (all class sets): 30 720
 constexpr int kImgSlotU4 = 2048;            // its slot in the encoder workspace (behind the forward image)
-constexpr int kLdsBytes = 2 * kYBuf + kDyBytes + kConsWaves * kSlabStride + kImgBytes;
+constexpr int kLdsBytes = 2 * kYBuf + kDyBytes + 2 * kSlabBuf + kImgBytes;
 constexpr int kThreads = 1024, kProdThreads = 256;  // 12 compute + 4 staging waves, four per SIMD (<= 128 registers)
 constexpr int kYSlots = 2 * 2 * kPairs * 128 / kProdThreads;  // 16-byte requests per staging thread and step: 8
 constexpr int kDySlots = (kDyPlanes * 64 + kProdThreads - 1) / kProdThreads;  // 2
@@ -694,7 +699,8 @@ __device__ __forceinline__ void conv2_dgrad_c1w_split_body(
     using namespace dsplit;
     extern __shared__ __attribute__((aligned(16))) char split_lds[];
     char *ybufs = split_lds, *dyst = split_lds + 2 * kYBuf, *slabs = dyst + kDyBytes;
-    uint4 *wlds = reinterpret_cast<uint4 *>(slabs + kConsWaves * kSlabStride);
+    uint4 *wlds = reinterpret_cast<uint4 *>(slabs + 2 * kSlabBuf);
+    static_assert(kSlabRow == 80 && kSlabBuf % 16 == 0 && kSlabPieces <= kConsWaves * kWave, "one 16-byte slab request per compute lane");
     const int NA = (O1 + 1) >> 1;  // 16 plane pairs / row pairs / voxels per x parity
     int b, a0, a1;
     const bool live = sample_plane_group(B, NA, kPairs, b, a0, a1, vblock);
@@ -799,38 +805,34 @@ __device__ __forceinline__ void conv2_dgrad_c1w_split_body(
         const float sc = scale1[m], sh = shift1[m];
         const bool tok1 = 16 + m < kTaps;
         const int t1 = tok1 ? 16 + m : 0;
-        int8_t *slab = reinterpret_cast<int8_t *>(slabs + cw * kSlabStride);
+        // the int8 input slab under super-tile (a, c): planes 4 ai .. 4 ai + 4 of the step's shared slab (staged by the staging waves)
+        const int8_t *slab = reinterpret_cast<const int8_t *>(slabs) + ai * (4 * 5 * kSlabRow);
         const int8_t *slab0 = slab + ((m / 9) * 5 + (m / 3) % 3) * kSlabRow + m % 3 + 16 * kq;
         const int8_t *slab1 = slab + ((t1 / 9) * 5 + (t1 / 3) % 3) * kSlabRow + t1 % 3 + 16 * kq;
+        // ... which the compute waves stage themselves, ONE 16-byte piece per lane and step, one step ahead (unconditional in every wave:
+        // a wave-uniform branch around the request would make the compiler wait for it at the join)
         const int8_t *in = grid_i8 + (rows ? rows[b] : (int64_t)b) * grid_row_stride;
         const int g3m16 = G * G * G - 16;
-        // the int8 input slab under super-tile (a, c): 5 planes x 5 rows x 80 bytes, two 16-byte requests per lane, one step ahead
-        uint4 sv0, sv1;
-        auto slab_req = [&](int c, int u) {
-            const int idx = min(lane + 64 * u, 124), row = idx / 5, seg = idx - 5 * row, zr = row / 5, yr = row - 5 * zr;
-            const int off = (min(4 * a + zr, G - 1) * G + min(4 * c + yr, G - 1)) * G + 16 * seg;
-            return *reinterpret_cast<const uint4 *>(in + min(off, g3m16));
-        };
-        auto slab_load = [&](int c) {
-            sv0 = slab_req(c, 0);
-            sv1 = slab_req(c, 1);
-        };
-        slab_load(0);
+        const int sp = min(cw * kWave + lane, kSlabPieces - 1), srow = sp >> 2, szr = srow / 5, syr = srow - 5 * szr;
+        const int sbase = min(4 * a0 + szr, G - 1) * G * G + 16 * (sp & 3);
+        char *sdst = slabs + srow * kSlabRow + 16 * (sp & 3);
+        auto slab_req = [&](int c) { return *reinterpret_cast<const uint4 *>(in + min(sbase + min(4 * c + syr, G - 1) * G, g3m16)); };
+        uint4 sv = slab_req(0);
+        *reinterpret_cast<uint4 *>(sdst) = sv;
+        sv = slab_req(1);
         const bool z1ok = 2 * a + 1 < O1;
         split_step_barrier();
         // (one step loop per class set: with the branch inside the loop the two instantiations' scalars overflow the SGPR file)
         auto run = [&](auto ty_c) {
             constexpr int TY = decltype(ty_c)::value;
             for (int c = 0; c < nsteps; ++c) {
-                reinterpret_cast<uint4 *>(slab)[lane] = sv0;
-                if (lane + 64 < 125) reinterpret_cast<uint4 *>(slab)[lane + 64] = sv1;
-                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-                __builtin_amdgcn_wave_barrier();
-                slab_load(min(c + 1, nsteps - 1));
+                *reinterpret_cast<uint4 *>(sdst + ((c + 1) & 1) * kSlabBuf) = sv;  // step c + 1's piece (every wave left that buffer at the last barrier)
+                sv = slab_req(c + 2);
                 __builtin_amdgcn_sched_barrier(0);
                 const bool y0ok = 2 * c < O1, y1ok = 2 * c + 1 < O1;
                 const char *ybuf = ybufs + (c & 1) * kYBuf;
-                dgrad_split_supertile<TY>(dyst, ybuf, slab0, slab1, wimg, ai, c, z1ok, y0ok, y1ok, O1, tok1, sc, sh, gscale, s2, T1a, T1b);
+                const int sboff = (c & 1) * kSlabBuf;
+                dgrad_split_supertile<TY>(dyst, ybuf, slab0 + sboff, slab1 + sboff, wimg, ai, c, z1ok, y0ok, y1ok, O1, tok1, sc, sh, gscale, s2, T1a, T1b);
                 split_step_barrier();
             }
         };

@@ -499,8 +499,6 @@ __global__ __launch_bounds__(kRayThreads) void k_raycast(
 constexpr int kFusedThreads = FUSED_THREADS;
 constexpr int kListThreads = 256;    // k_ray_list: rays per slice = lanes per workgroup
 constexpr int kListSlices = 16;     // slices per env and pass
-constexpr int kSchedStride = 16;    // k_walk_update's scheduler words: ints between two XCDs' counters (64 bytes)
-__host__ __device__ static inline size_t sched_n_pad(int n) { return ((size_t)n + 63) & ~(size_t)63; }
 
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 // streaming 16-byte load (read-once camera data: keep it out of the L2's way)
@@ -1658,158 +1656,11 @@ __global__ __launch_bounds__(kGridThreads) void k_grid_update_coded(const CodedG
     coded_update_items<VPL>(a, blockIdx.y, blockIdx.x * kGridThreads, a.g3 / VPL, gridDim.x * kGridThreads, blockIdx.x == 0, lut, s_cov);
 }
 
-// ===========================================================================
-// Ray walk + grid update as ONE persistent launch (round 4).
-//
-// k_ray_list (28 us: instruction issue, no bytes) and k_grid_update_coded (41 us: the HBM stream) ran one after the other although
-// env e's update only needs env e's path mask.  Here 4 workgroups per CU stay resident and pull TASKS:
-//   walk (e, s)   = slice s of env e's ray list, exactly k_ray_list's workgroup: 32 KiB path mask in LDS, flushed into the env's global
-//                   mask with atomicOr; then done[e] += 1 behind an agent-scope release;
-//   update (e, p) = 1/16 of env e's voxels, exactly k_grid_update_coded's arithmetic, once done[e] has reached the env's number of
-//                   live slices (one relaxed poll loop by lane 0, ONE agent-scope acquire, then plain loads).
-// Tasks are claimed from per-XCD counters (env e belongs to XCD e % 8, workgroup b looks at XCD b % 8 first: the masks of an env
-// stay in one L2 -- an observed placement used for speed only) in env order; a workgroup takes an update task as soon as the
-// head-of-line env is ready and a walk task otherwise, so the HBM-bound updates of finished envs run UNDER the issue-bound walks of
-// the others.  Nothing depends on residency or placement: a workgroup only ever waits for walk tasks that some RUNNING workgroup has
-// claimed (claims happen in the loop of a running workgroup), visibility comes from device-scope atomics (masks, counters) and the
-// release / acquire pair, and a workgroup that finds its XCD's queues empty helps the other XCDs before it leaves.
-// The scheduler words (done[n], fin[n], walk_next / upd_next per XCD, an exit counter) live behind the ray counts, start ZERO (the
-// workspace contract of GNBV_VOXEL_WS_CLEAN; the memset otherwise) and are left zero: the last of an env's 16 update parts to finish
-// clears done[e] / fin[e] (every part has passed its poll by then), the last workgroup to leave clears the task counters.
-// ===========================================================================
-struct WalkSched {
-    int *done, *fin, *walk_next, *upd_next, *exits;
-};
-__host__ __device__ static inline WalkSched sched_of(int32_t *ray_count, int n)
-{
-    WalkSched w;
-    w.done = ray_count + sched_n_pad(n);
-    w.fin = w.done + sched_n_pad(n);
-    w.walk_next = w.fin + sched_n_pad(n);
-    w.upd_next = w.walk_next + 8 * kSchedStride;
-    w.exits = w.upd_next + 8 * kSchedStride;
-    return w;
-}
-__device__ __forceinline__ int ld_relaxed_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int live_slices(int cnt) { return cnt <= 0 ? 1 : min(kListSlices, (cnt + kListThreads - 1) / kListThreads); }
-
-template <int VPL>
-__global__ __launch_bounds__(kGridThreads) void k_walk_update(
-    const CodedGridArgs a, const int32_t *ray_list, int64_t ray_cap, const float *__restrict__ poses_xyz, int64_t pose_stride,
-    const float *__restrict__ range_gt, const float *__restrict__ voxel_size, int g)
-{
-    static_assert(kGridThreads == kListThreads, "one workgroup shape for both task kinds");
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_path[];
-    __shared__ float lut[256];
-    __shared__ int s_cov[kGridThreads / kWave];
-    __shared__ int s_task;
-    const int tid = threadIdx.x, n = a.n, words = a.words;
-    for (int i = tid; i < 256; i += kGridThreads) lut[i] = a.tri_lut[i];
-    const WalkSched sc = sched_of(a.ray_count, n);
-    const int nitems = a.g3 / VPL, gg = g * g;
-    const int x0 = blockIdx.x & 7;
-    for (int xi = 0; xi < 8; ++xi) {
-        const int x = (x0 + xi) & 7;
-        const int ntask = n > x ? ((n - x + 7) >> 3) * kListSlices : 0;  // envs x, x + 8, ...: 16 walk slices / 16 update parts each
-        if (ntask == 0) continue;
-        int *walk_next = sc.walk_next + x * kSchedStride, *upd_next = sc.upd_next + x * kSchedStride;
-        bool walks_left = true;  // (lane 0's view)
-        for (;;) {
-            // ---- claim: >= 0 update task u, <= -2 walk task -2 - t, -1 nothing left on this XCD ----
-            __syncthreads();  // (the previous task is done with s_task / s_path / s_cov)
-            if (tid == 0) {
-                int task = -1;
-                bool have = false;
-                if (walks_left) {
-                    const int u = ld_relaxed_agent(upd_next);
-                    if (u < ntask) {  // head-of-line update: taken only if its env is ready (never wait while walks are left)
-                        const int e = (u >> 4) * 8 + x;
-                        // (compare-and-swap, not fetch-add: a fetch-add that lost a race would hand this workgroup a LATER env's part, whose
-                        // walk tasks may not even be claimed yet -- with every resident workgroup waiting like that, nobody would walk them)
-                        if (ld_relaxed_agent(sc.done + e) >= live_slices((int)min((int64_t)a.ray_count[e], ray_cap)) &&
-                            atomicCAS(upd_next, u, u + 1) == u) { task = u; have = true; }
-                    }
-                    if (!have) {
-                        const int t = atomicAdd(walk_next, 1);
-                        if (t < ntask) { task = -2 - t; have = true; }
-                        else walks_left = false;
-                    }
-                }
-                if (!have) {
-                    const int u2 = atomicAdd(upd_next, 1);
-                    if (u2 < ntask) task = u2;
-                }
-                s_task = task;
-            }
-            __syncthreads();
-            const int task = s_task;
-            if (task == -1) break;
-            if (task <= -2) {
-                // ---- walk task: k_ray_list's workgroup ----
-                const int t = -2 - task, e = (t >> 4) * 8 + x, sl = t & (kListSlices - 1);
-                const int cnt = (int)min((int64_t)a.ray_count[e], ray_cap);
-                if (sl >= live_slices(cnt)) continue;  // (a slice beyond the env's list: not counted in done[e] either)
-                if (cnt > 0) {
-                    for (int i = tid; i < words; i += kGridThreads) s_path[i] = 0u;
-                    const float *pp = poses_xyz + (size_t)e * pose_stride;
-                    const int src[3] = {pose_axis_to_idx(pp[0], range_gt[e * 6 + 1], voxel_size[e * 3 + 0]),
-                                        pose_axis_to_idx(pp[1], range_gt[e * 6 + 3], voxel_size[e * 3 + 1]),
-                                        pose_axis_to_idx(pp[2], range_gt[e * 6 + 5], voxel_size[e * 3 + 2])};
-                    const int32_t *list = ray_list + (size_t)e * ray_cap;
-                    __syncthreads();
-                    const bool src_in = (unsigned)src[0] < (unsigned)g && (unsigned)src[1] < (unsigned)g && (unsigned)src[2] < (unsigned)g;
-                    if (src_in)
-                        walk_slice<true>(src, list, cnt, sl * kListThreads + tid, kListSlices * kListThreads, g, gg, s_path);
-                    else
-                        walk_slice<false>(src, list, cnt, sl * kListThreads + tid, kListSlices * kListThreads, g, gg, s_path);
-                    __syncthreads();
-                    uint32_t *gp = a.path_mask + (size_t)e * words;
-                    for (int i = tid; i < words; i += kGridThreads) {
-                        const uint32_t v = s_path[i];
-                        if (v) atomicOr(&gp[i], v);
-                    }
-                }
-                // publish: every wave's atomics have been performed, then ONE agent-scope release, then the counter
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_fetch_add(sc.done + e, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                continue;
-            }
-            // ---- update task ----
-            const int e = (task >> 4) * 8 + x, part = task & 15;
-            if (tid == 0) {
-                const int need = live_slices((int)min((int64_t)a.ray_count[e], ray_cap));
-                // (ray_count[e] is cleared by part 0 of this env's update: by then done[e] >= every value `need` can still take)
-                // (bounded: ~10^5 polls of >= 1 us each is orders of magnitude beyond any launch; a scheduler that never gets there --
-                // corrupted scheduler words -- becomes a loud error through the overflow flag instead of a hung GPU)
-                int spins = 0;
-                while (ld_relaxed_agent(sc.done + e) < need && ++spins < (1 << 17)) __builtin_amdgcn_s_sleep(8);
-                if (spins >= (1 << 17) && a.overflow != nullptr) atomicOr(a.overflow, 2);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            __syncthreads();
-            const int per = (nitems + 15) >> 4;
-            coded_update_items<VPL>(a, e, part * per, min(nitems, (part + 1) * per), kGridThreads, part == 0, lut, s_cov);
-            // the last part of env e to finish leaves the env's scheduler words zero for the next call
-            if (tid == 0 && __hip_atomic_fetch_add(sc.fin + e, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 15) {
-                __hip_atomic_store(sc.done + e, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(sc.fin + e, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-    // the last workgroup to leave (every claim of this launch has been made) zeroes the task counters
-    if (tid == 0 && __hip_atomic_fetch_add(sc.exits, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
-        for (int x = 0; x < 8; ++x) {
-            __hip_atomic_store(sc.walk_next + x * kSchedStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(sc.upd_next + x * kSchedStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __hip_atomic_store(sc.exits, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
+// (Round 4 tried the ray walk and this update as ONE persistent launch -- workgroups pulling walk tasks and, behind per-env completion
+// counters, update parts: 220 us with a dynamic scheduler and agent-scope release / acquire fences, 196 us without the fences, 115 us
+// with a static schedule, against 27 + 41 us for the two launches.  Returning device-scope atomics cost 2-5 us each under the launch's
+// own memory traffic, and 4 workgroups per CU (the 32 KiB path mask in LDS) are half the waves the HBM-bound update needs to hide its
+// latency.  Removed; profiles/r04_notes.md.)
 
 __global__ void k_decode_prob(const uint8_t *__restrict__ code, int64_t count, const float *__restrict__ prob_lut, float *__restrict__ out)
 {
@@ -1974,8 +1825,7 @@ struct VoxelWorkspace {
 };
 
 GNBV_API size_t gnbv_voxel_workspace_bytes_hw(int n, int g, int h, int w);
-// ray counts [n padded to 64] + the scheduler words of k_walk_update: done / fin [n padded] each, 8 x 16 walk counters, 8 x 16 update counters, exit counter
-static inline size_t ray_count_ints(int n) { return 3 * (((size_t)n + 63) & ~(size_t)63) + 2 * 8 * 16 + 64; }
+static inline size_t ray_count_ints(int n) { return ((size_t)n + 63) & ~(size_t)63; }
 // an env lists one ray per distinct voxel and chunk: never more than its pixels
 static inline int64_t ray_list_cap(int g, int h, int w) { return ((int64_t)h * w + 63) & ~(int64_t)63; }
 
@@ -2096,21 +1946,13 @@ static int voxel_large_mode()
     return (v && (v[0] == '0' || v[0] == '1')) ? v[0] - '0' : -1;
 }
 
-// GENNBV_VOXEL_FUSED_WALK=0: k_ray_list + k_grid_update_coded as two launches instead of the persistent k_walk_update (A/B, parity tests)
-static bool fused_walk_off()
-{
-    const char *v = getenv("GENNBV_VOXEL_FUSED_WALK");
-    return v && v[0] == '0';
-}
-
 // launches 1 + 2 (and the memsets): hit mask and path mask of every env into the workspace
 static int launch_masks(const float *depth_raw, const float *seg_raw, const float *c2w, const float *inv_intri,
                         const float *poses_xyz, int64_t poses_row_stride, const float *range_gt, const float *voxel_size, int n,
                         int h, int w, int g, float depth_sense_dist, int32_t *coverage_count, const VoxelWorkspace &ws,
-                        hipStream_t st, bool masks_are_zero = false, bool *used_lists = nullptr, bool *defer_walk = nullptr)
+                        hipStream_t st, bool masks_are_zero = false, bool *used_lists = nullptr)
 {
     if (used_lists) *used_lists = false;
-    if (defer_walk) *defer_walk = false;
     Intrinsics K;
     int err = fetch_intrinsics(inv_intri, st, &K);
     if (err) return err;
@@ -2166,11 +2008,6 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
 #undef GNBV_HITLIST
         if ((err = gnbv_launch_status())) return err;
         const size_t ray_lds = mask_bytes;
-        // (the caller runs the ray walk inside its grid-update launch: k_walk_update)
-        if (defer_walk != nullptr && ray_lds <= 36 * 1024 && !fused_walk_off()) {
-            *defer_walk = true;
-            return 0;
-        }
         if (ray_lds > 64 * 1024 &&
             hipFuncSetAttribute((const void *)k_ray_list, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ray_lds) != hipSuccess)
             return (int)hipGetLastError();
@@ -2437,9 +2274,9 @@ GNBV_API int gnbv_update_occ_grid_coded(const float *depth_raw, const float *seg
     hipStream_t st = gnbv_stream(stream);
     VoxelWorkspace ws = carve(workspace, workspace_bytes, n, g, h, w);
     const bool clean = (workspace_flags & GNBV_VOXEL_WS_CLEAN) != 0;
-    bool lists = false, walk_pending = false;
+    bool lists = false;
     int err = launch_masks(depth_raw, seg_raw, c2w, inv_intri, poses_xyz, poses_row_stride, range_gt, voxel_size, n, h, w, g,
-                           depth_sense_dist, coverage_count, ws, st, clean, &lists, &walk_pending);
+                           depth_sense_dist, coverage_count, ws, st, clean, &lists);
     if (err) return err;
     const int leave_clean = (clean && lists) ? 1 : 0;  // (the two-launch mask kernels zero what they need themselves)
     GNBV_CHECK_ARG(tri_i8 == nullptr || tri_i8_row_stride >= g3);
@@ -2454,28 +2291,6 @@ GNBV_API int gnbv_update_occ_grid_coded(const float *depth_raw, const float *seg
     ca.n = n; ca.g3 = (int)g3; ca.words = ws.words; ca.words_gt = ws.words; ca.prob_code = prob_code; ca.tri_lut = tri_lut; ca.scanned_bits = scanned_bits;
     ca.tri_out = tri_out; ca.tri_stride = tri_row_stride; ca.tri_i8 = tri_i8; ca.tri_i8_stride = tri_i8_row_stride; ca.coverage = coverage_count;
     ca.overflow = overflow;
-    if (walk_pending) {
-        // ray walk + grid update as one persistent launch: 4 workgroups per CU (33 KiB of LDS each), tasks pulled from the scheduler words
-        static int n_cu = 0;
-        if (n_cu == 0) {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-            n_cu = v;
-        }
-        const int tasks = ((n + 7) / 8) * 8 * kListSlices;
-        int blocks = n_cu * 4;
-        blocks = blocks > 2 * tasks ? 2 * tasks : blocks;
-        blocks = (blocks + 7) & ~7;
-        const size_t lds = (size_t)ws.words * sizeof(uint32_t);
-#define GNBV_LAUNCH_WU(V)                                                                                                             \
-    hipLaunchKernelGGL(k_walk_update<V>, dim3(blocks), dim3(kGridThreads), lds, st, ca, (const int32_t *)ws.ray_list, ws.ray_cap, poses_xyz, poses_row_stride, \
-                       range_gt, voxel_size, g)
-        if (vpl == 16) GNBV_LAUNCH_WU(16);
-        else if (vpl == 4) GNBV_LAUNCH_WU(4);
-        else GNBV_LAUNCH_WU(1);
-#undef GNBV_LAUNCH_WU
-        return gnbv_launch_status();
-    }
     if (vpl == 16) hipLaunchKernelGGL(k_grid_update_coded<16>, dim3(bx, n), dim3(kGridThreads), 0, st, ca);
     else if (vpl == 4) hipLaunchKernelGGL(k_grid_update_coded<4>, dim3(bx, n), dim3(kGridThreads), 0, st, ca);
     else hipLaunchKernelGGL(k_grid_update_coded<1>, dim3(bx, n), dim3(kGridThreads), 0, st, ca);

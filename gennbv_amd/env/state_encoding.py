@@ -82,11 +82,7 @@ class OccupancyGridUpdater:
         decoded from the byte codes on demand (and the saturation flag is checked)."""
         if not self.coded:
             return self._prob_f32
-        flag = int(self.code_overflow.item())
-        if flag & 2:
-            raise _lib.GennbvHipError("k_walk_update: an update task gave up waiting for its env's ray walk (scheduler words of the voxel "
-                                      "workspace corrupted: they must be zero when GNBV_VOXEL_WS_CLEAN is passed)")
-        if flag != 0:
+        if int(self.code_overflow.item()) != 0:
             raise _lib.GennbvHipError("coded probability grid: a voxel saw more than 127 path steps between resets "
                                       "(pass a correct max_steps_between_resets, or none: the fp32 probability grid is used then)")
         n, g = self.num_envs, self.grid_size

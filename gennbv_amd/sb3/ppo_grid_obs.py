@@ -502,16 +502,7 @@ class PPO_Grid_Obs:
         g = st["graph"] if use_graph else None
         if g is None:
             return self._dp_step_body(st)
-        if not isinstance(g, tuple):
-            return g.replay()  # everything, collectives included, in one hipGraph
-        # fallback when the collectives could not be captured: two graphs, eager collectives + tail
-        opt, n_conv = st["opt"], st["n_conv"]
-        g[0].replay()
-        work = dist.all_reduce(opt.grads_with_slot[opt.SLOT + n_conv:], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
-        g[1].replay()
-        dist.all_reduce(opt.grads_with_slot[:opt.SLOT + n_conv], op=dist.ReduceOp.SUM, group=self._sync.group)
-        work.wait()
-        self._hip_minibatch_tail(st)
+        return g.replay()  # everything, collectives included, in one hipGraph
 
     def _train_hip(self) -> None:
         """train() on the gfx950 kernels (`_train_hip_once`), made safe against the operand ranges of the split-f16 arithmetic: the
@@ -601,7 +592,7 @@ class PPO_Grid_Obs:
         loss.stop_flag.zero_()
         idx = torch.from_numpy(np.asarray(buf.indices, dtype=np.int64)).to(self.device)
         rows_all = buf.rows_of(idx)  # the reference's flattened index -> row of the [T, N] layout
-        use_graph = self.use_graph and self.device.type == "cuda"
+        use_graph = self.use_graph and self.device.type == "cuda" and not st.get("graph_refused")
         hyper = (float(lr), float(clip_range), None if clip_range_vf is None else float(clip_range_vf))
         if st.get("hyper") != hyper:
             st["graph"], st["hyper"] = None, hyper  # kernel arguments are baked into the graph: re-capture
@@ -661,6 +652,8 @@ class PPO_Grid_Obs:
             else:
                 loss.rows.copy_(rows_all[:batch])
             st["graph"] = self._capture_minibatch_graph(st)
+            if st["graph"] is None:  # (data-parallel only: the collectives could not be captured -> eager steps from here on)
+                st["graph_refused"], use_graph = True, False
             loss.stats_row.zero_()
             loss.stop_flag.zero_()
             if rotating:
@@ -749,51 +742,30 @@ class PPO_Grid_Obs:
             with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                 self._hip_minibatch_body(st)
             return ga
-        try:
-            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
-                self._dp_step_body(st)
-            self.dp_graph_mode = "one hipGraph incl. RCCL collectives"
-            return ga
-        except Exception as ex:  # collectives not capturable on this stack: capture the compute only
-            if getattr(st["opt"], "shard", None) is not None:
-                # fall back to the all-reduced, replicated update, whose collectives sit between the two graphs.  Safe also when an
-                # EARLIER train() call ran sharded steps (a re-capture after lr / clip_range changed): captures only happen at the start
-                # of a train() call, the warm-up and the failed capture ran with the update masked, and every train() call ends by
-                # gathering the owners' moments into every rank's buffers (`_train_hip_once`) -- all ranks hold the complete Adam state
-                st["opt"].shard = None
-            self.dp_graph_mode = f"two compute graphs + eager collectives ({type(ex).__name__})"
-            if self.verbose >= 1:
-                print(f"[gennbv_amd] RCCL capture failed ({ex!r}); using two compute graphs + eager collectives")
-            self._abandon_capture()
-        # (a fresh capture stream: the one the refused capture ran on may still be in the `invalidated` capture state)
-        cap = torch.cuda.Stream(self.device)
-        ga = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga, stream=cap, capture_error_mode="thread_local"):
-            self._hip_minibatch_body(st, "A")
-        gb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gb, pool=ga.pool(), stream=cap, capture_error_mode="thread_local"):
-            self._hip_minibatch_body(st, "B")
-        return (ga, gb)
+        if not self._collectives_capturable():
+            # Fall back to the EAGER data-parallel step (same `_dp_step_body`, same sharded update, launch by launch): the compute cannot be
+            # captured by itself either -- BatchNorm's batch sums are exchanged inside the encoder calls (GnbvEncoderParams.sync_sum), so
+            # every piece of the step contains a collective.  (Rounds 2-3 fell back to "two compute graphs + eager collectives"; the
+            # first 2-rank test of that path, round 4, showed it cannot work: the second capture dies on the same collective.)
+            loss.stop_flag.zero_()
+            return None
+        with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+            self._dp_step_body(st)
+        self.dp_graph_mode = "one hipGraph incl. RCCL collectives"
+        return ga
 
-    def _abandon_capture(self) -> None:
-        """After a capture that was refused half-way (a collective that cannot be captured invalidates the capture): end it on the
-        capture stream torch keeps for `torch.cuda.graph` -- the failed `capture_end` raised before it cleared the stream's status,
-        and a stream left `invalidated` refuses every later capture ("Cannot register the state during capturing stage") -- and make
-        torch pick a new default capture stream."""
-        import ctypes
-        cap = getattr(torch.cuda.graph, "default_capture_stream", None)
-        try:
-            hip = ctypes.CDLL("libamdhip64.so")
-            for s_ in ([cap] if cap is not None else []) + [torch.cuda.current_stream(self.device)]:
-                g = ctypes.c_void_p()
-                hip.hipStreamEndCapture(ctypes.c_void_p(s_.cuda_stream), ctypes.byref(g))  # (an error code here is the expected outcome)
-                if g.value:
-                    hip.hipGraphDestroy(g)
-            hip.hipGetLastError()
-        except OSError:
-            pass
-        torch.cuda.graph.default_capture_stream = None
-        torch.cuda.synchronize(self.device)
+    def _collectives_capturable(self) -> bool:
+        """Can this process group's collectives be recorded into a hipGraph?  RCCL (backend "nccl"): yes -- the step, collectives
+        included, is one graph.  Anything else (gloo on device tensors: the multi-rank tests on one GPU) synchronises the stream inside
+        the collective, which a capture refuses -- and a capture refused half-way cannot be cleaned up from Python (torch's
+        `capture_end` raises before it restores the current stream, the stream stays `invalidated`, later collectives fail from the
+        autograd thread: tried in round 4), so the question is answered from the backend's name BEFORE anything is captured."""
+        import torch.distributed as dist
+        backend = str(dist.get_backend(self._sync.group)).lower()
+        ok = "nccl" in backend
+        if not ok:
+            self.dp_graph_mode = f"eager launches (the {backend} backend's collectives cannot be captured)"
+        return ok
 
     # ------------------------------------------------------------------------------
     def _env_step(self, actions, obs_out):

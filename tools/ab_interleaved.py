@@ -63,7 +63,7 @@ def build_train(a, dev):
     import torch
     import bench
     ns = argparse.Namespace(gpus=1, steps=1, warmup=0, envs=a.envs, grid=a.grid, height=a.height, width=a.width, n_steps=a.n_steps, batch_size=a.batch_size,
-                            n_epochs=1, frames=2, backend="hip", obs="compact", target_kl="off", semantic=a.semantic, no_cpu_baseline=True,
+                            n_epochs=16, frames=2, backend="hip", obs="compact", target_kl="off", semantic=a.semantic, no_cpu_baseline=True,
                             gemm_tuning=False, save_gemm_tuning=None, no_flat_rows=True, no_state_check=True)
     algo, cfg, env = bench.build_algo(ns, dev, 0, 1)
     algo.learning_rate = 1e-12
@@ -74,7 +74,9 @@ def build_train(a, dev):
     g = algo._hip["graph"]
     assert g is not None and not isinstance(g, tuple)
     torch.cuda.synchronize()
-    return (lambda: g.replay()), algo
+    loss = algo._hip["loss"]
+    assert loss.stats.shape[0] > 64  # (every replay appends a row to the statistics table: the chunk must fit, `reset` rewinds it)
+    return {"fn": (lambda: g.replay()), "reset": (lambda: loss.stats_row.zero_()), "max_chunk": int(loss.stats.shape[0]) - 2}, algo
 
 
 def build_voxel(a, dev):
@@ -124,6 +126,9 @@ def main():
     ap.add_argument("--what", default="train", choices=["train", "voxel", "rollout"])
     ap.add_argument("--variant", action="append", required=True)
     ap.add_argument("--rounds", type=int, default=20)
+    ap.add_argument("--captures", type=int, default=1, help="independent builds / graph captures per variant: a replayed hipGraph lands in one of "
+                    "several states per CAPTURE (+-12 us per minibatch between two captures of the same library, +-0.4 us inside one), so a "
+                    "kernel change is only resolved against the spread over captures")
     ap.add_argument("--chunk", type=int, default=None, help="calls per timed chunk (default: 50 train / 50 voxel / 1 rollout)")
     ap.add_argument("--envs", type=int, default=256)
     ap.add_argument("--grid", type=int, default=64)
@@ -142,38 +147,66 @@ def main():
     chunk = a.chunk or {"train": 50, "voxel": 50, "rollout": 1}[a.what]
     per_call_div = a.n_steps if a.what == "rollout" else 1
     variants = []
-    for v in a.variant:
+    for v in [x for _ in range(a.captures) for x in a.variant]:
         name, env, lib = parse_variant(v)
         print(f"[ab] building variant {name} env={env} lib={lib}", file=sys.stderr, flush=True)
         with _Env(env):
             _lib.activate(lib)
             fn, keep = build(a, dev)
+        if not isinstance(fn, dict):
+            fn = {"fn": fn}
+        if a.what != "train":  # eager launches read the library's switches at CALL time: the variant's environment / library around every chunk
+            fn["chunk_ctx"] = (env, lib)
         torch.cuda.synchronize()
         print(f"[ab] variant {name} built and captured", file=sys.stderr, flush=True)
-        variants.append({"name": name, "env": env, "lib": lib, "fn": fn, "keep": keep, "t": []})
+        variants.append({"name": name, "env": env, "lib": lib, "fn": fn["fn"], "reset": fn.get("reset"), "ctx": fn.get("chunk_ctx"), "keep": keep, "t": []})
+        if fn.get("max_chunk"):
+            chunk = min(chunk, fn["max_chunk"])
     _lib.activate(None)
     # GPU-busy warm-up (leave the idle power state: 0.3 s of the first variant), then the alternating rounds
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < 0.3:
-        for _ in range(chunk):
-            variants[0]["fn"]()
-        torch.cuda.synchronize()
+    def run_chunk(v, timed: bool):
+        env, lib = v["ctx"] if v["ctx"] else ({}, None)
+        with _Env(env if v["ctx"] else {}):
+            if v["ctx"]:
+                _lib.activate(lib)
+            if v["reset"]:
+                v["reset"]()
+            v["fn"]()  # one untimed call: the variant's code / data back in the caches
+            if timed:
+                ev0.record()
+            for _ in range(chunk):
+                v["fn"]()
+            if timed:
+                ev1.record()
+            torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) * 1e3 / chunk / per_call_div if timed else None
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    while time.perf_counter() - t0 < 0.3:
+        run_chunk(variants[0], False)
     for r in range(a.rounds):
         if r < 2:
             print(f"[ab] round {r}", file=sys.stderr, flush=True)
         order = variants[r % len(variants):] + variants[:r % len(variants)]  # rotate who goes first
         for v in order:
-            v["fn"]()  # one untimed call: the variant's code / data back in the caches
-            ev0.record()
-            for _ in range(chunk):
-                v["fn"]()
-            ev1.record()
-            torch.cuda.synchronize()
-            v["t"].append(ev0.elapsed_time(ev1) * 1e3 / chunk / per_call_div)  # us per call
+            v["t"].append(run_chunk(v, True))  # us per call
     unit = {"train": "us / minibatch", "voxel": "us / update", "rollout": "us / env step"}[a.what]
     base = variants[0]
     out = {"what": a.what, "unit": unit, "rounds": a.rounds, "chunk": chunk, "device": torch.cuda.get_device_name(0), "variants": []}
+    if a.captures > 1:  # pool the captures of a variant: the spread over captures is the noise floor of a comparison
+        names = []
+        for v in variants:
+            if v["name"] not in names:
+                names.append(v["name"])
+        print(f"# {a.captures} captures per variant; per-capture medians and the pooled figure:")
+        pooled = []
+        for nm in names:
+            caps = [statistics.median(v["t"]) for v in variants if v["name"] == nm]
+            allt = [x for v in variants if v["name"] == nm for x in v["t"]]
+            print(f"#   {nm:18s} captures: " + " ".join(f"{c:8.2f}" for c in caps) + f"   mean of captures {sum(caps) / len(caps):8.2f}, spread {max(caps) - min(caps):5.2f}")
+            pooled.append({"name": nm, "capture_medians": caps, "mean_of_captures": sum(caps) / len(caps), "min_capture": min(caps), "max_capture": max(caps),
+                           "median_all": statistics.median(allt)})
+        out["pooled"] = pooled
     for v in variants:
         med = statistics.median(v["t"])
         mad = statistics.median(abs(x - med) for x in v["t"])

@@ -23,6 +23,13 @@ case $st in
   abtrain2) timeout 600 python tools/ab_interleaved.py --what train --variant base --variant "twokernel:GENNBV_FUSED_TRAIN=0" --rounds 12 --json $O/r4_ab_train2.json 2>&1 | tail -12 ;;
   voxprof) python tools/microbench_voxel.py 2>&1 | tail -2; cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_v; rocprofv3 --kernel-trace --stats -d /tmp/prof_v -- python $GRAFT_REPO_ROOT/tools/microbench_voxel.py > /dev/null 2>&1; python $GRAFT_REPO_ROOT/tools/rocprof_summary.py /tmp/prof_v | grep -E "^kernel|k_|rocclr" | cut -c1-190 | tee $O/r4_voxel_kernel_trace.txt; cd $GRAFT_REPO_ROOT ;;
   dp1prof) GENNBV_FORCE_DP=1 GENNBV_FORCE_SHARD=1 bash tools/prof_minibatch.sh r4_dp1_mb 2>&1 | tail -3 ;;
+  enctests) timeout 1200 python -m pytest tests/test_encoder_gpu.py tests/test_ppo_g64_gpu.py tests/test_range_guard_gpu.py -m gpu -q -x -p no:cacheprovider --durations=8 > $O/r4_enctests.log 2>&1; tail -14 $O/r4_enctests.log ;;
+  partests2) timeout 900 python -m pytest tests/test_parallel_gpu.py -m gpu -q -p no:cacheprovider > $O/r4_partests2.log 2>&1; tail -8 $O/r4_partests2.log | cut -c1-300 ;;
+  abold)   timeout 900 python tools/ab_interleaved.py --what train --variant "old:LIB=gennbv_amd/libgennbv_hip_old.so" --variant new --variant "old2:LIB=gennbv_amd/libgennbv_hip_old.so" --rounds 16 --json $O/r4_ab_train_old_new.json 2>&1 | tail -8 ;;
+  abvoxold) timeout 600 python tools/ab_interleaved.py --what voxel --variant "old:LIB=gennbv_amd/libgennbv_hip_old.so" --variant new --rounds 20 --json $O/r4_ab_voxel_old_new.json 2>&1 | tail -5 ;;
+  convprof) cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_c; rocprofv3 --kernel-trace --stats -d /tmp/prof_c -- python $GRAFT_REPO_ROOT/tools/microbench_conv.py > /dev/null 2>&1; python $GRAFT_REPO_ROOT/tools/rocprof_summary.py /tmp/prof_c | grep -E "^kernel|k_" | cut -c1-190 | tee $O/r4_conv_kernel_trace.txt; cd $GRAFT_REPO_ROOT ;;
+  abold3)  timeout 1200 python tools/ab_interleaved.py --what train --captures 3 --variant "old:LIB=gennbv_amd/libgennbv_hip_old.so" --variant new --rounds 10 --json $O/r4_ab_train_old_new_c3.json 2>&1 | grep -v "^\[ab\]" | tail -14 ;;
+  partests3) timeout 600 python -m pytest tests/test_parallel_gpu.py -m gpu -q -p no:cacheprovider -k "2-" > $O/r4_partests3.log 2>&1; tail -8 $O/r4_partests3.log | cut -c1-300 ;;
   *) echo "unknown stage $st" ;;
 esac
 done
