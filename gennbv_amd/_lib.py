@@ -151,7 +151,7 @@ _lib = None
 _loaded = {}
 
 
-def _open(path: str):
+def _open(path: str, strict: bool = True):
     if path in _loaded:
         return _loaded[path]
     if not os.path.exists(path):
@@ -160,7 +160,12 @@ def _open(path: str):
             "(or __graft_entry__.build()).  gennbv_amd has no CPU fallback.")
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        try:
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        except AttributeError:
+            if strict:
+                raise
+            continue  # (activate(): an OLDER build of the same ABI under A/B may lack entry points added since)
         fn.restype = res
         fn.argtypes = args
     if lib.gnbv_abi_version() != 4:
@@ -182,7 +187,7 @@ def activate(path=None):
     Two builds can live in one process -- kernels are bound when a call / a hipGraph capture is made, so objects built and graphs
     captured while a library was active keep running its kernels."""
     global _lib
-    _lib = _open(os.path.abspath(path) if path else LIB_PATH)
+    _lib = _open(os.path.abspath(path), strict=False) if path else _open(LIB_PATH)
     return _lib
 
 

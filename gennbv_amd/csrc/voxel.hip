@@ -1531,42 +1531,24 @@ __device__ __forceinline__ uint32_t step_code(uint32_t c, bool hit, bool path, i
 // VPL voxels per lane and trip: 1 (unaligned rows), 4 (one 4-byte code word in, one 16-byte fp32 tri vector out) or
 // 16 (int8-only observations, tri_out == NULL: 16-byte code vector in/out, 16-byte int8 tri vector out).  Every
 // request is coalesced.  Either tri_out (fp32 observation rows) or tri_i8 (compact rows) may be NULL, not both.
-struct CodedGridArgs {
-    uint32_t *hit_mask, *path_mask;  // (not restrict: cleared in passing when `clean`)
-    int clean;
-    int32_t *ray_count;
-    const uint32_t *gt_bits;
-    const uint8_t *reset_mask;
-    int n, g3, words, words_gt;
-    uint8_t *prob_code;
-    const float *tri_lut;
-    uint32_t *scanned_bits;
-    float *tri_out;
-    int64_t tri_stride;
-    int8_t *tri_i8;
-    int64_t tri_i8_stride;
-    int32_t *coverage, *overflow;
-};
-
-// The update of env e's lane-items [first, end) in steps of `stride` (an item = VPL voxels) by ONE workgroup; `owner`: this workgroup
-// also clears the env's ray count.  lut / s_cov: the workgroup's LDS (tri-class table loaded by the caller).
 template <int VPL>
-__device__ __forceinline__ void coded_update_items(const CodedGridArgs &a, const int e, const int first, const int end, const int stride, const bool owner,
-                                                   const float *lut, int *s_cov)
+__global__ __launch_bounds__(kGridThreads) void k_grid_update_coded(
+    uint32_t *hit_mask, uint32_t *path_mask /*(not restrict: cleared in passing when `clean`)*/, int clean, int32_t *ray_count,
+    const uint32_t *__restrict__ gt_bits,
+    const uint8_t *__restrict__ reset_mask, int n, int g3, int words, int words_gt, uint8_t *__restrict__ prob_code,
+    const float *__restrict__ tri_lut, uint32_t *__restrict__ scanned_bits, float *__restrict__ tri_out, int64_t tri_stride,
+    int8_t *__restrict__ tri_i8, int64_t tri_i8_stride, int32_t *__restrict__ coverage, int32_t *__restrict__ overflow)
 {
-    const int words = a.words, words_gt = a.words_gt, g3 = a.g3, clean = a.clean;
-    const bool reset = a.reset_mask != nullptr && a.reset_mask[e] != 0;
-    uint32_t *hm = a.hit_mask + (size_t)e * words, *pm = a.path_mask + (size_t)e * words;
+    __shared__ float lut[256];
+    __shared__ int s_cov[kGridThreads / kWave];
+    for (int i = threadIdx.x; i < 256; i += kGridThreads) lut[i] = tri_lut[i];
+    __syncthreads();
+    const int e = blockIdx.y;
+    const bool reset = reset_mask != nullptr && reset_mask[e] != 0;
+    uint32_t *hm = hit_mask + (size_t)e * words, *pm = path_mask + (size_t)e * words;
     // `clean`: the masks and the ray count are left ZERO for the next call (the word's owner lane clears it after every lane
     // that shares the word -- neighbours in the same wave, same instruction -- has loaded it): saves the 16 MB fill launch
-    if (clean && a.ray_count != nullptr && owner && threadIdx.x == 0) a.ray_count[e] = 0;
-    const uint32_t *gt_bits = a.gt_bits;
-    uint32_t *scanned_bits = a.scanned_bits;
-    uint8_t *prob_code = a.prob_code;
-    float *tri_out = a.tri_out;
-    const int64_t tri_stride = a.tri_stride, tri_i8_stride = a.tri_i8_stride;
-    int8_t *tri_i8 = a.tri_i8;
-    int32_t *coverage = a.coverage, *overflow = a.overflow;
+    if (clean && ray_count != nullptr && blockIdx.x == 0 && threadIdx.x == 0) ray_count[e] = 0;
     const uint32_t *gb = gt_bits + (size_t)e * words_gt;
     uint32_t *sb = scanned_bits + (size_t)e * words_gt;
     uint8_t *code = prob_code + (size_t)e * g3;
@@ -1576,7 +1558,8 @@ __device__ __forceinline__ void coded_update_items(const CodedGridArgs &a, const
     if constexpr (VPL > 1) {
         constexpr int NW = VPL / 4;  // 4-voxel words per lane
         constexpr uint32_t kBits = (1u << VPL) - 1u;
-        for (int i = first + threadIdx.x; i < end; i += stride) {
+        const int nv = g3 / VPL;
+        for (int i = blockIdx.x * kGridThreads + threadIdx.x; i < nv; i += gridDim.x * kGridThreads) {
             const int v0 = i * VPL, wd = v0 >> 5, sh = v0 & 31;
             const uint32_t hw = hm[wd], pw = pm[wd];
             const uint32_t hb = (hw >> sh) & kBits, pb = (pw >> sh) & kBits;
@@ -1618,7 +1601,7 @@ __device__ __forceinline__ void coded_update_items(const CodedGridArgs &a, const
             }
         }
     } else {
-        for (int v = first + threadIdx.x; v < end; v += stride) {
+        for (int v = blockIdx.x * kGridThreads + threadIdx.x; v < g3; v += gridDim.x * kGridThreads) {
             const int wd = v >> 5;
             const uint32_t hw = hm[wd];
             const bool hb = (hw >> (v & 31)) & 1u, pb = (pm[wd] >> (v & 31)) & 1u;
@@ -1646,21 +1629,12 @@ __device__ __forceinline__ void coded_update_items(const CodedGridArgs &a, const
     }
 }
 
-template <int VPL>
-__global__ __launch_bounds__(kGridThreads) void k_grid_update_coded(const CodedGridArgs a)
-{
-    __shared__ float lut[256];
-    __shared__ int s_cov[kGridThreads / kWave];
-    for (int i = threadIdx.x; i < 256; i += kGridThreads) lut[i] = a.tri_lut[i];
-    __syncthreads();
-    coded_update_items<VPL>(a, blockIdx.y, blockIdx.x * kGridThreads, a.g3 / VPL, gridDim.x * kGridThreads, blockIdx.x == 0, lut, s_cov);
-}
-
 // (Round 4 tried the ray walk and this update as ONE persistent launch -- workgroups pulling walk tasks and, behind per-env completion
 // counters, update parts: 220 us with a dynamic scheduler and agent-scope release / acquire fences, 196 us without the fences, 115 us
 // with a static schedule, against 27 + 41 us for the two launches.  Returning device-scope atomics cost 2-5 us each under the launch's
 // own memory traffic, and 4 workgroups per CU (the 32 KiB path mask in LDS) are half the waves the HBM-bound update needs to hide its
-// latency.  Removed; profiles/r04_notes.md.)
+// latency.  Even the refactoring it needed -- this kernel's arguments as one struct, its body as a function over an item range with a
+// run-time stride -- cost 5.6 us per update (104.7 -> 110.4, same-box A/B) and was reverted with it.  profiles/r04_notes.md)
 
 __global__ void k_decode_prob(const uint8_t *__restrict__ code, int64_t count, const float *__restrict__ prob_lut, float *__restrict__ out)
 {
@@ -2286,14 +2260,14 @@ GNBV_API int gnbv_update_occ_grid_coded(const float *depth_raw, const float *seg
                        ((((uintptr_t)tri_i8 | (uintptr_t)tri_i8_row_stride) & 15) == 0);
     const int vpl = vec16 ? 16 : vec4 ? 4 : 1;
     const int bx = grid_update_blocks(g3 / vpl, n);
-    CodedGridArgs ca;
-    ca.hit_mask = ws.hit; ca.path_mask = ws.path; ca.clean = leave_clean; ca.ray_count = ws.ray_count; ca.gt_bits = gt_bits; ca.reset_mask = reset_mask;
-    ca.n = n; ca.g3 = (int)g3; ca.words = ws.words; ca.words_gt = ws.words; ca.prob_code = prob_code; ca.tri_lut = tri_lut; ca.scanned_bits = scanned_bits;
-    ca.tri_out = tri_out; ca.tri_stride = tri_row_stride; ca.tri_i8 = tri_i8; ca.tri_i8_stride = tri_i8_row_stride; ca.coverage = coverage_count;
-    ca.overflow = overflow;
-    if (vpl == 16) hipLaunchKernelGGL(k_grid_update_coded<16>, dim3(bx, n), dim3(kGridThreads), 0, st, ca);
-    else if (vpl == 4) hipLaunchKernelGGL(k_grid_update_coded<4>, dim3(bx, n), dim3(kGridThreads), 0, st, ca);
-    else hipLaunchKernelGGL(k_grid_update_coded<1>, dim3(bx, n), dim3(kGridThreads), 0, st, ca);
+#define GNBV_LAUNCH_CODED(V)                                                                                                          \
+    hipLaunchKernelGGL(k_grid_update_coded<V>, dim3(bx, n), dim3(kGridThreads), 0, st, ws.hit, ws.path, leave_clean, ws.ray_count, gt_bits, reset_mask, n, (int)g3, \
+                       ws.words, ws.words, prob_code, tri_lut, scanned_bits, tri_out, tri_row_stride, tri_i8, tri_i8_row_stride,        \
+                       coverage_count, overflow)
+    if (vpl == 16) GNBV_LAUNCH_CODED(16);
+    else if (vpl == 4) GNBV_LAUNCH_CODED(4);
+    else GNBV_LAUNCH_CODED(1);
+#undef GNBV_LAUNCH_CODED
     return gnbv_launch_status();
 }
 

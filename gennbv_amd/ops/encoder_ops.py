@@ -42,7 +42,7 @@ class RowGather:
         assert compact_state_dim is None or grid_i8 is not None
         self.grid_i8, self.compact_state_dim = grid_i8, compact_state_dim
         self.shape = (rows.shape[0], base.shape[1] + (0 if compact_state_dim is None else grid_i8.shape[1]))
-        self.device = base.device
+        self.device, self.is_cuda = base.device, base.is_cuda
 
     def float(self):
         return self

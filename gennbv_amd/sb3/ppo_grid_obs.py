@@ -852,6 +852,9 @@ class PPO_Grid_Obs:
                 # ONE policy evaluation of new_obs: its value is the time-out bootstrap of this
                 # step (:205-208) and its action / value / log-prob are next step's (:168).
                 # The last step only needs the value (:213-215) and must not draw from the RNG.
+                # (a replayed hipGraph of this evaluation -- two alternating graphs over RowGather(all rows, device-side rows) -- was
+                # measured in round 4: 535 against 509 us per env step; the step is not host-bound enough to pay for the graph's
+                # cross-queue hand-overs.  profiles/r04_notes.md)
                 new_in = self._with_grid_i8(new_obs, rollout_buffer.step + 1)  # (the buffer's step counter advances in add())
                 if n_steps < n_rollout_steps:
                     nxt = self.policy(new_in)

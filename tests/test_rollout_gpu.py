@@ -53,3 +53,4 @@ def test_hip_rollout_reproduces_reference_collect_rollouts(fused_add, monkeypatc
         assert np.array_equal(buf.observations[t].cpu().numpy(), last)
         ru.check_rollout(fx, r, buf, algo, value_tol=2e-5)
     assert algo.num_timesteps == int(fx["num_timesteps"])
+

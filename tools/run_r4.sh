@@ -30,6 +30,10 @@ case $st in
   convprof) cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_c; rocprofv3 --kernel-trace --stats -d /tmp/prof_c -- python $GRAFT_REPO_ROOT/tools/microbench_conv.py > /dev/null 2>&1; python $GRAFT_REPO_ROOT/tools/rocprof_summary.py /tmp/prof_c | grep -E "^kernel|k_" | cut -c1-190 | tee $O/r4_conv_kernel_trace.txt; cd $GRAFT_REPO_ROOT ;;
   abold3)  timeout 1200 python tools/ab_interleaved.py --what train --captures 3 --variant "old:LIB=gennbv_amd/libgennbv_hip_old.so" --variant new --rounds 10 --json $O/r4_ab_train_old_new_c3.json 2>&1 | grep -v "^\[ab\]" | tail -14 ;;
   partests3) timeout 600 python -m pytest tests/test_parallel_gpu.py -m gpu -q -p no:cacheprovider -k "2-" > $O/r4_partests3.log 2>&1; tail -8 $O/r4_partests3.log | cut -c1-300 ;;
+  semantic) timeout 900 python bench.py --steps 3 --warmup 1 --semantic --no-cpu-baseline --no-flat-rows 2>/dev/null | tail -1 > $O/r4_bench_semantic_n1.json; cut -c1-300 $O/r4_bench_semantic_n1.json ;;
+  config5) timeout 1500 python bench.py --steps 1 --warmup 1 --envs 512 --grid 128 --no-cpu-baseline --no-flat-rows 2>/dev/null | tail -1 > $O/r4_bench_config5_shard_n1.json; cut -c1-300 $O/r4_bench_config5_shard_n1.json ;;
+  rolltests) timeout 900 python -m pytest tests/test_rollout_gpu.py tests/test_fullsize_gpu.py tests/test_ppo_gpu.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -8 ;;
+  abroll)  timeout 600 python tools/ab_interleaved.py --what rollout --n-steps 32 --variant graph --variant "eager:ROLLOUT_GRAPH=0" --rounds 8 --json $O/r4_ab_rollout.json 2>&1 | tail -4 ;;
   *) echo "unknown stage $st" ;;
 esac
 done
