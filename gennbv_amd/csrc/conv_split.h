@@ -84,6 +84,16 @@ __device__ __forceinline__ void prep_w2_split_item(int i, const float *__restric
 // planes of z1 = 2^8 relu(bn1(y1)).  Request k of a thread: region rs = 4 k + (wave >> 1) = 2 plane + (row & 1 ^ 1), the 16-byte
 // piece `within` of that 2 KiB row.  Everything that selects a request is wave-uniform and the requests are UNCONDITIONAL
 // (clamped into the sample): a branch around a load makes the compiler wait for every load at the join.
+// NON-TEMPORAL requests for the streams of the minibatch that nothing re-reads soon (round 4): y1 (244 MB: written once by the training
+// forward, read once by each backward kernel), and in csrc/ppo.hip the optimizer's moments and gradient.  Same-process A/B over
+// three captures each (profiles/r04_notes.md): the y1 STORE as `nt` 581 -> 560 us per minibatch, the y1 LOADS -12.6, Adam's m / v / g
+// -16.3 -- the streams no longer push what IS reused (fc_grid's weight and its gradient, 55 MB each, the parameters) out of L2 and
+// the memory-side cache.  (The same flavour on k_grid_update_coded's stores made the voxel update 5 us SLOWER: measured, not assumed.)
+__device__ __forceinline__ float4 ld4_nt(const float *p)
+{
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
 struct ZStager {
     const float *ybase;
     uint32_t rowC, planeC, st_lane;
@@ -110,7 +120,7 @@ struct ZStager {
 #pragma unroll
         for (int k = 0; k < split::kSlots; ++k) {
             const int rs = 4 * k + half, pi = min(rs >> 1, npl - 1), row = min(max(2 * j + 1 + (rs & 1), 0), O1 - 1);
-            regs[k] = *reinterpret_cast<const float4 *>(ybase + (uint32_t)pi * planeC + (uint32_t)row * rowC);
+            regs[k] = ld4_nt(ybase + (uint32_t)pi * planeC + (uint32_t)row * rowC);  // (y1 is streamed: read once per launch)
         }
     }
     // ZERO_PAD: the padding voxel is stored as 0 instead of whatever the (never written) y1 slot holds -- needed where an
@@ -752,7 +762,7 @@ __device__ __forceinline__ void conv2_dgrad_c1w_split_body(
         // the inputs of step c: y1 rows 2c, 2c+1 of planes 2 a0 .. 2 a0 + 7; dy2 row c
         auto y_req = [&](int k, int c) {
             const int rowid = 2 * k + (ptid >> 7), pl = 2 * a0 + (rowid >> 1), row = 2 * c + (rowid & 1);  // (wave-uniform)
-            return *reinterpret_cast<const float4 *>(ybase + (uint32_t)min(pl, O1 - 1) * planeC + (uint32_t)min(max(row, 0), O1 - 1) * rowC);
+            return ld4_nt(ybase + (uint32_t)min(pl, O1 - 1) * planeC + (uint32_t)min(max(row, 0), O1 - 1) * rowC);
         };
         auto y_store = [&](int k, const float4 &v, int c) { *reinterpret_cast<float4 *>(ybufs + (c & 1) * kYBuf + (2 * k + (ptid >> 7)) * kYRow + yst) = v; };
         static_assert(kYSlots == 8, "eight y1 requests per staging thread");
@@ -1088,7 +1098,7 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
                     const bool own = (bool)((int)(row >= 0) & (int)(row < O1) & ((int)(pi < 2 * np) | ((int)(pi == 2 * np) & (int)(oz1 == O2))));
                     const uint32_t rowbase = vox1(b, min(2 * oz0 + pi, O1 - 1), min(max(row, 0), O1 - 1), 0, O1) * kC;
                     char *dst1 = reinterpret_cast<char *>(y1 + __builtin_amdgcn_readfirstlane(rowbase));
-                    *reinterpret_cast<float4 *>(dst1 + (own ? 4 * y1_lane : 4 * y1_pad)) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+                    __builtin_nontemporal_store((f32x4){yv[0], yv[1], yv[2], yv[3]}, reinterpret_cast<f32x4 *>(dst1 + (own ? 4 * y1_lane : 4 * y1_pad)));
                 }
                 char *dst = stage + (pi * kRing + slot) * kRowBytes + par * 1024 + n * 32 + g * 8;
                 *reinterpret_cast<h4 *>(dst) = hi;

@@ -433,15 +433,41 @@ __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, 
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
     const int64_t gap = skip_hi > skip_lo ? skip_hi - skip_lo : 0;  // (the grid covers the n - gap live elements only)
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n - gap; j += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = j < skip_lo ? j : j + gap;
-        const float gi = g[i] * coef;
-        const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);  // exp_avg.lerp_(grad, 1 - beta1)
-        const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;  // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
-        m[i] = mi;
-        v[i] = vi;
+    const int64_t live = n - gap, stride = (int64_t)gridDim.x * blockDim.x;
+    auto one = [&](float &pp, const float gg, float &mm, float &vv) {
+        const float gi = gg * coef;
+        const float mi = mm + (gi - mm) * (1.0f - beta1);  // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = vv * beta2 + (1.0f - beta2) * gi * gi;  // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+        mm = mi;
+        vv = vi;
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] = p[i] - step_size * (mi / denom);
+        pp = pp - step_size * (mi / denom);
+    };
+    // 16-byte requests (four elements per lane and trip, the same expressions per element: the same bits) where the four streams are
+    // aligned and the skipped slice starts and ends on a multiple of four (by itself no faster than 4-byte requests: measured; what
+    // pays is the cache policy below)
+    const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && (gap == 0 || (((skip_lo | gap) & 3) == 0));
+    const int64_t n4 = vec ? live / 4 : 0;
+    for (int64_t j4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j4 < n4; j4 += stride) {
+        const int64_t j = 4 * j4, i = j < skip_lo ? j : j + gap;
+        // (m, v and g are streamed -- their next use is a whole minibatch away, behind ~2 GB of other traffic: non-temporal both ways;
+        // the parameters are read again by the next forward: plain.  -16 us per minibatch, csrc/conv_split.h ld4_nt)
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        auto ldnt = [](const float *q) { const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(q)); return make_float4(t[0], t[1], t[2], t[3]); };
+        auto stnt = [](float *q, const float4 &t) { __builtin_nontemporal_store((f4v){t.x, t.y, t.z, t.w}, reinterpret_cast<f4v *>(q)); };
+        float4 p4 = *reinterpret_cast<const float4 *>(p + i), m4 = ldnt(m + i), v4 = ldnt(v + i);
+        const float4 g4 = ldnt(g + i);
+        one(p4.x, g4.x, m4.x, v4.x);
+        one(p4.y, g4.y, m4.y, v4.y);
+        one(p4.z, g4.z, m4.z, v4.z);
+        one(p4.w, g4.w, m4.w, v4.w);
+        stnt(m + i, m4);
+        stnt(v + i, v4);
+        *reinterpret_cast<float4 *>(p + i) = p4;
+    }
+    for (int64_t j = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < live; j += stride) {
+        const int64_t i = j < skip_lo ? j : j + gap;
+        one(p[i], g[i], m[i], v[i]);
     }
 }
 

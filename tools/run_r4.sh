@@ -34,6 +34,10 @@ case $st in
   config5) timeout 1500 python bench.py --steps 1 --warmup 1 --envs 512 --grid 128 --no-cpu-baseline --no-flat-rows 2>/dev/null | tail -1 > $O/r4_bench_config5_shard_n1.json; cut -c1-300 $O/r4_bench_config5_shard_n1.json ;;
   rolltests) timeout 900 python -m pytest tests/test_rollout_gpu.py tests/test_fullsize_gpu.py tests/test_ppo_gpu.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -8 ;;
   abroll)  timeout 600 python tools/ab_interleaved.py --what rollout --n-steps 32 --variant graph --variant "eager:ROLLOUT_GRAPH=0" --rounds 8 --json $O/r4_ab_rollout.json 2>&1 | tail -4 ;;
+  abvars)  timeout 1500 python tools/ab_interleaved.py --what train --captures 3 --variant "old:LIB=gennbv_amd/libgennbv_hip_old.so" --variant "adam:LIB=gennbv_amd/libgennbv_hip_adam.so" --variant "adam_nt:LIB=gennbv_amd/libgennbv_hip_adam_nt.so" --rounds 8 --json $O/r4_ab_train_vars.json 2>&1 | grep -v "^\[ab\]" | tail -16 ;;
+  ppotests) timeout 900 python -m pytest tests/test_ppo_gpu.py tests/test_rsl_rl_gpu.py tests/test_encoder_gpu.py -m gpu -q -x -p no:cacheprovider -k "adam or Adam or train or conv1_split or fused_train or rsl" 2>&1 | tail -5 ;;
+  abnt)    timeout 1500 python tools/ab_interleaved.py --what train --captures 3 --variant "b0:LIB=gennbv_amd/libgennbv_hip_b0.so" --variant "v1_ldnt:LIB=gennbv_amd/libgennbv_hip_v1.so" --variant "v2_adamnt:LIB=gennbv_amd/libgennbv_hip_v2.so" --rounds 8 --json $O/r4_ab_train_nt.json 2>&1 | grep -v "^\[ab\]" | tail -16 ;;
+  abvoxnt) timeout 600 python tools/ab_interleaved.py --what voxel --variant "b0:LIB=gennbv_amd/libgennbv_hip_b0.so" --variant "v3_nt:LIB=gennbv_amd/libgennbv_hip_v3.so" --variant "b0b:LIB=gennbv_amd/libgennbv_hip_b0.so" --rounds 20 --json $O/r4_ab_voxel_nt.json 2>&1 | tail -5 ;;
   *) echo "unknown stage $st" ;;
 esac
 done
