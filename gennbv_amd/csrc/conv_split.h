@@ -94,6 +94,12 @@ __device__ __forceinline__ float4 ld4_nt(const float *p)
     const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
     return make_float4(v[0], v[1], v[2], v[3]);
 }
+__device__ __forceinline__ uint4 ldu4_nt(const int8_t *p)
+{
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
 struct ZStager {
     const float *ybase;
     uint32_t rowC, planeC, st_lane;
@@ -826,7 +832,7 @@ __device__ __forceinline__ void conv2_dgrad_c1w_split_body(
         const int sp = min(cw * kWave + lane, kSlabPieces - 1), srow = sp >> 2, szr = srow / 5, syr = srow - 5 * szr;
         const int sbase = min(4 * a0 + szr, G - 1) * G * G + 16 * (sp & 3);
         char *sdst = slabs + srow * kSlabRow + 16 * (sp & 3);
-        auto slab_req = [&](int c) { return *reinterpret_cast<const uint4 *>(in + min(sbase + min(4 * c + syr, G - 1) * G, g3m16)); };
+        auto slab_req = [&](int c) { return ldu4_nt(in + min(sbase + min(4 * c + syr, G - 1) * G, g3m16)); };
         uint4 sv = slab_req(0);
         *reinterpret_cast<uint4 *>(sdst) = sv;
         sv = slab_req(1);
@@ -1022,7 +1028,7 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
         const int plane_g = min(4 * oz0 + fpl, G - 1);
         auto in_req = [&](int j) {  // input rows 4j+2 .. 4j+6 (clamped; UNCONDITIONAL)
             const int row_g = min(max(4 * j + 2 + frow, 0), G - 1);
-            return *reinterpret_cast<const uint4 *>(in + ((size_t)plane_g * G + row_g) * G + 16 * fq);
+            return ldu4_nt(in + ((size_t)plane_g * G + row_g) * G + 16 * fq);  // (the int8 input rows: -9.6 us per minibatch, -5.7 us per env step)
         };
         // int8 -> f16 on the way into the slab, two values per v_perm_b32 + v_pk_add_f16: the byte b ^ 0x80 under the exponent byte
         // 0x64 is the f16 number 1024 + (b + 128), minus 1152 = b (exact: integers below 2048)

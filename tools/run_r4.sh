@@ -38,6 +38,8 @@ case $st in
   ppotests) timeout 900 python -m pytest tests/test_ppo_gpu.py tests/test_rsl_rl_gpu.py tests/test_encoder_gpu.py -m gpu -q -x -p no:cacheprovider -k "adam or Adam or train or conv1_split or fused_train or rsl" 2>&1 | tail -5 ;;
   abnt)    timeout 1500 python tools/ab_interleaved.py --what train --captures 3 --variant "b0:LIB=gennbv_amd/libgennbv_hip_b0.so" --variant "v1_ldnt:LIB=gennbv_amd/libgennbv_hip_v1.so" --variant "v2_adamnt:LIB=gennbv_amd/libgennbv_hip_v2.so" --rounds 8 --json $O/r4_ab_train_nt.json 2>&1 | grep -v "^\[ab\]" | tail -16 ;;
   abvoxnt) timeout 600 python tools/ab_interleaved.py --what voxel --variant "b0:LIB=gennbv_amd/libgennbv_hip_b0.so" --variant "v3_nt:LIB=gennbv_amd/libgennbv_hip_v3.so" --variant "b0b:LIB=gennbv_amd/libgennbv_hip_b0.so" --rounds 20 --json $O/r4_ab_voxel_nt.json 2>&1 | tail -5 ;;
+  abv4)    timeout 1500 python tools/ab_interleaved.py --what train --captures 3 --variant "b1:LIB=gennbv_amd/libgennbv_hip_b1.so" --variant "v4_i8nt:LIB=gennbv_amd/libgennbv_hip_v4.so" --rounds 8 --json $O/r4_ab_train_v4.json 2>&1 | grep -v "^\[ab\]" | tail -12 ;;
+  abrollv4) timeout 900 python tools/ab_interleaved.py --what rollout --n-steps 32 --variant "b1:LIB=gennbv_amd/libgennbv_hip_b1.so" --variant "v4_i8nt:LIB=gennbv_amd/libgennbv_hip_v4.so" --variant "b1b:LIB=gennbv_amd/libgennbv_hip_b1.so" --rounds 8 --json $O/r4_ab_rollout_v4.json 2>&1 | tail -5 ;;
   *) echo "unknown stage $st" ;;
 esac
 done
