@@ -60,6 +60,10 @@ class OccupancyGridUpdater:
         # (GNBV_VOXEL_WS_CLEAN).  Switch off BEFORE the first update to keep the masks of the last step for `masks()`.
         self.self_clean = True
         self._ws_dirty = False
+        # measurement hook (bench.py): an object with `start()` / `stop()` that records HIP events on the current stream IMMEDIATELY around
+        # the library call -- the launch's duration without the Python in front of it (argument checks, tensor bookkeeping: ~10-15 us that
+        # an event pair around update() counts as kernel time whenever the GPU is ahead of the host)
+        self.timing = None
         assert self.workspace.data_ptr() % 256 == 0
         self._own_tri = None
         # Coded probability grid (1 byte per voxel, exact): only when the GT is binary (packed mode) and the caller
@@ -119,15 +123,21 @@ class OccupancyGridUpdater:
             assert self.coded, "the int8 copy of the tri-class grid is produced by the coded update only"
             assert tri_i8_out.dtype == torch.int8 and tri_i8_out.shape == (n, g ** 3) and tri_i8_out.stride(1) == 1
         if self.coded:
-            _lib.check(self.lib.gnbv_update_occ_grid_coded(
+            tm = self.timing
+            args = (
                 depth_raw.data_ptr(), seg_raw.data_ptr(), c2w.data_ptr(), self.inv_intri_host.data_ptr(),
                 poses.data_ptr(), poses.stride(0), self.range_gt.data_ptr(), self.voxel_size_gt.data_ptr(),
                 self.gt_bits.data_ptr(), _lib.ptr(reset_mask), n, self.h, self.w, g, self.depth_sense_dist,
                 self.prob_code.data_ptr(), self._tri_lut.data_ptr(), self.scanned_bits.data_ptr(), _lib.ptr(tri_out),
                 int(tri_row_stride or 0), _lib.ptr(tri_i8_out), 0 if tri_i8_out is None else int(tri_i8_out.stride(0)),
                 self.coverage_count.data_ptr(), self.code_overflow.data_ptr(), self.workspace.data_ptr(),
-                self.workspace.numel(), 1 if (self.self_clean and not self._ws_dirty) else 0, _lib.stream_ptr(self.device)),
-                "gnbv_update_occ_grid_coded")
+                self.workspace.numel(), 1 if (self.self_clean and not self._ws_dirty) else 0, _lib.stream_ptr(self.device))
+            if tm is not None:
+                tm.start()
+            err = self.lib.gnbv_update_occ_grid_coded(*args)
+            if tm is not None:
+                tm.stop()
+            _lib.check(err, "gnbv_update_occ_grid_coded")
             if not self.self_clean:
                 self._ws_dirty = True  # (a call without the flag leaves the masks in place: never claim "clean" again)
             return tri_out
