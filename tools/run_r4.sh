@@ -40,6 +40,8 @@ case $st in
   abvoxnt) timeout 600 python tools/ab_interleaved.py --what voxel --variant "b0:LIB=gennbv_amd/libgennbv_hip_b0.so" --variant "v3_nt:LIB=gennbv_amd/libgennbv_hip_v3.so" --variant "b0b:LIB=gennbv_amd/libgennbv_hip_b0.so" --rounds 20 --json $O/r4_ab_voxel_nt.json 2>&1 | tail -5 ;;
   abv4)    timeout 1500 python tools/ab_interleaved.py --what train --captures 3 --variant "b1:LIB=gennbv_amd/libgennbv_hip_b1.so" --variant "v4_i8nt:LIB=gennbv_amd/libgennbv_hip_v4.so" --rounds 8 --json $O/r4_ab_train_v4.json 2>&1 | grep -v "^\[ab\]" | tail -12 ;;
   abrollv4) timeout 900 python tools/ab_interleaved.py --what rollout --n-steps 32 --variant "b1:LIB=gennbv_amd/libgennbv_hip_b1.so" --variant "v4_i8nt:LIB=gennbv_amd/libgennbv_hip_v4.so" --variant "b1b:LIB=gennbv_amd/libgennbv_hip_b1.so" --rounds 8 --json $O/r4_ab_rollout_v4.json 2>&1 | tail -5 ;;
+  c5ab)    for L in gennbv_amd/libgennbv_hip_b3.so gennbv_amd/libgennbv_hip.so gennbv_amd/libgennbv_hip_b3.so gennbv_amd/libgennbv_hip.so; do GENNBV_HIP_LIB=$GRAFT_REPO_ROOT/$L timeout 900 python bench.py --steps 1 --warmup 1 --envs 512 --grid 128 --no-cpu-baseline --no-flat-rows --no-state-check 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$L', round(d['ms_per_step'],1), d['config']['breakdown_ms_per_step'])"; done ;;
+  g128tests) timeout 900 python -m pytest tests/test_encoder_gpu.py tests/test_ppo_g64_gpu.py -m gpu -q -x -p no:cacheprovider -k "128 or fp32" 2>&1 | tail -4 ;;
   *) echo "unknown stage $st" ;;
 esac
 done
