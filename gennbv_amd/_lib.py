@@ -203,9 +203,26 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_dev_idx = {}
+
+
 def stream_ptr(device=None):
-    """The caller's current HIP stream as void* (the kernels enqueue on it)."""
-    return torch.cuda.current_stream(device).cuda_stream
+    """The caller's current HIP stream as void* (the kernels enqueue on it).  Through torch's raw-stream accessor: the
+    `torch.cuda.current_stream(device).cuda_stream` it replaces builds a Stream object per call -- 15 calls and ~75 us of HOST time per
+    rollout step, which is launch-bound (tools/profile_rollout_host.py)."""
+    if _raw_stream is None:
+        return torch.cuda.current_stream(device).cuda_stream
+    idx = _dev_idx.get(device)
+    if idx is None:
+        d = torch.device(device) if device is not None else None
+        idx = d.index if (d is not None and d.index is not None) else None
+        if idx is not None and not isinstance(device, torch.Tensor):
+            try:
+                _dev_idx[device] = idx
+            except TypeError:
+                pass
+    return _raw_stream(torch.cuda.current_device() if idx is None else idx)
 
 
 def require_cuda(*tensors):

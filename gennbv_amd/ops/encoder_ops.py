@@ -147,6 +147,28 @@ def _params_struct(seq, grid_i8: Optional[torch.Tensor] = None,
     return p
 
 
+class _NoCtx:
+    """Stand-in for the autograd context when no graph is recorded (rollout, evaluation): `Function.apply` costs ~35 us of host time per
+    call even under no_grad (functorch wrappers, context set-up) -- five calls per rollout step, a third of its host time, and the step
+    is launch-bound (tools/profile_rollout_host.py).  The forward runs unchanged; what it hands to the context is dropped."""
+
+    def save_for_backward(self, *tensors):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass
+
+
+def _run(fn, *args):
+    """fn.apply(*args) when autograd records, fn.forward on a throw-away context otherwise (same code, same kernels)."""
+    if torch.is_grad_enabled():
+        return fn.apply(*args)
+    return fn.forward(_NoCtx(), *args)
+
+
 class _GridEncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, base, rows, grid_off, grid, training, skip_flag, seq, write_through, grid_i8, compact, autocorr, dp, guard, fold, w1, b1, g1, be1, w2, b2, g2, be2):
@@ -227,7 +249,7 @@ def grid_encoder(base: torch.Tensor, rows: Optional[torch.Tensor], grid_off: int
     `guard` = (force_fp32, range_flag int32 [1] or None[, autocorr_total int32 [768] or None]): GnbvEncoderParams.force_fp32 /
     .range_flag / .autocorr_total.  `fold`: returns (y2 [B, 16 P2] -- the second conv's raw output --, bn_state) for
     linear_relu(y2, lin, fold=(bn_state, P2, range_flag)) instead of the features (include/gennbv_hip.h gnbv_linear_forward_fold)."""
-    return _GridEncoderFn.apply(base, rows, grid_off, grid, training, skip_flag, seq, bool(write_through), grid_i8, bool(compact), autocorr, dp, guard, bool(fold), seq[0].weight, seq[0].bias,
+    return _run(_GridEncoderFn, base, rows, grid_off, grid, training, skip_flag, seq, bool(write_through), grid_i8, bool(compact), autocorr, dp, guard, bool(fold), seq[0].weight, seq[0].bias,
                                 seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias)
 
 
@@ -380,10 +402,10 @@ def linear_relu(x: torch.Tensor, lin: torch.nn.Linear, fold=None) -> torch.Tenso
     grid_encoder(..., fold=True) after linear_fold_ok(...): x is the conv stack's raw output, BatchNorm-2 + ReLU happen in the operand load."""
     n, k = lin.weight.shape
     if fold is not None:
-        return _LinearReluFn.apply(x, lin.weight, lin.bias, lin if getattr(lin, "_grad_write_through", False) else None, False, fold[0], fold[1], fold[2])
+        return _run(_LinearReluFn, x, lin.weight, lin.bias, lin if getattr(lin, "_grad_write_through", False) else None, False, fold[0], fold[1], fold[2])
     if k % 4 or n % 64 or not lin.weight.is_contiguous() or x.dtype != torch.float32:
         return torch.relu(torch.nn.functional.linear(x, lin.weight, lin.bias))
-    return _LinearReluFn.apply(x, lin.weight, lin.bias, lin if getattr(lin, "_grad_write_through", False) else None,
+    return _run(_LinearReluFn, x, lin.weight, lin.bias, lin if getattr(lin, "_grad_write_through", False) else None,
                                bool(getattr(lin, "_fp32_arith", False)))
 
 
@@ -589,7 +611,7 @@ def policy_head(enc, action_net, value_net, feature_action, feature_grid):
     """(logits [B, A], values [B], features [B, F]) from the two encoder branches."""
     lo = enc.output_layer[0]
     wt = all(getattr(m, "_grad_write_through", False) for m in (lo, action_net, value_net))
-    return _PolicyHeadFn.apply(feature_action, feature_grid, lo.weight, lo.bias, action_net.weight, action_net.bias, value_net.weight,
+    return _run(_PolicyHeadFn, feature_action, feature_grid, lo.weight, lo.bias, action_net.weight, action_net.bias, value_net.weight,
                                value_net.bias, (lo, action_net, value_net) if wt else None)
 
 
