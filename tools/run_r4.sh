@@ -42,6 +42,8 @@ case $st in
   abrollv4) timeout 900 python tools/ab_interleaved.py --what rollout --n-steps 32 --variant "b1:LIB=gennbv_amd/libgennbv_hip_b1.so" --variant "v4_i8nt:LIB=gennbv_amd/libgennbv_hip_v4.so" --variant "b1b:LIB=gennbv_amd/libgennbv_hip_b1.so" --rounds 8 --json $O/r4_ab_rollout_v4.json 2>&1 | tail -5 ;;
   c5ab)    for L in gennbv_amd/libgennbv_hip_b3.so gennbv_amd/libgennbv_hip.so gennbv_amd/libgennbv_hip_b3.so gennbv_amd/libgennbv_hip.so; do GENNBV_HIP_LIB=$GRAFT_REPO_ROOT/$L timeout 900 python bench.py --steps 1 --warmup 1 --envs 512 --grid 128 --no-cpu-baseline --no-flat-rows --no-state-check 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$L', round(d['ms_per_step'],1), d['config']['breakdown_ms_per_step'])"; done ;;
   g128tests) timeout 900 python -m pytest tests/test_encoder_gpu.py tests/test_ppo_g64_gpu.py -m gpu -q -x -p no:cacheprovider -k "128 or fp32" 2>&1 | tail -4 ;;
+  abv5)    timeout 1500 python tools/ab_interleaved.py --what train --captures 3 --variant "b3:LIB=gennbv_amd/libgennbv_hip_b3.so" --variant "vg_gplain:LIB=gennbv_amd/libgennbv_hip_vg.so" --variant "vd_dy2nt:LIB=gennbv_amd/libgennbv_hip_vd.so" --rounds 8 --json $O/r4_ab_train_v5.json 2>&1 | grep -v "^\[ab\]" | tail -14 ;;
+  abv6)    timeout 1500 python tools/ab_interleaved.py --what train --captures 3 --variant "b3:LIB=gennbv_amd/libgennbv_hip_b3.so" --variant "adam16k:LIB=gennbv_amd/libgennbv_hip_ab16384.so" --variant "adam4k:LIB=gennbv_amd/libgennbv_hip_ab4096.so" --rounds 8 --json $O/r4_ab_train_v6.json 2>&1 | grep -v "^\[ab\]" | head -5 ;;
   *) echo "unknown stage $st" ;;
 esac
 done
