@@ -372,10 +372,42 @@ class _LinearReluFn(torch.autograd.Function):
             return (dx, None, None) + (None,) * 6
         dx = g @ w if ctx.needs_input_grad[0] else None
         if direct:
-            torch.mm(g.t(), x, out=mod.weight.grad)
+            _wide_dw(g, x, mod.weight.grad)
             torch.sum(g, 0, out=mod.bias.grad)
             return (dx, None, None) + (None,) * 6
-        return (dx, g.t() @ x, g.sum(0)) + (None,) * 6
+        return (dx, _wide_dw(g, x, None), g.sum(0)) + (None,) * 6
+
+
+def _wide_dw(g: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor]) -> torch.Tensor:
+    """dW = g^T x for a layer applied to MANY rows (the semantic branch's patch embedding: 8192 rows, 64 x 128 weights): the
+    contraction runs over the rows, which is the split-K linear kernel's shape -- out[n][k] = sum_m g^T[n][m] x^T[k][m] -- in its fp32-MFMA
+    flavour (gradients have no fixed range for the split-f16 scalings).  The library picked a 60 us kernel for this 0.13 GFLOP product,
+    on the update's critical path (profiles/r04_semantic_minibatch_timeline.txt)."""
+    m, n = g.shape
+    k = x.shape[1]
+    if not (g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and m >= 1024 and m % 8 == 0 and k % 64 == 0 and n <= 128):
+        if out is None:
+            return g.t() @ x
+        return torch.mm(g.t(), x, out=out)
+    lib = _lib.load()
+    dev = g.device
+    gt, xt = g.t().contiguous(), x.t().contiguous()  # [n][m], [k][m]
+    key = ("wide_dw", n, k, m, str(dev))
+    cached = _ws_cache.get(key)
+    if cached is None:
+        cached = (torch.empty(lib.gnbv_linear_workspace_bytes(n, k, m), dtype=torch.uint8, device=dev), torch.zeros(k, dtype=torch.float32, device=dev))
+        _ws_cache[key] = cached
+    ws, zero_bias = cached
+    dst = out
+    if dst is None or not dst.is_contiguous() or dst.data_ptr() % 16:  # (a slice of the flat gradient buffer need not be 16-byte aligned)
+        dst = torch.empty(n, k, dtype=torch.float32, device=dev)
+    _lib.check(lib.gnbv_linear_forward(gt.data_ptr(), xt.data_ptr(), zero_bias.data_ptr(), n, k, m, 2, dst.data_ptr(), ws.data_ptr(), ws.numel(),
+                                       _lib.stream_ptr(dev)), "gnbv_linear_forward (wide dW)")
+    if out is None:
+        return dst
+    if dst is not out:
+        out.copy_(dst)
+    return out
 
 
 _deferred_wgrad = []

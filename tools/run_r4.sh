@@ -44,6 +44,7 @@ case $st in
   g128tests) timeout 900 python -m pytest tests/test_encoder_gpu.py tests/test_ppo_g64_gpu.py -m gpu -q -x -p no:cacheprovider -k "128 or fp32" 2>&1 | tail -4 ;;
   abv5)    timeout 1500 python tools/ab_interleaved.py --what train --captures 3 --variant "b3:LIB=gennbv_amd/libgennbv_hip_b3.so" --variant "vg_gplain:LIB=gennbv_amd/libgennbv_hip_vg.so" --variant "vd_dy2nt:LIB=gennbv_amd/libgennbv_hip_vd.so" --rounds 8 --json $O/r4_ab_train_v5.json 2>&1 | grep -v "^\[ab\]" | tail -14 ;;
   abv6)    timeout 1500 python tools/ab_interleaved.py --what train --captures 3 --variant "b3:LIB=gennbv_amd/libgennbv_hip_b3.so" --variant "adam16k:LIB=gennbv_amd/libgennbv_hip_ab16384.so" --variant "adam4k:LIB=gennbv_amd/libgennbv_hip_ab4096.so" --rounds 8 --json $O/r4_ab_train_v6.json 2>&1 | grep -v "^\[ab\]" | head -5 ;;
+  semprof) cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_s; rocprofv3 --kernel-trace --stats -d /tmp/prof_s -- python $GRAFT_REPO_ROOT/bench.py --semantic --steps 1 --warmup 1 --n-steps 16 --no-cpu-baseline --no-flat-rows --no-state-check > /tmp/prof_s.log 2>&1; python $GRAFT_REPO_ROOT/tools/rocprof_timeline.py /tmp/prof_s 600 k_ppo_fused > $O/r4_semantic_minibatch_timeline.txt; cut -c1-150 $O/r4_semantic_minibatch_timeline.txt; cd $GRAFT_REPO_ROOT ;;
   *) echo "unknown stage $st" ;;
 esac
 done
