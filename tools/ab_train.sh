@@ -1,5 +1,7 @@
 #!/bin/bash
 # run on the GPU box: A/B of the PPO update under environment switches, alternating, same box.
+# (round 3's harness, one process per configuration: differences under ~15 us per minibatch are inside its capture-to-capture noise --
+#  tools/ab_interleaved.py, one process with every variant captured and replayed alternately, replaced it in round 4.)
 #   tools/ab_train.sh "NAME=ENV1=a ENV2=b" "NAME2=..." ...   (each argument: label=space-separated env assignments)
 cd $GRAFT_REPO_ROOT
 REPS=${REPS:-2}
