@@ -76,17 +76,28 @@ def _local_to_global(perm, rank):
 
 
 def _worker(rank, WORLD, path, port, target_kl, out, shard=True, graph=False, epochs=EPOCHS):  # noqa: N803
+    import time
+    tm = [time.time()]
+    torch.set_num_threads(1)  # WORLD processes on one host: the CPU-side initialisers (orthogonal_ ...) must not each spin up a full thread pool
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    tm.append(time.time())
     from gennbv_amd import parallel
     blob = torch.load(path, weights_only=False)
+    tm.append(time.time())
     algo = _algo(_StubEnv(N_LOCAL), B_LOCAL, target_kl, epochs)
+    tm.append(time.time())
     _fill(algo, blob, list(range(rank * N_LOCAL, (rank + 1) * N_LOCAL)))
+    tm.append(time.time())
     algo.rollout_buffer.indices = blob["perm"].copy()  # the same permutation on every rank, over its own rows
     algo.use_graph = graph
     algo.shard_update = shard
     parallel.attach(algo, WORLD)
+    torch.cuda.synchronize()
+    tm.append(time.time())
     algo.train()
+    torch.cuda.synchronize()
+    tm.append(time.time())
     assert algo.policy.features_extractor._dp_sync is not None and algo.policy.features_extractor.training
     opt = algo._hip["opt"]
     if graph:  # gloo collectives cannot be captured: the fallback (eager launches of the same step) must have been taken, on every rank alike
@@ -118,6 +129,7 @@ def _worker(rank, WORLD, path, port, target_kl, out, shard=True, graph=False, ep
         out["params"], out["bn"] = vec.cpu().numpy(), bn.cpu().numpy()
         out["stats"] = algo.last_train_stats.copy()
         out["steps"] = int(algo._hip["opt"].step_count.item())
+        out["phase_s"] = [round(b - a, 2) for a, b in zip(tm, tm[1:] + [time.time()])]  # rendezvous, import + load, build, fill, attach, train(), checks
     dist.destroy_process_group()
 
 
@@ -135,7 +147,7 @@ def test_multi_rank_fused_update_equals_the_global_batch_update(tmp_path, world,
     """world 4 / 8: the fc_grid.weight shard boundaries (110 592 weights over 4 / 8 owners), gather_shard_state and the stop position at
     the target world size.  graph=True: the capture of the (gloo) collectives is refused -> eager launches of the same step, with 2 ranks."""
     WORLD = world  # noqa: N806
-    epochs = 1 if world >= 8 else EPOCHS  # (eight processes time-slicing one GPU: every stream synchronisation of a gloo collective costs a scheduling round)
+    epochs = EPOCHS
     from gennbv_amd.env import synthetic as S
     from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
     torch.manual_seed(0)
@@ -179,7 +191,10 @@ def test_multi_rank_fused_update_equals_the_global_batch_update(tmp_path, world,
     want_bn = torch.cat([b.detach().reshape(-1).float() for b in ref.policy.buffers()]).cpu().numpy()
     steps = int(ref._hip["opt"].step_count.item())
     out = mp.Manager().dict()
+    import time
+    t0 = time.time()
     mp.spawn(_worker, args=(WORLD, path, _free_port(), target_kl, out, shard, graph, epochs), nprocs=WORLD, join=True)
+    print("world %d: spawn..join %.1f s; rank 0 phases (rendezvous, import+load, build, fill, attach, train, checks) %s" % (WORLD, time.time() - t0, out.get("phase_s")))
     assert out["identical"], "ranks diverged"
     assert out["steps"] == steps and len(out["stats"]) == len(stats)  # same early-stop position
     # the ranks log the terms of their own rows; the KL (col 3) they act on is the global mean: check it through the stop position,
