@@ -9,7 +9,8 @@ all of them:
     python tools/ab_interleaved.py --what voxel  --variant base --variant "old:LIB=gennbv_amd/libgennbv_hip_old.so"
     python tools/ab_interleaved.py --what rollout ...
 
-A variant is `name[:K=V,K=V,...]`; `LIB=path` selects another build of libgennbv_hip.so (gennbv_amd._lib.activate), everything else
+A variant is `name[:K=V,K=V,...]`; `LIB=path` selects another build of libgennbv_hip.so (gennbv_amd._lib.activate), `STREAM=hp` builds,
+captures and replays the variant on a high-priority HIP stream (the streams the code forks onto keep the default priority), everything else
 is an environment variable that is set while the variant is BUILT and CAPTURED (the library reads its switches at call / capture
 time; a replayed hipGraph has them baked in).  `train`: the captured PPO minibatch graph of bench.py's algorithm object (learning
 rate 1e-12: thousands of replays must not walk the parameters away).  `voxel`: gnbv_update_occ_grid_coded as the env calls it
@@ -38,8 +39,27 @@ def parse_variant(v: str):
         if k == "LIB":
             lib = val
         else:
-            env[k] = val
+            env[k] = val  # (STREAM stays in here: main() pops it)
     return name, env, lib
+
+
+class _OnStream:
+    """everything inside runs with `stream` current (None: the ambient stream), ordered behind what was enqueued before"""
+    def __init__(self, stream):
+        self.stream, self.ctx = stream, None
+
+    def __enter__(self):
+        if self.stream is not None:
+            import torch
+            self.stream.wait_stream(torch.cuda.current_stream())
+            self.ctx = torch.cuda.stream(self.stream)
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            import torch
+            self.ctx.__exit__(*a)
+            torch.cuda.current_stream().wait_stream(self.stream)
 
 
 class _Env:
@@ -149,8 +169,9 @@ def main():
     variants = []
     for v in [x for _ in range(a.captures) for x in a.variant]:
         name, env, lib = parse_variant(v)
-        print(f"[ab] building variant {name} env={env} lib={lib}", file=sys.stderr, flush=True)
-        with _Env(env):
+        stream = torch.cuda.Stream(priority=-1) if env.pop("STREAM", None) == "hp" else None
+        print(f"[ab] building variant {name} env={env} lib={lib} stream={'high priority' if stream else 'ambient'}", file=sys.stderr, flush=True)
+        with _Env(env), _OnStream(stream):
             _lib.activate(lib)
             fn, keep = build(a, dev)
         if not isinstance(fn, dict):
@@ -159,7 +180,7 @@ def main():
             fn["chunk_ctx"] = (env, lib)
         torch.cuda.synchronize()
         print(f"[ab] variant {name} built and captured", file=sys.stderr, flush=True)
-        variants.append({"name": name, "env": env, "lib": lib, "fn": fn["fn"], "reset": fn.get("reset"), "ctx": fn.get("chunk_ctx"), "keep": keep, "t": []})
+        variants.append({"name": name, "env": env, "lib": lib, "fn": fn["fn"], "reset": fn.get("reset"), "ctx": fn.get("chunk_ctx"), "keep": keep, "t": [], "stream": stream})
         if fn.get("max_chunk"):
             chunk = min(chunk, fn["max_chunk"])
     _lib.activate(None)
@@ -167,7 +188,7 @@ def main():
     t0 = time.perf_counter()
     def run_chunk(v, timed: bool):
         env, lib = v["ctx"] if v["ctx"] else ({}, None)
-        with _Env(env if v["ctx"] else {}):
+        with _Env(env if v["ctx"] else {}), _OnStream(v["stream"]):
             if v["ctx"]:
                 _lib.activate(lib)
             if v["reset"]:

@@ -14,7 +14,7 @@ def main(path, pattern="k_"):
     out = {}
     for k, c, v, n in rows:
         if pattern in k:
-            out.setdefault(k.split("(")[0][:40], {})[c] = (v, n)
+            out.setdefault((k[5:] if k.startswith("void ") else k).split("(")[0].replace("anonymous namespace)::", "")[:60] or k[:60], {})[c] = (v, n)
     for k, d in out.items():
         print(k)
         for c, (v, n) in sorted(d.items()):
