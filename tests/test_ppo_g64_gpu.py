@@ -189,8 +189,9 @@ def test_train_semantic_branch_g64_b128_hipgraph_matches_fp64_oracle():
     """BASELINE configs[2] at the train() level: `Hybrid_Encoder(semantic_branch=True)` -- the two gray frames ->
     8x8 patch embeddings -> Linear 4096->256 -> concatenated in front of `output_layer` (768 inputs) -- through the captured minibatch
     graph with the rgb linears and the K2 = 512 head (what `bench.py --semantic` times), against the fp64 CPU loop of the same class
-    with the same torch modules.  Same tolerances as the default kernel set (1e-4 per logged scalar over 20 optimizer steps)."""
-    rec = _Recorded(semantic=True)
+    with the same torch modules.  Same tolerances as the default kernel set (1e-4 per logged scalar), over 2 epochs = 8 optimizer steps
+    (the default kernel set's 20-step run above covers the long horizon; the fp64 CPU loop is what this test's time goes into)."""
+    rec = _Recorded(semantic=True, epochs=2)
     enc = rec.algo.policy.features_extractor
     assert enc.semantic_branch and enc.output_layer[0].in_features == 768
     rgb = rec.flat_obs[..., rec.cfg.state_dim + G ** 3:]
@@ -199,7 +200,7 @@ def test_train_semantic_branch_g64_b128_hipgraph_matches_fp64_oracle():
     hip = _fresh_hip(rec, None, True)
     hip.train()
     assert hip._hip["graph"] is not None and hip._hip.get("fused_head")
-    _compare(hip, ref, EPOCHS * (N_ENVS * T // BATCH))
+    _compare(hip, ref, 2 * (N_ENVS * T // BATCH))
     # the branch is live: its parameters moved
     moved = {k: float((hip.policy.state_dict()[k].cpu() - v).abs().max()) for k, v in rec.state.items() if "_rgb" in k and "weight" in k}
     assert moved and min(moved.values()) > 0.0, moved
