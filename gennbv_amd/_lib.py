@@ -55,6 +55,7 @@ SIGNATURES = {
     "gnbv_input_autocorr": (_i, [_p, _i64, _i, _i, _p, _i64, _p]),
     "gnbv_encoder_workspace_bytes": (_sz, [_i, _i]),
     "gnbv_encoder_y1_elems": (_sz, [_i, _i]),
+    "gnbv_encoder_eval_prepare": (_i, [_i, _i, _p, _p, _p, _sz, _p]),
     "gnbv_encoder_grid_forward": (_i, [_p, _p, _i64, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnbv_encoder_grid_backward": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnbv_linear_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -114,7 +115,7 @@ class GnbvEncoderParams(C.Structure):
                 ("eps", _f), ("momentum", _f), ("grid_i8", _p), ("grid_i8_row_stride", _i64),
                 ("autocorr", _p), ("autocorr_row_stride", _i64),
                 ("world", _i), ("sync_sum", _p), ("sync_ctx", _p), ("sync_buf", _p), ("autocorr_global", _p),
-                ("autocorr_total", _p), ("force_fp32", _i), ("range_flag", _p)]
+                ("autocorr_total", _p), ("force_fp32", _i), ("range_flag", _p), ("eval_prepared", _i)]
 
 
 class GnbvAdamStep(C.Structure):
@@ -168,7 +169,7 @@ def _open(path: str, strict: bool = True):
             continue  # (activate(): an OLDER build of the same ABI under A/B may lack entry points added since)
         fn.restype = res
         fn.argtypes = args
-    if lib.gnbv_abi_version() != 4:
+    if lib.gnbv_abi_version() != 5:
         raise GennbvHipError("libgennbv_hip.so ABI version mismatch")
     _loaded[path] = lib
     return lib

@@ -2020,6 +2020,33 @@ static int launch_autocorr_total(const GnbvEncoderParams *p, const int64_t *rows
     return gnbv_launch_status();
 }
 
+// The launches of an inference forward that depend on the parameters only (GnbvEncoderParams.eval_prepared): BatchNorm-1's
+// (scale, shift, mean, rstd) from the running statistics + the bound check of its channels, the conv2 weight images, and -- bn2 --
+// BatchNorm-2's.  One-launch conv1 + conv2 inference path (fused_eval below) only.
+static int eval_prepare_launches(const GnbvEncoderParams *p, int batch, int O1, int P2, float *bn_state, const EncWs &w, hipStream_t st, bool bn2_too)
+{
+    float *bn1 = bn_state, *bn2 = bn_state + 4 * kC;
+    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps, p->momentum, p->bn1_rm,
+                       p->bn1_rv, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->w1, p->b1, p->range_flag);
+    hipLaunchKernelGGL(k_prep_w2_split_only, dim3(12), dim3(256), 0, st, p->w2, w.w2img);
+    if (bn2_too)
+        hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, (double)batch * P2, p->bn2_w, p->bn2_b, p->eps, p->momentum, p->bn2_rm,
+                           p->bn2_rv, bn2, bn2 + kC, bn2 + 2 * kC, bn2 + 3 * kC);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_encoder_eval_prepare(int batch, int grid, const GnbvEncoderParams *p, float *bn_state, void *workspace, size_t workspace_bytes,
+                                       void *stream)
+{
+    GNBV_CHECK_ARG(p && bn_state && workspace && batch > 0 && grid >= 7);
+    GNBV_CHECK_ARG(workspace_bytes >= gnbv_encoder_workspace_bytes(batch, grid) && ((uintptr_t)workspace & 255) == 0);
+    GNBV_CHECK_ARG(p->w1 && p->b1 && p->bn1_w && p->bn1_b && p->bn1_rm && p->bn1_rv && p->w2 && p->b2 && p->bn2_w && p->bn2_b &&
+                   p->bn2_rm && p->bn2_rv);
+    if (!(conv_split_path(p, grid) && conv1_i8_staged(p, grid) && grid == 64 && !env_off("GENNBV_FUSED_EVAL"))) return GNBV_ERR_NOT_APPLICABLE;
+    const int O1 = out_size(grid), O2 = out_size(O1);
+    return eval_prepare_launches(p, batch, O1, O2 * O2 * O2, bn_state, enc_carve(workspace, batch, grid), gnbv_stream(stream), /*bn2=*/true);
+}
+
 GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *rows, int64_t row_stride, int batch, int grid,
                                        const GnbvEncoderParams *p, int training, const int *skip_flag, void *y1, float *y2,
                                        float *bn_state /*[2][4][16]: scale, shift, mean, rstd per layer*/, float *features,
@@ -2045,10 +2072,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     const bool fused_eval = !training && conv_split_path(p, grid) && conv1_i8_staged(p, grid) && grid == 64 && !env_off("GENNBV_FUSED_EVAL");
     bool fused_train = false;
     if (fused_eval) {
-        hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, (double)batch * O1 * O1 * O1, p->bn1_w, p->bn1_b, p->eps, p->momentum, p->bn1_rm,
-                           p->bn1_rv, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->w1, p->b1, p->range_flag);
-        hipLaunchKernelGGL(k_prep_w2_split_only, dim3(12), dim3(256), 0, st, p->w2, w.w2img);
-        if ((err = gnbv_launch_status())) return err;
+        if (!p->eval_prepared && (err = eval_prepare_launches(p, batch, O1, P2, bn_state, w, st, /*bn2=*/false))) return err;
         static bool attr_fe = false;
         if (!attr_fe) {
             const hipError_t e = hipFuncSetAttribute((const void *)k_conv12_fwd_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fsplit::kLdsBytes);
@@ -2158,7 +2182,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
         hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, st, w.bn_part, g2, (double *)nullptr, (double)batch * P2, p->bn2_w, p->bn2_b,
                            p->eps, p->momentum, p->bn2_rm, p->bn2_rv, p->bn2_nbt, skip_flag, bn2, bn2 + kC, bn2 + 2 * kC, bn2 + 3 * kC,
                            (const float *)nullptr, (float *)nullptr);
-    else
+    else if (!(fused_eval && p->eval_prepared))
         hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, (double)batch * P2, p->bn2_w, p->bn2_b, p->eps, p->momentum, p->bn2_rm,
                            p->bn2_rv, bn2, bn2 + kC, bn2 + 2 * kC, bn2 + 3 * kC);
     if ((err = gnbv_launch_status())) return err;

@@ -93,6 +93,7 @@ class PPO_Grid_Obs:
         self.rotate_rows = True   # replayed graph on one GPU: the Adam launch leaves the next minibatch's row numbers behind (no host copy)
         self.grid_i8_rows = True  # int8 side copy of the grid rows next to flat fp32 rows (what the conv1 kernels of the update read)
         self.fused_add = True     # time-out bootstrap + the five buffer copies of rollout_buffer.add as one launch (gnbv_rollout_add)
+        self.rollout_plan = True  # collect_rollouts evaluates the policy through ops/rollout_plan.py (same kernels, step-invariant work hoisted)
         self.compact_obs = bool(compact_obs)
         # Time-out bootstrap (on_policy_algorithm_grid_obs.py:205-208).  "reference": what the reference computes --
         # `predict_values(new_obs)[0]` is ROW 0 of the [N, 1] values, so every timed-out env is bootstrapped with env 0's
@@ -824,6 +825,17 @@ class PPO_Grid_Obs:
                      and self.fused_add)
         n_steps = 0
         self._check_ranges()
+        # the policy evaluation of this rollout's steps with its step-invariant work hoisted out (ops/rollout_plan.py); None: general path
+        plan = self._rollout_forward(env.num_envs) if fused_add or getattr(self.policy, "_fused_rollout", False) else None
+
+        def evaluate(x, values_only=False):
+            if plan is not None and plan.applies_to(x):
+                logits, v = plan(x)
+                if values_only:
+                    return v.unsqueeze(1)
+                a, lp = self.policy.action_dist.sample_and_log_prob(logits, False)
+                return a, v.unsqueeze(1), lp
+            return self.policy.predict_values(x) if values_only else self.policy(x)
         rollout_buffer.reset()
         first = rollout_buffer.first_obs_row()
         if self._last_obs.data_ptr() != first.data_ptr():
@@ -837,7 +849,7 @@ class PPO_Grid_Obs:
         while n_steps < n_rollout_steps:
             with torch.no_grad():
                 if self._pending is None:
-                    actions, values, log_probs = self.policy(self._with_grid_i8(self._last_obs, rollout_buffer.step))
+                    actions, values, log_probs = evaluate(self._with_grid_i8(self._last_obs, rollout_buffer.step))
                 else:
                     actions, values, log_probs = self._pending
             new_obs, rewards, dones, infos = self._env_step(actions, rollout_buffer.next_obs_row())
@@ -857,11 +869,11 @@ class PPO_Grid_Obs:
                 # cross-queue hand-overs.  profiles/r04_notes.md)
                 new_in = self._with_grid_i8(new_obs, rollout_buffer.step + 1)  # (the buffer's step counter advances in add())
                 if n_steps < n_rollout_steps:
-                    nxt = self.policy(new_in)
+                    nxt = evaluate(new_in)
                     terminal_value = nxt[1]
                 else:
                     nxt = None
-                    terminal_value = self.policy.predict_values(new_in)
+                    terminal_value = evaluate(new_in, values_only=True)
             assert self.timeout_bootstrap in ("reference", "per_env")
             first = self.timeout_bootstrap == "reference"
             if fused_add and self._last_obs.data_ptr() == rollout_buffer.observations[rollout_buffer.step].data_ptr():
@@ -881,6 +893,18 @@ class PPO_Grid_Obs:
         if callback is not None:
             callback.on_rollout_end()
         return True
+
+    def _rollout_forward(self, n: int):
+        """The prepared policy evaluation of this rollout (ops/rollout_plan.RolloutForward), or None (attribute `rollout_plan = False`,
+        another device, a policy whose inference forward is not the kernel sequence the plan issues)."""
+        if not self.rollout_plan or self.device.type != "cuda" or "forward" in vars(self.policy) or "predict_values" in vars(self.policy):
+            return None  # (an instance-level override of the policy's evaluation -- tests force actions that way -- keeps the general path)
+        from ..ops.rollout_plan import RolloutForward
+        plan = getattr(self, "_rollout_plan_obj", None)
+        if plan is None or plan.n != n or plan.policy is not self.policy:
+            plan = self._rollout_plan_obj = RolloutForward.build(self.policy, n)
+        with torch.no_grad():
+            return plan if (plan is not None and plan.prepare()) else None
 
     def _update_info_buffer(self, infos) -> None:
         if self.ep_info_buffer is not None:

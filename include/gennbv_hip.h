@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNBV_ABI_VERSION 4
+#define GNBV_ABI_VERSION 5
 
 int gnbv_abi_version(void);
 /* Name of the device architecture the library was compiled for ("gfx950"). [host] */
@@ -279,6 +279,14 @@ typedef struct GnbvEncoderParams {
                                      253 (conv1's input is tri-class, |x| <= 1); 4 = a feature (fc_grid input) above 1000.
                                      The caller reads it once per train() / rollout; a non-zero word means the results of the
                                      calls since the last check may be clamped: raise, or repeat with force_fp32 */
+    int eval_prepared;            /* (ABI 5) inference only (training == 0), 0 by default.  1: the caller ran gnbv_encoder_eval_prepare()
+                                     for THESE parameters, this (batch, grid), this `bn_state` and this `workspace` since the parameters
+                                     or BatchNorm's running statistics last changed, and nothing else has written bn_state / used the
+                                     workspace since: the forward then skips the launches that only depend on the parameters
+                                     (BatchNorm scale / shift of both layers, the conv2 weight images) -- three small kernels on the
+                                     critical path of every env step of a rollout (sb3/ppo_grid_obs.py collect_rollouts: the
+                                     parameters are fixed between two train() calls).  Ignored where the inference path has no
+                                     such launches to skip. */
 } GnbvEncoderParams;
 
 typedef struct GnbvEncoderGrads {  /* outputs, same shapes as the parameters */
@@ -297,6 +305,13 @@ int gnbv_input_autocorr(const int8_t *grid_i8, int64_t grid_i8_row_stride, int n
                         void *stream);
 
 size_t gnbv_encoder_workspace_bytes(int batch, int grid);
+/* The parameter-only part of an INFERENCE forward (see GnbvEncoderParams.eval_prepared): BatchNorm-1 / -2 scale, shift, mean, rstd
+ * from the running statistics into bn_state, the conv2 weight images into the workspace.  Returns 0 when done, and
+ * GNBV_ERR_NOT_APPLICABLE (-2) -- nothing launched, nothing to skip -- where the inference forward of this (params, grid) does
+ * not take the one-launch conv1 + conv2 kernel (then call gnbv_encoder_grid_forward with eval_prepared = 0 as before). */
+#define GNBV_ERR_NOT_APPLICABLE (-2)
+int gnbv_encoder_eval_prepare(int batch, int grid, const GnbvEncoderParams *params, float *bn_state, void *workspace, size_t workspace_bytes,
+                              void *stream);
 /* number of fp32 ELEMENTS of the layer-1 activation buffers (y1, dz1_scratch) */
 size_t gnbv_encoder_y1_elems(int batch, int grid);
 

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     # the binding table covers the whole header, nothing more, nothing less
     assert sorted(_lib.SIGNATURES) == syms
     bound = _lib.load()
-    assert bound.gnbv_abi_version() == 4
+    assert bound.gnbv_abi_version() == 5
     assert bound.gnbv_build_arch() == b"gfx950"
     assert bound.gnbv_voxel_workspace_bytes(256, 64) == 2 * 256 * 8192 * 4
 

@@ -54,3 +54,48 @@ def test_hip_rollout_reproduces_reference_collect_rollouts(fused_add, monkeypatc
         ru.check_rollout(fx, r, buf, algo, value_tol=2e-5)
     assert algo.num_timesteps == int(fx["num_timesteps"])
 
+
+
+def test_prepared_rollout_forward_is_bit_identical_to_the_general_path():
+    """ops/rollout_plan.RolloutForward (collect_rollouts' policy evaluation with the step-invariant work hoisted out, the parameter-only
+    launches run once per rollout: GnbvEncoderParams.eval_prepared) issues the same kernels with the same arguments as
+    ActorCriticPolicy_Train_Eval.forward: two rollouts at G = 64 with compact rows (the bench's kernel set), a train() in between so that
+    the second rollout must prepare again from CHANGED parameters -- every buffer bit for bit against `rollout_plan = False`."""
+    from gennbv_amd.env import synthetic as S
+    from gennbv_amd.env.config import TaskConfig
+    from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
+    from gennbv_amd.network.hybrid_encoder import Hybrid_Encoder
+    from gennbv_amd.sb3.policies import ActorCriticPolicy_Train_Eval
+    from gennbv_amd.sb3.ppo_grid_obs import PPO_Grid_Obs
+    g, n, t = 64, 16, 6
+    cfg = TaskConfig(camera_width=80, camera_height=60, grid_size=g)
+    kw = dict(net_arch=[], features_extractor_class=Hybrid_Encoder, features_extractor_kwargs=dict(
+        encoder_param={"hidden_shapes": [256, 256], "visual_dim": 256},
+        net_param={"transformer_params": [[1, 256], [1, 256]], "append_hidden_shapes": [256, 256]},
+        state_input_shape=(cfg.state_dim,), visual_input_shape=(cfg.stack, cfg.camera_height, cfg.camera_width)))
+    out = {}
+    for use_plan in (False, True):
+        torch.manual_seed(0)
+        np.random.seed(0)
+        scene = S.make_scenes(n, g, seed=5, device=DEV)
+        env = ReplayFeedEnv(cfg, scene, ReplayFeed.synthetic(scene, cfg, 5, seed=5), DEV, max_episode_length=4)
+        algo = PPO_Grid_Obs(ActorCriticPolicy_Train_Eval, env, learning_rate=1e-4, n_steps=t, batch_size=32, n_epochs=1, gamma=0.99, gae_lambda=0.95,
+                            clip_range=0.2, clip_range_vf=0.2, ent_coef=0.01, vf_coef=0.8, max_grad_norm=1.0, target_kl=None, seed=1, device=DEV,
+                            compact_obs=True, policy_kwargs=kw)
+        algo.rollout_plan = use_plan
+        algo._setup_learn(total_timesteps=10 ** 9)
+        snaps = []
+        for r in range(2):
+            assert algo.collect_rollouts(env, None, algo.rollout_buffer, n_rollout_steps=t)
+            buf = algo.rollout_buffer
+            snaps.append({k: getattr(buf, k).detach().clone() for k in ("observations", "grid_i8", "actions", "values", "log_probs", "rewards",
+                                                                         "advantages", "returns", "episode_starts")})
+            if r == 0:
+                algo.train()
+        plan = getattr(algo, "_rollout_plan_obj", None)
+        assert (plan is not None and plan.prepared) == use_plan, "the prepared forward must have run (and only when asked for)"
+        out[use_plan] = snaps
+    for r in range(2):
+        for k, a in out[False][r].items():
+            assert torch.equal(a, out[True][r][k]), (r, k)
+    assert float(out[True][1]["values"].abs().max()) > 0 and not torch.equal(out[True][0]["values"], out[True][1]["values"])
