@@ -134,6 +134,14 @@ class ReplayFeedEnv:
         self.prev_ratio = z(n)
         self.rew_buf = z(n)
         self.reset_buf = z(n, dt=torch.uint8)
+        # `flag_views` (off by default; collect_rollouts of PPO_Grid_Obs turns it on): step() hands out `dones` and infos["time_outs"] as
+        # bool VIEWS of the kernels' 0 / 1 bytes instead of `.bool()` copies (two element-wise launches per env step).  `dones` of step t is
+        # still needed after step t + 1 has run (it is step t + 1's episode_starts): two buffers take turns.  time_outs is read inside the
+        # step that produced it (the time-out bootstrap) and is STATEFUL on the device (the reference only refreshes it on steps with a
+        # reset): one buffer, and a reader that keeps infos["time_outs"] across env steps must copy it.
+        self.flag_views = False
+        self._reset_bufs = (self.reset_buf, z(n, dt=torch.uint8))
+        self._reset_turn = 0
         self.reset_mask = torch.ones(n, dtype=torch.uint8, device=dev)
         self.time_out_buf = z(n, dt=torch.uint8)
         self.extras_time_outs = z(n, dt=torch.uint8)
@@ -259,8 +267,13 @@ class ReplayFeedEnv:
     def step(self, actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None, grid_i8_out: Optional[torch.Tensor] = None):
         _lib.require_cuda(actions)
         a = actions.to(torch.int64).contiguous()
+        views = self.flag_views
+        if views:
+            self._reset_turn ^= 1
+            self.reset_buf = self._reset_bufs[self._reset_turn]
+            self._post.dones = self.reset_buf.data_ptr()
         obs = self._observe_and_finish(a, obs_out, grid_i8_out)
-        self.extras["time_outs"] = self.extras_time_outs.bool()
+        self.extras["time_outs"] = self.extras_time_outs.view(torch.bool) if views else self.extras_time_outs.bool()
         info = _LazyEpisodeInfo(self, self._ep_step)
         self.extras["episode"] = info
         # dicts that are still referenced when their snapshot slot is about to be overwritten keep their last values (the
@@ -275,7 +288,7 @@ class ReplayFeedEnv:
             live.popleft()
             if d is not None:
                 d._freeze()
-        return obs, self.rew_buf, self.reset_buf.bool(), self.extras
+        return obs, self.rew_buf, (self.reset_buf.view(torch.bool) if views else self.reset_buf.bool()), self.extras
 
     # ------------------------------------------------------------------------
     REWARD_NAMES = ("surface_coverage", "short_path", "termination")  # cfg.rewards.scales order = episode_sums order

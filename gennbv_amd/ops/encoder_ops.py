@@ -101,9 +101,9 @@ def _workspace(lib, batch, grid, device):
     return ws
 
 
-def input_autocorr(grid_i8: torch.Tensor, grid: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def input_autocorr(grid_i8: torch.Tensor, grid: int, out: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
     """Per-row autocorrelation of the conv1 input patches of int8 grid rows [n, G^3] -> [n, 768] int32
-    (include/gennbv_hip.h: gnbv_input_autocorr)."""
+    (include/gennbv_hip.h: gnbv_input_autocorr).  `stream`: raw HIP stream to issue on (default: the current stream)."""
     lib = _lib.load()
     _lib.require_cuda(grid_i8)
     n = grid_i8.shape[0]
@@ -112,7 +112,7 @@ def input_autocorr(grid_i8: torch.Tensor, grid: int, out: Optional[torch.Tensor]
         out = torch.empty(n, lib.gnbv_input_autocorr_row_ints(), dtype=torch.int32, device=grid_i8.device)
     assert out.dtype == torch.int32 and out.shape[0] == n and out.stride(1) == 1
     _lib.check(lib.gnbv_input_autocorr(grid_i8.data_ptr(), grid_i8.stride(0), n, grid, out.data_ptr(), out.stride(0),
-                                       _lib.stream_ptr(grid_i8.device)), "gnbv_input_autocorr")
+                                       _lib.stream_ptr(grid_i8.device) if stream is None else stream), "gnbv_input_autocorr")
     return out
 
 

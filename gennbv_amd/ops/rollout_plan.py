@@ -131,8 +131,9 @@ class RolloutForward:
                 and obs.base.dtype == torch.float32 and obs.grid_i8 is not None and obs.grid_i8.stride(0) % 16 == 0
                 and obs.grid_i8.data_ptr() % 16 == 0 and not torch.is_grad_enabled() and self._sig == self._signature())
 
-    def __call__(self, obs):
-        """(logits [n, A], values [n]) of the compact observation rows `obs` (encoder_ops.DenseObs)."""
+    def __call__(self, obs, tail=None):
+        """(logits [n, A], values [n]) of the compact observation rows `obs` (encoder_ops.DenseObs).  `tail(raw_stream)`: more work for
+        the second stream, issued behind the pose branch and NOT joined here (the caller joins `self.side` when it needs the result)."""
         lib, n, dev = self.lib, self.n, self.dev
         base, g8 = obs.base, obs.grid_i8
         st = _lib.stream_ptr(dev)
@@ -160,6 +161,8 @@ class RolloutForward:
             x = out
         self.ev_join.record(side)
         cur.wait_event(self.ev_join)
+        if tail is not None:
+            tail(sst)
         logits = torch.empty(n, self.n_act, dtype=torch.float32, device=dev)  # (kept by the caller across the next step: not plan-owned)
         values = torch.empty(n, dtype=torch.float32, device=dev)
         w_out, b_out, f, w_act, b_act, a, w_val, b_val = self.head_w

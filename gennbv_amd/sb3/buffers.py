@@ -84,11 +84,11 @@ class TensorRolloutBuffer_Grid_Obs:
                 self._autocorr_grid = g
                 self.autocorr = torch.zeros(self.buffer_size + 1, self.n_envs, 768, dtype=torch.int32, device=self.device)
 
-    def update_autocorr(self, row: int) -> None:
-        """(Re)compute the autocorrelation rows of observation row `row` from its int8 grid rows."""
+    def update_autocorr(self, row: int, stream=None) -> None:
+        """(Re)compute the autocorrelation rows of observation row `row` from its int8 grid rows (`stream`: raw HIP stream, default current)."""
         if self.autocorr is not None:
             from ..ops import encoder_ops
-            encoder_ops.input_autocorr(self.grid_i8[row], self._autocorr_grid, out=self.autocorr[row])
+            encoder_ops.input_autocorr(self.grid_i8[row], self._autocorr_grid, out=self.autocorr[row], stream=stream)
 
     def next_grid_i8_row(self):
         return None if self.grid_i8 is None else self.grid_i8[self.step + 1]

@@ -769,11 +769,12 @@ class PPO_Grid_Obs:
         return ok
 
     # ------------------------------------------------------------------------------
-    def _env_step(self, actions, obs_out):
+    def _env_step(self, actions, obs_out, defer_autocorr: bool = False):
         g8 = self.rollout_buffer.next_grid_i8_row()
         if g8 is not None:
             out = self.env.step(actions, obs_out=obs_out, grid_i8_out=g8)
-            self.rollout_buffer.update_autocorr(self.rollout_buffer.step + 1)
+            if not defer_autocorr:  # (deferred: the caller issues it behind the policy evaluation's second-stream work -- collect_rollouts)
+                self.rollout_buffer.update_autocorr(self.rollout_buffer.step + 1)
             return out
         try:
             return self.env.step(actions, obs_out=obs_out)
@@ -828,13 +829,22 @@ class PPO_Grid_Obs:
         # the policy evaluation of this rollout's steps with its step-invariant work hoisted out (ops/rollout_plan.py); None: general path
         plan = self._rollout_forward(env.num_envs) if fused_add or getattr(self.policy, "_fused_rollout", False) else None
 
-        def evaluate(x, values_only=False):
+        # The new row's input autocorrelation (BatchNorm-1's analytic statistics in train(): nothing in the rollout reads it) goes to the
+        # second stream BEHIND the pose branch of the policy evaluation, where it runs beside the conv kernel instead of in front of it.
+        defer_ac = plan is not None and rollout_buffer.autocorr is not None
+        if hasattr(env, "flag_views"):
+            env.flag_views = True  # dones / time_outs as views of the kernels' bytes: both are consumed before they are overwritten (below)
+
+        def evaluate(x, values_only=False, autocorr_row=None):
             if plan is not None and plan.applies_to(x):
-                logits, v = plan(x)
+                tail = None if autocorr_row is None else (lambda st, r=autocorr_row: rollout_buffer.update_autocorr(r, stream=st))
+                logits, v = plan(x, tail)
                 if values_only:
                     return v.unsqueeze(1)
                 a, lp = self.policy.action_dist.sample_and_log_prob(logits, False)
                 return a, v.unsqueeze(1), lp
+            if autocorr_row is not None:
+                rollout_buffer.update_autocorr(autocorr_row)
             return self.policy.predict_values(x) if values_only else self.policy(x)
         rollout_buffer.reset()
         first = rollout_buffer.first_obs_row()
@@ -852,7 +862,7 @@ class PPO_Grid_Obs:
                     actions, values, log_probs = evaluate(self._with_grid_i8(self._last_obs, rollout_buffer.step))
                 else:
                     actions, values, log_probs = self._pending
-            new_obs, rewards, dones, infos = self._env_step(actions, rollout_buffer.next_obs_row())
+            new_obs, rewards, dones, infos = self._env_step(actions, rollout_buffer.next_obs_row(), defer_autocorr=defer_ac)
             self.num_timesteps += env.num_envs
             if callback is not None:
                 callback.update_locals(locals())
@@ -868,12 +878,13 @@ class PPO_Grid_Obs:
                 # measured in round 4: 535 against 509 us per env step; the step is not host-bound enough to pay for the graph's
                 # cross-queue hand-overs.  profiles/r04_notes.md)
                 new_in = self._with_grid_i8(new_obs, rollout_buffer.step + 1)  # (the buffer's step counter advances in add())
+                ac_row = rollout_buffer.step + 1 if defer_ac else None
                 if n_steps < n_rollout_steps:
-                    nxt = evaluate(new_in)
+                    nxt = evaluate(new_in, autocorr_row=ac_row)
                     terminal_value = nxt[1]
                 else:
                     nxt = None
-                    terminal_value = evaluate(new_in, values_only=True)
+                    terminal_value = evaluate(new_in, values_only=True, autocorr_row=ac_row)
             assert self.timeout_bootstrap in ("reference", "per_env")
             first = self.timeout_bootstrap == "reference"
             if fused_add and self._last_obs.data_ptr() == rollout_buffer.observations[rollout_buffer.step].data_ptr():
@@ -888,6 +899,8 @@ class PPO_Grid_Obs:
             self._last_episode_starts = dones
             self._pending = nxt
         last_values = terminal_value  # V(new_obs) of the last step (:213-215)
+        if plan is not None:
+            torch.cuda.current_stream(self.device).wait_stream(plan.side)  # (the deferred autocorrelation rows: train() reads them)
         self._check_ranges()
         rollout_buffer.compute_returns_and_advantage(last_values=last_values, dones=dones)
         if callback is not None:

@@ -88,7 +88,7 @@ def test_prepared_rollout_forward_is_bit_identical_to_the_general_path():
         for r in range(2):
             assert algo.collect_rollouts(env, None, algo.rollout_buffer, n_rollout_steps=t)
             buf = algo.rollout_buffer
-            snaps.append({k: getattr(buf, k).detach().clone() for k in ("observations", "grid_i8", "actions", "values", "log_probs", "rewards",
+            snaps.append({k: getattr(buf, k).detach().clone() for k in ("observations", "grid_i8", "autocorr", "actions", "values", "log_probs", "rewards",
                                                                          "advantages", "returns", "episode_starts")})
             if r == 0:
                 algo.train()
