@@ -161,7 +161,7 @@ class RolloutForward:
             x = out
         self.ev_join.record(side)
         cur.wait_event(self.ev_join)
-        if tail is not None:
+        if tail is not None:  # (behind the pose branch: in front of it the step measured 10-13 us slower -- the join waits for the branch)
             tail(sst)
         logits = torch.empty(n, self.n_act, dtype=torch.float32, device=dev)  # (kept by the caller across the next step: not plan-owned)
         values = torch.empty(n, dtype=torch.float32, device=dev)
