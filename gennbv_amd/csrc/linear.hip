@@ -186,9 +186,12 @@ __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 
 {
     __shared__ __attribute__((aligned(16))) char s_b[2][2][4096];  // [buffer][hi | lo][column tile 4][g 4][column 16][8 halfs]
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const int i = lane & 15, g = lane >> 4, mbase = blockIdx.y * 128;
+    // 1-D grid: the row slabs (128 rows each) of one (chunk, column tile) sit next to each other in dispatch order and on ONE XCD, so
+    // that the second slab's W requests meet the first one's lines in that XCD's L2 (the rollout's 256 rows: W was fetched twice)
+    const int nslab = (M + 127) / 128;
+    const int xcd = blockIdx.x & 7, t_ = blockIdx.x >> 3, slot = t_ / nslab;
+    const int i = lane & 15, g = lane >> 4, mbase = (t_ - slot * nslab) * 128;
     const int ntn = N / kTileN;
-    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
     const int nt = slot % ntn, chunk = (slot / ntn) * 8 + xcd;
     if (chunk >= nchunks) return;
     const int nstep32 = (K + 31) / 32;  // 32-k trips
@@ -656,7 +659,7 @@ GNBV_API int gnbv_linear_forward_fold(const float *y, const float *scale, const 
     hipStream_t st = gnbv_stream(stream);
     const int nchunks = pick_chunks(K), ntn = N / kTileN;
     const int blocks = ((nchunks + 7) / 8) * 8 * ntn;
-    hipLaunchKernelGGL(k_linear_splitk_split<true>, dim3(blocks, (M + 127) / 128), dim3(kLinThreads), 0, st, y, w, M, N, K, nchunks, (float *)workspace, scale,
+    hipLaunchKernelGGL(k_linear_splitk_split<true>, dim3(blocks * ((M + 127) / 128)), dim3(kLinThreads), 0, st, y, w, M, N, K, nchunks, (float *)workspace, scale,
                        shift, P, range_flag);
     int err;
     if ((err = gnbv_launch_status())) return err;
@@ -679,7 +682,7 @@ GNBV_API int gnbv_linear_forward(const float *x, const float *w, const float *bi
     const bool fp32_arith = (relu & 2) != 0;  // (flag word: include/gennbv_hip.h)
     relu &= 1;
     if (split_kernels_on() && !fp32_arith && K % 8 == 0 && K >= 64)
-        hipLaunchKernelGGL(k_linear_splitk_split<false>, dim3(blocks, (M + 127) / 128), dim3(kLinThreads), 0, st, x, w, M, N, K, nchunks, (float *)workspace);
+        hipLaunchKernelGGL(k_linear_splitk_split<false>, dim3(blocks * ((M + 127) / 128)), dim3(kLinThreads), 0, st, x, w, M, N, K, nchunks, (float *)workspace);
     else
         hipLaunchKernelGGL(k_linear_splitk, dim3(blocks, (M + 127) / 128), dim3(kLinThreads), 0, st, x, w, M, N, K, nchunks, (float *)workspace);
     int err;
