@@ -483,14 +483,15 @@ struct SampleArgs {
     int head_dims[kMaxHeads], head_off[kMaxHeads];
 };
 
-// one WAVE per row: lanes stride over a head's logits (wave-parallel max / sum-exp, inclusive scan for the CDF)
-__global__ __launch_bounds__(256) void k_multicategorical_sample(SampleArgs a, const float *__restrict__ logits, const float *__restrict__ uniforms,
-                                                                 int64_t *__restrict__ actions, float *__restrict__ log_prob)
+// one WORKGROUP per row, one WAVE per head (round 4: a wave used to walk the row's heads one after the other -- six dependent chains of
+// loads, exp and shuffle scans, 13-16 us on the rollout step's critical path): lanes stride over the head's logits (wave-parallel max /
+// sum-exp, inclusive scan for the CDF); the row's log-prob is summed by thread 0 in head order, as the sequential loop did.
+__global__ __launch_bounds__(64 * kMaxHeads) void k_multicategorical_sample(SampleArgs a, const float *__restrict__ logits, const float *__restrict__ uniforms,
+                                                                            int64_t *__restrict__ actions, float *__restrict__ log_prob)
 {
-    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= a.batch) return;
-    float lp = 0.0f;
-    for (int h = 0; h < a.n_heads; ++h) {
+    __shared__ float s_lp[kMaxHeads];
+    const int lane = threadIdx.x & 63, h = threadIdx.x >> 6, b = blockIdx.x;
+    {
         const float *row = logits + (size_t)b * a.n_logits + a.head_off[h];
         const int d = a.head_dims[h];
         // max and first arg-max (torch.argmax semantics: lowest index among equals)
@@ -527,10 +528,17 @@ __global__ __launch_bounds__(256) void k_multicategorical_sample(SampleArgs a, c
                 carry = __shfl(c, 63, 64);
             }
         }
-        if (lane == 0) actions[(size_t)b * a.n_heads + h] = act;
-        lp += row[act] - (mx + logf(s));
+        if (lane == 0) {
+            actions[(size_t)b * a.n_heads + h] = act;
+            s_lp[h] = row[act] - (mx + logf(s));
+        }
     }
-    if (lane == 0) log_prob[b] = lp;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float lp = 0.0f;
+        for (int k = 0; k < a.n_heads; ++k) lp += s_lp[k];
+        log_prob[b] = lp;
+    }
 }
 
 // ===========================================================================
@@ -725,6 +733,6 @@ GNBV_API int gnbv_multicategorical_sample(const float *logits, int batch, int n_
         }
     }
     GNBV_CHECK_ARG(off == n_logits);
-    hipLaunchKernelGGL(k_multicategorical_sample, dim3((batch + 3) / 4), dim3(256), 0, gnbv_stream(stream), a, logits, uniforms, actions, log_prob);
+    hipLaunchKernelGGL(k_multicategorical_sample, dim3(batch), dim3(64 * a.n_heads), 0, gnbv_stream(stream), a, logits, uniforms, actions, log_prob);
     return gnbv_launch_status();
 }
