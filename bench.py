@@ -582,6 +582,9 @@ def main():
                    "minibatches_last_iteration": int(len(algo.last_train_stats)) if getattr(algo, "last_train_stats", None) is not None else None,
                    "hbm_peak_allocated_gb": torch.cuda.max_memory_allocated(device) / 1e9,
                    "parallelism": f"env-sharded dp{world}", "dp_graph_mode": getattr(algo, "dp_graph_mode", None),
+                   # ms per masked replay of each captured candidate of the minibatch graph; the fastest is the one train() replays
+                   # (PPO_Grid_Obs._best_of_captures: a capture lands in one of several scheduling states for its whole life)
+                   "minibatch_graph_captures_ms": getattr(algo, "graph_capture_ms", None),
                    "dp_update": (None if world == 1 else "fc_grid.weight reduce-scattered, updated by its owner rank, all-gathered; the rest all-reduced"
                                  if getattr((algo._hip or {}).get("opt"), "shard", None) is not None else "whole gradient all-reduced, replicated update"),
                    "breakdown_ms_per_step": {"rollout": phases["rollout"].total_ms() / args.steps,

@@ -89,6 +89,7 @@ class PPO_Grid_Obs:
         self.kl_poll = "minibatch"
         self.train_impl = "hip"   # fused loss / flat Adam / device-side early stop when the encoder backend is "hip"
         self.use_graph = True     # replay the minibatch step as one hipGraph
+        self.graph_candidates = None  # None: 3 when a train() call replays the graph >= 256 times, else 1 (see _capture_minibatch_graph)
         self.grad_write_through = True  # backward kernels store into the flat gradient buffer (ops/direct_grad.py)
         self.rotate_rows = True   # replayed graph on one GPU: the Adam launch leaves the next minibatch's row numbers behind (no host copy)
         self.grid_i8_rows = True  # int8 side copy of the grid rows next to flat fp32 rows (what the conv1 kernels of the update read)
@@ -647,6 +648,7 @@ class PPO_Grid_Obs:
                 st["graph"], st["ac_total_on"] = None, use_tot  # (the pointer is a kernel argument baked into the graph)
             enc_._autocorr_total = loss.ac_slot if use_tot else None  # (only for the duration of this call: cleared below)
             rot[2].zero_()
+        st["replays_per_call"] = n_mb * self.n_epochs
         if use_graph and st["graph"] is None:
             if rotating:
                 loss.rows_ext.copy_(rot[0][0])
@@ -742,7 +744,7 @@ class PPO_Grid_Obs:
         if not dp:
             with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                 self._hip_minibatch_body(st)
-            return ga
+            return self._best_of_captures(st, ga)
         if not self._collectives_capturable():
             # Fall back to the EAGER data-parallel step (same `_dp_step_body`, same sharded update, launch by launch): the compute cannot be
             # captured by itself either -- BatchNorm's batch sums are exchanged inside the encoder calls (GnbvEncoderParams.sync_sum), so
@@ -754,6 +756,46 @@ class PPO_Grid_Obs:
             self._dp_step_body(st)
         self.dp_graph_mode = "one hipGraph incl. RCCL collectives"
         return ga
+
+    def _best_of_captures(self, st, first):
+        """A captured minibatch lands in one of several states PER CAPTURE -- the same kernels replay at 507-515 or at 521-532 us,
+        stable for the life of the graph object (when the graph's second queue gets going beside the two heaviest kernels differs from
+        instantiation to instantiation; profiles/r04_notes.md).  A train() call of BASELINE configs[1] replays the graph 1280 times, so when
+        the call is long enough to pay for it, the step is captured `graph_candidates` times and the fastest capture kept: each candidate is
+        replayed with the update masked (stop_flag = 1: parameters, Adam state and BatchNorm statistics untouched, as in the warm-up runs),
+        timed with events; the others are dropped with their memory pools."""
+        k = self.graph_candidates
+        if k is None:
+            k = 3 if st.get("replays_per_call", 0) >= 256 else 1
+        if k <= 1:
+            return first
+        loss = st["loss"]
+        cands = [first]
+        for _ in range(k - 1):
+            loss.stop_flag.fill_(1)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._hip_minibatch_body(st)
+            cands.append(g)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        times = [[] for _ in cands]
+        for rnd in range(3):  # alternate the candidates: clock / thermal drift is common to them
+            for c, g in enumerate(cands):
+                loss.stop_flag.fill_(1)
+                for j in range(13):
+                    if j == 3:
+                        ev0.record()
+                    loss.stats_row.zero_()  # (every replay appends a statistics row: the table only holds one train() call)
+                    g.replay()
+                ev1.record()
+                ev1.synchronize()
+                times[c].append(ev0.elapsed_time(ev1) / 10.0)
+        med = [sorted(t)[1] for t in times]
+        best = min(range(len(cands)), key=lambda c: med[c])
+        self.graph_capture_ms = [round(m, 4) for m in med]  # (bench.py reports it)
+        keep = cands[best]
+        del cands
+        return keep
 
     def _collectives_capturable(self) -> bool:
         """Can this process group's collectives be recorded into a hipGraph?  RCCL (backend "nccl"): yes -- the step, collectives

@@ -32,12 +32,19 @@ def _check(ppo, fx, loss_tol=1e-4):
 
 
 @pytest.mark.parametrize("name", ["F9_ppo_train", "F9_ppo_train_earlystop"])
-@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("graph", [False, True, "best of 2"])
 def test_fused_train_matches_reference(name, graph):
+    """graph = "best of 2": the minibatch is captured twice and the faster capture kept (PPO_Grid_Obs._best_of_captures: the candidates
+    are timed by MASKED replays) -- the reference's losses, early-stop position, parameters and BatchNorm statistics must come out all
+    the same, i.e. the timing replays leave no trace."""
     fx = gu.load(name)
     ppo = _ppo_from_fixture(fx, device=DEV, backend="hip")
-    ppo.use_graph = graph
+    ppo.use_graph = bool(graph)
+    if graph == "best of 2":
+        ppo.graph_candidates = 2
     _check(ppo, fx)
+    if graph == "best of 2":
+        assert len(ppo.graph_capture_ms) == 2 and min(ppo.graph_capture_ms) > 0
 
 
 def test_torch_backend_on_gpu_matches_reference_losses():
