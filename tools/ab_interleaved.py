@@ -88,6 +88,7 @@ def build_train(a, dev):
     algo, cfg, env = bench.build_algo(ns, dev, 0, 1)
     algo.learning_rate = 1e-12
     algo.lr_schedule = lambda _: 1e-12
+    algo.graph_candidates = 1  # (every harness capture is ONE capture: the spread over captures is what --captures measures)
     algo._setup_learn(total_timesteps=10 ** 12)
     algo.collect_rollouts(algo.env, None, algo.rollout_buffer, n_rollout_steps=algo.n_steps)
     algo.train()
@@ -95,6 +96,19 @@ def build_train(a, dev):
     assert g is not None and not isinstance(g, tuple)
     torch.cuda.synchronize()
     loss = algo._hip["loss"]
+    # the same capture with the update MASKED (what PPO_Grid_Obs._best_of_captures ranks its candidates by): printed beside the real figure
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    loss.stop_flag.fill_(1)
+    for j in range(33):
+        if j == 3:
+            e0.record()
+        loss.stats_row.zero_()
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"[ab]   masked replay of this capture: {e0.elapsed_time(e1) / 30.0 * 1e3:.2f} us", file=sys.stderr, flush=True)
+    loss.stop_flag.zero_()
+    loss.stats_row.zero_()
     assert loss.stats.shape[0] > 64  # (every replay appends a row to the statistics table: the chunk must fit, `reset` rewinds it)
     return {"fn": (lambda: g.replay()), "reset": (lambda: loss.stats_row.zero_()), "max_chunk": int(loss.stats.shape[0]) - 2}, algo
 
