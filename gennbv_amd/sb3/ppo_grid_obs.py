@@ -649,6 +649,7 @@ class PPO_Grid_Obs:
             enc_._autocorr_total = loss.ac_slot if use_tot else None  # (only for the duration of this call: cleared below)
             rot[2].zero_()
         st["replays_per_call"] = n_mb * self.n_epochs
+        st["calls_since_capture"] = st.get("calls_since_capture", 0) + 1
         if use_graph and st["graph"] is None:
             if rotating:
                 loss.rows_ext.copy_(rot[0][0])
@@ -766,7 +767,11 @@ class PPO_Grid_Obs:
         timed with events; the others are dropped with their memory pools."""
         k = self.graph_candidates
         if k is None:
-            k = 3 if st.get("replays_per_call", 0) >= 256 else 1
+            # (a learning-rate / clip-range schedule re-captures the graph in every train() call -- the hyper-parameters are kernel
+            # arguments --: candidates only for the first capture and for one that replaces a graph that lived >= 4 calls)
+            stable = st.get("captures", 0) == 0 or st.get("calls_since_capture", 0) >= 4
+            k = 3 if (st.get("replays_per_call", 0) >= 256 and stable) else 1
+        st["captures"], st["calls_since_capture"] = st.get("captures", 0) + 1, 0
         if k <= 1:
             return first
         loss = st["loss"]
