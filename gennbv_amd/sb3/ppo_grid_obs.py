@@ -914,6 +914,9 @@ class PPO_Grid_Obs:
             if callback is not None:
                 callback.update_locals(locals())
                 if callback.on_step() is False:
+                    if defer_ac:  # (leave the buffers as the general path would: this step's row and the second stream joined)
+                        rollout_buffer.update_autocorr(rollout_buffer.step + 1)
+                        torch.cuda.current_stream(self.device).wait_stream(plan.side)
                     return False
             self._update_info_buffer(infos)
             n_steps += 1
