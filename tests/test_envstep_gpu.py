@@ -33,12 +33,15 @@ def make_env_from_fixture(fx):
     return env, cfg
 
 
+@pytest.mark.parametrize("views", [False, True])  # True: ReplayFeedEnv.flag_views -- dones / time_outs as views of the kernels' bytes (collect_rollouts)
 @pytest.mark.parametrize("name", ["F5_envstep_g20", "F5_envstep_c0", "F5_envstep_g64"])
-def test_replay_env_matches_reference_env_bit_exact(name):
+def test_replay_env_matches_reference_env_bit_exact(name, views):
     if not os.path.exists(os.path.join(gu.GOLDEN, name + ".npz")):
         pytest.skip("fixture not generated")
     fx = gu.load(name)
     env, cfg = make_env_from_fixture(fx)
+    env.flag_views = views
+    prev_done = None
     nf = int(fx["num_frames"])
     env.feed.cursor = 0
     obs = env.reset()
@@ -56,6 +59,10 @@ def test_replay_env_matches_reference_env_bit_exact(name):
             np.testing.assert_allclose(got, fx["episode_info"][s], rtol=1e-6, atol=1e-9, err_msg=f"step {s}")
         assert rew.cpu().numpy().tobytes() == fx["rewards"][s].tobytes(), f"step {s}"
         assert np.array_equal(done.cpu().numpy(), fx["dones"][s].astype(bool)), f"step {s}"
+        assert done.dtype == torch.bool and info["time_outs"].dtype == torch.bool
+        if prev_done is not None:  # the previous step's dones are still the previous step's (they are this step's episode_starts)
+            assert np.array_equal(prev_done.cpu().numpy(), fx["dones"][s - 1].astype(bool)), f"step {s}: dones of step {s - 1} overwritten"
+        prev_done = done
         assert np.array_equal(info["time_outs"].cpu().numpy(), fx["time_outs"][s]), f"step {s}"
         # the fixture read reward_ratio_buf[-1] after reset_idx had zeroed the reset envs' entries
         assert env.prev_ratio.cpu().numpy().tobytes() == fx["coverage"][s].tobytes()
