@@ -484,12 +484,12 @@ __global__ __launch_bounds__(kRayThreads) void k_raycast(
 // prefix sum and appends them as a RAY LIST (one int32 target voxel per ray) to the env's slice of the workspace; the
 // mask goes out with plain stores (one workgroup per env) or atomicOr of the non-zero words.
 //
-// k_ray_list: N x 16 workgroups of 256 threads; workgroup (e, s) walks rays [256 s, 256 s + 256) (+ 4096 k) of env e's
-// list, one per lane (the reference's integer Bresenham, trace_ray_lane), into an LDS path mask and ORs the non-zero
-// words out.  The per-env ray counts differ 4x around their mean (an env that faces a large surface has thousands): with
-// one workgroup -- or a fixed split -- per env the launch lasts as long as its busiest env (28 of k_raycast's 65 us were
-// the walk, 59 us in a one-launch hit + walk kernel); slices of 256 rays spread an env over as many CUs as it needs and
-// the slices of light envs retire at once.  (Measured alternatives in profiles/r02_notes.md.)
+// k_ray_list: work items = slices of 384 rays of one env's list, one ray per lane (the reference's integer Bresenham as packed
+// 16-bit arithmetic, walk_packed), into an LDS path mask whose non-zero words are ORed out.  The per-env ray counts differ 4x
+// around their mean (an env that faces a large surface has thousands): with one workgroup -- or a fixed split -- per env the
+// launch lasts as long as its busiest env (28 of k_raycast's 65 us were the walk, 59 us in a one-launch hit + walk kernel);
+// slices spread an env over as many CUs as it needs.  The grid is compact: a block finds its (env, slice) from the counts
+// (see the kernel).  What bounds the walk: the CU's LDS atomic rate and its VALU issue, about equally (profiles/r05_notes.md).
 //
 // A voxel hit from pixels of two chunks is listed by both workgroups: harmless, the path is a set.
 // ===========================================================================
@@ -497,8 +497,11 @@ __global__ __launch_bounds__(kRayThreads) void k_raycast(
 #define FUSED_THREADS 1024
 #endif
 constexpr int kFusedThreads = FUSED_THREADS;
-constexpr int kListThreads = 256;    // k_ray_list: rays per slice = lanes per workgroup
-constexpr int kListSlices = 16;     // slices per env and pass
+constexpr int kListThreads = 384;    // k_ray_list: rays per work item = lanes per workgroup (four workgroups of six waves per CU: their
+                                     // 32 KiB masks are what limits the residency; 256 / 320 / 512 measured within 8 %, profiles/r05_notes.md)
+constexpr int kListGridSlices = 5;   // k_ray_list: grid = this many workgroups per env on average
+constexpr int kSlabThreads = 256;    // k_ray_slab: rays per slice
+constexpr int kListSlices = 16;      // k_ray_slab: slices per env and slab at most
 
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 // streaming 16-byte load (read-once camera data: keep it out of the L2's way)
@@ -988,78 +991,194 @@ template <bool INB>
 __device__ __forceinline__ void walk_slice(const int (&src)[3], const int32_t *__restrict__ list, int cnt, int first, int stride, int g, int gg,
                                            uint32_t *s_path)
 {
-    // Consecutive list entries are neighbouring voxels whose rays run through the same mask words step after step
-    // (64-way same-address LDS atomics): lane r walks entry (r * P) mod cnt instead, a bijection for P coprime to cnt.
-    const int64_t P = (cnt % 7919) ? 7919 : 7907;
+    // (the generic walk: a source voxel outside the grid.  Neighbouring lanes walk neighbouring voxels' rays -- same-address LDS atomics;
+    // poses are clipped to the grid's range, so this is the rare path)
     const unsigned ug = (unsigned)g;
     for (int r = first; r < cnt; r += stride) {
         RayWalk<INB> rw;
-        rw.init(src, list[(int)(((int64_t)r * P) % cnt)], g, gg, true);
+        rw.init(src, list[r], g, gg, true);
         for (int i = rw.left; i > 0; --i) rw.step(ug, s_path);
     }
 }
 
-// launch 2: load-balanced ray cast over the ray lists (see the header above)
+// ---------------------------------------------------------------------------------------------------------------------------
+// The walk of a ray whose source voxel lies in the grid, as PACKED 16-bit arithmetic (round 5).  The walk is bound by
+// instruction issue (profiles/r03_notes.md), so the step is written for the instruction count: the branch-free form above is
+// 17 VALU per step, this one 9.
+//
+//   P  = (p1, p2)  the two error terms of utils.py:72-73 as one i16 pair (|p| < 2 G);   m = P >> 15 = (-1 where p < 0, else 0)
+//   P' = m * (-2 da, -2 da) + (P + (2 db - 2 da, 2 dc - 2 da))     p >= 0: p + 2 d - 2 da;   p < 0: p + 2 d     (utils.py:76-88)
+//   W  = l + (left << 24):  linear voxel index (< 2^24) and the steps still to take in ONE register;
+//   W' = W + dot2((lb, lc), m) + (la + lb + lc - 2^24)  =  l + la + (p1 >= 0 ? lb : 0) + (p2 >= 0 ? lc : 0),  left - 1
+//        (la / lb / lc = the axes' strides in the linear index times their step signs; v_dot2_i32_i16 adds -lb, -lc where p < 0)
+//
+// and the loop is "advance, then emit" (the ray's FIRST voxel is the source voxel, the same for every ray of the env: the
+// workgroup sets that bit once instead of a 64-way same-address atomic per wave), so l only ever takes the values of emitted
+// voxels -- all inside the grid, since both ends are and the coordinates are monotone -- and a borrow can never reach the count.
+// Same integer recurrence as RayWalk / the reference kernel, voxel for voxel (tests/test_voxel_gpu.py: every path mask against the
+// oracle; tools/check_packed_walk.py restates the packing in Python against the plain walk).  Limits: G <= 181 (gg as i16).
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef short v2s_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s_t pack2(int lo, int hi) { return __builtin_bit_cast(v2s_t, (lo & 0xffff) | (hi << 16)); }
+
+__device__ __forceinline__ void walk_packed(int sx, int sy, int sz, int l_src, int lin_t, int g, int gg, float inv_g, float inv_gg,
+                                            uint32_t *s_path)
+{
+    int tx, ty, tz;
+    if ((g & (g - 1)) == 0) {  // (uniform) a power-of-two edge: shifts
+        const int sh = __builtin_ctz(g);
+        tx = lin_t >> (2 * sh); ty = (lin_t >> sh) & (g - 1); tz = lin_t & (g - 1);
+    } else {
+        tx = floor_div_small(lin_t, gg, inv_gg);
+        const int rem = lin_t - tx * gg;
+        ty = floor_div_small(rem, g, inv_g);
+        tz = rem - ty * g;
+    }
+    const int d0 = abs(tx - sx), d1 = abs(ty - sy), d2 = abs(tz - sz);
+    const int da = max(max(d0, d1), d2);
+    // dominant axis tested x, y, z (utils.py:69,102,133); the minors keep the reference's order; an axis that does not move has
+    // d = 0 and never steps, whatever its sign
+    const bool ax = da == d0, ay = !ax && da == d1;
+    const int l0 = sx < tx ? gg : -gg, l1 = sy < ty ? g : -g, l2 = sz < tz ? 1 : -1;
+    const int la = ax ? l0 : (ay ? l1 : l2), lb = ax ? l1 : l0, lc = (ax || ay) ? l2 : l1;
+    const int db = ax ? d1 : d0, dc = (ax || ay) ? d2 : d1;
+    int W = l_src + (da << 24);
+    v2s_t P = pack2(2 * db - da, 2 * dc - da);
+    const v2s_t neg2da = pack2(-2 * da, -2 * da), dl = pack2(2 * db - 2 * da, 2 * dc - 2 * da), lbc = pack2(lb, lc);
+    const int kp = la + lb + lc - (1 << 24);
+    while (W >= (1 << 24)) {
+        const v2s_t m = P >> (v2s_t)(15);
+        P = m * neg2da + (P + dl);
+        W = __builtin_amdgcn_sdot2(lbc, m, W, false) + kp;
+        // Neighbouring lanes walk neighbouring voxels' rays (list order = voxel order), which run through the SAME voxel for most of
+        // their length: a lane whose voxel is its left neighbour's leaves the bit to it.  (An LDS atomic of 64 lanes on one address
+        // costs ~450 cycles of the CU's LDS pipe, on 64 scattered addresses ~16: tools/ubench/ray_step_rate.hip.  A lane that is
+        // switched off -- its ray has ended -- reads as -1: no voxel.)
+        const int l = W & 0xffffff;
+        const int lp = __builtin_amdgcn_update_dpp(-1, l, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+        if (l != lp) atomicOr(&s_path[l >> 5], 1u << (l & 31));
+    }
+}
+
+// launch 2: load-balanced ray cast over the ray lists (see the header above).
+//
+// Work items = slices of `width` = 256 rpl rays of one env's list.  Which envs have how many slices is only known on the device, and
+// a workgroup that finds nothing to do still costs a dispatch slot: the chip starts ~40 workgroups per us and XCD whatever they do,
+// so a grid of N x 16 (env, slice) pairs of which a third is live lasts >= 14 us however fast the live ones are (round-4 layout;
+// profiles/r05_notes.md).  Round 5: the grid is COMPACT.  Block b runs on XCD b % 8 and takes item j = b / 8 of that XCD's envs
+// (e = 8 k + xcd: an env's path words stay in one XCD's L2): every wave reads the counts of those envs (<= 64 per pass), scans the
+// slice counts and finds the (env, slice) that holds item j -- ~40 instructions per wave, no inter-workgroup traffic.  Blocks past
+// the XCD's last item exit; they sit at the END of the dispatch order, behind every live workgroup.  A grid smaller than the item
+// count (an env with tens of thousands of rays) makes its workgroups take several items.
 __global__ __launch_bounds__(kListThreads) void k_ray_list(
     const int32_t *__restrict__ ray_count, const int32_t *__restrict__ ray_list, int64_t ray_cap, const float *__restrict__ poses_xyz,
     int64_t pose_stride, const float *__restrict__ range_gt, const float *__restrict__ voxel_size, int n, int g, int words,
     uint32_t *__restrict__ path_mask)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_path[];
-    // block -> (env, slice), env-major.  (Measured alternatives, per-workgroup time stamps in profiles/r03_notes.md: ~1300 of the 4096
-    // workgroups are live and ~1000 fit the chip's LDS at once, so the launch runs as two rounds -- live workgroups start over 15 us;
-    // slice-major order, 384- and 512-thread workgroups and two interleaved rays per lane all lengthen the slowest workgroup by more
-    // than they save: 29-35 us against 28.)
-    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
-    const int e = (slot / kListSlices) * 8 + xcd;
-    const int sl = slot % kListSlices;
-    if (e >= n) return;
-    const int cnt = (int)min((int64_t)ray_count[e], ray_cap);
-    if (sl * kListThreads >= cnt) return;  // light env: nothing for this slice
-    const int tid = threadIdx.x;
+    const int b = blockIdx.x, xcd = b & 7, per_xcd = (int)(gridDim.x >> 3);
+    const int env_groups = (n + 7) >> 3;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    constexpr int width = kListThreads;  // rays per item: one per lane
+    const int gg = g * g;
+    const float inv_g = __frcp_rn((float)g), inv_gg = __frcp_rn((float)gg);
 #ifdef PHASE_TIMING
     const uint64_t rt0 = wall_clock64();
+    int32_t *dbg = const_cast<int32_t *>(ray_list) + (size_t)n * ray_cap - 8 * 512 - 8 * (size_t)(blockIdx.x + 1);
+    bool first_item = true;
 #endif
-    for (int i = tid; i < words; i += kListThreads) s_path[i] = 0u;
-    const float *pp = poses_xyz + (size_t)e * pose_stride;
-    const int src[3] = {pose_axis_to_idx(pp[0], range_gt[e * 6 + 1], voxel_size[e * 3 + 0]),
-                        pose_axis_to_idx(pp[1], range_gt[e * 6 + 3], voxel_size[e * 3 + 1]),
-                        pose_axis_to_idx(pp[2], range_gt[e * 6 + 5], voxel_size[e * 3 + 2])};
-    const int gg = g * g;
-    const int32_t *list = ray_list + (size_t)e * ray_cap;
-    __syncthreads();
-    const bool src_in = (unsigned)src[0] < (unsigned)g && (unsigned)src[1] < (unsigned)g && (unsigned)src[2] < (unsigned)g;  // (per env: uniform)
-    if (src_in)
-        walk_slice<true>(src, list, cnt, sl * kListThreads + tid, kListSlices * kListThreads, g, gg, s_path);
-    else
-        walk_slice<false>(src, list, cnt, sl * kListThreads + tid, kListSlices * kListThreads, g, gg, s_path);
+    for (int j = b >> 3;; j += per_xcd) {
+        // ---- item j of this XCD -> (env, slice); the same in every wave ----
+        int e = -1, sl = 0, cnt = 0, before = 0;
+        for (int k0 = 0; k0 < env_groups; k0 += kWave) {
+            const int ek = (k0 + lane) * 8 + xcd;
+            const int c = (k0 + lane < env_groups && ek < n) ? (int)min((int64_t)ray_count[ek], ray_cap) : 0;
+            const int items = (c + width - 1) / width;
+            const int incl = wave_inclusive_scan(items);
+            const int chunk = __builtin_amdgcn_readlane(incl, kWave - 1);
+            if (j < before + chunk) {
+                const int kk = __ffsll((unsigned long long)__ballot(before + incl > j)) - 1;
+                e = (k0 + kk) * 8 + xcd;
+                sl = j - before - (__builtin_amdgcn_readlane(incl, kk) - __builtin_amdgcn_readlane(items, kk));
+                cnt = __builtin_amdgcn_readlane(c, kk);
+                break;
+            }
+            before += chunk;
+        }
+        if (e < 0) {  // past the XCD's last item
 #ifdef PHASE_TIMING
-    const uint64_t rt1w = wall_clock64();  // this wave's walk
+            if (tid == 0 && first_item) {
+                dbg[0] = (int32_t)(rt0 & 0x7fffffff); dbg[6] = (int32_t)(wall_clock64() - rt0); dbg[5] = 2;
+                dbg[2] = (int32_t)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4);   // HW_ID
+                dbg[1] = (int32_t)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | 20);  // XCC_ID
+            }
 #endif
-    __syncthreads();
+            return;
+        }
 #ifdef PHASE_TIMING
-    const uint64_t rt1 = wall_clock64();
+        const uint64_t rt_cnt = wall_clock64();
 #endif
-    uint32_t *gp = path_mask + (size_t)e * words;
-#if defined(RAY_ABL) && RAY_ABL == 3
-    if (words < 0)
+        // every request of the item's prologue at once: the pose, the frame, the lane's first list entry
+        const int32_t *list = ray_list + (size_t)e * ray_cap;
+        const float *pp = poses_xyz + (size_t)e * pose_stride;
+        const int r_first = sl * width + tid;
+        const int32_t lin_first = list[min(r_first, cnt - 1)];
+        const float pose0 = pp[0], pose1 = pp[1], pose2 = pp[2];
+        const float rmin0 = range_gt[e * 6 + 1], rmin1 = range_gt[e * 6 + 3], rmin2 = range_gt[e * 6 + 5];
+        const float vox0 = voxel_size[e * 3 + 0], vox1 = voxel_size[e * 3 + 1], vox2 = voxel_size[e * 3 + 2];
+        {
+            uint4 *s4 = reinterpret_cast<uint4 *>(s_path);  // (words is a multiple of 64)
+            for (int i = tid; i < words / 4; i += kListThreads) s4[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        const int src[3] = {pose_axis_to_idx(pose0, rmin0, vox0), pose_axis_to_idx(pose1, rmin1, vox1), pose_axis_to_idx(pose2, rmin2, vox2)};
+        __syncthreads();
+        const bool src_in = (unsigned)src[0] < (unsigned)g && (unsigned)src[1] < (unsigned)g && (unsigned)src[2] < (unsigned)g;  // (per env: uniform)
+#ifdef PHASE_TIMING
+        const uint64_t rt_src = src_in ? wall_clock64() : 0;  // (the pose loads have arrived)
 #endif
-    for (int i = tid; i < words; i += kListThreads) {
-        const uint32_t v = s_path[i];
-        if (v) atomicOr(&gp[i], v);
+        const int r_end = min(cnt, (sl + 1) * width);
+        if (src_in && g <= 181) {
+            const int l_src = src[0] * gg + src[1] * g + src[2];
+            if (tid == 0) atomicOr(&s_path[l_src >> 5], 1u << (l_src & 31));  // every ray's first voxel
+            for (int r = r_first; r < r_end; r += kListThreads)
+                walk_packed(src[0], src[1], src[2], l_src, r == r_first ? lin_first : list[r], g, gg, inv_g, inv_gg, s_path);
+        } else if (src_in) {
+            walk_slice<true>(src, list, r_end, r_first, kListThreads, g, gg, s_path);
+        } else {
+            walk_slice<false>(src, list, r_end, r_first, kListThreads, g, gg, s_path);
+        }
+#ifdef PHASE_TIMING
+        const uint64_t rt1w = wall_clock64();  // this wave's walk
+#endif
+        __syncthreads();
+        uint32_t *gp = path_mask + (size_t)e * words;
+        {
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(s_path);
+            for (int i = tid; i < words / 4; i += kListThreads) {
+                const uint4 v = s4[i];
+                if (v.x | v.y | v.z | v.w) {
+                    if (v.x) atomicOr(&gp[4 * i + 0], v.x);
+                    if (v.y) atomicOr(&gp[4 * i + 1], v.y);
+                    if (v.z) atomicOr(&gp[4 * i + 2], v.z);
+                    if (v.w) atomicOr(&gp[4 * i + 3], v.w);
+                }
+            }
+        }
+        __syncthreads();  // (the mask is cleared again for the next item)
+#ifdef PHASE_TIMING
+        if (tid == 0 && first_item) {
+            dbg[0] = (int32_t)(rt0 & 0x7fffffff);
+            dbg[1] = (int32_t)(rt1w - rt0);
+            dbg[2] = (int32_t)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4);   // HW_ID
+            dbg[3] = (int32_t)(wall_clock64() - rt0);
+            dbg[4] = (int32_t)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | 20);  // XCC_ID
+            dbg[5] = 1;
+            dbg[6] = (int32_t)(rt_cnt - rt0);
+            dbg[7] = (int32_t)(rt_src - rt0);
+        }
+        first_item = false;
+#endif
     }
-#ifdef PHASE_TIMING
-    __syncthreads();
-    if (tid == 0) {
-        int32_t *dbg = const_cast<int32_t *>(ray_list) + (size_t)n * ray_cap - 8 * 512 - 8 * (size_t)(blockIdx.x + 1);
-        dbg[0] = (int32_t)(rt0 & 0x7fffffff);
-        dbg[1] = (int32_t)(rt1w - rt0);
-        dbg[2] = (int32_t)(rt1 - rt0);
-        dbg[3] = (int32_t)(wall_clock64() - rt0);
-        dbg[4] = cnt;
-        dbg[5] = 1;
-    }
-#endif
 }
 
 // ===========================================================================
@@ -1326,7 +1445,7 @@ __device__ __forceinline__ void walk_slab(const int (&src)[3], const int32_t *__
     }
 }
 
-__global__ __launch_bounds__(kListThreads) void k_ray_slab(
+__global__ __launch_bounds__(kSlabThreads) void k_ray_slab(
     const int32_t *__restrict__ ray_count, const int32_t *__restrict__ ray_list, int64_t ray_cap, const float *__restrict__ poses_xyz,
     int64_t pose_stride, const float *__restrict__ range_gt, const float *__restrict__ voxel_size, int n, int g, int words, int slabs,
     int slab_planes, int slices, uint32_t *__restrict__ path_mask)
@@ -1340,12 +1459,12 @@ __global__ __launch_bounds__(kListThreads) void k_ray_slab(
     const int rem = slot % per_env, slab = rem / slices, sl = rem % slices;
     if (e >= n) return;
     const int cnt = (int)min((int64_t)ray_count[e], ray_cap);
-    if (sl * kListThreads >= cnt) return;
+    if (sl * kSlabThreads >= cnt) return;
     const int tid = threadIdx.x, gg = g * g;
     const int X0 = slab * slab_planes, X1 = min(g, X0 + slab_planes);
     const int w0 = (int)(((int64_t)X0 * gg) >> 5);  // (X0 * gg % 32 == 0: the host picks slab_planes that way)
     const int nw = min(words, (int)(((int64_t)X1 * gg + 31) >> 5)) - w0;
-    for (int i = tid; i < nw; i += kListThreads) s_path[i] = 0u;
+    for (int i = tid; i < nw; i += kSlabThreads) s_path[i] = 0u;
     const float *pp = poses_xyz + (size_t)e * pose_stride;
     const int src[3] = {pose_axis_to_idx(pp[0], range_gt[e * 6 + 1], voxel_size[e * 3 + 0]),
                         pose_axis_to_idx(pp[1], range_gt[e * 6 + 3], voxel_size[e * 3 + 1]),
@@ -1354,12 +1473,12 @@ __global__ __launch_bounds__(kListThreads) void k_ray_slab(
     __syncthreads();
     const bool src_in = (unsigned)src[0] < (unsigned)g && (unsigned)src[1] < (unsigned)g && (unsigned)src[2] < (unsigned)g;
     if (src_in)
-        walk_slab<true>(src, list, cnt, sl * kListThreads + tid, slices * kListThreads, g, gg, X0, X1, s_path);
+        walk_slab<true>(src, list, cnt, sl * kSlabThreads + tid, slices * kSlabThreads, g, gg, X0, X1, s_path);
     else
-        walk_slab<false>(src, list, cnt, sl * kListThreads + tid, slices * kListThreads, g, gg, X0, X1, s_path);
+        walk_slab<false>(src, list, cnt, sl * kSlabThreads + tid, slices * kSlabThreads, g, gg, X0, X1, s_path);
     __syncthreads();
     uint32_t *gp = path_mask + (size_t)e * words + w0;
-    for (int i = tid; i < nw; i += kListThreads) {
+    for (int i = tid; i < nw; i += kSlabThreads) {
         const uint32_t v = s_path[i];
         if (v) atomicOr(&gp[i], v);
     }
@@ -1985,7 +2104,9 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
         if (ray_lds > 64 * 1024 &&
             hipFuncSetAttribute((const void *)k_ray_list, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ray_lds) != hipSuccess)
             return (int)hipGetLastError();
-        hipLaunchKernelGGL(k_ray_list, dim3(env_groups * 8 * kListSlices), dim3(kListThreads), ray_lds, st, ws.ray_count, ws.ray_list,
+        // grid: kListGridSlices workgroups per env on average (an env takes as many as it has slices of kListThreads rays; 256 x 240x320 x
+        // 64^3: ~3.5); past that the workgroups take several items
+        hipLaunchKernelGGL(k_ray_list, dim3(env_groups * 8 * kListGridSlices), dim3(kListThreads), ray_lds, st, ws.ray_count, ws.ray_list,
                            ws.ray_cap, poses_xyz, poses_row_stride, range_gt, voxel_size, n, g, words, ws.path);
         return gnbv_launch_status();
     }
@@ -2032,7 +2153,7 @@ static int launch_masks(const float *depth_raw, const float *seg_raw, const floa
                 return (int)hipGetLastError();
             int slab_slices = 32 / slabs;  // ~32 workgroups per env, at least two per slab
             slab_slices = slab_slices < 2 ? 2 : (slab_slices > kListSlices ? kListSlices : slab_slices);
-            hipLaunchKernelGGL(k_ray_slab, dim3(env_groups * 8 * slabs * slab_slices), dim3(kListThreads), slab_lds, st, ws.ray_count, ws.ray_list, ws.ray_cap,
+            hipLaunchKernelGGL(k_ray_slab, dim3(env_groups * 8 * slabs * slab_slices), dim3(kSlabThreads), slab_lds, st, ws.ray_count, ws.ray_list, ws.ray_cap,
                                poses_xyz, poses_row_stride, range_gt, voxel_size, n, g, words, slabs, slab_planes, slab_slices, ws.path);
             return gnbv_launch_status();
         }

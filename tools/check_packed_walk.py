@@ -1,0 +1,65 @@
+"""The packed 16-bit Bresenham step of k_ray_list (csrc/voxel.hip::walk_packed), restated with Python integers and compared
+with the plain walk of the reference kernel (gennbv/utils.py:48-167) on random in-grid rays.  No GPU needed."""
+import random
+def s16(x): x &= 0xFFFF; return x - 0x10000 if x & 0x8000 else x
+def pk(lo, hi): return (lo & 0xFFFF) | ((hi & 0xFFFF) << 16)
+def lo(x): return s16(x); 
+def hi(x): return s16(x >> 16)
+def pk_ashr15(x): return pk(-1 if lo(x) < 0 else 0, -1 if hi(x) < 0 else 0)
+def pk_add(a, b): return pk(lo(a) + lo(b), hi(a) + hi(b))
+def pk_mad(a, b, c): return pk(lo(a) * lo(b) + lo(c), hi(a) * hi(b) + hi(c))
+def dot2(a, b, c): return (lo(a) * lo(b) + hi(a) * hi(b) + c)
+def s32(x): x &= 0xFFFFFFFF; return x - (1 << 32) if x & (1 << 31) else x
+def ref_walk(src, tgt, g):
+    d = [abs(tgt[i] - src[i]) for i in range(3)]; s = [1 if src[i] < tgt[i] else -1 for i in range(3)]
+    dm = max(d)
+    if dm == d[0]: ax = (0, 1, 2)
+    elif dm == d[1]: ax = (1, 0, 2)
+    else: ax = (2, 0, 1)
+    p = [src[a] for a in ax]; dd = [d[a] for a in ax]; ss = [s[a] for a in ax]
+    p1 = 2 * dd[1] - dd[0]; p2 = 2 * dd[2] - dd[0]
+    out = []
+    def emit():
+        c = [0, 0, 0]
+        for k, a in enumerate(ax): c[a] = p[k]
+        out.append((c[0] * g + c[1]) * g + c[2])
+    emit()
+    for i in range(dd[0]):
+        if p1 >= 0: p[1] += ss[1]; p1 -= 2 * dd[0]
+        if p2 >= 0: p[2] += ss[2]; p2 -= 2 * dd[0]
+        p[0] += ss[0]; p1 += 2 * dd[1]; p2 += 2 * dd[2]
+        emit()
+    return out
+def packed_walk(src, tgt, g):
+    gg = g * g
+    d = [abs(tgt[i] - src[i]) for i in range(3)]
+    dm = max(d)
+    ax_ = dm == d[0]; ay = (not ax_) and dm == d[1]
+    pa = src[0] if ax_ else (src[1] if ay else src[2]); pb = src[1] if ax_ else src[0]; pc = src[2] if (ax_ or ay) else src[1]
+    ta = tgt[0] if ax_ else (tgt[1] if ay else tgt[2]); tb = tgt[1] if ax_ else tgt[0]; tc = tgt[2] if (ax_ or ay) else tgt[1]
+    da = dm; db = d[1] if ax_ else d[0]; dc = d[2] if (ax_ or ay) else d[1]
+    st_a = gg if ax_ else (g if ay else 1); st_b = g if ax_ else gg; st_c = 1 if (ax_ or ay) else g
+    sa = 1 if pa < ta else -1; sb = 1 if pb < tb else -1; sc = 1 if pc < tc else -1
+    la, lb, lc = sa * st_a, sb * st_b, sc * st_c
+    l = pa * st_a + pb * st_b + pc * st_c
+    W = s32(l + (da << 24))
+    P = pk(2 * db - da, 2 * dc - da)
+    NEG2DA = pk(-2 * da, -2 * da); DL = pk(2 * db - 2 * da, 2 * dc - 2 * da); LBC = pk(lb, lc)
+    Kp = la + lb + lc - (1 << 24)
+    out = [l]  # the source voxel, emitted once per workgroup
+    while W >= (1 << 24):
+        m = pk_ashr15(P)
+        P = pk_mad(m, NEG2DA, pk_add(P, DL))
+        W = s32(dot2(LBC, m, W) + Kp)
+        out.append(W & 0xFFFFFF if True else 0)
+        addr = (W >> 3) & 0x3FFFC; bit = W & 31
+        assert addr == ((W & 0xFFFFFF) >> 5) * 4 and (W & 0xFFFFFF) < g ** 3, (W, addr)
+    return out
+random.seed(1)
+for g in (16, 20, 33, 64, 96, 104):
+    for it in range(20000):
+        src = [random.randrange(g) for _ in range(3)]; tgt = [random.randrange(g) for _ in range(3)]
+        if it % 7 == 0: tgt[random.randrange(3)] = src[random.randrange(3)]
+        a, b = ref_walk(src, tgt, g), packed_walk(src, tgt, g)
+        assert a == b, (g, src, tgt, a, b)
+print("packed recurrence == reference walk")

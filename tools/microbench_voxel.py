@@ -60,7 +60,7 @@ print(f"update_occ_grid: {ms:.4f} ms/step  -> {a.n / ms * 1e3:.0f} env-steps/s (
 
 if a.phase_times:
     import numpy as np
-    nrb = ((a.n + 7) // 8) * 8 * 16
+    nrb = ((a.n + 7) // 8) * 8 * 16  # (stamp slots: the ray launch's grid is at most this)
     # one more step on a zeroed stamp area, so that every stamp belongs to the SAME launch
     upd.workspace.view(torch.int32)[-(8 * 512 + 8 * nrb):].zero_()
     upd.update(frames[0].depth_raw, frames[0].seg_raw, c2ws[0], poses[0], **kw)
@@ -76,8 +76,41 @@ if a.phase_times:
     print("  corr(A, rays)", np.corrcoef(pa, rays)[0, 1].round(2))
 
     rt = upd.workspace.view(torch.int32)[-(8 * 512 + 8 * nrb):-8 * 512].cpu().numpy().reshape(nrb, 8)[::-1]
-    live = rt[rt[:, 5] == 1]
+    live, dead = rt[rt[:, 5] == 1], rt[rt[:, 5] == 2]
     t0 = live[:, 0] / 100.0
+    tall = np.concatenate([live[:, 0], dead[:, 0]]) / 100.0
+    print(f"k_ray_list: {len(dead)} dead workgroups, entry -> exit mean {dead[:, 6].mean() / 100:.2f} max {dead[:, 6].max() / 100:.2f} us; all entries spread {tall.max() - tall.min():.1f}; "
+          f"live: count known mean {live[:, 6].mean() / 100:.2f} max {live[:, 6].max() / 100:.2f}, pose known + mask clear mean {live[:, 7].mean() / 100:.2f} max {live[:, 7].max() / 100:.2f}")
+    order = np.argsort(t0)
+    print("  live starts (us after the first), every 10th percentile:", np.percentile(t0 - tall.min(), range(0, 101, 10)).round(1))
+    print("  live ends, every 10th percentile:", np.percentile(t0 + live[:, 3] / 100.0 - tall.min(), range(0, 101, 10)).round(1))
     print(f"k_ray_list phases over {len(live)} live workgroups of {nrb} (us): wave-0 walk mean {live[:, 1].mean() / 100:.1f} max {live[:, 1].max() / 100:.1f} | "
-          f"walk (all waves) mean {live[:, 2].mean() / 100:.1f} max {live[:, 2].max() / 100:.1f} | total mean {live[:, 3].mean() / 100:.1f} max {live[:, 3].max() / 100:.1f} | "
+          f"total mean {live[:, 3].mean() / 100:.1f} max {live[:, 3].max() / 100:.1f} | "
           f"start spread {t0.max() - t0.min():.1f} | end spread {(t0 + live[:, 3] / 100.0).max() - t0.min():.1f}")
+    lv_idx = np.nonzero(rt[:, 5] == 1)[0]
+    dur = rt[lv_idx, 3] / 100.0
+    print("  live duration percentiles (us):", np.percentile(dur, [10, 50, 90, 99, 100]).round(1))
+    # where the workgroups ran: HW_ID (cu_id [11:8], sh_id [12], se_id [15:13]) and XCC_ID [3:0]
+    def place(r, hw_col, xcc_col):
+        hw, xcc = r[:, hw_col], r[:, xcc_col] & 15
+        return xcc, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15
+    blk = np.arange(nrb)[::1]
+    rec = rt  # (row i = block i)
+    has = rec[:, 5] > 0
+    xcc = np.where(rec[:, 5] == 1, rec[:, 4], rec[:, 1]) & 15
+    hw = rec[:, 2]
+    se, sh, cu = (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15
+    b = np.arange(nrb)
+    print("  block -> XCC == block % 8 for", int(((xcc == (b & 7)) & has).sum()), "of", int(has.sum()), "; distinct (se, sh, cu) per XCC:",
+          len(set(zip(xcc[has], se[has], sh[has], cu[has]))) / max(1, len(set(xcc[has]))))
+    slot = b >> 3
+    for k in range(16):
+        m = has & (xcc == 0) & (slot < 16 * 3)
+    first = [(int(slot[i]), int(se[i]), int(sh[i]), int(cu[i]), int(rec[i, 5])) for i in np.nonzero(has & (xcc == 0))[0][:48]]
+    print("  XCC 0, first 48 blocks (slot, se, sh, cu, live=1/dead=2):", first)
+    lv = rec[:, 5] == 1
+    for x in range(2):
+        mm = lv & (xcc == x)
+        key = se[mm] * 100 + sh[mm] * 16 + cu[mm]
+        u, c = np.unique(key, return_counts=True)
+        print(f"  XCC {x}: live workgroups per CU: n_cu {len(u)} min {c.min()} max {c.max()} mean {c.mean():.1f}; per SE:", {int(k): int(((se[mm]) == k).sum()) for k in np.unique(se[mm])})
