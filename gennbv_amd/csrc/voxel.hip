@@ -1056,7 +1056,11 @@ __device__ __forceinline__ void walk_packed(int sx, int sy, int sz, int l_src, i
         // switched off -- its ray has ended -- reads as -1: no voxel.)
         const int l = W & 0xffffff;
         const int lp = __builtin_amdgcn_update_dpp(-1, l, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+#ifdef RAY_ABL_NOATOM  // (measurement build: the walk without its LDS atomics -- and with nothing to flush: 20.7 -> 13.4 us)
+        if (l == 0x7fffff) atomicOr(&s_path[l >> 5], 1u << (l & 31));
+#else
         if (l != lp) atomicOr(&s_path[l >> 5], 1u << (l & 31));
+#endif
     }
 }
 
@@ -1070,7 +1074,10 @@ __device__ __forceinline__ void walk_packed(int sx, int sy, int sz, int l_src, i
 // slice counts and finds the (env, slice) that holds item j -- ~40 instructions per wave, no inter-workgroup traffic.  Blocks past
 // the XCD's last item exit; they sit at the END of the dispatch order, behind every live workgroup.  A grid smaller than the item
 // count (an env with tens of thousands of rays) makes its workgroups take several items.
-__global__ __launch_bounds__(kListThreads) void k_ray_list(
+// (amdgpu_num_sgpr: with the 96 the compiler takes, a SIMD's SGPR file holds 7 waves; the six waves of a workgroup do not spread evenly
+// over the four SIMDs, so some CUs then held three workgroups instead of five and a tenth of the launch's workgroups started when the
+// first ones ended: -3.6 us per update, profiles/r05_notes.md)
+__global__ __launch_bounds__(kListThreads) __attribute__((amdgpu_num_sgpr(80))) void k_ray_list(
     const int32_t *__restrict__ ray_count, const int32_t *__restrict__ ray_list, int64_t ray_cap, const float *__restrict__ poses_xyz,
     int64_t pose_stride, const float *__restrict__ range_gt, const float *__restrict__ voxel_size, int n, int g, int words,
     uint32_t *__restrict__ path_mask)
@@ -1660,8 +1667,39 @@ __global__ __launch_bounds__(kGridThreads) void k_grid_update_coded(
 {
     __shared__ float lut[256];
     __shared__ int s_cov[kGridThreads / kWave];
-    for (int i = threadIdx.x; i < 256; i += kGridThreads) lut[i] = tri_lut[i];
+    __shared__ unsigned long long s_cls[3][4];  // codes with tri-class +1 / 0 / -1, 64 codes per entry
+    static_assert(kGridThreads == 256, "one thread per code below");
+    {
+        const float t = tri_lut[threadIdx.x];
+        lut[threadIdx.x] = t;
+        const unsigned long long b1 = __ballot(t == 1.0f), b0 = __ballot(t == 0.0f), bm = __ballot(t == -1.0f);
+        if ((threadIdx.x & (kWave - 1)) == 0) {
+            s_cls[0][threadIdx.x / kWave] = b1; s_cls[1][threadIdx.x / kWave] = b0; s_cls[2][threadIdx.x / kWave] = bm;
+        }
+    }
     __syncthreads();
+    // Byte-parallel tri-class (VPL = 16): the table of gnbv_prob_code_tables is, per base, +1 for the first K1 step counts, 0 up to K2,
+    // -1 from there (a probability that only falls), so tri(code) = (k < K1[base]) + (k < K2[base]) - 1 and four codes of a dword are
+    // classified with ~10 integer instructions instead of four table reads, conversions and merges (the update is as much VALU- as
+    // HBM-bound: ~14 instructions per voxel before, profiles/r05_notes.md).  Any other table takes the table path.
+    int K1[2], K2[2];
+#ifdef GRID_NO_SWAR
+    bool swar = false;
+#else
+    bool swar = true;
+#endif
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const unsigned long long p0 = s_cls[0][2 * b], p1 = s_cls[0][2 * b + 1], z0 = s_cls[1][2 * b], z1 = s_cls[1][2 * b + 1];
+        const unsigned long long m0 = s_cls[2][2 * b], m1 = s_cls[2][2 * b + 1];
+        K1[b] = __popcll(p0) + __popcll(p1);
+        K2[b] = K1[b] + __popcll(z0) + __popcll(z1);
+        auto prefix = [](unsigned long long lo, unsigned long long hi, int k) {  // bits [0, k) of the 128
+            const unsigned long long elo = k >= 64 ? ~0ull : ((1ull << k) - 1ull), ehi = k <= 64 ? 0ull : (k >= 128 ? ~0ull : ((1ull << (k - 64)) - 1ull));
+            return lo == elo && hi == ehi;
+        };
+        swar = swar && prefix(p0, p1, K1[b]) && prefix(p0 | z0, p1 | z1, K2[b]) && (p0 | z0 | m0) == ~0ull && (p1 | z1 | m1) == ~0ull;
+    }
     const int e = blockIdx.y;
     const bool reset = reset_mask != nullptr && reset_mask[e] != 0;
     uint32_t *hm = hit_mask + (size_t)e * words, *pm = path_mask + (size_t)e * words;
@@ -1689,6 +1727,30 @@ __global__ __launch_bounds__(kGridThreads) void k_grid_update_coded(
             } else {
                 cw[0] = reset ? 0u : reinterpret_cast<const uint32_t *>(code)[i];
             }
+            if (NW == 4 && swar) {
+                constexpr uint32_t k01 = 0x01010101u, k80 = 0x80808080u, k7f = 0x7f7f7f7fu;
+                const uint32_t a1 = (uint32_t)K1[0] * k01, b1 = (uint32_t)K1[1] * k01, a2 = (uint32_t)K2[0] * k01, b2 = (uint32_t)K2[1] * k01;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) {
+                    // step_code on four bytes: path -> k + 1 (saturating at 127), hit -> 0x80.  (x * 0x00204081) & 0x01010101 spreads four
+                    // bits to the low bits of four bytes; no byte carries into its neighbour: k + 1 <= 0x80, 0x80 | k - K >= 0.
+                    const uint32_t inc = (((pb >> (4 * q)) & 15u) * 0x00204081u) & k01;
+                    const uint32_t hb1 = (((hb >> (4 * q)) & 15u) * 0x00204081u) & k01;
+                    const uint32_t hmask = (hb1 << 8) - hb1;  // 0xff per hit byte
+                    uint32_t k = (cw[q] & k7f) + inc;
+                    const uint32_t sat = k & k80;
+                    ovf |= sat != 0u;
+                    k -= sat >> 7;
+                    const uint32_t o = ((cw[q] & k80) | k) & ~hmask | (k80 & hmask);
+                    out[q] = o;
+                    // tri-class bytes: 1 where k < K1[base], 0 where k < K2[base], 0xff otherwise
+                    const uint32_t bs = o & k80, bmask = (bs - (bs >> 7)) | bs;  // 0xff per byte with base 1
+                    const uint32_t t1 = (a1 & ~bmask) | (b1 & bmask), t2 = (a2 & ~bmask) | (b2 & bmask);
+                    const uint32_t kk = (o & k7f) | k80;
+                    const uint32_t ge1 = ((kk - t1) >> 7) & k01, g2 = (kk - t2) & k80;
+                    t8[q] = (ge1 ^ k01) | ((g2 - (g2 >> 7)) | g2);
+                }
+            } else
 #pragma unroll
             for (int q = 0; q < NW; ++q) {
                 float4 t4;
@@ -1705,18 +1767,25 @@ __global__ __launch_bounds__(kGridThreads) void k_grid_update_coded(
                 if constexpr (NW == 1)
                     if (tri) reinterpret_cast<float4 *>(tri)[i] = t4;
             }
+            // (a step touches ~3 % of the voxels: the codes of a lane change only where a hit / path bit is set or the env resets)
+            // (the stores below are conditional: -2.9 us per update at 256 x 64^3, same-box A/B, profiles/r05_notes.md)
+            const bool touched = reset || (hb | pb) != 0u;
             if constexpr (NW == 4) {
-                reinterpret_cast<uint4 *>(code)[i] = make_uint4(out[0], out[1], out[2], out[3]);
+                if (touched) reinterpret_cast<uint4 *>(code)[i] = make_uint4(out[0], out[1], out[2], out[3]);
                 reinterpret_cast<uint4 *>(tri8)[i] = make_uint4(t8[0], t8[1], t8[2], t8[3]);
             } else {
-                reinterpret_cast<uint32_t *>(code)[i] = out[0];
+                if (touched) reinterpret_cast<uint32_t *>(code)[i] = out[0];
                 if (tri8) reinterpret_cast<uint32_t *>(tri8)[i] = t8[0];
             }
             if (sh == 0) {  // one lane in 32 / VPL owns the 32-voxel word of the scanned set
-                const uint32_t sw = (reset ? 0u : sb[wd]) | (hw & gb[wd]);
-                sb[wd] = sw;
+                const uint32_t s0 = sb[wd];
+                const uint32_t sw = (reset ? 0u : s0) | (hw & gb[wd]);
+                if (sw != s0) sb[wd] = sw;
                 cov += __popc(sw);
-                if (clean) { hm[wd] = 0u; pm[wd] = 0u; }
+                if (clean) {
+                    if (hw) hm[wd] = 0u;
+                    if (pw) pm[wd] = 0u;
+                }
             }
         }
     } else {

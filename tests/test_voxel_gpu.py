@@ -177,6 +177,45 @@ def test_coded_probability_grid_tables_and_saturation():
         upd.prob_grid
 
 
+def test_coded_update_byte_parallel_tri_class_saturation_and_other_tables():
+    """The 16-voxels-per-lane update classifies four codes per dword with integer arithmetic when the tri-class table has the shape
+    gnbv_prob_code_tables gives it (+1 / 0 / -1 runs per base); ANY other table takes the table reads.  Both against the table applied
+    to the codes on the host; the byte-parallel step saturates at 127 path steps and raises the overflow flag like the scalar one."""
+    from gennbv_amd import _lib
+    from gennbv_amd.env.state_encoding import OccupancyGridUpdater
+    n, h, w, g = 3, 60, 80, 32
+    cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
+    scene = S.make_scenes(n, g, seed=5)
+    frames = S.make_frames(scene, cfg, 3, seed=5, with_rgba=False)
+    rng = np.random.default_rng(7)
+    for table in ("default", "random", "shifted"):
+        upd = OccupancyGridUpdater(n, g, h, w, S.inverse_intrinsics(h, w), scene.range_gt, scene.voxel_size, scene.grid_gt, DEV,
+                                   max_steps_between_resets=100)
+        if table == "random":  # not of the run shape: table reads
+            upd._tri_lut = torch.from_numpy(rng.integers(-1, 2, 256).astype(np.float32)).to(DEV)
+        elif table == "shifted":  # run shape with other thresholds (K1 = 0 for base 0, K2 = 128 for base 1)
+            t = np.concatenate([np.r_[np.zeros(40), -np.ones(88)], np.r_[np.ones(3), np.zeros(125)]]).astype(np.float32)
+            upd._tri_lut = torch.from_numpy(t).to(DEV)
+        lut = upd._tri_lut.cpu().numpy()
+        t8 = torch.full((n, g ** 3), 99, dtype=torch.int8, device=DEV)
+        for s in range(8):
+            f = frames[s % 3]
+            reset = torch.tensor([0, 1, 0], dtype=torch.uint8, device=DEV) if s == 4 else None
+            upd.update(f.depth_raw.to(DEV), f.seg_raw.to(DEV), S.c2w_from_view(f.view, scene.env_origins).to(DEV), f.poses.to(DEV).contiguous(),
+                       reset_mask=reset, tri_i8_out=t8, fp32_out=False)
+            code = upd.prob_code.cpu().numpy().reshape(n, -1)
+            assert np.array_equal(t8.cpu().numpy(), lut[code].astype(np.int8)), (table, s)
+        assert (code & 127).max() >= 3 and (code >= 128).any()
+    # saturation: more path steps than a byte holds
+    f = frames[0]
+    c2w = S.c2w_from_view(f.view, scene.env_origins).to(DEV)
+    for _ in range(130):
+        upd.update(f.depth_raw.to(DEV), f.seg_raw.to(DEV), c2w, f.poses.to(DEV).contiguous(), tri_i8_out=t8, fp32_out=False)
+    assert (upd.prob_code.cpu().numpy() & 127).max() == 127
+    with pytest.raises(_lib.GennbvHipError):
+        upd.prob_grid
+
+
 def test_f32_path_and_non_binary_ground_truth():
     """packed=False keeps the reference's fp32 scanned/gt tensors; a non-binary GT (0.4 per voxel:
     scanned accumulates 0.4, 0.8, then clips at 1) automatically takes that path."""

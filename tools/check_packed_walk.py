@@ -30,7 +30,7 @@ def ref_walk(src, tgt, g):
         p[0] += ss[0]; p1 += 2 * dd[1]; p2 += 2 * dd[2]
         emit()
     return out
-def packed_walk(src, tgt, g):
+def packed_walk(src, tgt, g, parts=1):
     gg = g * g
     d = [abs(tgt[i] - src[i]) for i in range(3)]
     dm = max(d)
@@ -42,24 +42,36 @@ def packed_walk(src, tgt, g):
     sa = 1 if pa < ta else -1; sb = 1 if pb < tb else -1; sc = 1 if pc < tc else -1
     la, lb, lc = sa * st_a, sb * st_b, sc * st_c
     l = pa * st_a + pb * st_b + pc * st_c
-    W = s32(l + (da << 24))
-    P = pk(2 * db - da, 2 * dc - da)
     NEG2DA = pk(-2 * da, -2 * da); DL = pk(2 * db - 2 * da, 2 * dc - 2 * da); LBC = pk(lb, lc)
     Kp = la + lb + lc - (1 << 24)
     out = [l]  # the source voxel, emitted once per workgroup
-    while W >= (1 << 24):
-        m = pk_ashr15(P)
-        P = pk_mad(m, NEG2DA, pk_add(P, DL))
-        W = s32(dot2(LBC, m, W) + Kp)
-        out.append(W & 0xFFFFFF if True else 0)
-        addr = (W >> 3) & 0x3FFFC; bit = W & 31
-        assert addr == ((W & 0xFFFFFF) >> 5) * 4 and (W & 0xFFFFFF) < g ** 3, (W, addr)
+    for part in range(parts):  # (RAY_PARTS: lane `part` of a ray starts after j0 steps from the closed form of the walker's state)
+        if parts == 1:
+            W = s32(l + (da << 24))
+            P = pk(2 * db - da, 2 * dc - da)
+        else:
+            j0, j1 = (part * da) // parts, ((part + 1) * da) // parts
+            two_da = 2 * max(da, 1)
+            nb, nc = (2 * db * j0 + da) // two_da, (2 * dc * j0 + da) // two_da
+            W = s32(l + j0 * la + nb * lb + nc * lc + ((j1 - j0) << 24))
+            p1, p2 = 2 * db * (j0 + 1) - da - 2 * da * nb, 2 * dc * (j0 + 1) - da - 2 * da * nc
+            assert -32768 <= p1 < 32768 and -32768 <= p2 < 32768
+            P = pk(p1, p2)
+        while W >= (1 << 24):
+            m = pk_ashr15(P)
+            P = pk_mad(m, NEG2DA, pk_add(P, DL))
+            W = s32(dot2(LBC, m, W) + Kp)
+            out.append(W & 0xFFFFFF if True else 0)
+            addr = (W >> 3) & 0x3FFFC; bit = W & 31
+            assert addr == ((W & 0xFFFFFF) >> 5) * 4 and (W & 0xFFFFFF) < g ** 3, (W, addr)
     return out
 random.seed(1)
 for g in (16, 20, 33, 64, 96, 104):
     for it in range(20000):
         src = [random.randrange(g) for _ in range(3)]; tgt = [random.randrange(g) for _ in range(3)]
         if it % 7 == 0: tgt[random.randrange(3)] = src[random.randrange(3)]
-        a, b = ref_walk(src, tgt, g), packed_walk(src, tgt, g)
-        assert a == b, (g, src, tgt, a, b)
-print("packed recurrence == reference walk")
+        a = ref_walk(src, tgt, g)
+        for parts in (1, 2, 3, 4):
+            b = packed_walk(src, tgt, g, parts)
+            assert a == b, (g, parts, src, tgt, a, b)
+print("packed recurrence (whole rays and 2 / 3 / 4 parts per ray) == reference walk")
