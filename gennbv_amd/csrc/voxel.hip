@@ -518,6 +518,12 @@ __device__ __forceinline__ void ld4_stream_async(v4f_t &dst, const float *p)
 {
     asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
 }
+// (the same with the base in scalar registers and a 32-bit byte offset per lane: no 64-bit address arithmetic -- a quarter-rate
+// v_mad_u64_u32 per request -- in the hot loop; `base` must be wave-uniform)
+__device__ __forceinline__ void ld4_stream_async_sbase(v4f_t &dst, const float *base, unsigned byte_off)
+{
+    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(byte_off), "s"(base) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vm_keep(v4f_t &a, v4f_t &b)
 {
@@ -654,21 +660,26 @@ __device__ __forceinline__ int pixel_predict(const VoxPredict &vp, const float (
     // per axis: two fma, v_fract (q - floor q, exact), its distance from 0.5, v_cvt_flr_i32_f32 (floor + convert), one unsigned compare
     float dev[3];
     int ii[3];
-    bool in = true;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float r = __fmaf_rn(vp.al[a], u, row[a]);
         const float q = __fmaf_rn(d, r, vp.ta[a]);
         dev[a] = __fsub_rn(__builtin_amdgcn_fractf(q), 0.5f);
         asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ii[a]) : "v"(q));
-        in = in && ((unsigned)ii[a] < ug);
     }
+    // in the grid on the three axes: one unsigned v_max3 + one compare (a negative index is a huge unsigned one)
+    unsigned imax;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(imax) : "v"(ii[0]), "v"(ii[1]), "v"(ii[2]));
+    const bool in = imax < ug;
     // distance to the nearest integer = 0.5 - |fract - 0.5| >= thr   <=>   max |dev| <= 0.5 - thr   (false for NaN; the two roundings
     // of this test are 2^-25 each against a slack of 0.2 thr: make_predictor keeps thr >= 1e-6)
     const float lim = __fmaf_rn(-vp.kap, d, vp.lim0);
     const bool sure = __builtin_fmaxf(__builtin_fmaxf(fabsf(dev[0]), fabsf(dev[1])), fabsf(dev[2])) <= lim;
     queue = fg && !(plain && sure);
-    const int lin = (int)(__umul24(__umul24((unsigned)ii[0], ug) + (unsigned)ii[1], ug) + (unsigned)ii[2]);
+    // (two v_mad_u32_u24: the compiler turned the outer one into the quarter-rate v_mad_u64_u32; the value is only used when `in`)
+    int lin;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(lin) : "v"(ii[0]), "s"(ug), "v"(ii[1]));
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(lin) : "v"(lin), "s"(ug), "v"(ii[2]));
     return (fg && plain && sure && in) ? lin : -1;
 }
 
@@ -752,8 +763,8 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80), 
 #pragma unroll
         for (int q = 0; q < kAhead; ++q) {
             const int pq = max(min(tile_px(max(min(q, ntiles - 1), 0)), plast), 0);
-            ld4_stream_async(dq[q], dptr + pq);
-            ld4_stream_async(sq[q], sptr + pq);
+            ld4_stream_async_sbase(dq[q], dptr, (unsigned)pq * 4u);
+            ld4_stream_async_sbase(sq[q], sptr, (unsigned)pq * 4u);
         }
         // (column, row) of the lane's first pixel, advanced by one tile per step without a division
         const int tdy = kTile / w, tdx = kTile - tdy * w;
@@ -808,8 +819,8 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80), 
                 // outstanding request -- at the end of each round); kAhead - 1 tiles per lane stay in flight during the arithmetic,
                 // 128 KiB per CU against the ~25 KiB its 10.8 B/clk x latency needs
                 const int pn = max(min(tile_px(max(min(t + kAhead, ntiles - 1), 0)), plast), 0);
-                ld4_stream_async(dq[q], dptr + pn);
-                ld4_stream_async(sq[q], sptr + pn);
+                ld4_stream_async_sbase(dq[q], dptr, (unsigned)pn * 4u);
+                ld4_stream_async_sbase(sq[q], sptr, (unsigned)pn * 4u);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the clamped duplicate requests of the last round)
