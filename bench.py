@@ -48,9 +48,6 @@ def parse():
     ap.add_argument("--semantic", action="store_true", help="BASELINE configs[2]: the opt-in semantic branch over the two gray frames "
                     "(Hybrid_Encoder(semantic_branch=True): build-defined, the released reference never reads them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gemm-tuning", action="store_true", help="enable TunableOp for library GEMMs (none is left on the timed path; "
-                    "its warm-up injected ~15 k flush_icache launches)")
-    ap.add_argument("--save-gemm-tuning", default=None, help="write the TunableOp selections to this file")
     ap.add_argument("--no-flat-rows", action="store_true", help="skip the second, shorter measurement with the reference's flat fp32 rows")
     ap.add_argument("--no-state-check", action="store_true", help="skip the oracle replay of sampled envs over the last timed rollout")
     return ap.parse_args()
@@ -516,9 +513,6 @@ def main():
     torch.cuda.set_device(device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from gennbv_amd import gemm_tuning
-    if args.gemm_tuning or args.save_gemm_tuning:
-        gemm_tuning.enable()  # rocBLAS / hipBLASLt algorithm selection (no library GEMM is left in the captured minibatch or the rollout step)
     algo, cfg, env = build_algo(args, device, rank, world)
     algo._setup_learn(total_timesteps=10 ** 12)
 
@@ -611,7 +605,7 @@ def main():
         try:
             from tests import state_check
             sel = sorted({0, args.envs // 2 - 27, args.envs - 1} & set(range(args.envs)))
-            res = state_check.check_rollout(algo, sel, max_steps=40)
+            res = state_check.check_rollout(algo, sel, max_steps=40, across_ends=1)  # + one env replayed ACROSS an episode end
             out["timed_state_check"] = res["status"]
             out["timed_state_check_detail"] = {k: v for k, v in res.items() if k != "status"}
         except Exception as ex:
@@ -644,8 +638,6 @@ def main():
                 out["config"]["flat_rows"] = flat_rows_line(args, device)
             except Exception as ex:
                 out["config"]["flat_rows"] = {"value": None, "error": repr(ex)}
-    if args.save_gemm_tuning and rank == 0:
-        gemm_tuning.save(args.save_gemm_tuning)
     if dist.is_initialized():
         dist.destroy_process_group()
     _flush_c_stdio()

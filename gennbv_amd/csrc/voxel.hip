@@ -725,7 +725,14 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80), 
     // XCD-aware block -> (env, chunk): all workgroups of env e run on XCD e % 8
     const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
     const int e = (slot / chunks) * 8 + xcd;
+#ifdef HIT_CHUNK_ROT
+    // Which of an env's chunks a slot takes rotates every 16 envs of the XCD: slots k and k + 32 of an XCD (two workgroups of one CU when
+    // the dispatcher deals workgroups round-robin over the XCD's 32 CUs) then hold DIFFERENT chunks, like slots k and k + 1 -- the top
+    // of an image is mostly background (a cheap chunk), the bottom foreground (an expensive one).
+    const int c = (slot + slot / (16 * chunks)) % chunks;
+#else
     const int c = slot % chunks;
+#endif
     if (e >= n) return;
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
 #ifdef PHASE_TIMING

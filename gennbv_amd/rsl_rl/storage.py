@@ -70,12 +70,12 @@ class RolloutStorage:
         self.advantages = adv.view_as(self.returns)
 
     def get_statistics(self):
-        done = self.dones
-        done[-1] = 1
-        flat_dones = done.permute(1, 0, 2).reshape(-1, 1)
-        done_indices = torch.cat((flat_dones.new_tensor([-1], dtype=torch.int64), flat_dones.nonzero(as_tuple=False)[:, 0]))
-        trajectory_lengths = done_indices[1:] - done_indices[:-1]
-        return trajectory_lengths.float().mean(), self.rewards.mean()
+        """:146-154: (mean trajectory length, mean reward) of the stored rollout; a trajectory ends at a done flag or at the buffer's
+        last row (the reference forces `dones[-1] = 1` IN the storage: kept, callers see it)."""
+        self.dones[-1] = 1
+        ends = self.dones.transpose(0, 1).reshape(-1).nonzero().flatten()  # env-major positions of the trajectory ends
+        lengths = torch.diff(ends, prepend=ends.new_full((1,), -1))
+        return lengths.float().mean(), self.rewards.mean()
 
     def mini_batch_generator(self, num_mini_batches, num_epochs=8, indices=None):
         """:156-192.  `indices` (additive): a fixed permutation instead of `torch.randperm` on the storage's device (the

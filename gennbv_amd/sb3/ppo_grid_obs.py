@@ -857,7 +857,26 @@ class PPO_Grid_Obs:
             buf.update_autocorr(0)
 
     def collect_rollouts(self, env, callback, rollout_buffer, n_rollout_steps: int) -> bool:
-        """on_policy_algorithm_grid_obs.py:128-221 (tensor-env branch)."""
+        """on_policy_algorithm_grid_obs.py:128-221 (tensor-env branch).
+
+        Inside the rollout the env hands out `dones` / `infos["time_outs"]` as views of its kernels' bytes (`flag_views`: no `.bool()`
+        launches); both are consumed before the env overwrites them.  The switch is put back however the rollout ends (early return of a
+        callback, exception), and what outlives the call -- `_last_episode_starts` -- is a copy, so env steps taken between two rollouts
+        (an evaluation on the same env, user code after learn()) see the reference's fresh-tensor behaviour and cannot reach into the
+        next rollout's row 0.  Callbacks that KEEP `self.locals["dones"]` beyond their `on_step()` must clone it.
+        """
+        prev = getattr(env, "flag_views", None)
+        if prev is not None:
+            env.flag_views = True
+        try:
+            return self._collect_rollouts(env, callback, rollout_buffer, n_rollout_steps)
+        finally:
+            if prev is not None:
+                env.flag_views = prev
+                if not prev and self._last_episode_starts is not None:
+                    self._last_episode_starts = self._last_episode_starts.clone()
+
+    def _collect_rollouts(self, env, callback, rollout_buffer, n_rollout_steps: int) -> bool:
         assert self._last_obs is not None, "No previous observation was provided"
         self.policy.set_training_mode(False)
         if not hasattr(self.policy, "_fused_rollout"):
@@ -879,8 +898,6 @@ class PPO_Grid_Obs:
         # The new row's input autocorrelation (BatchNorm-1's analytic statistics in train(): nothing in the rollout reads it) goes to the
         # second stream BEHIND the pose branch of the policy evaluation, where it runs beside the conv kernel instead of in front of it.
         defer_ac = plan is not None and rollout_buffer.autocorr is not None
-        if hasattr(env, "flag_views"):
-            env.flag_views = True  # dones / time_outs as views of the kernels' bytes: both are consumed before they are overwritten (below)
 
         def evaluate(x, values_only=False, autocorr_row=None):
             if plan is not None and plan.applies_to(x):

@@ -379,7 +379,7 @@ int gnbv_linear_bwd_dw_sq(const void *workspace, const float *x, int M, int N, i
  *     y (features == NULL in gnbv_encoder_grid_forward skips that call's own BN2 + ReLU pass).  *range_flag (may be NULL): bit 4 when an
  *     operand passes 1000 (the f16 split clamps at 1015).  gnbv_linear_fold_ok: 1 when (M, N, K, P) can take this path
  *     (P >= 512, K % P == 0, split kernels on); otherwise materialise the activations (features != NULL) as before.
- *     d/dy of the product = the existing gnbv_linear_bwd_dx (d/dx) followed by gnbv_encoder_backward (whose BN2 backward takes
+ *     d/dy of the product = the existing gnbv_linear_bwd_dx (d/dx) followed by gnbv_encoder_grid_backward (whose BN2 backward takes
  *     d/dx and y, never x). */
 int gnbv_linear_fold_ok(int M, int N, int K, int P);
 int gnbv_linear_forward_fold(const float *y, const float *scale, const float *shift, int P, int *range_flag, const float *w, const float *bias,

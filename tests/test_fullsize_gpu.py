@@ -51,6 +51,25 @@ def test_config1_full_size_rollout_vs_oracle_env(rec_full):
     assert int(tri.min()) >= -1 and int(tri.max()) <= 1 and bool((tri != 0).flatten(2).any(2).all())
 
 
+def test_config1_all_256_envs_across_episode_ends_vs_oracle_env():
+    """EVERY env of one full-size rollout (256 x 240x320 x 64^3, compact rows, the prepared policy evaluation)
+    replayed through the oracle env, ACROSS episode ends: episodes of 3 steps inside an 8-step buffer, so each env is replayed from its
+    first boundary through one or two further done -> deferred zeroing -> next-update hand-overs (env_train_gennbv.py:377-436) -- the
+    path that so far was only covered at fixture size.  Envs sharing a start row are one multi-env oracle (OpenMP over the envs)."""
+    from tests import state_check
+    from tests import test_ppo_g64_gpu as t64
+    rec = t64._Recorded(n_envs=256, t=8, hw=(240, 320), epochs=1, max_episode_length=3, frames=4)
+    algo = rec.algo
+    res = state_check.check_rollout(algo, range(256))
+    assert res["status"] == "bit-exact", res
+    assert len(res["envs"]) == 256 and all("skipped" not in r for r in res["envs"]), res["envs"][:4]
+    assert {r["from_step"] for r in res["envs"]} == {1, 2, 3}, "_setup_learn's random phases: first time-out at row 1, 2 or 3"
+    # boundaries every 3 rows: the env starting at row 1 ends again at rows 4 and 7, at row 2: 5 (and 8 = the last row), at row 3: 6
+    assert res["episode_ends_seen"] >= 256 and res["steps_replayed"] >= 256 * 5 and res.get("rewards_compared", 0) > 0, res
+    del rec, algo
+    torch.cuda.empty_cache()
+
+
 def test_config1_full_size_train_vs_fp64_loop(rec_full):
     """One epoch over the full-size buffer (256 x 6 samples = 12 minibatches of 128) against the fp64 CPU loop."""
     from tests import test_ppo_g64_gpu as t64

@@ -99,3 +99,56 @@ def test_prepared_rollout_forward_is_bit_identical_to_the_general_path():
         for k, a in out[False][r].items():
             assert torch.equal(a, out[True][r][k]), (r, k)
     assert float(out[True][1]["values"].abs().max()) > 0 and not torch.equal(out[True][0]["values"], out[True][1]["values"])
+
+
+def test_flag_views_are_scoped_to_collect_rollouts():
+    """`env.flag_views` (dones / time_outs as views of the kernels' bytes) is on only inside collect_rollouts -- also when a
+    callback ends the rollout early or raises --, and `_last_episode_starts` is a copy: env steps between two rollouts (an evaluation on
+    the same env) change neither it nor, through it, the next rollout's episode_starts row 0."""
+    from gennbv_amd.env import synthetic as S
+    from gennbv_amd.env.config import TaskConfig
+    from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
+    from gennbv_amd.network.hybrid_encoder import Hybrid_Encoder
+    from gennbv_amd.sb3.policies import ActorCriticPolicy_Train_Eval
+    from gennbv_amd.sb3.ppo_grid_obs import PPO_Grid_Obs
+    g, n, t = 16, 8, 5
+    cfg = TaskConfig(camera_width=80, camera_height=60, grid_size=g)
+    kw = dict(net_arch=[], features_extractor_class=Hybrid_Encoder, features_extractor_kwargs=dict(
+        encoder_param={"hidden_shapes": [256, 256], "visual_dim": 256},
+        net_param={"transformer_params": [[1, 256], [1, 256]], "append_hidden_shapes": [256, 256]},
+        state_input_shape=(cfg.state_dim,), visual_input_shape=(cfg.stack, cfg.camera_height, cfg.camera_width)))
+    torch.manual_seed(0)
+    np.random.seed(0)
+    scene = S.make_scenes(n, g, seed=3, device=DEV)
+    env = ReplayFeedEnv(cfg, scene, ReplayFeed.synthetic(scene, cfg, 5, seed=3), DEV, max_episode_length=3)
+    algo = PPO_Grid_Obs(ActorCriticPolicy_Train_Eval, env, learning_rate=1e-4, n_steps=t, batch_size=8, n_epochs=1, gamma=0.99, gae_lambda=0.95,
+                        target_kl=None, seed=1, device=DEV, compact_obs=True, policy_kwargs=kw)
+    algo._setup_learn(total_timesteps=10 ** 9)
+    assert env.flag_views is False
+    assert algo.collect_rollouts(env, None, algo.rollout_buffer, n_rollout_steps=t)
+    assert env.flag_views is False, "the switch is put back at the end of the rollout"
+    starts = algo._last_episode_starts.clone()
+    for _ in range(3):  # somebody else steps the env (three steps: both ping-pong buffers of `dones` are overwritten, an episode ends)
+        _, _, d, info = env.step(torch.zeros(n, 6, device=DEV))
+        assert d.dtype == torch.bool and info["time_outs"].dtype == torch.bool
+    assert torch.equal(algo._last_episode_starts, starts), "_last_episode_starts must not alias the env's buffers"
+
+    class Stop:
+        def __init__(self, raise_): self.raise_, self.k = raise_, 0
+        def on_rollout_start(self): pass
+        def on_rollout_end(self): pass
+        def update_locals(self, loc): pass
+        def on_step(self):
+            self.k += 1
+            if self.k == 2 and self.raise_:
+                raise RuntimeError("callback failed")
+            return self.k < 2
+    algo._pending = None
+    algo._last_obs = env.reset(obs_out=algo.rollout_buffer.first_obs_row(), grid_i8_out=algo.rollout_buffer.grid_i8[0])
+    algo.rollout_buffer.update_autocorr(0)
+    assert algo.collect_rollouts(env, Stop(False), algo.rollout_buffer, n_rollout_steps=t) is False
+    assert env.flag_views is False, "early return of a callback"
+    algo._pending = None
+    with pytest.raises(RuntimeError):
+        algo.collect_rollouts(env, Stop(True), algo.rollout_buffer, n_rollout_steps=t)
+    assert env.flag_views is False, "exception inside the rollout"

@@ -84,7 +84,7 @@ def build_train(a, dev):
     import bench
     ns = argparse.Namespace(gpus=1, steps=1, warmup=0, envs=a.envs, grid=a.grid, height=a.height, width=a.width, n_steps=a.n_steps, batch_size=a.batch_size,
                             n_epochs=16, frames=2, backend="hip", obs="compact", target_kl="off", semantic=a.semantic, no_cpu_baseline=True,
-                            gemm_tuning=False, save_gemm_tuning=None, no_flat_rows=True, no_state_check=True)
+                            no_flat_rows=True, no_state_check=True)
     algo, cfg, env = bench.build_algo(ns, dev, 0, 1)
     algo.learning_rate = 1e-12
     algo.lr_schedule = lambda _: 1e-12
@@ -144,7 +144,7 @@ def build_rollout(a, dev):
     import bench
     ns = argparse.Namespace(gpus=1, steps=1, warmup=0, envs=a.envs, grid=a.grid, height=a.height, width=a.width, n_steps=a.n_steps, batch_size=a.batch_size,
                             n_epochs=1, frames=4, backend="hip", obs="compact", target_kl="off", semantic=a.semantic, no_cpu_baseline=True,
-                            gemm_tuning=False, save_gemm_tuning=None, no_flat_rows=True, no_state_check=True)
+                            no_flat_rows=True, no_state_check=True)
     algo, cfg, env = bench.build_algo(ns, dev, 0, 1)
     algo._setup_learn(total_timesteps=10 ** 12)
 

@@ -8,8 +8,6 @@ import bench
 for mode in ("default", "no_async_wgrad", "single_stream"):
     args = bench.parse()
     args.steps, args.warmup, args.n_steps = 2, 1, 32
-    from gennbv_amd import gemm_tuning
-    gemm_tuning.enable()
     algo, cfg, env = bench.build_algo(args, "cuda:0", 0, 1)
     if mode in ("no_async_wgrad", "single_stream"):
         algo.async_wgrad = False

@@ -3,13 +3,11 @@ import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gennbv_amd.ops.encoder_ops import linear_relu
-from gennbv_amd import gemm_tuning
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--m", type=int, default=128); ap.add_argument("--n", type=int, default=256); ap.add_argument("--k", type=int, default=54000)
 ap.add_argument("--iters", type=int, default=50)
 a = ap.parse_args()
-gemm_tuning.enable()
 dev = "cuda:0"
 x = torch.rand(a.m, a.k, device=dev); lin = torch.nn.Linear(a.k, a.n).to(dev)
 

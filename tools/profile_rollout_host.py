@@ -13,7 +13,7 @@ import torch
 import bench
 
 ns = argparse.Namespace(gpus=1, steps=1, warmup=0, envs=256, grid=64, height=240, width=320, n_steps=64, batch_size=128, n_epochs=1, frames=4,
-                        backend="hip", obs="compact", target_kl="off", semantic=False, no_cpu_baseline=True, gemm_tuning=False, save_gemm_tuning=None,
+                        backend="hip", obs="compact", target_kl="off", semantic=False, no_cpu_baseline=True, 
                         no_flat_rows=True, no_state_check=True)
 algo, cfg, env = bench.build_algo(ns, "cuda:0", 0, 1)
 algo._setup_learn(total_timesteps=10 ** 12)
