@@ -571,6 +571,11 @@ def main():
                                f"{args.grid}^3 grid, n_steps={args.n_steps}, batch_size={args.batch_size}, "
                                f"n_epochs={args.n_epochs}, one step = one PPO iteration",
                    "global_envs": world * args.envs, "encoder_backend": args.backend, "obs_rows": args.obs,
+                   # data-parallel semantics: an optimizer step consumes minibatch k of EVERY rank (statistics and gradient over their
+                   # union), so N ranks take the same number of steps per iteration as one rank, each over N x batch_size samples --
+                   # not what a single GPU with N x envs would do at the same batch_size (N x the steps)
+                   "global_batch": world * args.batch_size,
+                   "optimizer_steps_per_iteration": (args.envs * args.n_steps // args.batch_size) * args.n_epochs,
                    "semantic_branch": bool(args.semantic),
                    "kl_early_stop": "reference (0.05)" if args.target_kl == "ref" else "never triggers (full work every iteration)",
                    "minibatches_last_iteration": int(len(algo.last_train_stats)) if getattr(algo, "last_train_stats", None) is not None else None,
@@ -598,6 +603,11 @@ def main():
                                                    "speedup_over_floor": (args.envs * b_ref / 8e12 * 1e3) / vox_ms},
                      "traffic": traffic, "traffic_source": traffic_src},
     }
+    if dist.is_initialized():
+        # Everything timed is done and reduced: the process group goes away NOW, so that ranks > 0 exit instead of sitting in a
+        # collective teardown while rank 0 spends seconds in the CPU-side checks below (none of them communicates).
+        barrier()
+        dist.destroy_process_group()
     if rank == 0 and args.backend == "hip" and not args.no_state_check:
         # Self-check of the TIMED tensors: sampled envs of the last timed rollout are replayed through the CPU oracle from an
         # episode boundary inside the buffer -- same frames, same actions -- and every stored observation row, reward, done flag and
@@ -615,14 +625,15 @@ def main():
             out["train_roofline"] = train_roofline(algo, args, phases["train"].total_ms() / args.steps)
         except Exception as ex:
             out["train_roofline"] = {"error": repr(ex)}
-        try:
-            out["encoder_roofline"] = encoder_roofline(algo, args, device)
-        except Exception as ex:
-            out["encoder_roofline"] = {"error": repr(ex)}
-        try:
-            out["ppo_loss_delta_vs_ref"] = ppo_loss_delta(args, device)
-        except Exception as ex:
-            out["ppo_loss_delta_vs_ref"] = {"error": repr(ex)}
+        if world == 1:  # (single-GPU diagnostics: a data-parallel encoder would exchange its BatchNorm sums with ranks that have left)
+            try:
+                out["encoder_roofline"] = encoder_roofline(algo, args, device)
+            except Exception as ex:
+                out["encoder_roofline"] = {"error": repr(ex)}
+            try:
+                out["ppo_loss_delta_vs_ref"] = ppo_loss_delta(args, device)
+            except Exception as ex:
+                out["ppo_loss_delta_vs_ref"] = {"error": repr(ex)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, cfg)
@@ -638,8 +649,6 @@ def main():
                 out["config"]["flat_rows"] = flat_rows_line(args, device)
             except Exception as ex:
                 out["config"]["flat_rows"] = {"value": None, "error": repr(ex)}
-    if dist.is_initialized():
-        dist.destroy_process_group()
     _flush_c_stdio()
     if rank == 0:
         sys.stdout.flush()

@@ -54,9 +54,21 @@ constexpr int kW2ImgU4 = kKSteps * 2 * 64;           // uint4 per image: [k-step
 __device__ __forceinline__ void split2(float x, _Float16 &hi, _Float16 &lo)
 {
     hi = (_Float16)x;
+#ifdef SPLIT_HI_ONLY
+    lo = (_Float16)0.0f;
+#else
     lo = (_Float16)(x - (float)hi);
+#endif
 }
 __device__ __forceinline__ f32x4 mfma_h(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+// the two correction products (a_lo b_hi, a_hi b_lo) of a split product.  -DSPLIT_HI_ONLY (measurement build): dropped,
+// with the `lo` planes' conversions and ring stores -- the arithmetic of a single-product f16 mode (11 significand bits) on this
+// kernel structure, to price what such a mode could buy before building it.  profiles/r05_notes.md
+#ifdef SPLIT_HI_ONLY
+__device__ __forceinline__ f32x4 mfma_lo(h8, h8, f32x4 c) { return c; }
+#else
+__device__ __forceinline__ f32x4 mfma_lo(h8 a, h8 b, f32x4 c) { return mfma_h(a, b, c); }
+#endif
 }  // namespace split
 
 // W2 [co][ci][27] -> the B-operand images of the split kernels, as two f16 planes scaled by 2^10:
@@ -152,7 +164,9 @@ struct ZStager {
             }
             char *dst = stage + (pi * kRing + slot) * kRowBytes + st_lane;
             *reinterpret_cast<h4 *>(dst) = hi;
+#ifndef SPLIT_HI_ONLY
             *reinterpret_cast<h4 *>(dst + 512) = lo;
+#endif
         }
     }
 };
@@ -286,8 +300,8 @@ __global__ __launch_bounds__(split::kThreads) void k_conv2_fwd_split(
                         al[(s + kAhead) % (kAhead + 1)] = *reinterpret_cast<const h8 *>(stage + a_off(s + kAhead) + 512);
                     }
                     acc_hh = mfma_h(ah[s % (kAhead + 1)], wh[s], acc_hh);
-                    acc_lh = mfma_h(al[s % (kAhead + 1)], wh[s], acc_lh);
-                    acc_hl = mfma_h(ah[s % (kAhead + 1)], wl[s], acc_hl);
+                    acc_lh = mfma_lo(al[s % (kAhead + 1)], wh[s], acc_lh);
+                    acc_hl = mfma_lo(ah[s % (kAhead + 1)], wl[s], acc_hl);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const f32x4 part = acc_hh + (acc_lh + acc_hl);
@@ -393,7 +407,9 @@ __device__ __forceinline__ void conv2_wgrad_split_body(
                 }
                 char *dst = dyst + ((j & 1) * kNP + dpl) * 1024 + dpiece * 8;
                 *reinterpret_cast<h4 *>(dst) = hi;
+#ifndef SPLIT_HI_ONLY
                 *reinterpret_cast<h4 *>(dst + 512) = lo;
+#endif
             }
         };
         float4 ra[kSlots], rb[kSlots], da, db;
@@ -450,13 +466,13 @@ __device__ __forceinline__ void conv2_wgrad_split_body(
                                 const char *a0 = stage + (2 * (2 * kb)) * kRing * kRowBytes + off, *a1 = a0 + 2 * kRing * kRowBytes;
                                 const h8 ah = tr_pair(a0, a1), al = tr_pair(a0 + 512, a1 + 512);
                                 acc[i] = mfma_h(ah, bh, acc[i]);
-                                acc[i] = mfma_h(al, bh, acc[i]);
-                                acc[i] = mfma_h(ah, bl, acc[i]);
+                                acc[i] = mfma_lo(al, bh, acc[i]);
+                                acc[i] = mfma_lo(ah, bl, acc[i]);
                             }
                         }
                         if (cw == 7) {
                             acc[3] = mfma_h(ones, bh, acc[3]);
-                            acc[3] = mfma_h(ones, bl, acc[3]);
+                            acc[3] = mfma_lo(ones, bl, acc[3]);
                         }
                     }
                 }
@@ -662,8 +678,8 @@ __device__ __forceinline__ void dgrad_split_supertile(
             const uint4 uh = wimg[(s * 2 + 0) * 64], ul = wimg[(s * 2 + 1) * 64];
             const h8 wh = *reinterpret_cast<const h8 *>(&uh), wl = *reinterpret_cast<const h8 *>(&ul);
             acc_hh = split::mfma_h(ah, wh, acc_hh);
-            acc_lh = split::mfma_h(al, wh, acc_lh);
-            acc_hl = split::mfma_h(ah, wl, acc_hl);
+            acc_lh = split::mfma_lo(al, wh, acc_lh);
+            acc_hl = split::mfma_lo(ah, wl, acc_hl);
         }
         const f32x4 raw = acc_hh + (acc_lh + acc_hl);  // D[i = voxel 4g + r][j = ci = m], scaled by gs 2^10
         uint32_t ylane = (uint32_t)((4 * g) * kYVox + m * 4);
@@ -698,9 +714,9 @@ __device__ __forceinline__ void dgrad_split_supertile(
             // f16 pipe as well: x in {-1, 0, 1} is exact in f16, g is split (scaled by `gscale` into f16 range); k = 32 =
             // [class P voxels 4g .. 4g+3, class Q voxels 4g .. 4g+3] for both operands.  A[i = tap][k], B[k][j = ci].
             T1a = split::mfma_h(xs, gh, T1a);
-            T1a = split::mfma_h(xs, gl, T1a);
+            T1a = split::mfma_lo(xs, gl, T1a);
             T1b = split::mfma_h(xt, gh, T1b);
-            T1b = split::mfma_h(xt, gl, T1b);
+            T1b = split::mfma_lo(xt, gl, T1b);
         }
     }
 }
@@ -761,7 +777,9 @@ __device__ __forceinline__ void conv2_dgrad_c1w_split_body(
                 }
                 char *dst = dyst + (dpl * kDyRing + (c + kDyRing) % kDyRing) * kDyRow + (dvox + 1) * 32 + (dpiece & 3) * 8;
                 *reinterpret_cast<h4 *>(dst) = hi;
+#ifndef SPLIT_HI_ONLY
                 *reinterpret_cast<h4 *>(dst + kDyHalf) = lo;
+#endif
             }
         };
         static_assert(kDySlots == 2, "two dy2 requests per staging thread");
@@ -1081,8 +1099,8 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 acc = mfma_h(wh, xb, acc);  // D[i = channel 4g + r][j = voxel n]
                 acc = mfma_h(wh2, xb2, acc);
-                acc = mfma_h(wl, xb, acc);
-                acc = mfma_h(wl2, xb2, acc);
+                acc = mfma_lo(wl, xb, acc);
+                acc = mfma_lo(wl2, xb2, acc);
                 if (k + 1 < kTilesPerWave) gather(k + 1, xb, xb2);
                 h4 hi, lo;
                 float yv[4];
@@ -1108,7 +1126,9 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
                 }
                 char *dst = stage + (pi * kRing + slot) * kRowBytes + par * 1024 + n * 32 + g * 8;
                 *reinterpret_cast<h4 *>(dst) = hi;
+#ifndef SPLIT_HI_ONLY
                 *reinterpret_cast<h4 *>(dst + 512) = lo;
+#endif
             }
         };
         // prologue: three barriers (the compute waves run the same count)
@@ -1200,8 +1220,8 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
                         al[(s + kAhead) % (kAhead + 1)] = *reinterpret_cast<const h8 *>(stage + a_off(s + kAhead) + 512);
                     }
                     acc_hh = mfma_h(ah[s % (kAhead + 1)], wh[s], acc_hh);
-                    acc_lh = mfma_h(al[s % (kAhead + 1)], wh[s], acc_lh);
-                    acc_hl = mfma_h(ah[s % (kAhead + 1)], wl[s], acc_hl);
+                    acc_lh = mfma_lo(al[s % (kAhead + 1)], wh[s], acc_lh);
+                    acc_hl = mfma_lo(ah[s % (kAhead + 1)], wl[s], acc_hl);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const f32x4 part = acc_hh + (acc_lh + acc_hl);
@@ -1277,7 +1297,7 @@ __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_split(
         for (int e = 0; e < 8; ++e) xb[e] = (_Float16)(short)origin[tapoff[e]];
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         acc = mfma_h(wh, xb, acc);  // D[i = channel 4g + r][j = voxel n]
-        acc = mfma_h(wl, xb, acc);
+        acc = mfma_lo(wl, xb, acc);
         const int x = 2 * n + par;
         if (x < O1) {
             const float s = 1.0f / fsplit::kW1Scale;

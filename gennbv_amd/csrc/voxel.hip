@@ -725,14 +725,9 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80), 
     // XCD-aware block -> (env, chunk): all workgroups of env e run on XCD e % 8
     const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
     const int e = (slot / chunks) * 8 + xcd;
-#ifdef HIT_CHUNK_ROT
-    // Which of an env's chunks a slot takes rotates every 16 envs of the XCD: slots k and k + 32 of an XCD (two workgroups of one CU when
-    // the dispatcher deals workgroups round-robin over the XCD's 32 CUs) then hold DIFFERENT chunks, like slots k and k + 1 -- the top
-    // of an image is mostly background (a cheap chunk), the bottom foreground (an expensive one).
-    const int c = (slot + slot / (16 * chunks)) % chunks;
-#else
+    // (Rotating which of an env's chunks a slot takes every 16 envs, so that the two workgroups of a CU hold different chunks whichever
+    // way the dispatcher deals them -- the top of an image is mostly background --: -0.5 us of 89, inside the noise; profiles/r05_notes.md)
     const int c = slot % chunks;
-#endif
     if (e >= n) return;
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
 #ifdef PHASE_TIMING
@@ -1790,6 +1785,8 @@ __global__ __launch_bounds__(kGridThreads) void k_grid_update_coded(
             const bool touched = reset || (hb | pb) != 0u;
             if constexpr (NW == 4) {
                 if (touched) reinterpret_cast<uint4 *>(code)[i] = make_uint4(out[0], out[1], out[2], out[3]);
+                // (non-temporal here: +5 us per update back to back, round 4; +1.6 us INSIDE the rollout, round 5 -- the policy's conv kernel
+                // reads this row 20 us later: profiles/r05_notes.md)
                 reinterpret_cast<uint4 *>(tri8)[i] = make_uint4(t8[0], t8[1], t8[2], t8[3]);
             } else {
                 if (touched) reinterpret_cast<uint32_t *>(code)[i] = out[0];

@@ -96,7 +96,10 @@ class RolloutForward:
         """what the cached arguments were derived from: a re-parametrised / re-allocated policy must rebuild the plan"""
         enc, pol = self.enc, self.policy
         ts = [m.weight for m in (self.seq[0], self.seq[1], self.seq[3], self.seq[4], *self.lins, enc.output_layer[0], pol.action_net, pol.value_net)]
-        return (tuple(t.data_ptr() for t in ts), bool(enc.training), bool(getattr(enc, "force_fp32", False)),
+        # (+ the tensors' in-place version counters and the BatchNorm running statistics the prepared scale / shift came from: a
+        # load_state_dict / set_parameters from a callback in the MIDDLE of a rollout sends the rest of it through the general path)
+        ts = ts + [b for m in (self.seq[1], self.seq[4]) for b in (m.weight, m.bias, m.running_mean, m.running_var)]
+        return (tuple((t.data_ptr(), t._version) for t in ts), bool(enc.training), bool(getattr(enc, "force_fp32", False)),
                 tuple(bool(getattr(lin, "_fp32_arith", False)) for lin in self.lins), id(getattr(enc, "_range_flag", None)))
 
     def prepare(self) -> bool:

@@ -525,9 +525,16 @@ class PPO_Grid_Obs:
             t = torch.tensor([flag], dtype=torch.int32, device=self.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._sync.group)
             flag = int(t.item())
+        self.logger.record("train/range_replays", getattr(self, "range_replays", 0))
+        self.logger.record("train/encoder_fp32_kernels", int(bool(getattr(enc, "force_fp32", False))))
         if not flag:
             return
         if snap is None:  # already on the fp32 kernels: only a feature above 1000 can get here, and nothing clamps there
+            return
+        if (self._hip or {}).get("force_fp32"):
+            # the PARAMETER pre-check inside the pass already moved the encoder to the fp32-MFMA kernels before anything was computed
+            # (the snapshot was taken before that): the pass ran exact arithmetic, a second one would repeat it for nothing
+            enc.check_operand_ranges(raise_on_flag=False)  # (clears the flag)
             return
         import warnings
         warnings.warn(f"[gennbv_amd] train(): an activation left the split-f16 operand range (flag {flag}); the call is repeated on the "
@@ -583,136 +590,150 @@ class PPO_Grid_Obs:
         fp32_now = self._check_ranges()
         if st.get("force_fp32") != fp32_now:
             st["graph"], st["force_fp32"] = None, fp32_now
-        lr = self.lr_schedule(self._current_progress_remaining)
-        self.logger.record("train/learning_rate", lr)
-        opt.lr = lr
-        clip_range = self.clip_range(self._current_progress_remaining)
-        clip_range_vf = None if self.clip_range_vf is None else self.clip_range_vf(self._current_progress_remaining)
-        loss.args.clip_range = float(clip_range)
-        loss.args.clip_range_vf = float(clip_range_vf) if clip_range_vf is not None else -1.0
-        loss.stats_row.zero_()
-        loss.stop_flag.zero_()
-        idx = torch.from_numpy(np.asarray(buf.indices, dtype=np.int64)).to(self.device)
-        rows_all = buf.rows_of(idx)  # the reference's flattened index -> row of the [T, N] layout
-        use_graph = self.use_graph and self.device.type == "cuda" and not st.get("graph_refused")
-        hyper = (float(lr), float(clip_range), None if clip_range_vf is None else float(clip_range_vf))
+        from types import SimpleNamespace
+        c = SimpleNamespace(buf=buf, loss=loss, opt=opt, n_mb=n_mb, batch=batch, adv_tab=None, ac_tab=None)
+        self._train_call_tables(st, c)
+        self._train_call_run(st, c)
+        self._train_call_log(st, c, training_start)
+
+    def _train_call_tables(self, st, c) -> None:
+        """Per-call state of the fused train(): hyper-parameters (kernel arguments: a change drops the captured graph), the row numbers of
+        every minibatch, and -- for the replayed graph on one GPU -- the rotation table [rows | advantage statistics | autocorrelation
+        total] the Adam launch deals out minibatch by minibatch."""
+        c.lr = self.lr_schedule(self._current_progress_remaining)
+        self.logger.record("train/learning_rate", c.lr)
+        c.opt.lr = c.lr
+        c.clip_range = self.clip_range(self._current_progress_remaining)
+        c.clip_range_vf = None if self.clip_range_vf is None else self.clip_range_vf(self._current_progress_remaining)
+        c.loss.args.clip_range = float(c.clip_range)
+        c.loss.args.clip_range_vf = float(c.clip_range_vf) if c.clip_range_vf is not None else -1.0
+        c.loss.stats_row.zero_()
+        c.loss.stop_flag.zero_()
+        idx = torch.from_numpy(np.asarray(c.buf.indices, dtype=np.int64)).to(self.device)
+        c.rows_all = c.buf.rows_of(idx)  # the reference's flattened index -> row of the [T, N] layout
+        c.use_graph = self.use_graph and self.device.type == "cuda" and not st.get("graph_refused")
+        hyper = (float(c.lr), float(c.clip_range), None if c.clip_range_vf is None else float(c.clip_range_vf))
         if st.get("hyper") != hyper:
             st["graph"], st["hyper"] = None, hyper  # kernel arguments are baked into the graph: re-capture
-        dp = self._sync is not None and self._sync.active
-        dp_stats = dp and self._sync.world > 1
-        if dp_stats:
+        c.dp = self._sync is not None and self._sync.active
+        c.dp_stats = c.dp and self._sync.world > 1
+        if c.dp_stats:
             # the advantages and the permutation are fixed for the whole train() call: the global minibatches' advantage
             # statistics and input-autocorrelation totals are computed once (three small all-reduces), not per step
-            t_, n_ = buf.buffer_size, buf.n_envs
-            adv_tab = self._sync.global_adv_norm(buf.advantages.view(t_ * n_)[rows_all].view(n_mb, batch))
-            ac_tab = self._sync.global_autocorr(buf.autocorr[:t_].view(t_ * n_, -1)[rows_all].view(n_mb, batch, -1))
-            st["adv_cur"].copy_(adv_tab[0])
-            st["ac_cur"].copy_(ac_tab[0])
+            t_, n_ = c.buf.buffer_size, c.buf.n_envs
+            c.adv_tab = self._sync.global_adv_norm(c.buf.advantages.view(t_ * n_)[c.rows_all].view(c.n_mb, c.batch))
+            c.ac_tab = self._sync.global_autocorr(c.buf.autocorr[:t_].view(t_ * n_, -1)[c.rows_all].view(c.n_mb, c.batch, -1))
+            st["adv_cur"].copy_(c.adv_tab[0])
+            st["ac_cur"].copy_(c.ac_tab[0])
         # Replayed graph on one GPU: the row numbers of ALL minibatches of this call go to a table once, and the Adam launch that ends
         # a minibatch leaves the next one's in `loss.rows` (gnbv_clip_adam_step_rotate) -- no copy and no host work between two
         # replays.  (The table and the counter are baked into the graph: persistent buffers.)
-        rotating = use_graph and not dp and n_mb > 0 and self.rotate_rows
-        rot = st.get("rows_rot")
-        if rotating and (rot is None or tuple(rot[0].shape) != (n_mb, batch + 1 + 384)):
+        c.rotating = c.use_graph and not c.dp and c.n_mb > 0 and self.rotate_rows
+        c.rot = st.get("rows_rot")
+        if c.rotating and (c.rot is None or tuple(c.rot[0].shape) != (c.n_mb, c.batch + 1 + 384)):
             # a table row = [the minibatch's row numbers | (mean, 1 / (std + 1e-8)) of its advantages | the sum of its input-autocorrelation
             # rows], rotated into loss.rows_ext
-            rot = (torch.zeros(n_mb, batch + 1 + 384, dtype=torch.int64, device=self.device), loss.rows_ext, torch.zeros(1, dtype=torch.int32, device=self.device))
-            st["rows_rot"], st["graph"] = rot, None
-        elif not rotating and rot is not None:
-            rot = st["rows_rot"] = None
+            c.rot = (torch.zeros(c.n_mb, c.batch + 1 + 384, dtype=torch.int64, device=self.device), c.loss.rows_ext, torch.zeros(1, dtype=torch.int32, device=self.device))
+            st["rows_rot"], st["graph"] = c.rot, None
+        elif not c.rotating and c.rot is not None:
+            c.rot = st["rows_rot"] = None
             st["graph"] = None
-        if not dp:
-            loss.args.adv_norm = loss.adv_slot.data_ptr() if (rotating and self.normalize_advantage) else None
-        if not rotating:
+        if not c.dp:
+            c.loss.args.adv_norm = c.loss.adv_slot.data_ptr() if (c.rotating and self.normalize_advantage) else None
+        if not c.rotating:
             self.policy.features_extractor._autocorr_total = None
             if st.get("ac_total_on"):
                 st["graph"], st["ac_total_on"] = None, False
-        if rotating:
-            rot[0][:, :batch].copy_(rows_all[:n_mb * batch].view(n_mb, batch))
+        if c.rotating:
+            c.rot[0][:, :c.batch].copy_(c.rows_all[:c.n_mb * c.batch].view(c.n_mb, c.batch))
             if self.normalize_advantage:
                 # The advantages and the permutation are fixed for the whole train() call: every minibatch's statistics
                 # (ppo_grid_obs.py:214-216: mean, unbiased std) once, instead of two dependent gather passes in every wave of every
                 # loss launch
-                adv = buf.advantages.view(-1)[rows_all[:n_mb * batch]].view(n_mb, batch)
+                adv = c.buf.advantages.view(-1)[c.rows_all[:c.n_mb * c.batch]].view(c.n_mb, c.batch)
                 stats = torch.stack((adv.mean(1), 1.0 / (adv.std(1) + 1e-8)), 1).contiguous()
-                rot[0][:, batch:batch + 1].view(torch.float32).copy_(stats)
+                c.rot[0][:, c.batch:c.batch + 1].view(torch.float32).copy_(stats)
             # BatchNorm-1's batch statistics come from the SUM of the minibatch's autocorrelation rows: one table per train() call
             # instead of a gather of 128 scattered rows in front of every forward (k_bn1_analytic)
             enc_ = self.policy.features_extractor
-            use_tot = buf.autocorr is not None and not dp
+            use_tot = c.buf.autocorr is not None and not c.dp
             if use_tot:
-                ac_rows = buf.autocorr[:buf.buffer_size].view(buf.buffer_size * buf.n_envs, -1)
-                tot = ac_rows[rows_all[:n_mb * batch]].view(n_mb, batch, -1).sum(1, dtype=torch.int64)
-                rot[0][:, batch + 1:].view(torch.int32).copy_(tot.to(torch.int32))
+                ac_rows = c.buf.autocorr[:c.buf.buffer_size].view(c.buf.buffer_size * c.buf.n_envs, -1)
+                tot = ac_rows[c.rows_all[:c.n_mb * c.batch]].view(c.n_mb, c.batch, -1).sum(1, dtype=torch.int64)
+                c.rot[0][:, c.batch + 1:].view(torch.int32).copy_(tot.to(torch.int32))
             if st.get("ac_total_on") != use_tot:
                 st["graph"], st["ac_total_on"] = None, use_tot  # (the pointer is a kernel argument baked into the graph)
-            enc_._autocorr_total = loss.ac_slot if use_tot else None  # (only for the duration of this call: cleared below)
-            rot[2].zero_()
-        st["replays_per_call"] = n_mb * self.n_epochs
+            enc_._autocorr_total = c.loss.ac_slot if use_tot else None  # (only for the duration of this call: cleared below)
+            c.rot[2].zero_()
+
+    def _train_call_run(self, st, c) -> None:
+        """Capture (when the graph was dropped) and the epochs x minibatches loop: no host synchronisation inside an epoch."""
+        st["replays_per_call"] = c.n_mb * self.n_epochs
         st["calls_since_capture"] = st.get("calls_since_capture", 0) + 1
-        if use_graph and st["graph"] is None:
-            if rotating:
-                loss.rows_ext.copy_(rot[0][0])
+        if c.use_graph and st["graph"] is None:
+            if c.rotating:
+                c.loss.rows_ext.copy_(c.rot[0][0])
             else:
-                loss.rows.copy_(rows_all[:batch])
+                c.loss.rows.copy_(c.rows_all[:c.batch])
             st["graph"] = self._capture_minibatch_graph(st)
             if st["graph"] is None:  # (data-parallel only: the collectives could not be captured -> eager steps from here on)
-                st["graph_refused"], use_graph = True, False
-            loss.stats_row.zero_()
-            loss.stop_flag.zero_()
-            if rotating:
-                rot[2].zero_()
-        if rotating:
-            loss.rows_ext.copy_(rot[0][0])
-        epochs_run = 0
+                st["graph_refused"], c.use_graph = True, False
+            c.loss.stats_row.zero_()
+            c.loss.stop_flag.zero_()
+            if c.rotating:
+                c.rot[2].zero_()
+        if c.rotating:
+            c.loss.rows_ext.copy_(c.rot[0][0])
         try:
             for epoch in range(self.n_epochs):
-                for k in range(n_mb):
-                    if not rotating:
-                        loss.rows.copy_(rows_all[k * batch:(k + 1) * batch])
-                    if dp_stats:
-                        st["adv_cur"].copy_(adv_tab[k])
-                        st["ac_cur"].copy_(ac_tab[k])
-                    if dp:
-                        self._dp_minibatch(st, use_graph)
-                    elif use_graph:
+                for k in range(c.n_mb):
+                    if not c.rotating:
+                        c.loss.rows.copy_(c.rows_all[k * c.batch:(k + 1) * c.batch])
+                    if c.dp_stats:
+                        st["adv_cur"].copy_(c.adv_tab[k])
+                        st["ac_cur"].copy_(c.ac_tab[k])
+                    if c.dp:
+                        self._dp_minibatch(st, c.use_graph)
+                    elif c.use_graph:
                         st["graph"].replay()
                     else:
                         self._hip_minibatch_body(st)
-                epochs_run += 1
                 # the ONLY read-back inside train(): early-stop flag, once per epoch (the reference
                 # reads approx_kl on the host after every minibatch, :261-268)
-                if self.target_kl is not None and int(loss.stop_flag.item()) != 0:
+                if self.target_kl is not None and int(c.loss.stop_flag.item()) != 0:
                     if self.verbose >= 1:
                         print(f"Early stopping at step {epoch} due to reaching max kl")
                     break
         finally:
             # (also when the loop raises: the slot holds the LAST minibatch's total -- never for another caller's training-mode forward)
             self.policy.features_extractor._autocorr_total = None
+
+    def _train_call_log(self, st, c, training_start) -> None:
+        """The call's only large read-back: the statistics table -> the reference's logger records (ppo_grid_obs.py:277-292)."""
         self._n_updates += self.n_epochs
-        if dp and getattr(opt, "shard", None) is not None and self._sync.world > 1:
+        if c.dp and getattr(c.opt, "shard", None) is not None and self._sync.world > 1:
             # sharded fc_grid update: the owners' Adam moments into every rank's flat buffers HERE, at a point every rank passes together
             # (two all-gathers of 55 MB per train() call), so that get_parameters() / save() never need a collective
-            opt.gather_shard_state(self._sync.group)
-        rows_done = int(loss.stats_row.item())
-        s = loss.stats[:rows_done].double().cpu().numpy()
+            c.opt.gather_shard_state(self._sync.group)
+        rows_done = int(c.loss.stats_row.item())
+        s = c.loss.stats[:rows_done].double().cpu().numpy()
         s = s[s[:, 6] > 0.5]  # minibatches the reference would have executed
         self.last_train_stats = s
-        last_epoch = (len(s) - 1) // n_mb
-        v_flat, r_flat = buf.flat_values_returns()
+        last_epoch = (len(s) - 1) // c.n_mb
+        v_flat, r_flat = c.buf.flat_values_returns()
         var_y = torch.var(r_flat, unbiased=False)
         explained_var = float("nan") if float(var_y) == 0 else float(1 - torch.var(r_flat - v_flat, unbiased=False) / var_y)
         self.logger.record("train/entropy_loss", float(np.mean(s[:, 2])))
         self.logger.record("train/policy_gradient_loss", float(np.mean(s[:, 0])))
         self.logger.record("train/value_loss", float(np.mean(s[:, 1])))
-        self.logger.record("train/approx_kl", float(np.mean(s[last_epoch * n_mb:, 3])))
+        self.logger.record("train/approx_kl", float(np.mean(s[last_epoch * c.n_mb:, 3])))
         self.logger.record("train/clip_fraction", float(np.mean(s[:, 4])))
         self.logger.record("train/loss", float(s[-1, 5]))
         self.logger.record("train/explained_variance", explained_var)
         self.logger.record("train/n_updates", self._n_updates)
-        self.logger.record("train/clip_range", clip_range)
-        if clip_range_vf is not None:
-            self.logger.record("train/clip_range_vf", clip_range_vf)
+        self.logger.record("train/clip_range", c.clip_range)
+        if c.clip_range_vf is not None:
+            self.logger.record("train/clip_range_vf", c.clip_range_vf)
         self.logger.record("time/training", time.time() - training_start)
 
     def _check_ranges(self) -> bool:
@@ -723,10 +744,10 @@ class PPO_Grid_Obs:
         return bool(enc.check_operand_ranges()["force_fp32"])
 
     def _capture_minibatch_graph(self, st):
-        """Capture gather+forward+loss+backward+Adam of one minibatch as a hipGraph (two graphs sharing a
-        memory pool -- phase A / phase B -- when data-parallel).  Warm-up runs happen on a side stream with
-        the update masked (stop_flag = 1), so parameters, Adam state and BatchNorm running statistics are
-        untouched."""
+        """Capture gather+forward+loss+backward+Adam of one minibatch as ONE hipGraph (data-parallel with RCCL: the collectives are
+        recorded into it; a backend whose collectives cannot be captured gets None = eager launches of the same step).  Warm-up runs
+        happen on a side stream with the update masked (stop_flag = 1), so parameters, Adam state and BatchNorm running statistics
+        are untouched."""
         loss = st["loss"]
         dp = self._sync is not None and self._sync.active
         side = torch.cuda.Stream(self.device)
@@ -743,9 +764,20 @@ class PPO_Grid_Obs:
         # thread_local: the RCCL watchdog thread may touch the HIP runtime while we capture
         ga = torch.cuda.CUDAGraph()
         if not dp:
-            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+            # The memory pool of the capture that was kept is PINNED (st["graph_pool"]): a later re-capture (every invalidation above drops
+            # the old graph first, so the pool's blocks are free) allocates the same intermediates at the same addresses.  Why: what makes
+            # one capture replay 5-10 us slower than another for its whole life is WHERE its private pool put the minibatch's
+            # intermediates (y1 2 x 242 MB, four 28 MB tensors) -- captures alive together, at different addresses, keep their rank over
+            # rounds of alternating replays, sequential re-captures into the same blocks agree within 2-5 us, and graphs WITHOUT the
+            # second stream show the same spread (tools/capture_states.py, profiles/r05_capture_states*.txt): not the executor's queue
+            # placement, as round 4 assumed.
+            # (a torch.cuda.MemPool object keeps its pool alive while no graph uses it: a bare pool id dies with its last graph)
+            pinned = st.get("graph_pool")
+            mp = pinned if pinned is not None else torch.cuda.MemPool()
+            with torch.cuda.graph(ga, pool=mp.id, capture_error_mode="thread_local"):
                 self._hip_minibatch_body(st)
-            return self._best_of_captures(st, ga)
+            keep, st["graph_pool"] = self._best_of_captures(st, ga, mp, fixed_placement=pinned is not None)
+            return keep
         if not self._collectives_capturable():
             # Fall back to the EAGER data-parallel step (same `_dp_step_body`, same sharded update, launch by launch): the compute cannot be
             # captured by itself either -- BatchNorm's batch sums are exchanged inside the encoder calls (GnbvEncoderParams.sync_sum), so
@@ -758,14 +790,17 @@ class PPO_Grid_Obs:
         self.dp_graph_mode = "one hipGraph incl. RCCL collectives"
         return ga
 
-    def _best_of_captures(self, st, first):
+    def _best_of_captures(self, st, first, first_pool=None, fixed_placement=False):
         """A captured minibatch lands in one of several states PER CAPTURE -- the same kernels replay at 507-515 or at 521-532 us,
-        stable for the life of the graph object (when the graph's second queue gets going beside the two heaviest kernels differs from
-        instantiation to instantiation; profiles/r04_notes.md).  A train() call of BASELINE configs[1] replays the graph 1280 times, so when
+        stable for the life of the graph object (round 5: the state is the PLACEMENT of the capture's private memory pool, see
+        _capture_minibatch_graph; the candidates below are candidates for a placement, and the winner's pool is pinned for every
+        later re-capture).  A train() call of BASELINE configs[1] replays the graph 1280 times, so when
         the call is long enough to pay for it, the step is captured `graph_candidates` times and the fastest capture kept: each candidate is
         replayed with the update masked (stop_flag = 1: parameters, Adam state and BatchNorm statistics untouched, as in the warm-up runs),
         timed with events; the others are dropped with their memory pools."""
         k = self.graph_candidates
+        if fixed_placement and k is None:
+            k = 1  # (a re-capture into the pinned pool: the placement was chosen when the pool was)
         if k is None:
             # (a learning-rate / clip-range schedule re-captures the graph in every train() call -- the hyper-parameters are kernel
             # arguments --: candidates only for the first capture and for one that replaces a graph that lived >= 4 calls)
@@ -773,17 +808,19 @@ class PPO_Grid_Obs:
             k = 3 if (st.get("replays_per_call", 0) >= 256 and stable) else 1
         st["captures"], st["calls_since_capture"] = st.get("captures", 0) + 1, 0
         if k <= 1:
-            return first
+            return first, first_pool
         loss = st["loss"]
-        cands = [first]
+        cands, pools = [first], [first_pool]
         for _ in range(k - 1):
             loss.stop_flag.fill_(1)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            g, mp = torch.cuda.CUDAGraph(), torch.cuda.MemPool()
+            with torch.cuda.graph(g, pool=mp.id, capture_error_mode="thread_local"):
                 self._hip_minibatch_body(st)
             cands.append(g)
+            pools.append(mp)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         times = [[] for _ in cands]
+        steps_before = int(st["opt"].step_count.item())  # (the masked replays below must not count as optimizer steps: checked after the loop)
         for rnd in range(3):  # alternate the candidates: clock / thermal drift is common to them
             for c, g in enumerate(cands):
                 loss.stop_flag.fill_(1)
@@ -795,12 +832,14 @@ class PPO_Grid_Obs:
                 ev1.record()
                 ev1.synchronize()
                 times[c].append(ev0.elapsed_time(ev1) / 10.0)
+        if int(st["opt"].step_count.item()) != steps_before:
+            raise RuntimeError("a masked replay (stop_flag = 1) advanced the optimizer: a kernel of the captured minibatch ignores the stop flag")
         med = [sorted(t)[1] for t in times]
         best = min(range(len(cands)), key=lambda c: med[c])
         self.graph_capture_ms = [round(m, 4) for m in med]  # (bench.py reports it)
-        keep = cands[best]
-        del cands
-        return keep
+        keep, keep_pool = cands[best], pools[best]
+        del cands, pools
+        return keep, keep_pool
 
     def _collectives_capturable(self) -> bool:
         """Can this process group's collectives be recorded into a hipGraph?  RCCL (backend "nccl"): yes -- the step, collectives
@@ -979,6 +1018,12 @@ class PPO_Grid_Obs:
         another device, a policy whose inference forward is not the kernel sequence the plan issues)."""
         if not self.rollout_plan or self.device.type != "cuda" or "forward" in vars(self.policy) or "predict_values" in vars(self.policy):
             return None  # (an instance-level override of the policy's evaluation -- tests force actions that way -- keeps the general path)
+        from .policies import ActorCriticPolicy_Train_Eval as _P
+        enc = self.policy.features_extractor
+        if any(getattr(type(self.policy), m, None) is not getattr(_P, m) for m in ("forward", "predict_values", "_fused_head", "extract_features")):
+            return None  # (a SUBCLASS that overrides the evaluation: the plan would silently bypass it)
+        if any(getattr(m, h, None) for m in (self.policy, enc) for h in ("_forward_hooks", "_forward_pre_hooks")):
+            return None  # (nn.Module hooks on the policy / the encoder only fire on the general path)
         from ..ops.rollout_plan import RolloutForward
         plan = getattr(self, "_rollout_plan_obj", None)
         if plan is None or plan.n != n or plan.policy is not self.policy:

@@ -160,11 +160,18 @@ def _compare(hip, ref, n_steps_expected):
     return worst
 
 
-@pytest.mark.parametrize("graph", [True, False])
+@pytest.mark.parametrize("graph", [True, False, "best of 2"])
 def test_train_g64_b128_matches_fp64_oracle(rec, oracle_full, graph):
+    """`best of 2`: PPO_Grid_Obs._best_of_captures at the size it is used at -- two captures, each replayed ~39 times
+    with the update MASKED to rank them, before the real replays: the masked replays must leave parameters, Adam state, step counter
+    and BatchNorm statistics untouched, or the 20 real steps below drift from the fp64 loop."""
     n_mb = N_ENVS * T // BATCH
-    hip = _fresh_hip(rec, None, graph)
+    hip = _fresh_hip(rec, None, bool(graph))
+    hip.graph_candidates = 2 if graph == "best of 2" else 1
     hip.train()
+    if graph == "best of 2":
+        assert len(hip.graph_capture_ms) == 2 and all(0.05 < m < 5.0 for m in hip.graph_capture_ms), hip.graph_capture_ms
+    hip.graph_candidates = None
     assert hip.rollout_buffer.compact_state_dim is not None and hip.rollout_buffer.autocorr is not None  # the bench's row layout
     _compare(hip, oracle_full, EPOCHS * n_mb)
 

@@ -47,6 +47,37 @@ def test_fused_train_matches_reference(name, graph):
         assert len(ppo.graph_capture_ms) == 2 and min(ppo.graph_capture_ms) > 0
 
 
+def test_recapture_reuses_the_pinned_pool_and_its_addresses():
+    """Round 5: what made one capture of the minibatch slower than another is the placement of its private memory pool, so the pool of
+    the capture that was kept is pinned (a torch.cuda.MemPool held in `_hip["graph_pool"]`) and a re-capture -- here forced by a new
+    clip range, a kernel argument baked into the graph -- allocates the same intermediates in the same blocks: same pool object, no
+    new device memory reserved, and the update still follows the reference (the second call trains on from the first call's result:
+    only finiteness and the step count are checked for it)."""
+    fx = gu.load("F9_ppo_train")
+    ppo = _ppo_from_fixture(fx, device=DEV, backend="hip")
+    ppo.use_graph = True
+    _check(ppo, fx)
+    st = ppo._hip
+    pool, captures = st["graph_pool"], st["captures"]  # (no reference to the graph itself: its blocks must be free for the re-capture)
+    assert pool is not None and st["graph"] is not None
+    torch.cuda.synchronize()
+
+    def pool_segments():  # (address, size) of the device segments that belong to the pinned pool
+        return sorted((sg["address"], sg["total_size"]) for sg in torch.cuda.memory_snapshot() if tuple(sg.get("segment_pool_id", ())) == tuple(pool.id))
+    seg0 = pool_segments()
+    assert seg0, "the captured minibatch allocates its intermediates from the pinned pool"
+    steps = int(st["opt"].step_count.item())
+    ppo.clip_range = lambda _: 0.15  # -> st["hyper"] changes -> the graph is dropped and captured again
+    ppo.train()
+    torch.cuda.synchronize()
+    assert ppo._hip is st and st["graph"] is not None and st["captures"] == captures + 1, "the minibatch must have been captured again"
+    assert st["graph_pool"] is pool, "re-captures go into the pinned pool"
+    assert pool_segments() == seg0, ("the re-capture must find its blocks in the pool's existing segments", seg0, pool_segments())
+    assert int(st["opt"].step_count.item()) > steps
+    for p_ in ppo.policy.parameters():
+        assert bool(torch.isfinite(p_).all())
+
+
 def test_torch_backend_on_gpu_matches_reference_losses():
     """The torch-module path on the GPU (library conv/BN) also reproduces the logged losses."""
     fx = gu.load("F9_ppo_train")

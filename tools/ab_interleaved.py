@@ -148,11 +148,13 @@ def build_rollout(a, dev):
     algo, cfg, env = bench.build_algo(ns, dev, 0, 1)
     algo._setup_learn(total_timesteps=10 ** 12)
 
+    vox = bench.instrument_voxel(algo.env)  # HIP events around every gnbv_update_occ_grid call INSIDE the rollout (what bench.py's roofline prices)
+
     def step():  # one whole rollout of n_steps env steps (per-call time is divided by n_steps below)
         algo.collect_rollouts(algo.env, None, algo.rollout_buffer, n_rollout_steps=algo.n_steps)
     step()
     torch.cuda.synchronize()
-    return step, algo
+    return {"fn": step, "vox": vox}, algo
 
 
 def main():
@@ -194,7 +196,8 @@ def main():
             fn["chunk_ctx"] = (env, lib)
         torch.cuda.synchronize()
         print(f"[ab] variant {name} built and captured", file=sys.stderr, flush=True)
-        variants.append({"name": name, "env": env, "lib": lib, "fn": fn["fn"], "reset": fn.get("reset"), "ctx": fn.get("chunk_ctx"), "keep": keep, "t": [], "stream": stream})
+        variants.append({"name": name, "env": env, "lib": lib, "fn": fn["fn"], "reset": fn.get("reset"), "ctx": fn.get("chunk_ctx"), "keep": keep, "t": [], "stream": stream,
+                         "vox": fn.get("vox"), "tv": []})
         if fn.get("max_chunk"):
             chunk = min(chunk, fn["max_chunk"])
     _lib.activate(None)
@@ -215,6 +218,11 @@ def main():
             if timed:
                 ev1.record()
             torch.cuda.synchronize()
+            if v.get("vox") is not None:
+                ph = v["vox"]
+                if timed and ph.count():
+                    v["tv"].append(ph.total_ms() / ph.count() * 1e3)
+                ph.pairs.clear()
         return ev0.elapsed_time(ev1) * 1e3 / chunk / per_call_div if timed else None
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     while time.perf_counter() - t0 < 0.3:
@@ -251,6 +259,14 @@ def main():
         out["variants"].append({"name": v["name"], "env": v["env"], "lib": v["lib"], "median": med, "mad": mad, "min": min(v["t"]), "max": max(v["t"]),
                                 "paired_delta_vs_first": dmed, "paired_delta_mad": dmad})
         print(f"{v['name']:20s} {med:9.2f} +- {mad:5.2f} {unit}   [min {min(v['t']):.2f}, max {max(v['t']):.2f}]   vs {base['name']}: {dmed:+7.2f} +- {dmad:4.2f}")
+    if any(v["tv"] for v in variants):
+        print("# voxel update inside the rollout (HIP events around the three launches), us per update:")
+        out["voxel_in_rollout_us"] = []
+        for v in variants:
+            med = statistics.median(v["tv"])
+            diffs = [x - y for x, y in zip(v["tv"], base["tv"])]
+            out["voxel_in_rollout_us"].append({"name": v["name"], "median": med, "min": min(v["tv"]), "max": max(v["tv"]), "paired_delta_vs_first": statistics.median(diffs)})
+            print(f"#   {v['name']:18s} {med:8.2f}   [min {min(v['tv']):.2f}, max {max(v['tv']):.2f}]   vs {base['name']}: {statistics.median(diffs):+6.2f}")
     if a.json:
         with open(a.json, "w") as f:
             json.dump(out, f, indent=1)

@@ -19,6 +19,7 @@ import bench
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--k", type=int, default=6)
+ap.add_argument("--one-stream", action="store_true", help="no second stream inside the captured minibatch (pose branch and fc_grid's dW on the main stream)")
 a = ap.parse_args()
 dev = "cuda:0"
 ns = argparse.Namespace(gpus=1, steps=1, warmup=0, envs=256, grid=64, height=240, width=320, n_steps=8, batch_size=128, n_epochs=16, frames=2,
@@ -27,6 +28,9 @@ algo, cfg, env = bench.build_algo(ns, dev, 0, 1)
 algo.learning_rate = 1e-12
 algo.lr_schedule = lambda _: 1e-12
 algo.graph_candidates = 1
+if a.one_stream:
+    algo.async_wgrad = False
+    algo.policy.features_extractor.overlap_branches = False
 algo._setup_learn(total_timesteps=10 ** 12)
 algo.collect_rollouts(algo.env, None, algo.rollout_buffer, n_rollout_steps=algo.n_steps)
 algo.train()
@@ -66,6 +70,7 @@ def timed(g, reps=3):
 st["graph"] = None
 gc.collect()
 torch.cuda.empty_cache()
+print(f"# one_stream={a.one_stream}")
 print("# A: sequential captures, each dropped before the next")
 for i in range(a.k):
     _, before = big_segments(set())

@@ -19,6 +19,11 @@ case $st in
   abvoxel)   timeout 600 python tools/ab_interleaved.py --what voxel --variant "old:LIB=$OLD" --variant new --variant "old2:LIB=$OLD" --rounds 20 --json $O/r05_ab_voxel.json 2>&1 | tail -5 ;;
   abrollout) timeout 900 python tools/ab_interleaved.py --what rollout --n-steps 32 --variant "old:LIB=$OLD" --variant new --variant "old2:LIB=$OLD" --rounds 8 --json $O/r05_ab_rollout.json 2>&1 | tail -5 ;;
   capstates) timeout 600 python tools/capture_states.py > $O/r05_capture_states.txt 2>$O/r05_capture_states.err; cat $O/r05_capture_states.txt ;;
+  capone)    timeout 600 python tools/capture_states.py --one-stream --k 5 > $O/r05_capture_states_one_stream.txt 2>$O/r05_capture_states_one_stream.err; cat $O/r05_capture_states_one_stream.txt ;;
+  tests_np2) GENNBV_WGRAD_NP=2 timeout 900 python -m pytest tests/test_encoder_gpu.py tests/test_ppo_gpu.py -m gpu -q --maxfail=6 -p no:cacheprovider > $O/r5_tests_np2.log 2>&1; tail -6 $O/r5_tests_np2.log ;;
+  tests_enc) timeout 900 python -m pytest tests/test_encoder_gpu.py tests/test_ppo_gpu.py tests/test_ppo_g64_gpu.py -m gpu -q --maxfail=6 -p no:cacheprovider > $O/r5_tests_enc.log 2>&1; tail -6 $O/r5_tests_enc.log ;;
+  abnp2)     timeout 1500 python tools/ab_interleaved.py --what train --captures 2 --variant "two:GENNBV_TAIL_MERGE=0" --variant sc1 --variant "np2:GENNBV_TAIL_MERGE=0,GENNBV_WGRAD_NP=2" --rounds 8 --json $O/r05_ab_train_sc1_np2.json 2>&1 | grep -v "^\[ab\]" | tail -14 ;;
+  convnp2)   cd /tmp && export TMPDIR=/tmp; for v in 4 2; do rm -rf /tmp/prof_c; GENNBV_WGRAD_NP=$v rocprofv3 --kernel-trace --stats -d /tmp/prof_c -- python $GRAFT_REPO_ROOT/tools/microbench_conv.py > /tmp/prof_c.log 2>&1; echo "== GENNBV_WGRAD_NP=$v"; tail -1 /tmp/prof_c.log; python $GRAFT_REPO_ROOT/tools/rocprof_summary.py /tmp/prof_c | grep -E "wgrad|reduce|finish|dgrad|conv12" | cut -c1-150; done | tee $O/r05_conv_np2_trace.txt; cd $GRAFT_REPO_ROOT ;;
   convpmc)   bash tools/conv_stall_pmc.sh > /dev/null 2>&1; wc -l $O/conv_stall_pmc.txt ;;
   *) echo "unknown stage $st" ;;
 esac
