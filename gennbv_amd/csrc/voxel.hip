@@ -730,6 +730,9 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80), 
     const int c = slot % chunks;
     if (e >= n) return;
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    // (Round 5 wrote this workgroup's share of the env's all-zero PATH mask as zeros here, to have its lines in this XCD's L2 when the ray
+    // walk ORs into them -- inside the rollout the masks come from HBM: +4.3 us back to back, +1.3 ... +4.5 us inside the rollout; the
+    // walk's 12 extra microseconds there are not its atomics' cache misses.  profiles/r05_notes.md section 1g)
 #ifdef PHASE_TIMING
     const uint64_t pt0 = wall_clock64();
 #endif

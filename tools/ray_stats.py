@@ -20,7 +20,55 @@ ap.add_argument("--n", type=int, default=256)
 ap.add_argument("--g", type=int, default=64)
 ap.add_argument("--h", type=int, default=240)
 ap.add_argument("--w", type=int, default=320)
+ap.add_argument("--bench", action="store_true", help="the workload INSIDE bench.py's rollout (ray source = the env's pose, which follows the policy's "
+                "actions, not the recorded camera) instead of the microbenchmark's frames")
 a = ap.parse_args()
+if a.bench:
+    import argparse as _ap
+    import bench
+    ns = _ap.Namespace(gpus=1, steps=1, warmup=0, envs=a.n, grid=a.g, height=a.h, width=a.w, n_steps=6, batch_size=128, n_epochs=1, frames=4, backend="hip",
+                       obs="compact", target_kl="off", semantic=False, no_cpu_baseline=True, no_flat_rows=True, no_state_check=True)
+    algo, cfg, env = bench.build_algo(ns, "cuda:0", 0, 1)
+    algo._setup_learn(total_timesteps=10 ** 12)
+    upd = env.updater
+    upd.self_clean = False
+    seen = []
+    orig = upd.update
+
+    def rec(depth, seg, c2w, poses, *x, **k):
+        seen.append(poses.detach().clone())
+        return orig(depth, seg, c2w, poses, *x, **k)
+    upd.update = rec
+    algo.collect_rollouts(env, None, algo.rollout_buffer, n_rollout_steps=6)
+    torch.cuda.synchronize()
+    n, g = a.n, a.g
+    hit, path = upd.masks()
+    hit = hit.reshape(n, g, g, g).cpu().numpy().astype(bool)
+    pose = seen[-1][:, :3].cpu().numpy()
+    rg, vs = upd.range_gt.cpu().numpy(), upd.voxel_size_gt.cpu().numpy()
+    src = np.floor((pose - (rg[:, 1::2] - 0.5 * vs)) / vs).astype(np.int64)
+    tot = {"list": 0, "sorted": 0, "perfect": 0.0, "seg16": 0, "seg8": 0}
+    Ls, inside = [], 0
+    for e in range(n):
+        t = np.argwhere(hit[e])  # ascending voxel index = the order of the env's ray list (per image chunk)
+        if len(t) == 0:
+            continue
+        inside += int(((src[e] >= 0) & (src[e] < g)).all())
+        L = np.abs(t - src[e]).max(1)
+        Ls.append(L)
+        for i in range(0, len(L), 64):
+            tot["list"] += int(L[i:i + 64].max())
+        Lq = np.sort(L)[::-1]
+        for i in range(0, len(Lq), 64):
+            tot["sorted"] += int(Lq[i])
+        tot["perfect"] += L.sum() / 64
+        for seg in (16, 8):  # fixed-length segments dealt to lanes: every wave runs `seg` steps (+ a set-up per segment)
+            tot[f"seg{seg}"] += int(np.ceil(np.ceil(L / seg).sum() / 64)) * seg
+    A = np.concatenate(Ls)
+    print(f"bench rollout, last update: rays/env mean {np.mean([len(x) for x in Ls]):.0f}; source voxel inside the grid in {inside} of {n} envs")
+    print(f"   steps per ray mean {A.mean():.1f} p50 {np.median(A):.0f} p90 {np.percentile(A, 90):.0f} max {A.max()}; hist/16 {np.histogram(A, bins=range(0, 200, 16))[0]}")
+    print(f"   wave-steps: list order {tot['list']}, length-sorted per env {tot['sorted']}, perfect {tot['perfect']:.0f}, 16-step segments {tot['seg16']}, 8-step segments {tot['seg8']}")
+    sys.exit(0)
 n, g, h, w = a.n, a.g, a.h, a.w
 dev = "cuda:0"
 cfg = TaskConfig(camera_width=w, camera_height=h, grid_size=g)
