@@ -141,6 +141,11 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_fused(GnbvPpoLoss a, float
     if (i < B) {
         const float *lg = a.logits + (size_t)i * a.n_logits;
         const int64_t r = src_row(a, i);
+        // (round 5: the sample's scalars are requested HERE, with the logits, instead of after the head statistics -- one dependent
+        // round trip less in a launch that is nothing but round trips)
+        const float adv_raw = a.advantages[r], old_lp = a.old_log_prob[r], v = a.values[i], vo = a.old_values[r], ret = a.returns[r];
+        const float norm_mean = (a.normalize_advantage && a.adv_norm) ? a.adv_norm[0] : 0.f;
+        const float norm_inv = (a.normalize_advantage && a.adv_norm) ? a.adv_norm[1] : 1.f;
         // ---- head statistics, log-prob of the taken actions, entropy ----
         float lse[kMaxHeads], hent[kMaxHeads];
         int act[kMaxHeads];
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_fused(GnbvPpoLoss a, float
         float mean = 0.f, inv_std = 1.f;
         if (a.normalize_advantage) {
             if (a.adv_norm) {
-                mean = a.adv_norm[0]; inv_std = a.adv_norm[1];
+                mean = norm_mean; inv_std = norm_inv;
             } else {
                 float s = 0.f;
                 for (int j = lane; j < B; j += 64) s += a.advantages[src_row(a, j)];
@@ -207,8 +212,8 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_fused(GnbvPpoLoss a, float
             }
         }
         // ---- this sample's scalar terms (every lane computes them: no broadcast needed) ----
-        const float adv = a.normalize_advantage ? (a.advantages[r] - mean) * inv_std : a.advantages[r];
-        const float log_ratio = logp - a.old_log_prob[r];
+        const float adv = a.normalize_advantage ? (adv_raw - mean) * inv_std : adv_raw;
+        const float log_ratio = logp - old_lp;
         const float ratio = expf(log_ratio);
         const float lo = 1.0f - a.clip_range, hi = 1.0f + a.clip_range;
         const float rc = fminf(fmaxf(ratio, lo), hi);
@@ -217,14 +222,13 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_fused(GnbvPpoLoss a, float
         const float g1 = s1 < s2 ? 1.f : (s1 > s2 ? 0.f : 0.5f), g2 = 1.f - g1;
         const float inrange = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
         const float gl = -invB * a.policy_scale * adv * ratio * (g1 + g2 * inrange);
-        const float v = a.values[i], vo = a.old_values[r];
         float vp = v, dvp = 1.f;
         if (a.clip_range_vf > 0.f) {
             const float dv = v - vo;
             vp = vo + fminf(fmaxf(dv, -a.clip_range_vf), a.clip_range_vf);
             dvp = (dv >= -a.clip_range_vf && dv <= a.clip_range_vf) ? 1.f : 0.f;
         }
-        const float err = vp - a.returns[r];
+        const float err = vp - ret;
         if (lane == 0) {
             a.d_values[i] = a.vf_coef * 2.0f * invB * err * dvp;
             float *t = terms + (size_t)i * 8;

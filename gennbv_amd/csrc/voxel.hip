@@ -736,6 +736,9 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_num_sgpr(80), 
 #ifdef PHASE_TIMING
     const uint64_t pt0 = wall_clock64();
 #endif
+    // (Round 5 wrote this workgroup's share of the env's all-zero PATH mask as zeros here, to have its lines in this XCD's L2 when the ray
+    // walk ORs into them -- inside the rollout the masks come from HBM: +4.3 us back to back, +1.3 ... +4.5 us inside the rollout: the
+    // walk's time there is not its atomics' cache misses.  profiles/r05_notes.md section 1g)
     for (int i = tid; i < words; i += kFusedThreads) smem[i] = 0u;
     if (tid == 0) *s_qcnt = 0;
     if (coverage_zero != nullptr && c == 0 && tid == 0) coverage_zero[e] = 0;  // (accumulated by the grid-update launch)
@@ -1090,6 +1093,10 @@ __device__ __forceinline__ void walk_packed(int sx, int sy, int sz, int l_src, i
 // slice counts and finds the (env, slice) that holds item j -- ~40 instructions per wave, no inter-workgroup traffic.  Blocks past
 // the XCD's last item exit; they sit at the END of the dispatch order, behind every live workgroup.  A grid smaller than the item
 // count (an env with tens of thousands of rays) makes its workgroups take several items.
+// (Round 5, measured and not kept -- tools/ray_phase_rollout.py, profiles/r05_notes.md 1g: the launch ends with its heaviest ITEMS, 23-25 us
+// where the mean item takes 11; rays walked in segments of <= 16 steps dealt evenly over the workgroup's lanes, so that no wave waits
+// for its longest ray: item mean 13.0 / max 25.2 us, the update +1.1 us; items numbered over all envs, 115 per XCD instead of 96-136:
+// last end 24-25 us all the same, the update +1.4 ... +2.8 us.  A heavy item is heavy in its LDS atomics, not in its longest ray.)
 // (amdgpu_num_sgpr: with the 96 the compiler takes, a SIMD's SGPR file holds 7 waves; the six waves of a workgroup do not spread evenly
 // over the four SIMDs, so some CUs then held three workgroups instead of five and a tenth of the launch's workgroups started when the
 // first ones ended: -3.6 us per update, profiles/r05_notes.md)
