@@ -112,6 +112,34 @@ __device__ __forceinline__ uint4 ldu4_nt(const int8_t *p)
     const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(p));
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
+// ---- the training forward's staging waves keep their own vector-memory books (round 5) -------------------------------------------
+// Its y1 store must not be skipped for tiles the workgroup does not own (a branch around it makes the compiler's wait-count merge wait
+// for the stores just issued), and as a branch-free store of all 64 lanes to a padding slot the dummies cost the store path as much
+// as real ones -- 26 % of the launch's 1-KiB store instructions, with the texture path stalled on store data 43 % of the launch
+// (profiles/r05_conv_pmc.txt).  So the store runs under an EXEC mask of ONE lane where the tile is not owned (the instruction still
+// counts in vmcnt: the counts stay static), which only inline asm can do -- and once the stores are invisible to the compiler, so
+// must be the requests of the same waves and the waits between them.
+typedef unsigned u4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ldu4_nt_async(u4v_t &dst, const int8_t *p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm_keep1(u4v_t &a)  // at most N younger vector-memory operations stay in flight; `a` is valid behind it
+{
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
+}
+// 16-byte non-temporal store of all lanes (mask_lo = mask_hi = ~0) or of lane 0 only (1, 0); both masks wave-uniform
+__device__ __forceinline__ void st4_nt_masked(char *sbase, uint32_t voff, f32x4 v, uint32_t mask_lo, uint32_t mask_hi)
+{
+    uint32_t s0, s1;
+    asm volatile("s_mov_b32 %0, exec_lo\n\ts_mov_b32 %1, exec_hi\n\ts_and_b32 exec_lo, exec_lo, %5\n\ts_and_b32 exec_hi, exec_hi, %6\n\t"
+                 "global_store_dwordx4 %2, %3, %4 nt\n\ts_mov_b32 exec_lo, %0\n\ts_mov_b32 exec_hi, %1"
+                 : "=&s"(s0), "=&s"(s1)
+                 : "v"(voff), "v"(v), "s"(sbase), "s"(mask_lo), "s"(mask_hi)
+                 : "memory", "scc");
+}
+
 struct ZStager {
     const float *ybase;
     uint32_t rowC, planeC, st_lane;
@@ -1046,12 +1074,20 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
         const int plane_g = min(4 * oz0 + fpl, G - 1);
         auto in_req = [&](int j) {  // input rows 4j+2 .. 4j+6 (clamped; UNCONDITIONAL)
             const int row_g = min(max(4 * j + 2 + frow, 0), G - 1);
-            return ldu4_nt(in + ((size_t)plane_g * G + row_g) * G + 16 * fq);  // (the int8 input rows: -9.6 us per minibatch, -5.7 us per env step)
+            const int8_t *src = in + ((size_t)plane_g * G + row_g) * G + 16 * fq;
+            if constexpr (TRAIN) {  // (opaque request: the caller waits with wait_vm_keep1, see st4_nt_masked)
+                u4v_t v;
+                ldu4_nt_async(v, src);
+                return v;
+            } else {
+                const uint4 u = ldu4_nt(src);  // (the int8 input rows: -9.6 us per minibatch, -5.7 us per env step)
+                return (u4v_t){u.x, u.y, u.z, u.w};
+            }
         };
         // int8 -> f16 on the way into the slab, two values per v_perm_b32 + v_pk_add_f16: the byte b ^ 0x80 under the exponent byte
         // 0x64 is the f16 number 1024 + (b + 128), minus 1152 = b (exact: integers below 2048)
-        auto in_store = [&](int j, const uint4 &v) {
-            const uint32_t w[4] = {v.x ^ 0x80808080u, v.y ^ 0x80808080u, v.z ^ 0x80808080u, v.w ^ 0x80808080u};
+        auto in_store = [&](int j, const u4v_t &v) {
+            const uint32_t w[4] = {v[0] ^ 0x80808080u, v[1] ^ 0x80808080u, v[2] ^ 0x80808080u, v[3] ^ 0x80808080u};
             uint32_t o[8];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1119,10 +1155,11 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
                     // BRANCH-FREE: a conditional store makes the compiler's wait-count merge wait for the stores just issued when
                     // the next input piece is taken from its registers.  Row base in scalar registers, lane part precomputed.
                     // (bitwise, not && / ||: the short-circuit form becomes control flow with the two addresses in a stack array)
-                    const bool own = (bool)((int)(row >= 0) & (int)(row < O1) & ((int)(pi < 2 * np) | ((int)(pi == 2 * np) & (int)(oz1 == O2))));
+                    const int own = __builtin_amdgcn_readfirstlane((int)(row >= 0) & (int)(row < O1) & ((int)(pi < 2 * np) | ((int)(pi == 2 * np) & (int)(oz1 == O2))));
                     const uint32_t rowbase = vox1(b, min(2 * oz0 + pi, O1 - 1), min(max(row, 0), O1 - 1), 0, O1) * kC;
                     char *dst1 = reinterpret_cast<char *>(y1 + __builtin_amdgcn_readfirstlane(rowbase));
-                    __builtin_nontemporal_store((f32x4){yv[0], yv[1], yv[2], yv[3]}, reinterpret_cast<f32x4 *>(dst1 + (own ? 4 * y1_lane : 4 * y1_pad)));
+                    // all 64 lanes where the workgroup owns the tile; lane 0 alone, into the row's padding slot, where it does not
+                    st4_nt_masked(dst1, own ? 4 * y1_lane : 4 * y1_pad, (f32x4){yv[0], yv[1], yv[2], yv[3]}, own ? ~0u : 1u, own ? ~0u : 0u);
                 }
                 char *dst = stage + (pi * kRing + slot) * kRowBytes + par * 1024 + n * 32 + g * 8;
                 *reinterpret_cast<h4 *>(dst) = hi;
@@ -1132,15 +1169,20 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
             }
         };
         // prologue: three barriers (the compute waves run the same count)
-        uint4 ra = in_req(-1), rb = in_req(0);
+        // (TRAIN: explicit waits.  A wave's vector-memory operations complete in issue order; behind the request a wait releases there
+        // are, in issue order: [the other register's request], then per half step 3 y1 stores + 1 request)
+        u4v_t ra = in_req(-1), rb = in_req(0);
+        if constexpr (TRAIN) wait_vm_keep1<1>(ra);
         in_store(-1, ra);
         ra = in_req(1);
         split_step_barrier();
         compute(-1, 1);
+        if constexpr (TRAIN) wait_vm_keep1<4>(rb);  // ra's request + 3 stores
         in_store(0, rb);
         rb = in_req(2);
         split_step_barrier();
         compute(0, 0);
+        if constexpr (TRAIN) wait_vm_keep1<7>(ra);  // 3 stores + rb's request + 3 stores: the steady state
         in_store(1, ra);
         ra = in_req(3);
         split_step_barrier();
@@ -1148,10 +1190,12 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
         // even iterations, ra odd ones.  Branch-free around the requests.
         for (int t = 1; t <= nsteps; t += 2) {
             compute(t, 1);
+            if constexpr (TRAIN) wait_vm_keep1<7>(rb);
             in_store(t + 1, rb);
             rb = in_req(t + 3);
             split_step_barrier();
             compute(t + 1, 0);
+            if constexpr (TRAIN) wait_vm_keep1<7>(ra);
             in_store(t + 2, ra);
             ra = in_req(t + 4);
             split_step_barrier();

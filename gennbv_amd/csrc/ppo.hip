@@ -171,7 +171,14 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_fused(GnbvPpoLoss a, float
 #pragma unroll
             for (int h = 0; h < kMaxHeads; ++h) {
                 if (h < a.n_heads) {
-                    xa[h] = lg[off + act[h]];
+                    // the taken action's logit: with the head in registers it is in lane act & 63 already (round 5: a lane exchange instead
+                    // of a third dependent round trip rows -> actions -> logits[action])
+                    if (regs) {
+                        const float lo_ = __shfl(x0[h], act[h] & 63, 64), hi_ = __shfl(x1[h], act[h] & 63, 64);
+                        xa[h] = act[h] < 64 ? lo_ : hi_;
+                    } else {
+                        xa[h] = lg[off + act[h]];
+                    }
                     off += a.head_dims[h];
                 }
             }
