@@ -1159,6 +1159,8 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
                     const uint32_t rowbase = vox1(b, min(2 * oz0 + pi, O1 - 1), min(max(row, 0), O1 - 1), 0, O1) * kC;
                     char *dst1 = reinterpret_cast<char *>(y1 + __builtin_amdgcn_readfirstlane(rowbase));
                     // all 64 lanes where the workgroup owns the tile; lane 0 alone, into the row's padding slot, where it does not
+                    // (the first 32 / 64 samples' y1 stored WITHOUT the non-temporal hint, so that the backward finds a part of it in the
+                    // memory-side cache: +1.4 / +7.3 us per minibatch, profiles/r05_ab_train_y1_cached_samples.json)
                     st4_nt_masked(dst1, own ? 4 * y1_lane : 4 * y1_pad, (f32x4){yv[0], yv[1], yv[2], yv[3]}, own ? ~0u : 1u, own ? ~0u : 0u);
                 }
                 char *dst = stage + (pi * kRing + slot) * kRowBytes + par * 1024 + n * 32 + g * 8;
