@@ -133,6 +133,7 @@ __device__ __forceinline__ void wait_vm_keep1(u4v_t &a)  // at most N younger ve
 __device__ __forceinline__ void st4_nt_masked(char *sbase, uint32_t voff, f32x4 v, uint32_t mask_lo, uint32_t mask_hi)
 {
     uint32_t s0, s1;
+    mask_lo = __builtin_amdgcn_readfirstlane(mask_lo), mask_hi = __builtin_amdgcn_readfirstlane(mask_hi);  // (scalar registers, whatever the caller's select became)
     asm volatile("s_mov_b32 %0, exec_lo\n\ts_mov_b32 %1, exec_hi\n\ts_and_b32 exec_lo, exec_lo, %5\n\ts_and_b32 exec_hi, exec_hi, %6\n\t"
                  "global_store_dwordx4 %2, %3, %4 nt\n\ts_mov_b32 exec_lo, %0\n\ts_mov_b32 exec_hi, %1"
                  : "=&s"(s0), "=&s"(s1)
