@@ -178,8 +178,11 @@ __device__ __forceinline__ void lsplit8(const float4 &p, const float4 &q, float 
 // folded into this kernel's operand load.  P >= 512 (the caller checks): a chunk of <= 512 columns then meets at most one channel
 // boundary, and a 32-column trip that does not contain it takes the scalar path (one fma + one max per element).  The largest
 // operand is tracked for the range guard (bit 4 of *range_flag when it passes 1000: the split clamps x at 1015).
-template <bool FOLD>
-__global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linear_splitk_split(
+// WAVES = 4: a workgroup = 128 rows (the minibatch); WAVES = 8 (round 5): 256 rows (the rollout's policy evaluation) behind ONE staged W tile --
+// two 128-row workgroups staged (fetched, split, stored) every W tile twice: 66 us for a launch whose operands take 20 at the HBM rate.
+// Same per-row arithmetic in the same order: bit-identical rows.
+template <bool FOLD, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linear_splitk_split(
     const float *__restrict__ x /*[M][K]*/, const float *w /*[N][K]*/, int M, int N, int K, int nchunks,
     float *__restrict__ partial /*[nchunks][M][N]*/, const float *__restrict__ xs_scale = nullptr, const float *__restrict__ xs_shift = nullptr,
     int xs_P = 0, int *__restrict__ range_flag = nullptr)
@@ -188,9 +191,11 @@ __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     // 1-D grid: the row slabs (128 rows each) of one (chunk, column tile) sit next to each other in dispatch order and on ONE XCD, so
     // that the second slab's W requests meet the first one's lines in that XCD's L2 (the rollout's 256 rows: W was fetched twice)
-    const int nslab = (M + 127) / 128;
+    constexpr int kThreads = 64 * WAVES, kRows = 32 * WAVES, kNR = 512 / kThreads;  // rows per workgroup; staging repetitions per thread
+    static_assert(WAVES == 4 || WAVES == 8, "128 or 256 rows per workgroup");
+    const int nslab = (M + kRows - 1) / kRows;
     const int xcd = blockIdx.x & 7, t_ = blockIdx.x >> 3, slot = t_ / nslab;
-    const int i = lane & 15, g = lane >> 4, mbase = (t_ - slot * nslab) * 128;
+    const int i = lane & 15, g = lane >> 4, mbase = (t_ - slot * nslab) * kRows;
     const int ntn = N / kTileN;
     const int nt = slot % ntn, chunk = (slot / ntn) * 8 + xcd;
     if (chunk >= nchunks) return;
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 
     const int s0 = (int)((int64_t)chunk * nstep32 / nchunks), s1 = (int)((int64_t)(chunk + 1) * nstep32 / nchunks);
     if (s0 >= s1) {  // (a chunk without work still owns its partial slab)
         float *out = partial + (size_t)chunk * M * N;
-        for (int r = threadIdx.x; r < 128 * kTileN; r += kLinThreads) {
+        for (int r = threadIdx.x; r < kRows * kTileN; r += kThreads) {
             const int row = mbase + r / kTileN;
             if (row < M) out[(size_t)row * N + nt * kTileN + r % kTileN] = 0.0f;
         }
@@ -210,12 +215,12 @@ __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 
     const int t8 = threadIdx.x & 7, tcol = threadIdx.x >> 3;
     const float *wst[2];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) wst[r] = w + (size_t)(nt * kTileN + 32 * r + tcol) * K + 4 * t8;
+    for (int r = 0; r < 2; ++r) wst[r] = w + (size_t)(nt * kTileN + (kNR == 2 ? 32 * r : 0) + tcol) * K + 4 * t8;  // (WAVES = 8: one column per thread, r = 1 unused)
     // LDS byte offsets: staging store of this thread's (column 32 r + tcol, k-quad t8); B-operand read of this lane
     uint32_t st_off[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const int col = 32 * r + tcol;
+        const int col = (kNR == 2 ? 32 * r : 0) + tcol;
         st_off[r] = (uint32_t)((((col >> 4) * 4 + (t8 >> 1)) * 16 + (col & 15)) * 16 + (t8 & 1) * 8);
     }
     const uint32_t rd_off = (uint32_t)((g * 16 + i) * 16);
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 
     auto request_b = [&](int s, Trip &t) {
         const int kc = min(min(s, s1 - 1) * 32, K - 4 - 4 * t8);
         t.b0 = ld4g(wst[0] + kc);
-        t.b1 = ld4g(wst[1] + kc);
+        if (kNR == 2) t.b1 = ld4g(wst[1] + kc);
     };
     auto stage_one = [&](int buf, bool ok, const float4 &b, uint32_t off) {
         const float v[4] = {b.x, b.y, b.z, b.w};
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(2, 
     auto stage_b = [&](int buf, int s, Trip &t) {
         const bool ok = s < s1 && s * 32 + 4 * t8 + 3 < K;  // past the chunk / past K: zeros
         stage_one(buf, ok, t.b0, st_off[0]);
-        stage_one(buf, ok, t.b1, st_off[1]);
+        if (kNR == 2) stage_one(buf, ok, t.b1, st_off[1]);
     };
     // FOLD: the channel of the chunk's first column, the first column of the next channel, both channels' (scale, shift)
     float f_sc[2] = {0.f, 0.f}, f_sh[2] = {0.f, 0.f}, zmax = 0.0f;
@@ -659,8 +664,12 @@ GNBV_API int gnbv_linear_forward_fold(const float *y, const float *scale, const 
     hipStream_t st = gnbv_stream(stream);
     const int nchunks = pick_chunks(K), ntn = N / kTileN;
     const int blocks = ((nchunks + 7) / 8) * 8 * ntn;
-    hipLaunchKernelGGL(k_linear_splitk_split<true>, dim3(blocks * ((M + 127) / 128)), dim3(kLinThreads), 0, st, y, w, M, N, K, nchunks, (float *)workspace, scale,
-                       shift, P, range_flag);
+    if (M > 128)  // (the rollout: 256 rows behind one staged W tile)
+        hipLaunchKernelGGL((k_linear_splitk_split<true, 8>), dim3(blocks * ((M + 255) / 256)), dim3(512), 0, st, y, w, M, N, K, nchunks, (float *)workspace, scale,
+                           shift, P, range_flag);
+    else
+        hipLaunchKernelGGL((k_linear_splitk_split<true, 4>), dim3(blocks * ((M + 127) / 128)), dim3(kLinThreads), 0, st, y, w, M, N, K, nchunks, (float *)workspace, scale,
+                           shift, P, range_flag);
     int err;
     if ((err = gnbv_launch_status())) return err;
     const int64_t total4 = (int64_t)M * N / 4;
@@ -681,8 +690,10 @@ GNBV_API int gnbv_linear_forward(const float *x, const float *w, const float *bi
     const int blocks = ((nchunks + 7) / 8) * 8 * ntn;
     const bool fp32_arith = (relu & 2) != 0;  // (flag word: include/gennbv_hip.h)
     relu &= 1;
-    if (split_kernels_on() && !fp32_arith && K % 8 == 0 && K >= 64)
-        hipLaunchKernelGGL(k_linear_splitk_split<false>, dim3(blocks * ((M + 127) / 128)), dim3(kLinThreads), 0, st, x, w, M, N, K, nchunks, (float *)workspace);
+    if (split_kernels_on() && !fp32_arith && K % 8 == 0 && K >= 64 && M > 128)
+        hipLaunchKernelGGL((k_linear_splitk_split<false, 8>), dim3(blocks * ((M + 255) / 256)), dim3(512), 0, st, x, w, M, N, K, nchunks, (float *)workspace);
+    else if (split_kernels_on() && !fp32_arith && K % 8 == 0 && K >= 64)
+        hipLaunchKernelGGL((k_linear_splitk_split<false, 4>), dim3(blocks * ((M + 127) / 128)), dim3(kLinThreads), 0, st, x, w, M, N, K, nchunks, (float *)workspace);
     else
         hipLaunchKernelGGL(k_linear_splitk, dim3(blocks, (M + 127) / 128), dim3(kLinThreads), 0, st, x, w, M, N, K, nchunks, (float *)workspace);
     int err;

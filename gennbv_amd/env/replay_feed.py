@@ -219,6 +219,9 @@ class ReplayFeedEnv:
         self._post.episode_length_buf = self.episode_length_buf.data_ptr()  # the algorithm may have replaced the tensor
         _lib.check(lib.gnbv_env_pre_step(actions_in.data_ptr(), C.byref(self._lat), self.episode_length_buf.data_ptr(), n,
                                          self.actions.data_ptr(), self.poses.data_ptr(), st), "gnbv_env_pre_step")
+        # (Round 5 ran the two small observation kernels below on a second stream beside the voxel update, joined in front of the
+        # post-step kernel: the env step +1.9 ... +5.4 us, the voxel update +4.9 us -- they take slots from k_hit_list's single round of
+        # workgroups.  profiles/r05_ab_rollout_obs_overlap.json)
         # obs["state"]
         _lib.check(lib.gnbv_env_obs_state(self.pose_hist.data_ptr(), self.poses.data_ptr(), self.reset_mask.data_ptr(),
                                           C.byref(self._lat), n, cfg.stack, obs.data_ptr(), stride, st), "gnbv_env_obs_state")

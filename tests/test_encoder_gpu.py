@@ -259,6 +259,12 @@ def test_splitk_linear_relu_vs_fp64(m, n, k, arith, monkeypatch):
     assert torch.allclose(out.double(), ref, rtol=1e-5, atol=2e-6), float((out.double() - ref).abs().max())
     # deterministic: identical bits on a second call
     assert torch.equal(out, linear_relu(x, lin))
+    if m > 128 and arith == "split":
+        # round 5: more than 128 rows go through 256-row workgroups (one staged W tile for both halves); the rows' arithmetic is that
+        # of the 128-row workgroups, bit for bit
+        with torch.no_grad():
+            halves = torch.cat([linear_relu(x[i:i + 128].detach().contiguous(), lin) for i in range(0, m, 128)])
+        assert torch.equal(out.detach(), halves)
     d = torch.randn(m, n, generator=gen).to(DEV)
     out.backward(d)
     g = d.double() * (ref > 0)
