@@ -172,6 +172,23 @@ class TensorRolloutBuffer_Grid_Obs:
             self.full = True
 
     def compute_returns_and_advantage(self, last_values: torch.Tensor, dones) -> None:
+        if self.rewards.device.type == "cpu":
+            # A buffer the caller PLACED on the CPU (BASELINE configs[0]: MLP policy, PPO on the CPU over a recorded feed -- the
+            # plain-torch configuration, which never touches the kernels): buffers.py:706-724 as a backward recurrence over the rows,
+            #   A_t = d_t + gamma lam m_t A_{t+1},   d_t = r_t + gamma m_t V_{t+1} - V_t,   m_t = 1 - (start of t+1 | done after the last row).
+            # Not a fallback: device tensors go to the gfx950 kernel below, which fails loudly without its library.
+            t_steps = self.buffer_size
+            v_next = last_values.detach().reshape(self.n_envs, 1).to(self.values.dtype)
+            alive = 1.0 - torch.as_tensor(dones).reshape(self.n_envs, 1).to(self.values.dtype)
+            run = torch.zeros_like(v_next)
+            for t in range(t_steps - 1, -1, -1):
+                delta = self.rewards[t] + self.gamma * v_next * alive - self.values[t]
+                run = delta + self.gamma * self.gae_lambda * alive * run
+                self.advantages[t] = run
+                v_next = self.values[t]
+                alive = 1.0 - self.episode_starts[t].reshape(self.n_envs, 1).to(self.values.dtype)
+            self.returns.copy_(self.advantages + self.values)
+            return
         gae_ops.compute_returns_and_advantage(self.rewards, self.values, self.episode_starts, last_values.detach(), dones,
                                               self.gamma, self.gae_lambda, advantages=self.advantages, returns=self.returns)
 

@@ -1,6 +1,7 @@
 """ActorCriticPolicy_Train_Eval (stable_baselines3/common/policies.py:797-1090) for the
 configuration GenNBV trains with: `net_arch=[]` (identity mlp_extractor), a features
-extractor class + kwargs, MultiDiscrete actions, Adam(eps=1e-5).
+extractor class + kwargs, MultiDiscrete actions, Adam(eps=1e-5) -- and, for BASELINE configs[0], SB3's
+MLP policy (`FlattenExtractor` + `MlpExtractor`, sb3/torch_layers.py) on the plain-torch path.
 
 Same constructor keywords, methods and `state_dict` keys
 (`features_extractor.*`, `action_net.*`, `value_net.*`)."""
@@ -42,7 +43,14 @@ class ActorCriticPolicy_Train_Eval(nn.Module):
                  optimizer_kwargs: Optional[Dict[str, Any]] = None, **unused):
         super().__init__()
         assert not use_sde, "gSDE is not on the GenNBV path"
-        assert net_arch is None or len(net_arch) == 0, "GenNBV trains with net_arch=[] (train_gennbv.py:150)"
+        # GenNBV trains with net_arch=[] (train_gennbv.py:150); a non-empty net_arch builds SB3's MlpExtractor (BASELINE configs[0]: the
+        # CPU-runnable MLP policy, sb3/torch_layers.py).  net_arch=None is SB3's default for an MLP policy: two towers of 64, 64.
+        # Defaults as the reference's (policies.py:844, :868-872): FlattenExtractor, two towers of 64, 64.
+        if features_extractor_class is None:
+            from .torch_layers import FlattenExtractor
+            features_extractor_class = FlattenExtractor
+        if net_arch is None:
+            net_arch = [dict(pi=[64, 64], vf=[64, 64])]
         if optimizer_kwargs is None:
             optimizer_kwargs = {}
             if optimizer_class == torch.optim.Adam:
@@ -52,10 +60,14 @@ class ActorCriticPolicy_Train_Eval(nn.Module):
         self.ortho_init = ortho_init
         self.features_extractor = features_extractor_class(observation_space, **(features_extractor_kwargs or {}))
         self.features_dim = self.features_extractor.features_dim
-        self.mlp_extractor = _IdentityExtractor(self.features_dim)
+        if len(net_arch) == 0:
+            self.mlp_extractor = _IdentityExtractor(self.features_dim)
+        else:
+            from .torch_layers import MlpExtractor
+            self.mlp_extractor = MlpExtractor(self.features_dim, net_arch, activation_fn)
         self.action_dist = MultiCategoricalDistribution(list(action_space.nvec))
-        self.action_net = self.action_dist.proba_distribution_net(latent_dim=self.features_dim)
-        self.value_net = nn.Linear(self.features_dim, 1)
+        self.action_net = self.action_dist.proba_distribution_net(latent_dim=self.mlp_extractor.latent_dim_pi)
+        self.value_net = nn.Linear(self.mlp_extractor.latent_dim_vf, 1)
         if ortho_init:
             # policies.py:983-994: Linear/Conv2d only -- Conv3d keeps torch's default init
             for module, gain in ((self.features_extractor, np.sqrt(2)), (self.mlp_extractor, np.sqrt(2)),
