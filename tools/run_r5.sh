@@ -12,6 +12,9 @@ case $st in
   benchdrv)  timeout 1200 python bench.py --steps 20 --warmup 5 2>$O/r5_benchdrv.err | tail -1 > $O/r5_bench_driver_cfg_n1.json; cut -c1-400 $O/r5_bench_driver_cfg_n1.json ;;
   dp1)       GENNBV_FORCE_DP=1 GENNBV_FORCE_SHARD=1 timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-flat-rows 2>$O/r5_dp1.err | tail -1 > $O/r5_bench_dp1_n1.json; cut -c1-500 $O/r5_bench_dp1_n1.json ;;
   prof)      bash tools/collect_profiles.sh r05 2>&1 | tail -5 ;;
+  refdef)    timeout 1200 python bench.py --steps 3 --warmup 1 --height 400 --width 400 --grid 20 --no-flat-rows 2>$O/r5_refdef.err | tail -1 > $O/r5_bench_refdefault_n1.json; cut -c1-400 $O/r5_bench_refdefault_n1.json ;;
+  semantic)  timeout 900 python bench.py --steps 3 --warmup 1 --semantic --no-cpu-baseline --no-flat-rows 2>/dev/null | tail -1 > $O/r5_bench_semantic_n1.json; cut -c1-300 $O/r5_bench_semantic_n1.json ;;
+  config5)   timeout 1500 python bench.py --steps 1 --warmup 1 --envs 512 --grid 128 --no-cpu-baseline --no-flat-rows 2>/dev/null | tail -1 > $O/r5_bench_config5_shard_n1.json; cut -c1-300 $O/r5_bench_config5_shard_n1.json ;;
   abvoxrot)  timeout 300 python tools/ab_interleaved.py --what voxel --variant base --variant "rot:LIB=gennbv_amd/libgennbv_hip_rot.so" --variant base2 --rounds 20 --json $O/r05_ab_voxel_chunk_rot.json 2>&1 | tail -4 ;;
   abrollrot) timeout 600 python tools/ab_interleaved.py --what rollout --n-steps 32 --variant base --variant "rot:LIB=gennbv_amd/libgennbv_hip_rot.so" --variant base2 --rounds 6 --json $O/r05_ab_rollout_chunk_rot.json 2>&1 | tail -4 ;;
   abtail)    timeout 1200 python tools/ab_interleaved.py --what train --captures 3 --variant "two:GENNBV_TAIL_MERGE=0" --variant merged --rounds 8 --json $O/r05_ab_train_tail_merge.json 2>&1 | grep -v "^\[ab\]" | tail -12 ;;
