@@ -233,3 +233,27 @@ def test_train_g128_eight_samples_matches_fp64_oracle():
     diffs = torch.cat([(p.detach().double().cpu() - q.detach()).abs().reshape(-1)
                        for (_, p), (_, q) in zip(hip.policy.named_parameters(), ref.policy.named_parameters())])
     assert float(torch.quantile(diffs[::61].float(), 0.999)) <= 2e-4 and float(diffs.max()) <= LR * 4 * 1.05
+
+
+def test_train_g128_128_samples_matches_fp64_oracle():
+    """the 128^3 optimizer path at a real sample count -- 16 envs x 8 steps = 128 samples, four minibatches of 32 under
+    the hipGraph (fp32-MFMA conv kernels, int8 slab conv1, compact rows, analytic BN1 over 32-sample batches) against the fp64 CPU loop:
+    every logged scalar within 1e-4, BatchNorm running statistics 1e-5, parameters within the step size."""
+    rec = _Recorded(n_envs=16, t=8, hw=(60, 80), epochs=1, g=128, batch=32, frames=4)
+    assert rec.algo.policy.features_extractor.grid_size == 128
+    ref = rec.oracle(None)
+    hip = _fresh_hip(rec, None, True)
+    hip.train()
+    s_h, s_r = hip.last_train_stats, ref.last_train_stats
+    assert len(s_h) == len(s_r) == 4 and int(hip._hip["opt"].step_count.item()) == 4 and hip._hip["graph"] is not None
+    d = np.abs(s_h[:, :6] - s_r[:, :6]) / np.maximum(1.0, np.abs(s_r[:, :6]))
+    assert float(d.max()) <= 1e-4, d
+    sd_h, sd_r = hip.policy.state_dict(), ref.policy.state_dict()
+    for k, v in sd_r.items():
+        if "running" in k:
+            assert float((sd_h[k].double().cpu() - v).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), k
+    diffs = torch.cat([(p.detach().double().cpu() - q.detach()).abs().reshape(-1)
+                       for (_, p), (_, q) in zip(hip.policy.named_parameters(), ref.policy.named_parameters())])
+    assert float(torch.quantile(diffs[::61].float(), 0.999)) <= 2e-4 and float(diffs.max()) <= LR * 4 * 1.05
+    del rec, ref, hip
+    torch.cuda.empty_cache()
