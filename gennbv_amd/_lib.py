@@ -49,6 +49,7 @@ SIGNATURES = {
     "gnbv_env_pre_step": (_i, [_p, _p, _p, _i, _p, _p, _p]),
     "gnbv_env_obs_state": (_i, [_p, _p, _p, _p, _i, _i, _p, _i64, _p]),
     "gnbv_env_obs_rgb": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i64, _p]),
+    "gnbv_env_observe": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _i64, _p, _p, _i, _i, _i, _i, _p, _p]),
     "gnbv_env_post_step": (_i, [_p, _p]),
     "gnbv_rollout_add": (_i, [_i, _i, _p, _p, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnbv_input_autocorr_row_ints": (_i, []),

@@ -19,6 +19,16 @@
 // ---------------------------------------------------------------------------
 // pre-step: actions -> clipped actions, poses; episode_length_buf += 1
 // ---------------------------------------------------------------------------
+// action a of env e after step()'s clip and forced init action (env_train_gennbv.py:249-253), and the pose it means:
+// poses = action * action_unit + clip_pose_low (env_train_base.py:665-667): int64 -> fp32, two roundings
+__device__ __forceinline__ int64_t env_action(const int64_t *__restrict__ actions_in, const GnbvLattice &lat, bool fresh, int e, int a)
+{
+    int64_t v = actions_in[(size_t)e * 6 + a];
+    v = v < lat.clip_low[a] ? lat.clip_low[a] : (v > lat.clip_up[a] ? lat.clip_up[a] : v);
+    return fresh ? lat.init_action[a] : v;
+}
+__device__ __forceinline__ float env_pose(const GnbvLattice &lat, int64_t v, int a) { return __fadd_rn(__fmul_rn((float)v, lat.action_unit[a]), lat.pose_low[a]); }
+
 __global__ void k_env_pre_step(const int64_t *__restrict__ actions_in, GnbvLattice lat, int64_t *__restrict__ episode_length_buf,
                                int n, int64_t *__restrict__ actions_out, float *__restrict__ poses_out)
 {
@@ -27,12 +37,9 @@ __global__ void k_env_pre_step(const int64_t *__restrict__ actions_in, GnbvLatti
     const bool fresh = episode_length_buf[e] == 0;  // env_train_gennbv.py:249-253
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-        int64_t v = actions_in[(size_t)e * 6 + a];
-        v = v < lat.clip_low[a] ? lat.clip_low[a] : (v > lat.clip_up[a] ? lat.clip_up[a] : v);
-        if (fresh) v = lat.init_action[a];
+        const int64_t v = env_action(actions_in, lat, fresh, e, a);
         actions_out[(size_t)e * 6 + a] = v;
-        // poses = action * action_unit + clip_pose_low (env_train_base.py:665-667): int64 -> fp32, two roundings
-        poses_out[(size_t)e * 6 + a] = __fadd_rn(__fmul_rn((float)v, lat.action_unit[a]), lat.pose_low[a]);
+        poses_out[(size_t)e * 6 + a] = env_pose(lat, v, a);
     }
     episode_length_buf[e] += 1;  // post_physics_step :337
 }
@@ -77,13 +84,13 @@ __global__ __launch_bounds__(64) void k_env_obs_state(float *__restrict__ pose_h
 // observation, rgb slice: [older gray | newest gray]; newest = nearest-resized,
 // grayscaled RGBA (env_train_base.py:517-520, parity unpinned -- torchvision).
 // ---------------------------------------------------------------------------
-__global__ void k_env_obs_rgb(const uint8_t *__restrict__ rgba, float *__restrict__ gray_prev, const uint8_t *__restrict__ reset_mask,
-                              int n, int h, int w, int oh, int ow, float *__restrict__ obs_rgb, int64_t obs_row_stride)
+__device__ __forceinline__ void env_obs_rgb_body(const uint8_t *__restrict__ rgba, float *__restrict__ gray_prev, const uint8_t *__restrict__ reset_mask,
+                                                 int n, int h, int w, int oh, int ow, float *__restrict__ obs_rgb, int64_t obs_row_stride, int first, int stride)
 {
     const int per = oh * ow;
     const int total = n * per;
     const float sh = (float)h / (float)oh, sw = (float)w / (float)ow;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    for (int i = first; i < total; i += stride) {
         const int e = i / per, r = i - e * per, y = r / ow, x = r - y * ow;
         int sy = (int)floorf(__fmul_rn((float)y, sh)), sx = (int)floorf(__fmul_rn((float)x, sw));
         sy = min(sy, h - 1);
@@ -98,6 +105,61 @@ __global__ void k_env_obs_rgb(const uint8_t *__restrict__ rgba, float *__restric
         row[r] = reset ? 0.0f : gray_prev[i];
         row[per + r] = v;
         gray_prev[i] = v;
+    }
+}
+__global__ void k_env_obs_rgb(const uint8_t *__restrict__ rgba, float *__restrict__ gray_prev, const uint8_t *__restrict__ reset_mask,
+                              int n, int h, int w, int oh, int ow, float *__restrict__ obs_rgb, int64_t obs_row_stride)
+{
+    env_obs_rgb_body(rgba, gray_prev, reset_mask, n, h, w, oh, ow, obs_rgb, obs_row_stride, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// ---------------------------------------------------------------------------
+// pre-step + both observation slices as ONE launch (round 5: three dependent launches of 7-10 us each in front of every voxel update).
+// Blocks [0, n): env e -- lanes 0-5 clip / force the action and write it with its pose (lane 0 counts the step), every lane shifts the
+// pose history with the new pose computed in place (the same two roundings); blocks [n, n + rgb_blocks): the gray frames.
+// 256 threads per block: an env block uses its first 64.  Same arithmetic as the three kernels: bit-identical outputs.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_env_observe(const int64_t *__restrict__ actions_in, GnbvLattice lat, int64_t *__restrict__ episode_length_buf, int n,
+                                                    int64_t *__restrict__ actions_out, float *__restrict__ poses_out, float *__restrict__ pose_hist,
+                                                    const uint8_t *__restrict__ reset_mask, int stack, float *__restrict__ obs, int64_t obs_row_stride,
+                                                    const uint8_t *__restrict__ rgba, float *__restrict__ gray_prev, int h, int w, int oh, int ow,
+                                                    float *__restrict__ obs_rgb, int rgb_blocks)
+{
+    if ((int)blockIdx.x >= n) {
+        env_obs_rgb_body(rgba, gray_prev, reset_mask, n, h, w, oh, ow, obs_rgb, obs_row_stride, ((int)blockIdx.x - n) * 256 + (int)threadIdx.x, rgb_blocks * 256);
+        return;
+    }
+    if (threadIdx.x >= 64) return;
+    const int e = blockIdx.x;
+    const bool fresh = episode_length_buf[e] == 0;  // (read by every lane BEFORE lane 0 counts the step: same wave, program order)
+    const int len = stack * 6;
+    float *hist = pose_hist + (size_t)e * len;
+    float *out = obs + (size_t)e * obs_row_stride;
+    const bool reset = reset_mask != nullptr && reset_mask[e] != 0;
+    constexpr int kMaxPerLane = 16;  // stack <= 170
+    float reg[kMaxPerLane];
+#pragma unroll
+    for (int k = 0; k < kMaxPerLane; ++k) {
+        const int i = threadIdx.x + k * 64;
+        if (i < len) {
+            const int src = i + 6;
+            reg[k] = src < len ? (reset ? lat.init_pose[src % 6] : hist[src]) : env_pose(lat, env_action(actions_in, lat, fresh, e, src - len), src - len);
+        }
+    }
+    if (threadIdx.x < 6) {
+        const int64_t v = env_action(actions_in, lat, fresh, e, threadIdx.x);
+        actions_out[(size_t)e * 6 + threadIdx.x] = v;
+        poses_out[(size_t)e * 6 + threadIdx.x] = env_pose(lat, v, threadIdx.x);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (threadIdx.x == 0) episode_length_buf[e] += 1;  // post_physics_step :337
+#pragma unroll
+    for (int k = 0; k < kMaxPerLane; ++k) {
+        const int i = threadIdx.x + k * 64;
+        if (i < len) {
+            hist[i] = reg[k];
+            out[i] = reg[k];
+        }
     }
 }
 
@@ -247,6 +309,20 @@ GNBV_API int gnbv_env_obs_rgb(const uint8_t *rgba, float *gray_prev, const uint8
     grid = grid > 2048 ? 2048 : grid;
     hipLaunchKernelGGL(k_env_obs_rgb, dim3(grid), dim3(256), 0, gnbv_stream(stream), rgba, gray_prev, reset_mask, n, h, w, oh, ow,
                        obs_rgb, obs_row_stride);
+    return gnbv_launch_status();
+}
+
+GNBV_API int gnbv_env_observe(const int64_t *actions_in, const GnbvLattice *lattice, int64_t *episode_length_buf, int n, int64_t *actions_out,
+                              float *poses_out, float *pose_hist, const uint8_t *reset_mask, int stack, float *obs, int64_t obs_row_stride,
+                              const uint8_t *rgba, float *gray_prev, int h, int w, int oh, int ow, float *obs_rgb, void *stream)
+{
+    GNBV_CHECK_ARG(actions_in && lattice && episode_length_buf && actions_out && poses_out && n > 0);
+    GNBV_CHECK_ARG(pose_hist && obs && stack > 0 && stack * 6 <= 16 * 64 && obs_row_stride >= (int64_t)stack * 6);
+    GNBV_CHECK_ARG(rgba && gray_prev && obs_rgb && h > 0 && w > 0 && oh > 0 && ow > 0 && obs_row_stride >= (int64_t)2 * oh * ow);
+    int rgb_blocks = (n * oh * ow + 255) / 256;
+    rgb_blocks = rgb_blocks > 2048 ? 2048 : rgb_blocks;
+    hipLaunchKernelGGL(k_env_observe, dim3(n + rgb_blocks), dim3(256), 0, gnbv_stream(stream), actions_in, *lattice, episode_length_buf, n, actions_out,
+                       poses_out, pose_hist, reset_mask, stack, obs, obs_row_stride, rgba, gray_prev, h, w, oh, ow, obs_rgb, rgb_blocks);
     return gnbv_launch_status();
 }
 

@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import collections
 import ctypes as C
+import os
 import weakref
 from dataclasses import dataclass
 from typing import Optional
@@ -140,6 +141,7 @@ class ReplayFeedEnv:
         # step that produced it (the time-out bootstrap) and is STATEFUL on the device (the reference only refreshes it on steps with a
         # reset): one buffer, and a reader that keeps infos["time_outs"] across env steps must copy it.
         self.flag_views = False
+        self.fused_observe = os.environ.get("GENNBV_FUSED_OBSERVE", "1") != "0"  # pre-step + both observation slices as one launch; =0: A/B runs / tests
         self._reset_bufs = (self.reset_buf, z(n, dt=torch.uint8))
         self._reset_turn = 0
         self.reset_mask = torch.ones(n, dtype=torch.uint8, device=dev)
@@ -217,23 +219,20 @@ class ReplayFeedEnv:
         depth_raw, seg_raw, rgba, c2w = self.feed.next()
         # step(): clip, forced init action, poses; episode_length_buf += 1
         self._post.episode_length_buf = self.episode_length_buf.data_ptr()  # the algorithm may have replaced the tensor
-        _lib.check(lib.gnbv_env_pre_step(actions_in.data_ptr(), C.byref(self._lat), self.episode_length_buf.data_ptr(), n,
-                                         self.actions.data_ptr(), self.poses.data_ptr(), st), "gnbv_env_pre_step")
-        # (Round 5 ran the two small observation kernels below on a second stream beside the voxel update, joined in front of the
-        # post-step kernel: the env step +1.9 ... +5.4 us, the voxel update +4.9 us -- they take slots from k_hit_list's single round of
-        # workgroups.  profiles/r05_ab_rollout_obs_overlap.json)
-        # obs["state"]
-        _lib.check(lib.gnbv_env_obs_state(self.pose_hist.data_ptr(), self.poses.data_ptr(), self.reset_mask.data_ptr(),
-                                          C.byref(self._lat), n, cfg.stack, obs.data_ptr(), stride, st), "gnbv_env_obs_state")
-        # obs["state_rgb"]
+        rgb_off = cfg.state_dim + (0 if compact else cfg.grid_dim)
         if rgba is None:
             if self._zero_rgba is None:
                 self._zero_rgba = torch.zeros(n, cfg.camera_height, cfg.camera_width, 4, dtype=torch.uint8, device=self.device)
             rgba = self._zero_rgba
-        rgb_off = cfg.state_dim + (0 if compact else cfg.grid_dim)
-        _lib.check(lib.gnbv_env_obs_rgb(rgba.data_ptr(), self.gray_prev.data_ptr(), self.reset_mask.data_ptr(), n,
-                                        cfg.camera_height, cfg.camera_width, cfg.rgb_h, cfg.rgb_w,
-                                        obs.data_ptr() + 4 * rgb_off, stride, st), "gnbv_env_obs_rgb")
+        fused_observe = self.fused_observe and getattr(lib, "gnbv_env_observe", None) is not None
+        if fused_observe:
+            # round 5: the three launches below as one (same arithmetic, bit-identical: tests/test_envstep_gpu.py)
+            _lib.check(lib.gnbv_env_observe(actions_in.data_ptr(), C.byref(self._lat), self.episode_length_buf.data_ptr(), n, self.actions.data_ptr(),
+                                            self.poses.data_ptr(), self.pose_hist.data_ptr(), self.reset_mask.data_ptr(), cfg.stack, obs.data_ptr(), stride,
+                                            rgba.data_ptr(), self.gray_prev.data_ptr(), cfg.camera_height, cfg.camera_width, cfg.rgb_h, cfg.rgb_w,
+                                            obs.data_ptr() + 4 * rgb_off, st), "gnbv_env_observe")
+        else:
+            self._observe_three_launches(actions_in, obs, stride, rgba, rgb_off, st)
         # obs["grid"]: tri-class grid straight into the observation rows
         if compact:
             self.updater.update(depth_raw, seg_raw, c2w, self.poses, reset_mask=self.reset_mask, tri_i8_out=grid_i8_out, fp32_out=False)
@@ -246,6 +245,22 @@ class ReplayFeedEnv:
         self._post.episode_info = self.episode_info_hist[self._ep_step % self._ep_hist].data_ptr()
         _lib.check(lib.gnbv_env_post_step(C.byref(self._post), st), "gnbv_env_post_step")
         return obs
+
+    def _observe_three_launches(self, actions_in, obs, stride, rgba, rgb_off, st):
+        """step()'s head and the two small observation slices as the three separate launches (`fused_observe = False`)."""
+        cfg, n, lib = self.cfg, self.num_envs, self.lib
+        _lib.check(lib.gnbv_env_pre_step(actions_in.data_ptr(), C.byref(self._lat), self.episode_length_buf.data_ptr(), n,
+                                         self.actions.data_ptr(), self.poses.data_ptr(), st), "gnbv_env_pre_step")
+        # (Round 5 ran the two small observation kernels below on a second stream beside the voxel update, joined in front of the
+        # post-step kernel: the env step +1.9 ... +5.4 us, the voxel update +4.9 us -- they take slots from k_hit_list's single round of
+        # workgroups.  profiles/r05_ab_rollout_obs_overlap.json)
+        # obs["state"]
+        _lib.check(lib.gnbv_env_obs_state(self.pose_hist.data_ptr(), self.poses.data_ptr(), self.reset_mask.data_ptr(),
+                                          C.byref(self._lat), n, cfg.stack, obs.data_ptr(), stride, st), "gnbv_env_obs_state")
+        # obs["state_rgb"]
+        _lib.check(lib.gnbv_env_obs_rgb(rgba.data_ptr(), self.gray_prev.data_ptr(), self.reset_mask.data_ptr(), n,
+                                        cfg.camera_height, cfg.camera_width, cfg.rgb_h, cfg.rgb_w,
+                                        obs.data_ptr() + 4 * rgb_off, stride, st), "gnbv_env_obs_rgb")
 
     @property
     def supports_grid_i8(self) -> bool:

@@ -177,6 +177,13 @@ int gnbv_env_obs_state(float *pose_hist, const float *poses, const uint8_t *rese
 int gnbv_env_obs_rgb(const uint8_t *rgba, float *gray_prev, const uint8_t *reset_mask, int n, int h, int w, int oh, int ow,
                      float *obs_rgb, int64_t obs_row_stride, void *stream);
 
+/* The three calls above as ONE launch (round 5; a new entry point of ABI 5, no layout changes): same arguments, same arithmetic, bit-identical outputs -- what a reference-side integration
+ * would issue between `step(actions)` and `update_occ_grid` (env_train_gennbv.py:246-275).  obs_rgb = the row's state_rgb slice (same
+ * row stride as obs). */
+int gnbv_env_observe(const int64_t *actions_in, const GnbvLattice *lattice /*[host]*/, int64_t *episode_length_buf, int n, int64_t *actions_out,
+                     float *poses_out, float *pose_hist, const uint8_t *reset_mask, int stack, float *obs, int64_t obs_row_stride,
+                     const uint8_t *rgba, float *gray_prev, int h, int w, int oh, int ow, float *obs_rgb, void *stream);
+
 /* compute_reward (env_train_base.py:377-398), _reward_* / check_termination /
  * reset_idx (env_train_gennbv.py:377-457,535-556), update_extra_episode_info
  * (env_train_base.py:629-639). All pointers device, arrays [N] unless noted. [host struct] */

@@ -33,13 +33,18 @@ def make_env_from_fixture(fx):
     return env, cfg
 
 
-@pytest.mark.parametrize("views", [False, True])  # True: ReplayFeedEnv.flag_views -- dones / time_outs as views of the kernels' bytes (collect_rollouts)
-@pytest.mark.parametrize("name", ["F5_envstep_g20", "F5_envstep_c0", "F5_envstep_g64"])
+@pytest.mark.parametrize("views", [False, True, "three launches"])  # True: ReplayFeedEnv.flag_views -- dones / time_outs as views of the kernels' bytes
+@pytest.mark.parametrize("name", ["F5_envstep_g20", "F5_envstep_c0", "F5_envstep_g64"])                # (collect_rollouts); "three launches": fused_observe off
 def test_replay_env_matches_reference_env_bit_exact(name, views):
     if not os.path.exists(os.path.join(gu.GOLDEN, name + ".npz")):
         pytest.skip("fixture not generated")
     fx = gu.load(name)
     env, cfg = make_env_from_fixture(fx)
+    # default: step()'s head + the pose-history and gray-frame slices as ONE launch (gnbv_env_observe, round 5); the three separate
+    # launches must give the same bytes
+    assert env.fused_observe
+    if views == "three launches":
+        env.fused_observe, views = False, False
     env.flag_views = views
     prev_done = None
     nf = int(fx["num_frames"])
