@@ -18,7 +18,7 @@ case $st in
   abvoxrot)  timeout 300 python tools/ab_interleaved.py --what voxel --variant base --variant "rot:LIB=gennbv_amd/libgennbv_hip_rot.so" --variant base2 --rounds 20 --json $O/r05_ab_voxel_chunk_rot.json 2>&1 | tail -4 ;;
   abrollrot) timeout 600 python tools/ab_interleaved.py --what rollout --n-steps 32 --variant base --variant "rot:LIB=gennbv_amd/libgennbv_hip_rot.so" --variant base2 --rounds 6 --json $O/r05_ab_rollout_chunk_rot.json 2>&1 | tail -4 ;;
   abtail)    timeout 1200 python tools/ab_interleaved.py --what train --captures 3 --variant "two:GENNBV_TAIL_MERGE=0" --variant merged --rounds 8 --json $O/r05_ab_train_tail_merge.json 2>&1 | grep -v "^\[ab\]" | tail -12 ;;
-  abside)    timeout 1500 python tools/ab_interleaved.py --what train --captures 3 --variant base --variant "side:GENNBV_WGRAD_FINISH_SIDE=1" --rounds 8 --json $O/r05_ab_train_wgrad_finish_side.json 2>&1 | grep -v "^\[ab\]" | tail -12 ;;
+  abside)    GENNBV_WGRAD_FINISH_SIDE=1 timeout 900 python -m pytest tests/test_ppo_g64_gpu.py -x -q -m gpu 2>&1 | tail -3; timeout 1500 python tools/ab_interleaved.py --what train --captures 3 --variant base --variant "side:GENNBV_WGRAD_FINISH_SIDE=1" --rounds 8 --json $O/r05_ab_train_wgrad_finish_second_branch.json 2>&1 | grep -v "^\[ab\]" | tail -12 ;;
   abtrain)   timeout 1500 python tools/ab_interleaved.py --what train --captures 3 --variant "old:LIB=$OLD" --variant new --rounds 8 --json $O/r05_ab_train.json 2>&1 | grep -v "^\[ab\]" | tail -12 ;;
   abvoxel)   timeout 600 python tools/ab_interleaved.py --what voxel --variant "old:LIB=$OLD" --variant new --variant "old2:LIB=$OLD" --rounds 20 --json $O/r05_ab_voxel.json 2>&1 | tail -5 ;;
   abrollout) timeout 900 python tools/ab_interleaved.py --what rollout --n-steps 32 --variant "old:LIB=$OLD" --variant new --variant "old2:LIB=$OLD" --rounds 8 --json $O/r05_ab_rollout.json 2>&1 | tail -5 ;;
