@@ -413,8 +413,9 @@ def _wide_dw(g: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor]) -> t
 _deferred_wgrad = []
 
 
-def join_async_wgrads(device) -> None:
-    """Launch the deferred weight-gradient GEMMs (`_async_wgrad`) on the second stream and make the current stream wait for them."""
+def join_async_wgrads(device, join: bool = True) -> None:
+    """Launch the deferred weight-gradient GEMMs (`_async_wgrad`) on the second stream and make the current stream wait for them
+    (`join=False`: the caller orders its consumers behind `second_stream(device)` itself -- the data-parallel step's exchange)."""
     if not _deferred_wgrad:
         return
     cur = torch.cuda.current_stream(device)
@@ -426,7 +427,8 @@ def join_async_wgrads(device) -> None:
             launch()
         for t in keep:
             t.record_stream(side)
-    cur.wait_stream(side)
+    if join:
+        cur.wait_stream(side)
 
 
 def linear_relu(x: torch.Tensor, lin: torch.nn.Linear, fold=None) -> torch.Tensor:
@@ -561,9 +563,14 @@ def hybrid_branches(enc, observations):
     return feature_action, feature_grid
 
 
-def pose_branch_backward(enc, device) -> None:
+def second_stream(device):
+    """The stream the pose branch and the deferred weight-gradient GEMMs run on."""
+    return _side_stream(device, 0)
+
+
+def pose_branch_backward(enc, device, join: bool = True) -> None:
     """Second half of the `_defer_pose_backward` protocol (see hybrid_branches): the pose branch's backward on the second
-    stream, joined into the current stream."""
+    stream, joined into the current stream (unless `join=False`, see join_async_wgrads)."""
     pending = getattr(enc, "_pose_deferred", None)
     if pending is None:
         return
@@ -573,9 +580,14 @@ def pose_branch_backward(enc, device) -> None:
         return
     side, cur = _side_stream(device), torch.cuda.current_stream(device)
     side.wait_event(evt)
+    # (the gradient was allocated on the current stream and is dropped when this function returns: without the join below the caching
+    # allocator would hand its block to the next allocation on the current stream while the second stream still reads it -- seen as wrong
+    # updates in the replayed data-parallel graph, where no host time hides the race)
+    leaf.grad.record_stream(side)
     with torch.cuda.stream(side):
         torch.autograd.backward([out], [leaf.grad])
-    cur.wait_stream(side)
+    if join:
+        cur.wait_stream(side)
 
 
 class _PolicyHeadFn(torch.autograd.Function):

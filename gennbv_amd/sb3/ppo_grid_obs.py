@@ -93,6 +93,10 @@ class PPO_Grid_Obs:
         self.grad_write_through = True  # backward kernels store into the flat gradient buffer (ops/direct_grad.py)
         self.rotate_rows = True   # replayed graph on one GPU: the Adam launch leaves the next minibatch's row numbers behind (no host copy)
         self.grid_i8_rows = True  # int8 side copy of the grid rows next to flat fp32 rows (what the conv1 kernels of the update read)
+        # data-parallel step: phase A's second-stream work (pose branch backward, fc_grid dW) is joined by the gradient exchange, not by the
+        # conv backward (GENNBV_DP_LATE_ASIDE=0: the round-4 order, for A/B runs)
+        self.dp_late_grads_aside = os.environ.get("GENNBV_DP_LATE_ASIDE", "1") != "0"
+        self.dp_rotate_rows = os.environ.get("GENNBV_DP_ROTATE", "1") != "0"  # (the rotation table also in the data-parallel hipGraph)
         self.fused_add = True     # time-out bootstrap + the five buffer copies of rollout_buffer.add as one launch (gnbv_rollout_add)
         self.rollout_plan = True  # collect_rollouts evaluates the policy through ops/rollout_plan.py (same kernels, step-invariant work hoisted)
         self.compact_obs = bool(compact_obs)
@@ -356,8 +360,10 @@ class PPO_Grid_Obs:
                 raise ValueError("data-parallel training runs on the fused gfx950 path: it needs the int8 grid rows with their "
                                  "autocorrelation rows (an env with supports_grid_i8, G % 16 == 0; e.g. compact_obs=True)")
             cb, sync_buf = self._sync.encoder_sync(self.device)
-            self._hip["adv_cur"] = torch.zeros(2, dtype=torch.float32, device=self.device)
-            self._hip["ac_cur"] = torch.zeros(768, dtype=torch.int32, device=self.device)
+            # (round 5: the two slots ARE the tail of the loss op's row buffer -- [rows | advantage statistics | autocorrelation total] --, so
+            # that the rotation table of the replayed graph can deal them out with the row numbers; eager steps copy into them as before)
+            self._hip["adv_cur"] = loss.adv_slot
+            self._hip["ac_cur"] = loss.ac_slot
             loss.args.adv_norm = self._hip["adv_cur"].data_ptr()
             self.policy.features_extractor._dp_sync = {"world": self._sync.world, "cb": cb, "sync_buf": sync_buf,
                                                        "autocorr_global": self._hip["ac_cur"]}
@@ -378,11 +384,11 @@ class PPO_Grid_Obs:
         self._hip["fused_head"] = (getattr(enc, "backend", "") == "hip"
                                    and isinstance(self.policy.mlp_extractor, _IdentityExtractor)
                                    and encoder_ops.policy_head_supported(enc, self.policy.action_net, self.policy.value_net))
-        # fc_grid's weight gradient on a second stream (only the optimizer needs it; joined in _hip_minibatch_body).  Only
-        # without data parallelism: there phase A ends right behind it and the all-reduce needs it at once.
+        # fc_grid's weight gradient on a second stream (only the optimizer needs it; joined in _hip_minibatch_body).  Data-parallel
+        # (round 5, `dp_late_grads_aside`): the exchange of the late gradients is what waits for that stream, not the conv backward.
         if getattr(enc, "backend", "") == "hip":
             enc.output_layer_grid[0]._async_wgrad = (bool(self.grad_write_through) and getattr(self, "async_wgrad", True)
-                                                     and (self._sync is None or not self._sync.active))
+                                                     and (self._sync is None or not self._sync.active or self.dp_late_grads_aside))
         self._hip["skip_zero"] = bool(self.grad_write_through) and all(
             id(p) in covered for p in self.policy.parameters() if p.requires_grad)
         # fc_grid's weight gradient (94 % of all parameters) leaves its GEMM with sum(dW^2) as fp64 partial sums: the clip's norm
@@ -448,8 +454,11 @@ class PPO_Grid_Obs:
             torch.autograd.backward([logits, values], [d_logits, d_values])
             if lin is not None:
                 lin._defer_wgrad = False
-            encoder_ops.pose_branch_backward(enc, self.device)
-            encoder_ops.join_async_wgrads(self.device)
+            # (round 5) the pose branch's backward and fc_grid's weight gradient stay on the second stream WITHOUT a join: only the exchange
+            # of the late gradients needs them (_dp_step_body orders it behind that stream), phase B needs the data gradient alone
+            join = not self.dp_late_grads_aside
+            encoder_ops.pose_branch_backward(enc, self.device, join=join)
+            encoder_ops.join_async_wgrads(self.device, join=join)
         else:  # phase "B": conv-stack backward from d loss / d (conv-stack output)
             enc = pol.features_extractor
             torch.autograd.backward([enc._grid_feats_out], [enc._grid_feats_leaf.grad])
@@ -457,7 +466,8 @@ class PPO_Grid_Obs:
     def _hip_minibatch_tail(self, st):
         """data-parallel tail: global KL decision + clip + Adam on the summed gradient."""
         loss, opt = st["loss"], st["opt"]
-        opt.step(self.max_grad_norm, loss.stop_flag, grad_scale=1.0 / self._sync.world, kl_slot_target=loss.args.target_kl)
+        opt.step(self.max_grad_norm, loss.stop_flag, grad_scale=1.0 / self._sync.world, kl_slot_target=loss.args.target_kl,
+                 rotate=st.get("rows_rot"))
 
     def _dp_step_body(self, st):
         """[phase A] -> exchange of the late gradients overlapped with [phase B] -> all-reduce(KL slot + conv grads) -> clip/Adam
@@ -475,8 +485,18 @@ class PPO_Grid_Obs:
         n_conv = st["n_conv"]
         sh = getattr(opt, "shard", None)
         self._hip_minibatch_body(st, "A")
+        # the exchange of the late gradients is issued behind the SECOND stream (pose branch backward, fc_grid's weight gradient) and behind
+        # what phase A left on this one (heads, fc_grid's bias): the conv backward below starts as soon as its data gradient exists
+        from contextlib import nullcontext
+        late = nullcontext()
+        if self.dp_late_grads_aside and self.device.type == "cuda":
+            from ..ops import encoder_ops
+            side = encoder_ops.second_stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            late = torch.cuda.stream(side)
         if sh is None:
-            work = dist.all_reduce(opt.grads_with_slot[opt.SLOT + n_conv:], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
+            with late:
+                work = dist.all_reduce(opt.grads_with_slot[opt.SLOT + n_conv:], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
             self._hip_minibatch_body(st, "B")
             dist.all_reduce(opt.grads_with_slot[:opt.SLOT + n_conv], op=dist.ReduceOp.SUM, group=self._sync.group)
             work.wait()
@@ -484,16 +504,19 @@ class PPO_Grid_Obs:
             return
         lo, hi, loss = sh["lo"], sh["hi"], st["loss"]
         assert lo == n_conv, "the sharded slice is the first of the late gradients (parameter order: conv stack, fc_grid.weight, ...)"
-        w_rs = dist.reduce_scatter_tensor(sh["grad"], opt.grads[lo:hi], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
-        w_ar = dist.all_reduce(opt.grads[hi:], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
+        with late:
+            w_rs = dist.reduce_scatter_tensor(sh["grad"], opt.grads[lo:hi], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
+            w_ar = dist.all_reduce(opt.grads[hi:], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
         self._hip_minibatch_body(st, "B")
         dist.all_reduce(opt.grads_with_slot[:opt.SLOT + n_conv], op=dist.ReduceOp.SUM, group=self._sync.group)
         w_rs.wait()
+        # (the shard's square sum and its 2 KB all-reduce behind the reduce-scatter on the second stream, beside the conv backward, would take one
+        # launch and one collective's latency off this tail: the one-rank RCCL capture of that order died inside librccl -- round 5, not pursued)
         opt.shard_sq()  # (one launch: 256 fp64 partial sums of the shard's squares; three torch kernels and 2 x 110 MB of fp64 temporaries before)
         dist.all_reduce(sh["sq"], op=dist.ReduceOp.SUM, group=self._sync.group)
         w_ar.wait()
         opt.step(self.max_grad_norm, loss.stop_flag, grad_scale=1.0 / self._sync.world, kl_slot_target=loss.args.target_kl,
-                 sq_slice=(lo, hi, sh["sq"]), skip_update=True)
+                 sq_slice=(lo, hi, sh["sq"]), skip_update=True, rotate=st.get("rows_rot"))
         opt.shard_step(loss.stop_flag)
         p_shard, _, _ = opt.shard_views()
         dist.all_gather_into_tensor(opt.params[lo:hi], p_shard, group=self._sync.group)
@@ -628,7 +651,10 @@ class PPO_Grid_Obs:
         # Replayed graph on one GPU: the row numbers of ALL minibatches of this call go to a table once, and the Adam launch that ends
         # a minibatch leaves the next one's in `loss.rows` (gnbv_clip_adam_step_rotate) -- no copy and no host work between two
         # replays.  (The table and the counter are baked into the graph: persistent buffers.)
-        c.rotating = c.use_graph and not c.dp and c.n_mb > 0 and self.rotate_rows
+        # Data-parallel (round 5): the same table when the step is one hipGraph (RCCL) -- its statistics columns then hold the GLOBAL
+        # minibatches' figures computed above; with eager collectives (gloo) the three slots are copied between two steps as before.
+        c.rotating = (c.use_graph and c.n_mb > 0 and self.rotate_rows
+                      and (not c.dp or (self.dp_rotate_rows and self._collectives_capturable())))
         c.rot = st.get("rows_rot")
         if c.rotating and (c.rot is None or tuple(c.rot[0].shape) != (c.n_mb, c.batch + 1 + 384)):
             # a table row = [the minibatch's row numbers | (mean, 1 / (std + 1e-8)) of its advantages | the sum of its input-autocorrelation
@@ -638,7 +664,7 @@ class PPO_Grid_Obs:
         elif not c.rotating and c.rot is not None:
             c.rot = st["rows_rot"] = None
             st["graph"] = None
-        if not c.dp:
+        if not c.dp_stats:  # (several ranks: always the slot, filled from the global table -- _hip_setup)
             c.loss.args.adv_norm = c.loss.adv_slot.data_ptr() if (c.rotating and self.normalize_advantage) else None
         if not c.rotating:
             self.policy.features_extractor._autocorr_total = None
@@ -646,7 +672,10 @@ class PPO_Grid_Obs:
                 st["graph"], st["ac_total_on"] = None, False
         if c.rotating:
             c.rot[0][:, :c.batch].copy_(c.rows_all[:c.n_mb * c.batch].view(c.n_mb, c.batch))
-            if self.normalize_advantage:
+            if c.dp_stats:
+                c.rot[0][:, c.batch:c.batch + 1].view(torch.float32).copy_(c.adv_tab)
+                c.rot[0][:, c.batch + 1:].view(torch.int32).copy_(c.ac_tab)
+            elif self.normalize_advantage:
                 # The advantages and the permutation are fixed for the whole train() call: every minibatch's statistics
                 # (ppo_grid_obs.py:214-216: mean, unbiased std) once, instead of two dependent gather passes in every wave of every
                 # loss launch
@@ -656,7 +685,7 @@ class PPO_Grid_Obs:
             # BatchNorm-1's batch statistics come from the SUM of the minibatch's autocorrelation rows: one table per train() call
             # instead of a gather of 128 scattered rows in front of every forward (k_bn1_analytic)
             enc_ = self.policy.features_extractor
-            use_tot = c.buf.autocorr is not None and not c.dp
+            use_tot = c.buf.autocorr is not None and not c.dp_stats  # (several ranks: GnbvEncoderParams.autocorr_global = the same slot)
             if use_tot:
                 ac_rows = c.buf.autocorr[:c.buf.buffer_size].view(c.buf.buffer_size * c.buf.n_envs, -1)
                 tot = ac_rows[c.rows_all[:c.n_mb * c.batch]].view(c.n_mb, c.batch, -1).sum(1, dtype=torch.int64)
@@ -689,7 +718,7 @@ class PPO_Grid_Obs:
                 for k in range(c.n_mb):
                     if not c.rotating:
                         c.loss.rows.copy_(c.rows_all[k * c.batch:(k + 1) * c.batch])
-                    if c.dp_stats:
+                    if c.dp_stats and not c.rotating:
                         st["adv_cur"].copy_(c.adv_tab[k])
                         st["ac_cur"].copy_(c.ac_tab[k])
                     if c.dp:

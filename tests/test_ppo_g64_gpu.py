@@ -176,6 +176,33 @@ def test_train_g64_b128_matches_fp64_oracle(rec, oracle_full, graph):
     _compare(hip, oracle_full, EPOCHS * n_mb)
 
 
+@pytest.mark.parametrize("shard", [False, True])
+def test_train_g64_b128_one_rank_rccl_step_matches_fp64_oracle(rec, oracle_full, shard, monkeypatch):
+    """The data-parallel step of `bench.py --gpus N` (PPO_Grid_Obs._dp_step_body) at the timed size, as ONE hipGraph with a one-rank RCCL
+    communicator: phase A -> exchange of the late gradients issued behind the second stream -> conv backward -> all-reduce(KL slot + conv
+    gradients) -> clip / Adam with the rotation table (sharded: reduce-scatter -> owner's Adam -> all-gather) -- 20 optimizer steps against
+    the fp64 loop, same bounds as the plain step.  (Round 5: the first version of that order raced in the REPLAYED graph only -- the pose
+    branch's upstream gradient was freed on the main stream while the second stream still read it; fixture F9 caught it, tools/dp_probe.py.)"""
+    import os
+    import torch.distributed as dist
+    from gennbv_amd import parallel
+    monkeypatch.setenv("GENNBV_FORCE_SHARD", "1" if shard else "0")
+    if not dist.is_initialized():
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", RANK="0", WORLD_SIZE="1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    n_mb = N_ENVS * T // BATCH
+    hip = _fresh_hip(rec, None, True)
+    try:
+        parallel.attach(hip, 1, always_sync=True)
+        hip.train()
+        assert hip.dp_graph_mode == "one hipGraph incl. RCCL collectives" and hip._hip.get("rows_rot") is not None
+        assert (getattr(hip._hip["opt"], "shard", None) is not None) == shard
+        _compare(hip, oracle_full, EPOCHS * n_mb)
+    finally:
+        hip._sync, hip._hip = None, None
+
+
 def test_train_g64_b128_early_stop_position(rec, oracle_full):
     """target_kl chosen between two consecutive running maxima of the oracle's KL trace: both sides must stop at the
     same minibatch (ppo_grid_obs.py:261-268: the step that trips the test is evaluated but not applied)."""

@@ -172,14 +172,21 @@ def test_flat_adam_matches_torch_adam_with_clipping():
         torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("name,shard", [("F9_ppo_train", False), ("F9_ppo_train_earlystop", False), ("F9_ppo_train", True), ("F9_ppo_train_earlystop", True)])
-def test_data_parallel_code_path_on_one_gpu(name, shard, monkeypatch):
+@pytest.mark.parametrize("name,shard,order", [("F9_ppo_train", False, "r5"), ("F9_ppo_train_earlystop", False, "r5"), ("F9_ppo_train", True, "r5"),
+                                              ("F9_ppo_train_earlystop", True, "r5"), ("F9_ppo_train_earlystop", True, "r4")])
+def test_data_parallel_code_path_on_one_gpu(name, shard, order, monkeypatch):
     """The multi-GPU branch (graph body -> RCCL all-reduce of the flat gradient + KL slot -> clip/Adam
     tail with the global KL decision) with a one-rank NCCL communicator must reproduce the goldens.
     shard: the sharded update of fc_grid.weight (reduce-scatter -> owner's Adam -> all-gather, GENNBV_FORCE_SHARD=1 makes the one
-    rank its only owner) -- the RCCL reduce_scatter / all_gather calls captured in the minibatch hipGraph."""
+    rank its only owner) -- the RCCL reduce_scatter / all_gather calls captured in the minibatch hipGraph.
+    order "r5" (default): the exchange of the late gradients is issued behind the second stream (the conv backward does not wait for the
+    pose branch / fc_grid dW), and the Adam launch deals out the next minibatch's rows and statistics (rotation table) inside the
+    graph; "r4": both off (GENNBV_DP_LATE_ASIDE=0, GENNBV_DP_ROTATE=0) -- phase A joined before the exchange, three host copies per step."""
     import os
     monkeypatch.setenv("GENNBV_FORCE_SHARD", "1" if shard else "0")
+    if order == "r4":
+        monkeypatch.setenv("GENNBV_DP_LATE_ASIDE", "0")
+        monkeypatch.setenv("GENNBV_DP_ROTATE", "0")
     import torch.distributed as dist
     from gennbv_amd import parallel
     if not dist.is_initialized():
@@ -193,6 +200,8 @@ def test_data_parallel_code_path_on_one_gpu(name, shard, monkeypatch):
     assert (getattr(ppo._hip["opt"], "shard", None) is not None) == shard
     if shard:
         assert ppo.dp_graph_mode == "one hipGraph incl. RCCL collectives", ppo.dp_graph_mode
+    assert ppo.dp_late_grads_aside == (order == "r5")
+    assert (ppo._hip.get("rows_rot") is not None) == (order == "r5" and ppo._hip.get("graph") is not None)
 
 
 @pytest.mark.parametrize("dims", [(81, 81, 51, 1, 13, 13), (7, 5, 3, 1, 4, 2), (200, 1, 65)])  # the reference's action lattice first (81-way heads > one wave)

@@ -1,0 +1,36 @@
+"""GPU probe (round 5): the one-rank RCCL data-parallel step on fixture F9 under the switches of _dp_step_body
+(use_graph x dp_late_grads_aside x dp_rotate_rows x shard): max |logged scalar - fixture| per combination."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.distributed as dist
+
+from tests import golden_util as gu
+from tests.test_policy_ppo_cpu import _ppo_from_fixture
+from gennbv_amd import parallel
+
+DEV = "cuda:0"
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", RANK="0", WORLD_SIZE="1")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+fx = gu.load("F9_ppo_train")
+KEYS = ("train/entropy_loss", "train/policy_gradient_loss", "train/value_loss", "train/approx_kl", "train/loss")
+for shard in (0, 1):
+    os.environ["GENNBV_FORCE_SHARD"] = str(shard)
+    for graph in (True, False):
+        for late in (False, True):
+            for rot in (False, True):
+                ppo = _ppo_from_fixture(fx, device=DEV, backend="hip")
+                ppo.use_graph, ppo.dp_late_grads_aside, ppo.dp_rotate_rows = graph, late, rot
+                parallel.attach(ppo, 1, always_sync=True)
+                ppo.train()
+                torch.cuda.synchronize()
+                log = ppo.logger.name_to_value
+                err = max(abs(float(log[k]) - float(fx["log/" + k])) / max(1.0, abs(float(fx["log/" + k]))) for k in KEYS)
+                print(f"shard={shard} graph={int(graph)} late={int(late)} rotate={int(rot)}  max rel err {err:.2e}  {'ok' if err <= 1e-4 else 'WRONG'}"
+                      f"   graph object: {ppo._hip.get('graph') is not None}", flush=True)
+                del ppo
+dist.destroy_process_group()

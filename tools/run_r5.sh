@@ -10,6 +10,12 @@ case $st in
   tests_sel) timeout 1200 python -m pytest tests/test_rollout_gpu.py tests/test_fullsize_gpu.py tests/test_ppo_gpu.py tests/test_ppo_g64_gpu.py tests/test_encoder_gpu.py tests/test_rsl_rl_gpu.py -m gpu -q --maxfail=6 --durations=6 -p no:cacheprovider > $O/r5_tests_sel.log 2>&1; tail -25 $O/r5_tests_sel.log ;;
   bench)     timeout 900 python bench.py --steps 5 --warmup 2 2>$O/r5_bench.err | tail -1 > $O/r5_bench_n1.json; cut -c1-600 $O/r5_bench_n1.json ;;
   benchdrv)  timeout 1200 python bench.py --steps 20 --warmup 5 2>$O/r5_benchdrv.err | tail -1 > $O/r5_bench_driver_cfg_n1.json; cut -c1-400 $O/r5_bench_driver_cfg_n1.json ;;
+  dpab)      timeout 1200 python -m pytest tests/test_parallel_gpu.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -4
+             for v in ${DPAB_VARIANTS:-"new:" "old:GENNBV_DP_LATE_ASIDE=0,GENNBV_DP_ROTATE=0" "new2:"}; do n=${v%%:*}; e=${v#*:}; env ${e//,/ } GENNBV_FORCE_DP=1 GENNBV_FORCE_SHARD=1 timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-flat-rows 2>$O/r5_dp1_$n.err | tail -1 > $O/r5_bench_dp1_$n.json; python - <<PY
+import json
+d=json.load(open("$O/r5_bench_dp1_$n.json")); print("$n", round(d["ms_per_step"],1), "ms", d["train_roofline"]["ms_per_minibatch"], d.get("timed_state_check"), d["config"].get("dp_graph_mode"))
+PY
+             done ;;
   dp1)       GENNBV_FORCE_DP=1 GENNBV_FORCE_SHARD=1 timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-flat-rows 2>$O/r5_dp1.err | tail -1 > $O/r5_bench_dp1_n1.json; cut -c1-500 $O/r5_bench_dp1_n1.json ;;
   prof)      bash tools/collect_profiles.sh r05 2>&1 | tail -5 ;;
   refdef)    timeout 1200 python bench.py --steps 3 --warmup 1 --height 400 --width 400 --grid 20 --no-flat-rows 2>$O/r5_refdef.err | tail -1 > $O/r5_bench_refdefault_n1.json; cut -c1-400 $O/r5_bench_refdefault_n1.json ;;
