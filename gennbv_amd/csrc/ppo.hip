@@ -631,7 +631,11 @@ GNBV_API int gnbv_clip_adam_step_ex(const GnbvAdamStep *a, void *stream)
     hipLaunchKernelGGL(k_grad_sqnorm, dim3(blocks + fold + (finish ? 1 : 0)), dim3(256), 0, st, a->grads, n_eff, sliced ? a->sq_lo : a->n, gap, partial,
                        a->grad_scale, a->step, a->stop_flag, a->kl_slot, a->target_kl, blocks, sliced ? a->sq_partial : (const double *)nullptr,
                        sliced ? a->sq_parts : 0, fin_block, fin);
-    int ab = (int)((a->n - (a->upd_skip_hi > a->upd_skip_lo ? a->upd_skip_hi - a->upd_skip_lo : 0) + 255) / 256);
+    const int64_t upd_gap = a->upd_skip_hi > a->upd_skip_lo ? a->upd_skip_hi - a->upd_skip_lo : 0;
+    int ab = (int)((a->n - upd_gap + 255) / 256);
+    // (a sharded step updates the 0.8 M parameters outside the slice here: one element per lane was 3 125 workgroups, ~10 us of DISPATCH
+    // for 23 MB of traffic -- two 16-byte trips per lane instead: 17 -> 8 us in the one-rank data-parallel step)
+    if (upd_gap > 0) ab = (int)((a->n - upd_gap + 256 * 8 - 1) / (256 * 8));
     ab = ab < 1 ? 1 : ab;
 #ifndef GNBV_ADAM_BLOCKS
 #define GNBV_ADAM_BLOCKS 8192  // (same-call A/B of the whole bench: 2048 workgroups +5 us per minibatch, 4096 +1-2 us)
@@ -660,13 +664,14 @@ GNBV_API int gnbv_adam_shard_step(float *params, const float *grads, float *exp_
 // sum(g^2) of a gradient shard as kSqParts fp64 partial sums in one fixed order (the sharded data-parallel update: every rank squares the
 // shard of the REDUCED gradient it received; the partial sums ride an all-reduce and enter the clip factor through GnbvAdamStep.sq_partial)
 constexpr int kSqParts = 256;
-__global__ __launch_bounds__(256) void k_sq_partials(const float *__restrict__ g, int64_t n, double *__restrict__ partial)
+constexpr int kSqThreads = 1024;  // (round 5: 256 lanes per partial sum kept 4 requests x 64 K lanes in flight: 3.1 TB/s over a 55 MB shard)
+__global__ __launch_bounds__(kSqThreads) void k_sq_partials(const float *__restrict__ g, int64_t n, double *__restrict__ partial)
 {
-    __shared__ double sh[256];
+    __shared__ double sh[kSqThreads];
     double acc = 0.0;
     const bool vec = (((uintptr_t)g & 15) == 0);
-    const int64_t n4 = vec ? n / 4 : 0, stride = (int64_t)gridDim.x * 256;
-    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+    const int64_t n4 = vec ? n / 4 : 0, stride = (int64_t)gridDim.x * kSqThreads;
+    for (int64_t i0 = (int64_t)blockIdx.x * kSqThreads + threadIdx.x; i0 < n4; i0 += 4 * stride) {
         float4 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const float4 *>(g)[min(i0 + u * stride, n4 - 1)];  // (clamped: unconditional requests)
@@ -675,10 +680,10 @@ __global__ __launch_bounds__(256) void k_sq_partials(const float *__restrict__ g
             if (i0 + u * stride < n4)
                 acc += (double)v[u].x * (double)v[u].x + (double)v[u].y * (double)v[u].y + (double)v[u].z * (double)v[u].z + (double)v[u].w * (double)v[u].w;
     }
-    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) acc += (double)g[i] * (double)g[i];
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * kSqThreads + threadIdx.x; i < n; i += stride) acc += (double)g[i] * (double)g[i];
     sh[threadIdx.x] = acc;
     __syncthreads();
-    for (int d = 128; d > 0; d >>= 1) {
+    for (int d = kSqThreads / 2; d > 0; d >>= 1) {
         if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
         __syncthreads();
     }
@@ -690,7 +695,7 @@ GNBV_API int gnbv_sq_partials_count(void) { return kSqParts; }
 GNBV_API int gnbv_sq_partials(const float *grads, int64_t n, double *partial, void *stream)
 {
     GNBV_CHECK_ARG(grads && partial && n > 0);
-    hipLaunchKernelGGL(k_sq_partials, dim3(kSqParts), dim3(256), 0, gnbv_stream(stream), grads, n, partial);
+    hipLaunchKernelGGL(k_sq_partials, dim3(kSqParts), dim3(kSqThreads), 0, gnbv_stream(stream), grads, n, partial);
     return gnbv_launch_status();
 }
 

@@ -215,6 +215,12 @@ class PpoLossOp:
         self.args = a
         self.device = device
 
+    def finish_stats(self) -> None:
+        """The statistics row / KL slot of the last call with `args.defer_stats = 1`, as a launch of its own on the current stream
+        (gnbv_ppo_loss_finish) -- for callers whose optimizer launch cannot carry it (GnbvAdamStep.loss_finish): the data-parallel step needs
+        the rank's KL in front of the gradient exchange."""
+        _lib.check(_lib.load().gnbv_ppo_loss_finish(C.byref(self.args), _lib.stream_ptr(self.device)), "gnbv_ppo_loss_finish")
+
     def bind(self, buf):
         """Fused gather: the loss kernel reads actions / values / log_probs / advantages / returns of rows
         `self.rows` (row = t*N + n) straight out of the rollout buffer (GnbvPpoLoss.rows)."""

@@ -341,7 +341,8 @@ class PPO_Grid_Obs:
             loss.args.kl_out = opt.kl_slot.data_ptr()
         # one GPU: the loss launch leaves its per-sample terms behind and the optimizer's norm launch adds them up in passing (no release
         # fence + ticket per loss workgroup on the critical path); data-parallel: the KL must exist before the gradient exchange
-        loss.args.defer_stats = 0 if (self._sync is not None and self._sync.active) else 1
+        # (round 5, `dp_late_grads_aside`: deferred there too -- gnbv_ppo_loss_finish runs on the second stream, in front of the exchange)
+        loss.args.defer_stats = 0 if (self._sync is not None and self._sync.active and not self.dp_late_grads_aside) else 1
         self.policy.features_extractor._bn_skip_flag = loss.stop_flag
         # (GENNBV_FORCE_SHARD=1: also with a one-rank communicator -- the captured reduce-scatter / all-gather code path on one GPU)
         if (self._sync is not None and self._sync.active and (self._sync.world > 1 or os.environ.get("GENNBV_FORCE_SHARD") == "1")
@@ -488,16 +489,33 @@ class PPO_Grid_Obs:
         # the exchange of the late gradients is issued behind the SECOND stream (pose branch backward, fc_grid's weight gradient) and behind
         # what phase A left on this one (heads, fc_grid's bias): the conv backward below starts as soon as its data gradient exists
         from contextlib import nullcontext
-        late = nullcontext()
-        if self.dp_late_grads_aside and self.device.type == "cuda":
+        late, stats_done, w_rs = nullcontext(), None, None
+        if self.dp_late_grads_aside:
             from ..ops import encoder_ops
+            assert self.device.type == "cuda"
             side = encoder_ops.second_stream(self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             late = torch.cuda.stream(side)
+            # (second stream: pose branch backward -> fc_grid's weight gradient -> statistics / KL -> the exchange is issued.  Issuing the
+            # reduce-scatter right behind the weight gradient, BEFORE the pose branch's backward, was measured: 804 -> 860 ms per iteration at
+            # one rank -- the collective's stream then runs beside both other streams, and a replayed graph that is three branches wide is
+            # serialised by the executor, profiles/r05_notes.md sections 3 and 9)
+            with late:
+                # the minibatch's statistics row and this rank's approx-KL (the slot in front of the flat gradient, all-reduced with the conv
+                # gradients below): one small launch beside the conv backward instead of a release fence + ticket per workgroup in
+                # k_ppo_fused, on the critical path.  The main stream waits for it only AFTER phase B (`kl_ready`).
+                st["loss"].finish_stats()
+                stats_done = torch.cuda.Event()
+                stats_done.record(side)
+
+        def kl_ready():
+            if stats_done is not None:
+                torch.cuda.current_stream(self.device).wait_event(stats_done)
         if sh is None:
             with late:
                 work = dist.all_reduce(opt.grads_with_slot[opt.SLOT + n_conv:], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
             self._hip_minibatch_body(st, "B")
+            kl_ready()
             dist.all_reduce(opt.grads_with_slot[:opt.SLOT + n_conv], op=dist.ReduceOp.SUM, group=self._sync.group)
             work.wait()
             self._hip_minibatch_tail(st)
@@ -505,9 +523,11 @@ class PPO_Grid_Obs:
         lo, hi, loss = sh["lo"], sh["hi"], st["loss"]
         assert lo == n_conv, "the sharded slice is the first of the late gradients (parameter order: conv stack, fc_grid.weight, ...)"
         with late:
-            w_rs = dist.reduce_scatter_tensor(sh["grad"], opt.grads[lo:hi], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
+            if w_rs is None:
+                w_rs = dist.reduce_scatter_tensor(sh["grad"], opt.grads[lo:hi], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
             w_ar = dist.all_reduce(opt.grads[hi:], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
         self._hip_minibatch_body(st, "B")
+        kl_ready()
         dist.all_reduce(opt.grads_with_slot[:opt.SLOT + n_conv], op=dist.ReduceOp.SUM, group=self._sync.group)
         w_rs.wait()
         # (the shard's square sum and its 2 KB all-reduce behind the reduce-scatter on the second stream, beside the conv backward, would take one

@@ -18,10 +18,13 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
 fx = gu.load("F9_ppo_train")
 KEYS = ("train/entropy_loss", "train/policy_gradient_loss", "train/value_loss", "train/approx_kl", "train/loss")
-for shard in (0, 1):
+LATES = [bool(int(x)) for x in os.environ.get("PROBE_LATE", "0,1").split(",")]
+GRAPHS = [bool(int(x)) for x in os.environ.get("PROBE_GRAPH", "1,0").split(",")]
+REPEAT = int(os.environ.get("PROBE_REPEAT", "1"))
+for shard in (0, 1) * REPEAT:
     os.environ["GENNBV_FORCE_SHARD"] = str(shard)
-    for graph in (True, False):
-        for late in (False, True):
+    for graph in GRAPHS:
+        for late in LATES:
             for rot in (False, True):
                 ppo = _ppo_from_fixture(fx, device=DEV, backend="hip")
                 ppo.use_graph, ppo.dp_late_grads_aside, ppo.dp_rotate_rows = graph, late, rot
