@@ -583,7 +583,8 @@ def pose_branch_backward(enc, device, join: bool = True) -> None:
     # (the gradient was allocated on the current stream and is dropped when this function returns: without the join below the caching
     # allocator would hand its block to the next allocation on the current stream while the second stream still reads it -- seen as wrong
     # updates in the replayed data-parallel graph, where no host time hides the race)
-    leaf.grad.record_stream(side)
+    if not join:
+        leaf.grad.record_stream(side)
     with torch.cuda.stream(side):
         torch.autograd.backward([out], [leaf.grad])
     if join:
