@@ -477,7 +477,9 @@ typedef struct GnbvPpoLoss {
                                    a release fence + a ticket per workgroup on the update's critical path).  1: it only leaves the
                                    per-sample terms in `scratch`; the caller finishes them with gnbv_ppo_loss_finish, or -- no launch
                                    of its own -- inside gnbv_clip_adam_step_ex (GnbvAdamStep.loss_finish), before the update reads
-                                   the stop flag.  Not with kl_out (the data-parallel KL must exist before the gradient exchange). */
+                                   the stop flag.  With kl_out (data-parallel replicas: the rank's KL must exist before the all-reduce
+                                   that carries it) only gnbv_ppo_loss_finish, launched in front of that exchange -- e.g. on a second
+                                   stream beside the backward (sb3/ppo_grid_obs.py _dp_step_body). */
 } GnbvPpoLoss;
 
 int gnbv_ppo_loss(const GnbvPpoLoss *args /*[host]*/, void *stream);
