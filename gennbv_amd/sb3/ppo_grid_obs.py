@@ -472,7 +472,9 @@ class PPO_Grid_Obs:
 
     def _dp_step_body(self, st):
         """[phase A] -> exchange of the late gradients overlapped with [phase B] -> all-reduce(KL slot + conv grads) -> clip/Adam
-        tail.  Capturable: RCCL collectives are recorded into the hipGraph.
+        tail.  Capturable: RCCL collectives are recorded into the hipGraph.  Round 5 (`dp_late_grads_aside`): phase A leaves the pose
+        branch's backward and fc_grid's weight gradient on the second stream un-joined, the loss statistics / KL and the exchange are issued
+        from that stream, and phase B starts on this one as soon as fc_grid's data gradient exists.
 
         Sharded (default at world > 1, `opt.shard`): fc_grid's weight (13.8 M of the 14.6 M parameters at G = 64) is exchanged as a
         REDUCE-SCATTER -- every rank receives the sum of its 1 / world of that gradient --, updated by its owner only (Adam moments
@@ -489,7 +491,7 @@ class PPO_Grid_Obs:
         # the exchange of the late gradients is issued behind the SECOND stream (pose branch backward, fc_grid's weight gradient) and behind
         # what phase A left on this one (heads, fc_grid's bias): the conv backward below starts as soon as its data gradient exists
         from contextlib import nullcontext
-        late, stats_done, w_rs = nullcontext(), None, None
+        late, stats_done = nullcontext(), None
         if self.dp_late_grads_aside:
             from ..ops import encoder_ops
             assert self.device.type == "cuda"
@@ -523,15 +525,14 @@ class PPO_Grid_Obs:
         lo, hi, loss = sh["lo"], sh["hi"], st["loss"]
         assert lo == n_conv, "the sharded slice is the first of the late gradients (parameter order: conv stack, fc_grid.weight, ...)"
         with late:
-            if w_rs is None:
-                w_rs = dist.reduce_scatter_tensor(sh["grad"], opt.grads[lo:hi], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
+            w_rs = dist.reduce_scatter_tensor(sh["grad"], opt.grads[lo:hi], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
             w_ar = dist.all_reduce(opt.grads[hi:], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
         self._hip_minibatch_body(st, "B")
         kl_ready()
         dist.all_reduce(opt.grads_with_slot[:opt.SLOT + n_conv], op=dist.ReduceOp.SUM, group=self._sync.group)
         w_rs.wait()
         # (the shard's square sum and its 2 KB all-reduce behind the reduce-scatter on the second stream, beside the conv backward, would take one
-        # launch and one collective's latency off this tail: the one-rank RCCL capture of that order died inside librccl -- round 5, not pursued)
+        # launch and one collective's latency off this tail: the one-rank RCCL capture of that order killed the process -- round 5, not pursued)
         opt.shard_sq()  # (one launch: 256 fp64 partial sums of the shard's squares; three torch kernels and 2 x 110 MB of fp64 temporaries before)
         dist.all_reduce(sh["sq"], op=dist.ReduceOp.SUM, group=self._sync.group)
         w_ar.wait()
