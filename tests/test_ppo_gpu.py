@@ -172,6 +172,25 @@ def test_flat_adam_matches_torch_adam_with_clipping():
         torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("n,offset", [(1, 0), (1023, 0), (4099, 1), (1 << 20, 0), (1728000, 0), (13824000 // 8 + 2, 3)])
+def test_sq_partials_fixed_order_fp64(n, offset):
+    """gnbv_sq_partials (the sharded data-parallel update's sum of squares of the gradient shard a rank received): 256 fp64 partial sums whose
+    total equals sum(g^2) in fp64, the same bits on every call; any length, any 4-byte alignment (a shard starts wherever lo + rank * sh falls)."""
+    from gennbv_amd import _lib
+    lib = _lib.load()
+    parts = int(lib.gnbv_sq_partials_count())
+    gen = torch.Generator().manual_seed(n)
+    full = (torch.randn(n + offset, generator=gen) * 3e-2).to(DEV)
+    g = full[offset:]
+    out = [torch.full((parts,), -1.0, dtype=torch.float64, device=DEV) for _ in range(2)]
+    for o in out:
+        _lib.check(lib.gnbv_sq_partials(g.data_ptr(), n, o.data_ptr(), _lib.stream_ptr(torch.device(DEV))), "gnbv_sq_partials")
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], out[1]) and bool((out[0] >= 0).all())
+    want = float((g.double() ** 2).sum())
+    assert abs(float(out[0].sum()) - want) <= 1e-11 * max(want, 1e-30)
+
+
 @pytest.mark.parametrize("name,shard,order", [("F9_ppo_train", False, "r5"), ("F9_ppo_train_earlystop", False, "r5"), ("F9_ppo_train", True, "r5"),
                                               ("F9_ppo_train_earlystop", True, "r5"), ("F9_ppo_train_earlystop", True, "r4")])
 def test_data_parallel_code_path_on_one_gpu(name, shard, order, monkeypatch):
