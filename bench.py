@@ -506,6 +506,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         torch.cuda.set_device(local_rank)
+        from gennbv_amd import parallel as _parallel
+        _parallel.capture_safe_env()  # (eager + captured RCCL collectives in one process: see its docstring)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
         dist.barrier()  # creates the communicator now (RCCL prints its banner through C stdio here)
         _flush_c_stdio()

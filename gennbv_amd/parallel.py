@@ -40,11 +40,26 @@ import torch
 import torch.distributed as dist
 
 
+def capture_safe_env() -> None:
+    """Environment defaults for a process that mixes EAGER and hipGraph-CAPTURED RCCL collectives (every data-parallel run here: attach()
+    broadcasts and the warm-up steps are eager, the step itself is captured).  Call before the process group is created.
+
+    Round 5: two processes in a few hundred died in ProcessGroupNCCL's watchdog thread with "operation not permitted on an event last
+    recorded in a capturing stream": the watchdog (and its flight recorder, which times every collective through the work's events) queries
+    events of eager works while events from the same cache are being recorded by captured works.  Without the event cache a captured work
+    never records an event an eager work's bookkeeping still knows, and without the trace buffer nothing but completion is queried.
+    (`setdefault`: a caller's own setting wins.  Not reproducible on demand, so this is a precaution, not a proven fix; the capture itself
+    also waits for the watchdog to drain -- PPO_Grid_Obs._capture_minibatch_graph.)"""
+    os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
+    os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "0")
+
+
 def init_process_group(backend: Optional[str] = None) -> int:
     """RANK / WORLD_SIZE / MASTER_* come from the launcher (torch.distributed.run)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts
+        capture_safe_env()
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend)
     return world

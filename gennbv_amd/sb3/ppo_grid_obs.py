@@ -835,6 +835,10 @@ class PPO_Grid_Obs:
             # first 2-rank test of that path, round 4, showed it cannot work: the second capture dies on the same collective.)
             loss.stop_flag.zero_()
             return None
+        # the eager collectives above (warm-up steps; attach()'s broadcasts before them) are finished AND retired by the process group's
+        # watchdog thread (it polls every 100 ms) before the first captured collective records an event: see parallel.capture_safe_env
+        torch.cuda.synchronize(self.device)
+        time.sleep(0.35)
         with torch.cuda.graph(ga, capture_error_mode="thread_local"):
             self._dp_step_body(st)
         self.dp_graph_mode = "one hipGraph incl. RCCL collectives"

@@ -190,6 +190,7 @@ def test_train_g64_b128_one_rank_rccl_step_matches_fp64_oracle(rec, oracle_full,
     if not dist.is_initialized():
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", RANK="0", WORLD_SIZE="1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        parallel.capture_safe_env()
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
     n_mb = N_ENVS * T // BATCH
     hip = _fresh_hip(rec, None, True)

@@ -211,6 +211,7 @@ def test_data_parallel_code_path_on_one_gpu(name, shard, order, monkeypatch):
     if not dist.is_initialized():
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        parallel.capture_safe_env()
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
     fx = gu.load(name)
     ppo = _ppo_from_fixture(fx, device=DEV, backend="hip")

@@ -15,6 +15,7 @@ from gennbv_amd import parallel
 DEV = "cuda:0"
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", RANK="0", WORLD_SIZE="1")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+parallel.capture_safe_env()
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
 fx = gu.load("F9_ppo_train")
 KEYS = ("train/entropy_loss", "train/policy_gradient_loss", "train/value_loss", "train/approx_kl", "train/loss")
