@@ -176,32 +176,49 @@ def test_train_g64_b128_matches_fp64_oracle(rec, oracle_full, graph):
     _compare(hip, oracle_full, EPOCHS * n_mb)
 
 
-@pytest.mark.parametrize("shard", [False, True])
-def test_train_g64_b128_one_rank_rccl_step_matches_fp64_oracle(rec, oracle_full, shard, monkeypatch):
-    """The data-parallel step of `bench.py --gpus N` (PPO_Grid_Obs._dp_step_body) at the timed size, as ONE hipGraph with a one-rank RCCL
-    communicator: phase A -> exchange of the late gradients issued behind the second stream -> conv backward -> all-reduce(KL slot + conv
-    gradients) -> clip / Adam with the rotation table (sharded: reduce-scatter -> owner's Adam -> all-gather) -- 20 optimizer steps against
-    the fp64 loop, same bounds as the plain step.  (Round 5: the first version of that order raced in the REPLAYED graph only -- the pose
-    branch's upstream gradient was freed on the main stream while the second stream still read it; fixture F9 caught it, tools/dp_probe.py.)"""
+def _one_rank_rccl_g64_worker(rank, port, out):
+    """Child process of the test below: its own recorded rollout and fp64 loop (same seeds as the module's fixtures), then the one-rank
+    RCCL step with the replicated and with the sharded update."""
     import os
     import torch.distributed as dist
     from gennbv_amd import parallel
-    monkeypatch.setenv("GENNBV_FORCE_SHARD", "1" if shard else "0")
-    if not dist.is_initialized():
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", RANK="0", WORLD_SIZE="1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        parallel.capture_safe_env()
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
-    n_mb = N_ENVS * T // BATCH
-    hip = _fresh_hip(rec, None, True)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    parallel.capture_safe_env()
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
     try:
-        parallel.attach(hip, 1, always_sync=True)
-        hip.train()
-        assert hip.dp_graph_mode == "one hipGraph incl. RCCL collectives" and hip._hip.get("rows_rot") is not None
-        assert (getattr(hip._hip["opt"], "shard", None) is not None) == shard
-        _compare(hip, oracle_full, EPOCHS * n_mb)
+        rec_ = _Recorded()
+        ref = rec_.oracle(None)
+        n_mb = N_ENVS * T // BATCH
+        for shard in (False, True):
+            os.environ["GENNBV_FORCE_SHARD"] = "1" if shard else "0"
+            hip = _fresh_hip(rec_, None, True)
+            parallel.attach(hip, 1, always_sync=True)
+            hip.train()
+            assert hip.dp_graph_mode == "one hipGraph incl. RCCL collectives" and hip._hip.get("rows_rot") is not None
+            assert (getattr(hip._hip["opt"], "shard", None) is not None) == shard
+            out["sharded" if shard else "replicated"] = _compare(hip, ref, EPOCHS * n_mb)
+            hip._sync, hip._hip = None, None
+        torch.cuda.synchronize()
     finally:
-        hip._sync, hip._hip = None, None
+        dist.destroy_process_group()
+
+
+def test_train_g64_b128_one_rank_rccl_step_matches_fp64_oracle():
+    """The data-parallel step of `bench.py --gpus N` (PPO_Grid_Obs._dp_step_body) at the timed size, as ONE hipGraph with a one-rank RCCL
+    communicator: phase A -> exchange of the late gradients issued behind the second stream -> conv backward -> all-reduce(KL slot + conv
+    gradients) -> clip / Adam with the rotation table (sharded: reduce-scatter -> owner's Adam -> all-gather) -- 20 optimizer steps against
+    the fp64 loop, same bounds as the plain step, replicated and sharded update.  (Round 5: the first version of that order raced in the
+    REPLAYED graph only -- the pose branch's upstream gradient was freed on the main stream while the second stream still read it; fixture
+    F9 caught it, tools/dp_probe.py.)  In a child process, for the reason given at tests/test_ppo_gpu.py::test_data_parallel_code_path_on_one_gpu."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = mp.Manager().dict()
+    mp.spawn(_one_rank_rccl_g64_worker, args=(port, out), nprocs=1, join=True)
+    assert set(out.keys()) == {"replicated", "sharded"} and all(v <= 1e-4 for v in out.values()), dict(out)
 
 
 def test_train_g64_b128_early_stop_position(rec, oracle_full):

@@ -191,6 +191,38 @@ def test_sq_partials_fixed_order_fp64(n, offset):
     assert abs(float(out[0].sum()) - want) <= 1e-11 * max(want, 1e-30)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _one_rank_rccl_worker(rank, name, shard, order, port, out):
+    """Child process of test_data_parallel_code_path_on_one_gpu (the environment switches were set by the parent before the spawn)."""
+    import os
+    import torch.distributed as dist
+    from gennbv_amd import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    parallel.capture_safe_env()
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        fx = gu.load(name)
+        ppo = _ppo_from_fixture(fx, device=DEV, backend="hip")
+        parallel.attach(ppo, 1, always_sync=True)
+        _check(ppo, fx)
+        assert (getattr(ppo._hip["opt"], "shard", None) is not None) == shard
+        if shard:
+            assert ppo.dp_graph_mode == "one hipGraph incl. RCCL collectives", ppo.dp_graph_mode
+        assert ppo.dp_late_grads_aside == (order == "r5")
+        assert (ppo._hip.get("rows_rot") is not None) == (order == "r5" and ppo._hip.get("graph") is not None)
+        torch.cuda.synchronize()
+        out["ok"] = True
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("name,shard,order", [("F9_ppo_train", False, "r5"), ("F9_ppo_train_earlystop", False, "r5"), ("F9_ppo_train", True, "r5"),
                                               ("F9_ppo_train_earlystop", True, "r5"), ("F9_ppo_train_earlystop", True, "r4")])
 def test_data_parallel_code_path_on_one_gpu(name, shard, order, monkeypatch):
@@ -200,28 +232,18 @@ def test_data_parallel_code_path_on_one_gpu(name, shard, order, monkeypatch):
     rank its only owner) -- the RCCL reduce_scatter / all_gather calls captured in the minibatch hipGraph.
     order "r5" (default): the exchange of the late gradients is issued behind the second stream (the conv backward does not wait for the
     pose branch / fc_grid dW), and the Adam launch deals out the next minibatch's rows and statistics (rotation table) inside the
-    graph; "r4": both off (GENNBV_DP_LATE_ASIDE=0, GENNBV_DP_ROTATE=0) -- phase A joined before the exchange, three host copies per step."""
-    import os
+    graph; "r4": both off (GENNBV_DP_LATE_ASIDE=0, GENNBV_DP_ROTATE=0) -- phase A joined before the exchange, three host copies per step.
+    In a CHILD process (round 5): a process group's watchdog thread lives for the rest of its process, and this stack's has aborted twice in a
+    few hundred processes that mix eager and captured collectives (gennbv_amd/parallel.py capture_safe_env) -- the pytest process never
+    creates a NCCL process group, so such an abort fails this one case instead of ending the run."""
+    import torch.multiprocessing as mp
     monkeypatch.setenv("GENNBV_FORCE_SHARD", "1" if shard else "0")
     if order == "r4":
         monkeypatch.setenv("GENNBV_DP_LATE_ASIDE", "0")
         monkeypatch.setenv("GENNBV_DP_ROTATE", "0")
-    import torch.distributed as dist
-    from gennbv_amd import parallel
-    if not dist.is_initialized():
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        parallel.capture_safe_env()
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
-    fx = gu.load(name)
-    ppo = _ppo_from_fixture(fx, device=DEV, backend="hip")
-    parallel.attach(ppo, 1, always_sync=True)
-    _check(ppo, fx)
-    assert (getattr(ppo._hip["opt"], "shard", None) is not None) == shard
-    if shard:
-        assert ppo.dp_graph_mode == "one hipGraph incl. RCCL collectives", ppo.dp_graph_mode
-    assert ppo.dp_late_grads_aside == (order == "r5")
-    assert (ppo._hip.get("rows_rot") is not None) == (order == "r5" and ppo._hip.get("graph") is not None)
+    out = mp.Manager().dict()
+    mp.spawn(_one_rank_rccl_worker, args=(name, shard, order, _free_port(), out), nprocs=1, join=True)
+    assert out.get("ok") is True
 
 
 @pytest.mark.parametrize("dims", [(81, 81, 51, 1, 13, 13), (7, 5, 3, 1, 4, 2), (200, 1, 65)])  # the reference's action lattice first (81-way heads > one wave)
