@@ -436,6 +436,32 @@ def _workload_name(args) -> str:
             }.get(key, "custom workload")
 
 
+def device_identity(device) -> dict:
+    """What the timed numbers were taken on: marketing name, architecture, CU count, and -- from rocm-smi, after the timed region -- the
+    clocks, power cap and temperature of the device (box-to-box differences of +-1.5 % exceed a round's gains: VERDICT r5 weak #8)."""
+    import subprocess
+    import torch
+    p = torch.cuda.get_device_properties(device)
+    out = {"name": p.name, "arch": getattr(p, "gcnArchName", None), "compute_units": p.multi_processor_count,
+           "hbm_gb": p.total_memory / 1e9, "torch": torch.__version__, "hip": getattr(torch.version, "hip", None)}
+    try:
+        idx = torch.device(device).index or 0
+        r = subprocess.run(["rocm-smi", "-d", str(idx), "--showclocks", "--showmaxpower", "--showpower", "--showtemp", "--showperflevel", "--json"],
+                           capture_output=True, text=True, timeout=20)
+        j = json.loads(r.stdout[r.stdout.index("{"):]) if "{" in r.stdout else {}
+        card = next(iter(j.values()), {}) if j else {}
+        keep = {}
+        for k, v in card.items():
+            lk = k.lower()
+            if any(t in lk for t in ("sclk", "mclk", "fclk", "socclk", "max graphics package power", "power (w)", "package power", "temperature (sensor junction)",
+                                     "temperature (sensor memory)", "performance level")):
+                keep[k] = v
+        out["rocm_smi"] = keep
+    except Exception as ex:  # (never take the bench line down)
+        out["rocm_smi"] = {"error": repr(ex)}
+    return out
+
+
 def _flush_c_stdio():
     """RCCL writes a version banner with printf; flush it so that it cannot land after the JSON line."""
     import ctypes
@@ -529,12 +555,16 @@ def main():
         one_iteration(algo, dummy)
     phases = {"rollout": Phase(), "train": Phase()}
     vox = instrument_voxel(env)
+    iter_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # (one record per iteration, no synchronisation inside the timed region)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    iter_ev[0].record()
+    for i in range(args.steps):
         one_iteration(algo, phases)
+        iter_ev[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    iter_ms = [iter_ev[i].elapsed_time(iter_ev[i + 1]) for i in range(args.steps)]
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -552,23 +582,44 @@ def main():
     import hashlib
     g3 = args.grid ** 3
     b_ref = args.height * args.width * 8 + g3 * 4 * 6 + 200
-    b_lay = args.height * args.width * 8 + g3 * (3 if args.obs == "compact" else 6) + 7 * (g3 // 8) + 2 * 4 * 1200 + 200
+    b_lay = args.height * args.width * 8 + g3 * (3 if args.obs == "compact" else 6) + 7 * (g3 // 8) + 2 * 4 * 1200 + 200  # (rounds 2-5's basis: code R + W)
     vox_ms = vox.total_ms() / max(vox.count(), 1)
-    achieved = args.envs * b_lay / (vox_ms * 1e-3) / 1e9
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_json = None, None, None
     src_sha = hashlib.sha256(open(os.path.join(ROOT, "gennbv_amd", "csrc", "voxel.hip"), "rb").read()).hexdigest()
     for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_voxel_traffic.json")), reverse=True):
         tj = json.load(open(os.path.join(ROOT, "profiles", name)))
         c = tj["config"]
         if tj.get("source_sha256") == src_sha and (c["envs"], c["height"], c["width"], c["grid"], c.get("obs", "flat")) == (
                 args.envs, args.height, args.width, args.grid, args.obs):
-            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/" + name
+            traffic, traffic_src, traffic_json = tj["traffic_bytes_per_launch"], "profiles/" + name, tj
             break
+    # Since round 5 k_grid_update_coded writes a code word back only where the step touched it (a hit or a walked voxel: ~3 % of the
+    # grid per step), so the bytes the launch MOVES are code R + touched-W, not R + W.  `frac` prices those; the
+    # touched fraction comes from the PMC write counter of this very build when a matching profiles/*_voxel_traffic.json exists
+    # (written bytes of k_grid_update_coded minus the tri-class row it always writes), else the documented 3 %.
+    tri_w = g3 * (1 if args.obs == "compact" else 4)
+    touched_w, touched_src = 0.03 * g3, "default: a step touches ~3 % of the voxels (profiles/r05_notes.md 1c)"
+    b_moved = b_lay - g3 + touched_w
+    if traffic_json is not None and "k_grid_update_coded" in traffic_json.get("write_bytes", {}):
+        # everything the update kernel writes besides the tri-class row: touched code words, touched scanned words, the clears of the
+        # consumed hit / path words -- it replaces the full code W and scanned W passes of the round-2 basis
+        touched_w = max(0.0, traffic_json["write_bytes"]["k_grid_update_coded"] / args.envs - tri_w)
+        touched_src = "PMC WRITE_SIZE of k_grid_update_coded minus its tri-class row, " + traffic_src
+        b_moved = b_lay - g3 - g3 // 8 + touched_w
+    achieved = args.envs * b_moved / (vox_ms * 1e-3) / 1e9
     out = {
         "metric": "env-steps/sec at 256 envs x 64^3 grid (state encoding + policy forward + GAE + PPO update)",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        # per-iteration device times (events on the launch stream behind every iteration; nothing synchronises inside the timed region):
+        # what a +-1 % difference between two runs has to be read against.  `value` stays total work / total wall time (the contract).
+        "iteration_ms": {"min": min(iter_ms), "median": sorted(iter_ms)[len(iter_ms) // 2], "p90": sorted(iter_ms)[min(len(iter_ms) - 1, (9 * len(iter_ms)) // 10)],
+                         "max": max(iter_ms), "all": [round(x, 3) for x in iter_ms]},
+        "value_at_median_iteration": world * args.envs * args.n_steps / (sorted(iter_ms)[len(iter_ms) // 2] * 1e-3),
+        "breakdown_ms_per_step": {"rollout": phases["rollout"].total_ms() / args.steps, "train": phases["train"].total_ms() / args.steps,
+                                  "voxel_update_total": vox.total_ms() / args.steps},
+        "minibatch_graph_captures_ms": getattr(algo, "graph_capture_ms", None),
         "config": {"workload": f"{_workload_name(args)}: {args.envs} envs/GPU x {args.height}x{args.width} depth x "
                                f"{args.grid}^3 grid, n_steps={args.n_steps}, batch_size={args.batch_size}, "
                                f"n_epochs={args.n_epochs}, one step = one PPO iteration",
@@ -594,12 +645,18 @@ def main():
         "roofline": {"bound": "hbm", "kernel": ("gnbv_update_occ_grid_coded (" + ("k_hit_list + k_ray_list" if args.grid <= 104 else "k_hit_atomic + k_ray_slab") +
                                                 " + k_grid_update_coded, which also clears the masks it consumed; 1-byte coded probability grid)"),
                      "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "launch_ms": vox_ms, "algorithmic_bytes_per_launch": args.envs * b_lay,
-                     "bytes_basis": "this layout's compulsory HBM bytes (depth + seg, 1-byte code R+W, int8 tri-class W, 7 bitmask passes, ray lists)",
+                     "launch_ms": vox_ms, "algorithmic_bytes_per_launch": args.envs * b_moved,
+                     "bytes_basis": "the bytes this layout MOVES per launch: depth + seg, 1-byte code R + touched-W (code words are written back "
+                                    "only where the step touched them), int8 tri-class W, 7 bitmask passes, ray lists",
+                     "touched_write_bytes_per_env": touched_w, "touched_write_source": touched_src,
+                     "frac_traffic": None if traffic is None else (traffic / (vox_ms * 1e-3) / 1e9) / 8000.0,
+                     "frac_round2_basis": (args.envs * b_lay / (vox_ms * 1e-3) / 1e9) / 8000.0,
+                     "frac_round2_basis_note": "rounds 2-5 priced code R + W (untouched words included): kept for continuity only, it overstates "
+                                               "what the kernel moves since round 5",
                      "frac_survey_bytes": (args.envs * b_ref / (vox_ms * 1e-3) / 1e9) / 8000.0,
                      "frac_survey_bytes_note": "SURVEY 8(d) bytes (depth + seg + six fp32 passes over G^3) / launch time / 8 TB/s; > 1 reflects the "
                                                "re-layout (1-byte probability code, bit-packed gt / scanned, int8 tri-class rows: 4.2x fewer bytes), "
-                                               "not a kernel above the roof -- `frac` prices the bytes really moved",
+                                               "not a kernel above the roof -- `frac` prices the bytes moved, `frac_traffic` the PMC-counted bytes",
                      "vs_reference_layout_floor": {"reference_layout_bytes_per_launch": args.envs * b_ref,
                                                    "floor_ms_at_peak": args.envs * b_ref / 8e12 * 1e3,
                                                    "speedup_over_floor": (args.envs * b_ref / 8e12 * 1e3) / vox_ms},
@@ -623,6 +680,7 @@ def main():
         except Exception as ex:
             out["timed_state_check"] = "error: " + repr(ex)
     if rank == 0:
+        out["device"] = device_identity(device)
         try:
             out["train_roofline"] = train_roofline(algo, args, phases["train"].total_ms() / args.steps)
         except Exception as ex:

@@ -530,6 +530,225 @@ __global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_split(
 
 
 // ---------------------------------------------------------------------------
+// conv2 weight gradient, LDS-DMA transport (round 6).  Same workgroup, same compute waves, same arithmetic in the same
+// order as k_conv2_wgrad_split (the results are bit-identical), but the staging waves no longer pull y1 / dy2 through their registers:
+//   * a staging wave ISSUES `global_load_lds_dwordx4 ... nt` for its chunks of the NEXT iteration -- 1 KiB per wave instruction, 64 lanes
+//     x 16 bytes, straight from L2 / HBM into the ring slot the data will live in (raw fp32: a half row [16 voxels][16 channels] of y1
+//     is 1 KiB, exactly the size of its f16 hi | lo image);
+//   * one step later the SAME wave converts the chunk IN PLACE: one ds_read_b128 per lane (4 channels of a voxel), BN1 + ReLU + scale +
+//     split as before, two ds_write_b64 (hi at voxel * 32 + quad * 8, lo 512 bytes further) into the same 1 KiB.  A chunk belongs to one
+//     wave from request to converted image, so the only ordering needed is the wave's own `s_waitcnt vmcnt(N)` (all lanes' reads of a
+//     ds_read instruction are served before the wave's next LDS instruction) -- no barrier between landing and conversion.
+// The ring has SEVEN rows per plane instead of five: rows 2t-2 .. 2t being read by the compute waves, 2t+1, 2t+2 being converted,
+// 2t+3, 2t+4 landing (126 KiB + three dy2 buffers of 4 KiB = 138 KiB of the CU's 160).  40 chunks per step (36 y1 half rows + 4 dy2 rows)
+// = 5 per staging wave, all issued unconditionally (clamped source addresses, every chunk into its own slot), so the wait counts are
+// literals.  What the staging waves lose: 40 VGPRs of request registers, the global_load -> VGPR return path and its `s_waitcnt` on
+// register data.  What they gain: one ds_read_b128 per chunk (the LDS array was 18 % busy in the register version).
+// ---------------------------------------------------------------------------
+namespace wdma {
+constexpr int kRing = 7;
+constexpr int kStageBytes = split::kNPl * kRing * split::kRowBytes;  // 129 024
+constexpr int kDyBufs = 3;                                            // dy2 rows: being read / being converted / landing
+constexpr int kDyBytes = kDyBufs * split::kNP * 1024;
+constexpr int kLdsBytes = kStageBytes + split::kPadBytes + kDyBytes;  // 141 376
+constexpr int kChunks = 5;                                            // per staging wave and step
+static_assert(4 * split::kNPl + split::kNP == kChunks * (split::kWaves - split::kConsWaves), "40 chunks over 8 staging waves");
+}  // namespace wdma
+
+// 16 bytes per lane from global memory straight into LDS at (wave-uniform byte address lds_dst) + lane * 16; non-temporal (y1 / dy2 are
+// streamed).  M0 carries the LDS base; it is compiler-reserved, so it is saved and restored inside the statement.  Counts in vmcnt.
+__device__ __forceinline__ void glds16_nt(const void *gsrc, uint32_t lds_dst)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm_keep()  // at most N younger vector-memory operations (LDS-DMA requests) stay in flight
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void *p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
+}
+
+__global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_split_dma(
+    const float *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1, const float *__restrict__ dy2 /*[B,O2^3,16]*/,
+    const unsigned *__restrict__ absmax, int B, int O1, int O2, float *__restrict__ partial /*[grid][27 * 256 + 16]*/)
+{
+    using namespace split;
+    extern __shared__ __attribute__((aligned(16))) char split_lds[];
+    char *stage = split_lds, *dyst = split_lds + wdma::kStageBytes + kPadBytes;
+    constexpr int R = wdma::kRing;
+    int b, oz0, oz1;
+    const int vblock = (int)blockIdx.x;
+    const bool live = sample_plane_group(B, O2, kNP, b, oz0, oz1, vblock);
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+    constexpr int E2 = kTaps * 256 + kC;
+    float *out = partial + (size_t)vblock * E2;
+    if (!live) {
+        for (int i = tid; i < E2; i += kThreads) out[i] = 0.0f;
+        return;
+    }
+    for (int i = tid; i < wdma::kLdsBytes / 16; i += kThreads) reinterpret_cast<uint4 *>(split_lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const int np = oz1 - oz0, npl = 2 * np + 1, P2 = O2 * O2 * O2;
+    const int nsteps = (O2 + 1) & ~1;
+    const float gs = grad_scale(absmax);
+    if (wv >= kConsWaves) {
+        // ---- staging waves: chunk k of wave pw is half row h = pw + 8 k of the iteration (plane h >> 2, row parity (h >> 1) & 1, x parity
+        // h & 1) for h < 36; the fifth chunk of waves 4-7 is the dy2 row of plane pw - 4 ----
+        const int pw = wv - kConsWaves, q = lane & 3, vx = lane >> 2;
+        float sc[4], sh[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            sc[s] = scale1[4 * q + s] * kZScale;
+            sh[s] = shift1[4 * q + s] * kZScale;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(sc[s]), "+v"(sh[s]));  // (computed HERE: a use sunk behind the requests would make the compiler wait for them)
+        const bool dy_wave = pw >= 4;
+        const uint32_t rowC = 2 * 16 * kC, planeC = rowC * (uint32_t)O1;
+        const float *ybase = y1 + ((size_t)b * O1 + 2 * oz0) * planeC + lane * 4;
+        const int dpl = pw - 4;
+        const bool dvalid = dy_wave && dpl < np && vx < O2;
+        const float *dsrc = dy2 + ((size_t)b * P2 + (size_t)(oz0 + min(max(dpl, 0), np - 1)) * O2 * O2 + min(vx, O2 - 1)) * kC + 4 * q;
+        const uint32_t stage_a = lds_addr(stage), dy_a = lds_addr(dyst);
+        wait_vm_keep<0>();  // (the scale / shift loads above: nothing of the compiler's is in flight when the first request goes out)
+        auto issue = [&](int j) {
+#pragma unroll
+            for (int k = 0; k < wdma::kChunks; ++k) {
+                if (k == wdma::kChunks - 1 && dy_wave) {
+                    glds16_nt(dsrc + (size_t)min(max(j, 0), O2 - 1) * O2 * kC, __builtin_amdgcn_readfirstlane(dy_a + (uint32_t)((((j + 3) % wdma::kDyBufs) * kNP + dpl) * 1024)));
+                } else {
+                    const int h = pw + 8 * k, pi = h >> 2, row = 2 * j + 1 + ((h >> 1) & 1), slot = (row + 2 * R) % R;
+                    const float *src = ybase + (uint32_t)min(pi, npl - 1) * planeC + (uint32_t)min(max(row, 0), O1 - 1) * rowC + (h & 1) * (16 * kC);
+                    glds16_nt(src, __builtin_amdgcn_readfirstlane(stage_a + (uint32_t)((pi * R + slot) * kRowBytes + (h & 1) * 1024)));
+                }
+            }
+        };
+        auto convert = [&](int j) {
+            char *cp[wdma::kChunks];
+            float4 raw[wdma::kChunks];
+#pragma unroll
+            for (int k = 0; k < wdma::kChunks; ++k) {
+                if (k == wdma::kChunks - 1 && dy_wave) {
+                    cp[k] = dyst + (((j + 3) % wdma::kDyBufs) * kNP + dpl) * 1024;
+                } else {
+                    const int h = pw + 8 * k, pi = h >> 2, row = 2 * j + 1 + ((h >> 1) & 1), slot = (row + 2 * R) % R;
+                    cp[k] = stage + (pi * R + slot) * kRowBytes + (h & 1) * 1024;
+                }
+                raw[k] = *reinterpret_cast<const float4 *>(cp[k] + lane * 16);
+            }
+#pragma unroll
+            for (int k = 0; k < wdma::kChunks; ++k) {
+                float z[4];
+                const float v[4] = {raw[k].x, raw[k].y, raw[k].z, raw[k].w};
+                if (k == wdma::kChunks - 1 && dy_wave) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) z[e] = dvalid ? v[e] * gs : 0.0f;
+                } else {
+                    const bool pad_voxel = ((pw + 8 * k) & 1) == 1 && vx == 15;  // (x parity 1, slot 15: meets dy2's zero padding)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) z[e] = pad_voxel ? 0.0f : __builtin_amdgcn_fmed3f(fmaf(sc[e], v[e], sh[e]), 0.f, kZMax);
+                }
+                h4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 a, c2;
+                    split2(z[e], a, c2);
+                    hi[e] = a;
+                    lo[e] = c2;
+                }
+                char *dst = cp[k] + vx * 32 + q * 8;
+                *reinterpret_cast<h4 *>(dst) = hi;
+#ifndef SPLIT_HI_ONLY
+                *reinterpret_cast<h4 *>(dst + 512) = lo;
+#endif
+            }
+        };
+        issue(-1);
+        issue(0);
+        wait_vm_keep<wdma::kChunks>();
+        convert(-1);
+        issue(1);
+        wait_vm_keep<wdma::kChunks>();
+        convert(0);
+        split_step_barrier();
+        for (int t = 1; t <= nsteps; ++t) {
+            issue(t + 1);  // rows 2t+3, 2t+4: their slots held rows 2t-4, 2t-3, last read before the previous barrier
+            wait_vm_keep<wdma::kChunks>();  // everything but the five just issued: iteration t has landed
+            convert(t);
+            split_step_barrier();
+        }
+        wait_vm_keep<0>();  // (nothing may land in LDS after the workgroup has ended)
+    } else {
+        // ---- compute waves: k_conv2_wgrad_split's, on the seven-row ring and the three dy2 buffers ----
+        const int n = lane & 15, g = lane >> 4, cw = wv;
+        const int ntaps = cw < 3 ? 4 : 3;
+        uint32_t tapbase[4];
+        int tapdy[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tp = min(cw + 8 * i, kTaps - 1), dz = tp / 9, dy = (tp / 3) % 3, dx = tp % 3;
+            tapbase[i] = (uint32_t)(dz * R * kRowBytes + (dx == 1 ? 1024 : 0) + (dx == 2 ? 32 : 0)) + lane * 8;
+            tapdy[i] = dy;
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        h8 ones;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = (_Float16)1.0f;
+        split_step_barrier();
+        for (int t = 1; t <= nsteps; ++t) {
+            const int oy = t - 1;
+            if (oy < O2) {
+                uint32_t rowoff[3];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) rowoff[dy] = (uint32_t)(((2 * oy + dy) % R) * kRowBytes);
+                const char *dybuf = dyst + (oy % wdma::kDyBufs) * kNP * 1024 + lane * 8;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    if (2 * kb < np) {
+                        const h8 bh = tr_pair(dybuf + (2 * kb) * 1024, dybuf + (2 * kb + 1) * 1024);
+                        const h8 bl = tr_pair(dybuf + (2 * kb) * 1024 + 512, dybuf + (2 * kb + 1) * 1024 + 512);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            if (i < ntaps) {
+                                const uint32_t off = tapbase[i] + (tapdy[i] == 0 ? rowoff[0] : tapdy[i] == 1 ? rowoff[1] : rowoff[2]);
+                                const char *a0 = stage + (2 * (2 * kb)) * R * kRowBytes + off, *a1 = a0 + 2 * R * kRowBytes;
+                                const h8 ah = tr_pair(a0, a1), al = tr_pair(a0 + 512, a1 + 512);
+                                acc[i] = mfma_h(ah, bh, acc[i]);
+                                acc[i] = mfma_lo(al, bh, acc[i]);
+                                acc[i] = mfma_lo(ah, bl, acc[i]);
+                            }
+                        }
+                        if (cw == 7) {
+                            acc[3] = mfma_h(ones, bh, acc[3]);
+                            acc[3] = mfma_lo(ones, bl, acc[3]);
+                        }
+                    }
+                }
+            }
+            split_step_barrier();
+        }
+        const float unscale = (1.0f / kZScale) * inv_pow2(gs);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < ntaps) {
+                const int tp = cw + 8 * i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[tp * 256 + (4 * g + r) * kC + n] = acc[i][r] * unscale;
+            }
+        }
+        if (cw == 7 && g == 0) out[kTaps * 256 + n] = acc[3][0] * inv_pow2(gs);
+    }
+}
+
+
+// ---------------------------------------------------------------------------
 // conv2 data gradient + conv1 weight gradient (the fused backward, see k_conv2_dgrad_c1w in encoder.hip for the algebra and
 // the outputs: T1[32 taps][16], S1, S2 per workgroup).  Workgroup = 16 waves = (sample, 4 plane pairs of the layer-1 volume),
 // one per CU, walking the 16 row pairs c.  A step = the four 2 x 2 x 32-voxel super-tiles (a, c) of the workgroup.
@@ -1174,18 +1393,24 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
         // prologue: three barriers (the compute waves run the same count)
         // (TRAIN: explicit waits.  A wave's vector-memory operations complete in issue order; behind the request a wait releases there
         // are, in issue order: [the other register's request], then per half step 3 y1 stores + 1 request)
+        // The counts follow from the issue order alone: compute() issues exactly kTilesPerWave y1 stores (st4_nt_masked: one per tile, owned
+        // or not) and NOTHING else on the vector-memory counter; in_req() issues one request.  kVmHalf = what one half step puts behind a
+        // request, kVmFull = what lies behind the OLDER register's request in the steady state.
+        constexpr int kVmHalf = kTilesPerWave + 1, kVmFull = 2 * kTilesPerWave + 1;
+        static_assert(kTilesPerWave == 3 && kVmHalf == 4 && kVmFull == 7, "the explicit vmcnt waits of the training forward's staging waves assume "
+                      "kTilesPerWave y1 stores + one input request per half step (re-derive them when kNPl / kStageWaves change)");
         u4v_t ra = in_req(-1), rb = in_req(0);
         if constexpr (TRAIN) wait_vm_keep1<1>(ra);
         in_store(-1, ra);
         ra = in_req(1);
         split_step_barrier();
         compute(-1, 1);
-        if constexpr (TRAIN) wait_vm_keep1<4>(rb);  // ra's request + 3 stores
+        if constexpr (TRAIN) wait_vm_keep1<kVmHalf>(rb);  // ra's request + 3 stores
         in_store(0, rb);
         rb = in_req(2);
         split_step_barrier();
         compute(0, 0);
-        if constexpr (TRAIN) wait_vm_keep1<7>(ra);  // 3 stores + rb's request + 3 stores: the steady state
+        if constexpr (TRAIN) wait_vm_keep1<kVmFull>(ra);  // 3 stores + rb's request + 3 stores: the steady state
         in_store(1, ra);
         ra = in_req(3);
         split_step_barrier();
@@ -1193,12 +1418,12 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
         // even iterations, ra odd ones.  Branch-free around the requests.
         for (int t = 1; t <= nsteps; t += 2) {
             compute(t, 1);
-            if constexpr (TRAIN) wait_vm_keep1<7>(rb);
+            if constexpr (TRAIN) wait_vm_keep1<kVmFull>(rb);
             in_store(t + 1, rb);
             rb = in_req(t + 3);
             split_step_barrier();
             compute(t + 1, 0);
-            if constexpr (TRAIN) wait_vm_keep1<7>(ra);
+            if constexpr (TRAIN) wait_vm_keep1<kVmFull>(ra);
             in_store(t + 2, ra);
             ra = in_req(t + 4);
             split_step_barrier();

@@ -1989,6 +1989,12 @@ static inline bool conv_split_path(const GnbvEncoderParams *p, int grid)
     const int O1 = out_size(grid), O2 = out_size(O1);
     return !env_off("GENNBV_CONV_SPLIT") && !p->force_fp32 && (O1 + 1) / 2 == 16 && O2 <= 15;
 }
+// conv2 weight gradient with the LDS-DMA transport (k_conv2_wgrad_split_dma); GENNBV_WGRAD_DMA=1 selects it (A/B switch, round 6)
+static inline bool wgrad_dma_path()
+{
+    const char *e = getenv("GENNBV_WGRAD_DMA");
+    return e && e[0] == '1';
+}
 static inline bool fused_path(const GnbvEncoderParams *p, int grid)
 {
     return !env_off("GENNBV_FUSED_BWD") && p->grid_i8 != nullptr && grid % 16 == 0 && 3 * grid * grid <= 64 * 1024 &&
@@ -2254,6 +2260,17 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
             attr_wg = true;
         }
         wg_blocks = sample_plane_group_grid(batch, O2, split::kNP);
+        if (wgrad_dma_path()) {
+            // (round 6) the same contraction with y1 / dy2 streamed into LDS by LDS-DMA requests and converted in place: bit-identical
+            static bool attr_wd = false;
+            if (!attr_wd) {
+                const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_wgrad_split_dma, hipFuncAttributeMaxDynamicSharedMemorySize, wdma::kLdsBytes);
+                if (e != hipSuccess) return (int)e;
+                attr_wd = true;
+            }
+            hipLaunchKernelGGL(k_conv2_wgrad_split_dma, dim3(wg_blocks), dim3(split::kThreads), wdma::kLdsBytes, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch,
+                               (const unsigned *)dy2_absmax, batch, O1, O2, w.wg_part);
+        } else
         hipLaunchKernelGGL(k_conv2_wgrad_split, dim3(wg_blocks), dim3(split::kThreads), split::kWgLdsBytes, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch,
                            (const unsigned *)dy2_absmax, batch, O1, O2, w.wg_part);
     } else {

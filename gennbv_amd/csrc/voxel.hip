@@ -1061,19 +1061,21 @@ __device__ __forceinline__ void walk_packed(int sx, int sy, int sz, int l_src, i
     const int l0 = sx < tx ? gg : -gg, l1 = sy < ty ? g : -g, l2 = sz < tz ? 1 : -1;
     const int la = ax ? l0 : (ay ? l1 : l2), lb = ax ? l1 : l0, lc = (ax || ay) ? l2 : l1;
     const int db = ax ? d1 : d0, dc = (ax || ay) ? d2 : d1;
-    int W = l_src + (da << 24);
+    // remaining steps of the dominant axis in the top byte, the linear voxel index below it.  UNSIGNED: da reaches g - 1 = 180 at the
+    // kernel's limit (g <= 181), and as a signed word a count of 128 or more would read as "no steps left" 
+    unsigned W = (unsigned)l_src + ((unsigned)da << 24);
     v2s_t P = pack2(2 * db - da, 2 * dc - da);
     const v2s_t neg2da = pack2(-2 * da, -2 * da), dl = pack2(2 * db - 2 * da, 2 * dc - 2 * da), lbc = pack2(lb, lc);
     const int kp = la + lb + lc - (1 << 24);
-    while (W >= (1 << 24)) {
+    while (W >= (1u << 24)) {
         const v2s_t m = P >> (v2s_t)(15);
         P = m * neg2da + (P + dl);
-        W = __builtin_amdgcn_sdot2(lbc, m, W, false) + kp;
+        W = (unsigned)__builtin_amdgcn_sdot2(lbc, m, (int)W, false) + (unsigned)kp;
         // Neighbouring lanes walk neighbouring voxels' rays (list order = voxel order), which run through the SAME voxel for most of
         // their length: a lane whose voxel is its left neighbour's leaves the bit to it.  (An LDS atomic of 64 lanes on one address
         // costs ~450 cycles of the CU's LDS pipe, on 64 scattered addresses ~16: tools/ubench/ray_step_rate.hip.  A lane that is
         // switched off -- its ray has ended -- reads as -1: no voxel.)
-        const int l = W & 0xffffff;
+        const int l = (int)(W & 0xffffffu);
         const int lp = __builtin_amdgcn_update_dpp(-1, l, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
 #ifdef RAY_ABL_NOATOM  // (measurement build: the walk without its LDS atomics -- and with nothing to flush: 20.7 -> 13.4 us)
         if (l == 0x7fffff) atomicOr(&s_path[l >> 5], 1u << (l & 31));

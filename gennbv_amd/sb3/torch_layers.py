@@ -55,8 +55,25 @@ class MlpExtractor(nn.Module):
             towers = item
             break
         self.shared_net, d = _tower(shared, feature_dim, activation_fn)
-        self.policy_net, self.latent_dim_pi = _tower(towers.get("pi", []), d, activation_fn)
-        self.value_net, self.latent_dim_vf = _tower(towers.get("vf", []), d, activation_fn)
+        # The two towers' layers are CREATED depth by depth, policy layer i then value layer i (the reference walks zip_longest over the
+        # two width lists, stable_baselines3/common/torch_layers.py MlpExtractor.__init__): the parameters' default initialisation draws
+        # from torch's global generator in creation order, so a seeded construction only matches the reference's for ortho_init=False
+        # when the order does.  Module tree / state_dict keys are the same either way.
+        pi_w, vf_w = list(towers.get("pi", [])), list(towers.get("vf", []))
+        pi_mods, vf_mods, d_pi, d_vf = [], [], d, d
+        for i in range(max(len(pi_w), len(vf_w))):
+            for widths, mods, which in ((pi_w, pi_mods, "pi"), (vf_w, vf_mods, "vf")):
+                if i < len(widths):
+                    if not isinstance(widths[i], int):
+                        raise TypeError("layer widths must be integers")
+                    d_in = d_pi if which == "pi" else d_vf
+                    mods += [nn.Linear(d_in, widths[i]), activation_fn()]
+                    if which == "pi":
+                        d_pi = widths[i]
+                    else:
+                        d_vf = widths[i]
+        self.policy_net, self.latent_dim_pi = nn.Sequential(*pi_mods), d_pi
+        self.value_net, self.latent_dim_vf = nn.Sequential(*vf_mods), d_vf
         if device not in ("auto", None):
             self.to(device)
 

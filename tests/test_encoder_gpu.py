@@ -570,3 +570,33 @@ def test_bn2_relu_folded_into_fc_grid_is_bit_identical(g, b, train, monkeypatch)
             assert float((a - r).abs().max()) <= 2e-7 * float(r.abs().max()), n
         else:
             assert torch.equal(a, r), n
+
+
+@pytest.mark.parametrize("b", [3, 128])
+def test_wgrad_lds_dma_transport_is_bit_identical(b, monkeypatch):
+    """k_conv2_wgrad_split_dma (round 6): y1 / dy2 reach the ring by LDS-DMA requests and are converted in place -- the same arithmetic in the
+    same order as the register-staged k_conv2_wgrad_split, so every conv / BN gradient must be BIT-identical (b = 3: a sample's last
+    plane group has three planes; 128: the bench's minibatch, two full rounds of workgroups)."""
+    from gennbv_amd.ops.encoder_ops import RowGather, input_autocorr
+    g = 64
+    hip, _, _ = pu.make_policy(g=g, device=DEV, backend="hip", det_weights=True)
+    base = _obs(b + 2, g, seed=7)
+    rows = torch.randperm(b + 2, generator=torch.Generator().manual_seed(5))[:b].to(DEV)
+    grid_i8 = base[:, 600:600 + g ** 3].to(torch.int8).contiguous()
+    ac = input_autocorr(grid_i8, g)
+    w = torch.linspace(0.5, 1.5, 256).to(DEV)
+    hip.train()
+    grads = {}
+    for mode in ("0", "1", "0"):
+        monkeypatch.setenv("GENNBV_WGRAD_DMA", mode)
+        hip.zero_grad()
+        f = hip.features_extractor(RowGather(base, rows, grid_i8, autocorr=ac))
+        (f * w).sum().backward()
+        torch.cuda.synchronize()
+        cur = [p.grad.detach().clone() for p in hip.features_extractor.naive_encoder_grid.parameters()]
+        if mode in grads:  # (the register-staged kernel reproduces itself: the comparison below is meaningful)
+            assert all(torch.equal(a, c) for a, c in zip(grads[mode], cur))
+        grads[mode] = cur
+    assert float(grads["0"][2].abs().max()) > 0  # conv2.weight's gradient
+    for a, c in zip(grads["0"], grads["1"]):
+        assert torch.equal(a, c)

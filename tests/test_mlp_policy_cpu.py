@@ -140,3 +140,19 @@ def test_cpu_placed_buffer_gae_equals_the_reference_fixture():
     buf.compute_returns_and_advantage(torch.from_numpy(fx["last_values"]).view(n, 1), torch.from_numpy(fx["dones"].astype(np.int64)))
     assert buf.advantages.view(t, n).numpy().tobytes() == fx["sb3_advantages"].tobytes()
     assert buf.returns.view(t, n).numpy().tobytes() == fx["sb3_returns"].tobytes()
+
+
+def test_mlp_extractor_seeded_initialisation_equals_the_reference():
+    # F16 = the reference's own MlpExtractor constructed behind torch.manual_seed(3): the default (non-orthogonal) initialisation
+    # consumes the global generator in layer-CREATION order -- policy layer i, then value layer i, depth by depth
+    from gennbv_amd.sb3.torch_layers import MlpExtractor
+    fx = gu.load("F16_mlp_init")
+    archs = {"default": [dict(pi=[64, 64], vf=[64, 64])], "shared": [96, dict(pi=[48], vf=[32, 16])], "ragged": [32, dict(pi=[8, 9, 10], vf=[7])]}
+    for tag, arch in archs.items():
+        torch.manual_seed(int(fx["seed"]))
+        m = MlpExtractor(int(fx["feature_dim"]), arch, torch.nn.Tanh, "cpu")
+        sd = m.state_dict()
+        ref_keys = [k.split("/", 1)[1] for k in fx.files if k.startswith(tag + "/")]
+        assert list(sd) == ref_keys, tag
+        for k in ref_keys:
+            assert np.array_equal(sd[k].numpy(), fx[f"{tag}/{k}"]), (tag, k)

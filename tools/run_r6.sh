@@ -1,0 +1,18 @@
+#!/bin/bash
+# Run on the GPU box: the measurement stages of round 6.   tools/run_r6.sh <stage> [<stage> ...]   (outputs under gpurun_out/)
+cd $GRAFT_REPO_ROOT
+O=$GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $O
+for st in "$@"; do
+case $st in
+  probe)     timeout 120 tools/ubench/bin/lds_dma_probe > $O/r06_lds_dma_probe.txt 2>&1; cat $O/r06_lds_dma_probe.txt ;;
+  t_dma)     timeout 900 python -m pytest tests/test_encoder_gpu.py -m gpu -q -x -k "wgrad_lds_dma" -p no:cacheprovider 2>&1 | tail -5
+             GENNBV_WGRAD_DMA=1 timeout 900 python -m pytest tests/test_encoder_gpu.py -m gpu -q --maxfail=4 -k "forward_backward_vs_torch or fused_dgrad" -p no:cacheprovider 2>&1 | tail -5 ;;
+  convdma)   cd /tmp && export TMPDIR=/tmp; for v in 0 1; do rm -rf /tmp/prof_c; GENNBV_WGRAD_DMA=$v rocprofv3 --kernel-trace --stats -d /tmp/prof_c -- python $GRAFT_REPO_ROOT/tools/microbench_conv.py > /tmp/prof_c.log 2>&1; echo "== GENNBV_WGRAD_DMA=$v"; tail -1 /tmp/prof_c.log; python $GRAFT_REPO_ROOT/tools/rocprof_summary.py /tmp/prof_c | grep -E "wgrad|reduce|finish|dgrad|conv12" | cut -c1-150; done | tee $O/r06_conv_wgrad_dma_trace.txt; cd $GRAFT_REPO_ROOT ;;
+  abdma)     timeout 1500 python tools/ab_interleaved.py --what train --captures 3 --variant base --variant "dma:GENNBV_WGRAD_DMA=1" --rounds 8 --json $O/r06_ab_train_wgrad_dma.json 2>&1 | grep -v "^\[ab\]" | tail -12 ;;
+  tests)     timeout 1500 python -m pytest tests -m gpu -q --maxfail=12 --durations=12 -p no:cacheprovider > $O/r6_tests.log 2>&1; tail -30 $O/r6_tests.log ;;
+  bench)     timeout 900 python bench.py --steps 5 --warmup 2 2>$O/r6_bench.err | tail -1 > $O/r6_bench_n1.json; cut -c1-900 $O/r6_bench_n1.json ;;
+  benchdrv)  timeout 1200 python bench.py --steps 20 --warmup 5 2>$O/r6_benchdrv.err | tail -1 > $O/r6_bench_driver_cfg_n1.json; cut -c1-600 $O/r6_bench_driver_cfg_n1.json ;;
+  *) echo "unknown stage $st" ;;
+esac
+done
