@@ -591,23 +591,16 @@ __global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_split_dma(
         for (int i = tid; i < E2; i += kThreads) out[i] = 0.0f;
         return;
     }
-    for (int i = tid; i < wdma::kLdsBytes / 16; i += kThreads) reinterpret_cast<uint4 *>(split_lds)[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
+    // Only the padding voxel behind the ring is cleared: every ring slot and every dy2 buffer is written in full (1 KiB chunks, all nine
+    // planes, clamped sources) before its first read, so nothing stale can reach an operand -- and the first requests can go out at once,
+    // before anything else of the workgroup's start-up (no clear of 138 KiB + barrier in front of them, no round trip for the scales).
+    if (tid < kPadBytes / 16) reinterpret_cast<uint4 *>(split_lds + wdma::kStageBytes)[tid] = make_uint4(0, 0, 0, 0);
     const int np = oz1 - oz0, npl = 2 * np + 1, P2 = O2 * O2 * O2;
     const int nsteps = (O2 + 1) & ~1;
-    const float gs = grad_scale(absmax);
     if (wv >= kConsWaves) {
         // ---- staging waves: chunk k of wave pw is half row h = pw + 8 k of the iteration (plane h >> 2, row parity (h >> 1) & 1, x parity
         // h & 1) for h < 36; the fifth chunk of waves 4-7 is the dy2 row of plane pw - 4 ----
         const int pw = wv - kConsWaves, q = lane & 3, vx = lane >> 2;
-        float sc[4], sh[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            sc[s] = scale1[4 * q + s] * kZScale;
-            sh[s] = shift1[4 * q + s] * kZScale;
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(sc[s]), "+v"(sh[s]));  // (computed HERE: a use sunk behind the requests would make the compiler wait for them)
         const bool dy_wave = pw >= 4;
         const uint32_t rowC = 2 * 16 * kC, planeC = rowC * (uint32_t)O1;
         const float *ybase = y1 + ((size_t)b * O1 + 2 * oz0) * planeC + lane * 4;
@@ -615,8 +608,10 @@ __global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_split_dma(
         const bool dvalid = dy_wave && dpl < np && vx < O2;
         const float *dsrc = dy2 + ((size_t)b * P2 + (size_t)(oz0 + min(max(dpl, 0), np - 1)) * O2 * O2 + min(vx, O2 - 1)) * kC + 4 * q;
         const uint32_t stage_a = lds_addr(stage), dy_a = lds_addr(dyst);
-        wait_vm_keep<0>();  // (the scale / shift loads above: nothing of the compiler's is in flight when the first request goes out)
         auto issue = [&](int j) {
+#ifdef WDMA_ABL_NODMA  // (measurement build: no requests -- conversion + contraction alone)
+            return;
+#endif
 #pragma unroll
             for (int k = 0; k < wdma::kChunks; ++k) {
                 if (k == wdma::kChunks - 1 && dy_wave) {
@@ -628,7 +623,24 @@ __global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_split_dma(
                 }
             }
         };
+        issue(-1);
+        issue(0);
+        // the scales, requested BEHIND the first ten chunks: the compiler's wait for them (it does not count the requests above) also retires
+        // those -- which the first conversion needs anyway
+        const float gs = grad_scale(absmax);
+        float sc[4], sh[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            sc[s] = scale1[4 * q + s] * kZScale;
+            sh[s] = shift1[4 * q + s] * kZScale;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(sc[s]), "+v"(sh[s]));  // (computed HERE: a use sunk behind later requests would make the compiler wait for them)
+        wait_vm_keep<0>();
         auto convert = [&](int j) {
+#ifdef WDMA_ABL_NOCONV  // (measurement build: the chunks stay raw -- transport + contraction alone, results meaningless)
+            return;
+#endif
             char *cp[wdma::kChunks];
             float4 raw[wdma::kChunks];
 #pragma unroll
@@ -668,13 +680,9 @@ __global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_split_dma(
 #endif
             }
         };
-        issue(-1);
-        issue(0);
-        wait_vm_keep<wdma::kChunks>();
         convert(-1);
         issue(1);
-        wait_vm_keep<wdma::kChunks>();
-        convert(0);
+        convert(0);  // (iteration 0 landed with iteration -1: the wait above was for everything)
         split_step_barrier();
         for (int t = 1; t <= nsteps; ++t) {
             issue(t + 1);  // rows 2t+3, 2t+4: their slots held rows 2t-4, 2t-3, last read before the previous barrier
@@ -685,6 +693,7 @@ __global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_split_dma(
         wait_vm_keep<0>();  // (nothing may land in LDS after the workgroup has ended)
     } else {
         // ---- compute waves: k_conv2_wgrad_split's, on the seven-row ring and the three dy2 buffers ----
+        const float gs = grad_scale(absmax);
         const int n = lane & 15, g = lane >> 4, cw = wv;
         const int ntaps = cw < 3 ? 4 : 3;
         uint32_t tapbase[4];
@@ -704,27 +713,43 @@ __global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_split_dma(
         split_step_barrier();
         for (int t = 1; t <= nsteps; ++t) {
             const int oy = t - 1;
+#ifdef WDMA_ABL_NOCOMP  // (measurement build: the compute waves only keep the barriers -- transport + conversion alone)
+            if (false) {
+#else
             if (oy < O2) {
+#endif
                 uint32_t rowoff[3];
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) rowoff[dy] = (uint32_t)(((2 * oy + dy) % R) * kRowBytes);
                 const char *dybuf = dyst + (oy % wdma::kDyBufs) * kNP * 1024 + lane * 8;
+                // Every operand of a k-block is requested before its first MFMA, and the MFMAs run tap-interleaved (hh of every tap, then
+                // lh, then hl): as written in k_conv2_wgrad_split -- per tap four reads, a wait, three MFMAs on ONE accumulator -- a step
+                // of a compute wave was a chain of ~7 LDS round trips and 21 dependent matrix instructions, which nothing hid once the
+                // transport stopped being the bound.  Each accumulator still receives its products in the same order: bit-identical.
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
                     if (2 * kb < np) {
                         const h8 bh = tr_pair(dybuf + (2 * kb) * 1024, dybuf + (2 * kb + 1) * 1024);
                         const h8 bl = tr_pair(dybuf + (2 * kb) * 1024 + 512, dybuf + (2 * kb + 1) * 1024 + 512);
+                        h8 ah[4], al[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            if (i < ntaps) {
+                            if (i < 3 || ntaps == 4) {
                                 const uint32_t off = tapbase[i] + (tapdy[i] == 0 ? rowoff[0] : tapdy[i] == 1 ? rowoff[1] : rowoff[2]);
                                 const char *a0 = stage + (2 * (2 * kb)) * R * kRowBytes + off, *a1 = a0 + 2 * R * kRowBytes;
-                                const h8 ah = tr_pair(a0, a1), al = tr_pair(a0 + 512, a1 + 512);
-                                acc[i] = mfma_h(ah, bh, acc[i]);
-                                acc[i] = mfma_lo(al, bh, acc[i]);
-                                acc[i] = mfma_lo(ah, bl, acc[i]);
+                                ah[i] = tr_pair(a0, a1);
+                                al[i] = tr_pair(a0 + 512, a1 + 512);
                             }
                         }
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) acc[i] = mfma_h(ah[i], bh, acc[i]);
+                        if (ntaps == 4) acc[3] = mfma_h(ah[3], bh, acc[3]);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) acc[i] = mfma_lo(al[i], bh, acc[i]);
+                        if (ntaps == 4) acc[3] = mfma_lo(al[3], bh, acc[3]);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) acc[i] = mfma_lo(ah[i], bl, acc[i]);
+                        if (ntaps == 4) acc[3] = mfma_lo(ah[3], bl, acc[3]);
                         if (cw == 7) {
                             acc[3] = mfma_h(ones, bh, acc[3]);
                             acc[3] = mfma_lo(ones, bl, acc[3]);
@@ -1052,6 +1077,10 @@ __device__ __forceinline__ void conv2_dgrad_c1w_split_body(
         dy_store(0, R.d0, (C)); dy_store(1, R.d1, (C));                                                                           \
     }
         StepRegs ra, rb;
+#ifdef DSPLIT_ABL_NOSTAGE  // (measurement build: no y1 / dy2 requests after the first two sets -- the contraction alone on stale rows)
+#undef GNBV_DS_LOAD
+#define GNBV_DS_LOAD(R, C) { if ((C) < 2) { R.y0 = y_req(0, (C)); R.y1 = y_req(1, (C)); R.y2 = y_req(2, (C)); R.y3 = y_req(3, (C)); R.y4 = y_req(4, (C)); R.y5 = y_req(5, (C)); R.y6 = y_req(6, (C)); R.y7 = y_req(7, (C)); R.d0 = dy_req(0, (C)); R.d1 = dy_req(1, (C)); } }
+#endif
         GNBV_DS_LOAD(ra, 0);
         GNBV_DS_LOAD(rb, 1);
         GNBV_DS_STORE(ra, 0);
@@ -1114,7 +1143,9 @@ __device__ __forceinline__ void conv2_dgrad_c1w_split_body(
                 const bool y0ok = 2 * c < O1, y1ok = 2 * c + 1 < O1;
                 const char *ybuf = ybufs + (c & 1) * kYBuf;
                 const int sboff = (c & 1) * kSlabBuf;
+#ifndef DSPLIT_ABL_NOCOMP  // (measurement build: the compute waves keep their slab requests and the barriers only -- the staging alone)
                 dgrad_split_supertile<TY>(dyst, ybuf, slab0 + sboff, slab1 + sboff, wimg, ai, c, z1ok, y0ok, y1ok, O1, tok1, sc, sh, gscale, s2, T1a, T1b);
+#endif
                 split_step_barrier();
             }
         };
@@ -1381,7 +1412,11 @@ __global__ __launch_bounds__(split::kThreads) void k_conv12_fwd_split(
                     // all 64 lanes where the workgroup owns the tile; lane 0 alone, into the row's padding slot, where it does not
                     // (the first 32 / 64 samples' y1 stored WITHOUT the non-temporal hint, so that the backward finds a part of it in the
                     // memory-side cache: +1.4 / +7.3 us per minibatch, profiles/r05_ab_train_y1_cached_samples.json)
+#ifdef FSPLIT_ABL_NOSTORE  // (measurement build: every y1 store under the one-lane mask -- the forward without its 244 MB write)
+                    st4_nt_masked(dst1, 4 * y1_pad, (f32x4){yv[0], yv[1], yv[2], yv[3]}, 1u, 0u);
+#else
                     st4_nt_masked(dst1, own ? 4 * y1_lane : 4 * y1_pad, (f32x4){yv[0], yv[1], yv[2], yv[3]}, own ? ~0u : 1u, own ? ~0u : 0u);
+#endif
                 }
                 char *dst = stage + (pi * kRing + slot) * kRowBytes + par * 1024 + n * 32 + g * 8;
                 *reinterpret_cast<h4 *>(dst) = hi;

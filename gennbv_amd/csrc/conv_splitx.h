@@ -1,0 +1,369 @@
+// The conv2 kernels on the f16 matrix pipe with SPLIT operands for rows WIDER than 16 voxel slots per x parity (round 6; SURVEY row N1,
+// BASELINE configs[4]: G = 128 -> O1 = 63, 32 slots per half row, O2 = 31).  Included by encoder.hip behind conv_split.h, whose arithmetic
+// (split2, the three-product MFMA, the operand scalings), ring, roles and step structure these kernels keep.  Reference operators:
+// gennbv/network/hybrid_encoder.py:31-38 (the conv stack is size-agnostic; only :40,83-84 hard-code 20^3).
+//
+// What changes against conv_split.h is the x direction only.  A workgroup handles an X TILE of 16 outputs ox = 16 tx + m of its four
+// output planes; output m reads the even-parity input voxels 16 tx + m (tap dx = 0) and 16 tx + m + 1 (dx = 2) and the odd-parity voxel
+// 16 tx + m (dx = 1).  With 15 valid outputs per row (G = 64) the sixteenth output is padding and so is the seventeenth even voxel it
+// reads; with 16 valid outputs (tile 0 of a 31-output row) that voxel is DATA.  So the ring row here holds 17 voxels per plane:
+//       row = [x parity 2][hi | lo][17 voxels][16 channels] f16  = 4 x 544 bytes   (conv_split.h: 4 x 512)
+// staged from the WINDOW of slots 16 tx .. 16 tx + 16 (even) / .. + 15 (odd) of the y1 row; a staged voxel outside the row
+// (x = 2 slot + parity >= O1) is stored as ZERO.  132 sixteen-byte pieces per row instead of 128, so a staging thread's pieces are no
+// longer one row per wave pair: piece f = 512 k + thread of the step's 18 rows, (row, parity, voxel) per lane, precomputed once.
+// Neighbouring tiles share one even voxel: 66 staged voxels per 63-voxel row (+ 5 %).  Everything a tile needs beyond that -- planes, rows,
+// taps, the k-half hand-over, the BN2 partial sums -- is conv_split.h's, with 544 / 1088 / 2176 where that file has 512 / 1024 / 2048.
+// The same kernels run G = 64 (one tile per row; GENNBV_SPLITX=1) -- which is how the G = 64 tests cover this file against the fp64 reference.
+#pragma once
+
+namespace splitx {
+using split::kThreads; using split::kWaves; using split::kConsWaves; using split::kProdThreads; using split::kNP; using split::kNPl; using split::kRing;
+using split::kPadBytes; using split::kRedBytes; using split::kDyBytes; using split::kKSteps; using split::kKHalf; using split::kZScale; using split::kWScale; using split::kZMax;
+constexpr int kVox = 17;
+constexpr int kPlaneB = kVox * 32, kParB = 2 * kPlaneB, kRowBytes = 2 * kParB;  // 544, 1088, 2176
+constexpr int kStageBytes = kNPl * kRing * kRowBytes;                              // 97 920
+constexpr int kEven = kVox * 4, kPieces = kEven + 16 * 4;                          // 16-byte fp32 pieces of a staged row: 68 even + 64 odd
+constexpr int kStepPieces = 2 * kNPl * kPieces;                                    // 18 rows: 2 376
+constexpr int kSlots = (kStepPieces + kProdThreads - 1) / kProdThreads;            // 5
+constexpr int kLdsBytes = kStageBytes + kPadBytes + kRedBytes;
+constexpr int kWgLdsBytes = kStageBytes + kPadBytes + kDyBytes;
+static_assert(kSlots <= 8 && kPlaneB % 32 == 0, "flag bits / operand alignment");
+
+// item -> (sample b, plane group [oz0, oz1), x tile tx); all items of a sample on XCD b % 8 (sample_plane_group's mapping with XT tiles
+// per plane group)
+__device__ __forceinline__ bool item_of(int B, int O2, int XT, int item, int &b, int &oz0, int &oz1, int &tx)
+{
+    const int ng = (O2 + kNP - 1) / kNP, per = ng * XT;
+    const int xcd = item & 7, slot = item >> 3, gi = slot % per;
+    b = (slot / per) * 8 + xcd;
+    tx = gi % XT;
+    oz0 = (gi / XT) * kNP;
+    oz1 = min(O2, oz0 + kNP);
+    return b < B;
+}
+static inline int items(int B, int O2, int XT) { return ((B + 7) / 8) * 8 * ((O2 + kNP - 1) / kNP) * XT; }
+
+// The staging role: one of 512 threads that move the step's 18 new input rows (windows of 33 voxels) through registers into the ring as
+// f16 hi | lo planes of z1 = 2^8 relu(bn1(y1)).  Requests are unconditional (clamped into the sample and the row); a thread whose piece
+// index lies past the step's last piece requests a duplicate and stores nothing.
+struct XStager {
+    const float *ybase;
+    uint32_t rowC, src_off[kSlots], lds_off[kSlots];
+    uint32_t flags;  // bit k: slot k holds a piece; bit 8 + k: it belongs to the step's SECOND row; bit 16 + k: its voxel lies outside the row
+    int O1;
+    float sc[4], sh[4];
+    __device__ __forceinline__ void init(const float *y1, const float *scale1, const float *shift1, int b, int oz0, int npl, int O1_, int x0, int ptid)
+    {
+        const int q = ptid & 3, XH = (O1_ + 1) >> 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            sc[s] = scale1[4 * q + s] * kZScale;
+            sh[s] = shift1[4 * q + s] * kZScale;
+        }
+        O1 = O1_;
+        rowC = 2 * XH * kC;
+        const uint32_t planeC = rowC * O1, parC = XH * kC;
+        flags = 0;
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) {
+            const int f = k * kProdThreads + ptid, live = f < kStepPieces, ff = min(f, kStepPieces - 1);
+            const int rs = ff / kPieces, within = ff - rs * kPieces;  // rs = 2 plane + (row & 1 ^ 1)
+            const int par = within >= kEven, vox = (within - par * kEven) >> 2, slotx = x0 + vox;
+            const int zero = 2 * slotx + par >= O1;
+            src_off[k] = (uint32_t)min(rs >> 1, npl - 1) * planeC + par * parC + (uint32_t)min(slotx, XH - 1) * kC;
+            lds_off[k] = (uint32_t)((rs >> 1) * kRing * kRowBytes + par * kParB + vox * 32 + q * 8);
+            flags |= (uint32_t)live << k | (uint32_t)(rs & 1) << (8 + k) | (uint32_t)zero << (16 + k);
+        }
+        ybase = y1 + ((size_t)b * O1 + 2 * oz0) * planeC + q * 4;
+    }
+    __device__ __forceinline__ void load(float4 (&regs)[kSlots], int j) const
+    {
+        const uint32_t r0 = (uint32_t)min(max(2 * j + 1, 0), O1 - 1) * rowC, r1 = (uint32_t)min(max(2 * j + 2, 0), O1 - 1) * rowC;
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) regs[k] = ld4_nt(ybase + src_off[k] + ((flags >> (8 + k)) & 1 ? r1 : r0));  // (y1 is streamed: read once per launch)
+    }
+    __device__ __forceinline__ void store(char *stage, const float4 (&regs)[kSlots], int j) const
+    {
+        const uint32_t s0 = (uint32_t)(((2 * j + 1 + kRing) % kRing) * kRowBytes), s1 = (uint32_t)(((2 * j + 2 + kRing) % kRing) * kRowBytes);
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) {
+            if (!((flags >> k) & 1)) continue;
+            const bool zero = (flags >> (16 + k)) & 1;
+            const float v[4] = {regs[k].x, regs[k].y, regs[k].z, regs[k].w};
+            h4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 a, c2;
+                split::split2(zero ? 0.0f : __builtin_amdgcn_fmed3f(fmaf(sc[e], v[e], sh[e]), 0.f, kZMax), a, c2);
+                hi[e] = a;
+                lo[e] = c2;
+            }
+            char *dst = stage + lds_off[k] + ((flags >> (8 + k)) & 1 ? s1 : s0);
+            *reinterpret_cast<h4 *>(dst) = hi;
+            *reinterpret_cast<h4 *>(dst + kPlaneB) = lo;
+        }
+    }
+};
+}  // namespace splitx
+
+// ---------------------------------------------------------------------------
+// conv2 forward, one x tile per workgroup (k_conv2_fwd_split's roles: waves 8-15 stage, waves 0-7 compute -- output plane = wave / 2, half
+// of the 14 k-steps each, the odd wave's partial tile handed to the even one through LDS one step later).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(split::kThreads) void k_conv2_fwd_splitx(
+    const float *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1, int B, int O1, int O2, int XT,
+    const uint4 *__restrict__ w2img, const float *__restrict__ b2, float *__restrict__ y2, float *__restrict__ partials)
+{
+    using namespace splitx;
+    extern __shared__ __attribute__((aligned(16))) char split_lds[];
+    char *stage = split_lds;
+    float *red = reinterpret_cast<float *>(split_lds + kStageBytes + kPadBytes);
+    int b, oz0, oz1, tx;
+    const bool live = item_of(B, O2, XT, (int)blockIdx.x, b, oz0, oz1, tx);
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+    if (!live) { write_partials(partials, kWaves, wv, 0.f, 0.f); return; }
+    const int np = oz1 - oz0, npl = 2 * np + 1;
+    float s_sum = 0.0f, s_sq = 0.0f;
+    const int nsteps = (O2 + 2) & ~1;  // O2 compute steps + the deferred epilogue of the last row, rounded up to even
+    if (wv >= kConsWaves) {
+        // ---- staging waves ----
+        XStager zs;
+        zs.init(y1, scale1, shift1, b, oz0, npl, O1, 16 * tx, tid - kConsWaves * kWave);
+        float4 ra[kSlots], rb[kSlots];
+        zs.load(ra, -1);
+        zs.load(rb, 0);
+        zs.store(stage, ra, -1);
+        zs.load(ra, 1);
+        zs.store(stage, rb, 0);
+        zs.load(rb, 2);
+        split_step_barrier();
+        for (int t = 1; t <= nsteps; t += 2) {  // ra holds odd iterations, rb even ones; branch-free around the requests
+            zs.store(stage, ra, t);
+            zs.load(ra, t + 2);
+            split_step_barrier();
+            zs.store(stage, rb, t + 1);
+            zs.load(rb, t + 3);
+            split_step_barrier();
+        }
+    } else {
+        // ---- compute waves ----
+        const int m = lane & 15, g = lane >> 4;
+        const int pl = wv >> 1, kh = wv & 1;
+        h8 wh[kKHalf], wl[kKHalf];
+#pragma unroll
+        for (int s = 0; s < kKHalf; ++s) {
+            const uint4 uh = w2img[((kh * kKHalf + s) * 2 + 0) * 64 + lane], ul = w2img[((kh * kKHalf + s) * 2 + 1) * 64 + lane];
+            wh[s] = *reinterpret_cast<const h8 *>(&uh);
+            wl[s] = *reinterpret_cast<const h8 *>(&ul);
+        }
+        const float bias = b2[m];
+        const int P2 = O2 * O2 * O2;
+        const uint32_t a_lane = (uint32_t)(2 * pl * kRing * kRowBytes + m * 32 + (g & 1) * 16);
+        const bool second = (g >> 1) != 0;  // lanes 32-63 feed the second tap of a k-step
+        f32x4 prev = {0.f, 0.f, 0.f, 0.f};
+        float *const out_base = y2 + ((size_t)b * kC + m) * P2 + (size_t)(oz0 + pl) * O2 * O2 + 16 * tx;
+        split_step_barrier();
+        for (int t = 1; t <= nsteps; ++t) {
+            const int oy = t - 1;
+            if (kh == 0 && pl < np && oy >= 1 && oy - 1 < O2) {
+                const f32x4 other = *reinterpret_cast<const f32x4 *>(red + (((t - 1) & 1) * kNP + pl) * 256 + lane * 4);
+                const f32x4 acc = (prev + other) * (1.0f / (kZScale * kWScale));
+                float *out = out_base + (size_t)(oy - 1) * O2;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int oxi = 4 * g + rr;
+                    if (16 * tx + oxi < O2) {
+                        const float y = acc[rr] + bias;
+                        out[oxi] = y;
+                        s_sum += y;
+                        s_sq += y * y;
+                    }
+                }
+            }
+            if (pl < np && oy < O2) {
+                uint32_t rowoff[3];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) rowoff[dy] = (uint32_t)(((2 * oy + dy) % kRing) * kRowBytes);
+                auto tap_off = [&](int tp) {
+                    const int dz = tp / 9, dy = (tp / 3) % 3, dx = tp % 3;
+                    return (uint32_t)(dz * kRing * kRowBytes + (dx == 1 ? kParB : 0) + (dx == 2 ? 32 : 0)) + rowoff[dy];
+                };
+                auto a_off = [&](int s) {
+                    const uint32_t ta = kh ? tap_off(2 * (kKHalf + s)) : tap_off(2 * s);
+                    const uint32_t tb = kh ? tap_off(min(2 * (kKHalf + s) + 1, kTaps - 1)) : tap_off(2 * s + 1);
+                    return a_lane + (second ? tb : ta);
+                };
+                f32x4 acc_hh = {0.f, 0.f, 0.f, 0.f}, acc_lh = acc_hh, acc_hl = acc_hh;
+                constexpr int kAhead = 2;
+                h8 ah[kAhead + 1], al[kAhead + 1];
+#pragma unroll
+                for (int s = 0; s < kAhead; ++s) {
+                    ah[s] = *reinterpret_cast<const h8 *>(stage + a_off(s));
+                    al[s] = *reinterpret_cast<const h8 *>(stage + a_off(s) + kPlaneB);
+                }
+#pragma unroll
+                for (int s = 0; s < kKHalf; ++s) {
+                    if (s + kAhead < kKHalf) {
+                        ah[(s + kAhead) % (kAhead + 1)] = *reinterpret_cast<const h8 *>(stage + a_off(s + kAhead));
+                        al[(s + kAhead) % (kAhead + 1)] = *reinterpret_cast<const h8 *>(stage + a_off(s + kAhead) + kPlaneB);
+                    }
+                    acc_hh = split::mfma_h(ah[s % (kAhead + 1)], wh[s], acc_hh);
+                    acc_lh = split::mfma_lo(al[s % (kAhead + 1)], wh[s], acc_lh);
+                    acc_hl = split::mfma_lo(ah[s % (kAhead + 1)], wl[s], acc_hl);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const f32x4 part = acc_hh + (acc_lh + acc_hl);
+                if (kh)
+                    *reinterpret_cast<f32x4 *>(red + ((t & 1) * kNP + pl) * 256 + lane * 4) = part;
+                else
+                    prev = part;
+            }
+            split_step_barrier();
+        }
+    }
+    write_partials(partials, kWaves, wv, s_sum, s_sq);
+}
+
+// ---------------------------------------------------------------------------
+// conv2 weight gradient over x tiles (k_conv2_wgrad_split's contraction: every tap belongs to one compute wave, operands through
+// `ds_read_b64_tr_b16`, accumulators in registers).  A workgroup walks items blockIdx.x, + gridDim.x, ... and keeps its accumulators
+// across them -- one partial row per WORKGROUP, so the partial buffer stays at <= 512 rows however many (sample, plane group, tile)
+// items a minibatch has (2 048 at G = 128, batch 128).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_splitx(
+    const float *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1, const float *__restrict__ dy2 /*[B,O2^3,16]*/,
+    const unsigned *__restrict__ absmax, int B, int O1, int O2, int XT, int nitems, float *__restrict__ partial /*[grid][27 * 256 + 16]*/)
+{
+    using namespace splitx;
+    extern __shared__ __attribute__((aligned(16))) char split_lds[];
+    char *stage = split_lds, *dyst = split_lds + kStageBytes + kPadBytes;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+    constexpr int E2 = kTaps * 256 + kC;
+    float *out = partial + (size_t)blockIdx.x * E2;
+    // (stale LDS may hold NaN patterns; the ring is read next to slots not yet written in an item's first steps)
+    for (int i = tid; i < kWgLdsBytes / 16; i += kThreads) reinterpret_cast<uint4 *>(split_lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const int P2 = O2 * O2 * O2;
+    const int nsteps = (O2 + 1) & ~1;
+    const float gs = grad_scale(absmax);
+    // (the two roles walk the items in their own loops, in lock step through the step barriers: with one loop around both, the compute
+    // waves' accumulators are live across the staging code as well, and the staging waves spill)
+    if (wv >= kConsWaves) {
+        // ---- staging waves ----
+        const int ptid = tid - kConsWaves * kWave, pw = wv - kConsWaves;
+        for (int item = (int)blockIdx.x; item < nitems; item += (int)gridDim.x) {
+            int b, oz0, oz1, tx;
+            if (!item_of(B, O2, XT, item, b, oz0, oz1, tx)) continue;  // (workgroup-uniform)
+            const int np = oz1 - oz0, npl = 2 * np + 1;
+            XStager zs;
+            zs.init(y1, scale1, shift1, b, oz0, npl, O1, 16 * tx, ptid);
+            // dy2: thread -> (plane, voxel, channel quad) of the step's rows; the upper four waves request a duplicate they never store
+            const int dpl = (ptid >> 6) & 3, dpiece = ptid & 63, dvox = dpiece >> 2, dxg = 16 * tx + dvox;
+            const bool dvalid = dpl < np && dxg < O2;
+            const float *dsrc = dy2 + ((size_t)b * P2 + (size_t)(oz0 + min(dpl, np - 1)) * O2 * O2 + min(dxg, O2 - 1)) * kC + 4 * (dpiece & 3);
+            auto load_iter = [&](float4 (&regs)[kSlots], float4 &d, int j) {
+                zs.load(regs, j);
+                d = *reinterpret_cast<const float4 *>(dsrc + (size_t)min(max(j, 0), O2 - 1) * O2 * kC);
+            };
+            auto store_iter = [&](const float4 (&regs)[kSlots], const float4 &d, int j) {
+                zs.store(stage, regs, j);
+                if (pw < 4) {
+                    const float v[4] = {d.x, d.y, d.z, d.w};
+                    h4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        _Float16 a, c2;
+                        split::split2(dvalid ? v[e] * gs : 0.0f, a, c2);
+                        hi[e] = a;
+                        lo[e] = c2;
+                    }
+                    char *dst = dyst + ((j & 1) * kNP + dpl) * 1024 + dpiece * 8;
+                    *reinterpret_cast<h4 *>(dst) = hi;
+                    *reinterpret_cast<h4 *>(dst + 512) = lo;
+                }
+            };
+            float4 ra[kSlots], rb[kSlots], da, db;
+            load_iter(ra, da, -1);
+            load_iter(rb, db, 0);
+            store_iter(ra, da, -1);
+            load_iter(ra, da, 1);
+            store_iter(rb, db, 0);
+            load_iter(rb, db, 2);
+            split_step_barrier();
+            for (int t = 1; t <= nsteps; t += 2) {
+                store_iter(ra, da, t);
+                load_iter(ra, da, t + 2);
+                split_step_barrier();
+                store_iter(rb, db, t + 1);
+                load_iter(rb, db, t + 3);
+                split_step_barrier();
+            }
+        }
+    } else {
+        // ---- compute waves ----
+        const int n = lane & 15, g = lane >> 4, cw = wv;
+        const int ntaps = cw < 3 ? 4 : 3;
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        uint32_t tapbase[4];
+        int tapdy[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tp = min(cw + 8 * i, kTaps - 1), dz = tp / 9, dy = (tp / 3) % 3, dx = tp % 3;
+            tapbase[i] = (uint32_t)(dz * kRing * kRowBytes + (dx == 1 ? kParB : 0) + (dx == 2 ? 32 : 0)) + lane * 8;
+            tapdy[i] = dy;
+        }
+        h8 ones;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = (_Float16)1.0f;
+        for (int item = (int)blockIdx.x; item < nitems; item += (int)gridDim.x) {
+            int b, oz0, oz1, tx;
+            if (!item_of(B, O2, XT, item, b, oz0, oz1, tx)) continue;
+            const int np = oz1 - oz0;
+            split_step_barrier();
+            for (int t = 1; t <= nsteps; ++t) {
+                const int oy = t - 1;
+                if (oy < O2) {
+                    uint32_t rowoff[3];
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) rowoff[dy] = (uint32_t)(((2 * oy + dy) % kRing) * kRowBytes);
+                    const char *dybuf = dyst + (oy & 1) * kNP * 1024 + lane * 8;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        if (2 * kb < np) {  // (np = 3: the second block's missing plane is staged as zeros)
+                            const h8 bh = tr_pair(dybuf + (2 * kb) * 1024, dybuf + (2 * kb + 1) * 1024);
+                            const h8 bl = tr_pair(dybuf + (2 * kb) * 1024 + 512, dybuf + (2 * kb + 1) * 1024 + 512);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                if (i < ntaps) {
+                                    const uint32_t off = tapbase[i] + (tapdy[i] == 0 ? rowoff[0] : tapdy[i] == 1 ? rowoff[1] : rowoff[2]);
+                                    const char *a0 = stage + (2 * (2 * kb)) * kRing * kRowBytes + off, *a1 = a0 + 2 * kRing * kRowBytes;
+                                    const h8 ah = tr_pair(a0, a1), al = tr_pair(a0 + kPlaneB, a1 + kPlaneB);
+                                    acc[i] = split::mfma_h(ah, bh, acc[i]);
+                                    acc[i] = split::mfma_lo(al, bh, acc[i]);
+                                    acc[i] = split::mfma_lo(ah, bl, acc[i]);
+                                }
+                            }
+                            if (cw == 7) {
+                                acc[3] = split::mfma_h(ones, bh, acc[3]);
+                                acc[3] = split::mfma_lo(ones, bl, acc[3]);
+                            }
+                        }
+                    }
+                }
+                split_step_barrier();
+            }
+        }
+        const float unscale = (1.0f / kZScale) * inv_pow2(gs);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < ntaps) {
+                const int tp = cw + 8 * i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[tp * 256 + (4 * g + r) * kC + n] = acc[i][r] * unscale;
+            }
+        }
+        if (cw == 7 && g == 0) out[kTaps * 256 + n] = acc[3][0] * inv_pow2(gs);
+    }
+}

@@ -1915,6 +1915,7 @@ __global__ void k_conv1_wgrad_finish(const double *__restrict__ tmp /*[slices][E
 // C-ABI
 // ===========================================================================
 #include "conv_split.h"
+#include "conv_splitx.h"
 
 static inline int out_size(int g) { return (g - 3) / 2 + 1; }
 
@@ -1988,6 +1989,16 @@ static inline bool conv_split_path(const GnbvEncoderParams *p, int grid)
 {
     const int O1 = out_size(grid), O2 = out_size(O1);
     return !env_off("GENNBV_CONV_SPLIT") && !p->force_fp32 && (O1 + 1) / 2 == 16 && O2 <= 15;
+}
+// the same arithmetic for rows wider than 16 voxel slots per x parity (conv_splitx.h: x tiles of 16 outputs, 17-voxel ring rows): the
+// G = 128 class (O1 = 63, O2 = 31); GENNBV_SPLITX=1 also routes the G = 64 class through these kernels (tests)
+static inline bool conv_splitx_path(const GnbvEncoderParams *p, int grid)
+{
+    const int O1 = out_size(grid), O2 = out_size(O1), XH = (O1 + 1) / 2;
+    if (env_off("GENNBV_CONV_SPLIT") || p->force_fp32 || O2 < 1) return false;
+    const char *e = getenv("GENNBV_SPLITX");
+    if (e && e[0] == '0') return false;
+    return (XH > 16 && XH <= 32 && O2 <= 32) || (XH == 16 && O2 <= 15 && e && e[0] == '1');
 }
 // conv2 weight gradient with the LDS-DMA transport (k_conv2_wgrad_split_dma); GENNBV_WGRAD_DMA=1 selects it (A/B switch, round 6)
 static inline bool wgrad_dma_path()
@@ -2159,6 +2170,17 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     if (fused_eval || fused_train) {
         // (y2 was written by k_conv12_fwd_split above)
         g2 = sample_plane_group_grid(batch, O2, split::kNP);
+    } else if (conv_splitx_path(p, grid)) {
+        const int XT = (O2 + 15) / 16;
+        g2 = splitx::items(batch, O2, XT);
+        static bool attr_sx = false;
+        if (!attr_sx) {
+            const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_fwd_splitx, hipFuncAttributeMaxDynamicSharedMemorySize, splitx::kLdsBytes);
+            if (e != hipSuccess) return (int)e;
+            attr_sx = true;
+        }
+        hipLaunchKernelGGL(k_conv2_fwd_splitx, dim3(g2), dim3(split::kThreads), splitx::kLdsBytes, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, XT,
+                           (const uint4 *)w.w2split, p->b2, y2, training ? w.bn_part : nullptr);
     } else if (conv_split_path(p, grid)) {
         // (its weight images, and the data-gradient kernel's, were written by the conv1 kernel in passing)
         g2 = sample_plane_group_grid(batch, O2, split::kNP);
@@ -2252,7 +2274,18 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     int wg_blocks = (nrows2 + kEncWaves - 1) / kEncWaves;
     wg_blocks = wg_blocks > 512 ? 512 : ((wg_blocks + 7) & ~7);
     const bool split_bwd = conv_split_path(p, grid);
-    if (split_bwd) {
+    if (conv_splitx_path(p, grid)) {
+        static bool attr_wx = false;
+        if (!attr_wx) {
+            const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_wgrad_splitx, hipFuncAttributeMaxDynamicSharedMemorySize, splitx::kWgLdsBytes);
+            if (e != hipSuccess) return (int)e;
+            attr_wx = true;
+        }
+        const int XT = (O2 + 15) / 16, nitems = splitx::items(batch, O2, XT);
+        wg_blocks = nitems > 512 ? 512 : nitems;  // (a workgroup keeps its accumulators across its items: <= 512 partial rows)
+        hipLaunchKernelGGL(k_conv2_wgrad_splitx, dim3(wg_blocks), dim3(split::kThreads), splitx::kWgLdsBytes, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch,
+                           (const unsigned *)dy2_absmax, batch, O1, O2, XT, nitems, w.wg_part);
+    } else if (split_bwd) {
         static bool attr_wg = false;
         if (!attr_wg) {
             const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_wgrad_split, hipFuncAttributeMaxDynamicSharedMemorySize, split::kWgLdsBytes);

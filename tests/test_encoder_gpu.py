@@ -50,17 +50,22 @@ def _obs_clear_of_the_relu_threshold(ref, b, g):
     raise AssertionError("no clean seed")
 
 
-@pytest.mark.parametrize("conv2", ["fp32", "split"])
-@pytest.mark.parametrize("g,b", [(20, 8), (16, 5), (33, 3), (64, 4), (128, 1), (64, 128)])  # last: the bench's minibatch
+@pytest.mark.parametrize("conv2", ["fp32", "split", "splitx"])
+@pytest.mark.parametrize("g,b", [(20, 8), (16, 5), (33, 3), (64, 4), (128, 1), (128, 3), (64, 128)])  # last: the bench's minibatch
 def test_encoder_forward_backward_vs_torch_reference(g, b, conv2, monkeypatch):
     """Reference = the same torch modules in fp64 on the CPU (ground truth), tolerance = fp32 round-off.
     (torch-GPU fp32 is NOT used as the reference: MIOpen's conv/BN backward is off by 0.7-4.6 % at
     G=64 against fp64, tools/check_conv_grads.py; the hand-written kernels are within 1e-6.)
     conv2 = "split": the conv2 kernels on the f16 matrix pipe with split (hi + lo) operands (csrc/conv_split.h; G = 64, the
-    default there) -- SAME tolerances as the fp32-MFMA kernels, which conv2 = "fp32" (GENNBV_CONV_SPLIT=0) keeps covered."""
-    if conv2 == "split" and g != 64:
-        pytest.skip("the split kernels cover G = 64 (16 voxel slots per half row)")
-    monkeypatch.setenv("GENNBV_CONV_SPLIT", "1" if conv2 == "split" else "0")
+    default there) -- SAME tolerances as the fp32-MFMA kernels, which conv2 = "fp32" (GENNBV_CONV_SPLIT=0) keeps covered.
+    conv2 = "splitx": the x-tiled kernels of csrc/conv_splitx.h (17-voxel ring rows) -- what G = 128 runs by default (there "split" and
+    "splitx" are the same path, so only "split" is kept), and at G = 64 the same kernels with one tile per row (GENNBV_SPLITX=1)."""
+    if conv2 != "fp32" and g not in (64, 128):
+        pytest.skip("the split kernels cover the G = 64 class (16 voxel slots per half row) and, x-tiled, the G = 128 class")
+    if (conv2 == "splitx" and g == 128) or ((g, b) == (128, 3) and conv2 == "fp32"):
+        pytest.skip("covered by the neighbouring case")
+    monkeypatch.setenv("GENNBV_CONV_SPLIT", "0" if conv2 == "fp32" else "1")
+    monkeypatch.setenv("GENNBV_SPLITX", "1" if conv2 == "splitx" else "")
     hip, _, _ = pu.make_policy(g=g, device=DEV, backend="hip", det_weights=True)
     ref, _, _ = pu.make_policy(g=g, device="cpu", backend="torch", det_weights=True)
     ref = ref.double()

@@ -10,6 +10,7 @@ case $st in
              GENNBV_WGRAD_DMA=1 timeout 900 python -m pytest tests/test_encoder_gpu.py -m gpu -q --maxfail=4 -k "forward_backward_vs_torch or fused_dgrad" -p no:cacheprovider 2>&1 | tail -5 ;;
   convdma)   cd /tmp && export TMPDIR=/tmp; for v in 0 1; do rm -rf /tmp/prof_c; GENNBV_WGRAD_DMA=$v rocprofv3 --kernel-trace --stats -d /tmp/prof_c -- python $GRAFT_REPO_ROOT/tools/microbench_conv.py > /tmp/prof_c.log 2>&1; echo "== GENNBV_WGRAD_DMA=$v"; tail -1 /tmp/prof_c.log; python $GRAFT_REPO_ROOT/tools/rocprof_summary.py /tmp/prof_c | grep -E "wgrad|reduce|finish|dgrad|conv12" | cut -c1-150; done | tee $O/r06_conv_wgrad_dma_trace.txt; cd $GRAFT_REPO_ROOT ;;
   abdma)     timeout 1500 python tools/ab_interleaved.py --what train --captures 3 --variant base --variant "dma:GENNBV_WGRAD_DMA=1" --rounds 8 --json $O/r06_ab_train_wgrad_dma.json 2>&1 | grep -v "^\[ab\]" | tail -12 ;;
+  abl)       cd /tmp && export TMPDIR=/tmp; for v in ${ABL_LIBS:-"" _abl_NOCONV _abl_NOCOMP _abl_NODMA _abl_NOCONV_NOCOMP}; do rm -rf /tmp/prof_c; GENNBV_HIP_LIB=$GRAFT_REPO_ROOT/gennbv_amd/libgennbv_hip$v.so GENNBV_WGRAD_DMA=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_c -- python $GRAFT_REPO_ROOT/tools/microbench_conv.py > /tmp/prof_c.log 2>&1; echo "== lib$v"; python $GRAFT_REPO_ROOT/tools/rocprof_summary.py /tmp/prof_c | grep -E "wgrad_split|dgrad_c1w|conv12" | cut -c1-150; done | tee $O/${ABL_OUT:-r06_wgrad_dma_ablation.txt}; cd $GRAFT_REPO_ROOT ;;
   tests)     timeout 1500 python -m pytest tests -m gpu -q --maxfail=12 --durations=12 -p no:cacheprovider > $O/r6_tests.log 2>&1; tail -30 $O/r6_tests.log ;;
   bench)     timeout 900 python bench.py --steps 5 --warmup 2 2>$O/r6_bench.err | tail -1 > $O/r6_bench_n1.json; cut -c1-900 $O/r6_bench_n1.json ;;
   benchdrv)  timeout 1200 python bench.py --steps 20 --warmup 5 2>$O/r6_benchdrv.err | tail -1 > $O/r6_bench_driver_cfg_n1.json; cut -c1-600 $O/r6_bench_driver_cfg_n1.json ;;
