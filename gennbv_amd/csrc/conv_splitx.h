@@ -367,3 +367,242 @@ __global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_splitx(
         if (cw == 7 && g == 0) out[kTaps * 256 + n] = acc[3][0] * inv_pow2(gs);
     }
 }
+
+// ---------------------------------------------------------------------------
+// conv2 data gradient + conv1 weight gradient over x tiles: k_conv2_dgrad_c1w_split's workgroup (12 compute waves = 4 plane pairs x 3 class
+// sets, 4 staging waves, the same super-tile arithmetic: dgrad_split_supertile is called unchanged with the row length counted from the
+// tile's first voxel) for rows of more than 16 voxels per x parity.  A tile = layer-1 voxels x = 2 (16 tx + j) + ex, j = 0 .. 15:
+//   * y1: the window of 16 slots per parity from slot 16 tx (the 80-byte-stride fp32 image of the step's 16 rows, as before);
+//   * dy2: the class taps read output voxels 16 tx + j - xo, xo in {0, 1}: voxels 16 tx - 1 .. 16 tx + 15 -- position 0 of a staged dy2 row,
+//     a structural zero at G = 64, is the LEFT NEIGHBOUR's last voxel for tx > 0.  It and position 17 are staged by the 40 threads of the
+//     second dy2 request that used to fetch duplicates (5 planes x 2 sides x 4 channel quads), zero where outside the row;
+//   * the int8 input slab: bytes 64 tx .. 64 tx + 79 of a row (FIVE 16-byte pieces: input x = 4 j + 2 ex + dx reaches 64 tx + 64 for a
+//     valid voxel when the row goes on), 425 pieces over the 768 compute lanes.
+// A workgroup walks items blockIdx.x, + gridDim.x, ... and keeps T1 / S1 / S2 across them (one partial row per workgroup); the dy2 ring is
+// cleared between items (an item's row -1 is a ring slot nobody stages).
+// ---------------------------------------------------------------------------
+namespace dsplitx {
+using namespace dsplit;
+constexpr int kSlabPiecesX = kSlabPlanes * 5 * 5;  // 425
+static_assert(kSlabPiecesX <= kConsWaves * kWave, "one slab request per compute lane");
+__device__ __forceinline__ bool item_of(int B, int NA, int XT, int item, int &b, int &a0, int &a1, int &tx)
+{
+    const int ng = (NA + kPairs - 1) / kPairs, per = ng * XT;
+    const int xcd = item & 7, slot = item >> 3, gi = slot % per;
+    b = (slot / per) * 8 + xcd;
+    tx = gi % XT;
+    a0 = (gi / XT) * kPairs;
+    a1 = min(NA, a0 + kPairs);
+    return b < B;
+}
+static inline int items(int B, int NA, int XT) { return ((B + 7) / 8) * 8 * ((NA + kPairs - 1) / kPairs) * XT; }
+}  // namespace dsplitx
+
+__global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_splitx(
+    const float *__restrict__ dy2, const uint4 *__restrict__ w2img /*prep_w2_dgrad_split_item*/, const float *__restrict__ wbound /*[8 classes][16 ci]*/,
+    const unsigned *__restrict__ absmax, const float *__restrict__ y1,
+    const float *__restrict__ scale1, const float *__restrict__ shift1, const float *__restrict__ mean1, const float *__restrict__ rstd1,
+    const int8_t *__restrict__ grid_i8, const int64_t *__restrict__ rows, int64_t grid_row_stride, int B, int G, int O1, int O2, int XT, int nitems,
+    float *__restrict__ partial /*[grid][kE1F]*/)
+{
+    using namespace dsplitx;
+    extern __shared__ __attribute__((aligned(16))) char split_lds[];
+    char *ybufs = split_lds, *dyst = split_lds + 2 * kYBuf, *slabs = dyst + kDyBytes;
+    uint4 *wlds = reinterpret_cast<uint4 *>(slabs + 2 * kSlabBuf);
+    const int NA = (O1 + 1) >> 1, XH = NA;  // plane pairs / row pairs; voxel slots per x parity of a y1 row
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int m = lane & 15, kq = lane >> 4;
+    float s1 = 0.f, s2 = 0.f, t1_unscale = 0.0f, g_unscale = 0.0f;
+    f32x4 T1a = {0.f, 0.f, 0.f, 0.f}, T1b = T1a;
+    for (int i = tid; i < (kLdsBytes - kImgBytes) / 16; i += kThreads) reinterpret_cast<uint4 *>(split_lds)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < kImgBytes / 16; i += kThreads) wlds[i] = w2img[i];
+    __syncthreads();
+    const int nsteps = (NA + 1) & ~1;  // row pairs, rounded up to even (the staging loop advances by two)
+    const float gs = grad_scale(absmax);
+    const int P2 = O2 * O2 * O2;
+    bool first = true;
+    for (int item = (int)blockIdx.x; item < nitems; item += (int)gridDim.x) {
+        int b, a0, a1, tx;
+        if (!item_of(B, NA, XT, item, b, a0, a1, tx)) continue;  // (workgroup-uniform)
+        const int x0 = 16 * tx;
+        if (!first) {
+            // the previous item's dy2 rows must not be read as this item's rows -1 / as planes it does not stage
+            __syncthreads();
+            for (int i = tid; i < kDyBytes / 16; i += kThreads) reinterpret_cast<uint4 *>(dyst)[i] = make_uint4(0, 0, 0, 0);
+            __syncthreads();
+        }
+        first = false;
+        if (wv >= kConsWaves) {
+            // ---- staging waves ----
+            const int ptid = tid - kConsWaves * kWave;
+            const uint32_t rowC = 2 * XH * kC, planeC = rowC * O1, parC = XH * kC;
+            const uint32_t within = ptid & 127, wpar = within >> 6, wvox = (within >> 2) & 15;
+            const float *ybase = y1 + (size_t)b * O1 * planeC + wpar * parC + (uint32_t)min(x0 + (int)wvox, XH - 1) * kC + (within & 3) * 4;
+            const uint32_t yst = wpar * kYHalf + wvox * kYVox + (within & 3) * 16;
+            // dy2 request k = 0: plane ptid >> 6 (0 .. 3), voxel x0 + (piece >> 2) at position (piece >> 2) + 1; request k = 1: threads 0 .. 63 the
+            // same for plane 4, threads 64 .. 103 the two halo voxels (positions 0 and 17) of the five planes
+            const int dpiece = ptid & 63;
+            const int hh = min(max(ptid - 64, 0), 39);
+            const bool halo = ptid >= 64;
+            const int dpl1 = halo ? hh >> 3 : 4, dpos1 = halo ? ((hh >> 2) & 1) * 17 : (dpiece >> 2) + 1, dq1 = halo ? hh & 3 : dpiece & 3;
+            const bool dlive1 = ptid < 104;
+            auto dy_req = [&](int k, int c) {
+                const int dpl = k == 0 ? ptid >> 6 : dpl1, pos = k == 0 ? (dpiece >> 2) + 1 : dpos1, dq = k == 0 ? dpiece & 3 : dq1;
+                const int doz = a0 - 1 + dpl, gx = x0 + pos - 1;
+                return *reinterpret_cast<const float4 *>(dy2 + ((size_t)b * P2 + ((size_t)min(max(doz, 0), O2 - 1) * O2 + min(max(c, 0), O2 - 1)) * O2 + min(max(gx, 0), O2 - 1)) * kC + 4 * dq);
+            };
+            auto dy_store = [&](int k, const float4 &d, int c) {
+                const int dpl = k == 0 ? ptid >> 6 : dpl1, pos = k == 0 ? (dpiece >> 2) + 1 : dpos1, dq = k == 0 ? dpiece & 3 : dq1;
+                const int doz = a0 - 1 + dpl, gx = x0 + pos - 1;
+                if (k == 0 || dlive1) {
+                    const float v[4] = {d.x, d.y, d.z, d.w};
+                    const bool ok = doz >= 0 && doz < O2 && gx >= 0 && gx < O2 && c >= 0 && c < O2;
+                    h4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        _Float16 a, c2;
+                        split::split2(ok ? v[e] * gs : 0.0f, a, c2);
+                        hi[e] = a;
+                        lo[e] = c2;
+                    }
+                    char *dst = dyst + (dpl * kDyRing + (c + kDyRing) % kDyRing) * kDyRow + pos * 32 + dq * 8;
+                    *reinterpret_cast<h4 *>(dst) = hi;
+                    *reinterpret_cast<h4 *>(dst + kDyHalf) = lo;
+                }
+            };
+            auto y_req = [&](int k, int c) {
+                const int rowid = 2 * k + (ptid >> 7), pl = 2 * a0 + (rowid >> 1), row = 2 * c + (rowid & 1);  // (wave-uniform)
+                return ld4_nt(ybase + (uint32_t)min(pl, O1 - 1) * planeC + (uint32_t)min(max(row, 0), O1 - 1) * rowC);
+            };
+            auto y_store = [&](int k, const float4 &v, int c) { *reinterpret_cast<float4 *>(ybufs + (c & 1) * kYBuf + (2 * k + (ptid >> 7)) * kYRow + yst) = v; };
+            struct StepRegs { float4 y0, y1, y2, y3, y4, y5, y6, y7, d0, d1; };
+#define GNBV_DX_LOAD(R, C)                                                                                                      \
+    {                                                                                                                           \
+        R.y0 = y_req(0, (C)); R.y1 = y_req(1, (C)); R.y2 = y_req(2, (C)); R.y3 = y_req(3, (C));                                   \
+        R.y4 = y_req(4, (C)); R.y5 = y_req(5, (C)); R.y6 = y_req(6, (C)); R.y7 = y_req(7, (C));                                   \
+        R.d0 = dy_req(0, (C)); R.d1 = dy_req(1, (C));                                                                             \
+    }
+#define GNBV_DX_STORE(R, C)                                                                                                     \
+    {                                                                                                                           \
+        y_store(0, R.y0, (C)); y_store(1, R.y1, (C)); y_store(2, R.y2, (C)); y_store(3, R.y3, (C));                               \
+        y_store(4, R.y4, (C)); y_store(5, R.y5, (C)); y_store(6, R.y6, (C)); y_store(7, R.y7, (C));                               \
+        dy_store(0, R.d0, (C)); dy_store(1, R.d1, (C));                                                                           \
+    }
+            StepRegs ra, rb;
+            GNBV_DX_LOAD(ra, 0);
+            GNBV_DX_LOAD(rb, 1);
+            GNBV_DX_STORE(ra, 0);
+            GNBV_DX_LOAD(ra, 2);
+            split_step_barrier();
+            for (int c = 0; c < nsteps; c += 2) {
+                GNBV_DX_STORE(rb, c + 1);
+                GNBV_DX_LOAD(rb, c + 3);
+                split_step_barrier();
+                GNBV_DX_STORE(ra, c + 2);
+                GNBV_DX_LOAD(ra, c + 4);
+                split_step_barrier();
+            }
+#undef GNBV_DX_LOAD
+#undef GNBV_DX_STORE
+        } else {
+            // ---- compute waves ----
+            const int cw = wv, ai = cw / kSets, ty = cw - ai * kSets, a = a0 + ai;
+            float wb = fmaxf(wbound[lane], wbound[64 + lane]);
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) wb = fmaxf(wb, __shfl_xor(wb, d, 64));
+            int we = 0;
+            (void)frexpf(fmaxf(wb, 1.0e-30f), &we);  // wb < 2^we
+            we = __builtin_amdgcn_readfirstlane(we);
+            const float gscale = ldexpf(1.0f, -(10 + we));
+            t1_unscale = ldexpf(1.0f, we) * inv_pow2(gs);
+            g_unscale = t1_unscale;
+            const uint4 *wimg = wlds + ty * kKSteps * 2 * 64 + lane;
+            const float sc = scale1[m], sh = shift1[m];
+            const bool tok1 = 16 + m < kTaps;
+            const int t1 = tok1 ? 16 + m : 0;
+            const int8_t *slab = reinterpret_cast<const int8_t *>(slabs) + ai * (4 * 5 * kSlabRow);
+            const int8_t *slab0 = slab + ((m / 9) * 5 + (m / 3) % 3) * kSlabRow + m % 3 + 16 * kq;
+            const int8_t *slab1 = slab + ((t1 / 9) * 5 + (t1 / 3) % 3) * kSlabRow + t1 % 3 + 16 * kq;
+            const int8_t *in = grid_i8 + (rows ? rows[b] : (int64_t)b) * grid_row_stride;
+            const int g3m16 = G * G * G - 16;
+            const int sp = min(cw * kWave + lane, kSlabPiecesX - 1), srow = sp / 5, spc = sp - 5 * srow, szr = srow / 5, syr = srow - 5 * szr;
+            const int sbase = min(4 * a0 + szr, G - 1) * G * G + min(64 * tx + 16 * spc, G - 16);
+            char *sdst = slabs + srow * kSlabRow + 16 * spc;
+            auto slab_req = [&](int c) { return ldu4_nt(in + min(sbase + min(4 * c + syr, G - 1) * G, g3m16)); };
+            uint4 sv = slab_req(0);
+            *reinterpret_cast<uint4 *>(sdst) = sv;
+            sv = slab_req(1);
+            const bool z1ok = 2 * a + 1 < O1 && a < a1;
+            const bool pair_ok = a < a1;  // (the last plane group of a sample may hold fewer than four pairs)
+            const int O1x = O1 - 2 * x0;  // the row's length counted from the tile's first voxel: x = 2 (x0 + j) + ex < O1
+            split_step_barrier();
+            auto run = [&](auto ty_c) {
+                constexpr int TY = decltype(ty_c)::value;
+                for (int c = 0; c < nsteps; ++c) {
+                    *reinterpret_cast<uint4 *>(sdst + ((c + 1) & 1) * kSlabBuf) = sv;
+                    sv = slab_req(c + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bool y0ok = pair_ok && 2 * c < O1, y1ok = pair_ok && 2 * c + 1 < O1;
+                    const char *ybuf = ybufs + (c & 1) * kYBuf;
+                    const int sboff = (c & 1) * kSlabBuf;
+                    dgrad_split_supertile<TY>(dyst, ybuf, slab0 + sboff, slab1 + sboff, wimg, ai, c, z1ok, y0ok, y1ok, O1x, tok1, sc, sh, gscale, s2, T1a, T1b);
+                    split_step_barrier();
+                }
+            };
+            if (ty == 0)
+                run(std::integral_constant<int, 0>{});
+            else if (ty == 1)
+                run(std::integral_constant<int, 1>{});
+            else
+                run(std::integral_constant<int, 2>{});
+        }
+    }
+    // ---- workgroup-level sums: binary tree over the 16 waves (the staging waves add zeros; fixed order -> deterministic) ----
+    T1a *= t1_unscale;
+    T1b *= t1_unscale;
+    s1 = __shfl(T1b[3], 32 + m, 64);
+    s2 = kgroup_sum(s2) * g_unscale;
+    if (wv < kConsWaves) s2 = rstd1[m] * (s2 - mean1[m] * s1);
+    if (kq != 0) s1 = 0.0f;
+    s1 = kgroup_sum(s1);
+    if (kq == 2) T1b[3] = 0.0f;  // (row 27 is not a tap)
+    __syncthreads();
+    constexpr int kSlot = 2 * kWave * 4 + 2 * kC;
+    float *red = reinterpret_cast<float *>(split_lds);
+#pragma unroll
+    for (int half = kThreads / kWave / 2; half >= 1; half >>= 1) {
+        if (wv >= half && wv < 2 * half) {
+            float *slot = red + (wv - half) * kSlot;
+            reinterpret_cast<f32x4 *>(slot)[lane] = T1a;
+            reinterpret_cast<f32x4 *>(slot)[kWave + lane] = T1b;
+            if (lane < kC) {
+                slot[2 * kWave * 4 + lane] = s1;
+                slot[2 * kWave * 4 + kC + lane] = s2;
+            }
+        }
+        __syncthreads();
+        if (wv < half) {
+            const float *slot = red + wv * kSlot;
+            T1a += reinterpret_cast<const f32x4 *>(slot)[lane];
+            T1b += reinterpret_cast<const f32x4 *>(slot)[kWave + lane];
+            s1 += slot[2 * kWave * 4 + m];
+            s2 += slot[2 * kWave * 4 + kC + m];
+        }
+        __syncthreads();
+    }
+    float *fin = red + 16 * kSlot;
+    if (wv == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            fin[(4 * kq + r) * kC + m] = T1a[r];
+            fin[(16 + 4 * kq + r) * kC + m] = T1b[r];
+        }
+        if (lane < kC) {
+            fin[512 + lane] = s1;
+            fin[512 + kC + lane] = s2;
+        }
+    }
+    __syncthreads();
+    float *out = partial + (size_t)blockIdx.x * kE1F;
+    for (int o = tid; o < kE1F; o += kThreads) out[o] = fin[o];
+}

@@ -2000,6 +2000,14 @@ static inline bool conv_splitx_path(const GnbvEncoderParams *p, int grid)
     if (e && e[0] == '0') return false;
     return (XH > 16 && XH <= 32 && O2 <= 32) || (XH == 16 && O2 <= 15 && e && e[0] == '1');
 }
+// most workgroups of the x-tiled backward kernels (each walks items block, block + grid, ...); GENNBV_SPLITX_MAXWG lowers it so that small
+// test shapes exercise the several-items-per-workgroup path
+static inline int splitx_max_wg()
+{
+    const char *e = getenv("GENNBV_SPLITX_MAXWG");
+    const int v = e ? atoi(e) : 0;
+    return v >= 8 && v <= 512 ? (v & ~7) : 512;
+}
 // conv2 weight gradient with the LDS-DMA transport (k_conv2_wgrad_split_dma); GENNBV_WGRAD_DMA=1 selects it (A/B switch, round 6)
 static inline bool wgrad_dma_path()
 {
@@ -2282,7 +2290,7 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
             attr_wx = true;
         }
         const int XT = (O2 + 15) / 16, nitems = splitx::items(batch, O2, XT);
-        wg_blocks = nitems > 512 ? 512 : nitems;  // (a workgroup keeps its accumulators across its items: <= 512 partial rows)
+        wg_blocks = min(nitems, splitx_max_wg());  // (a workgroup keeps its accumulators across its items: <= 512 partial rows)
         hipLaunchKernelGGL(k_conv2_wgrad_splitx, dim3(wg_blocks), dim3(split::kThreads), splitx::kWgLdsBytes, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch,
                            (const unsigned *)dy2_absmax, batch, O1, O2, XT, nitems, w.wg_part);
     } else if (split_bwd) {
@@ -2324,9 +2332,22 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
         if ((err = gnbv_launch_status())) return err;
     }
     // ---- conv2 data gradient (+ ReLU1 mask, BN1 backward sums) ----
-    const int gd = sample_plane_group_grid(batch, (O1 + 1) / 2, kPlanesPerGroup);  // groups of plane PAIRS
+    int gd = sample_plane_group_grid(batch, (O1 + 1) / 2, kPlanesPerGroup);  // groups of plane PAIRS
     if (fused) {
-        if (split_bwd) {
+        if (conv_splitx_path(p, grid)) {
+            static bool attr_dx = false;
+            if (!attr_dx) {
+                const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_dgrad_c1w_splitx, hipFuncAttributeMaxDynamicSharedMemorySize, dsplit::kLdsBytes);
+                if (e != hipSuccess) return (int)e;
+                attr_dx = true;
+            }
+            const int NA = (O1 + 1) / 2, XT = (NA + 15) / 16, nitems = dsplitx::items(batch, NA, XT);
+            gd = min(nitems, splitx_max_wg());  // (T1 / S1 / S2 are kept across a workgroup's items: <= 512 partial rows)
+            hipLaunchKernelGGL(k_conv2_dgrad_c1w_splitx, dim3(gd), dim3(dsplit::kThreads), dsplit::kLdsBytes, st, dy2_scratch, (const uint4 *)(w.w2split + split::kW2ImgU4),
+                               (const float *)(w.w2split + split::kW2ImgU4 + dsplit::kImgSlotU4),
+                               (const unsigned *)dy2_absmax, (const float *)y1, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->grid_i8, rows, p->grid_i8_row_stride,
+                               batch, grid, O1, O2, XT, nitems, wg1_part);
+        } else if (split_bwd) {
             static bool attr_dg = false;
             if (!attr_dg) {
                 const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_dgrad_c1w_split, hipFuncAttributeMaxDynamicSharedMemorySize, dsplit::kLdsBytes);
