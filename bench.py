@@ -324,6 +324,7 @@ def encoder_roofline(algo, args, device, iters: int = 200, warm_ms: float = 150.
     y2 = b * o2 ** 3 * 16 * 4
     fused = gi8 is not None and g % 16 == 0
     split = fused and (o1 + 1) // 2 == 16 and os.environ.get("GENNBV_CONV_SPLIT", "1") != "0"
+    splitx = fused and 16 < (o1 + 1) // 2 <= 32 and o2 <= 32 and os.environ.get("GENNBV_CONV_SPLIT", "1") != "0"  # (csrc/conv_splitx.h: G = 128 class)
     # conv1 + conv2 forward as ONE launch (BN1 statistics known beforehand from the autocorrelation rows): y1 is written once and
     # read by the two backward kernels only
     one_fwd = split and ac is not None and g == 64 and all(os.environ.get(k, "1") != "0" for k in ("GENNBV_FUSED_TRAIN", "GENNBV_CONV1_SPLIT", "GENNBV_ANALYTIC_BN1"))
@@ -332,13 +333,14 @@ def encoder_roofline(algo, args, device, iters: int = 200, warm_ms: float = 150.
     return {"kernel": "conv stack of one PPO minibatch: gnbv_encoder_grid_forward + _backward (" +
                       ("k_conv12_fwd_split<true>, k_conv2_wgrad_split, k_conv2_dgrad_c1w_split" if one_fwd else
                        "k_conv1_fwd_split, k_conv2_fwd_split, k_conv2_wgrad_split, k_conv2_dgrad_c1w_split" if split else
+                       "k_conv1_fwd_lds, k_conv2_fwd_splitx, k_conv2_wgrad_splitx, k_conv2_dgrad_c1w_splitx" if splitx else
                        "k_conv1_fwd_lds, k_conv2_fwd, k_conv2_wgrad, k_conv2_dgrad_c1w" if fused else
                        "k_conv1_fwd_lds, k_conv2_fwd, k_conv2_wgrad, k_conv2_dgrad, k_conv1_wgrad_lds") +
                       " + BN / reduction launches)",
-            "bound": "hbm" if split else "mfma",
+            "bound": "hbm" if (split or splitx) else "mfma",
             "note": ("the split kernels stream at 3-4.5 TB/s each but are NOT byte-bound: letting the two backward kernels share y1 through L2 "
                      "removed 184 MB of HBM reads per minibatch and no time (round-3 experiment, profiles/r03_notes.md); both roofs are context")
-                    if split else None,
+                    if (split or splitx) else None,
             "ms": ms, "ms_spread": spread, "unstable": spread["unstable"], "batch": b, "grid_input": "fp32 rows" if gi8 is None else "int8 copy", "algorithmic_flops": flops,
             "algorithmic_bytes": nbytes,
             "mfma": {"achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "dtype": "f32"},

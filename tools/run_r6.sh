@@ -11,6 +11,12 @@ case $st in
   convdma)   cd /tmp && export TMPDIR=/tmp; for v in 0 1; do rm -rf /tmp/prof_c; GENNBV_WGRAD_DMA=$v rocprofv3 --kernel-trace --stats -d /tmp/prof_c -- python $GRAFT_REPO_ROOT/tools/microbench_conv.py > /tmp/prof_c.log 2>&1; echo "== GENNBV_WGRAD_DMA=$v"; tail -1 /tmp/prof_c.log; python $GRAFT_REPO_ROOT/tools/rocprof_summary.py /tmp/prof_c | grep -E "wgrad|reduce|finish|dgrad|conv12" | cut -c1-150; done | tee $O/r06_conv_wgrad_dma_trace.txt; cd $GRAFT_REPO_ROOT ;;
   abdma)     timeout 1500 python tools/ab_interleaved.py --what train --captures 3 --variant base --variant "dma:GENNBV_WGRAD_DMA=1" --rounds 8 --json $O/r06_ab_train_wgrad_dma.json 2>&1 | grep -v "^\[ab\]" | tail -12 ;;
   abl)       cd /tmp && export TMPDIR=/tmp; for v in ${ABL_LIBS:-"" _abl_NOCONV _abl_NOCOMP _abl_NODMA _abl_NOCONV_NOCOMP}; do rm -rf /tmp/prof_c; GENNBV_HIP_LIB=$GRAFT_REPO_ROOT/gennbv_amd/libgennbv_hip$v.so GENNBV_WGRAD_DMA=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_c -- python $GRAFT_REPO_ROOT/tools/microbench_conv.py > /tmp/prof_c.log 2>&1; echo "== lib$v"; python $GRAFT_REPO_ROOT/tools/rocprof_summary.py /tmp/prof_c | grep -E "wgrad_split|dgrad_c1w|conv12" | cut -c1-150; done | tee $O/${ABL_OUT:-r06_wgrad_dma_ablation.txt}; cd $GRAFT_REPO_ROOT ;;
+  config5)   timeout 1500 python bench.py --steps 1 --warmup 1 --envs 512 --grid 128 --no-cpu-baseline --no-flat-rows 2>$O/r6_config5.err | tail -1 > $O/r06_bench_config5_shard_n1.json; python - <<PY
+import json
+d=json.load(open("$O/r06_bench_config5_shard_n1.json")); print("config5", round(d["value"]), "env-steps/s", d["breakdown_ms_per_step"], d["train_roofline"]["ms_per_minibatch"], d.get("timed_state_check"), d.get("encoder_roofline",{}).get("ms"))
+PY
+             ;;
+  t_g128)    timeout 900 python -m pytest tests/test_ppo_g64_gpu.py -m gpu -q -x -k "g128" -p no:cacheprovider 2>&1 | tail -3 ;;
   tests)     timeout 1500 python -m pytest tests -m gpu -q --maxfail=12 --durations=12 -p no:cacheprovider > $O/r6_tests.log 2>&1; tail -30 $O/r6_tests.log ;;
   bench)     timeout 900 python bench.py --steps 5 --warmup 2 2>$O/r6_bench.err | tail -1 > $O/r6_bench_n1.json; cut -c1-900 $O/r6_bench_n1.json ;;
   benchdrv)  timeout 1200 python bench.py --steps 20 --warmup 5 2>$O/r6_benchdrv.err | tail -1 > $O/r6_bench_driver_cfg_n1.json; cut -c1-600 $O/r6_bench_driver_cfg_n1.json ;;
