@@ -665,6 +665,11 @@ def main():
                      "traffic": traffic, "traffic_source": traffic_src},
     }
     if dist.is_initialized():
+        try:  # (every rank: collectives) what the step's exchanges cost by themselves on this node -- ring or direct, answered by the numbers
+            from gennbv_amd import parallel as _par
+            out["dp_exchange_probe"] = _par.exchange_probe(algo)
+        except Exception as ex:
+            out["dp_exchange_probe"] = {"error": repr(ex)}
         # Everything timed is done and reduced: the process group goes away NOW, so that ranks > 0 exit instead of sitting in a
         # collective teardown while rank 0 spends seconds in the CPU-side checks below (none of them communicates).
         barrier()

@@ -2008,11 +2008,12 @@ static inline int splitx_max_wg()
     const int v = e ? atoi(e) : 0;
     return v >= 8 && v <= 512 ? (v & ~7) : 512;
 }
-// conv2 weight gradient with the LDS-DMA transport (k_conv2_wgrad_split_dma); GENNBV_WGRAD_DMA=1 selects it (A/B switch, round 6)
+// conv2 weight gradient with the LDS-DMA transport (k_conv2_wgrad_split_dma, round 6): the default at G = 64 -- bit-identical to the
+// register-staged k_conv2_wgrad_split, which GENNBV_WGRAD_DMA=0 keeps selectable (A/B runs, tests/test_encoder_gpu.py)
 static inline bool wgrad_dma_path()
 {
     const char *e = getenv("GENNBV_WGRAD_DMA");
-    return e && e[0] == '1';
+    return !(e && e[0] == '0');
 }
 static inline bool fused_path(const GnbvEncoderParams *p, int grid)
 {

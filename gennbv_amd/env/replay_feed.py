@@ -141,7 +141,7 @@ class ReplayFeedEnv:
         # step that produced it (the time-out bootstrap) and is STATEFUL on the device (the reference only refreshes it on steps with a
         # reset): one buffer, and a reader that keeps infos["time_outs"] across env steps must copy it.
         self.flag_views = False
-        self.fused_observe = os.environ.get("GENNBV_FUSED_OBSERVE", "1") != "0"  # pre-step + both observation slices as one launch; =0: A/B runs / tests
+        self.fused_observe = True  # pre-step + both observation slices as one launch (False: the three separate entry points, kept covered by tests/test_envstep_gpu.py)
         self._reset_bufs = (self.reset_buf, z(n, dt=torch.uint8))
         self._reset_turn = 0
         self.reset_mask = torch.ones(n, dtype=torch.uint8, device=dev)

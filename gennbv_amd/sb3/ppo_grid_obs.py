@@ -93,10 +93,12 @@ class PPO_Grid_Obs:
         self.grad_write_through = True  # backward kernels store into the flat gradient buffer (ops/direct_grad.py)
         self.rotate_rows = True   # replayed graph on one GPU: the Adam launch leaves the next minibatch's row numbers behind (no host copy)
         self.grid_i8_rows = True  # int8 side copy of the grid rows next to flat fp32 rows (what the conv1 kernels of the update read)
-        # data-parallel step: phase A's second-stream work (pose branch backward, fc_grid dW) is joined by the gradient exchange, not by the
-        # conv backward (GENNBV_DP_LATE_ASIDE=0: the round-4 order, for A/B runs)
-        self.dp_late_grads_aside = os.environ.get("GENNBV_DP_LATE_ASIDE", "1") != "0"
-        self.dp_rotate_rows = os.environ.get("GENNBV_DP_ROTATE", "1") != "0"  # (the rotation table also in the data-parallel hipGraph)
+        # (the data-parallel step has ONE order since round 6: phase A's second-stream work is joined by the gradient exchange, not by the conv
+        # backward, and the rotation table is used inside the RCCL graph as well; the round-4 order behind GENNBV_DP_LATE_ASIDE / GENNBV_DP_ROTATE
+        # lost both of its measurements -- 847-869 against 804-816 ms per iteration, profiles/r05_notes.md section 9 -- and is gone)
+        # seconds between the eager warm-up collectives and the first RCCL capture (GENNBV_DP_SETTLE; see _capture_minibatch_graph)
+        self.dp_capture_settle_s = float(os.environ.get("GENNBV_DP_SETTLE", "0.35"))
+        self.dp_stress_spin_cycles = 0  # > 0: tests only, see _dp_minibatch
         self.fused_add = True     # time-out bootstrap + the five buffer copies of rollout_buffer.add as one launch (gnbv_rollout_add)
         self.rollout_plan = True  # collect_rollouts evaluates the policy through ops/rollout_plan.py (same kernels, step-invariant work hoisted)
         self.compact_obs = bool(compact_obs)
@@ -341,8 +343,8 @@ class PPO_Grid_Obs:
             loss.args.kl_out = opt.kl_slot.data_ptr()
         # one GPU: the loss launch leaves its per-sample terms behind and the optimizer's norm launch adds them up in passing (no release
         # fence + ticket per loss workgroup on the critical path); data-parallel: the KL must exist before the gradient exchange
-        # (round 5, `dp_late_grads_aside`: deferred there too -- gnbv_ppo_loss_finish runs on the second stream, in front of the exchange)
-        loss.args.defer_stats = 0 if (self._sync is not None and self._sync.active and not self.dp_late_grads_aside) else 1
+        # (round 5: deferred there too -- gnbv_ppo_loss_finish runs on the second stream, in front of the exchange)
+        loss.args.defer_stats = 1
         self.policy.features_extractor._bn_skip_flag = loss.stop_flag
         # (GENNBV_FORCE_SHARD=1: also with a one-rank communicator -- the captured reduce-scatter / all-gather code path on one GPU)
         if (self._sync is not None and self._sync.active and (self._sync.world > 1 or os.environ.get("GENNBV_FORCE_SHARD") == "1")
@@ -351,7 +353,7 @@ class PPO_Grid_Obs:
             import torch.distributed as dist
             sl = opt.slice_of(self.policy.features_extractor.output_layer_grid[0].weight)
             if sl is not None and sl[0] == self._hip["n_conv"]:
-                opt.enable_shard(sl[0], sl[1], dist.get_rank(self._sync.group), self._sync.world)
+                opt.enable_shard(sl[0], sl[1], self._sync.rank(), self._sync.world)
         if self._sync is not None and self._sync.active and self._sync.world > 1:  # (one rank: its statistics ARE the global ones)
             # global-minibatch statistics (gennbv_amd/parallel.py): advantage mean / std and BatchNorm-1's input
             # autocorrelation total come from per-train() tables (one row per minibatch, copied into these two buffers
@@ -386,10 +388,9 @@ class PPO_Grid_Obs:
                                    and isinstance(self.policy.mlp_extractor, _IdentityExtractor)
                                    and encoder_ops.policy_head_supported(enc, self.policy.action_net, self.policy.value_net))
         # fc_grid's weight gradient on a second stream (only the optimizer needs it; joined in _hip_minibatch_body).  Data-parallel
-        # (round 5, `dp_late_grads_aside`): the exchange of the late gradients is what waits for that stream, not the conv backward.
+        # (round 5): the exchange of the late gradients is what waits for that stream, not the conv backward.
         if getattr(enc, "backend", "") == "hip":
-            enc.output_layer_grid[0]._async_wgrad = (bool(self.grad_write_through) and getattr(self, "async_wgrad", True)
-                                                     and (self._sync is None or not self._sync.active or self.dp_late_grads_aside))
+            enc.output_layer_grid[0]._async_wgrad = bool(self.grad_write_through) and getattr(self, "async_wgrad", True)
         self._hip["skip_zero"] = bool(self.grad_write_through) and all(
             id(p) in covered for p in self.policy.parameters() if p.requires_grad)
         # fc_grid's weight gradient (94 % of all parameters) leaves its GEMM with sum(dW^2) as fp64 partial sums: the clip's norm
@@ -457,9 +458,8 @@ class PPO_Grid_Obs:
                 lin._defer_wgrad = False
             # (round 5) the pose branch's backward and fc_grid's weight gradient stay on the second stream WITHOUT a join: only the exchange
             # of the late gradients needs them (_dp_step_body orders it behind that stream), phase B needs the data gradient alone
-            join = not self.dp_late_grads_aside
-            encoder_ops.pose_branch_backward(enc, self.device, join=join)
-            encoder_ops.join_async_wgrads(self.device, join=join)
+            encoder_ops.pose_branch_backward(enc, self.device, join=False)
+            encoder_ops.join_async_wgrads(self.device, join=False)
         else:  # phase "B": conv-stack backward from d loss / d (conv-stack output)
             enc = pol.features_extractor
             torch.autograd.backward([enc._grid_feats_out], [enc._grid_feats_leaf.grad])
@@ -472,7 +472,7 @@ class PPO_Grid_Obs:
 
     def _dp_step_body(self, st):
         """[phase A] -> exchange of the late gradients overlapped with [phase B] -> all-reduce(KL slot + conv grads) -> clip/Adam
-        tail.  Capturable: RCCL collectives are recorded into the hipGraph.  Round 5 (`dp_late_grads_aside`): phase A leaves the pose
+        tail.  Capturable: RCCL collectives are recorded into the hipGraph.  Round 5: phase A leaves the pose
         branch's backward and fc_grid's weight gradient on the second stream un-joined, the loss statistics / KL and the exchange are issued
         from that stream, and phase B starts on this one as soon as fc_grid's data gradient exists.
 
@@ -483,70 +483,70 @@ class PPO_Grid_Obs:
         traffic per step on every rank -- shrinks to 1 / world of it for 94 % of the parameters, and the gather half of the exchange
         carries parameters the next forward needs ~0.1 ms later instead of gradients the update needs at once.  The clip factor needs
         sum(g^2) of the WHOLE summed gradient: each rank adds its shard's squared sum to one fp64 that rides a 1-element all-reduce."""
-        import torch.distributed as dist
-        opt = st["opt"]
+        opt, sync = st["opt"], self._sync
         n_conv = st["n_conv"]
         sh = getattr(opt, "shard", None)
         self._hip_minibatch_body(st, "A")
         # the exchange of the late gradients is issued behind the SECOND stream (pose branch backward, fc_grid's weight gradient) and behind
         # what phase A left on this one (heads, fc_grid's bias): the conv backward below starts as soon as its data gradient exists
-        from contextlib import nullcontext
-        late, stats_done = nullcontext(), None
-        if self.dp_late_grads_aside:
-            from ..ops import encoder_ops
-            assert self.device.type == "cuda"
-            side = encoder_ops.second_stream(self.device)
-            side.wait_stream(torch.cuda.current_stream(self.device))
-            late = torch.cuda.stream(side)
-            # (second stream: pose branch backward -> fc_grid's weight gradient -> statistics / KL -> the exchange is issued.  Issuing the
-            # reduce-scatter right behind the weight gradient, BEFORE the pose branch's backward, was measured: 804 -> 860 ms per iteration at
-            # one rank -- the collective's stream then runs beside both other streams, and a replayed graph that is three branches wide is
-            # serialised by the executor, profiles/r05_notes.md sections 3 and 9)
-            with late:
-                # the minibatch's statistics row and this rank's approx-KL (the slot in front of the flat gradient, all-reduced with the conv
-                # gradients below): one small launch beside the conv backward instead of a release fence + ticket per workgroup in
-                # k_ppo_fused, on the critical path.  The main stream waits for it only AFTER phase B (`kl_ready`).
-                st["loss"].finish_stats()
-                stats_done = torch.cuda.Event()
-                stats_done.record(side)
+        from ..ops import encoder_ops
+        assert self.device.type == "cuda"
+        side = encoder_ops.second_stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        late = torch.cuda.stream(side)
+        # (second stream: pose branch backward -> fc_grid's weight gradient -> statistics / KL -> the exchange is issued.  Issuing the
+        # reduce-scatter right behind the weight gradient, BEFORE the pose branch's backward, was measured: 804 -> 860 ms per iteration at
+        # one rank -- the collective's stream then runs beside both other streams, and a replayed graph that is three branches wide is
+        # serialised by the executor, profiles/r05_notes.md sections 3 and 9)
+        with late:
+            # the minibatch's statistics row and this rank's approx-KL (the slot in front of the flat gradient, all-reduced with the conv
+            # gradients below): one small launch beside the conv backward instead of a release fence + ticket per workgroup in
+            # k_ppo_fused, on the critical path.  The main stream waits for it only AFTER phase B (`kl_ready`).
+            st["loss"].finish_stats()
+            stats_done = torch.cuda.Event()
+            stats_done.record(side)
 
         def kl_ready():
-            if stats_done is not None:
-                torch.cuda.current_stream(self.device).wait_event(stats_done)
+            torch.cuda.current_stream(self.device).wait_event(stats_done)
         if sh is None:
             with late:
-                work = dist.all_reduce(opt.grads_with_slot[opt.SLOT + n_conv:], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
+                work = sync.all_reduce(opt.grads_with_slot[opt.SLOT + n_conv:], async_op=True)
             self._hip_minibatch_body(st, "B")
             kl_ready()
-            dist.all_reduce(opt.grads_with_slot[:opt.SLOT + n_conv], op=dist.ReduceOp.SUM, group=self._sync.group)
+            sync.all_reduce(opt.grads_with_slot[:opt.SLOT + n_conv])
             work.wait()
             self._hip_minibatch_tail(st)
             return
         lo, hi, loss = sh["lo"], sh["hi"], st["loss"]
         assert lo == n_conv, "the sharded slice is the first of the late gradients (parameter order: conv stack, fc_grid.weight, ...)"
         with late:
-            w_rs = dist.reduce_scatter_tensor(sh["grad"], opt.grads[lo:hi], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
-            w_ar = dist.all_reduce(opt.grads[hi:], op=dist.ReduceOp.SUM, group=self._sync.group, async_op=True)
+            w_rs = sync.reduce_scatter(sh["grad"], opt.grads[lo:hi], async_op=True)
+            w_ar = sync.all_reduce(opt.grads[hi:], async_op=True)
         self._hip_minibatch_body(st, "B")
         kl_ready()
-        dist.all_reduce(opt.grads_with_slot[:opt.SLOT + n_conv], op=dist.ReduceOp.SUM, group=self._sync.group)
+        sync.all_reduce(opt.grads_with_slot[:opt.SLOT + n_conv])
         w_rs.wait()
         # (the shard's square sum and its 2 KB all-reduce behind the reduce-scatter on the second stream, beside the conv backward, would take one
         # launch and one collective's latency off this tail: the one-rank RCCL capture of that order killed the process -- round 5, not pursued)
         opt.shard_sq()  # (one launch: 256 fp64 partial sums of the shard's squares; three torch kernels and 2 x 110 MB of fp64 temporaries before)
-        dist.all_reduce(sh["sq"], op=dist.ReduceOp.SUM, group=self._sync.group)
+        sync.all_reduce(sh["sq"])
         w_ar.wait()
         opt.step(self.max_grad_norm, loss.stop_flag, grad_scale=1.0 / self._sync.world, kl_slot_target=loss.args.target_kl,
                  sq_slice=(lo, hi, sh["sq"]), skip_update=True, rotate=st.get("rows_rot"))
         opt.shard_step(loss.stop_flag)
         p_shard, _, _ = opt.shard_views()
-        dist.all_gather_into_tensor(opt.params[lo:hi], p_shard, group=self._sync.group)
+        sync.all_gather(opt.params[lo:hi], p_shard)
 
     def _dp_minibatch(self, st, use_graph: bool):
         """One data-parallel optimizer step (see _dp_step_body)."""
         import torch.distributed as dist
         g = st["graph"] if use_graph else None
         if g is None:
+            if self.dp_stress_spin_cycles:
+                # replay-order stress (tests): the device is held back at the head of every eager step, so the host enqueues the WHOLE step --
+                # both streams, every allocation and free -- before the first kernel runs, as a graph replay does.  A block handed to a second
+                # stream without record_stream / an event then shows as wrong numbers here too, not only in the replayed RCCL graph.
+                torch.cuda._sleep(int(self.dp_stress_spin_cycles))
             return self._dp_step_body(st)
         return g.replay()  # everything, collectives included, in one hipGraph
 
@@ -567,7 +567,7 @@ class PPO_Grid_Obs:
         if self._sync is not None and self._sync.active and self._sync.world > 1:
             import torch.distributed as dist
             t = torch.tensor([flag], dtype=torch.int32, device=self.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._sync.group)
+            self._sync.all_reduce_eager_(t, op=dist.ReduceOp.MAX)  # (eager, once per train(): the side group when the main one is RCCL)
             flag = int(t.item())
         self.logger.record("train/range_replays", getattr(self, "range_replays", 0))
         self.logger.record("train/encoder_fp32_kernels", int(bool(getattr(enc, "force_fp32", False))))
@@ -675,7 +675,7 @@ class PPO_Grid_Obs:
         # Data-parallel (round 5): the same table when the step is one hipGraph (RCCL) -- its statistics columns then hold the GLOBAL
         # minibatches' figures computed above; with eager collectives (gloo) the three slots are copied between two steps as before.
         c.rotating = (c.use_graph and c.n_mb > 0 and self.rotate_rows
-                      and (not c.dp or (self.dp_rotate_rows and self._collectives_capturable())))
+                      and (not c.dp or self._collectives_capturable()))
         c.rot = st.get("rows_rot")
         if c.rotating and (c.rot is None or tuple(c.rot[0].shape) != (c.n_mb, c.batch + 1 + 384)):
             # a table row = [the minibatch's row numbers | (mean, 1 / (std + 1e-8)) of its advantages | the sum of its input-autocorrelation
@@ -764,7 +764,7 @@ class PPO_Grid_Obs:
         if c.dp and getattr(c.opt, "shard", None) is not None and self._sync.world > 1:
             # sharded fc_grid update: the owners' Adam moments into every rank's flat buffers HERE, at a point every rank passes together
             # (two all-gathers of 55 MB per train() call), so that get_parameters() / save() never need a collective
-            c.opt.gather_shard_state(self._sync.group)
+            self._gather_shard_state(st, c.opt)
         rows_done = int(c.loss.stats_row.item())
         s = c.loss.stats[:rows_done].double().cpu().numpy()
         s = s[s[:, 6] > 0.5]  # minibatches the reference would have executed
@@ -786,6 +786,21 @@ class PPO_Grid_Obs:
             self.logger.record("train/clip_range_vf", c.clip_range_vf)
         self.logger.record("time/training", time.time() - training_start)
 
+    def _gather_shard_state(self, st, opt) -> None:
+        """The owners' Adam moments into every rank's flat buffers at the end of train().  With RCCL the two all-gathers are a captured
+        hipGraph of their own (captured once per optimizer state, replayed per call): the communicator then carries captured work only
+        (VERDICT r5 item 5a); backends whose collectives cannot be captured run them eagerly."""
+        if not (self.use_graph and self.device.type == "cuda" and not st.get("graph_refused") and self._collectives_capturable()):
+            return opt.gather_shard_state(self._sync.group)
+        g = st.get("gather_graph")
+        if g is None:
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                opt.gather_shard_state(self._sync.group)
+            st["gather_graph"] = g
+        g.replay()
+
     def _check_ranges(self) -> bool:
         """Hybrid_Encoder.check_operand_ranges (split-f16 kernels' limits made loud) -> whether the encoder is on the fp32 kernels."""
         enc = self.policy.features_extractor
@@ -800,16 +815,23 @@ class PPO_Grid_Obs:
         are untouched."""
         loss = st["loss"]
         dp = self._sync is not None and self._sync.active
-        side = torch.cuda.Stream(self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                loss.stop_flag.fill_(1)
-                if dp:
-                    self._dp_step_body(st)
-                else:
-                    self._hip_minibatch_body(st)
-        torch.cuda.current_stream(self.device).wait_stream(side)
+        # Data-parallel: the eager warm-up (its collectives are the only eager work the RCCL communicator ever sees besides the rendezvous)
+        # runs in front of the FIRST capture of an optimizer state only; re-captures (a learning-rate / clip-range schedule re-captures in
+        # every train() call) find kernels, workspaces and the communicator warm.
+        if not (dp and getattr(self, "_dp_warm_for", None) is st["opt"]):
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    loss.stop_flag.fill_(1)
+                    if dp:
+                        self._dp_step_body(st)
+                    else:
+                        self._hip_minibatch_body(st)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            if dp:
+                self._dp_warm_for = st["opt"]
+                self._dp_eager_since_sync = True
         loss.stop_flag.fill_(1)
         # thread_local: the RCCL watchdog thread may touch the HIP runtime while we capture
         ga = torch.cuda.CUDAGraph()
@@ -838,7 +860,9 @@ class PPO_Grid_Obs:
         # the eager collectives above (warm-up steps; attach()'s broadcasts before them) are finished AND retired by the process group's
         # watchdog thread (it polls every 100 ms) before the first captured collective records an event: see parallel.capture_safe_env
         torch.cuda.synchronize(self.device)
-        time.sleep(0.35)
+        if getattr(self, "_dp_eager_since_sync", False) and self.dp_capture_settle_s > 0:
+            time.sleep(self.dp_capture_settle_s)  # (only behind eager collectives, i.e. in front of the first capture)
+        self._dp_eager_since_sync = False
         with torch.cuda.graph(ga, capture_error_mode="thread_local"):
             self._dp_step_body(st)
         self.dp_graph_mode = "one hipGraph incl. RCCL collectives"
@@ -901,9 +925,7 @@ class PPO_Grid_Obs:
         the collective, which a capture refuses -- and a capture refused half-way cannot be cleaned up from Python (torch's
         `capture_end` raises before it restores the current stream, the stream stays `invalidated`, later collectives fail from the
         autograd thread: tried in round 4), so the question is answered from the backend's name BEFORE anything is captured."""
-        import torch.distributed as dist
-        backend = str(dist.get_backend(self._sync.group)).lower()
-        ok = "nccl" in backend
+        ok, backend = self._sync.capturable()
         if not ok:
             self.dp_graph_mode = f"eager launches (the {backend} backend's collectives cannot be captured)"
         return ok

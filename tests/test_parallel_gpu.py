@@ -20,6 +20,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 G, N_LOCAL, T, B_LOCAL, EPOCHS = 16, 8, 4, 8, 2
 HW = (48, 64)
+# "g64" (round 6): the TIMED kernel set -- G = 64, 64 rows per rank and minibatch (the global minibatch of 128 is the
+# bench's), the split-f16 conv kernels, the LDS-DMA weight gradient -- with two ranks
+SHAPES = {"g16": (16, 8, 4, 8), "g64": (64, 16, 8, 64)}
+
+
+def _set_shape(name):
+    global G, N_LOCAL, T, B_LOCAL
+    G, N_LOCAL, T, B_LOCAL = SHAPES[name]
 
 
 def _cfg():
@@ -75,9 +83,10 @@ def _local_to_global(perm, rank):
     return (rank * N_LOCAL + perm // T) * T + perm % T
 
 
-def _worker(rank, WORLD, path, port, target_kl, out, shard=True, graph=False, epochs=EPOCHS):  # noqa: N803
+def _worker(rank, WORLD, path, port, target_kl, out, shard=True, graph=False, epochs=EPOCHS, shape="g16"):  # noqa: N803
     import time
     tm = [time.time()]
+    _set_shape(shape)
     if torch.cuda.device_count() >= WORLD > 1:
         # a node with a GPU per rank: every rank on ITS OWN device (what the ranks are in a real run) -- nothing is oversubscribed there,
         # so nothing below may be excused
@@ -146,14 +155,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,target_kl,shard,graph", [(2, None, True, False), (2, "auto", True, False), (2, None, False, False),
-                                                         (4, "auto", True, False), (8, None, True, False),
-                                                         (2, "auto", True, True)])
-def test_multi_rank_fused_update_equals_the_global_batch_update(tmp_path, world, target_kl, shard, graph):
+@pytest.mark.parametrize("world,target_kl,shard,graph,shape", [(2, None, True, False, "g16"), (2, "auto", True, False, "g16"), (2, None, False, False, "g16"),
+                                                               (4, "auto", True, False, "g16"), (8, None, True, False, "g16"),
+                                                               (2, "auto", True, True, "g16"), (2, None, True, False, "g64")])
+def test_multi_rank_fused_update_equals_the_global_batch_update(tmp_path, world, target_kl, shard, graph, shape):
     """world 4 / 8: the fc_grid.weight shard boundaries (110 592 weights over 4 / 8 owners), gather_shard_state and the stop position at
     the target world size.  graph=True: the capture of the (gloo) collectives is refused -> eager launches of the same step, with 2 ranks."""
     WORLD = world  # noqa: N806
     epochs = EPOCHS
+    _set_shape(shape)
     from gennbv_amd.env import synthetic as S
     from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
     torch.manual_seed(0)
@@ -212,7 +222,7 @@ def test_multi_rank_fused_update_equals_the_global_batch_update(tmp_path, world,
         os.environ["GPU_MAX_HW_QUEUES"] = "2"
     try:
         try:
-            mp.spawn(_worker, args=(WORLD, path, _free_port(), target_kl, out, shard, graph, epochs), nprocs=WORLD, join=True)
+            mp.spawn(_worker, args=(WORLD, path, _free_port(), target_kl, out, shard, graph, epochs, shape), nprocs=WORLD, join=True)
         except mp.ProcessExitedException as e:
             if getattr(e, "signal_name", None) is None or WORLD < 8 or not one_device:
                 raise

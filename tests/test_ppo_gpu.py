@@ -215,8 +215,7 @@ def _one_rank_rccl_worker(rank, name, shard, order, port, out):
         assert (getattr(ppo._hip["opt"], "shard", None) is not None) == shard
         if shard:
             assert ppo.dp_graph_mode == "one hipGraph incl. RCCL collectives", ppo.dp_graph_mode
-        assert ppo.dp_late_grads_aside == (order == "r5")
-        assert (ppo._hip.get("rows_rot") is not None) == (order == "r5" and ppo._hip.get("graph") is not None)
+        assert (ppo._hip.get("rows_rot") is not None) == (ppo._hip.get("graph") is not None)
         torch.cuda.synchronize()
         out["ok"] = True
     finally:
@@ -224,23 +223,20 @@ def _one_rank_rccl_worker(rank, name, shard, order, port, out):
 
 
 @pytest.mark.parametrize("name,shard,order", [("F9_ppo_train", False, "r5"), ("F9_ppo_train_earlystop", False, "r5"), ("F9_ppo_train", True, "r5"),
-                                              ("F9_ppo_train_earlystop", True, "r5"), ("F9_ppo_train_earlystop", True, "r4")])
+                                              ("F9_ppo_train_earlystop", True, "r5")])
 def test_data_parallel_code_path_on_one_gpu(name, shard, order, monkeypatch):
     """The multi-GPU branch (graph body -> RCCL all-reduce of the flat gradient + KL slot -> clip/Adam
     tail with the global KL decision) with a one-rank NCCL communicator must reproduce the goldens.
     shard: the sharded update of fc_grid.weight (reduce-scatter -> owner's Adam -> all-gather, GENNBV_FORCE_SHARD=1 makes the one
     rank its only owner) -- the RCCL reduce_scatter / all_gather calls captured in the minibatch hipGraph.
-    order "r5" (default): the exchange of the late gradients is issued behind the second stream (the conv backward does not wait for the
-    pose branch / fc_grid dW), and the Adam launch deals out the next minibatch's rows and statistics (rotation table) inside the
-    graph; "r4": both off (GENNBV_DP_LATE_ASIDE=0, GENNBV_DP_ROTATE=0) -- phase A joined before the exchange, three host copies per step.
+    The order of the step (round 5; the round-4 order and its switches were retired in round 6): the exchange of the late gradients is issued
+    behind the second stream (the conv backward does not wait for the pose branch / fc_grid dW), and the Adam launch deals out the next
+    minibatch's rows and statistics (rotation table) inside the graph.
     In a CHILD process (round 5): a process group's watchdog thread lives for the rest of its process, and this stack's has aborted twice in a
     few hundred processes that mix eager and captured collectives (gennbv_amd/parallel.py capture_safe_env) -- the pytest process never
     creates a NCCL process group, so such an abort fails this one case instead of ending the run."""
     import torch.multiprocessing as mp
     monkeypatch.setenv("GENNBV_FORCE_SHARD", "1" if shard else "0")
-    if order == "r4":
-        monkeypatch.setenv("GENNBV_DP_LATE_ASIDE", "0")
-        monkeypatch.setenv("GENNBV_DP_ROTATE", "0")
     out = mp.Manager().dict()
     mp.spawn(_one_rank_rccl_worker, args=(name, shard, order, _free_port(), out), nprocs=1, join=True)
     assert out.get("ok") is True
@@ -433,3 +429,25 @@ def test_fused_rollout_add_equals_bootstrap_plus_add(first):
     for name in ("actions", "rewards", "episode_starts", "values", "log_probs"):
         assert torch.equal(getattr(bufs[0], name), getattr(bufs[1], name)), name
     assert bufs[1].step == t and bufs[1].full
+
+
+@pytest.mark.parametrize("name", ["F9_ppo_train", "F9_ppo_train_earlystop"])
+@pytest.mark.parametrize("shard", [False, True])
+@pytest.mark.parametrize("mode", ["eager behind a spin kernel", "hipGraph"])
+def test_data_parallel_step_replay_order_stress_without_a_process_group(name, shard, mode, monkeypatch):
+    """Round 6.  The data-parallel step (`_dp_step_body`: phase A -> exchange issued from the second stream -> conv
+    backward -> tail) with a NULL exchange (parallel.attach_null: one rank, no process group, every collective the identity), so it runs in
+    the pytest process itself, and must reproduce the reference's F9 like the plain step.  "eager behind a spin kernel": the device is held
+    back ~15 ms at the head of every step, so the host enqueues the whole step -- both streams, every allocation and free -- before the
+    first kernel runs, which is the order a graph replay has: the use-after-free of round 5 (the pose branch's upstream gradient handed to
+    the conv backward's scratch while the second stream still read it) was invisible to eager launches because host time hid it."""
+    from gennbv_amd import parallel
+    monkeypatch.setenv("GENNBV_FORCE_SHARD", "1" if shard else "0")
+    fx = gu.load(name)
+    ppo = _ppo_from_fixture(fx, device=DEV, backend="hip")
+    parallel.attach_null(ppo)
+    ppo.use_graph = mode == "hipGraph"
+    ppo.dp_stress_spin_cycles = 0 if ppo.use_graph else 30_000_000
+    _check(ppo, fx)
+    assert (getattr(ppo._hip["opt"], "shard", None) is not None) == shard
+    assert (ppo._hip.get("graph") is not None) == ppo.use_graph

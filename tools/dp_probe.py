@@ -1,5 +1,7 @@
 """GPU probe (round 5): the one-rank RCCL data-parallel step on fixture F9 under the switches of _dp_step_body
-(use_graph x dp_late_grads_aside x dp_rotate_rows x shard): max |logged scalar - fixture| per combination."""
+(use_graph x shard, PROBE_REPEAT times): max |logged scalar - fixture| per combination.  Round 6: with PROBE_REPEAT=50 and
+GENNBV_DP_SETTLE=0 this is the "200 captures in one process without the settle time" run of VERDICT r5 item 5a
+(every algorithm object = eager warm-up collectives + a capture of the RCCL step + its replays)."""
 import os
 import sys
 
@@ -19,22 +21,21 @@ parallel.capture_safe_env()
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
 fx = gu.load("F9_ppo_train")
 KEYS = ("train/entropy_loss", "train/policy_gradient_loss", "train/value_loss", "train/approx_kl", "train/loss")
-LATES = [bool(int(x)) for x in os.environ.get("PROBE_LATE", "0,1").split(",")]
 GRAPHS = [bool(int(x)) for x in os.environ.get("PROBE_GRAPH", "1,0").split(",")]
 REPEAT = int(os.environ.get("PROBE_REPEAT", "1"))
 for shard in (0, 1) * REPEAT:
     os.environ["GENNBV_FORCE_SHARD"] = str(shard)
     for graph in GRAPHS:
-        for late in LATES:
-            for rot in (False, True):
-                ppo = _ppo_from_fixture(fx, device=DEV, backend="hip")
-                ppo.use_graph, ppo.dp_late_grads_aside, ppo.dp_rotate_rows = graph, late, rot
-                parallel.attach(ppo, 1, always_sync=True)
-                ppo.train()
-                torch.cuda.synchronize()
-                log = ppo.logger.name_to_value
-                err = max(abs(float(log[k]) - float(fx["log/" + k])) / max(1.0, abs(float(fx["log/" + k]))) for k in KEYS)
-                print(f"shard={shard} graph={int(graph)} late={int(late)} rotate={int(rot)}  max rel err {err:.2e}  {'ok' if err <= 1e-4 else 'WRONG'}"
-                      f"   graph object: {ppo._hip.get('graph') is not None}", flush=True)
-                del ppo
+        ppo = _ppo_from_fixture(fx, device=DEV, backend="hip")
+        ppo.use_graph = graph
+        parallel.attach(ppo, 1, always_sync=True)
+        ppo.train()
+        torch.cuda.synchronize()
+        log = ppo.logger.name_to_value
+        err = max(abs(float(log[k]) - float(fx["log/" + k])) / max(1.0, abs(float(fx["log/" + k]))) for k in KEYS)
+        N_DONE = globals().get("N_DONE", 0) + 1
+        print(f"#{N_DONE} shard={shard} graph={int(graph)}  max rel err {err:.2e}  {'ok' if err <= 1e-4 else 'WRONG'}"
+              f"   graph object: {ppo._hip.get('graph') is not None}", flush=True)
+        del ppo
+print(f"done: {globals().get('N_DONE', 0)} algorithm objects in one process, settle {os.environ.get('GENNBV_DP_SETTLE', 'default')} s", flush=True)
 dist.destroy_process_group()

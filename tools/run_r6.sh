@@ -17,6 +17,21 @@ d=json.load(open("$O/r06_bench_config5_shard_n1.json")); print("config5", round(
 PY
              ;;
   t_g128)    timeout 900 python -m pytest tests/test_ppo_g64_gpu.py -m gpu -q -x -k "g128" -p no:cacheprovider 2>&1 | tail -3 ;;
+  wgpmc)     OUT=$O/r06_wgrad_pmc.txt; : > $OUT
+             for v in 0 1; do echo "### GENNBV_WGRAD_DMA=$v" >> $OUT
+               for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE" \
+                        "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR" \
+                        "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_IFETCH" \
+                        "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TD_TCP_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum" \
+                        "TA_TA_BUSY_sum TD_TD_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" \
+                        "TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_GATE_EN1_sum" \
+                        "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum"; do
+                 echo "## --pmc $C" >> $OUT
+                 GENNBV_WGRAD_DMA=$v $GRAFT_REPO_ROOT/tools/run_pmc.sh $OUT "k_conv2_wgrad_split" "$C" -- python $GRAFT_REPO_ROOT/tools/microbench_conv.py --iters 3
+                 grep -iE "error|invalid|not supported|unable" /tmp/pmc_run.log | head -2 >> $OUT
+               done; done; cat $OUT | cut -c1-220 | tail -80 ;;
+  dp200)     GENNBV_DP_SETTLE=0 PROBE_REPEAT=100 PROBE_GRAPH=1 timeout 1500 python tools/dp_probe.py > $O/r06_dp_200_captures.txt 2>&1; tail -4 $O/r06_dp_200_captures.txt; grep -c " ok " $O/r06_dp_200_captures.txt ;;
+  t_dp)      timeout 1500 python -m pytest tests/test_parallel_gpu.py tests/test_ppo_gpu.py -m gpu -q --maxfail=6 --durations=6 -k "multi_rank or data_parallel or recapture" -p no:cacheprovider 2>&1 | tail -15 ;;
   tests)     timeout 1500 python -m pytest tests -m gpu -q --maxfail=12 --durations=12 -p no:cacheprovider > $O/r6_tests.log 2>&1; tail -30 $O/r6_tests.log ;;
   bench)     timeout 900 python bench.py --steps 5 --warmup 2 2>$O/r6_bench.err | tail -1 > $O/r6_bench_n1.json; cut -c1-900 $O/r6_bench_n1.json ;;
   benchdrv)  timeout 1200 python bench.py --steps 20 --warmup 5 2>$O/r6_benchdrv.err | tail -1 > $O/r6_bench_driver_cfg_n1.json; cut -c1-600 $O/r6_bench_driver_cfg_n1.json ;;
