@@ -30,8 +30,9 @@ PY
                  GENNBV_WGRAD_DMA=$v $GRAFT_REPO_ROOT/tools/run_pmc.sh $OUT "k_conv2_wgrad_split" "$C" -- python $GRAFT_REPO_ROOT/tools/microbench_conv.py --iters 3
                  grep -iE "error|invalid|not supported|unable" /tmp/pmc_run.log | head -2 >> $OUT
                done; done; cat $OUT | cut -c1-220 | tail -80 ;;
-  dp200)     GENNBV_DP_SETTLE=0 PROBE_REPEAT=100 PROBE_GRAPH=1 timeout 1500 python tools/dp_probe.py > $O/r06_dp_200_captures.txt 2>&1; tail -4 $O/r06_dp_200_captures.txt; grep -c " ok " $O/r06_dp_200_captures.txt ;;
-  t_dp)      timeout 1500 python -m pytest tests/test_parallel_gpu.py tests/test_ppo_gpu.py -m gpu -q --maxfail=6 --durations=6 -k "multi_rank or data_parallel or recapture" -p no:cacheprovider 2>&1 | tail -15 ;;
+  dp200)     GENNBV_DP_SETTLE=0 PROBE_REPEAT=100 PROBE_GRAPH=1 timeout 1500 python tools/dp_probe.py > $O/r06_dp_200_captures_settle0.txt 2>&1; tail -4 $O/r06_dp_200_captures_settle0.txt; grep -c " ok " $O/r06_dp_200_captures_settle0.txt ;;
+  dp200s)    PROBE_REPEAT=100 PROBE_GRAPH=1 timeout 1800 python tools/dp_probe.py > $O/r06_dp_200_captures.txt 2>&1; tail -2 $O/r06_dp_200_captures.txt; grep -c " ok " $O/r06_dp_200_captures.txt ;;
+  t_dp)      timeout 1500 python -m pytest tests/test_parallel_gpu.py tests/test_ppo_gpu.py -m gpu -q --maxfail=6 --durations=6 -k "multi_rank or data_parallel or recapture" -p no:cacheprovider > $O/r6_tests_dp.log 2>&1; tail -15 $O/r6_tests_dp.log ;;
   tests)     timeout 1500 python -m pytest tests -m gpu -q --maxfail=12 --durations=12 -p no:cacheprovider > $O/r6_tests.log 2>&1; tail -30 $O/r6_tests.log ;;
   bench)     timeout 900 python bench.py --steps 5 --warmup 2 2>$O/r6_bench.err | tail -1 > $O/r6_bench_n1.json; cut -c1-900 $O/r6_bench_n1.json ;;
   benchdrv)  timeout 1200 python bench.py --steps 20 --warmup 5 2>$O/r6_benchdrv.err | tail -1 > $O/r6_bench_driver_cfg_n1.json; cut -c1-600 $O/r6_bench_driver_cfg_n1.json ;;
