@@ -99,14 +99,31 @@ class Phase:
 
     def __enter__(self):
         import torch
-        self.e0 = torch.cuda.Event(enable_timing=True)
-        self.e1 = torch.cuda.Event(enable_timing=True)
+        if getattr(self, "_pool", None):
+            self.e0, self.e1 = self._pool.pop(), self._pool.pop()
+        else:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
         self.e0.record()
         return self
 
     def __exit__(self, *a):
         self.e1.record()
         self.pairs.append((self.e0, self.e1))
+
+    def reserve(self, n_pairs: int):
+        """Create the events of `n_pairs` start() / stop() pairs NOW: a torch event gets its HIP event at its first record(), and the
+        runtime grows its event / signal pools in steps -- a bench that times every voxel update creates 256 events per iteration, and the
+        ~1000th creation inside the timed region cost one iteration ~100 ms (rounds 1-5 carried that in their averages; iteration_ms of
+        round 6's first runs: 693 693 694 692 780 and 699 700 701 803 700 ...).  Recording each event once up front moves it out."""
+        import torch
+        if os.environ.get("GENNBV_BENCH_NO_RESERVE") == "1":  # (A/B of this very effect)
+            return
+        self._pool = getattr(self, "_pool", None) or []
+        for _ in range(2 * n_pairs - len(self._pool)):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._pool.append(e)
 
     def start(self):
         import torch
@@ -558,6 +575,14 @@ def main():
     phases = {"rollout": Phase(), "train": Phase()}
     vox = instrument_voxel(env)
     iter_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # (one record per iteration, no synchronisation inside the timed region)
+    # (every event of the timed region exists before it starts: Phase.reserve.  At least 3 072 pairs: the one-off ~100 ms stall of the
+    # runtime comes with roughly the 4 096th HIP event a process creates -- with 2 064 events reserved it moved from the fifth timed
+    # iteration to the third, profiles/r06_bench_event_reserve_ab.txt -- and belongs in front of the timed region, not inside it)
+    vox.reserve(max(args.steps * args.n_steps + 8, 3072))
+    for ph_ in phases.values():
+        ph_.reserve(args.steps + 1)
+    for e in iter_ev:
+        e.record()
     barrier()
     t0 = time.perf_counter()
     iter_ev[0].record()

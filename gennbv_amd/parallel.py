@@ -174,19 +174,34 @@ class GradSync:
     null = False
 
     class _Done:
+        """Work handle of a null / synchronous exchange.  Like a process group's work, `wait()` makes the CALLER's current stream wait for the
+        stream the exchange was issued on (an event recorded there) -- inside a capture that is what joins the second stream's branch."""
+
+        def __init__(self, event=None):
+            self.event = event
+
         def wait(self):
+            if self.event is not None:
+                torch.cuda.current_stream().wait_event(self.event)
             return True
+
+    def _done_here(self, t: torch.Tensor):
+        if not t.is_cuda:
+            return self._Done()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(t.device))
+        return self._Done(ev)
 
     def all_reduce(self, t: torch.Tensor, async_op: bool = False):
         if self.null:
-            return self._Done()
+            return self._done_here(t) if async_op else self._Done()
         w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return w if async_op else self._Done()
 
     def reduce_scatter(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
         if self.null:
             out.copy_(inp)  # (one rank owns the whole slice)
-            return self._Done()
+            return self._done_here(out) if async_op else self._Done()
         w = dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return w if async_op else self._Done()
 
@@ -269,7 +284,12 @@ def attach(algo, world: int, group=None, always_sync: bool = False, side_group="
         side_group = None
         if world > 1 and _is_nccl(group):
             ranks = None if group is None else dist.get_process_group_ranks(group)
-            side_group = dist.new_group(ranks=ranks, backend="gloo")
+            try:
+                side_group = dist.new_group(ranks=ranks, backend="gloo")
+            except Exception as ex:  # (no usable host interface for gloo: the same on every rank -- the eager exchanges stay on the main group)
+                import warnings
+                warnings.warn(f"[gennbv_amd] no gloo side group ({ex!r}): attach()'s broadcasts and the per-train() tables use the RCCL group")
+                side_group = None
     sync = GradSync(world, group, always_sync, side_group)
     algo._sync = sync
     if sync.active and _is_nccl(group):

@@ -87,7 +87,7 @@ class GraphCaptureMixin:
             # (a learning-rate / clip-range schedule re-captures the graph in every train() call -- the hyper-parameters are kernel
             # arguments --: candidates only for the first capture and for one that replaces a graph that lived >= 4 calls)
             stable = st.get("captures", 0) == 0 or st.get("calls_since_capture", 0) >= 4
-            k = 3 if (st.get("replays_per_call", 0) >= 256 and stable) else 1
+            k = int(os.environ.get("GENNBV_GRAPH_CANDIDATES", "3")) if (st.get("replays_per_call", 0) >= 256 and stable) else 1
         st["captures"], st["calls_since_capture"] = st.get("captures", 0) + 1, 0
         if k <= 1:
             return first, first_pool
