@@ -33,6 +33,13 @@ PY
   dp200)     GENNBV_DP_SETTLE=0 PROBE_REPEAT=100 PROBE_GRAPH=1 timeout 1500 python tools/dp_probe.py > $O/r06_dp_200_captures_settle0.txt 2>&1; tail -4 $O/r06_dp_200_captures_settle0.txt; grep -c " ok " $O/r06_dp_200_captures_settle0.txt ;;
   dp200s)    PROBE_REPEAT=100 PROBE_GRAPH=1 timeout 1800 python tools/dp_probe.py > $O/r06_dp_200_captures.txt 2>&1; tail -2 $O/r06_dp_200_captures.txt; grep -c " ok " $O/r06_dp_200_captures.txt ;;
   t_dp)      timeout 1500 python -m pytest tests/test_parallel_gpu.py tests/test_ppo_gpu.py -m gpu -q --maxfail=6 --durations=6 -k "multi_rank or data_parallel or recapture" -p no:cacheprovider > $O/r6_tests_dp.log 2>&1; tail -15 $O/r6_tests_dp.log ;;
+  dp1)       GENNBV_FORCE_DP=1 GENNBV_FORCE_SHARD=1 timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-flat-rows 2>$O/r6_dp1.err | tail -1 > $O/r06_bench_dp1_n1.json; python - <<PY
+import json
+d=json.load(open("$O/r06_bench_dp1_n1.json")); print("dp1", round(d["ms_per_step"],1), "ms", d["train_roofline"]["ms_per_minibatch"], d.get("timed_state_check"), d["config"].get("dp_graph_mode"), d.get("dp_exchange_probe"))
+PY
+             ;;
+  refdef)    timeout 1200 python bench.py --steps 3 --warmup 1 --height 400 --width 400 --grid 20 --no-flat-rows 2>$O/r6_refdef.err | tail -1 > $O/r06_bench_refdefault_n1.json; cut -c1-300 $O/r06_bench_refdefault_n1.json ;;
+  semantic)  timeout 900 python bench.py --steps 3 --warmup 1 --semantic --no-cpu-baseline --no-flat-rows 2>/dev/null | tail -1 > $O/r06_bench_semantic_n1.json; cut -c1-300 $O/r06_bench_semantic_n1.json ;;
   tests)     timeout 1500 python -m pytest tests -m gpu -q --maxfail=12 --durations=12 -p no:cacheprovider > $O/r6_tests.log 2>&1; tail -30 $O/r6_tests.log ;;
   bench)     timeout 900 python bench.py --steps 5 --warmup 2 2>$O/r6_bench.err | tail -1 > $O/r6_bench_n1.json; cut -c1-900 $O/r6_bench_n1.json ;;
   benchdrv)  timeout 1200 python bench.py --steps 20 --warmup 5 2>$O/r6_benchdrv.err | tail -1 > $O/r6_bench_driver_cfg_n1.json; cut -c1-600 $O/r6_bench_driver_cfg_n1.json ;;
