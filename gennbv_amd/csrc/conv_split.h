@@ -575,27 +575,25 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p)
 
 __global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_split_dma(
     const float *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1, const float *__restrict__ dy2 /*[B,O2^3,16]*/,
-    const unsigned *__restrict__ absmax, int B, int O1, int O2, float *__restrict__ partial /*[grid][27 * 256 + 16]*/)
+    const unsigned *__restrict__ absmax, int B, int O1, int O2, int nitems, float *__restrict__ partial /*[grid][27 * 256 + 16]*/)
 {
+    // A workgroup walks the items (sample, plane group) blockIdx.x, + gridDim.x, ... and keeps its accumulators across them (round 6): with
+    // 256 workgroups for the 512 items of a 128-sample minibatch every CU starts ONE workgroup instead of two in a row -- the second one's
+    // launch, scale loads and first round trip were dead time on the CU (the x-tiled kernels showed it: 90.7 -> 80.6 us from 512 to 256
+    // workgroups, profiles/r06_splitx_at_g64_trace.txt).  With gridDim.x >= nitems it is the one-item kernel, bit-identical to
+    // k_conv2_wgrad_split; with fewer workgroups a partial row sums two items in fp32 before the fp64 reduction.
     using namespace split;
     extern __shared__ __attribute__((aligned(16))) char split_lds[];
     char *stage = split_lds, *dyst = split_lds + wdma::kStageBytes + kPadBytes;
     constexpr int R = wdma::kRing;
-    int b, oz0, oz1;
-    const int vblock = (int)blockIdx.x;
-    const bool live = sample_plane_group(B, O2, kNP, b, oz0, oz1, vblock);
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(tid / kWave);
     constexpr int E2 = kTaps * 256 + kC;
-    float *out = partial + (size_t)vblock * E2;
-    if (!live) {
-        for (int i = tid; i < E2; i += kThreads) out[i] = 0.0f;
-        return;
-    }
+    float *out = partial + (size_t)blockIdx.x * E2;
     // Only the padding voxel behind the ring is cleared: every ring slot and every dy2 buffer is written in full (1 KiB chunks, all nine
     // planes, clamped sources) before its first read, so nothing stale can reach an operand -- and the first requests can go out at once,
     // before anything else of the workgroup's start-up (no clear of 138 KiB + barrier in front of them, no round trip for the scales).
     if (tid < kPadBytes / 16) reinterpret_cast<uint4 *>(split_lds + wdma::kStageBytes)[tid] = make_uint4(0, 0, 0, 0);
-    const int np = oz1 - oz0, npl = 2 * np + 1, P2 = O2 * O2 * O2;
+    const int P2 = O2 * O2 * O2;
     const int nsteps = (O2 + 1) & ~1;
     if (wv >= kConsWaves) {
         // ---- staging waves: chunk k of wave pw is half row h = pw + 8 k of the iteration (plane h >> 2, row parity (h >> 1) & 1, x parity
@@ -603,94 +601,103 @@ __global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_split_dma(
         const int pw = wv - kConsWaves, q = lane & 3, vx = lane >> 2;
         const bool dy_wave = pw >= 4;
         const uint32_t rowC = 2 * 16 * kC, planeC = rowC * (uint32_t)O1;
-        const float *ybase = y1 + ((size_t)b * O1 + 2 * oz0) * planeC + lane * 4;
         const int dpl = pw - 4;
-        const bool dvalid = dy_wave && dpl < np && vx < O2;
-        const float *dsrc = dy2 + ((size_t)b * P2 + (size_t)(oz0 + min(max(dpl, 0), np - 1)) * O2 * O2 + min(vx, O2 - 1)) * kC + 4 * q;
         const uint32_t stage_a = lds_addr(stage), dy_a = lds_addr(dyst);
-        auto issue = [&](int j) {
+        float gs = 1.0f, sc[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+        bool first = true;
+        for (int item = (int)blockIdx.x; item < nitems; item += (int)gridDim.x) {
+            int b, oz0, oz1;
+            if (!sample_plane_group(B, O2, kNP, b, oz0, oz1, item)) continue;  // (workgroup-uniform: both roles skip it)
+            const int np = oz1 - oz0, npl = 2 * np + 1;
+            const float *ybase = y1 + ((size_t)b * O1 + 2 * oz0) * planeC + lane * 4;
+            const bool dvalid = dy_wave && dpl < np && vx < O2;
+            const float *dsrc = dy2 + ((size_t)b * P2 + (size_t)(oz0 + min(max(dpl, 0), np - 1)) * O2 * O2 + min(vx, O2 - 1)) * kC + 4 * q;
+            auto issue = [&](int j) {
 #ifdef WDMA_ABL_NODMA  // (measurement build: no requests -- conversion + contraction alone)
-            return;
+                return;
 #endif
 #pragma unroll
-            for (int k = 0; k < wdma::kChunks; ++k) {
-                if (k == wdma::kChunks - 1 && dy_wave) {
-                    glds16_nt(dsrc + (size_t)min(max(j, 0), O2 - 1) * O2 * kC, __builtin_amdgcn_readfirstlane(dy_a + (uint32_t)((((j + 3) % wdma::kDyBufs) * kNP + dpl) * 1024)));
-                } else {
-                    const int h = pw + 8 * k, pi = h >> 2, row = 2 * j + 1 + ((h >> 1) & 1), slot = (row + 2 * R) % R;
-                    const float *src = ybase + (uint32_t)min(pi, npl - 1) * planeC + (uint32_t)min(max(row, 0), O1 - 1) * rowC + (h & 1) * (16 * kC);
-                    glds16_nt(src, __builtin_amdgcn_readfirstlane(stage_a + (uint32_t)((pi * R + slot) * kRowBytes + (h & 1) * 1024)));
+                for (int k = 0; k < wdma::kChunks; ++k) {
+                    if (k == wdma::kChunks - 1 && dy_wave) {
+                        glds16_nt(dsrc + (size_t)min(max(j, 0), O2 - 1) * O2 * kC, __builtin_amdgcn_readfirstlane(dy_a + (uint32_t)((((j + 3) % wdma::kDyBufs) * kNP + dpl) * 1024)));
+                    } else {
+                        const int h = pw + 8 * k, pi = h >> 2, row = 2 * j + 1 + ((h >> 1) & 1), slot = (row + 2 * R) % R;
+                        const float *src = ybase + (uint32_t)min(pi, npl - 1) * planeC + (uint32_t)min(max(row, 0), O1 - 1) * rowC + (h & 1) * (16 * kC);
+                        glds16_nt(src, __builtin_amdgcn_readfirstlane(stage_a + (uint32_t)((pi * R + slot) * kRowBytes + (h & 1) * 1024)));
+                    }
                 }
-            }
-        };
-        issue(-1);
-        issue(0);
-        // the scales, requested BEHIND the first ten chunks: the compiler's wait for them (it does not count the requests above) also retires
-        // those -- which the first conversion needs anyway
-        const float gs = grad_scale(absmax);
-        float sc[4], sh[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            sc[s] = scale1[4 * q + s] * kZScale;
-            sh[s] = shift1[4 * q + s] * kZScale;
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(sc[s]), "+v"(sh[s]));  // (computed HERE: a use sunk behind later requests would make the compiler wait for them)
-        wait_vm_keep<0>();
-        auto convert = [&](int j) {
+            };
+            auto convert = [&](int j) {
 #ifdef WDMA_ABL_NOCONV  // (measurement build: the chunks stay raw -- transport + contraction alone, results meaningless)
-            return;
+                return;
 #endif
-            char *cp[wdma::kChunks];
-            float4 raw[wdma::kChunks];
+                char *cp[wdma::kChunks];
+                float4 raw[wdma::kChunks];
 #pragma unroll
-            for (int k = 0; k < wdma::kChunks; ++k) {
-                if (k == wdma::kChunks - 1 && dy_wave) {
-                    cp[k] = dyst + (((j + 3) % wdma::kDyBufs) * kNP + dpl) * 1024;
-                } else {
-                    const int h = pw + 8 * k, pi = h >> 2, row = 2 * j + 1 + ((h >> 1) & 1), slot = (row + 2 * R) % R;
-                    cp[k] = stage + (pi * R + slot) * kRowBytes + (h & 1) * 1024;
+                for (int k = 0; k < wdma::kChunks; ++k) {
+                    if (k == wdma::kChunks - 1 && dy_wave) {
+                        cp[k] = dyst + (((j + 3) % wdma::kDyBufs) * kNP + dpl) * 1024;
+                    } else {
+                        const int h = pw + 8 * k, pi = h >> 2, row = 2 * j + 1 + ((h >> 1) & 1), slot = (row + 2 * R) % R;
+                        cp[k] = stage + (pi * R + slot) * kRowBytes + (h & 1) * 1024;
+                    }
+                    raw[k] = *reinterpret_cast<const float4 *>(cp[k] + lane * 16);
                 }
-                raw[k] = *reinterpret_cast<const float4 *>(cp[k] + lane * 16);
-            }
 #pragma unroll
-            for (int k = 0; k < wdma::kChunks; ++k) {
-                float z[4];
-                const float v[4] = {raw[k].x, raw[k].y, raw[k].z, raw[k].w};
-                if (k == wdma::kChunks - 1 && dy_wave) {
+                for (int k = 0; k < wdma::kChunks; ++k) {
+                    float z[4];
+                    const float v[4] = {raw[k].x, raw[k].y, raw[k].z, raw[k].w};
+                    if (k == wdma::kChunks - 1 && dy_wave) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) z[e] = dvalid ? v[e] * gs : 0.0f;
-                } else {
-                    const bool pad_voxel = ((pw + 8 * k) & 1) == 1 && vx == 15;  // (x parity 1, slot 15: meets dy2's zero padding)
+                        for (int e = 0; e < 4; ++e) z[e] = dvalid ? v[e] * gs : 0.0f;
+                    } else {
+                        const bool pad_voxel = ((pw + 8 * k) & 1) == 1 && vx == 15;  // (x parity 1, slot 15: meets dy2's zero padding)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) z[e] = pad_voxel ? 0.0f : __builtin_amdgcn_fmed3f(fmaf(sc[e], v[e], sh[e]), 0.f, kZMax);
-                }
-                h4 hi, lo;
+                        for (int e = 0; e < 4; ++e) z[e] = pad_voxel ? 0.0f : __builtin_amdgcn_fmed3f(fmaf(sc[e], v[e], sh[e]), 0.f, kZMax);
+                    }
+                    h4 hi, lo;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    _Float16 a, c2;
-                    split2(z[e], a, c2);
-                    hi[e] = a;
-                    lo[e] = c2;
-                }
-                char *dst = cp[k] + vx * 32 + q * 8;
-                *reinterpret_cast<h4 *>(dst) = hi;
+                    for (int e = 0; e < 4; ++e) {
+                        _Float16 a, c2;
+                        split2(z[e], a, c2);
+                        hi[e] = a;
+                        lo[e] = c2;
+                    }
+                    char *dst = cp[k] + vx * 32 + q * 8;
+                    *reinterpret_cast<h4 *>(dst) = hi;
 #ifndef SPLIT_HI_ONLY
-                *reinterpret_cast<h4 *>(dst + 512) = lo;
+                    *reinterpret_cast<h4 *>(dst + 512) = lo;
 #endif
+                }
+            };
+            issue(-1);
+            issue(0);
+            if (first) {
+                // the scales, requested BEHIND the first ten chunks: the compiler's wait for them (it does not count the requests above) also
+                // retires those -- which the first conversion needs anyway
+                gs = grad_scale(absmax);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    sc[s] = scale1[4 * q + s] * kZScale;
+                    sh[s] = shift1[4 * q + s] * kZScale;
+                }
+                first = false;
             }
-        };
-        convert(-1);
-        issue(1);
-        convert(0);  // (iteration 0 landed with iteration -1: the wait above was for everything)
-        split_step_barrier();
-        for (int t = 1; t <= nsteps; ++t) {
-            issue(t + 1);  // rows 2t+3, 2t+4: their slots held rows 2t-4, 2t-3, last read before the previous barrier
-            wait_vm_keep<wdma::kChunks>();  // everything but the five just issued: iteration t has landed
-            convert(t);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(sc[s]), "+v"(sh[s]));  // (computed HERE: a use sunk behind later requests would make the compiler wait for them)
+            wait_vm_keep<0>();
+            convert(-1);
+            issue(1);
+            convert(0);  // (iteration 0 landed with iteration -1: the wait above was for everything)
             split_step_barrier();
+            for (int t = 1; t <= nsteps; ++t) {
+                issue(t + 1);  // rows 2t+3, 2t+4: their slots held rows 2t-4, 2t-3, last read before the previous barrier
+                wait_vm_keep<wdma::kChunks>();  // everything but the five just issued: iteration t has landed
+                convert(t);
+                split_step_barrier();
+            }
+            wait_vm_keep<0>();  // (nothing may land in a slot the next item's first requests target, or after the workgroup has ended)
         }
-        wait_vm_keep<0>();  // (nothing may land in LDS after the workgroup has ended)
     } else {
         // ---- compute waves: k_conv2_wgrad_split's, on the seven-row ring and the three dy2 buffers ----
         const float gs = grad_scale(absmax);
@@ -710,54 +717,57 @@ __global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_split_dma(
         h8 ones;
 #pragma unroll
         for (int e = 0; e < 8; ++e) ones[e] = (_Float16)1.0f;
-        split_step_barrier();
-        for (int t = 1; t <= nsteps; ++t) {
-            const int oy = t - 1;
+        for (int item = (int)blockIdx.x; item < nitems; item += (int)gridDim.x) {
+            int b, oz0, oz1;
+            if (!sample_plane_group(B, O2, kNP, b, oz0, oz1, item)) continue;
+            const int np = oz1 - oz0;
+            split_step_barrier();
+            for (int t = 1; t <= nsteps; ++t) {
+                const int oy = t - 1;
 #ifdef WDMA_ABL_NOCOMP  // (measurement build: the compute waves only keep the barriers -- transport + conversion alone)
-            if (false) {
+                if (false) {
 #else
-            if (oy < O2) {
+                if (oy < O2) {
 #endif
-                uint32_t rowoff[3];
+                    uint32_t rowoff[3];
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) rowoff[dy] = (uint32_t)(((2 * oy + dy) % R) * kRowBytes);
-                const char *dybuf = dyst + (oy % wdma::kDyBufs) * kNP * 1024 + lane * 8;
-                // Every operand of a k-block is requested before its first MFMA, and the MFMAs run tap-interleaved (hh of every tap, then
-                // lh, then hl): as written in k_conv2_wgrad_split -- per tap four reads, a wait, three MFMAs on ONE accumulator -- a step
-                // of a compute wave was a chain of ~7 LDS round trips and 21 dependent matrix instructions, which nothing hid once the
-                // transport stopped being the bound.  Each accumulator still receives its products in the same order: bit-identical.
+                    for (int dy = 0; dy < 3; ++dy) rowoff[dy] = (uint32_t)(((2 * oy + dy) % R) * kRowBytes);
+                    const char *dybuf = dyst + (oy % wdma::kDyBufs) * kNP * 1024 + lane * 8;
+                    // Every operand of a k-block is requested before its first MFMA, and the MFMAs run tap-interleaved (hh of every tap, then
+                    // lh, then hl).  Each accumulator still receives its products in the same order as in k_conv2_wgrad_split.
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    if (2 * kb < np) {
-                        const h8 bh = tr_pair(dybuf + (2 * kb) * 1024, dybuf + (2 * kb + 1) * 1024);
-                        const h8 bl = tr_pair(dybuf + (2 * kb) * 1024 + 512, dybuf + (2 * kb + 1) * 1024 + 512);
-                        h8 ah[4], al[4];
+                    for (int kb = 0; kb < 2; ++kb) {
+                        if (2 * kb < np) {
+                            const h8 bh = tr_pair(dybuf + (2 * kb) * 1024, dybuf + (2 * kb + 1) * 1024);
+                            const h8 bl = tr_pair(dybuf + (2 * kb) * 1024 + 512, dybuf + (2 * kb + 1) * 1024 + 512);
+                            h8 ah[4], al[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            if (i < 3 || ntaps == 4) {
-                                const uint32_t off = tapbase[i] + (tapdy[i] == 0 ? rowoff[0] : tapdy[i] == 1 ? rowoff[1] : rowoff[2]);
-                                const char *a0 = stage + (2 * (2 * kb)) * R * kRowBytes + off, *a1 = a0 + 2 * R * kRowBytes;
-                                ah[i] = tr_pair(a0, a1);
-                                al[i] = tr_pair(a0 + 512, a1 + 512);
+                            for (int i = 0; i < 4; ++i) {
+                                if (i < 3 || ntaps == 4) {
+                                    const uint32_t off = tapbase[i] + (tapdy[i] == 0 ? rowoff[0] : tapdy[i] == 1 ? rowoff[1] : rowoff[2]);
+                                    const char *a0 = stage + (2 * (2 * kb)) * R * kRowBytes + off, *a1 = a0 + 2 * R * kRowBytes;
+                                    ah[i] = tr_pair(a0, a1);
+                                    al[i] = tr_pair(a0 + 512, a1 + 512);
+                                }
                             }
-                        }
 #pragma unroll
-                        for (int i = 0; i < 3; ++i) acc[i] = mfma_h(ah[i], bh, acc[i]);
-                        if (ntaps == 4) acc[3] = mfma_h(ah[3], bh, acc[3]);
+                            for (int i = 0; i < 3; ++i) acc[i] = mfma_h(ah[i], bh, acc[i]);
+                            if (ntaps == 4) acc[3] = mfma_h(ah[3], bh, acc[3]);
 #pragma unroll
-                        for (int i = 0; i < 3; ++i) acc[i] = mfma_lo(al[i], bh, acc[i]);
-                        if (ntaps == 4) acc[3] = mfma_lo(al[3], bh, acc[3]);
+                            for (int i = 0; i < 3; ++i) acc[i] = mfma_lo(al[i], bh, acc[i]);
+                            if (ntaps == 4) acc[3] = mfma_lo(al[3], bh, acc[3]);
 #pragma unroll
-                        for (int i = 0; i < 3; ++i) acc[i] = mfma_lo(ah[i], bl, acc[i]);
-                        if (ntaps == 4) acc[3] = mfma_lo(ah[3], bl, acc[3]);
-                        if (cw == 7) {
-                            acc[3] = mfma_h(ones, bh, acc[3]);
-                            acc[3] = mfma_lo(ones, bl, acc[3]);
+                            for (int i = 0; i < 3; ++i) acc[i] = mfma_lo(ah[i], bl, acc[i]);
+                            if (ntaps == 4) acc[3] = mfma_lo(ah[3], bl, acc[3]);
+                            if (cw == 7) {
+                                acc[3] = mfma_h(ones, bh, acc[3]);
+                                acc[3] = mfma_lo(ones, bl, acc[3]);
+                            }
                         }
                     }
                 }
+                split_step_barrier();
             }
-            split_step_barrier();
         }
         const float unscale = (1.0f / kZScale) * inv_pow2(gs);
 #pragma unroll

@@ -2008,6 +2008,15 @@ static inline int splitx_max_wg()
     const int v = e ? atoi(e) : 0;
     return v >= 8 && v <= 512 ? (v & ~7) : 512;
 }
+// most workgroups of the G = 64 split kernels that walk several items (round 6: k_conv2_wgrad_split_dma): 256 = one per CU, i.e. two items
+// per workgroup at the bench's minibatch instead of two workgroups per CU one after the other; GENNBV_CONV_MAXWG=512 restores one item per
+// workgroup (bit-identity tests against the register-staged kernel, A/B runs)
+static inline int conv_max_wg()
+{
+    const char *e = getenv("GENNBV_CONV_MAXWG");
+    const int v = e ? atoi(e) : 0;
+    return v >= 8 && v <= 512 ? (v & ~7) : 256;
+}
 // conv2 weight gradient with the LDS-DMA transport (k_conv2_wgrad_split_dma, round 6): the default at G = 64 -- bit-identical to the
 // register-staged k_conv2_wgrad_split, which GENNBV_WGRAD_DMA=0 keeps selectable (A/B runs, tests/test_encoder_gpu.py)
 static inline bool wgrad_dma_path()
@@ -2310,8 +2319,10 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
                 if (e != hipSuccess) return (int)e;
                 attr_wd = true;
             }
+            const int nitems = wg_blocks;
+            wg_blocks = min(nitems, conv_max_wg());  // (a workgroup walks items block, block + grid, ...: one workgroup per CU by default)
             hipLaunchKernelGGL(k_conv2_wgrad_split_dma, dim3(wg_blocks), dim3(split::kThreads), wdma::kLdsBytes, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch,
-                               (const unsigned *)dy2_absmax, batch, O1, O2, w.wg_part);
+                               (const unsigned *)dy2_absmax, batch, O1, O2, nitems, w.wg_part);
         } else
         hipLaunchKernelGGL(k_conv2_wgrad_split, dim3(wg_blocks), dim3(split::kThreads), split::kWgLdsBytes, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch,
                            (const unsigned *)dy2_absmax, batch, O1, O2, w.wg_part);
