@@ -15,6 +15,12 @@
 // taps, the k-half hand-over, the BN2 partial sums -- is conv_split.h's, with 544 / 1088 / 2176 where that file has 512 / 1024 / 2048.
 // The same kernels run G = 64 (one tile per row; GENNBV_SPLITX=1) -- which is how the G = 64 tests cover this file against the fp64 reference.
 #pragma once
+// The backward kernels come in two instantiations.  LOOP = false: one item per workgroup (gridDim.x >= nitems) -- the item "loop" runs
+// once and the compiler knows it; LOOP = true: a workgroup walks items block, block + grid, ... and keeps its accumulators.  The loop
+// form is the general one (any number of items into <= 512 partial rows) but costs registers where these kernels have none to spare:
+// at G = 64 the data gradient takes 130.8 us with it and 100.4 without, the weight gradient 85.0 and 72.0 (296 / 152 bytes of scratch
+// against none; profiles/r06_splitx_noloop_trace.txt), so the host launches LOOP = false whenever the partial buffers hold a row per item.
+#define SPLITX_FOR_ITEMS for (int item = (int)blockIdx.x, once_ = 1; (LOOP || once_) && item < nitems; item += (int)gridDim.x, once_ = 0)
 
 namespace splitx {
 using split::kThreads; using split::kWaves; using split::kConsWaves; using split::kProdThreads; using split::kNP; using split::kNPl; using split::kRing;
@@ -230,6 +236,7 @@ __global__ __launch_bounds__(split::kThreads) void k_conv2_fwd_splitx(
 // across them -- one partial row per WORKGROUP, so the partial buffer stays at <= 512 rows however many (sample, plane group, tile)
 // items a minibatch has (2 048 at G = 128, batch 128).
 // ---------------------------------------------------------------------------
+template <bool LOOP>
 __global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_splitx(
     const float *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1, const float *__restrict__ dy2 /*[B,O2^3,16]*/,
     const unsigned *__restrict__ absmax, int B, int O1, int O2, int XT, int nitems, float *__restrict__ partial /*[grid][27 * 256 + 16]*/)
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_splitx(
     if (wv >= kConsWaves) {
         // ---- staging waves ----
         const int ptid = tid - kConsWaves * kWave, pw = wv - kConsWaves;
-        for (int item = (int)blockIdx.x; item < nitems; item += (int)gridDim.x) {
+        SPLITX_FOR_ITEMS {
             int b, oz0, oz1, tx;
             if (!item_of(B, O2, XT, item, b, oz0, oz1, tx)) continue;  // (workgroup-uniform)
             const int np = oz1 - oz0, npl = 2 * np + 1;
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(split::kThreads) void k_conv2_wgrad_splitx(
         h8 ones;
 #pragma unroll
         for (int e = 0; e < 8; ++e) ones[e] = (_Float16)1.0f;
-        for (int item = (int)blockIdx.x; item < nitems; item += (int)gridDim.x) {
+        SPLITX_FOR_ITEMS {
             int b, oz0, oz1, tx;
             if (!item_of(B, O2, XT, item, b, oz0, oz1, tx)) continue;
             const int np = oz1 - oz0;
@@ -398,6 +405,7 @@ __device__ __forceinline__ bool item_of(int B, int NA, int XT, int item, int &b,
 static inline int items(int B, int NA, int XT) { return ((B + 7) / 8) * 8 * ((NA + kPairs - 1) / kPairs) * XT; }
 }  // namespace dsplitx
 
+template <bool LOOP>
 __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_splitx(
     const float *__restrict__ dy2, const uint4 *__restrict__ w2img /*prep_w2_dgrad_split_item*/, const float *__restrict__ wbound /*[8 classes][16 ci]*/,
     const unsigned *__restrict__ absmax, const float *__restrict__ y1,
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(dsplit::kThreads) void k_conv2_dgrad_c1w_splitx(
     const float gs = grad_scale(absmax);
     const int P2 = O2 * O2 * O2;
     bool first = true;
-    for (int item = (int)blockIdx.x; item < nitems; item += (int)gridDim.x) {
+    SPLITX_FOR_ITEMS {
         int b, a0, a1, tx;
         if (!item_of(B, NA, XT, item, b, a0, a1, tx)) continue;  // (workgroup-uniform)
         const int x0 = 16 * tx;

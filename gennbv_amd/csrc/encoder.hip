@@ -2295,14 +2295,22 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     if (conv_splitx_path(p, grid)) {
         static bool attr_wx = false;
         if (!attr_wx) {
-            const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_wgrad_splitx, hipFuncAttributeMaxDynamicSharedMemorySize, splitx::kWgLdsBytes);
+            hipError_t e = hipFuncSetAttribute((const void *)k_conv2_wgrad_splitx<true>, hipFuncAttributeMaxDynamicSharedMemorySize, splitx::kWgLdsBytes);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_conv2_wgrad_splitx<false>, hipFuncAttributeMaxDynamicSharedMemorySize, splitx::kWgLdsBytes);
             if (e != hipSuccess) return (int)e;
             attr_wx = true;
         }
         const int XT = (O2 + 15) / 16, nitems = splitx::items(batch, O2, XT);
-        wg_blocks = min(nitems, splitx_max_wg());  // (a workgroup keeps its accumulators across its items: <= 512 partial rows)
-        hipLaunchKernelGGL(k_conv2_wgrad_splitx, dim3(wg_blocks), dim3(split::kThreads), splitx::kWgLdsBytes, sw, (const float *)y1, bn1, bn1 + kC, dy2_scratch,
-                           (const unsigned *)dy2_absmax, batch, O1, O2, XT, nitems, w.wg_part);
+        // one item per workgroup while the partial buffer holds a row per item (2 048 rows of E2: the whole of wg_part -- the conv1 partials
+        // behind row 512 are written later on this stream, by the data gradient); else workgroups walk items (<= 512 rows)
+        const bool wx_loop = nitems > 2048 || splitx_max_wg() < 512;
+        wg_blocks = wx_loop ? min(nitems, splitx_max_wg()) : nitems;
+        if (wx_loop)
+            hipLaunchKernelGGL(k_conv2_wgrad_splitx<true>, dim3(wg_blocks), dim3(split::kThreads), splitx::kWgLdsBytes, sw, (const float *)y1, bn1, bn1 + kC,
+                               dy2_scratch, (const unsigned *)dy2_absmax, batch, O1, O2, XT, nitems, w.wg_part);
+        else
+            hipLaunchKernelGGL(k_conv2_wgrad_splitx<false>, dim3(wg_blocks), dim3(split::kThreads), splitx::kWgLdsBytes, sw, (const float *)y1, bn1, bn1 + kC,
+                               dy2_scratch, (const unsigned *)dy2_absmax, batch, O1, O2, XT, nitems, w.wg_part);
     } else if (split_bwd) {
         static bool attr_wg = false;
         if (!attr_wg) {
@@ -2349,16 +2357,24 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
         if (conv_splitx_path(p, grid)) {
             static bool attr_dx = false;
             if (!attr_dx) {
-                const hipError_t e = hipFuncSetAttribute((const void *)k_conv2_dgrad_c1w_splitx, hipFuncAttributeMaxDynamicSharedMemorySize, dsplit::kLdsBytes);
+                hipError_t e = hipFuncSetAttribute((const void *)k_conv2_dgrad_c1w_splitx<true>, hipFuncAttributeMaxDynamicSharedMemorySize, dsplit::kLdsBytes);
+                if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_conv2_dgrad_c1w_splitx<false>, hipFuncAttributeMaxDynamicSharedMemorySize, dsplit::kLdsBytes);
                 if (e != hipSuccess) return (int)e;
                 attr_dx = true;
             }
             const int NA = (O1 + 1) / 2, XT = (NA + 15) / 16, nitems = dsplitx::items(batch, NA, XT);
-            gd = min(nitems, splitx_max_wg());  // (T1 / S1 / S2 are kept across a workgroup's items: <= 512 partial rows)
-            hipLaunchKernelGGL(k_conv2_dgrad_c1w_splitx, dim3(gd), dim3(dsplit::kThreads), dsplit::kLdsBytes, st, dy2_scratch, (const uint4 *)(w.w2split + split::kW2ImgU4),
-                               (const float *)(w.w2split + split::kW2ImgU4 + dsplit::kImgSlotU4),
-                               (const unsigned *)dy2_absmax, (const float *)y1, bn1, bn1 + kC, bn1 + 2 * kC, bn1 + 3 * kC, p->grid_i8, rows, p->grid_i8_row_stride,
-                               batch, grid, O1, O2, XT, nitems, wg1_part);
+            // (one item per workgroup while wg1_part -- 1 536 rows of E2 floats -- holds a row of kE1F floats per item; else T1 / S1 / S2 are kept
+            // across a workgroup's items: <= 512 partial rows)
+            const bool dx_loop = (size_t)nitems * kE1F > (size_t)1536 * (kTaps * 256 + kC) || splitx_max_wg() < 512;
+            gd = dx_loop ? min(nitems, splitx_max_wg()) : nitems;
+#define GNBV_DGX_ARGS dim3(gd), dim3(dsplit::kThreads), dsplit::kLdsBytes, st, dy2_scratch, (const uint4 *)(w.w2split + split::kW2ImgU4),                    \
+                      (const float *)(w.w2split + split::kW2ImgU4 + dsplit::kImgSlotU4), (const unsigned *)dy2_absmax, (const float *)y1, bn1, bn1 + kC,        \
+                      bn1 + 2 * kC, bn1 + 3 * kC, p->grid_i8, rows, p->grid_i8_row_stride, batch, grid, O1, O2, XT, nitems, wg1_part
+            if (dx_loop)
+                hipLaunchKernelGGL(k_conv2_dgrad_c1w_splitx<true>, GNBV_DGX_ARGS);
+            else
+                hipLaunchKernelGGL(k_conv2_dgrad_c1w_splitx<false>, GNBV_DGX_ARGS);
+#undef GNBV_DGX_ARGS
         } else if (split_bwd) {
             static bool attr_dg = false;
             if (!attr_dg) {
