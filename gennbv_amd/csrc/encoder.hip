@@ -155,12 +155,15 @@ __global__ void k_prep_w2(const float *__restrict__ W2, float *__restrict__ img_
 __device__ void prep_w2_split_in_passing(const float *__restrict__ W2, float *__restrict__ w2img);  // conv_split.h: the f16 images of the split kernels
 template <bool WIDE>
 __device__ __forceinline__ void prep_w2_split_items(const float *__restrict__ W2, float *__restrict__ w2img, int first, int stride);
-__device__ __forceinline__ void prep_w2_in_passing(const float *__restrict__ W2, float *__restrict__ w2img)
+// `split_images` = 0: the fp32 images only.  The f16 images belong to the split kernels (G = 64, 128); their last 128 items are sums over
+// |W2| whose loads the narrow form chains -- at the reference's 20^3, where no split kernel runs, that chain WAS the conv1 launch: 20 us
+// with it, for 6 us of convolution (round 6).
+__device__ __forceinline__ void prep_w2_in_passing(const float *__restrict__ W2, float *__restrict__ w2img, int split_images = 1)
 {
     if (W2 != nullptr) {
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kTaps * 256; i += gridDim.x * blockDim.x)
             prep_w2_element(i, W2, w2img, w2img + kTaps * 256);
-        prep_w2_split_in_passing(W2, w2img);
+        if (split_images) prep_w2_split_in_passing(W2, w2img);
     }
 }
 
@@ -172,9 +175,9 @@ template <typename A, typename IN = float>
 __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd(
     const IN *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, int B, int G, int O1,
     const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ b1, typename A::T *__restrict__ y1,
-    float *__restrict__ partials, const float *__restrict__ W2 = nullptr, float *__restrict__ w2img = nullptr)
+    float *__restrict__ partials, const float *__restrict__ W2 = nullptr, float *__restrict__ w2img = nullptr, int split_images = 1)
 {
-    prep_w2_in_passing(W2, w2img);
+    prep_w2_in_passing(W2, w2img, split_images);
     int b, oz;
     const bool live = sample_plane(B, O1, b, oz);
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform -> SALU index math
@@ -262,9 +265,9 @@ template <typename A, typename IN, bool LDS8 = false>
 __global__ __launch_bounds__(kEncThreads) void k_conv1_fwd_lds(
     const IN *__restrict__ obs_base, const int64_t *__restrict__ rows, int64_t row_stride, int B, int G, int O1,
     const float *__restrict__ W1 /*[16][27]*/, const float *__restrict__ b1, typename A::T *__restrict__ y1,
-    float *__restrict__ partials, const float *__restrict__ W2 = nullptr, float *__restrict__ w2img = nullptr)
+    float *__restrict__ partials, const float *__restrict__ W2 = nullptr, float *__restrict__ w2img = nullptr, int split_images = 1)
 {
-    prep_w2_in_passing(W2, w2img);
+    prep_w2_in_passing(W2, w2img, split_images);
     extern __shared__ __attribute__((aligned(16))) float s_in[];  // [3][NR][G]
     int b, oz;
     const bool live = sample_plane(B, O1, b, oz);
@@ -388,6 +391,16 @@ __device__ __forceinline__ bool sample_plane_group(int B, int O, int PZ, int &b,
 }
 static inline int sample_plane_group_grid(int B, int O, int PZ) { return ((B + 7) / 8) * 8 * ((O + PZ - 1) / PZ); }
 constexpr int kPlanesPerGroup = 4;
+// Planes per workgroup of the fp32 conv2 forward kernel: the smallest of 1, 2, 4 whose grid is at most 512 workgroups (two
+// per CU: one round), four beyond that.  At the reference's 20^3 (O2 = 4, 128 samples) four planes were ONE workgroup per sample whose
+// waves walked two tiles one after the other in a launch that is nothing but latency:
+// forward 128 -> 512 workgroups: 14.3 -> 11.7 us.  (The data gradient does NOT gain: see gnbv_encoder_grid_backward.)
+static inline int planes_per_group(int B, int O)
+{
+    for (int pz = 1; pz < kPlanesPerGroup; pz <<= 1)
+        if (sample_plane_group_grid(B, O, pz) <= 512) return pz;
+    return kPlanesPerGroup;
+}
 constexpr int kBigThreads = 1024;  // conv2 fwd / dgrad: 16 waves share one 27 KiB weight image -> 32 waves per CU
 constexpr int kBigWaves = kBigThreads / kWave;
 
@@ -400,12 +413,12 @@ template <typename A>
 __global__ __launch_bounds__(kFwdThreads) void k_conv2_fwd(
     const typename A::T *__restrict__ y1, const float *__restrict__ scale1, const float *__restrict__ shift1, int B, int O1, int O2,
     const float *__restrict__ W2img /*k_prep_w2 fwd image*/, const float *__restrict__ b2, float *__restrict__ y2,
-    float *__restrict__ partials)
+    float *__restrict__ partials, int PZ /*output planes per workgroup: planes_per_group()*/)
 {
     __shared__ __attribute__((aligned(16))) float w2s[kTaps * 4 * 4 * kC];  // [tap][lane = 16kq + n][s] = W2[n][4kq+s][tap]
     fill_lds_image(w2s, W2img);
     int b, oz0, oz1;
-    const bool live = sample_plane_group(B, O2, kPlanesPerGroup, b, oz0, oz1);
+    const bool live = sample_plane_group(B, O2, PZ, b, oz0, oz1);
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform -> SALU index math
     const int m = lane & 15, kq = lane >> 4;
     if (!live) { write_partials(partials, kFwdWaves, wv, 0.f, 0.f); return; }
@@ -1099,13 +1112,13 @@ template <typename A>
 __global__ __launch_bounds__(kBigThreads) void k_conv2_dgrad(
     const float *__restrict__ dy2, const float *__restrict__ W2, const typename A::T *__restrict__ y1, const float *__restrict__ scale1,
     const float *__restrict__ shift1, const float *__restrict__ mean1, const float *__restrict__ rstd1, int B, int O1, int O2,
-    typename A::T *__restrict__ dz1p, float *__restrict__ partials)
+    typename A::T *__restrict__ dz1p, float *__restrict__ partials, int PZ /*plane pairs per workgroup: planes_per_group()*/)
 {
     __shared__ __attribute__((aligned(16))) float w2d[kTaps * 4 * 4 * kC];  // [tap][lane = 16kq + n][s] = W2[co = 4kq+s][ci = n][tap]
     fill_lds_image(w2d, W2 /* k_prep_w2 dgrad image */);
     const int NA = (O1 + 1) >> 1;  // plane pairs / row pairs / voxels per x-parity
     int b, a0, a1;
-    const bool live = sample_plane_group(B, NA, kPlanesPerGroup, b, a0, a1);
+    const bool live = sample_plane_group(B, NA, PZ, b, a0, a1);
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform -> SALU index math
     const int m = lane & 15, kq = lane >> 4;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -2137,6 +2150,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
         if ((err = gnbv_launch_status())) return err;
     }
     float *c1_part = (training && !analytic) ? w.bn_part : nullptr;
+    const int split_img = (conv_split_path(p, grid) || conv_splitx_path(p, grid)) ? 1 : 0;  // (the f16 weight images: only where a split kernel reads them)
     // conv1 (+ BN1 statistics)
     if (fused_train) {
         static bool attr_ft = false;
@@ -2157,20 +2171,20 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
                                O1, p->w1, p->b1, (float *)y1, p->w2, w.w2img);
         else if (conv1_i8_staged(p, grid))  // compact int8 copy of the tri-class grid: a quarter of the input bytes
             hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, int8_t>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, p->grid_i8, rows,
-                               p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, p->w2, w.w2img);
+                               p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, p->w2, w.w2img, split_img);
         else if (c1_staged)
             hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, float>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds, st, obs_grid, rows,
-                               row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, p->w2, w.w2img);
+                               row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, p->w2, w.w2img, split_img);
         else if (p->grid_i8 != nullptr && grid % 16 == 0 && p->grid_i8_row_stride % 16 == 0 && (((uintptr_t)p->grid_i8 & 15) == 0) &&
                  c1_lds / 4 <= 64 * 1024 && 2 * O1 + 1 <= grid)  // int8 rows, fp32 slab too large (G = 128): int8 slab
             hipLaunchKernelGGL((k_conv1_fwd_lds<ActF32, int8_t, true>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), c1_lds / 4, st, p->grid_i8,
-                               rows, p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, p->w2, w.w2img);
+                               rows, p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, p->w2, w.w2img, split_img);
         else if (obs_grid == nullptr)  // compact rows at a size the staged kernels do not take
             hipLaunchKernelGGL((k_conv1_fwd<ActF32, int8_t>), dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, p->grid_i8, rows,
-                               p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, p->w2, w.w2img);
+                               p->grid_i8_row_stride, batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, p->w2, w.w2img, split_img);
         else
             hipLaunchKernelGGL(k_conv1_fwd<ActF32>, dim3(sample_plane_grid(batch, O1)), dim3(kEncThreads), 0, st, obs_grid, rows, row_stride,
-                               batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, p->w2, w.w2img);
+                               batch, grid, O1, p->w1, p->b1, (float *)y1, c1_part, p->w2, w.w2img, split_img);
     }
     if ((err = gnbv_launch_status())) return err;
     if (analytic) {
@@ -2184,7 +2198,8 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
     if ((err = gnbv_launch_status())) return err;
     }
     // conv2 (BN1 + ReLU on load; + BN2 statistics).  Its LDS weight images were written by the conv1 kernel in passing.
-    int g2 = sample_plane_group_grid(batch, O2, kPlanesPerGroup);
+    const int pz2 = planes_per_group(batch, O2);
+    int g2 = sample_plane_group_grid(batch, O2, pz2);
     if (fused_eval || fused_train) {
         // (y2 was written by k_conv12_fwd_split above)
         g2 = sample_plane_group_grid(batch, O2, split::kNP);
@@ -2212,7 +2227,7 @@ GNBV_API int gnbv_encoder_grid_forward(const float *obs_grid, const int64_t *row
                            (const uint4 *)w.w2split, p->b2, y2, training ? w.bn_part : nullptr);
     } else {
         hipLaunchKernelGGL(k_conv2_fwd<ActF32>, dim3(g2), dim3(kFwdThreads), 0, st, (const float *)y1, bn1, bn1 + kC, batch, O1, O2, w.w2img, p->b2, y2,
-                       training ? w.bn_part : nullptr);
+                       training ? w.bn_part : nullptr, pz2);
     }
     if ((err = gnbv_launch_status())) return err;
     if (training && dp) {
@@ -2353,6 +2368,9 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     }
     // ---- conv2 data gradient (+ ReLU1 mask, BN1 backward sums) ----
     int gd = sample_plane_group_grid(batch, (O1 + 1) / 2, kPlanesPerGroup);  // groups of plane PAIRS
+    // (the data gradient keeps four plane pairs per workgroup at every size: with two -- 384 workgroups at 20^3 -- or one -- 640 -- it took
+    // 20-21 us instead of 16: every workgroup starts by copying the 27 KiB weight image, and that prologue is what these launches are made of)
+    const int pzd = kPlanesPerGroup;
     if (fused) {
         if (conv_splitx_path(p, grid)) {
             static bool attr_dx = false;
@@ -2408,7 +2426,7 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     }
     {
         hipLaunchKernelGGL(k_conv2_dgrad<ActF32>, dim3(gd), dim3(kBigThreads), 0, st, dy2_scratch, (const float *)(w.w2img + kTaps * 256), (const float *)y1, bn1, bn1 + kC, bn1 + 2 * kC,
-                       bn1 + 3 * kC, batch, O1, O2, (float *)dz1_scratch, w.bn_part);
+                       bn1 + 3 * kC, batch, O1, O2, (float *)dz1_scratch, w.bn_part, pzd);
     }
     if ((err = gnbv_launch_status())) return err;
     double *S1 = w.red + 192;

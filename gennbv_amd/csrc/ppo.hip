@@ -331,9 +331,20 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_loss_rsl(int B, const floa
 __global__ __launch_bounds__(256) void k_grad_sqnorm(const float *__restrict__ g, int64_t n_eff, int64_t lo, int64_t gap, double *__restrict__ partial,
                                                      float grad_scale, int64_t *step, int *stop_flag, const float *kl_slot, float target_kl,
                                                      int nblocks /*norm blocks; then, if launched: one block that folds `extra`, one that finishes the loss*/,
-                                                     const double *__restrict__ extra, int nextra, int fin_block, GnbvPpoLoss fin)
+                                                     const double *__restrict__ extra, int nextra, int fin_block, GnbvPpoLoss fin,
+                                                     float *__restrict__ hyper /*[2]: Adam's step size lr / (1 - beta1^t) and sqrt(1 - beta2^t)*/, float lr,
+                                                     float beta1, float beta2)
 {
     static_assert(kLossThreads == 256, "the finish block is one loss workgroup");
+    // Adam's bias corrections (fp64 pow, like torch's scalar path) are functions of the step counter alone: evaluated ONCE, by the thread
+    // that has just counted the step, instead of by every lane of the update launch (two fp64 pow per lane were a quarter of that
+    // launch at 20^3, where it is 2 070 workgroups of prologue and one trip of work).  Same expressions: the same bits.
+    auto bias_corrections = [&]() {
+        const double t = (double)(*step);
+        const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
+        hyper[0] = (float)((double)lr / bc1);
+        hyper[1] = (float)sqrt(bc2);
+    };
     if (extra != nullptr && (int)blockIdx.x == nblocks) {
         // the producer's partial sums of the skipped slice (gnbv_linear_bwd_dw_sq: 844 of them) folded into ONE more partial here,
         // so that the update's workgroups re-add ~200 numbers each instead of ~1040 (that prologue cost the Adam launch 5-10 us)
@@ -354,6 +365,7 @@ __global__ __launch_bounds__(256) void k_grad_sqnorm(const float *__restrict__ g
         // scalars, the KL stop decision and -- in the SAME thread, after that decision -- the optimizer step counter
         __shared__ float fscratch[kLossThreads / 64 + 1];
         ppo_stats_finish(fin, fin.scratch, fscratch, step);
+        if (threadIdx.x == 0 && hyper != nullptr) bias_corrections();  // (thread 0 counted the step: program order)
         return;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && step != nullptr && fin_block < 0) {
@@ -361,6 +373,7 @@ __global__ __launch_bounds__(256) void k_grad_sqnorm(const float *__restrict__ g
         // stop flag before this step's update
         if (stop_flag != nullptr && kl_slot != nullptr && target_kl > 0.f && (*kl_slot) * grad_scale > 1.5f * target_kl) *stop_flag = 1;
         if (!(stop_flag != nullptr && *stop_flag != 0)) *step += 1;
+        if (hyper != nullptr) bias_corrections();
     }
     double acc = 0.0;
     const bool vec = (((uintptr_t)g & 15) == 0) && (gap == 0 || ((lo & 3) == 0 && (gap & 3) == 0));  // (no gap: `lo` = n marks nothing and need not be aligned)
@@ -403,8 +416,11 @@ __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, 
                             const int *__restrict__ stop_flag,
                             const int64_t *__restrict__ step /*already incremented*/, float lr, float beta1, float beta2, float eps,
                             const int64_t *__restrict__ rot_table = nullptr, int rot_rows = 0, int rot_len = 0, int64_t *__restrict__ rot_out = nullptr,
-                            int *__restrict__ rot_counter = nullptr)
+                            int *__restrict__ rot_counter = nullptr, const float *__restrict__ hyper = nullptr /*[2] from the norm launch, or NULL*/,
+                            int *__restrict__ defer_skip = nullptr /*GnbvAdamStep.defer_skip*/)
 {
+    // (a slice of this step is updated LATER, by gnbv_adam_slice_step in front of the next forward: tell it whether this step is masked)
+    if (defer_skip != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *defer_skip = (stop_flag != nullptr && *stop_flag != 0) ? 1 : 0;
     // (replayed minibatch graphs: the LAST launch of a minibatch leaves the next minibatch's row numbers in the buffer every kernel
     // of the graph reads them from -- no copy node, no host work between two replays.  Also when the update itself is masked.)
     if (rot_table != nullptr && blockIdx.x == 0) {
@@ -439,10 +455,16 @@ __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, 
         }
     }
     // bias corrections in double like torch's scalar path (1 - beta**step evaluated in Python floats)
-    const double t = (double)(*step);
-    const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
-    const float step_size = (float)((double)lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
+    float step_size, bc2_sqrt;
+    if (hyper != nullptr) {  // (k_grad_sqnorm evaluated them once for this step)
+        step_size = hyper[0];
+        bc2_sqrt = hyper[1];
+    } else {
+        const double t = (double)(*step);
+        const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
+        step_size = (float)((double)lr / bc1);
+        bc2_sqrt = (float)sqrt(bc2);
+    }
     const int64_t gap = skip_hi > skip_lo ? skip_hi - skip_lo : 0;  // (the grid covers the n - gap live elements only)
     const int64_t live = n - gap, stride = (int64_t)gridDim.x * blockDim.x;
     auto one = [&](float &pp, const float gg, float &mm, float &vv) {
@@ -618,6 +640,7 @@ GNBV_API int gnbv_clip_adam_step_ex(const GnbvAdamStep *a, void *stream)
     GNBV_CHECK_ARG(a->upd_skip_hi <= a->upd_skip_lo || (a->upd_skip_lo >= 0 && a->upd_skip_hi <= a->n));
     hipStream_t st = gnbv_stream(stream);
     double *partial = (double *)a->workspace;
+    float *hyper = (float *)(partial + 1026);  // (the 64 bytes behind the partial sums)
     const int64_t gap = sliced ? a->sq_hi - a->sq_lo : 0, n_eff = a->n - gap;
     int blocks = (int)((n_eff + 256 * 16 - 1) / (256 * 16));
     blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
@@ -630,12 +653,15 @@ GNBV_API int gnbv_clip_adam_step_ex(const GnbvAdamStep *a, void *stream)
     const int fold = sliced ? 1 : 0, fin_block = finish ? blocks + fold : -1;
     hipLaunchKernelGGL(k_grad_sqnorm, dim3(blocks + fold + (finish ? 1 : 0)), dim3(256), 0, st, a->grads, n_eff, sliced ? a->sq_lo : a->n, gap, partial,
                        a->grad_scale, a->step, a->stop_flag, a->kl_slot, a->target_kl, blocks, sliced ? a->sq_partial : (const double *)nullptr,
-                       sliced ? a->sq_parts : 0, fin_block, fin);
+                       sliced ? a->sq_parts : 0, fin_block, fin, hyper, a->lr, a->beta1, a->beta2);
     const int64_t upd_gap = a->upd_skip_hi > a->upd_skip_lo ? a->upd_skip_hi - a->upd_skip_lo : 0;
     int ab = (int)((a->n - upd_gap + 255) / 256);
     // (a sharded step updates the 0.8 M parameters outside the slice here: one element per lane was 3 125 workgroups, ~10 us of DISPATCH
     // for 23 MB of traffic -- two 16-byte trips per lane instead: 17 -> 8 us in the one-rank data-parallel step)
     if (upd_gap > 0) ab = (int)((a->n - upd_gap + 256 * 8 - 1) / (256 * 8));
+    // (small parameter sets -- the reference's 20^3 encoder: 0.53 M -- two 16-byte trips per lane: 2 070 workgroups that each repeat the
+    // prologue for a quarter of a trip of work became 259; above 2 M parameters the cap below decides as before)
+    else if (ab <= 8192) ab = (int)((a->n + 256 * 8 - 1) / (256 * 8));
     ab = ab < 1 ? 1 : ab;
 #ifndef GNBV_ADAM_BLOCKS
 #define GNBV_ADAM_BLOCKS 8192  // (same-call A/B of the whole bench: 2048 workgroups +5 us per minibatch, 4096 +1-2 us)
@@ -644,7 +670,25 @@ GNBV_API int gnbv_clip_adam_step_ex(const GnbvAdamStep *a, void *stream)
     hipLaunchKernelGGL(k_adam_flat, dim3(ab), dim3(256), 0, st, a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->n, (const double *)partial, blocks + fold,
                        (const double *)nullptr, 0, a->max_grad_norm, a->grad_scale, a->norm_out,
                        (const float *)nullptr, a->upd_skip_lo, a->upd_skip_hi, (const int *)a->stop_flag, (const int64_t *)a->step, a->lr, a->beta1, a->beta2, a->eps, a->table, a->table_rows, a->row_len, a->out,
-                       a->counter);
+                       a->counter, (const float *)hyper, a->defer_skip);
+    return gnbv_launch_status();
+}
+
+// Adam on a contiguous slice of n parameters with the clip factor (norm_out[1]) and the bias corrections (workspace) that
+// gnbv_clip_adam_step_ex of the SAME optimizer step left behind -- the slice that step skipped (upd_skip_lo / hi), updated LATER: in front
+// of the next minibatch's forward, on a second stream beside the conv kernels, which do not read it (fc_grid.weight: 13.8 M of the
+// 14.4 M parameters at G = 64, i.e. nearly all of the update's 400 MB of traffic).  `skip` = GnbvAdamStep.defer_skip of that step
+// (nonzero: the step was masked, or nothing is pending); neither the step counter nor any flag is modified.
+GNBV_API int gnbv_adam_slice_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const float *norm_out,
+                                  const void *workspace, float lr, float beta1, float beta2, float eps, const int64_t *step, const int *skip, void *stream)
+{
+    GNBV_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && norm_out && workspace && step && skip && n > 0);
+    const float *hyper = (const float *)((const double *)workspace + 1026);
+    int ab = (int)((n + 255) / 256);
+    ab = ab > GNBV_ADAM_BLOCKS ? GNBV_ADAM_BLOCKS : ab;
+    hipLaunchKernelGGL(k_adam_flat, dim3(ab), dim3(256), 0, gnbv_stream(stream), params, grads, exp_avg, exp_avg_sq, n, (const double *)nullptr, 0,
+                       (const double *)nullptr, 0, 0.0f, 1.0f, (float *)nullptr, norm_out, (int64_t)0, (int64_t)0, skip, step, lr, beta1, beta2, eps,
+                       (const int64_t *)nullptr, 0, 0, (int64_t *)nullptr, (int *)nullptr, hyper);
     return gnbv_launch_status();
 }
 

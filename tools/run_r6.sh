@@ -40,6 +40,9 @@ PY
              ;;
   refdef)    timeout 1200 python bench.py --steps 3 --warmup 1 --height 400 --width 400 --grid 20 --no-flat-rows 2>$O/r6_refdef.err | tail -1 > $O/r06_bench_refdefault_n1.json; cut -c1-300 $O/r06_bench_refdefault_n1.json ;;
   semantic)  timeout 900 python bench.py --steps 3 --warmup 1 --semantic --no-cpu-baseline --no-flat-rows 2>/dev/null | tail -1 > $O/r06_bench_semantic_n1.json; cut -c1-300 $O/r06_bench_semantic_n1.json ;;
+  t_small)   timeout 900 python -m pytest tests/test_ppo_gpu.py tests/test_encoder_gpu.py -m gpu -q -x -p no:cacheprovider > $O/r6_t_small.log 2>&1; tail -5 $O/r6_t_small.log ;;
+  ab20)      timeout 900 python tools/ab_interleaved.py --what train --grid 20 --height 400 --width 400 --rounds 12 --captures 2 --variant "base:LIB=gennbv_amd/libgennbv_hip_r6base.so" --variant "new" --json $O/r06_ab_train_g20.json 2>&1 | tail -12 ;;
+  ab64)      timeout 900 python tools/ab_interleaved.py --what train --rounds 12 --captures 3 --variant "base:LIB=gennbv_amd/libgennbv_hip_r6base.so" --variant "new" --json $O/r06_ab_train_g64_adam_hyper.json 2>&1 | tail -12 ;;
   tests)     timeout 1500 python -m pytest tests -m gpu -q --maxfail=12 --durations=12 -p no:cacheprovider > $O/r6_tests.log 2>&1; tail -30 $O/r6_tests.log ;;
   bench)     timeout 900 python bench.py --steps 5 --warmup 2 2>$O/r6_bench.err | tail -1 > $O/r6_bench_n1.json; cut -c1-900 $O/r6_bench_n1.json ;;
   benchdrv)  timeout 1200 python bench.py --steps 20 --warmup 5 2>$O/r6_benchdrv.err | tail -1 > $O/r6_bench_driver_cfg_n1.json; cut -c1-600 $O/r6_bench_driver_cfg_n1.json ;;
