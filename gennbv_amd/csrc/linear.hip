@@ -452,13 +452,29 @@ __global__ __launch_bounds__(256) void k_fc_bwd_prep(const float *__restrict__ d
     if (!is_dx && row >= N) return;
     const int C = is_dx ? N : M;                  // contraction length
     const int Cp = (C + 31) & ~31, ksteps = Cp / 32;
-    float amax = 0.0f, sum = 0.0f;
-    for (int c = lane; c < C; c += 64) {
-        const size_t idx = is_dx ? (size_t)row * N + c : (size_t)c * N + row;
-        const float gv = out[idx] > 0.0f ? d_out[idx] : 0.0f;
-        amax = fmaxf(amax, fabsf(gv));
-        sum += gv;
+    // C <= 256 (gnbv_linear_bwd_prep): at most four values per lane, ALL requested before the first is used and kept for the second
+    // pass (the two run-time loops were up to four dependent round trips each in a launch that sits on the update's critical path;
+    // same operations in the same order per lane: the same bits)
+    float gvs[4];
+    {
+        float o[4], d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = min(lane + 64 * u, C - 1);
+            const size_t idx = is_dx ? (size_t)row * N + c : (size_t)c * N + row;
+            o[u] = out[idx];
+            d[u] = d_out[idx];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gvs[u] = (lane + 64 * u < C && o[u] > 0.0f) ? d[u] : 0.0f;
     }
+    float amax = 0.0f, sum = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (lane + 64 * u < C) {
+            amax = fmaxf(amax, fabsf(gvs[u]));
+            sum += gvs[u];
+        }
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         amax = fmaxf(amax, __shfl_xor(amax, d, 64));
@@ -466,18 +482,17 @@ __global__ __launch_bounds__(256) void k_fc_bwd_prep(const float *__restrict__ d
     }
     const float sc = pow2_scale_for(amax);
     _Float16 *frag = is_dx ? fragA_dx : fragA_dw;
-    for (int c = lane; c < Cp; c += 64) {
-        float gv = 0.0f;
-        if (c < C) {
-            const size_t idx = is_dx ? (size_t)row * N + c : (size_t)c * N + row;
-            gv = out[idx] > 0.0f ? d_out[idx] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = lane + 64 * u;
+        if (c < Cp) {
+            _Float16 hi, lo;
+            const float t = gvs[u] * sc;  // (gvs[u] is 0 for c >= C: the padding columns of the last k-step)
+            hi = (_Float16)t;
+            lo = (_Float16)(t - (float)hi);
+            frag[frag_pos(row, c, ksteps, 0)] = hi;
+            frag[frag_pos(row, c, ksteps, 1)] = lo;
         }
-        _Float16 hi, lo;
-        const float t = gv * sc;
-        hi = (_Float16)t;
-        lo = (_Float16)(t - (float)hi);
-        frag[frag_pos(row, c, ksteps, 0)] = hi;
-        frag[frag_pos(row, c, ksteps, 1)] = lo;
     }
     if (lane == 0) {
         (is_dx ? inv_dx : inv_dw)[row] = 1.0f / sc;

@@ -99,24 +99,44 @@ __device__ void ppo_stats_finish(const GnbvPpoLoss &a, const float *__restrict__
 {
     const int B = a.batch, tid = threadIdx.x;
     const float invB = 1.0f / (float)B;
+    // (thread 0's two dependent words are requested before the sums, not after them: this workgroup is the longest of its launch)
+    int stopped_before = 0;
+    int64_t stats_row = 0;
+    if (tid == 0) {
+        stopped_before = a.stop_flag ? *a.stop_flag : 0;
+        stats_row = *a.stats_row;
+    }
     float pg = 0.f, vl = 0.f, en = 0.f, kl = 0.f, cf = 0.f;
     for (int j = tid; j < B; j += kLossThreads) {
         const volatile float *t = terms + (size_t)j * 8;
         pg += t[0]; vl += t[1]; en += t[2]; kl += t[3]; cf += t[4];
     }
-    pg = block_sum<kLossThreads>(pg, scratch) * invB;
-    vl = block_sum<kLossThreads>(vl, scratch) * invB;
-    en = block_sum<kLossThreads>(en, scratch) * invB;
-    kl = block_sum<kLossThreads>(kl, scratch) * invB;
-    cf = block_sum<kLossThreads>(cf, scratch) * invB;
+    // the five block sums TOGETHER: the five wave reductions interleave and share one pair of barriers (five block_sum calls were ten
+    // barriers and five exposed reduction chains in a row); per sum the same operations in the same order as block_sum: the same bits
+    {
+        __shared__ float five[5][kLossThreads / 64];
+        pg = wave_reduce_sum(pg); vl = wave_reduce_sum(vl); en = wave_reduce_sum(en); kl = wave_reduce_sum(kl); cf = wave_reduce_sum(cf);
+        __syncthreads();
+        if ((tid & 63) == 0) {
+            const int w = tid >> 6;
+            five[0][w] = pg; five[1][w] = vl; five[2][w] = en; five[3][w] = kl; five[4][w] = cf;
+        }
+        __syncthreads();
+        float t5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int i = 0; i < kLossThreads / 64; ++i) t5[q] += five[q][i];
+        pg = t5[0] * invB; vl = t5[1] * invB; en = t5[2] * invB; kl = t5[3] * invB; cf = t5[4] * invB;
+    }
+    (void)scratch;
     if (tid == 0) {
         const float loss = pg * a.policy_scale + a.ent_coef * en + a.vf_coef * vl;
-        const int stopped_before = a.stop_flag ? *a.stop_flag : 0;
-        float *row = a.stats + (size_t)(*a.stats_row) * 8;
+        float *row = a.stats + (size_t)stats_row * 8;
         row[0] = pg; row[1] = vl; row[2] = en; row[3] = kl; row[4] = cf; row[5] = loss;
         row[6] = stopped_before ? 0.f : 1.f;  // live row (the reference never ran this minibatch otherwise)
         row[7] = 0.f;
-        *a.stats_row += 1;
+        *a.stats_row = stats_row + 1;
         if (a.kl_out) *a.kl_out = kl;  // data-parallel: the decision is taken on the global mean after the all-reduce
         else if (a.stop_flag && a.target_kl > 0.f && kl > 1.5f * a.target_kl) *a.stop_flag = 1;  // sticky (:264-268)
         if (step != nullptr && !(a.stop_flag != nullptr && *a.stop_flag != 0)) *step += 1;
@@ -131,6 +151,12 @@ __device__ void ppo_stats_finish(const GnbvPpoLoss &a, const float *__restrict__
 // scalars, which the workgroup that finishes last adds up in a fixed order (per-sample terms in `scratch`).
 // (A single workgroup walking all samples serially was measured at ~130 us.)
 // ---------------------------------------------------------------------------
+// NH > 0, REGS: the number of heads is a compile-time constant and every head has <= 128 categories (the reference's action lattice:
+// six heads of 81, 81, 51, 1, 13, 13).  The per-head code then is ONE straight-line block -- no `h < n_heads` / `regs` / pointer branches
+// between the heads --, so the scheduler interleaves the six heads' reductions (18 dependent lane exchanges each, ~60 cycles apiece: six
+// chains one after the other were ~2.5 us of this launch, which sits on the critical path of every minibatch).  Same operations per
+// head in the same order: the same bits.  NH = 0: heads and their sizes at run time (any lattice).
+template <int NH, bool REGS>
 __global__ __launch_bounds__(kLossThreads) void k_ppo_fused(GnbvPpoLoss a, float *__restrict__ terms /*[B][8]*/, int *__restrict__ counter)
 {
     __shared__ float scratch[kLossThreads / 64 + 1];
@@ -138,6 +164,7 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_fused(GnbvPpoLoss a, float
     const int B = a.batch, tid = threadIdx.x, lane = tid & 63;
     const int i = blockIdx.x * (kLossThreads / 64) + (tid >> 6);
     const float invB = 1.0f / (float)B;
+    const int n_heads = NH ? NH : a.n_heads;
     if (i < B) {
         const float *lg = a.logits + (size_t)i * a.n_logits;
         const int64_t r = src_row(a, i);
@@ -158,22 +185,23 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_fused(GnbvPpoLoss a, float
             int off = 0;
 #pragma unroll
             for (int h = 0; h < kMaxHeads; ++h) {
-                if (h < a.n_heads) {
+                if (h < n_heads) {
                     const int n = a.head_dims[h];
                     regs = regs && n <= 128;
                     x0[h] = lg[off + min(lane, n - 1)];
                     x1[h] = lg[off + min(lane + 64, n - 1)];
-                    act[h] = (int)a.actions[(size_t)r * a.n_heads + h];  // actions are stored as float (buffers.py:664)
+                    act[h] = (int)a.actions[(size_t)r * n_heads + h];  // actions are stored as float (buffers.py:664)
                     off += n;
                 }
             }
+            if (REGS) regs = true;
             off = 0;
 #pragma unroll
             for (int h = 0; h < kMaxHeads; ++h) {
-                if (h < a.n_heads) {
+                if (h < n_heads) {
                     // the taken action's logit: with the head in registers it is in lane act & 63 already (round 5: a lane exchange instead
                     // of a third dependent round trip rows -> actions -> logits[action])
-                    if (regs) {
+                    if (REGS || regs) {
                         const float lo_ = __shfl(x0[h], act[h] & 63, 64), hi_ = __shfl(x1[h], act[h] & 63, 64);
                         xa[h] = act[h] < 64 ? lo_ : hi_;
                     } else {
@@ -187,15 +215,23 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_fused(GnbvPpoLoss a, float
             int off = 0;
 #pragma unroll
             for (int h = 0; h < kMaxHeads; ++h) {
-                if (h < a.n_heads) {
+                if (h < n_heads) {
                     const int n = a.head_dims[h];
-                    const HeadStats hs = regs ? head_stats_regs(x0[h], x1[h], n, lane) : head_stats(lg + off, n, lane);
+                    const HeadStats hs = (REGS || regs) ? head_stats_regs(x0[h], x1[h], n, lane) : head_stats(lg + off, n, lane);
                     lse[h] = hs.lse; hent[h] = hs.ent;
                     logp += xa[h] - hs.lse;
                     ent += hs.ent;
-                    if (a.head_entropy && lane == 0) a.head_entropy[(size_t)i * a.n_heads + h] = hs.ent;
-                    if (a.head_lse && lane == 0) a.head_lse[(size_t)i * a.n_heads + h] = hs.lse;
                     off += n;
+                }
+            }
+            // (the optional per-head outputs: stored behind the loop, so that no pointer test ends a head's basic block)
+            if ((a.head_entropy || a.head_lse) && lane == 0) {
+#pragma unroll
+                for (int h = 0; h < kMaxHeads; ++h) {
+                    if (h < n_heads) {
+                        if (a.head_entropy) a.head_entropy[(size_t)i * n_heads + h] = hent[h];
+                        if (a.head_lse) a.head_lse[(size_t)i * n_heads + h] = lse[h];
+                    }
                 }
             }
         }
@@ -250,12 +286,24 @@ __global__ __launch_bounds__(kLossThreads) void k_ppo_fused(GnbvPpoLoss a, float
         int off = 0;
 #pragma unroll
         for (int h = 0; h < kMaxHeads; ++h) {
-            if (h < a.n_heads) {
+            if (h < n_heads) {
                 const int n = a.head_dims[h];
-                for (int j = lane; j < n; j += 64) {
-                    const float xv = regs ? (j == lane ? x0[h] : x1[h]) : lg[off + j];
-                    const float lp = xv - lse[h], p = expf(lp);
-                    dl[off + j] = gl * ((j == act[h] ? 1.f : 0.f) - p) + a.ent_coef * invB * p * (lp + hent[h]);
+                if (REGS) {
+                    // (two predicated steps instead of a loop over j = lane, lane + 64: straight-line across the heads)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int j = lane + 64 * half;
+                        const float xv = half ? x1[h] : x0[h];
+                        const float lp = xv - lse[h], p = expf(lp);
+                        const float d = gl * ((j == act[h] ? 1.f : 0.f) - p) + a.ent_coef * invB * p * (lp + hent[h]);
+                        if (j < n) dl[off + j] = d;
+                    }
+                } else {
+                    for (int j = lane; j < n; j += 64) {
+                        const float xv = regs ? (j == lane ? x0[h] : x1[h]) : lg[off + j];
+                        const float lp = xv - lse[h], p = expf(lp);
+                        dl[off + j] = gl * ((j == act[h] ? 1.f : 0.f) - p) + a.ent_coef * invB * p * (lp + hent[h]);
+                    }
                 }
                 off += n;
             }
@@ -598,7 +646,14 @@ GNBV_API int gnbv_ppo_loss(const GnbvPpoLoss *a, void *stream)
     GNBV_CHECK_ARG(sum == a->n_logits && a->scratch);
     hipStream_t st = gnbv_stream(stream);
     const int blocks = (a->batch + kLossThreads / 64 - 1) / (kLossThreads / 64);
-    hipLaunchKernelGGL(k_ppo_fused, dim3(blocks), dim3(kLossThreads), 0, st, *a, a->scratch, (int *)(a->scratch + 8 * (size_t)a->batch));
+    bool small_heads = true;
+    for (int h = 0; h < a->n_heads; ++h) small_heads = small_heads && a->head_dims[h] >= 1 && a->head_dims[h] <= 128;
+    const char *ge = getenv("GENNBV_PPO_GENERIC");  // (=1: the run-time form for every lattice -- A/B runs, the bit-identity test)
+    const bool generic_only = ge && ge[0] == '1';
+    if (a->n_heads == 6 && small_heads && !generic_only)  // (the reference's lattice has six heads; any other count takes the run-time form)
+        hipLaunchKernelGGL((k_ppo_fused<6, true>), dim3(blocks), dim3(kLossThreads), 0, st, *a, a->scratch, (int *)(a->scratch + 8 * (size_t)a->batch));
+    else
+        hipLaunchKernelGGL((k_ppo_fused<0, false>), dim3(blocks), dim3(kLossThreads), 0, st, *a, a->scratch, (int *)(a->scratch + 8 * (size_t)a->batch));
     return gnbv_launch_status();
 }
 

@@ -121,6 +121,35 @@ def test_ppo_loss_kernel_vs_torch_autograd():
     assert int(op.stats_row.item()) == 1 and int(op.stop_flag.item()) == int(ref[3] > 0.075)
 
 
+@pytest.mark.parametrize("dims", [[81, 81, 51, 1, 13, 13], [7, 5, 128, 1, 64, 2]])
+def test_ppo_loss_six_head_kernel_is_bit_identical_to_the_runtime_form(dims, monkeypatch):
+    """Round 6: with six heads of <= 128 categories (the reference's lattice) the loss kernel is the instantiation whose per-head code is one
+    straight-line block (k_ppo_fused<6, true>: the heads' reductions interleave); GENNBV_PPO_GENERIC=1 selects the run-time form every other
+    lattice takes.  Same operations per head in the same order: gradients, per-sample terms and statistics must be the same bits."""
+    from gennbv_amd.ops.ppo_ops import PpoLossOp
+    torch.manual_seed(1)
+    B = 128
+    logits = torch.randn(B, sum(dims), device=DEV) * 2
+    values = torch.randn(B, device=DEV)
+    acts = torch.stack([torch.randint(0, n, (B,)) for n in dims], -1).float().to(DEV)
+    rnd = [torch.randn(B, device=DEV) for _ in range(4)]
+    out = []
+    for generic in ("0", "1"):
+        monkeypatch.setenv("GENNBV_PPO_GENERIC", generic)
+        op = PpoLossOp(B, dims, DEV, 4, 0.2, 0.2, 0.01, 0.8, 10.0, 0.05)
+        op.actions.copy_(acts)
+        op.old_values.copy_(values + 0.3 * rnd[0])
+        op.advantages.copy_(rnd[1] * 2 + 0.5)
+        op.returns.copy_(rnd[2])
+        op.old_log_prob.copy_(-8.0 + 0.25 * rnd[3])
+        dl, dv = op(logits, values)
+        torch.cuda.synchronize()
+        out.append((dl.clone(), dv.clone(), op.scratch[:8 * B].clone(), op.stats[0].clone()))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert bool(torch.isfinite(out[0][0]).all()) and float(out[0][0].abs().max()) > 0
+
+
 def test_flat_adam_matches_torch_adam_with_clipping():
     from gennbv_amd.ops.ppo_ops import FlatAdam
     torch.manual_seed(1)

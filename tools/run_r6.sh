@@ -41,11 +41,14 @@ PY
   refdef)    timeout 1200 python bench.py --steps 3 --warmup 1 --height 400 --width 400 --grid 20 --no-flat-rows 2>$O/r6_refdef.err | tail -1 > $O/r06_bench_refdefault_n1.json; cut -c1-300 $O/r06_bench_refdefault_n1.json ;;
   semantic)  timeout 900 python bench.py --steps 3 --warmup 1 --semantic --no-cpu-baseline --no-flat-rows 2>/dev/null | tail -1 > $O/r06_bench_semantic_n1.json; cut -c1-300 $O/r06_bench_semantic_n1.json ;;
   t_small)   timeout 900 python -m pytest tests/test_ppo_gpu.py tests/test_encoder_gpu.py -m gpu -q -x -p no:cacheprovider > $O/r6_t_small.log 2>&1; tail -5 $O/r6_t_small.log ;;
-  ab20)      timeout 900 python tools/ab_interleaved.py --what train --grid 20 --height 400 --width 400 --rounds 12 --captures 2 --variant "base:LIB=gennbv_amd/libgennbv_hip_r6base.so" --variant "new" --json $O/r06_ab_train_g20.json 2>&1 | tail -12 ;;
-  ab64)      timeout 900 python tools/ab_interleaved.py --what train --rounds 12 --captures 3 --variant "base:LIB=gennbv_amd/libgennbv_hip_r6base.so" --variant "new" --json $O/r06_ab_train_g64_adam_hyper.json 2>&1 | tail -12 ;;
+  ab20)      timeout 900 python tools/ab_interleaved.py --what train --grid 20 --height 400 --width 400 --rounds 12 --captures 2 --variant "base:LIB=gennbv_amd/libgennbv_hip_r6base.so" --variant "new" --json $O/r06_ab_train_g20_b.json 2>&1 | tail -12 ;;
+  ab64)      timeout 900 python tools/ab_interleaved.py --what train --rounds 12 --captures 3 --variant "base:LIB=gennbv_amd/libgennbv_hip_r6base.so" --variant "new" --json $O/r06_ab_train_g64_b.json 2>&1 | tail -12 ;;
   t_pipe)    timeout 900 python -m pytest tests/test_ppo_gpu.py -m gpu -q -x -p no:cacheprovider -k "pipelined or fused_train or recapture" > $O/r6_t_pipe.log 2>&1; tail -5 $O/r6_t_pipe.log ;;
   ab64p)     timeout 900 python tools/ab_interleaved.py --what train --rounds 12 --captures 3 --variant "onelaunch:GENNBV_PIPELINED_ADAM=0" --variant "pipelined" --json $O/r06_ab_train_g64_pipelined_adam.json 2>&1 | tail -12 ;;
   ab20p)     timeout 900 python tools/ab_interleaved.py --what train --grid 20 --height 400 --width 400 --rounds 12 --captures 2 --variant "onelaunch:GENNBV_PIPELINED_ADAM=0" --variant "pipelined" --json $O/r06_ab_train_g20_pipelined_adam.json 2>&1 | tail -10 ;;
+  t_ppo)     timeout 900 python -m pytest tests/test_ppo_gpu.py -m gpu -q -x -p no:cacheprovider > $O/r6_t_ppo.log 2>&1; tail -5 $O/r6_t_ppo.log ;;
+  ab64k)     timeout 900 python tools/ab_interleaved.py --what train --rounds 12 --captures 3 --variant "generic:GENNBV_PPO_GENERIC=1" --variant "sixheads" --json $O/r06_ab_train_g64_ppo_six_heads.json 2>&1 | tail -12 ;;
+  ab20k)     timeout 900 python tools/ab_interleaved.py --what train --grid 20 --height 400 --width 400 --rounds 12 --captures 2 --variant "generic:GENNBV_PPO_GENERIC=1" --variant "sixheads" --json $O/r06_ab_train_g20_ppo_six_heads.json 2>&1 | tail -10 ;;
   tests)     timeout 1500 python -m pytest tests -m gpu -q --maxfail=12 --durations=12 -p no:cacheprovider > $O/r6_tests.log 2>&1; tail -30 $O/r6_tests.log ;;
   bench)     timeout 900 python bench.py --steps 5 --warmup 2 2>$O/r6_bench.err | tail -1 > $O/r6_bench_n1.json; cut -c1-900 $O/r6_bench_n1.json ;;
   benchdrv)  timeout 1200 python bench.py --steps 20 --warmup 5 2>$O/r6_benchdrv.err | tail -1 > $O/r6_bench_driver_cfg_n1.json; cut -c1-600 $O/r6_bench_driver_cfg_n1.json ;;
