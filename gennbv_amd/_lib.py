@@ -85,7 +85,6 @@ SIGNATURES = {
     "gnbv_sq_partials_count": (_i, []),
     "gnbv_sq_partials": (_i, [_p, _i64, _p, _p]),
     "gnbv_adam_shard_step": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _p, _p, _p]),
-    "gnbv_adam_slice_step": (_i, [_p, _p, _p, _p, _i64, _p, _p, _f, _f, _f, _f, _p, _p, _p]),
     "gnbv_chamfer_workspace_bytes": (_sz, [_i, _i]),
     "gnbv_chamfer_distance": (_i, [_p, _i, _p, _i, _p, _p, _sz, _p]),
     "gnbv_gae_sb3": (_i, [_p, _p, _p, _p, _p, _i, _i, _d, _d, _p, _p, _p]),
@@ -127,8 +126,7 @@ class GnbvAdamStep(C.Structure):
                 ("step", _p), ("stop_flag", _p), ("grad_scale", _f), ("kl_slot", _p), ("target_kl", _f),
                 ("norm_out", _p), ("workspace", _p), ("workspace_bytes", _sz),
                 ("table", _p), ("table_rows", _i), ("row_len", _i), ("out", _p), ("counter", _p),
-                ("sq_lo", _i64), ("sq_hi", _i64), ("sq_partial", _p), ("sq_parts", _i), ("loss_finish", _p), ("upd_skip_lo", _i64), ("upd_skip_hi", _i64),
-                ("defer_skip", _p)]
+                ("sq_lo", _i64), ("sq_hi", _i64), ("sq_partial", _p), ("sq_parts", _i), ("loss_finish", _p), ("upd_skip_lo", _i64), ("upd_skip_hi", _i64)]
 
 
 class GnbvEncoderGrads(C.Structure):

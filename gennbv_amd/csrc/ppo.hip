@@ -464,11 +464,8 @@ __global__ void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, 
                             const int *__restrict__ stop_flag,
                             const int64_t *__restrict__ step /*already incremented*/, float lr, float beta1, float beta2, float eps,
                             const int64_t *__restrict__ rot_table = nullptr, int rot_rows = 0, int rot_len = 0, int64_t *__restrict__ rot_out = nullptr,
-                            int *__restrict__ rot_counter = nullptr, const float *__restrict__ hyper = nullptr /*[2] from the norm launch, or NULL*/,
-                            int *__restrict__ defer_skip = nullptr /*GnbvAdamStep.defer_skip*/)
+                            int *__restrict__ rot_counter = nullptr, const float *__restrict__ hyper = nullptr /*[2] from the norm launch, or NULL*/)
 {
-    // (a slice of this step is updated LATER, by gnbv_adam_slice_step in front of the next forward: tell it whether this step is masked)
-    if (defer_skip != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *defer_skip = (stop_flag != nullptr && *stop_flag != 0) ? 1 : 0;
     // (replayed minibatch graphs: the LAST launch of a minibatch leaves the next minibatch's row numbers in the buffer every kernel
     // of the graph reads them from -- no copy node, no host work between two replays.  Also when the update itself is masked.)
     if (rot_table != nullptr && blockIdx.x == 0) {
@@ -725,25 +722,7 @@ GNBV_API int gnbv_clip_adam_step_ex(const GnbvAdamStep *a, void *stream)
     hipLaunchKernelGGL(k_adam_flat, dim3(ab), dim3(256), 0, st, a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->n, (const double *)partial, blocks + fold,
                        (const double *)nullptr, 0, a->max_grad_norm, a->grad_scale, a->norm_out,
                        (const float *)nullptr, a->upd_skip_lo, a->upd_skip_hi, (const int *)a->stop_flag, (const int64_t *)a->step, a->lr, a->beta1, a->beta2, a->eps, a->table, a->table_rows, a->row_len, a->out,
-                       a->counter, (const float *)hyper, a->defer_skip);
-    return gnbv_launch_status();
-}
-
-// Adam on a contiguous slice of n parameters with the clip factor (norm_out[1]) and the bias corrections (workspace) that
-// gnbv_clip_adam_step_ex of the SAME optimizer step left behind -- the slice that step skipped (upd_skip_lo / hi), updated LATER: in front
-// of the next minibatch's forward, on a second stream beside the conv kernels, which do not read it (fc_grid.weight: 13.8 M of the
-// 14.4 M parameters at G = 64, i.e. nearly all of the update's 400 MB of traffic).  `skip` = GnbvAdamStep.defer_skip of that step
-// (nonzero: the step was masked, or nothing is pending); neither the step counter nor any flag is modified.
-GNBV_API int gnbv_adam_slice_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const float *norm_out,
-                                  const void *workspace, float lr, float beta1, float beta2, float eps, const int64_t *step, const int *skip, void *stream)
-{
-    GNBV_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && norm_out && workspace && step && skip && n > 0);
-    const float *hyper = (const float *)((const double *)workspace + 1026);
-    int ab = (int)((n + 255) / 256);
-    ab = ab > GNBV_ADAM_BLOCKS ? GNBV_ADAM_BLOCKS : ab;
-    hipLaunchKernelGGL(k_adam_flat, dim3(ab), dim3(256), 0, gnbv_stream(stream), params, grads, exp_avg, exp_avg_sq, n, (const double *)nullptr, 0,
-                       (const double *)nullptr, 0, 0.0f, 1.0f, (float *)nullptr, norm_out, (int64_t)0, (int64_t)0, skip, step, lr, beta1, beta2, eps,
-                       (const int64_t *)nullptr, 0, 0, (int64_t *)nullptr, (int *)nullptr, hyper);
+                       a->counter, (const float *)hyper);
     return gnbv_launch_status();
 }
 

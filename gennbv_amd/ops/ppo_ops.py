@@ -55,8 +55,7 @@ class FlatAdam:
         self.grads.zero_()
 
     def step(self, max_grad_norm: float, stop_flag: Optional[torch.Tensor] = None, grad_scale: float = 1.0,
-             kl_slot_target: Optional[float] = None, rotate=None, sq_slice=None, skip_update: bool = False, loss_finish=None,
-             defer_skip: Optional[torch.Tensor] = None):
+             kl_slot_target: Optional[float] = None, rotate=None, sq_slice=None, skip_update: bool = False, loss_finish=None):
         """grad_scale = 1/world and kl_slot_target = target_kl for the data-parallel tail.  rotate = (table [rows, len] int64,
         out [len] int64, counter [1] int32): the launch also leaves the next minibatch's row of `table` in `out`.
         sq_slice = (lo, hi, partial fp64 tensor): sum(grad[lo:hi]^2) was left in `partial` by the kernel that produced that
@@ -83,20 +82,9 @@ class FlatAdam:
             a.sq_lo, a.sq_hi, a.sq_partial, a.sq_parts = int(lo), int(hi), part.data_ptr(), int(part.numel())
             if skip_update:
                 a.upd_skip_lo, a.upd_skip_hi = int(lo), int(hi)
-        if defer_skip is not None:  # (with skip_update: the slice is updated later by slice_step(); this launch tells it whether the step is masked)
-            assert skip_update and defer_skip.dtype == torch.int32
-            a.defer_skip = defer_skip.data_ptr()
         if loss_finish is not None:  # a GnbvPpoLoss with defer_stats = 1 (PpoLossOp.args): its statistics are finished inside the norm launch
             a.loss_finish = C.addressof(loss_finish)
         _lib.check(self.lib.gnbv_clip_adam_step_ex(C.byref(a), _lib.stream_ptr(self.params.device)), "gnbv_clip_adam_step_ex")
-
-    def slice_step(self, lo: int, hi: int, skip: torch.Tensor) -> None:
-        """Adam on parameters [lo, hi) -- the slice the last step(..., skip_update=True, defer_skip=skip) left out -- with that step's clip
-        factor and bias corrections, on the current stream (include/gennbv_hip.h gnbv_adam_slice_step).  *skip != 0: no-op."""
-        _lib.check(self.lib.gnbv_adam_slice_step(self.params[lo:hi].data_ptr(), self.grads[lo:hi].data_ptr(), self.exp_avg[lo:hi].data_ptr(),
-                                                 self.exp_avg_sq[lo:hi].data_ptr(), int(hi - lo), self.norm_out.data_ptr(), self.ws.data_ptr(),
-                                                 float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                                                 self.step_count.data_ptr(), skip.data_ptr(), _lib.stream_ptr(self.params.device)), "gnbv_adam_slice_step")
 
     # ---- data-parallel replicas: the update of one large slice sharded over the ranks (gennbv_amd/parallel.py) ----
     def enable_shard(self, lo: int, hi: int, rank: int, world: int) -> bool:

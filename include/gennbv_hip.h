@@ -542,10 +542,7 @@ typedef struct GnbvAdamStep {
                                            step counter) -- same stop_flag as this call's */
     int64_t upd_skip_lo, upd_skip_hi;   /* parameters [upd_skip_lo, upd_skip_hi) are NOT updated by this call (their gradient still
                                            counts for the norm through sq_partial): a slice whose update is sharded over the
-                                           data-parallel replicas, gnbv_adam_shard_step -- or deferred, gnbv_adam_slice_step */
-    int *defer_skip;                    /* (appended in round 6; NULL = unused) [device] one int the update launch sets to 1 when this step is
-                                           masked by stop_flag and to 0 otherwise: the `skip` argument of the gnbv_adam_slice_step that
-                                           applies this step's skipped slice later */
+                                           data-parallel replicas, gnbv_adam_shard_step */
 } GnbvAdamStep;
 int gnbv_clip_adam_step_ex(const GnbvAdamStep *a /*[host]*/, void *stream);
 /* sum(grads[0 .. n)^2) as gnbv_sq_partials_count() fp64 partial sums in one fixed order -> partial [device].  The sharded data-parallel
@@ -557,13 +554,6 @@ int gnbv_sq_partials(const float *grads, int64_t n, double *partial /*[gnbv_sq_p
  * behind (same step counter and stop flag, neither is modified). */
 int gnbv_adam_shard_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const float *norm_out,
                          float lr, float beta1, float beta2, float eps, const int64_t *step, const int *stop_flag, void *stream);
-/* Adam on a contiguous slice of n parameters that gnbv_clip_adam_step_ex of the SAME optimizer step skipped (upd_skip_lo / hi), with
- * the clip factor (norm_out[1]) and the bias corrections (`workspace`: that call's workspace) it left behind -- applied LATER, in front of
- * the next minibatch's forward on a second stream, beside kernels that do not read the slice (sb3/_train_hip.py: the update of
- * fc_grid.weight overlaps the next conv forward).  *skip != 0 (GnbvAdamStep.defer_skip of that step: it was masked; or the caller's
- * "nothing pending"): no-op.  Modifies neither the step counter nor a flag.  Same arithmetic per element as the one-launch update. */
-int gnbv_adam_slice_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const float *norm_out,
-                         const void *workspace, float lr, float beta1, float beta2, float eps, const int64_t *step, const int *skip, void *stream);
 
 
 /* ------------------------------------------------------------------------- */

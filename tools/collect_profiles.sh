@@ -12,7 +12,7 @@ rocprofv3 --kernel-trace --stats -d /tmp/prof_k -- python $GRAFT_REPO_ROOT/bench
 echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 --n-steps 16 --no-cpu-baseline --no-flat-rows --no-state-check" > $OUT/bench_kernel_trace.txt
 python $GRAFT_REPO_ROOT/tools/rocprof_summary.py /tmp/prof_k >> $OUT/bench_kernel_trace.txt
 # one PPO minibatch / one rollout step as timelines (same trace)
-python $GRAFT_REPO_ROOT/tools/rocprof_timeline.py /tmp/prof_k 600 k_ppo_fused > $OUT/minibatch_timeline.txt
+python $GRAFT_REPO_ROOT/tools/rocprof_timeline.py /tmp/prof_k 600 "void k_ppo_fused" > $OUT/minibatch_timeline.txt
 python $GRAFT_REPO_ROOT/tools/rocprof_timeline.py /tmp/prof_k 5 "void k_hit_list" > $OUT/rollout_step_timeline.txt
 rm -rf /tmp/prof_v
 rocprofv3 --kernel-trace --stats -d /tmp/prof_v -- python $GRAFT_REPO_ROOT/tools/microbench_voxel.py > /tmp/prof_v.log 2>&1
