@@ -57,8 +57,8 @@ __device__ __forceinline__ f32x4 contract_nt(const float *arow, const float *aro
     }
     return acc;
 }
-constexpr int kHeadU = 32;  // 16-k groups per round trip in output_layer's contraction: K = 512 is ONE round trip (round 6; 256 VGPRs of operands in a one-wave workgroup)
-constexpr int kHeadUB = 8;  // 32-k (or 32-row) groups per round trip in the backward contractions (4-byte requests: 16 per group; round 6: eight -- A + 1 = 241 and F = 256 are one round trip)
+constexpr int kHeadU = 16;  // 16-k groups per round trip in the forward contractions
+constexpr int kHeadUB = 4;  // 32-k (or 32-row) groups per round trip in the backward contractions (4-byte requests: 16 per group)
 
 // ===========================================================================================
 // forward 1: feat[M][F] = relu([fa | fg] W_out^T + b_out)
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_fwd_out(const float *__re
     if (ti * 16 >= M) return;
     const int i = min(ti * 16 + x, M - 1), j = tj * 16 + x;
     const float *brow = j < A ? W_act + (size_t)j * F : W_val;  // column A = the value head
-    const f32x4 acc = contract_nt<16>(feat + (size_t)i * F + 4 * kq, feat, F, brow + 4 * kq, F, true, j <= A);  // (F = 256: one round trip as it is)
+    const f32x4 acc = contract_nt<kHeadU>(feat + (size_t)i * F + 4 * kq, feat, F, brow + 4 * kq, F, true, j <= A);
     const float bias = j < A ? b_act[j] : (j == A ? b_val[0] : 0.0f);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_bwd_dh(const float *__res
     const int i = min(ti * 16 + x, M - 1), j = tj * 16 + x, K = A + 1;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const float dv = d_values[i], wv_j = W_val[j];
-    for (int k0 = 0; k0 < K; k0 += 32 * kHeadUB) {  // (kHeadUB x 32 k per round trip: A + 1 = 241 is one)
+    for (int k0 = 0; k0 < K; k0 += 32 * kHeadUB) {  // (kHeadUB x 16 requests per round trip: A + 1 = 241 -> two instead of eight)
         float a[2 * kHeadUB][4], b[2 * kHeadUB][4];
 #pragma unroll
         for (int u = 0; u < 2 * kHeadUB; ++u)
