@@ -249,6 +249,19 @@ __global__ __launch_bounds__(kPostThreads) void k_env_post_step(GnbvEnvPost a)
         base_count += tile_total;
         __syncthreads();
     }
+    // the ring's entries (this step's appends included: stored above, in front of the tile loop's last barrier) into LDS by ALL threads, in
+    // deque order -- thread 0 then adds them in that order from LDS instead of walking up to ring_len pairs of dependent global loads by
+    // itself (the same additions in the same order: the same fp64 bits; 100 entries were ~100 round trips of this single workgroup)
+    __shared__ float s_ring[2][kPostThreads];
+    const int64_t total_all = a.ring_state[0] + base_count;
+    const int k_all = (int)(total_all < a.ring_len ? total_all : a.ring_len);
+    const bool ring_lds = a.episode_info != nullptr && k_all <= kPostThreads;
+    if (ring_lds && tid < k_all) {
+        const int64_t pos = total_all - k_all + tid;
+        s_ring[0][tid] = ((const volatile float *)a.ring_reward)[pos % a.ring_len];
+        s_ring[1][tid] = ((const volatile float *)a.ring_length)[pos % a.ring_len];
+    }
+    __syncthreads();
     if (tid == 0) {
         const int64_t total = a.ring_state[0] + base_count;  // total finished episodes so far
         a.ring_state[0] = total;
@@ -260,10 +273,17 @@ __global__ __launch_bounds__(kPostThreads) void k_env_post_step(GnbvEnvPost a)
             }
             const int k = (int)(total < a.ring_len ? total : a.ring_len);
             double sr = 0.0, sl = 0.0;
-            for (int i = 0; i < k; ++i) {  // deque order: oldest -> newest
-                const int64_t pos = total - k + i;
-                sr += (double)((const volatile float *)a.ring_reward)[pos % a.ring_len];
-                sl += (double)((const volatile float *)a.ring_length)[pos % a.ring_len];
+            if (ring_lds) {
+                for (int i = 0; i < k; ++i) {  // deque order: oldest -> newest
+                    sr += (double)s_ring[0][i];
+                    sl += (double)s_ring[1][i];
+                }
+            } else {
+                for (int i = 0; i < k; ++i) {
+                    const int64_t pos = total - k + i;
+                    sr += (double)((const volatile float *)a.ring_reward)[pos % a.ring_len];
+                    sl += (double)((const volatile float *)a.ring_length)[pos % a.ring_len];
+                }
             }
             a.episode_info[0] = a.episode_state[0];
             a.episode_info[1] = k ? sr / k : 0.0;
