@@ -15,6 +15,13 @@ hosts (tools/profile_rollout_host.py).  During collect_rollouts the parameters a
 * `__call__(dense_obs)`: the six calls with precomputed arguments -> (logits [n, A], values [n]), bit-identical to the general path
   (tests/test_rollout_gpu.py).
 
+Two forms, chosen by what the general path would do for the same policy and observation (so that the plan stays bit-identical to it):
+* "compact" (the bench's kernel set, G = 64): compact int8 rows -> the one-launch inference conv kernel -> fc_grid with BatchNorm-2 folded into
+  its operand load;
+* "flat" (round 6; the reference's own 20^3 workload, where fc_grid cannot fold): fp32 observation rows -> the fp32 conv kernels + BatchNorm
+  launches of gnbv_encoder_grid_forward -> materialised features -> fc_grid.  No parameter-only launches to hoist there (prepare() only looks
+  the arguments up); what the plan removes is the general path's host time -- at 20^3 the rollout step is HOST-bound: 185 us of kernels in 375.
+
 Same kernels, same arguments, same streams as ops/encoder_ops.py -- this file adds no arithmetic."""
 from __future__ import annotations
 
@@ -58,8 +65,8 @@ class RolloutForward:
         self.s, self.g = s, g
         o2 = encoder_ops.conv_out(encoder_ops.conv_out(g))
         self.p2 = o2 ** 3
-        if not encoder_ops.linear_fold_ok(lin_g, n, self.p2, False):
-            return None
+        # (what the general path decides per call from the same arguments: hybrid_branches -> linear_fold_ok)
+        self.fold = bool(encoder_ops.linear_fold_ok(lin_g, n, self.p2, False))
         self.seq = enc.naive_encoder_grid
         self.lins = lins
         f32 = dict(dtype=torch.float32, device=dev)
@@ -68,6 +75,7 @@ class RolloutForward:
         self.y1 = torch.empty(lib.gnbv_encoder_y1_elems(n, g), **f32)
         self.y2 = torch.empty(n * 16 * self.p2, **f32)
         self.bn_state = torch.empty(2 * 4 * 16 + 768, **f32)
+        self.feats = None if self.fold else torch.empty(n, 16 * self.p2, **f32)  # ("flat": BatchNorm-2 + ReLU materialised for fc_grid)
         self.ws_enc = encoder_ops._workspace(lib, n, g, dev)
         self.pose_in = torch.empty(n, 4 * s, **f32)
         self.h1 = torch.empty(n, seq_a[0].out_features, **f32)
@@ -112,15 +120,17 @@ class RolloutForward:
         self.flag_ptr = None if flag is None else flag.data_ptr()
         # (grid_i8 pointer / stride are filled in per call; a dummy row makes the path predicates of the prepare call meaningful)
         self.params = encoder_ops._params_struct(self.seq, None, None, None, (False, flag, None))
-        self.params.grid_i8 = self.y1.data_ptr()  # any 16-byte aligned device pointer: the prepare launches do not read it
-        self.params.grid_i8_row_stride = self.g ** 3
-        st = _lib.stream_ptr(self.dev)
-        err = self.lib.gnbv_encoder_eval_prepare(self.n, self.g, C.byref(self.params), self.bn_state.data_ptr(), self.ws_enc.data_ptr(),
-                                                 self.ws_enc.numel(), st)
-        if err == -2:  # GNBV_ERR_NOT_APPLICABLE: no one-launch inference kernel for this (parameters, grid)
-            return False
-        _lib.check(err, "gnbv_encoder_eval_prepare")
-        self.params.eval_prepared = 1
+        if self.fold:
+            self.params.grid_i8 = self.y1.data_ptr()  # any 16-byte aligned device pointer: the prepare launches do not read it
+            self.params.grid_i8_row_stride = self.g ** 3
+            st = _lib.stream_ptr(self.dev)
+            err = self.lib.gnbv_encoder_eval_prepare(self.n, self.g, C.byref(self.params), self.bn_state.data_ptr(), self.ws_enc.data_ptr(),
+                                                     self.ws_enc.numel(), st)
+            if err == -2:  # GNBV_ERR_NOT_APPLICABLE: no one-launch inference kernel for this (parameters, grid)
+                return False
+            _lib.check(err, "gnbv_encoder_eval_prepare")
+            self.params.eval_prepared = 1
+        # ("flat": the conv forward issues its BatchNorm launches itself, every step, as on the general path)
         self._sig = self._signature()
         pol, lo = self.policy, enc.output_layer[0]
         self.head_w = (lo.weight.data_ptr(), lo.bias.data_ptr(), lo.out_features, pol.action_net.weight.data_ptr(), pol.action_net.bias.data_ptr(),
@@ -130,28 +140,42 @@ class RolloutForward:
         return True
 
     def applies_to(self, obs) -> bool:
-        return (self.prepared and isinstance(obs, encoder_ops.DenseObs) and obs.compact_state_dim is not None and obs.base.shape[0] == self.n
-                and obs.base.dtype == torch.float32 and obs.grid_i8 is not None and obs.grid_i8.stride(0) % 16 == 0
-                and obs.grid_i8.data_ptr() % 16 == 0 and not torch.is_grad_enabled() and self._sig == self._signature())
+        if not self.prepared or torch.is_grad_enabled():
+            return False
+        if self.fold:  # "compact"
+            return (isinstance(obs, encoder_ops.DenseObs) and obs.compact_state_dim is not None and obs.base.shape[0] == self.n
+                    and obs.base.dtype == torch.float32 and obs.grid_i8 is not None and obs.grid_i8.stride(0) % 16 == 0
+                    and obs.grid_i8.data_ptr() % 16 == 0 and self._sig == self._signature())
+        # "flat": plain fp32 observation rows [n, state | G^3 | ...] (no int8 side copy: that is another kernel set on the general path)
+        return (isinstance(obs, torch.Tensor) and obs.dim() == 2 and obs.shape[0] == self.n and obs.dtype == torch.float32 and obs.is_cuda
+                and obs.stride(1) == 1 and obs.shape[1] >= self.s + self.g ** 3 and obs.data_ptr() % 16 == 0 and self._sig == self._signature())
 
     def __call__(self, obs, tail=None):
         """(logits [n, A], values [n]) of the compact observation rows `obs` (encoder_ops.DenseObs).  `tail(raw_stream)`: more work for
         the second stream, issued behind the pose branch and NOT joined here (the caller joins `self.side` when it needs the result)."""
         lib, n, dev = self.lib, self.n, self.dev
-        base, g8 = obs.base, obs.grid_i8
         st = _lib.stream_ptr(dev)
         cur = torch.cuda.current_stream(dev)
         self.ev_fork.record(cur)  # the fork point; the pose kernels are issued after the grid branch (encoder_ops.hybrid_branches)
         p = self.params
-        p.grid_i8, p.grid_i8_row_stride = g8.data_ptr(), int(g8.stride(0))
-        _lib.check(lib.gnbv_encoder_grid_forward(None, None, base.stride(0), n, self.g, C.byref(p), 0, None, self.y1.data_ptr(), self.y2.data_ptr(),
-                                                 self.bn_state.data_ptr(), None, self.ws_enc.data_ptr(), self.ws_enc.numel(), st),
-                   "gnbv_encoder_grid_forward")
         w, b, nn_, k = self.lin_w[2]
-        sc = self.bn_state.data_ptr() + 4 * 64
         ws = self.ws_lin[2]
-        _lib.check(lib.gnbv_linear_forward_fold(self.y2.data_ptr(), sc, sc + 4 * 16, self.p2, self.flag_ptr, w, b, n, nn_, k, 1, self.fg.data_ptr(),
-                                                ws.data_ptr(), ws.numel(), st), "gnbv_linear_forward_fold")
+        if self.fold:
+            base, g8 = obs.base, obs.grid_i8
+            p.grid_i8, p.grid_i8_row_stride = g8.data_ptr(), int(g8.stride(0))
+            _lib.check(lib.gnbv_encoder_grid_forward(None, None, base.stride(0), n, self.g, C.byref(p), 0, None, self.y1.data_ptr(), self.y2.data_ptr(),
+                                                     self.bn_state.data_ptr(), None, self.ws_enc.data_ptr(), self.ws_enc.numel(), st),
+                       "gnbv_encoder_grid_forward")
+            sc = self.bn_state.data_ptr() + 4 * 64
+            _lib.check(lib.gnbv_linear_forward_fold(self.y2.data_ptr(), sc, sc + 4 * 16, self.p2, self.flag_ptr, w, b, n, nn_, k, 1, self.fg.data_ptr(),
+                                                    ws.data_ptr(), ws.numel(), st), "gnbv_linear_forward_fold")
+        else:
+            base = obs
+            _lib.check(lib.gnbv_encoder_grid_forward(base.data_ptr() + 4 * self.s, None, base.stride(0), n, self.g, C.byref(p), 0, None, self.y1.data_ptr(),
+                                                     self.y2.data_ptr(), self.bn_state.data_ptr(), self.feats.data_ptr(), self.ws_enc.data_ptr(),
+                                                     self.ws_enc.numel(), st), "gnbv_encoder_grid_forward")
+            _lib.check(lib.gnbv_linear_forward(self.feats.data_ptr(), w, b, n, nn_, k, 1, self.fg.data_ptr(), ws.data_ptr(), ws.numel(), st),
+                       "gnbv_linear_forward")
         side = self.side
         side.wait_event(self.ev_fork)
         sst = side.cuda_stream

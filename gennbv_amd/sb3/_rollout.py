@@ -174,7 +174,8 @@ class RolloutMixin:
     def _rollout_forward(self, n: int):
         """The prepared policy evaluation of this rollout (ops/rollout_plan.RolloutForward), or None (attribute `rollout_plan = False`,
         another device, a policy whose inference forward is not the kernel sequence the plan issues)."""
-        if not self.rollout_plan or self.device.type != "cuda" or "forward" in vars(self.policy) or "predict_values" in vars(self.policy):
+        if (not self.rollout_plan or os.environ.get("GENNBV_ROLLOUT_PLAN") == "0" or self.device.type != "cuda" or "forward" in vars(self.policy)
+                or "predict_values" in vars(self.policy)):
             return None  # (an instance-level override of the policy's evaluation -- tests force actions that way -- keeps the general path)
         from .policies import ActorCriticPolicy_Train_Eval as _P
         enc = self.policy.features_extractor

@@ -56,18 +56,21 @@ def test_hip_rollout_reproduces_reference_collect_rollouts(fused_add, monkeypatc
 
 
 
-def test_prepared_rollout_forward_is_bit_identical_to_the_general_path():
+@pytest.mark.parametrize("g,compact", [(64, True), (20, False)])
+def test_prepared_rollout_forward_is_bit_identical_to_the_general_path(g, compact):
     """ops/rollout_plan.RolloutForward (collect_rollouts' policy evaluation with the step-invariant work hoisted out, the parameter-only
     launches run once per rollout: GnbvEncoderParams.eval_prepared) issues the same kernels with the same arguments as
-    ActorCriticPolicy_Train_Eval.forward: two rollouts at G = 64 with compact rows (the bench's kernel set), a train() in between so that
-    the second rollout must prepare again from CHANGED parameters -- every buffer bit for bit against `rollout_plan = False`."""
+    ActorCriticPolicy_Train_Eval.forward: two rollouts at G = 64 with compact rows (the bench's kernel set) and at G = 20 with fp32
+    observation rows (round 6: the plan's "flat" form -- the reference's own workload, whose fc layer cannot fold BatchNorm-2), a train()
+    in between so that the second rollout must prepare again from CHANGED parameters -- every buffer bit for bit against
+    `rollout_plan = False`."""
     from gennbv_amd.env import synthetic as S
     from gennbv_amd.env.config import TaskConfig
     from gennbv_amd.env.replay_feed import ReplayFeed, ReplayFeedEnv
     from gennbv_amd.network.hybrid_encoder import Hybrid_Encoder
     from gennbv_amd.sb3.policies import ActorCriticPolicy_Train_Eval
     from gennbv_amd.sb3.ppo_grid_obs import PPO_Grid_Obs
-    g, n, t = 64, 16, 6
+    n, t = 16, 6
     cfg = TaskConfig(camera_width=80, camera_height=60, grid_size=g)
     kw = dict(net_arch=[], features_extractor_class=Hybrid_Encoder, features_extractor_kwargs=dict(
         encoder_param={"hidden_shapes": [256, 256], "visual_dim": 256},
@@ -81,7 +84,7 @@ def test_prepared_rollout_forward_is_bit_identical_to_the_general_path():
         env = ReplayFeedEnv(cfg, scene, ReplayFeed.synthetic(scene, cfg, 5, seed=5), DEV, max_episode_length=4)
         algo = PPO_Grid_Obs(ActorCriticPolicy_Train_Eval, env, learning_rate=1e-4, n_steps=t, batch_size=32, n_epochs=1, gamma=0.99, gae_lambda=0.95,
                             clip_range=0.2, clip_range_vf=0.2, ent_coef=0.01, vf_coef=0.8, max_grad_norm=1.0, target_kl=None, seed=1, device=DEV,
-                            compact_obs=True, policy_kwargs=kw)
+                            compact_obs=compact, policy_kwargs=kw)
         algo.rollout_plan = use_plan
         algo._setup_learn(total_timesteps=10 ** 9)
         snaps = []
@@ -89,7 +92,8 @@ def test_prepared_rollout_forward_is_bit_identical_to_the_general_path():
             assert algo.collect_rollouts(env, None, algo.rollout_buffer, n_rollout_steps=t)
             buf = algo.rollout_buffer
             snaps.append({k: getattr(buf, k).detach().clone() for k in ("observations", "grid_i8", "autocorr", "actions", "values", "log_probs", "rewards",
-                                                                         "advantages", "returns", "episode_starts")})
+                                                                         "advantages", "returns", "episode_starts") if getattr(buf, k, None) is not None})
+            assert ("grid_i8" in snaps[-1]) == compact
             if r == 0:
                 algo.train()
         plan = getattr(algo, "_rollout_plan_obj", None)
