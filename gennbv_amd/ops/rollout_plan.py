@@ -102,13 +102,23 @@ class RolloutForward:
     # ------------------------------------------------------------------------------------------------------------------
     def _signature(self):
         """what the cached arguments were derived from: a re-parametrised / re-allocated policy must rebuild the plan"""
-        enc, pol = self.enc, self.policy
-        ts = [m.weight for m in (self.seq[0], self.seq[1], self.seq[3], self.seq[4], *self.lins, enc.output_layer[0], pol.action_net, pol.value_net)]
+        enc = self.enc
         # (+ the tensors' in-place version counters and the BatchNorm running statistics the prepared scale / shift came from: a
         # load_state_dict / set_parameters from a callback in the MIDDLE of a rollout sends the rest of it through the general path)
-        ts = ts + [b for m in (self.seq[1], self.seq[4]) for b in (m.weight, m.bias, m.running_mean, m.running_var)]
-        return (tuple((t.data_ptr(), t._version) for t in ts), bool(enc.training), bool(getattr(enc, "force_fp32", False)),
-                tuple(bool(getattr(lin, "_fp32_arith", False)) for lin in self.lins), id(getattr(enc, "_range_flag", None)))
+        # Evaluated before EVERY policy evaluation: the tensors are fetched from the modules' own dicts (`_sig_slots`: whatever tensor a
+        # slot holds NOW is what is compared), not through nn.Module.__getattr__ / Sequential.__getitem__ -- that form cost 47 us per env
+        # step of a rollout that is host-bound at 20^3 (tools/profile_rollout_host.py).
+        slots = self.__dict__.get("_sig_slots")
+        if slots is None:
+            pol = self.policy
+            mods = (self.seq[0], self.seq[1], self.seq[3], self.seq[4], *self.lins, enc.output_layer[0], pol.action_net, pol.value_net)
+            slots = [(m._parameters, "weight") for m in mods]
+            for m in (self.seq[1], self.seq[4]):
+                slots += [(m._parameters, "weight"), (m._parameters, "bias"), (m._buffers, "running_mean"), (m._buffers, "running_var")]
+            self._sig_slots = slots
+        ts = [d[k] for d, k in slots]
+        return (tuple((t.data_ptr(), t._version) for t in ts), bool(enc.training), bool(enc.__dict__.get("force_fp32", False)),
+                tuple(bool(lin.__dict__.get("_fp32_arith", False)) for lin in self.lins), id(enc._buffers.get("_range_flag")))
 
     def prepare(self) -> bool:
         """Once per collect_rollouts, before its first policy evaluation.  False: this rollout runs through the general path."""

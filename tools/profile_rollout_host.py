@@ -12,7 +12,12 @@ import torch
 
 import bench
 
-ns = argparse.Namespace(gpus=1, steps=1, warmup=0, envs=256, grid=64, height=240, width=320, n_steps=64, batch_size=128, n_epochs=1, frames=4,
+_ap = argparse.ArgumentParser()
+_ap.add_argument("--grid", type=int, default=64)
+_ap.add_argument("--height", type=int, default=240)
+_ap.add_argument("--width", type=int, default=320)
+_a = _ap.parse_args()
+ns = argparse.Namespace(gpus=1, steps=1, warmup=0, envs=256, grid=_a.grid, height=_a.height, width=_a.width, n_steps=64, batch_size=128, n_epochs=1, frames=4,
                         backend="hip", obs="compact", target_kl="off", semantic=False, no_cpu_baseline=True, 
                         no_flat_rows=True, no_state_check=True)
 algo, cfg, env = bench.build_algo(ns, "cuda:0", 0, 1)
