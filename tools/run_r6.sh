@@ -51,8 +51,8 @@ PY
   ab20k)     timeout 900 python tools/ab_interleaved.py --what train --grid 20 --height 400 --width 400 --rounds 12 --captures 2 --variant "generic:GENNBV_PPO_GENERIC=1" --variant "sixheads" --json $O/r06_ab_train_g20_ppo_six_heads.json 2>&1 | tail -10 ;;
   ab64t)     timeout 900 python tools/ab_interleaved.py --what train --rounds 12 --captures 3 --variant "inline:GENNBV_WGRAD_TAIL_ASIDE=0" --variant "aside" --json $O/r06_ab_train_g64_wgrad_tail_aside.json 2>&1 | tail -12 ;;
   ab20t)     timeout 900 python tools/ab_interleaved.py --what train --grid 20 --height 400 --width 400 --rounds 12 --captures 2 --variant "inline:GENNBV_WGRAD_TAIL_ASIDE=0" --variant "aside" --json $O/r06_ab_train_g20_wgrad_tail_aside.json 2>&1 | tail -10 ;;
-  ab64h)     timeout 900 python tools/ab_interleaved.py --what train --rounds 12 --captures 3 --variant "base:LIB=gennbv_amd/libgennbv_hip_r6head.so" --variant "new" --json $O/r06_ab_train_g64_head_one_trip.json 2>&1 | tail -12 ;;
-  ab20h)     timeout 900 python tools/ab_interleaved.py --what train --grid 20 --height 400 --width 400 --rounds 12 --captures 2 --variant "base:LIB=gennbv_amd/libgennbv_hip_r6head.so" --variant "new" --json $O/r06_ab_train_g20_head_one_trip.json 2>&1 | tail -10 ;;
+  ab64h)     timeout 900 python tools/ab_interleaved.py --what train --rounds 12 --captures 3 --variant "base:LIB=gennbv_amd/libgennbv_hip_r6head.so" --variant "new" --json $O/r06_ab_train_g64_bn2_means.json 2>&1 | tail -12 ;;
+  ab20h)     timeout 900 python tools/ab_interleaved.py --what train --grid 20 --height 400 --width 400 --rounds 12 --captures 2 --variant "base:LIB=gennbv_amd/libgennbv_hip_r6head.so" --variant "new" --json $O/r06_ab_train_g20_bn2_means.json 2>&1 | tail -10 ;;
   ab64c)     timeout 900 python tools/ab_interleaved.py --what train --rounds 10 --captures 2 --variant "c128" --variant "c256:GENNBV_LIN_CHUNKS=256" --variant "c64:GENNBV_LIN_CHUNKS=64" --json $O/r06_ab_train_g64_lin_chunks.json 2>&1 | tail -12 ;;
   ab20r)     timeout 900 python tools/ab_interleaved.py --what rollout --grid 20 --height 400 --width 400 --rounds 30 --variant "general:GENNBV_ROLLOUT_PLAN=0" --variant "plan" --json $O/r06_ab_rollout_g20_flat_plan.json 2>&1 | tail -6 ;;
   tests)     timeout 1500 python -m pytest tests -m gpu -q --maxfail=12 --durations=12 -p no:cacheprovider > $O/r6_tests.log 2>&1; tail -30 $O/r6_tests.log ;;
