@@ -2304,7 +2304,10 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     // vector-load path, profiles/r01_notes.md)
     hipStream_t sw = st;
     int nrows2 = batch * O2 * O2;
-    int wg_blocks = (nrows2 + kEncWaves - 1) / kEncWaves;
+    // (the fp32 kernel: FOUR rows per wave where there are fewer rows than 512 workgroups x 4 waves x 4 -- at the reference's 20^3 one row per
+    // wave made the launch its epilogue, 512 workgroup-level reductions and 14 MB of partial rows for 2 048 rows of four outputs: 128
+    // workgroups -2.9 us per minibatch, 64: -1.4; profiles/r06_ab_train_g20_wgrad_blocks*.json)
+    int wg_blocks = (nrows2 + 4 * kEncWaves - 1) / (4 * kEncWaves);
     wg_blocks = wg_blocks > 512 ? 512 : ((wg_blocks + 7) & ~7);
     const bool split_bwd = conv_split_path(p, grid);
     if (conv_splitx_path(p, grid)) {
@@ -2436,7 +2439,9 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     if ((err = gnbv_launch_status())) return err;
     // ---- conv1 weight gradient (BN1 backward fused) ----
     int nrows1 = batch * O1 * O1;
-    int wg1_blocks = (nrows1 + kEncWaves - 1) / kEncWaves;
+    // (five rows per wave below the cap, for the same reason as the conv2 weight gradient above: 20^3, 2 048 -> 520 workgroups -6.7 us per
+    // minibatch, 256: -4.2, 128: +4.3)
+    int wg1_blocks = (nrows1 + 5 * kEncWaves - 1) / (5 * kEncWaves);
     wg1_blocks = wg1_blocks > 2048 ? 2048 : ((wg1_blocks + 7) & ~7);  // VGPR-light: 32 waves per CU hide the load latency
     const size_t c1w_lds = (size_t)kEncWaves * (2 * ((O1 + 1) / 2) * kC + 9 * grid) * sizeof(float);
     const int c1w_nr = (2 * ((O1 + 1) / 2) * kC + 255) / 256, c1w_ni = (9 * grid + 255) / 256;  // 16-byte requests per lane and row
