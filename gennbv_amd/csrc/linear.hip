@@ -642,7 +642,9 @@ inline int pick_chunks(int K)
 {
     const int nstep16 = (K + 15) / 16;
     int c = 128;  // 2 workgroups of 4 waves per CU at N = 256
-    while (c > 1 && nstep16 / c < 8) c >>= 1;  // keep >= 8 steps per chunk
+    // keep >= 4 steps per chunk (round 6: 8 before -- fc_grid at the reference's 20^3, K = 1 024, was 8 chunks = 32 workgroups; 16 chunks:
+    // -1.35 us per minibatch, 32: +1.5; profiles/r06_ab_train_g20_lin_min_steps.json.  K = 54 000 has 26 steps per chunk either way)
+    while (c > 1 && nstep16 / c < 4) c >>= 1;
     return c;
 }
 
