@@ -2373,7 +2373,12 @@ GNBV_API int gnbv_encoder_grid_backward(const float *obs_grid, const int64_t *ro
     int gd = sample_plane_group_grid(batch, (O1 + 1) / 2, kPlanesPerGroup);  // groups of plane PAIRS
     // (the data gradient keeps four plane pairs per workgroup at every size: with two -- 384 workgroups at 20^3 -- or one -- 640 -- it took
     // 20-21 us instead of 16: every workgroup starts by copying the 27 KiB weight image, and that prologue is what these launches are made of)
-    const int pzd = kPlanesPerGroup;
+    // What does help is BALANCE at the same number of workgroups: the plane pairs of a sample in ceil(NA / 4) groups of equal size -- at
+    // 20^3 (NA = 5) groups of 3 + 2 instead of 4 + 1: 15 super-tiles on a workgroup's 16 waves instead of 20, one round: -2.2 us per minibatch
+    // (five in one group: +3.5; profiles/r06_ab_train_g20_dgrad_pz.json).  NA = 16, 32 (G = 64, 128) stay at four.
+    const int nad = (O1 + 1) / 2, ngd = (nad + kPlanesPerGroup - 1) / kPlanesPerGroup;
+    const int pzd = fused ? kPlanesPerGroup : (nad + ngd - 1) / ngd;
+    if (!fused) gd = sample_plane_group_grid(batch, nad, pzd);
     if (fused) {
         if (conv_splitx_path(p, grid)) {
             static bool attr_dx = false;
