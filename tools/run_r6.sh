@@ -55,7 +55,7 @@ PY
   ab20h)     timeout 900 python tools/ab_interleaved.py --what train --grid 20 --height 400 --width 400 --rounds 12 --captures 2 --variant "base:LIB=gennbv_amd/libgennbv_hip_r6head.so" --variant "new" --json $O/r06_ab_train_g20_bn2_means.json 2>&1 | tail -10 ;;
   ab64c)     timeout 900 python tools/ab_interleaved.py --what train --rounds 10 --captures 2 --variant "c128" --variant "c256:GENNBV_LIN_CHUNKS=256" --variant "c64:GENNBV_LIN_CHUNKS=64" --json $O/r06_ab_train_g64_lin_chunks.json 2>&1 | tail -12 ;;
   ab20r)     timeout 900 python tools/ab_interleaved.py --what rollout --grid 20 --height 400 --width 400 --rounds 30 --variant "general:GENNBV_ROLLOUT_PLAN=0" --variant "plan" --json $O/r06_ab_rollout_g20_flat_plan.json 2>&1 | tail -6 ;;
-  ab20w)     timeout 900 python tools/ab_interleaved.py --what train --grid 20 --height 400 --width 400 --rounds 10 --captures 1 --variant "pz4" --variant "pz3:GENNBV_DGRAD_PZ=3" --variant "pz5:GENNBV_DGRAD_PZ=5" --json $O/r06_ab_train_g20_dgrad_pz.json 2>&1 | tail -5 ;;
+  ab20w)     timeout 900 python tools/ab_interleaved.py --what train --grid 20 --height 400 --width 400 --rounds 10 --captures 1 --variant "per8" --variant "per4:GENNBV_ADAM_PER=4" --variant "per16:GENNBV_ADAM_PER=16" --variant "per32:GENNBV_ADAM_PER=32" --json $O/r06_ab_train_g20_adam_per.json 2>&1 | tail -5 ;;
   tests)     timeout 1500 python -m pytest tests -m gpu -q --maxfail=12 --durations=12 -p no:cacheprovider > $O/r6_tests.log 2>&1; tail -30 $O/r6_tests.log ;;
   bench)     timeout 900 python bench.py --steps 5 --warmup 2 2>$O/r6_bench.err | tail -1 > $O/r6_bench_n1.json; cut -c1-900 $O/r6_bench_n1.json ;;
   benchdrv)  timeout 1200 python bench.py --steps 20 --warmup 5 2>$O/r6_benchdrv.err | tail -1 > $O/r6_bench_driver_cfg_n1.json; cut -c1-600 $O/r6_bench_driver_cfg_n1.json ;;
